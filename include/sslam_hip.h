@@ -1,0 +1,84 @@
+/*
+ * sslam_hip.h - C-ABI of libsslam_hip.so, the MI355X (gfx950) backend for the
+ * ALIKED + LightGlue + local-BA hot path of KlrShaK/opencv-SimpleSLAM.
+ *
+ * The reference has no FFI of its own: its hot path is Python calling
+ * third-party wheels.  The drop-in boundary is the set
+ * of Python names `slam/monocular/main_revamped.py` imports; this C-ABI sits
+ * directly behind those names and is what a ctypes binding of that path binds
+ * (INTEGRATION.md shows the binding).  Each entry point cites the reference
+ * call it replaces as  file:line  relative to the reference root.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / C++ types in any signature
+ *   - every function returns 0 on success, non-zero on error;
+ *     sslam_last_error() returns the message of the calling thread's last error
+ *   - "_host" entry points take host pointers and block until results are in
+ *     the caller's buffers; "_dev" entry points take device pointers, enqueue
+ *     on the context's HIP stream and return without synchronising
+ *   - outputs are caller-allocated
+ *   - one context per process per GPU; a context is not thread-safe
+ */
+#ifndef SSLAM_HIP_H
+#define SSLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sslam_ctx sslam_ctx;          /* device + stream + timers            */
+typedef struct sslam_aliked sslam_aliked;    /* ALIKED-n16 extractor instance       */
+typedef struct sslam_lightglue sslam_lightglue; /* LightGlue(features='aliked') inst.*/
+
+/* ------------------------------------------------------------------ library */
+int sslam_abi_version(void);
+const char* sslam_last_error(void);
+int sslam_device_count(int* n_out);
+
+/* ------------------------------------------------------------------ context
+ * Replaces the implicit `torch.cuda` device selection at
+ * slam/core/features_utils.py:24 and :222.  `stream` may be NULL (the context
+ * then owns a new non-blocking HIP stream) or an existing hipStream_t. */
+int sslam_ctx_create(int device, void* stream, sslam_ctx** out);
+int sslam_ctx_destroy(sslam_ctx* ctx);
+int sslam_ctx_sync(sslam_ctx* ctx);
+void* sslam_ctx_stream(sslam_ctx* ctx);
+/* HIP-event timer on the context's stream (bench.py roofline measurement). */
+int sslam_timer_start(sslam_ctx* ctx);
+int sslam_timer_stop(sslam_ctx* ctx, float* elapsed_ms_out);
+/* Device memory helpers so a ctypes host needs no other GPU runtime. */
+int sslam_malloc(sslam_ctx* ctx, size_t bytes, void** dptr_out);
+int sslam_free(sslam_ctx* ctx, void* dptr);
+int sslam_memcpy_h2d(sslam_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int sslam_memcpy_d2h(sslam_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+
+/* ------------------------------------------------------------------ local BA
+ * Batched reprojection residual + Jacobian.  Replaces the per-observation
+ * `cost_functions.ReprojErrorCost(CameraModelId.PINHOLE, uv)` blocks that
+ * slam/core/ba_utils.py:56-68 adds and Ceres evaluates inside
+ * `pyceres.solve` (ba_utils.py:293).  All float64.
+ *   pose_idx[n_obs], point_idx[n_obs] : int32 indices into q/t and X
+ *   uv[n_obs*2]; q[n_poses*4] quaternion (x,y,z,w) cam-from-world;
+ *   t[n_poses*3]; X[n_points*3]; intr[4] = fx,fy,cx,cy
+ *   r[n_obs*2]; Jq[n_obs*8] (2x4 row-major, ambient xyzw); Jt[n_obs*6];
+ *   JX[n_obs*6].  Any of Jq/Jt/JX may be NULL (residual only). */
+int sslam_ba_residual_jacobian_host(sslam_ctx* ctx, int n_obs,
+                                    const int32_t* pose_idx, const int32_t* point_idx,
+                                    const double* uv, int n_poses, const double* q,
+                                    const double* t, int n_points, const double* X,
+                                    const double* intr, double* r, double* Jq,
+                                    double* Jt, double* JX);
+int sslam_ba_residual_jacobian_dev(sslam_ctx* ctx, int n_obs,
+                                   const int32_t* pose_idx, const int32_t* point_idx,
+                                   const double* uv, int n_poses, const double* q,
+                                   const double* t, int n_points, const double* X,
+                                   const double* intr, double* r, double* Jq,
+                                   double* Jt, double* JX);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSLAM_HIP_H */

@@ -1,0 +1,38 @@
+import importlib
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+PKG_NAME = "opencv-simpleslam_amd"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_pkg(sub: str = ""):
+    """Import (a submodule of) the hyphen-named product package."""
+    return importlib.import_module(PKG_NAME + (("." + sub) if sub else ""))
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return load_pkg()
+
+
+@pytest.fixture(scope="session")
+def native():
+    return load_pkg("_native")
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx(native):
+    """Process-wide GPU context; fails (not skips) when the HIP library or the
+    device is missing, so a silent fallback can never make GPU tests pass."""
+    assert native.device_count() >= 1, "no HIP device visible - GPU tests need an MI355X"
+    return native.default_context(0)
