@@ -78,6 +78,37 @@ int sslam_ba_residual_jacobian_dev(sslam_ctx* ctx, int n_obs,
                                    const double* intr, double* r, double* Jq,
                                    double* Jt, double* JX);
 
+/* ------------------------------------------------------------------ LightGlue
+ * Replaces `LightGlue(features='aliked').eval().to(device)` at
+ * slam/core/features_utils.py:26 and the forward + confidence filter at
+ * features_utils.py:157-169.  `weights` is the fp32 blob produced by
+ * opencv-simpleslam_amd/weights.py::pack_lightglue from an upstream state dict
+ * (host pointer, copied).  max_kpts bounds M and N of every later call. */
+int sslam_lightglue_create(sslam_ctx* ctx, const float* weights, size_t n_floats, int max_kpts,
+                           sslam_lightglue** out);
+int sslam_lightglue_destroy(sslam_lightglue* lg);
+int sslam_lightglue_capacity(sslam_lightglue* lg, int* kc_out);
+/* Upstream conf: depth_confidence 0.95, width_confidence 0.99, filter_threshold
+ * 0.1; prune_min_kpts = pruning_keypoint_thresholds[device] (-1 on CPU: pruning
+ * evaluated after every layer; pass a value >= max_kpts to disable). */
+int sslam_lightglue_set_conf(sslam_lightglue* lg, float depth_confidence, float width_confidence,
+                             float filter_threshold, int prune_min_kpts);
+/* xy0[M*2], desc0[M*128], xy1[N*2], desc1[N*128] float32.
+ * ij_out[2*min(M,N)] int32 (queryIdx, trainIdx) pairs, ascending queryIdx;
+ * score_out[min(M,N)]; only matches with score > filter_threshold AND
+ * score > min_conf (features_utils.py:167-169) are emitted.
+ * M == 0 or N == 0 -> k_out = 0 (features_utils.py:118-124). */
+int sslam_lightglue_match_host(sslam_lightglue* lg, const float* xy0, const float* desc0, int M,
+                               const float* xy1, const float* desc1, int N, float min_conf,
+                               int32_t* ij_out, float* score_out, int32_t* k_out,
+                               int32_t* stop_layer_out);
+/* Device-pointer variant; info_out[4] (device) = {K, stop_layer, n0, n1 after pruning}. */
+int sslam_lightglue_match_dev(sslam_lightglue* lg, const float* xy0, const float* desc0, int M,
+                              const float* xy1, const float* desc1, int N, float min_conf,
+                              int32_t* ij_out, float* score_out, int32_t* info_out);
+/* Test hook: copy an internal buffer to the host (see lightglue_kernels.hip). */
+int sslam_lightglue_debug_read(sslam_lightglue* lg, int which, void* dst, size_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

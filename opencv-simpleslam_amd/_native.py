@@ -27,7 +27,7 @@ _lib = None
 
 
 def _signatures():
-    vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
+    vp, i32, sz, f32 = C.c_void_p, C.c_int, C.c_size_t, C.c_float
     return {
         "sslam_abi_version": (i32, []),
         "sslam_last_error": (C.c_char_p, []),
@@ -44,6 +44,13 @@ def _signatures():
         "sslam_memcpy_d2h": (i32, [vp, vp, vp, sz]),
         "sslam_ba_residual_jacobian_host": (i32, [vp, i32] + [vp] * 3 + [i32, vp, vp, i32, vp, vp] + [vp] * 4),
         "sslam_ba_residual_jacobian_dev": (i32, [vp, i32] + [vp] * 3 + [i32, vp, vp, i32, vp, vp] + [vp] * 4),
+        "sslam_lightglue_create": (i32, [vp, vp, sz, i32, c_void_pp]),
+        "sslam_lightglue_destroy": (i32, [vp]),
+        "sslam_lightglue_capacity": (i32, [vp, c_int_p]),
+        "sslam_lightglue_set_conf": (i32, [vp, f32, f32, f32, i32]),
+        "sslam_lightglue_match_host": (i32, [vp, vp, vp, i32, vp, vp, i32, f32, vp, vp, c_int_p, c_int_p]),
+        "sslam_lightglue_match_dev": (i32, [vp, vp, vp, i32, vp, vp, i32, f32, vp, vp, vp]),
+        "sslam_lightglue_debug_read": (i32, [vp, i32, vp, sz]),
     }
 
 

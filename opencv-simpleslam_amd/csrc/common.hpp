@@ -40,7 +40,10 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct Arena {
     char* base = nullptr;
     size_t cap = 0, off = 0;
+    bool dry = false;   // measuring pass: take() only advances `off`
+    void measure() { dry = true; cap = ~(size_t)0; off = 0; base = nullptr; }
     int init(size_t bytes) {
+        dry = false;
         cap = bytes;
         off = 0;
         SSLAM_HIP_CHECK(hipMalloc((void**)&base, bytes));

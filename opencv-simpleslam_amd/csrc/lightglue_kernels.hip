@@ -1,0 +1,1250 @@
+// lightglue_kernels.hip - LightGlue(features='aliked') forward on gfx950.
+//
+// Replaces `matcher({...})` at slam/core/features_utils.py:157-162 (the
+// cvg/LightGlue forward) plus the confidence filter at :164-169.
+//
+// Numeric type: fp32 end to end.  Every contraction (linear layers, QK^T, PV,
+// the final similarity) runs on the exact-fp32 matrix core instruction
+// v_mfma_f32_32x32x2_f32, so results differ from a torch-CPU fp32 run only by
+// summation order; the roofline is the fp32 MFMA peak (157.3 TFLOP/s).
+//
+// Data layout in HBM (per instance, sized for max_kpts = Kc rows per image):
+//   x      [2][Kc][256]   token states, image-major (image 1 at row Kc)
+//   enc    [2][Kc][32]    cos / sin of the Fourier positional projection
+//   q,k,v  [2][4][Kc][64] head-major, rotary already applied to q,k
+//   msg    [2][Kc][256]   attention context / message
+//   hid    [2][Kc][512]   FFN hidden
+//   sim    [Kc][Kc]       final similarity
+// Control flow that the reference decides on the host per layer (early stop,
+// point pruning) lives in a device-side control block `LGCtrl`; every kernel
+// reads its row counts from it, so one pair is a fixed launch sequence with no
+// host round trip (graph-capturable).
+#include "common.hpp"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int D = 256;       // descriptor_dim
+constexpr int DH = 64;       // head dim
+constexpr int NH = 4;        // heads
+constexpr int DIN = 128;     // ALIKED descriptor dim
+constexpr int NL = 9;        // layers
+constexpr int ENC = 32;      // rotary frequencies per token
+
+struct LGCtrl {
+    int n[2];        // current (possibly pruned) token count per image
+    int n_prev[2];   // count before the last pruning step
+    int n_orig[2];   // M, N of the call
+    int stop;        // 0 running, 1 stopped early, 2 empty set
+    int stop_layer;  // index i of the layer whose log_assignment is used
+    int unconf;      // #tokens with confidence < threshold (both images)
+    int n_matches;   // K
+    int pad[6];
+};
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int acc_row(int r, int lane) {  // C/D row of accumulator reg r
+    return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+}
+
+// ------------------------------------------------------------------------ //
+//  0. prepare: bbox-normalise keypoints, rotary tables, control block
+//     (lightglue.py normalize_keypoints(size=None), LearnableFourierPositionalEncoding)
+// ------------------------------------------------------------------------ //
+__global__ __launch_bounds__(1024) void lg_prepare_kernel(
+    const float* __restrict__ xy0, const float* __restrict__ xy1, int M, int N, int Kc,
+    const float* __restrict__ Wr, float* __restrict__ enc_cos, float* __restrict__ enc_sin,
+    int* __restrict__ ind, int* __restrict__ prune, LGCtrl* __restrict__ ctrl) {
+    const int img = blockIdx.x;
+    const float* xy = img ? xy1 : xy0;
+    const int n = img ? N : M;
+    __shared__ float red[4][32];
+    float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float x = xy[2 * i], y = xy[2 * i + 1];
+        mnx = fminf(mnx, x); mxx = fmaxf(mxx, x);
+        mny = fminf(mny, y); mxy = fmaxf(mxy, y);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mnx = fminf(mnx, __shfl_xor(mnx, o)); mxx = fmaxf(mxx, __shfl_xor(mxx, o));
+        mny = fminf(mny, __shfl_xor(mny, o)); mxy = fmaxf(mxy, __shfl_xor(mxy, o));
+    }
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 0) { red[0][w] = mnx; red[1][w] = mxx; red[2][w] = mny; red[3][w] = mxy; }
+    __syncthreads();
+    const int nw = blockDim.x >> 6;
+    mnx = red[0][0]; mxx = red[1][0]; mny = red[2][0]; mxy = red[3][0];
+    for (int i = 1; i < nw; ++i) {
+        mnx = fminf(mnx, red[0][i]); mxx = fmaxf(mxx, red[1][i]);
+        mny = fminf(mny, red[2][i]); mxy = fmaxf(mxy, red[3][i]);
+    }
+    // size = 1 + max - min ; shift = size / 2 ; scale = max(size) / 2
+    const float sx = 1.0f + mxx - mnx, sy = 1.0f + mxy - mny;
+    const float shx = sx / 2.0f, shy = sy / 2.0f;
+    const float scale = fmaxf(sx, sy) / 2.0f;
+    for (int i = threadIdx.x; i < n * ENC; i += blockDim.x) {
+        const int tok = i / ENC, f = i % ENC;
+        const float kx = (xy[2 * tok] - shx) / scale;
+        const float ky = (xy[2 * tok + 1] - shy) / scale;
+        const float proj = kx * Wr[2 * f] + ky * Wr[2 * f + 1];
+        enc_cos[((size_t)img * Kc + tok) * ENC + f] = cosf(proj);
+        enc_sin[((size_t)img * Kc + tok) * ENC + f] = sinf(proj);
+    }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        ind[img * Kc + i] = i;
+        prune[img * Kc + i] = 1;
+    }
+    if (threadIdx.x == 0) {
+        ctrl->n[img] = n; ctrl->n_prev[img] = n; ctrl->n_orig[img] = n;
+        if (img == 0) { ctrl->stop = (M == 0 || N == 0) ? 2 : 0; ctrl->stop_layer = NL - 1;
+                        ctrl->unconf = 0; ctrl->n_matches = 0; }
+    }
+}
+
+// ------------------------------------------------------------------------ //
+//  1. GEMM  C[rows][N] = A[rows][K] . W[N][K]^T   (torch nn.Linear layout)
+//     fp32 MFMA 32x32x2; block 256 threads = 2x2 waves; LDS double buffer.
+// ------------------------------------------------------------------------ //
+constexpr int BK = 32;
+constexpr int LDS_LD = BK + 4;   // +16 B pad: ds_read_b128 conflict-free (16 rows cover 64 banks)
+
+template <int BM, int BN>
+struct __attribute__((aligned(16))) GemmSmem {
+    float a[2][BM * LDS_LD];
+    float w[2][BN * LDS_LD];
+};
+
+struct GemmA {            // A operand: optional concat of two row-major sources along K
+    const float* A0; int lda0;
+    const float* A1; int lda1;   // lda1 == lda0 when A1 is used
+    int K0;               // columns [0,K0) from A0, [K0,K) from A1 (K0 % 32 == 0)
+};
+
+#define LD4(dst, ptr) dst = *reinterpret_cast<const float4*>(ptr)
+#define ST4(ptr, src) *reinterpret_cast<float4*>(ptr) = src
+
+template <int BM, int BN, int TM, int TN>
+__device__ __forceinline__ void gemm_mainloop(const GemmA& ga, const float* __restrict__ W, int ldw,
+                                              int K, int row0, int row_cap, int col0, int col_cap,
+                                              GemmSmem<BM, BN>& sm, f32x16 (&acc)[TM][TN]) {
+    static_assert(BM == 64 * TM && BN == 64 * TN, "2x2 waves of 32*TM x 32*TN");
+    constexpr int NA = BM / 32, NW = BN / 32;      // float4 per thread per k-tile
+    static_assert(NA <= 4 && NW <= 4, "named prefetch registers cover up to 128-row tiles");
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, lr = lane & 31;
+
+    // Register prefetch of the next k-tile in NAMED registers (an indexed float4 array here
+    // ends up as a private array in scratch / LDS and exposes the whole load latency).
+    float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
+    ra0 = ra1 = ra2 = ra3 = rw0 = rw1 = rw2 = rw3 = make_float4(0, 0, 0, 0);
+    const int lr8 = t >> 3, lc4 = (t & 7) * 4;     // this thread's (row, k-offset) in a 32-row slab
+    size_t oa[4], ow[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        oa[j] = (size_t)min(row0 + lr8 + 32 * j, row_cap - 1) * ga.lda0 + lc4;
+        ow[j] = (size_t)min(col0 + lr8 + 32 * j, col_cap - 1) * ldw + lc4;
+    }
+    const int sto = lr8 * LDS_LD + lc4;
+
+#define GEMM_GLOAD(kt_)                                                        \
+    {                                                                          \
+        const int k_ = (kt_) * BK;                                             \
+        const float* pa_ = (k_ < ga.K0) ? ga.A0 + k_ : ga.A1 + (k_ - ga.K0);   \
+        const float* pw_ = W + k_;                                             \
+        LD4(ra0, pa_ + oa[0]);                                                 \
+        if constexpr (NA > 1) LD4(ra1, pa_ + oa[1]);                           \
+        if constexpr (NA > 2) LD4(ra2, pa_ + oa[2]);                           \
+        if constexpr (NA > 3) LD4(ra3, pa_ + oa[3]);                           \
+        LD4(rw0, pw_ + ow[0]);                                                 \
+        if constexpr (NW > 1) LD4(rw1, pw_ + ow[1]);                           \
+        if constexpr (NW > 2) LD4(rw2, pw_ + ow[2]);                           \
+        if constexpr (NW > 3) LD4(rw3, pw_ + ow[3]);                           \
+    }
+#define GEMM_SSTORE(buf_)                                                      \
+    {                                                                          \
+        float* da_ = &sm.a[buf_][sto];                                         \
+        float* dw_ = &sm.w[buf_][sto];                                         \
+        ST4(da_, ra0);                                                         \
+        if constexpr (NA > 1) ST4(da_ + 32 * LDS_LD, ra1);                     \
+        if constexpr (NA > 2) ST4(da_ + 64 * LDS_LD, ra2);                     \
+        if constexpr (NA > 3) ST4(da_ + 96 * LDS_LD, ra3);                     \
+        ST4(dw_, rw0);                                                         \
+        if constexpr (NW > 1) ST4(dw_ + 32 * LDS_LD, rw1);                     \
+        if constexpr (NW > 2) ST4(dw_ + 64 * LDS_LD, rw2);                     \
+        if constexpr (NW > 3) ST4(dw_ + 96 * LDS_LD, rw3);                     \
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nkt = K / BK;
+    GEMM_GLOAD(0);
+    GEMM_SSTORE(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) GEMM_GLOAD(kt + 1);
+        const float* sa = sm.a[cur] + (wm * 32 * TM + lr) * LDS_LD + 4 * h;
+        const float* sw = sm.w[cur] + (wn * 32 * TN + lr) * LDS_LD + 4 * h;
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            float4 af[TM], wf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) LD4(af[i], sa + i * 32 * LDS_LD + g * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) LD4(wf[j], sw + j * 32 * LDS_LD + g * 8);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = mfma32(af[i].x, wf[j].x, acc[i][j]);
+                    acc[i][j] = mfma32(af[i].y, wf[j].y, acc[i][j]);
+                    acc[i][j] = mfma32(af[i].z, wf[j].z, acc[i][j]);
+                    acc[i][j] = mfma32(af[i].w, wf[j].w, acc[i][j]);
+                }
+        }
+        if (kt + 1 < nkt) GEMM_SSTORE(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+#undef GEMM_GLOAD
+#undef GEMM_SSTORE
+}
+
+// Row-block -> (image, first row) for the two-image token buffers.
+struct RowDom {
+    int img, row0, n;
+};
+template <int BM>
+__device__ __forceinline__ RowDom row_domain(const LGCtrl* ctrl, int Kc) {
+    const int nb = (Kc + BM - 1) / BM;
+    RowDom d;
+    d.img = blockIdx.y / nb;
+    d.row0 = (blockIdx.y % nb) * BM;
+    d.n = ctrl->n[d.img];
+    return d;
+}
+
+enum { EPI_PLAIN = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_CROSSQKV = 3 };
+
+struct LinearArgs {
+    const float* A0; int lda0; const float* A1; int lda1; int K0; int K;   // per-image strides = Kc*ld
+    const float* W; const float* bias; int N;
+    long w_layer_stride;  // floats between consecutive layers' W (used with by_stop_layer)
+    long b_layer_stride;
+    int by_stop_layer;    // select W/bias by ctrl->stop_layer (log_assignment[i])
+    float out_scale;      // multiplies (acc + bias)
+    float* out; int ldo;  // PLAIN / RESID destination (per-image stride Kc*ldo); RESID adds `out` itself
+    float* q; float* k; float* v;           // QKV destinations [2][4][Kc][64]
+    const float* enc_cos; const float* enc_sin;
+    const LGCtrl* ctrl; int Kc;
+    int ignore_stop;      // final_proj runs after the stop
+};
+
+template <int BM, int BN, int TM, int TN, int EPI>
+__global__ __launch_bounds__(256) void lg_linear_kernel(LinearArgs p) {
+    __shared__ GemmSmem<BM, BN> sm;
+    if (p.ctrl->stop && !p.ignore_stop) return;
+    if (p.ctrl->stop == 2) return;
+    const RowDom rd = row_domain<BM>(p.ctrl, p.Kc);
+    if (rd.row0 >= rd.n) return;
+    const int col0 = blockIdx.x * BN;
+    const size_t ibase = (size_t)rd.img * p.Kc;
+    GemmA ga{p.A0 + ibase * p.lda0, p.lda0, p.A1 ? p.A1 + ibase * p.lda1 : nullptr, p.lda1, p.K0};
+    const float* W = p.W;
+    const float* bias = p.bias;
+    if (p.by_stop_layer) {
+        W += (size_t)p.ctrl->stop_layer * p.w_layer_stride;
+        bias += (size_t)p.ctrl->stop_layer * p.b_layer_stride;
+    }
+    f32x16 acc[TM][TN];
+    gemm_mainloop<BM, BN, TM, TN>(ga, W, p.K, p.K, rd.row0, p.Kc, col0, p.N, sm, acc);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = col0 + wn * 32 * TN + j * 32 + (lane & 31);
+            const float b = bias ? bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rd.row0 + wm * 32 * TM + i * 32 + acc_row(r, lane);
+                float val = (acc[i][j][r] + b) * p.out_scale;
+                if constexpr (EPI == EPI_QKV) {
+                    // col order is [s][head][d] (weights.py _qkv_row_perm); rotary on q,k:
+                    // out[2i] = x[2i] cos_i - x[2i+1] sin_i ; out[2i+1] = x[2i+1] cos_i + x[2i] sin_i
+                    const int s = col >> 8, hd = (col >> 6) & 3, d = col & 63;
+                    const float partner = __shfl_xor(val, 1);
+                    const int rr = min(row, p.Kc - 1);
+                    if (s < 2) {
+                        const float c = p.enc_cos[(ibase + rr) * ENC + (d >> 1)];
+                        const float sn = p.enc_sin[(ibase + rr) * ENC + (d >> 1)];
+                        val = (d & 1) ? (val * c + partner * sn) : (val * c - partner * sn);
+                    }
+                    float* dst = s == 0 ? p.q : (s == 1 ? p.k : p.v);
+                    if (row < rd.n) dst[(((size_t)rd.img * NH + hd) * p.Kc + row) * DH + d] = val;
+                } else if constexpr (EPI == EPI_CROSSQKV) {
+                    const int s = col >> 8, hd = (col >> 6) & 3, d = col & 63;   // s: 0 = qk, 1 = v
+                    float* dst = s == 0 ? p.q : p.v;
+                    if (row < rd.n) dst[(((size_t)rd.img * NH + hd) * p.Kc + row) * DH + d] = val;
+                } else {
+                    if (row < rd.n) {
+                        float* o = p.out + (ibase + row) * p.ldo + col;
+                        if constexpr (EPI == EPI_RESID) val += *o;
+                        *o = val;
+                    }
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------ //
+//  2. LayerNorm(512) + exact GELU, in place on the FFN hidden (one wave / row)
+// ------------------------------------------------------------------------ //
+__global__ __launch_bounds__(256) void lg_ln_gelu_kernel(float* __restrict__ hid,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta,
+                                                         const LGCtrl* __restrict__ ctrl, int Kc) {
+    if (ctrl->stop) return;
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);     // global wave = row over both images
+    const int img = gw / Kc, row = gw % Kc;
+    if (img > 1 || row >= ctrl->n[img]) return;
+    float* p = hid + ((size_t)img * Kc + row) * 512;
+    float4 a = *reinterpret_cast<float4*>(p + lane * 4);
+    float4 b = *reinterpret_cast<float4*>(p + 256 + lane * 4);
+    float s = (a.x + a.y) + (a.z + a.w) + (b.x + b.y) + (b.z + b.w);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / 512.0f;
+    float v[8] = {a.x - mean, a.y - mean, a.z - mean, a.w - mean, b.x - mean, b.y - mean, b.z - mean, b.w - mean};
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q += v[i] * v[i];
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / 512.0f + 1e-5f);
+    float out[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = (i < 4 ? 0 : 256) + lane * 4 + (i & 3);
+        const float y = v[i] * rstd * gamma[c] + beta[c];
+        out[i] = 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
+    }
+    *reinterpret_cast<float4*>(p + lane * 4) = make_float4(out[0], out[1], out[2], out[3]);
+    *reinterpret_cast<float4*>(p + 256 + lane * 4) = make_float4(out[4], out[5], out[6], out[7]);
+}
+
+// ------------------------------------------------------------------------ //
+//  3. Attention (flash-style, fp32 MFMA).  One wave = 32 query rows; block =
+//     4 waves = 128 queries of one (image, head); grid.z splits the keys.
+//     S^T = K.Q^T so a lane owns one query column: softmax runs over registers
+//     (+ one cross-half exchange) and P feeds PV straight from the accumulator.
+// ------------------------------------------------------------------------ //
+constexpr int AQ = 128;          // queries per block
+constexpr int AK = 64;           // keys per LDS tile
+constexpr int AK_LD = DH + 4;
+
+struct __attribute__((aligned(16))) AttnSmem {
+    float k[2][AK * AK_LD];
+    float v[2][AK * DH];
+};
+
+struct AttnArgs {
+    const float* Q; const float* K; const float* V;   // [2][4][Kc][64]
+    int cross;                                        // keys/values come from the other image
+    float* o_part; float* m_part; float* l_part;      // [KS][2][4][Kc][64] / [KS][2][4][Kc]
+    int KS; int Kc; const LGCtrl* ctrl;
+};
+
+__global__ __launch_bounds__(256) void lg_attention_kernel(AttnArgs p) {
+    __shared__ AttnSmem sm;
+    if (p.ctrl->stop) return;
+    const int img = blockIdx.y >> 2, head = blockIdx.y & 3;
+    const int kimg = p.cross ? 1 - img : img;
+    const int nq = p.ctrl->n[img], nk = p.ctrl->n[kimg];
+    const int q0 = blockIdx.x * AQ;
+    if (q0 >= nq) return;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, lr = lane & 31;
+    const int z = blockIdx.z;
+    const int ntiles = (nk + AK - 1) / AK;
+    const int t0 = (int)((long)z * ntiles / p.KS), t1 = (int)((long)(z + 1) * ntiles / p.KS);
+
+    const float* Qb = p.Q + ((size_t)img * NH + head) * p.Kc * DH;
+    const float* Kb = p.K + ((size_t)kimg * NH + head) * p.Kc * DH;
+    const float* Vb = p.V + ((size_t)kimg * NH + head) * p.Kc * DH;
+
+    // Q fragment: B operand of S^T = K.Q^T -> lane holds Q[i = lr][dims 8g+4h .. +3], pre-scaled
+    // by 1/sqrt(64) * log2(e) so the softmax uses exp2.
+    const float qscale = 0.125f * 1.4426950408889634f;
+    const int qi = min(q0 + wave * 32 + lr, p.Kc - 1);
+    float qreg[32];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const float4 f = *reinterpret_cast<const float4*>(Qb + (size_t)qi * DH + g * 8 + 4 * h);
+        qreg[g * 4 + 0] = f.x * qscale; qreg[g * 4 + 1] = f.y * qscale;
+        qreg[g * 4 + 2] = f.z * qscale; qreg[g * 4 + 3] = f.w * qscale;
+    }
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.0f; o1[r] = 0.0f; }
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    float4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3;      // named: see gemm_mainloop
+    rk0 = rk1 = rk2 = rk3 = rv0 = rv1 = rv2 = rv3 = make_float4(0, 0, 0, 0);
+    const int ar = t >> 4, ac4 = (t & 15) * 4;       // (row, dim offset) inside a 16-row slab
+#define ATTN_GLOAD(tile_)                                                                   \
+    {                                                                                       \
+        const int rb_ = (tile_) * AK + ar;                                                  \
+        const size_t o0_ = (size_t)min(rb_, p.Kc - 1) * DH + ac4;                           \
+        const size_t o1_ = (size_t)min(rb_ + 16, p.Kc - 1) * DH + ac4;                      \
+        const size_t o2_ = (size_t)min(rb_ + 32, p.Kc - 1) * DH + ac4;                      \
+        const size_t o3_ = (size_t)min(rb_ + 48, p.Kc - 1) * DH + ac4;                      \
+        LD4(rk0, Kb + o0_); LD4(rk1, Kb + o1_); LD4(rk2, Kb + o2_); LD4(rk3, Kb + o3_);     \
+        LD4(rv0, Vb + o0_); LD4(rv1, Vb + o1_); LD4(rv2, Vb + o2_); LD4(rv3, Vb + o3_);     \
+    }
+#define ATTN_SSTORE(buf_)                                                                   \
+    {                                                                                       \
+        float* dk_ = &sm.k[buf_][ar * AK_LD + ac4];                                         \
+        float* dv_ = &sm.v[buf_][ar * DH + ac4];                                            \
+        ST4(dk_, rk0); ST4(dk_ + 16 * AK_LD, rk1); ST4(dk_ + 32 * AK_LD, rk2);              \
+        ST4(dk_ + 48 * AK_LD, rk3);                                                         \
+        ST4(dv_, rv0); ST4(dv_ + 16 * DH, rv1); ST4(dv_ + 32 * DH, rv2); ST4(dv_ + 48 * DH, rv3); \
+    }
+
+    if (t0 < t1) {
+        ATTN_GLOAD(t0);
+        ATTN_SSTORE(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int tile = t0; tile < t1; ++tile) {
+        if (tile + 1 < t1) ATTN_GLOAD(tile + 1);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+            const float* sk = sm.k[cur] + (sub * 32 + lr) * AK_LD + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const float4 kf = *reinterpret_cast<const float4*>(sk + g * 8);
+                s = mfma32(kf.x, qreg[g * 4 + 0], s);
+                s = mfma32(kf.y, qreg[g * 4 + 1], s);
+                s = mfma32(kf.z, qreg[g * 4 + 2], s);
+                s = mfma32(kf.w, qreg[g * 4 + 3], s);
+            }
+            // mask keys beyond nk, tile max
+            const int kbase = tile * AK + sub * 32;
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (kbase + acc_row(r, lane) >= nk) s[r] = -INFINITY;
+                tmax = fmaxf(tmax, s[r]);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float m_new = fmaxf(m_run, tmax);
+            // (m_new is finite: every block's first sub-tile holds at least one valid key)
+            const float alpha = exp2f(m_run - m_new);
+            m_run = m_new;
+            float psum = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] = exp2f(s[r] - m_new);
+                psum += s[r];
+            }
+            l_run = l_run * alpha + psum;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            // O^T[d][i] += V^T[d][j] P^T[j][i] ; acc reg r of S^T is key row acc_row(r) -> k index
+            const float* sv = sm.v[cur] + (size_t)(sub * 32) * DH + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = (r & 3) + 8 * (r >> 2) + 4 * h;
+                o0 = mfma32(sv[j * DH], s[r], o0);
+                o1 = mfma32(sv[j * DH + 32], s[r], o1);
+            }
+        }
+        if (tile + 1 < t1) ATTN_SSTORE(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+#undef ATTN_GLOAD
+#undef ATTN_SSTORE
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const int qrow = q0 + wave * 32 + lr;
+    if (qrow < nq) {
+        const size_t pbase = (((size_t)z * 2 + img) * NH + head) * p.Kc + qrow;
+        float* op = p.o_part + pbase * DH;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            *reinterpret_cast<float4*>(op + 8 * g4 + 4 * h) =
+                make_float4(o0[4 * g4], o0[4 * g4 + 1], o0[4 * g4 + 2], o0[4 * g4 + 3]);
+            *reinterpret_cast<float4*>(op + 32 + 8 * g4 + 4 * h) =
+                make_float4(o1[4 * g4], o1[4 * g4 + 1], o1[4 * g4 + 2], o1[4 * g4 + 3]);
+        }
+        if (h == 0) { p.m_part[pbase] = m_run; p.l_part[pbase] = l_tot; }
+    }
+}
+
+// merge key-split partials -> msg[img][row][head*64 + d]
+__global__ __launch_bounds__(256) void lg_attn_merge_kernel(const float* __restrict__ o_part,
+                                                            const float* __restrict__ m_part,
+                                                            const float* __restrict__ l_part,
+                                                            float* __restrict__ msg, int KS, int Kc,
+                                                            const LGCtrl* __restrict__ ctrl) {
+    if (ctrl->stop) return;
+    // one thread = one float4 of one (img, head, row)
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c4 = (int)(gid & 15);
+    const long rid = gid >> 4;                      // (img*4+head)*Kc + row
+    if (rid >= (long)2 * NH * Kc) return;
+    const int row = (int)(rid % Kc), ih = (int)(rid / Kc), img = ih >> 2, head = ih & 3;
+    if (row >= ctrl->n[img]) return;
+    float M = -INFINITY;
+    for (int z = 0; z < KS; ++z) M = fmaxf(M, m_part[(size_t)z * 2 * NH * Kc + rid]);
+    float4 acc = make_float4(0, 0, 0, 0);
+    float L = 0.0f;
+    for (int z = 0; z < KS; ++z) {
+        const size_t pb = (size_t)z * 2 * NH * Kc + rid;
+        const float mz = m_part[pb];
+        const float wz = (mz == -INFINITY) ? 0.0f : exp2f(mz - M);
+        const float4 o = *reinterpret_cast<const float4*>(o_part + pb * DH + c4 * 4);
+        acc.x += o.x * wz; acc.y += o.y * wz; acc.z += o.z * wz; acc.w += o.w * wz;
+        L += l_part[pb] * wz;
+    }
+    const float inv = 1.0f / L;
+    *reinterpret_cast<float4*>(msg + ((size_t)img * Kc + row) * D + head * DH + c4 * 4) =
+        make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+}
+
+// ------------------------------------------------------------------------ //
+//  4. token confidence + matchability, early-stop decision, point pruning
+// ------------------------------------------------------------------------ //
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float logsigmoidf_(float x) {   // min(x,0) - log1p(exp(-|x|))
+    return fminf(x, 0.0f) - log1pf(expf(-fabsf(x)));
+}
+
+// one wave per token: conf = sigmoid(w_c.x + b_c), mat = (w_m.x + b_m)
+__global__ __launch_bounds__(256) void lg_token_heads_kernel(
+    const float* __restrict__ x, const float* __restrict__ wc, const float* __restrict__ bc,
+    const float* __restrict__ wm, const float* __restrict__ bm, long m_layer_stride, int use_stop_layer,
+    float conf_thr, float* __restrict__ conf, float* __restrict__ mat, LGCtrl* __restrict__ ctrl, int Kc,
+    int count_unconf) {
+    __shared__ int s_unconf[4];
+    if (ctrl->stop == 2) return;
+    if (ctrl->stop && !use_stop_layer) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gw = blockIdx.x * 4 + wave;
+    const int img = gw / Kc, row = gw % Kc;
+    const bool live = img <= 1 && row < ctrl->n[img];
+    int unconf = 0;
+    if (live) {
+        if (use_stop_layer) {
+            wm += (size_t)ctrl->stop_layer * m_layer_stride;
+            bm += (size_t)ctrl->stop_layer * m_layer_stride;   // both padded to the same stride
+        }
+        const float4 xv = *reinterpret_cast<const float4*>(x + ((size_t)img * Kc + row) * D + lane * 4);
+        float sm_ = 0.0f, sc = 0.0f;
+        {
+            const float4 w = *reinterpret_cast<const float4*>(wm + lane * 4);
+            sm_ = xv.x * w.x + xv.y * w.y + xv.z * w.z + xv.w * w.w;
+        }
+        if (wc) {
+            const float4 w = *reinterpret_cast<const float4*>(wc + lane * 4);
+            sc = xv.x * w.x + xv.y * w.y + xv.z * w.z + xv.w * w.w;
+        }
+        for (int o = 32; o > 0; o >>= 1) { sm_ += __shfl_xor(sm_, o); sc += __shfl_xor(sc, o); }
+        if (lane == 0) {
+            mat[img * Kc + row] = sm_ + bm[0];
+            if (wc) {
+                const float c = sigmoidf_(sc + bc[0]);
+                conf[img * Kc + row] = c;
+                unconf = c < conf_thr;
+            }
+        }
+    }
+    if (!count_unconf) return;
+    if (lane == 0) s_unconf[wave] = unconf;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = s_unconf[0] + s_unconf[1] + s_unconf[2] + s_unconf[3];
+        if (tot) atomicAdd(&ctrl->unconf, tot);
+    }
+}
+
+// single block: early-stop test, then order-preserving compaction maps
+__global__ __launch_bounds__(1024) void lg_decide_kernel(
+    int layer, float conf_thr, float depth_conf, float width_conf, int prune_min, int do_stop,
+    const float* __restrict__ conf, const float* __restrict__ mat, int* __restrict__ ind,
+    int* __restrict__ gmap, int* __restrict__ prune, LGCtrl* __restrict__ ctrl, int Kc) {
+    __shared__ int wsum[16];
+    __shared__ int s_stop;
+    if (ctrl->stop) return;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) {
+        int stop = 0;
+        if (do_stop) {
+            const float ratio = 1.0f - (float)ctrl->unconf / (float)(ctrl->n_orig[0] + ctrl->n_orig[1]);
+            stop = ratio > depth_conf;
+        }
+        ctrl->unconf = 0;
+        if (stop) { ctrl->stop = 1; ctrl->stop_layer = layer; }
+        s_stop = stop;
+        ctrl->n_prev[0] = ctrl->n[0];
+        ctrl->n_prev[1] = ctrl->n[1];
+    }
+    __syncthreads();
+    if (s_stop || width_conf <= 0.0f) return;
+    const int per = (Kc + 1023) / 1024;
+    for (int img = 0; img < 2; ++img) {
+        const int n = ctrl->n[img];
+        if (!(n > prune_min)) continue;
+        // thread owns the contiguous chunk [t*per, t*per+per)
+        int keep[8], oldind[8], cnt = 0;
+        for (int j = 0; j < per; ++j) {
+            const int i = t * per + j;
+            int k = 0;
+            if (i < n) {
+                const float sc = sigmoidf_(mat[img * Kc + i]);
+                k = sc > (1.0f - width_conf);
+                if (do_stop) k |= conf[img * Kc + i] <= conf_thr;
+                oldind[j] = ind[img * Kc + i];
+            }
+            keep[j] = k;
+            cnt += k;
+        }
+        int incl = cnt;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int base = 0, total = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wave) base += wsum[w];
+            total += wsum[w];
+        }
+        int pos = base + incl - cnt;
+        __syncthreads();       // all reads of ind[] done before any write
+        for (int j = 0; j < per; ++j) {
+            const int i = t * per + j;
+            if (i < n && keep[j]) {
+                ind[img * Kc + pos] = oldind[j];
+                gmap[img * Kc + pos] = i;
+                prune[img * Kc + oldind[j]] += 1;
+                ++pos;
+            }
+        }
+        if (t == 0) {
+            ctrl->n[img] = total;
+            if (total == 0) { ctrl->stop = 2; ctrl->stop_layer = layer; }
+        }
+        __syncthreads();
+    }
+}
+
+// gather surviving rows: x, enc -> tmp (then copied back by lg_copyback_kernel)
+__global__ __launch_bounds__(256) void lg_gather_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ ec,
+                                                        const float* __restrict__ es,
+                                                        const int* __restrict__ gmap,
+                                                        float* __restrict__ tx, float* __restrict__ tc,
+                                                        float* __restrict__ ts,
+                                                        const LGCtrl* __restrict__ ctrl, int Kc, int back) {
+    if (ctrl->stop) return;
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int img = gw / Kc, row = gw % Kc;
+    if (img > 1 || ctrl->n[img] == ctrl->n_prev[img] || row >= ctrl->n[img]) return;
+    const size_t dst = (size_t)img * Kc + row;
+    const size_t src = back ? dst : (size_t)img * Kc + gmap[img * Kc + row];
+    // back == 1: tmp -> x (plain copy); back == 0: x[gmap] -> tmp
+    const float* sx = back ? tx : x; float* dx = back ? const_cast<float*>(x) : tx;
+    const float* sc = back ? tc : ec; float* dc = back ? const_cast<float*>(ec) : tc;
+    const float* ss = back ? ts : es; float* ds = back ? const_cast<float*>(es) : ts;
+    *reinterpret_cast<float4*>(dx + dst * D + lane * 4) = *reinterpret_cast<const float4*>(sx + src * D + lane * 4);
+    if (lane < 32) dc[dst * ENC + lane] = sc[src * ENC + lane];
+    else ds[dst * ENC + lane - 32] = ss[src * ENC + lane - 32];
+}
+
+// ------------------------------------------------------------------------ //
+//  5. assignment: sim GEMM, dual log-softmax statistics, arg-max, mutual check
+// ------------------------------------------------------------------------ //
+struct SimArgs { const float* md; float* sim; int Kc; const LGCtrl* ctrl; };
+
+template <int BM, int BN, int TM, int TN>
+__global__ __launch_bounds__(256) void lg_sim_kernel(SimArgs p) {
+    __shared__ GemmSmem<BM, BN> sm;
+    if (p.ctrl->stop == 2) return;
+    const int n0 = p.ctrl->n[0], n1 = p.ctrl->n[1];
+    const int row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
+    if (row0 >= n0 || col0 >= n1) return;
+    GemmA ga{p.md, D, nullptr, 0, D};
+    f32x16 acc[TM][TN];
+    gemm_mainloop<BM, BN, TM, TN>(ga, p.md + (size_t)p.Kc * D, D, D, row0, p.Kc, col0, p.Kc, sm, acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = col0 + wn * 32 * TN + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wm * 32 * TM + i * 32 + acc_row(r, lane);
+                if (row < n0 && col < n1) p.sim[(size_t)row * p.Kc + col] = acc[i][j][r];
+            }
+        }
+}
+
+// row statistics: one wave per row i: max_j, log(sum_j exp(sim - max))
+__global__ __launch_bounds__(256) void lg_row_stats_kernel(const float* __restrict__ sim,
+                                                           float* __restrict__ rmax, float* __restrict__ rlog,
+                                                           int Kc, const LGCtrl* __restrict__ ctrl) {
+    if (ctrl->stop == 2) return;
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n0 = ctrl->n[0], n1 = ctrl->n[1];
+    if (row >= n0) return;
+    const float* p = sim + (size_t)row * Kc;
+    float m = -INFINITY;
+    for (int j = lane; j < n1; j += 64) m = fmaxf(m, p[j]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float s = 0.0f;
+    for (int j = lane; j < n1; j += 64) s += expf(p[j] - m);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) { rmax[row] = m; rlog[row] = logf(s); }
+}
+
+// column statistics over sim[n0][n1]: grid (n1/64, CSLAB); a block owns 64 columns x one
+// slab of rows (4 row-interleaved partials inside the block).  Partials are merged by
+// lg_col_stats_merge_kernel (max / rescaled sum), so the row dimension is spread over the chip.
+constexpr int CSLAB = 16;
+
+__global__ __launch_bounds__(256) void lg_col_stats_kernel(const float* __restrict__ sim,
+                                                           float* __restrict__ pmax, float* __restrict__ psum,
+                                                           int Kc, const LGCtrl* __restrict__ ctrl) {
+    __shared__ float sh[4][64];
+    if (ctrl->stop == 2) return;
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    const int n0 = ctrl->n[0], n1 = ctrl->n[1];
+    if (blockIdx.x * 64 >= n1) return;
+    const int rows_per = (n0 + CSLAB - 1) / CSLAB;
+    const int r0 = blockIdx.y * rows_per, r1 = min(n0, r0 + rows_per);
+    const bool ok = col < n1;
+    float m = -INFINITY;
+    if (ok) for (int i = r0 + part; i < r1; i += 4) m = fmaxf(m, sim[(size_t)i * Kc + col]);
+    sh[part][lane] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(sh[0][lane], sh[1][lane]), fmaxf(sh[2][lane], sh[3][lane]));
+    __syncthreads();
+    float s = 0.0f;
+    if (ok && m > -INFINITY) for (int i = r0 + part; i < r1; i += 4) s += expf(sim[(size_t)i * Kc + col] - m);
+    sh[part][lane] = s;
+    __syncthreads();
+    if (part == 0 && ok) {
+        pmax[(size_t)blockIdx.y * Kc + col] = m;
+        psum[(size_t)blockIdx.y * Kc + col] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+    }
+}
+
+__global__ __launch_bounds__(256) void lg_col_stats_merge_kernel(const float* __restrict__ pmax,
+                                                                 const float* __restrict__ psum,
+                                                                 float* __restrict__ cmax, float* __restrict__ clog,
+                                                                 int Kc, const LGCtrl* __restrict__ ctrl) {
+    if (ctrl->stop == 2) return;
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ctrl->n[1]) return;
+    float m = -INFINITY;
+    for (int z = 0; z < CSLAB; ++z) m = fmaxf(m, pmax[(size_t)z * Kc + col]);
+    float s = 0.0f;
+    for (int z = 0; z < CSLAB; ++z) {
+        const float pm = pmax[(size_t)z * Kc + col];
+        if (pm > -INFINITY) s += psum[(size_t)z * Kc + col] * expf(pm - m);
+    }
+    cmax[col] = m;
+    clog[col] = logf(s);
+}
+
+// scores[i][j] = ((sim - rmax_i) - rlog_i) + ((sim - cmax_j) - clog_j) + (ls0_i + ls1_j)
+__device__ __forceinline__ float score_ij(float s, float rm, float rl, float cm, float cl, float a, float b) {
+    return (((s - rm) - rl) + ((s - cm) - cl)) + (a + b);
+}
+
+__global__ __launch_bounds__(256) void lg_row_argmax_kernel(
+    const float* __restrict__ sim, const float* __restrict__ rmax, const float* __restrict__ rlog,
+    const float* __restrict__ cmax, const float* __restrict__ clog, const float* __restrict__ z,
+    float* __restrict__ best0, int* __restrict__ arg0, int Kc, const LGCtrl* __restrict__ ctrl) {
+    if (ctrl->stop == 2) return;
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n0 = ctrl->n[0], n1 = ctrl->n[1];
+    if (row >= n0) return;
+    const float rm = rmax[row], rl = rlog[row], a = logsigmoidf_(z[row]);
+    float bv = -INFINITY; int bj = 0x7fffffff;
+    for (int j = lane; j < n1; j += 64) {
+        const float v = score_ij(sim[(size_t)row * Kc + j], rm, rl, cmax[j], clog[j], a, logsigmoidf_(z[Kc + j]));
+        if (v > bv) { bv = v; bj = j; }          // ascending j per lane: first maximum kept
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o); const int oj = __shfl_xor(bj, o);
+        if (ov > bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
+    }
+    if (lane == 0) { best0[row] = bv; arg0[row] = bj; }
+}
+
+__global__ __launch_bounds__(256) void lg_col_argmax_kernel(
+    const float* __restrict__ sim, const float* __restrict__ rmax, const float* __restrict__ rlog,
+    const float* __restrict__ cmax, const float* __restrict__ clog, const float* __restrict__ z,
+    float* __restrict__ pval, int* __restrict__ parg, int Kc, const LGCtrl* __restrict__ ctrl) {
+    __shared__ float shv[4][64];
+    __shared__ int shi[4][64];
+    if (ctrl->stop == 2) return;
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    const int n0 = ctrl->n[0], n1 = ctrl->n[1];
+    if (blockIdx.x * 64 >= n1) return;
+    const int rows_per = (n0 + CSLAB - 1) / CSLAB;
+    const int r0 = blockIdx.y * rows_per, r1 = min(n0, r0 + rows_per);
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    if (col < n1) {
+        const float cm = cmax[col], cl = clog[col], b = logsigmoidf_(z[Kc + col]);
+        for (int i = r0 + part; i < r1; i += 4) {
+            const float v = score_ij(sim[(size_t)i * Kc + col], rmax[i], rlog[i], cm, cl, logsigmoidf_(z[i]), b);
+            if (v > bv) { bv = v; bi = i; }
+        }
+    }
+    shv[part][lane] = bv; shi[part][lane] = bi;
+    __syncthreads();
+    if (part == 0 && col < n1) {
+        for (int q = 1; q < 4; ++q) {
+            const float ov = shv[q][lane]; const int oi = shi[q][lane];
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        pval[(size_t)blockIdx.y * Kc + col] = bv;
+        parg[(size_t)blockIdx.y * Kc + col] = bi;
+    }
+}
+
+__device__ __forceinline__ int col_argmax_merge(const float* __restrict__ pval, const int* __restrict__ parg,
+                                                int Kc, int col) {
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int z = 0; z < CSLAB; ++z) {
+        const float ov = pval[(size_t)z * Kc + col]; const int oi = parg[(size_t)z * Kc + col];
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    return bi;
+}
+
+// single block: mutual check, thresholds, ordered emission in original indices
+__global__ __launch_bounds__(1024) void lg_emit_kernel(
+    const float* __restrict__ best0, const int* __restrict__ arg0, const float* __restrict__ pval,
+    const int* __restrict__ parg, const int* __restrict__ ind, float filter_thr, float min_conf, int32_t* __restrict__ ij_out,
+    float* __restrict__ score_out, int32_t* __restrict__ info_out, LGCtrl* __restrict__ ctrl, int Kc) {
+    __shared__ int wsum[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n0 = ctrl->stop == 2 ? 0 : ctrl->n[0];
+    const int per = (Kc + 1023) / 1024;
+    int keep[8], jj[8], cnt = 0; float sc[8];
+    for (int q = 0; q < per; ++q) {
+        const int i = t * per + q;
+        int k = 0;
+        if (i < n0) {
+            const int j = arg0[i];
+            const float s = expf(best0[i]);
+            k = (col_argmax_merge(pval, parg, Kc, j) == i) && (s > filter_thr) && (s > min_conf);
+            jj[q] = j; sc[q] = s;
+        }
+        keep[q] = k; cnt += k;
+    }
+    int incl = cnt;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int w = 0; w < 16; ++w) { if (w < wave) base += wsum[w]; total += wsum[w]; }
+    int pos = base + incl - cnt;
+    for (int q = 0; q < per; ++q) {
+        const int i = t * per + q;
+        if (i < n0 && keep[q]) {
+            ij_out[2 * pos] = ind[i];
+            ij_out[2 * pos + 1] = ind[Kc + jj[q]];
+            score_out[pos] = sc[q];
+            ++pos;
+        }
+    }
+    if (t == 0) {
+        ctrl->n_matches = total;
+        info_out[0] = total;
+        info_out[1] = ctrl->stop_layer + 1;     // upstream "stop" = i + 1
+        info_out[2] = ctrl->n[0];
+        info_out[3] = ctrl->n[1];
+    }
+}
+
+}  // namespace
+
+// ======================================================================== //
+//  host side
+// ======================================================================== //
+struct LGLayerW {
+    const float *wqkv, *bqkv, *wo, *bo, *w1, *b1, *lnw, *lnb, *w2, *b2;
+    const float *cqkv, *cbqkv, *cwo, *cbo, *cw1, *cb1, *clnw, *clnb, *cw2, *cb2;
+};
+
+struct sslam_lightglue {
+    sslam_ctx* ctx = nullptr;
+    int Kc = 0, KS = 4;
+    float depth_conf = 0.95f, width_conf = 0.99f, filter_thr = 0.1f;
+    int prune_min = -1;
+    sslam::Arena arena;
+    float* blob = nullptr;
+    const float *w_in, *b_in, *w_r;
+    LGLayerW L[NL];
+    const float *fp_w, *fp_b, *mt_w, *mt_b;   // layer 0; strides below
+    long fp_stride = 0, mt_stride = 0;
+    const float* tc_w[NL - 1];
+    const float* tc_b[NL - 1];
+    // workspace
+    LGCtrl* ctrl;
+    float *x, *enc_cos, *enc_sin, *q, *k, *v, *msg, *msg2, *hid, *tx, *tc, *ts;
+    float *o_part, *m_part, *l_part, *conf, *mat, *md, *sim, *rmax, *rlog, *cmax, *clog, *best0;
+    float *cpmax, *cpsum, *cpval;
+    int* cparg;
+    int *ind, *gmap, *prune, *arg0, *arg1;
+    float *in_xy, *in_desc, *out_score;
+    int32_t *out_ij, *out_info;
+};
+
+namespace {
+
+size_t pad64(size_t n) { return (n + 63) / 64 * 64; }
+
+int lg_bind_weights(sslam_lightglue* g, size_t n_floats) {
+    size_t off = 0;
+    auto take = [&](size_t n) { const float* p = g->blob + off; off += pad64(n); return p; };
+    g->w_in = take((size_t)D * DIN); g->b_in = take(D); g->w_r = take(ENC * 2);
+    for (int i = 0; i < NL; ++i) {
+        LGLayerW& l = g->L[i];
+        l.wqkv = take(3 * D * D); l.bqkv = take(3 * D); l.wo = take(D * D); l.bo = take(D);
+        l.w1 = take(4 * D * D); l.b1 = take(2 * D); l.lnw = take(2 * D); l.lnb = take(2 * D);
+        l.w2 = take(2 * D * D); l.b2 = take(D);
+        l.cqkv = take(2 * D * D); l.cbqkv = take(2 * D); l.cwo = take(D * D); l.cbo = take(D);
+        l.cw1 = take(4 * D * D); l.cb1 = take(2 * D); l.clnw = take(2 * D); l.clnb = take(2 * D);
+        l.cw2 = take(2 * D * D); l.cb2 = take(D);
+    }
+    for (int i = 0; i < NL; ++i) {
+        const float* fw = take(D * D); const float* fb = take(D);
+        const float* mw = take(D); const float* mb = take(1);
+        if (i == 0) { g->fp_w = fw; g->fp_b = fb; g->mt_w = mw; g->mt_b = mb; }
+        if (i == 1) { g->fp_stride = fw - g->fp_w; g->mt_stride = mw - g->mt_w; }
+    }
+    for (int i = 0; i < NL - 1; ++i) { g->tc_w[i] = take(D); g->tc_b[i] = take(1); }
+    SSLAM_REQUIRE(off == n_floats, "sslam_lightglue_create: weight blob has %zu floats, expected %zu",
+                  n_floats, off);
+    return 0;
+}
+
+float conf_threshold(int layer) {   // np.clip(0.8 + 0.1 * exp(-4 i / n_layers), 0, 1), cast to fp32
+    double v = 0.8 + 0.1 * exp(-4.0 * layer / (double)NL);
+    v = v < 0 ? 0 : (v > 1 ? 1 : v);
+    return (float)v;
+}
+
+template <int BM, int BN, int TM, int TN, int EPI>
+void launch_linear(hipStream_t s, const LinearArgs& a) {
+    dim3 grid(a.N / BN, 2 * sslam::cdiv(a.Kc, BM));
+    hipLaunchKernelGGL((lg_linear_kernel<BM, BN, TM, TN, EPI>), grid, dim3(256), 0, s, a);
+}
+
+LinearArgs lin(const sslam_lightglue* g, const float* A0, int lda0, const float* A1, int lda1, int K0,
+               int K, const float* W, const float* b, int N) {
+    LinearArgs a{};
+    a.A0 = A0; a.lda0 = lda0; a.A1 = A1; a.lda1 = lda1; a.K0 = K0; a.K = K;
+    a.W = W; a.bias = b; a.N = N; a.out_scale = 1.0f; a.ctrl = g->ctrl; a.Kc = g->Kc;
+    a.enc_cos = g->enc_cos; a.enc_sin = g->enc_sin;
+    return a;
+}
+
+void launch_attention(const sslam_lightglue* g, hipStream_t s, const float* Q, const float* K,
+                      const float* V, int cross) {
+    AttnArgs a{Q, K, V, cross, g->o_part, g->m_part, g->l_part, g->KS, g->Kc, g->ctrl};
+    dim3 grid(sslam::cdiv(g->Kc, AQ), 2 * NH, g->KS);
+    hipLaunchKernelGGL(lg_attention_kernel, grid, dim3(256), 0, s, a);
+    const long n4 = (long)2 * NH * g->Kc * 16;
+    hipLaunchKernelGGL(lg_attn_merge_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s,
+                       g->o_part, g->m_part, g->l_part, g->msg, g->KS, g->Kc, g->ctrl);
+}
+
+void launch_ffn(const sslam_lightglue* g, hipStream_t s, const float* message, const float* w1,
+                const float* b1, const float* lnw, const float* lnb, const float* w2, const float* b2) {
+    // hid = [x | message] W1^T + b1 ; LN + GELU ; x += hid W2^T + b2
+    LinearArgs a = lin(g, g->x, D, message, D, D, 2 * D, w1, b1, 2 * D);
+    a.out = g->hid; a.ldo = 2 * D;
+    launch_linear<64, 128, 1, 2, EPI_PLAIN>(s, a);
+    hipLaunchKernelGGL(lg_ln_gelu_kernel, dim3(sslam::cdiv(2 * g->Kc, 4)), dim3(256), 0, s, g->hid, lnw,
+                       lnb, g->ctrl, g->Kc);
+    LinearArgs c = lin(g, g->hid, 2 * D, nullptr, 0, 2 * D, 2 * D, w2, b2, D);
+    c.out = g->x; c.ldo = D;
+    launch_linear<64, 64, 1, 1, EPI_RESID>(s, c);
+}
+
+// Enqueue one pair on the context stream.  Inputs are already staged in
+// g->in_xy / g->in_desc ([2][Kc][2] and [2][Kc][128]).
+int lg_enqueue(sslam_lightglue* g, int M, int N, float min_conf, int32_t* ij_out, float* score_out,
+               int32_t* info_out) {
+    hipStream_t s = g->ctx->stream;
+    const int Kc = g->Kc;
+    hipLaunchKernelGGL(lg_prepare_kernel, dim3(2), dim3(1024), 0, s, g->in_xy, g->in_xy + 2 * Kc, M, N,
+                       Kc, g->w_r, g->enc_cos, g->enc_sin, g->ind, g->prune, g->ctrl);
+    {   // input_proj (lightglue.py: desc = self.input_proj(desc))
+        LinearArgs a = lin(g, g->in_desc, DIN, nullptr, 0, DIN, DIN, g->w_in, g->b_in, D);
+        a.out = g->x; a.ldo = D;
+        launch_linear<64, 64, 1, 1, EPI_PLAIN>(s, a);
+    }
+    const unsigned tokblocks = sslam::cdiv(2 * Kc, 4);
+    for (int i = 0; i < NL; ++i) {
+        const LGLayerW& l = g->L[i];
+        // ---- self block
+        {
+            LinearArgs a = lin(g, g->x, D, nullptr, 0, D, D, l.wqkv, l.bqkv, 3 * D);
+            a.q = g->q; a.k = g->k; a.v = g->v;
+            launch_linear<64, 128, 1, 2, EPI_QKV>(s, a);
+        }
+        launch_attention(g, s, g->q, g->k, g->v, 0);
+        {
+            LinearArgs a = lin(g, g->msg, D, nullptr, 0, D, D, l.wo, l.bo, D);
+            a.out = g->msg2; a.ldo = D;
+            launch_linear<64, 64, 1, 1, EPI_PLAIN>(s, a);
+        }
+        launch_ffn(g, s, g->msg2, l.w1, l.b1, l.lnw, l.lnb, l.w2, l.b2);
+        // ---- cross block
+        {
+            LinearArgs a = lin(g, g->x, D, nullptr, 0, D, D, l.cqkv, l.cbqkv, 2 * D);
+            a.q = g->q; a.v = g->v;
+            launch_linear<64, 128, 1, 2, EPI_CROSSQKV>(s, a);
+        }
+        launch_attention(g, s, g->q, g->q, g->v, 1);
+        {
+            LinearArgs a = lin(g, g->msg, D, nullptr, 0, D, D, l.cwo, l.cbo, D);
+            a.out = g->msg2; a.ldo = D;
+            launch_linear<64, 64, 1, 1, EPI_PLAIN>(s, a);
+        }
+        launch_ffn(g, s, g->msg2, l.cw1, l.cb1, l.clnw, l.clnb, l.cw2, l.cb2);
+        if (i == NL - 1) break;
+        // ---- early stop + point pruning (lightglue.py check_if_stop / get_pruning_mask)
+        const int do_stop = g->depth_conf > 0.0f;
+        const int do_prune = g->width_conf > 0.0f;
+        if (!do_stop && !do_prune) continue;
+        const float thr = conf_threshold(i);
+        hipLaunchKernelGGL(lg_token_heads_kernel, dim3(tokblocks), dim3(256), 0, s, g->x,
+                           do_stop ? g->tc_w[i] : nullptr, do_stop ? g->tc_b[i] : nullptr,
+                           g->mt_w + (size_t)i * g->mt_stride, g->mt_b + (size_t)i * g->mt_stride, 0L, 0,
+                           thr, g->conf, g->mat, g->ctrl, Kc, do_stop);
+        hipLaunchKernelGGL(lg_decide_kernel, dim3(1), dim3(1024), 0, s, i, thr, g->depth_conf,
+                           g->width_conf, g->prune_min, do_stop, g->conf, g->mat, g->ind, g->gmap,
+                           g->prune, g->ctrl, Kc);
+        if (do_prune) {
+            hipLaunchKernelGGL(lg_gather_kernel, dim3(tokblocks), dim3(256), 0, s, g->x, g->enc_cos,
+                               g->enc_sin, g->gmap, g->tx, g->tc, g->ts, g->ctrl, Kc, 0);
+            hipLaunchKernelGGL(lg_gather_kernel, dim3(tokblocks), dim3(256), 0, s, g->x, g->enc_cos,
+                               g->enc_sin, g->gmap, g->tx, g->tc, g->ts, g->ctrl, Kc, 1);
+        }
+    }
+    // ---- assignment with log_assignment[stop_layer]
+    {
+        LinearArgs a = lin(g, g->x, D, nullptr, 0, D, D, g->fp_w, g->fp_b, D);
+        a.by_stop_layer = 1; a.w_layer_stride = g->fp_stride; a.b_layer_stride = g->fp_stride;
+        a.ignore_stop = 1; a.out = g->md; a.ldo = D;
+        a.out_scale = 0.25f;                    // 1 / 256^0.25
+        launch_linear<64, 64, 1, 1, EPI_PLAIN>(s, a);
+    }
+    hipLaunchKernelGGL(lg_token_heads_kernel, dim3(tokblocks), dim3(256), 0, s, g->x, nullptr, nullptr,
+                       g->mt_w, g->mt_b, g->mt_stride, 1, 0.0f, g->conf, g->mat, g->ctrl, Kc, 0);
+    {
+        SimArgs a{g->md, g->sim, Kc, g->ctrl};
+        dim3 grid(sslam::cdiv(Kc, 128), sslam::cdiv(Kc, 64));
+        hipLaunchKernelGGL((lg_sim_kernel<64, 128, 1, 2>), grid, dim3(256), 0, s, a);
+    }
+    hipLaunchKernelGGL(lg_row_stats_kernel, dim3(sslam::cdiv(Kc, 4)), dim3(256), 0, s, g->sim, g->rmax,
+                       g->rlog, Kc, g->ctrl);
+    hipLaunchKernelGGL(lg_col_stats_kernel, dim3(sslam::cdiv(Kc, 64), CSLAB), dim3(256), 0, s, g->sim,
+                       g->cpmax, g->cpsum, Kc, g->ctrl);
+    hipLaunchKernelGGL(lg_col_stats_merge_kernel, dim3(sslam::cdiv(Kc, 256)), dim3(256), 0, s, g->cpmax,
+                       g->cpsum, g->cmax, g->clog, Kc, g->ctrl);
+    hipLaunchKernelGGL(lg_row_argmax_kernel, dim3(sslam::cdiv(Kc, 4)), dim3(256), 0, s, g->sim, g->rmax,
+                       g->rlog, g->cmax, g->clog, g->mat, g->best0, g->arg0, Kc, g->ctrl);
+    hipLaunchKernelGGL(lg_col_argmax_kernel, dim3(sslam::cdiv(Kc, 64), CSLAB), dim3(256), 0, s, g->sim,
+                       g->rmax, g->rlog, g->cmax, g->clog, g->mat, g->cpval, g->cparg, Kc, g->ctrl);
+    hipLaunchKernelGGL(lg_emit_kernel, dim3(1), dim3(1024), 0, s, g->best0, g->arg0, g->cpval, g->cparg, g->ind,
+                       g->filter_thr, min_conf, ij_out, score_out, info_out, g->ctrl, Kc);
+    SSLAM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sslam_lightglue_create(sslam_ctx* ctx, const float* weights, size_t n_floats, int max_kpts,
+                           sslam_lightglue** out) {
+    SSLAM_REQUIRE(ctx && weights && out, "sslam_lightglue_create: NULL argument");
+    SSLAM_REQUIRE(max_kpts >= 1 && max_kpts <= 8192, "sslam_lightglue_create: max_kpts %d not in [1, 8192]",
+                  max_kpts);
+    SSLAM_HIP_CHECK(hipSetDevice(ctx->device));
+    sslam_lightglue* g = new sslam_lightglue();
+    g->ctx = ctx;
+    const int Kc = (max_kpts + 127) / 128 * 128;     // whole attention / GEMM row blocks
+    g->Kc = Kc;
+    g->KS = Kc >= 1024 ? 4 : (Kc >= 512 ? 2 : 1);
+    const size_t K = (size_t)Kc;
+    auto carve = [&](sslam::Arena& A) {
+        g->blob = A.take<float>(n_floats);
+        g->ctrl = A.take<LGCtrl>(1);
+        g->x = A.take<float>(2 * K * D); g->msg = A.take<float>(2 * K * D); g->msg2 = A.take<float>(2 * K * D);
+        g->tx = A.take<float>(2 * K * D); g->md = A.take<float>(2 * K * D);
+        g->hid = A.take<float>(2 * K * 2 * D);
+        g->q = A.take<float>(2 * K * D); g->k = A.take<float>(2 * K * D); g->v = A.take<float>(2 * K * D);
+        g->enc_cos = A.take<float>(2 * K * ENC); g->enc_sin = A.take<float>(2 * K * ENC);
+        g->tc = A.take<float>(2 * K * ENC); g->ts = A.take<float>(2 * K * ENC);
+        g->o_part = A.take<float>((size_t)g->KS * 2 * NH * K * DH);
+        g->m_part = A.take<float>((size_t)g->KS * 2 * NH * K);
+        g->l_part = A.take<float>((size_t)g->KS * 2 * NH * K);
+        g->conf = A.take<float>(2 * K); g->mat = A.take<float>(2 * K);
+        g->sim = A.take<float>(K * K);
+        g->rmax = A.take<float>(K); g->rlog = A.take<float>(K); g->cmax = A.take<float>(K);
+        g->clog = A.take<float>(K); g->best0 = A.take<float>(K);
+        g->ind = A.take<int>(2 * K); g->gmap = A.take<int>(2 * K); g->prune = A.take<int>(2 * K);
+        g->arg0 = A.take<int>(K); g->arg1 = A.take<int>(K);
+        g->cpmax = A.take<float>(CSLAB * K); g->cpsum = A.take<float>(CSLAB * K);
+        g->cpval = A.take<float>(CSLAB * K); g->cparg = A.take<int>(CSLAB * K);
+        g->in_xy = A.take<float>(2 * K * 2); g->in_desc = A.take<float>(2 * K * DIN);
+        g->out_ij = A.take<int32_t>(2 * K); g->out_score = A.take<float>(K); g->out_info = A.take<int32_t>(8);
+    };
+    sslam::Arena probe;
+    probe.measure();
+    carve(probe);
+    if (g->arena.init(probe.off + 256)) { delete g; return 1; }
+    carve(g->arena);
+    SSLAM_REQUIRE(g->out_info != nullptr, "sslam_lightglue_create: workspace arena exhausted");
+    SSLAM_HIP_CHECK(hipMemcpy(g->blob, weights, n_floats * 4, hipMemcpyHostToDevice));
+    if (int rc = lg_bind_weights(g, n_floats)) { g->arena.release(); delete g; return rc; }
+    *out = g;
+    return 0;
+}
+
+int sslam_lightglue_destroy(sslam_lightglue* g) {
+    if (!g) return 0;
+    (void)hipStreamSynchronize(g->ctx->stream);
+    g->arena.release();
+    delete g;
+    return 0;
+}
+
+int sslam_lightglue_set_conf(sslam_lightglue* g, float depth_confidence, float width_confidence,
+                             float filter_threshold, int prune_min_kpts) {
+    SSLAM_REQUIRE(g != nullptr, "sslam_lightglue_set_conf: NULL instance");
+    g->depth_conf = depth_confidence; g->width_conf = width_confidence;
+    g->filter_thr = filter_threshold; g->prune_min = prune_min_kpts;
+    return 0;
+}
+
+int sslam_lightglue_match_dev(sslam_lightglue* g, const float* xy0, const float* desc0, int M,
+                              const float* xy1, const float* desc1, int N, float min_conf,
+                              int32_t* ij_out, float* score_out, int32_t* info_out) {
+    SSLAM_REQUIRE(g && ij_out && score_out && info_out, "sslam_lightglue_match_dev: NULL argument");
+    SSLAM_REQUIRE(M >= 0 && N >= 0 && M <= g->Kc && N <= g->Kc,
+                  "sslam_lightglue_match_dev: M=%d N=%d exceed max_kpts capacity %d", M, N, g->Kc);
+    SSLAM_REQUIRE((M == 0 || (xy0 && desc0)) && (N == 0 || (xy1 && desc1)),
+                  "sslam_lightglue_match_dev: NULL input");
+    hipStream_t s = g->ctx->stream;
+    const size_t K = (size_t)g->Kc;
+    if (M) {
+        SSLAM_HIP_CHECK(hipMemcpyAsync(g->in_xy, xy0, (size_t)M * 8, hipMemcpyDeviceToDevice, s));
+        SSLAM_HIP_CHECK(hipMemcpyAsync(g->in_desc, desc0, (size_t)M * DIN * 4, hipMemcpyDeviceToDevice, s));
+    }
+    if (N) {
+        SSLAM_HIP_CHECK(hipMemcpyAsync(g->in_xy + 2 * K, xy1, (size_t)N * 8, hipMemcpyDeviceToDevice, s));
+        SSLAM_HIP_CHECK(hipMemcpyAsync(g->in_desc + K * DIN, desc1, (size_t)N * DIN * 4, hipMemcpyDeviceToDevice, s));
+    }
+    return lg_enqueue(g, M, N, min_conf, ij_out, score_out, info_out);
+}
+
+int sslam_lightglue_match_host(sslam_lightglue* g, const float* xy0, const float* desc0, int M,
+                               const float* xy1, const float* desc1, int N, float min_conf,
+                               int32_t* ij_out, float* score_out, int32_t* k_out,
+                               int32_t* stop_layer_out) {
+    SSLAM_REQUIRE(g && ij_out && score_out && k_out, "sslam_lightglue_match_host: NULL argument");
+    SSLAM_REQUIRE(M >= 0 && N >= 0 && M <= g->Kc && N <= g->Kc,
+                  "sslam_lightglue_match_host: M=%d N=%d exceed max_kpts capacity %d", M, N, g->Kc);
+    *k_out = 0;
+    if (stop_layer_out) *stop_layer_out = 0;
+    if (M == 0 || N == 0) return 0;            // features_utils.py:118-124 -> []
+    SSLAM_REQUIRE(xy0 && desc0 && xy1 && desc1, "sslam_lightglue_match_host: NULL input");
+    SSLAM_HIP_CHECK(hipSetDevice(g->ctx->device));
+    hipStream_t s = g->ctx->stream;
+    const size_t K = (size_t)g->Kc;
+    SSLAM_HIP_CHECK(hipMemcpyAsync(g->in_xy, xy0, (size_t)M * 8, hipMemcpyHostToDevice, s));
+    SSLAM_HIP_CHECK(hipMemcpyAsync(g->in_desc, desc0, (size_t)M * DIN * 4, hipMemcpyHostToDevice, s));
+    SSLAM_HIP_CHECK(hipMemcpyAsync(g->in_xy + 2 * K, xy1, (size_t)N * 8, hipMemcpyHostToDevice, s));
+    SSLAM_HIP_CHECK(hipMemcpyAsync(g->in_desc + K * DIN, desc1, (size_t)N * DIN * 4, hipMemcpyHostToDevice, s));
+    if (int rc = lg_enqueue(g, M, N, min_conf, g->out_ij, g->out_score, g->out_info)) return rc;
+    int32_t info[4];
+    SSLAM_HIP_CHECK(hipMemcpyAsync(info, g->out_info, sizeof(info), hipMemcpyDeviceToHost, s));
+    SSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    const int Kn = info[0];
+    SSLAM_REQUIRE(Kn >= 0 && Kn <= (M < N ? M : N), "sslam_lightglue_match_host: corrupt match count %d", Kn);
+    if (Kn) {
+        SSLAM_HIP_CHECK(hipMemcpyAsync(ij_out, g->out_ij, (size_t)Kn * 8, hipMemcpyDeviceToHost, s));
+        SSLAM_HIP_CHECK(hipMemcpyAsync(score_out, g->out_score, (size_t)Kn * 4, hipMemcpyDeviceToHost, s));
+        SSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    *k_out = Kn;
+    if (stop_layer_out) *stop_layer_out = info[1];
+    return 0;
+}
+
+/* Test hook: copy an internal buffer to the host after a match call.
+ * which: 0 = x (token states) [2][Kc][256], 1 = sim [Kc][Kc], 2 = ind [2][Kc] (int32),
+ *        3 = prune counters [2][Kc] (int32), 4 = info {K, stop, n0, n1}, 5 = enc_cos [2][Kc][32] */
+int sslam_lightglue_debug_read(sslam_lightglue* g, int which, void* dst, size_t bytes) {
+    SSLAM_REQUIRE(g && dst, "sslam_lightglue_debug_read: NULL argument");
+    const size_t K = (size_t)g->Kc;
+    const void* src = nullptr; size_t cap = 0;
+    switch (which) {
+        case 0: src = g->x; cap = 2 * K * D * 4; break;
+        case 1: src = g->sim; cap = K * K * 4; break;
+        case 2: src = g->ind; cap = 2 * K * 4; break;
+        case 3: src = g->prune; cap = 2 * K * 4; break;
+        case 4: src = g->out_info; cap = 16; break;
+        case 5: src = g->enc_cos; cap = 2 * K * ENC * 4; break;
+        default: SSLAM_REQUIRE(false, "sslam_lightglue_debug_read: unknown buffer %d", which);
+    }
+    SSLAM_REQUIRE(bytes <= cap, "sslam_lightglue_debug_read: %zu bytes requested, buffer has %zu", bytes, cap);
+    SSLAM_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    SSLAM_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int sslam_lightglue_capacity(sslam_lightglue* g, int* kc_out) {
+    SSLAM_REQUIRE(g && kc_out, "sslam_lightglue_capacity: NULL argument");
+    *kc_out = g->Kc;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,88 @@
+"""LightGlue(features='aliked') matcher instance on the HIP backend.
+
+Stands in for the `lightglue.LightGlue` nn.Module the reference builds at
+slam/core/features_utils.py:26; `match()` is `matcher({...})` + `rbd` + the
+`scores > min_conf` filter of features_utils.py:157-169.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native, weights as W
+
+
+class LightGlueHIP:
+    default_conf = dict(depth_confidence=0.95, width_confidence=0.99, filter_threshold=0.1,
+                        prune_min_kpts=-1)
+
+    def __init__(self, state_dict=None, max_kpts: int = 4096, ctx=None, **conf):
+        self.ctx = ctx or _native.default_context()
+        self.state_dict = state_dict if state_dict is not None else W.random_lightglue_state_dict(0)
+        blob = W.pack_lightglue(self.state_dict)
+        h = C.c_void_p()
+        _native.check(_native.lib().sslam_lightglue_create(
+            self.ctx.handle, _native.ptr(blob), blob.size, int(max_kpts), C.byref(h)),
+            "sslam_lightglue_create")
+        self.handle = h
+        kc = C.c_int()
+        _native.check(_native.lib().sslam_lightglue_capacity(h, C.byref(kc)))
+        self.capacity = int(kc.value)
+        self.max_kpts = int(max_kpts)
+        self.conf = dict(self.default_conf)
+        self.set_conf(**conf)
+
+    def set_conf(self, **conf):
+        self.conf.update(conf)
+        c = self.conf
+        _native.check(_native.lib().sslam_lightglue_set_conf(
+            self.handle, float(c["depth_confidence"]), float(c["width_confidence"]),
+            float(c["filter_threshold"]), int(c["prune_min_kpts"])), "sslam_lightglue_set_conf")
+
+    def parameters(self):          # the reference probes `next(matcher.parameters()).device`
+        return iter(())
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _native.lib().sslam_lightglue_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def match(self, xy0, desc0, xy1, desc1, min_conf: float = 0.7):
+        """Host arrays in, host arrays out: (matches [K,2] int32, scores [K], stop_layer)."""
+        xy0 = np.ascontiguousarray(xy0, np.float32).reshape(-1, 2)
+        xy1 = np.ascontiguousarray(xy1, np.float32).reshape(-1, 2)
+        M, N = len(xy0), len(xy1)
+        if M == 0 or N == 0:
+            return np.zeros((0, 2), np.int32), np.zeros((0,), np.float32), 0
+        desc0 = np.ascontiguousarray(desc0, np.float32).reshape(M, -1)
+        desc1 = np.ascontiguousarray(desc1, np.float32).reshape(N, -1)
+        if desc0.shape[1] != 128 or desc1.shape[1] != 128:
+            raise ValueError("LightGlue(features='aliked') expects 128-d descriptors")
+        kmax = max(1, min(M, N))
+        ij = np.empty((kmax, 2), np.int32)
+        sc = np.empty((kmax,), np.float32)
+        k, stop = C.c_int(0), C.c_int(0)
+        P = _native.ptr
+        _native.check(_native.lib().sslam_lightglue_match_host(
+            self.handle, P(xy0), P(desc0), M, P(xy1), P(desc1), N, float(min_conf), P(ij), P(sc),
+            C.byref(k), C.byref(stop)), "sslam_lightglue_match_host")
+        return ij[:k.value].copy(), sc[:k.value].copy(), int(stop.value)
+
+    def match_dev(self, xy0, desc0, M, xy1, desc1, N, ij_out, score_out, info_out, min_conf=0.7):
+        """Device pointers (ints or torch tensors); enqueues only, no sync."""
+        P = _native.ptr
+        _native.check(_native.lib().sslam_lightglue_match_dev(
+            self.handle, P(xy0), P(desc0), int(M), P(xy1), P(desc1), int(N), float(min_conf),
+            P(ij_out), P(score_out), P(info_out)), "sslam_lightglue_match_dev")
+
+    def debug_read(self, which: int, shape, dtype=np.float32):
+        out = np.empty(shape, dtype)
+        _native.check(_native.lib().sslam_lightglue_debug_read(self.handle, which, _native.ptr(out), out.nbytes))
+        return out

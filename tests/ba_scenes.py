@@ -96,7 +96,7 @@ def reference_test_scene(n_frames, n_points=50, add_noise=True, pix_noise=5.0,
 
 
 def scaled_scene(n_kf=15, n_points=5000, seed=42, pix_noise=1.0, point_noise=0.05,
-                 rot_noise_deg=0.5, trans_noise=0.05):
+                 rot_noise_deg=0.5, trans_noise=0.05, n_fixed_clean=5):
     rng = np.random.default_rng(seed)
     K = K_KITTI
     poses_gt = []
@@ -104,11 +104,12 @@ def scaled_scene(n_kf=15, n_points=5000, seed=42, pix_noise=1.0, point_noise=0.0
         T = np.eye(4); T[:3, :3] = _yaw(i * 1.0); T[:3, 3] = [0.02 * i, 0, 0.8 * i]
         poses_gt.append(_inv(T))            # T_cw
     wmap = WorldMap(); kfs = []
-    for T_cw in poses_gt:
+    for i, T_cw in enumerate(poses_gt):
         axis = rng.normal(size=3); axis /= np.linalg.norm(axis)
         Tn = T_cw.copy()
-        Tn[:3, :3] = _rodrigues(axis * math.radians(rot_noise_deg) * rng.normal()) @ T_cw[:3, :3]
-        Tn[:3, 3] += rng.normal(0, trans_noise, 3)
+        amp = 0.0 if i < n_fixed_clean else 1.0      # gauge keyframes: already converged
+        Tn[:3, :3] = _rodrigues(axis * math.radians(rot_noise_deg) * rng.normal() * amp) @ T_cw[:3, :3]
+        Tn[:3, 3] += rng.normal(0, trans_noise, 3) * amp
         wmap.poses.append(Tn); kfs.append(types.SimpleNamespace(pose=Tn.copy(), kps=[]))
     for pid in range(n_points):
         first = int(rng.integers(0, n_kf - 1))

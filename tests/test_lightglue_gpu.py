@@ -1,0 +1,118 @@
+"""GPU parity: HIP LightGlue vs the torch-CPU oracle, through the C-ABI.
+
+Bar (BASELINE.json north_star): match-index arrays identical to the oracle's;
+floating-point intermediates (token states, similarity, scores) within 1e-3."""
+import numpy as np
+import pytest
+
+import lg_inputs
+from conftest import load_pkg
+from oracle import lightglue_ref as R
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def W():
+    return load_pkg("weights")
+
+
+@pytest.fixture(scope="module")
+def LG():
+    return load_pkg("lightglue").LightGlueHIP
+
+
+def _compare(lg, sd, k0, d0, k1, d1, min_conf, conf=None, check_state=True):
+    ij, sc, stop = lg.match(k0, d0, k1, d1, min_conf=min_conf)
+    ref = R.lightglue_forward(sd, k0, d0, k1, d1, conf, return_debug=True)
+    keep = ref["scores"] > min_conf
+    ref_ij = ref["matches"][keep].numpy()
+    ref_sc = ref["scores"][keep].numpy()
+    assert stop == ref["stop"]
+    np.testing.assert_array_equal(ij, ref_ij)            # bit-exact indices
+    np.testing.assert_allclose(sc, ref_sc, atol=TOL, rtol=TOL)
+    assert np.all(np.diff(ij[:, 0]) > 0) if len(ij) > 1 else True
+    if check_state and "x_out0" in ref["debug"]:
+        Kc = lg.capacity
+        x = lg.debug_read(0, (2, Kc, 256))
+        n0, n1 = ref["debug"]["x_out0"].shape[0], ref["debug"]["x_out1"].shape[0]
+        info = lg.debug_read(4, (4,), np.int32)
+        assert (info[2], info[3]) == (n0, n1)
+        np.testing.assert_allclose(x[0, :n0], ref["debug"]["x_out0"].numpy(), atol=TOL, rtol=TOL)
+        np.testing.assert_allclose(x[1, :n1], ref["debug"]["x_out1"].numpy(), atol=TOL, rtol=TOL)
+        sim = lg.debug_read(1, (Kc, Kc))[:n0, :n1]
+        np.testing.assert_allclose(sim, ref["debug"]["sim"].numpy(), atol=TOL, rtol=TOL)
+    return ij, ref
+
+
+@pytest.mark.parametrize("m,n", [(512, 512), (300, 417), (64, 33), (1, 5), (129, 128)])
+def test_matches_bit_exact_vs_oracle(W, LG, m, n):
+    sd = W.random_lightglue_state_dict(1, match_gain=4.0, match_bias=3.0)
+    lg = LG(sd, max_kpts=640)
+    k0, d0, k1, d1 = lg_inputs.make_pair(m, n, seed=m + n)
+    ij, ref = _compare(lg, sd, k0, d0, k1, d1, min_conf=0.7)
+    if min(m, n) >= 64:
+        assert len(ij) > 0.2 * min(m, n)       # the test is not vacuous
+    # min_conf = 0 keeps everything above LightGlue's own 0.1 filter
+    _compare(lg, sd, k0, d0, k1, d1, min_conf=0.0, check_state=False)
+    lg.close()
+
+
+def test_c2_size_2048(W, LG):
+    """BASELINE config C2: 2048 keypoints per image, all 9 layers."""
+    sd = W.random_lightglue_state_dict(2, match_gain=4.0, match_bias=3.0)
+    lg = LG(sd, max_kpts=2048)
+    k0, d0, k1, d1 = lg_inputs.make_pair(2048, seed=11)
+    ij, ref = _compare(lg, sd, k0, d0, k1, d1, min_conf=0.7)
+    assert ref["stop"] == 9 and len(ij) > 100
+    lg.close()
+
+
+def test_early_stop_layer_is_respected(W, LG):
+    # confident tokens everywhere -> upstream stops after the first layer (stop == 1)
+    sd = W.random_lightglue_state_dict(3, match_gain=4.0, match_bias=3.0, conf_bias=12.0)
+    lg = LG(sd, max_kpts=512)
+    k0, d0, k1, d1 = lg_inputs.make_pair(384, seed=5)
+    ij, ref = _compare(lg, sd, k0, d0, k1, d1, min_conf=0.3)
+    assert ref["stop"] == 1
+    lg.close()
+
+
+def test_point_pruning_matches_oracle(W, LG):
+    # matchability logits centred below the 0.01 keep threshold and confident tokens just
+    # under the stop ratio -> some points are pruned after each layer
+    sd = W.random_lightglue_state_dict(4, match_gain=4.0, match_bias=-4.6, conf_bias=2.3)
+    lg = LG(sd, max_kpts=512)
+    k0, d0, k1, d1 = lg_inputs.make_pair(400, 350, seed=6)
+    ij, ref = _compare(lg, sd, k0, d0, k1, d1, min_conf=0.0)
+    n0, n1 = ref["debug"]["x_out0"].shape[0], ref["debug"]["x_out1"].shape[0]
+    assert (n0 < 400 or n1 < 350), "pruning did not trigger in the oracle - test is vacuous"
+    Kc = lg.capacity
+    ind = lg.debug_read(2, (2, Kc), np.int32)
+    np.testing.assert_array_equal(ind[0, :n0], ref["debug"]["ind0"].numpy())
+    np.testing.assert_array_equal(ind[1, :n1], ref["debug"]["ind1"].numpy())
+    pr = lg.debug_read(3, (2, Kc), np.int32)
+    np.testing.assert_array_equal(pr[0, :400], ref["prune0"].numpy())
+    np.testing.assert_array_equal(pr[1, :350], ref["prune1"].numpy())
+    lg.close()
+
+
+def test_pruning_switch_off(W, LG):
+    sd = W.random_lightglue_state_dict(4, match_gain=4.0, match_bias=-4.6, conf_bias=2.3)
+    lg = LG(sd, max_kpts=512, prune_min_kpts=100000)
+    k0, d0, k1, d1 = lg_inputs.make_pair(256, seed=7)
+    _compare(lg, sd, k0, d0, k1, d1, min_conf=0.0, conf={"prune_min_kpts": 100000})
+    lg.close()
+
+
+def test_empty_inputs_and_capacity_errors(W, LG, native):
+    lg = LG(W.random_lightglue_state_dict(0), max_kpts=128)
+    k0, d0, k1, d1 = lg_inputs.make_pair(16, seed=1)
+    ij, sc, stop = lg.match(k0[:0], d0[:0], k1, d1)
+    assert ij.shape == (0, 2) and sc.shape == (0,)
+    big = lg_inputs.make_pair(300, seed=2)
+    with pytest.raises(native.NativeError, match="exceed"):
+        lg.match(*big)
+    lg.close()
