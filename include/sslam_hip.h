@@ -78,6 +78,28 @@ int sslam_ba_residual_jacobian_dev(sslam_ctx* ctx, int n_obs,
                                    const double* intr, double* r, double* Jq,
                                    double* Jt, double* JX);
 
+/* ------------------------------------------------------------------ ALIKED
+ * Replaces `ALIKED(max_num_keypoints=...).eval().to(device)` at
+ * slam/core/features_utils.py:25 and `_bgr_to_tensor` + `detector.extract` +
+ * `rbd` + descriptor re-normalisation at features_utils.py:92-100, :219-222.
+ * `weights` = blob from opencv-simpleslam_amd/weights.py::pack_aliked.
+ * max_h/max_w bound the input image, max_kpts the keypoints per call. */
+int sslam_aliked_create(sslam_ctx* ctx, const float* weights, size_t n_floats, int max_h, int max_w,
+                        int max_kpts, sslam_aliked** out);
+int sslam_aliked_destroy(sslam_aliked* al);
+/* img: uint8 HWC, C = 3 (BGR as cv2.imread gives), 1 (gray) or 4 (BGRA).
+ * xy_out[2*max_kpts] (x, y) in input-image pixels, desc_out[128*max_kpts]
+ * unit-norm rows, score_out[max_kpts] (may be NULL), n_out = keypoints found
+ * (<= max_kpts; threshold mode, ordered as upstream: raster order, or by
+ * descending score when more than max_kpts pass the detection threshold). */
+int sslam_aliked_extract_host(sslam_aliked* al, const uint8_t* img, int H, int W, int C, int max_kpts,
+                              float* xy_out, float* desc_out, float* score_out, int32_t* n_out);
+/* Device-pointer variant (all pointers device, n_out[1] device int32); enqueue only. */
+int sslam_aliked_extract_dev(sslam_aliked* al, const uint8_t* img, int H, int W, int C, int max_kpts,
+                             float* xy_out, float* desc_out, float* score_out, int32_t* n_out);
+/* Test hook: copy an internal buffer to the host (see aliked_kernels.hip). */
+int sslam_aliked_debug_read(sslam_aliked* al, int which, void* dst, size_t bytes);
+
 /* ------------------------------------------------------------------ LightGlue
  * Replaces `LightGlue(features='aliked').eval().to(device)` at
  * slam/core/features_utils.py:26 and the forward + confidence filter at

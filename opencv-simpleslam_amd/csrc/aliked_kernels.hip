@@ -1,0 +1,1134 @@
+// aliked_kernels.hip - ALIKED-n16 keypoint + descriptor extraction on gfx950.
+//
+// Replaces `detector.extract(_bgr_to_tensor(img))` + rbd + the descriptor
+// re-normalisation at slam/core/features_utils.py:92-100 (the cvg/LightGlue
+// `ALIKED` module: image preprocessor, conv encoder with two deformable stages,
+// feature aggregation, score head, DKD keypoint detection, SDDH descriptors).
+//
+// Numeric type fp32.  Roofline of the dense part: HBM (small-channel 3x3 convs);
+// the 128-channel, 162 MB normalised feature map of the reference is NEVER
+// materialised: the score head consumes it on the fly, and the descriptor head
+// rebuilds the 128-vector only at the <= 73 pixels per keypoint it reads.
+//
+// HBM layout (planar CHW, padded network size Hp x Wp = multiple of 32):
+//   img   [3][Hp][Wp]   preprocessed RGB        x1 [16][Hp][Wp]
+//   x2 [32][Hp/2][Wp/2]  x3 [64][Hp/8][Wp/8]    x4 [128][Hp/32][Wp/32]
+//   g2,g3,g4 [32][..]    gated 1x1 projections of x2..x4 (x1's is recomputed)
+//   s8 [8][Hp][Wp]       first score-head layer  rnorm [Hp][Wp] 1/||F||
+//   score [h][w]         un-padded score map     nms [h][w]
+#include "common.hpp"
+#include "gemm_f32.hpp"
+
+namespace {
+
+using sslam::f32x16;
+using sslam::acc_row;
+using sslam::GemmSmem;
+using sslam::GemmA;
+using sslam::gemm_mainloop;
+
+constexpr float SELU_SCALE = 1.0507009873554804934193349852946f;
+constexpr float SELU_ALPHA = 1.6732632423543772848170429916717f;
+__device__ __forceinline__ float selu(float x) {
+    return SELU_SCALE * (x > 0.0f ? x : SELU_ALPHA * expm1f(x));
+}
+
+struct ALCtrl {
+    int n_cand;       // candidates above threshold
+    int n_kp;         // keypoints emitted
+    int overflow;     // candidate buffer overflow flag
+    int need_fallback;  // no pixel above detection_threshold -> threshold = mean(score map)
+    int pad[12];
+};
+
+struct Dims {
+    int H, W, C;          // input image
+    int h, w;             // resized
+    int Hp, Wp;           // padded (multiple of 32)
+    int pl, pt;           // left / top padding
+};
+
+// ------------------------------------------------------------------------ //
+//  0. pre-processing: u8 HWC (BGR | gray | BGRA) -> RGB/255 -> [blur] -> resize -> pad
+// ------------------------------------------------------------------------ //
+__global__ void al_to_float_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, Dims d,
+                                   const float* __restrict__ gx, int kx, int blur) {
+    // dst [3][H][W] = horizontally blurred RGB/255 (reflect border), or plain RGB/255
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= d.W) return;
+    for (int c = 0; c < 3; ++c) {
+        const int sc = d.C == 1 ? 0 : 2 - c;                      // BGR -> RGB
+        float v;
+        if (!blur) {
+            v = (float)src[((size_t)y * d.W + x) * d.C + sc] / 255.0f;
+        } else {
+            v = 0.0f;
+            const int r = kx / 2;
+            for (int k = 0; k < kx; ++k) {
+                int xx = x + k - r;
+                xx = xx < 0 ? -xx : (xx >= d.W ? 2 * d.W - 2 - xx : xx);       // reflect
+                v += gx[k] * ((float)src[((size_t)y * d.W + xx) * d.C + sc] / 255.0f);
+            }
+        }
+        dst[((size_t)c * d.H + y) * d.W + x] = v;
+    }
+}
+
+__global__ void al_resize_pad_kernel(const float* __restrict__ src, float* __restrict__ img, Dims d,
+                                     const float* __restrict__ gy, int ky, int blur) {
+    // img [3][Hp][Wp]: replicate-padded bilinear (align_corners=False) resize of (vertically blurred) src
+    const int xp = blockIdx.x * blockDim.x + threadIdx.x, yp = blockIdx.y;
+    if (xp >= d.Wp) return;
+    const int y = min(max(yp - d.pt, 0), d.h - 1), x = min(max(xp - d.pl, 0), d.w - 1);
+    const float sy_ = (float)d.H / (float)d.h, sx_ = (float)d.W / (float)d.w;
+    float fy = sy_ * ((float)y + 0.5f) - 0.5f, fx = sx_ * ((float)x + 0.5f) - 0.5f;
+    fy = fy < 0.0f ? 0.0f : fy;
+    fx = fx < 0.0f ? 0.0f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < d.H - 1), x1 = x0 + (x0 < d.W - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
+    for (int c = 0; c < 3; ++c) {
+        const float* p = src + (size_t)c * d.H * d.W;
+        float v00, v01, v10, v11;
+        if (!blur) {
+            v00 = p[(size_t)y0 * d.W + x0]; v01 = p[(size_t)y0 * d.W + x1];
+            v10 = p[(size_t)y1 * d.W + x0]; v11 = p[(size_t)y1 * d.W + x1];
+        } else {
+            v00 = v01 = v10 = v11 = 0.0f;
+            const int r = ky / 2;
+            for (int k = 0; k < ky; ++k) {
+                int ya = y0 + k - r, yb = y1 + k - r;
+                ya = ya < 0 ? -ya : (ya >= d.H ? 2 * d.H - 2 - ya : ya);
+                yb = yb < 0 ? -yb : (yb >= d.H ? 2 * d.H - 2 - yb : yb);
+                const float g = gy[k];
+                v00 += g * p[(size_t)ya * d.W + x0]; v01 += g * p[(size_t)ya * d.W + x1];
+                v10 += g * p[(size_t)yb * d.W + x0]; v11 += g * p[(size_t)yb * d.W + x1];
+            }
+        }
+        img[((size_t)c * d.Hp + yp) * d.Wp + xp] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+    }
+}
+
+// ------------------------------------------------------------------------ //
+//  1. dense 3x3 conv (zero pad) + BN affine (+ residual) + SELU, planar CHW.
+//     Block = 32x8 output pixels, one pixel per thread, COUT accumulators in
+//     registers; the input tile (+halo, optionally POOLxPOOL average-pooled
+//     while loading) sits in LDS; weights [ci][tap][co] are wave-uniform
+//     scalar loads.  DOWN additionally emits the ResBlock's 1x1 "downsample"
+//     branch of the (pooled) input.
+// ------------------------------------------------------------------------ //
+constexpr int CT_W = 32, CT_H = 8;
+
+template <int CIN, int COUT, int POOL, bool DOWN, bool RESID>
+__global__ __launch_bounds__(256) void al_conv3x3_kernel(
+    const float* __restrict__ in, int inH, int inW,         // source map (before pooling)
+    float* __restrict__ out, int H, int W,                  // output map (= pooled size)
+    const float* __restrict__ w, const float* __restrict__ alpha, const float* __restrict__ beta,
+    const float* __restrict__ wd, const float* __restrict__ bd, float* __restrict__ idn,
+    const float* __restrict__ resid) {
+    __shared__ float tile[CIN][CT_H + 2][CT_W + 2];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CT_H;
+    for (int i = threadIdx.x; i < CIN * (CT_H + 2) * (CT_W + 2); i += 256) {
+        const int c = i / ((CT_H + 2) * (CT_W + 2)), rem = i % ((CT_H + 2) * (CT_W + 2));
+        const int yy = y0 + rem / (CT_W + 2) - 1, xx = x0 + rem % (CT_W + 2) - 1;
+        float v = 0.0f;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            if (POOL == 1) {
+                v = in[((size_t)c * inH + yy) * inW + xx];
+            } else {
+                float s = 0.0f;
+                for (int a = 0; a < POOL; ++a)
+                    for (int b = 0; b < POOL; ++b)
+                        s += in[((size_t)c * inH + yy * POOL + a) * inW + xx * POOL + b];
+                v = s / (float)(POOL * POOL);
+            }
+        }
+        (&tile[0][0][0])[i] = v;
+    }
+    __syncthreads();
+    float acc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = 0.0f;
+    for (int ci = 0; ci < CIN; ++ci) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float v = tile[ci][ty + tap / 3][tx + tap % 3];
+            const float* wp = w + (ci * 9 + tap) * COUT;
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) acc[o] = fmaf(v, wp[o], acc[o]);
+        }
+    }
+    const int x = x0 + tx, y = y0 + ty;
+    if (x >= W || y >= H) return;
+    if (DOWN) {
+        float dn[COUT];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) dn[o] = 0.0f;
+        for (int ci = 0; ci < CIN; ++ci) {
+            const float v = tile[ci][ty + 1][tx + 1];
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) dn[o] = fmaf(v, wd[ci * COUT + o], dn[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) idn[((size_t)o * H + y) * W + x] = dn[o] + bd[o];
+    }
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) {
+        float v = fmaf(acc[o], alpha[o], beta[o]);
+        if (RESID) v += resid[((size_t)o * H + y) * W + x];
+        out[((size_t)o * H + y) * W + x] = selu(v);
+    }
+}
+
+// ------------------------------------------------------------------------ //
+//  2. small-map stages (1/8 and 1/32 resolution): pooling, offset conv,
+//     deformable conv (torchvision deform_conv2d semantics) + BN + residual + SELU
+// ------------------------------------------------------------------------ //
+__global__ void al_avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int H, int W,
+                                  int P) {   // out [C][H/P][W/P]
+    const int oh = H / P, ow = W / P;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * oh * ow) return;
+    const int c = i / (oh * ow), y = (i / ow) % oh, x = i % ow;
+    float s = 0.0f;
+    for (int a = 0; a < P; ++a)
+        for (int b = 0; b < P; ++b) s += in[((size_t)c * H + y * P + a) * W + x * P + b];
+    out[i] = s / (float)(P * P);
+}
+
+// offset conv: 3x3, zero pad, bias, clamp to +-max_off; thread = (co, pixel)
+__global__ void al_offset_conv_kernel(const float* __restrict__ in, float* __restrict__ off, int CIN, int H,
+                                      int W, const float* __restrict__ w /*[ci][tap][18]*/,
+                                      const float* __restrict__ b, float max_off) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 18 * H * W) return;
+    const int co = i / (H * W), y = (i / W) % H, x = i % W;
+    float acc = 0.0f;
+    for (int ci = 0; ci < CIN; ++ci)
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+                acc = fmaf(in[((size_t)ci * H + yy) * W + xx], w[(ci * 9 + tap) * 18 + co], acc);
+        }
+    acc += b[co];
+    off[i] = fminf(fmaxf(acc, -max_off), max_off);
+}
+
+__device__ __forceinline__ float dcn_sample(const float* __restrict__ p, int H, int W, float y, float x) {
+    if (y <= -1.0f || y >= (float)H || x <= -1.0f || x >= (float)W) return 0.0f;
+    const float fy = floorf(y), fx = floorf(x);
+    const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
+    const float ly = y - fy, lx = x - fx, hy = 1.0f - ly, hx = 1.0f - lx;
+    const float v1 = (y0 >= 0 && x0 >= 0) ? p[y0 * W + x0] : 0.0f;
+    const float v2 = (y0 >= 0 && x1 <= W - 1) ? p[y0 * W + x1] : 0.0f;
+    const float v3 = (y1 <= H - 1 && x0 >= 0) ? p[y1 * W + x0] : 0.0f;
+    const float v4 = (y1 <= H - 1 && x1 <= W - 1) ? p[y1 * W + x1] : 0.0f;
+    return (hy * hx) * v1 + (hy * lx) * v2 + (ly * hx) * v3 + (ly * lx) * v4;
+}
+
+// block = PIX pixels x COUT threads.  Phase 1: the PIX*CIN*9 bilinear samples go to LDS;
+// phase 2: thread (pixel, co) reduces them against w[ci][tap][co] (coalesced over co).
+template <int CIN, int COUT, bool RESID>
+__global__ __launch_bounds__(256) void al_deform_conv_kernel(
+    const float* __restrict__ in, const float* __restrict__ off, float* __restrict__ out, int H, int W,
+    const float* __restrict__ w, const float* __restrict__ alpha, const float* __restrict__ beta,
+    const float* __restrict__ res_in, int RC, const float* __restrict__ wd, const float* __restrict__ bd) {
+    constexpr int PIX = 256 / COUT;
+    __shared__ float col[PIX][CIN * 9];
+    const int pix0 = blockIdx.x * PIX;
+    for (int i = threadIdx.x; i < PIX * CIN * 9; i += 256) {
+        const int pp = i / (CIN * 9), k = i % (CIN * 9), ci = k / 9, tap = k % 9;
+        const int pix = pix0 + pp;
+        float v = 0.0f;
+        if (pix < H * W) {
+            const int y = pix / W, x = pix % W;
+            const float dy = off[((size_t)(2 * tap) * H + y) * W + x];
+            const float dx = off[((size_t)(2 * tap + 1) * H + y) * W + x];
+            v = dcn_sample(in + (size_t)ci * H * W, H, W, (float)(y - 1 + tap / 3) + dy,
+                           (float)(x - 1 + tap % 3) + dx);
+        }
+        col[pp][k] = v;
+    }
+    __syncthreads();
+    const int pp = threadIdx.x / COUT, co = threadIdx.x % COUT;
+    const int pix = pix0 + pp;
+    if (pix >= H * W) return;
+    float acc = 0.0f;
+    for (int k = 0; k < CIN * 9; ++k) acc = fmaf(col[pp][k], w[k * COUT + co], acc);
+    float v = fmaf(acc, alpha[co], beta[co]);
+    if (RESID) {
+        float dn = 0.0f;
+        for (int ci = 0; ci < RC; ++ci) dn = fmaf(res_in[(size_t)ci * H * W + pix], wd[ci * COUT + co], dn);
+        v += dn + bd[co];
+    }
+    out[(size_t)co * H * W + pix] = selu(v);
+}
+
+// 1x1 conv (no bias) + SELU: thread = (co of 32, pixel)
+__global__ void al_gate_kernel(const float* __restrict__ in, float* __restrict__ out, int CIN, int HW,
+                               const float* __restrict__ w /*[ci][32]*/) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 32 * HW) return;
+    const int co = i / HW, p = i % HW;
+    float acc = 0.0f;
+    for (int ci = 0; ci < CIN; ++ci) acc = fmaf(in[(size_t)ci * HW + p], w[ci * 32 + co], acc);
+    out[i] = selu(acc);
+}
+
+// ------------------------------------------------------------------------ //
+//  3. feature aggregation.  F(p) = [ selu(W1 x1(p)) | up2(g2)(p) | up8(g3)(p) | up32(g4)(p) ]
+//     (bilinear, align_corners=True).  The aggregate kernel turns F into the first
+//     score-head layer s8 = selu(Ws0 F) and 1/||F|| without storing F.
+// ------------------------------------------------------------------------ //
+struct Pyr {
+    const float* x1; const float* g2; const float* g3; const float* g4;
+    const float* w1;      // conv1 [16][32]
+    int Hp, Wp;
+};
+
+struct UpTap { int o00, o01, o10, o11; float w00, w01, w10, w11; };
+
+__device__ __forceinline__ UpTap up_tap(int y, int x, int Hp, int Wp, int S) {
+    const int ih = Hp / S, iw = Wp / S;
+    const float sy = (float)(ih - 1) / (float)(Hp - 1), sx = (float)(iw - 1) / (float)(Wp - 1);
+    const float fy = sy * (float)y, fx = sx * (float)x;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < ih - 1), x1 = x0 + (x0 < iw - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
+    UpTap t;
+    t.o00 = y0 * iw + x0; t.o01 = y0 * iw + x1; t.o10 = y1 * iw + x0; t.o11 = y1 * iw + x1;
+    t.w00 = hx; t.w01 = lx; t.w10 = hy; t.w11 = ly;     // combined as hy*(hx*a+lx*b)+ly*(hx*c+lx*d)
+    return t;
+}
+__device__ __forceinline__ float up_eval(const float* __restrict__ p, const UpTap& t) {
+    return t.w10 * (t.w00 * p[t.o00] + t.w01 * p[t.o01]) + t.w11 * (t.w00 * p[t.o10] + t.w01 * p[t.o11]);
+}
+
+__global__ __launch_bounds__(256) void al_aggregate_kernel(Pyr P, const float* __restrict__ ws0 /*[128][8]*/,
+                                                           float* __restrict__ s8, float* __restrict__ rnorm) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= P.Wp) return;
+    const size_t HW = (size_t)P.Hp * P.Wp, pix = (size_t)y * P.Wp + x;
+    float xv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) xv[k] = P.x1[k * HW + pix];
+    float s[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) s[o] = 0.0f;
+    float n2 = 0.0f;
+    for (int c = 0; c < 32; ++c) {
+        float a = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a = fmaf(xv[k], P.w1[k * 32 + c], a);
+        a = selu(a);
+        n2 = fmaf(a, a, n2);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) s[o] = fmaf(a, ws0[c * 8 + o], s[o]);
+    }
+    const UpTap t2 = up_tap(y, x, P.Hp, P.Wp, 2), t3 = up_tap(y, x, P.Hp, P.Wp, 8),
+                t4 = up_tap(y, x, P.Hp, P.Wp, 32);
+    const size_t hw2 = HW / 4, hw3 = HW / 64, hw4 = HW / 1024;
+    for (int c = 0; c < 32; ++c) {
+        const float a = up_eval(P.g2 + c * hw2, t2);
+        n2 = fmaf(a, a, n2);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) s[o] = fmaf(a, ws0[(32 + c) * 8 + o], s[o]);
+    }
+    for (int c = 0; c < 32; ++c) {
+        const float a = up_eval(P.g3 + c * hw3, t3);
+        n2 = fmaf(a, a, n2);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) s[o] = fmaf(a, ws0[(64 + c) * 8 + o], s[o]);
+    }
+    for (int c = 0; c < 32; ++c) {
+        const float a = up_eval(P.g4 + c * hw4, t4);
+        n2 = fmaf(a, a, n2);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) s[o] = fmaf(a, ws0[(96 + c) * 8 + o], s[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) s8[o * HW + pix] = selu(s[o]);
+    rnorm[pix] = 1.0f / fmaxf(sqrtf(n2), 1e-12f);            // F.normalize eps
+}
+
+// Normalised feature vector at integer pixel (y,x) of the UN-padded map: one wave per pixel,
+// lane l returns channels l and l+64.
+__device__ __forceinline__ float2 feat_pair(const Pyr& P, const float* __restrict__ rnorm, int pl, int pt,
+                                            int y, int x, int lane) {
+    const int yp = y + pt, xp = x + pl;
+    const size_t HW = (size_t)P.Hp * P.Wp, pix = (size_t)yp * P.Wp + xp;
+    float a, b;
+    const int c = lane & 31;
+    if (lane < 32) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = fmaf(P.x1[k * HW + pix], P.w1[k * 32 + c], acc);
+        a = selu(acc);
+        b = up_eval(P.g3 + c * (HW / 64), up_tap(yp, xp, P.Hp, P.Wp, 8));
+    } else {
+        a = up_eval(P.g2 + c * (HW / 4), up_tap(yp, xp, P.Hp, P.Wp, 2));
+        b = up_eval(P.g4 + c * (HW / 1024), up_tap(yp, xp, P.Hp, P.Wp, 32));
+    }
+    const float r = rnorm[pix];
+    return make_float2(a * r, b * r);        // channels: lane<32: (c, 64+c) ; lane>=32: (32+c, 96+c)
+}
+
+// ------------------------------------------------------------------------ //
+//  4. score head tail: 3x3 (8->4) SELU, 3x3 (4->4) SELU, 3x3 (4->1), sigmoid.
+//     One kernel, intermediate layers kept in LDS; zero padding at the padded-map border.
+// ------------------------------------------------------------------------ //
+constexpr int ST_W = 32, ST_H = 8;
+
+__global__ __launch_bounds__(256) void al_score_tail_kernel(const float* __restrict__ s8, int Hp, int Wp,
+                                                            const float* __restrict__ w2 /*[8][9][4]*/,
+                                                            const float* __restrict__ w4 /*[4][9][4]*/,
+                                                            const float* __restrict__ w6 /*[4][9][1]*/,
+                                                            float* __restrict__ score, int h, int w, int pl,
+                                                            int pt) {
+    __shared__ float t0[8][ST_H + 6][ST_W + 6];
+    __shared__ float t1[4][ST_H + 4][ST_W + 4];
+    __shared__ float t2[4][ST_H + 2][ST_W + 2];
+    const int x0 = blockIdx.x * ST_W, y0 = blockIdx.y * ST_H;
+    const size_t HW = (size_t)Hp * Wp;
+    for (int i = threadIdx.x; i < 8 * (ST_H + 6) * (ST_W + 6); i += 256) {
+        const int c = i / ((ST_H + 6) * (ST_W + 6)), rem = i % ((ST_H + 6) * (ST_W + 6));
+        const int yy = y0 + rem / (ST_W + 6) - 3, xx = x0 + rem % (ST_W + 6) - 3;
+        (&t0[0][0][0])[i] = (yy >= 0 && yy < Hp && xx >= 0 && xx < Wp) ? s8[c * HW + (size_t)yy * Wp + xx] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (ST_H + 4) * (ST_W + 4); i += 256) {
+        const int ly = i / (ST_W + 4), lx = i % (ST_W + 4);
+        const int yy = y0 + ly - 2, xx = x0 + lx - 2;
+        float a[4] = {0, 0, 0, 0};
+        if (yy >= 0 && yy < Hp && xx >= 0 && xx < Wp) {
+            for (int ci = 0; ci < 8; ++ci)
+                for (int tap = 0; tap < 9; ++tap) {
+                    const float v = t0[ci][ly + tap / 3][lx + tap % 3];
+                    for (int o = 0; o < 4; ++o) a[o] = fmaf(v, w2[(ci * 9 + tap) * 4 + o], a[o]);
+                }
+            for (int o = 0; o < 4; ++o) a[o] = selu(a[o]);
+        }
+        for (int o = 0; o < 4; ++o) t1[o][ly][lx] = a[o];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (ST_H + 2) * (ST_W + 2); i += 256) {
+        const int ly = i / (ST_W + 2), lx = i % (ST_W + 2);
+        const int yy = y0 + ly - 1, xx = x0 + lx - 1;
+        float a[4] = {0, 0, 0, 0};
+        if (yy >= 0 && yy < Hp && xx >= 0 && xx < Wp) {
+            for (int ci = 0; ci < 4; ++ci)
+                for (int tap = 0; tap < 9; ++tap) {
+                    const float v = t1[ci][ly + tap / 3][lx + tap % 3];
+                    for (int o = 0; o < 4; ++o) a[o] = fmaf(v, w4[(ci * 9 + tap) * 4 + o], a[o]);
+                }
+            for (int o = 0; o < 4; ++o) a[o] = selu(a[o]);
+        }
+        for (int o = 0; o < 4; ++o) t2[o][ly][lx] = a[o];
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int yy = y0 + ly, xx = x0 + lx;
+    float a = 0.0f;
+    for (int ci = 0; ci < 4; ++ci)
+        for (int tap = 0; tap < 9; ++tap) a = fmaf(t2[ci][ly + tap / 3][lx + tap % 3], w6[ci * 9 + tap], a);
+    const int uy = yy - pt, ux = xx - pl;
+    if (uy >= 0 && uy < h && ux >= 0 && ux < w) score[(size_t)uy * w + ux] = 1.0f / (1.0f + expf(-a));
+}
+
+// ------------------------------------------------------------------------ //
+//  5. DKD: simple_nms (5x5, two recovery rounds) + border + threshold -> candidates
+// ------------------------------------------------------------------------ //
+constexpr int NT_W = 64, NT_H = 16, NHALO = 10;     // dependency radius 2 + 4 + 4
+constexpr int NE_W = NT_W + 2 * NHALO, NE_H = NT_H + 2 * NHALO;
+
+__device__ __forceinline__ float pool5(const float (*a)[NE_W], int y, int x) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int dy = -2; dy <= 2; ++dy)
+#pragma unroll
+        for (int dx = -2; dx <= 2; ++dx) {
+            const int yy = y + dy, xx = x + dx;
+            if (yy >= 0 && yy < NE_H && xx >= 0 && xx < NE_W) m = fmaxf(m, a[yy][xx]);
+        }
+    return m;
+}
+
+__global__ __launch_bounds__(256) void al_nms_kernel(const float* __restrict__ score, int h, int w,
+                                                     float* __restrict__ nms, float* __restrict__ block_sum) {
+    // s: scores (-inf outside the map = max_pool2d's implicit padding); m: max_mask; q: scratch
+    __shared__ float s[NE_H][NE_W], m[NE_H][NE_W], q[NE_H][NE_W];
+    const int x0 = blockIdx.x * NT_W - NHALO, y0 = blockIdx.y * NT_H - NHALO;
+    for (int i = threadIdx.x; i < NE_H * NE_W; i += 256) {
+        const int ly = i / NE_W, lx = i % NE_W, yy = y0 + ly, xx = x0 + lx;
+        s[ly][lx] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? score[(size_t)yy * w + xx] : -INFINITY;
+    }
+    __syncthreads();
+    // values at the LDS-tile rim are wrong (missing neighbours) but the 10-pixel halo keeps them
+    // out of the dependency cone of the central NT_H x NT_W outputs
+    for (int i = threadIdx.x; i < NE_H * NE_W; i += 256) {
+        const int ly = i / NE_W, lx = i % NE_W;
+        m[ly][lx] = (s[ly][lx] == pool5(s, ly, lx) && s[ly][lx] > -INFINITY) ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+    constexpr int NPASS = (NE_H * NE_W + 255) / 256;
+    for (int round = 0; round < 2; ++round) {
+        // q = supp ? 0 : s  (supp = maxpool(max_mask) > 0); outside the map stays -inf
+        bool supp_r[NPASS];
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            supp_r[k] = false;
+            if (i < NE_H * NE_W) {
+                const int ly = i / NE_W, lx = i % NE_W;
+                supp_r[k] = pool5(m, ly, lx) > 0.0f;
+                q[ly][lx] = (s[ly][lx] == -INFINITY) ? -INFINITY : (supp_r[k] ? 0.0f : s[ly][lx]);
+            }
+        }
+        __syncthreads();
+        bool upd[NPASS];
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            upd[k] = false;
+            if (i < NE_H * NE_W) {
+                const int ly = i / NE_W, lx = i % NE_W;
+                const bool newmax = q[ly][lx] == pool5(q, ly, lx) && q[ly][lx] > -INFINITY;
+                upd[k] = m[ly][lx] > 0.0f || (newmax && !supp_r[k]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            if (i < NE_H * NE_W) m[i / NE_W][i % NE_W] = upd[k] ? 1.0f : 0.0f;
+        }
+        __syncthreads();
+    }
+    float lsum = 0.0f;
+    for (int i = threadIdx.x; i < NT_H * NT_W; i += 256) {
+        const int ly = i / NT_W + NHALO, lx = i % NT_W + NHALO;
+        const int yy = y0 + ly, xx = x0 + lx;
+        if (yy < h && xx < w) {
+            float v = m[ly][lx] > 0.0f ? s[ly][lx] : 0.0f;
+            if (yy < 2 || xx < 2 || yy >= h - 2 || xx >= w - 2) v = 0.0f;      // border of `radius`
+            nms[(size_t)yy * w + xx] = v;
+            lsum += s[ly][lx];
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+    __shared__ float ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sum[blockIdx.y * gridDim.x + blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+// collect pixels with nms > thr into an (unordered) candidate list of 64-bit keys:
+// key = score_bits << 32 | (0xffffffff - index)  -> larger key = better (score desc, index asc)
+__global__ __launch_bounds__(256) void al_collect_kernel(const float* __restrict__ nms, int n_px, float thr,
+                                                         int fallback, const float* __restrict__ block_sum,
+                                                         int n_blocks, unsigned long long* __restrict__ cand,
+                                                         int cap, ALCtrl* __restrict__ ctrl) {
+    if (fallback) {
+        if (!ctrl->need_fallback) return;           // the normal threshold found keypoints
+        float s = 0.0f;                             // mean of the raw score map, fixed summation order
+        for (int i = 0; i < n_blocks; ++i) s += block_sum[i];
+        thr = s / (float)n_px;
+    }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_px) return;
+    const float v = nms[i];
+    if (v > thr) {
+        const int pos = atomicAdd(&ctrl->n_cand, 1);
+        if (pos < cap) cand[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+        else ctrl->overflow = 1;
+    }
+}
+// decided between the two collect launches so every thread of the fallback launch sees one answer
+__global__ void al_fallback_flag_kernel(ALCtrl* __restrict__ ctrl) { ctrl->need_fallback = ctrl->n_cand == 0; }
+
+// kornia get_gaussian_kernel1d in fp32: gk[0..kx) horizontal taps, gk[32..32+ky) vertical taps
+__global__ void al_taps_kernel(float* __restrict__ gk, int kx, float sx, int ky, float sy) {
+    if (threadIdx.x != 0) return;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int ks = pass ? ky : kx;
+        const float sigma = pass ? sy : sx;
+        float* o = gk + 32 * pass;
+        float sum = 0.0f;
+        for (int i = 0; i < ks; ++i) {
+            float x = (float)(i - ks / 2);
+            if (ks % 2 == 0) x += 0.5f;
+            o[i] = expf(-(x * x) / (2.0f * sigma * sigma));
+            sum += o[i];
+        }
+        for (int i = 0; i < ks; ++i) o[i] /= sum;
+    }
+}
+
+// ------------------------------------------------------------------------ //
+//  6. selection: top-n_limit by (score desc, index asc) or all in raster order; one block.
+// ------------------------------------------------------------------------ //
+constexpr int SEL_CAP = 8192;      // max keypoints (sort capacity)
+
+__device__ void bitonic_sort_desc(unsigned long long* a, int n_pow2) {
+    for (int k = 2; k <= n_pow2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n_pow2; i += blockDim.x) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long x = a[i], y = a[ixj];
+                    const bool up = (i & k) == 0;         // descending overall
+                    if (up ? (x < y) : (x > y)) { a[i] = y; a[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+__global__ __launch_bounds__(1024) void al_select_kernel(const unsigned long long* __restrict__ cand, int cap,
+                                                         int n_limit, int* __restrict__ kp_index,
+                                                         ALCtrl* __restrict__ ctrl) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];   // SEL_CAP
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_remaining;
+    __shared__ int s_count;
+    const int n = min(ctrl->n_cand, cap);
+    const int t = threadIdx.x;
+    int n_sel;
+    if (n <= n_limit) {
+        // raster order: sort by index ascending = key with score bits cleared, descending on (~index)
+        for (int i = t; i < SEL_CAP; i += blockDim.x) keys[i] = i < n ? (cand[i] & 0xffffffffull) : 0ull;
+        n_sel = n;
+    } else {
+        // radix-select the n_limit-th largest 64-bit key, 8 bits at a time (keys are unique)
+        unsigned long long prefix = 0ull;
+        int remaining = n_limit;
+        for (int shift = 56; shift >= 0; shift -= 8) {
+            for (int i = t; i < 256; i += blockDim.x) hist[i] = 0;
+            __syncthreads();
+            const unsigned long long mask_hi = shift == 56 ? 0ull : (~0ull << (shift + 8));
+            for (int i = t; i < n; i += blockDim.x) {
+                const unsigned long long k = cand[i];
+                if ((k & mask_hi) == prefix) atomicAdd(&hist[(k >> shift) & 255], 1u);
+            }
+            __syncthreads();
+            if (t == 0) {
+                int rem = remaining, d = 255;
+                for (; d > 0; --d) {
+                    if ((int)hist[d] >= rem) break;
+                    rem -= hist[d];
+                }
+                s_prefix = d; s_remaining = rem;
+            }
+            __syncthreads();
+            prefix |= (unsigned long long)s_prefix << shift;
+            remaining = s_remaining;
+            __syncthreads();
+        }
+        // prefix == the n_limit-th largest key: keep keys >= prefix
+        if (t == 0) s_count = 0;
+        for (int i = t; i < SEL_CAP; i += blockDim.x) keys[i] = 0ull;
+        __syncthreads();
+        for (int i = t; i < n; i += blockDim.x) {
+            const unsigned long long k = cand[i];
+            if (k >= prefix) {
+                const int pos = atomicAdd(&s_count, 1);
+                if (pos < SEL_CAP) keys[pos] = k;
+            }
+        }
+        n_sel = n_limit;
+    }
+    __syncthreads();
+    int p2 = 1;
+    while (p2 < n_sel) p2 <<= 1;
+    p2 = max(p2, 2);
+    bitonic_sort_desc(keys, p2);
+    for (int i = t; i < n_sel; i += blockDim.x)
+        kp_index[i] = (int)(0xffffffffu - (unsigned)(keys[i] & 0xffffffffull));
+    if (t == 0) ctrl->n_kp = n_sel;
+}
+
+// soft-argmax refinement + score sampling (DKD.forward sub_pixel=True)
+__global__ void al_refine_kernel(const float* __restrict__ score, int h, int w, const int* __restrict__ kp_index,
+                                 float* __restrict__ kp_norm, float* __restrict__ kp_score,
+                                 const ALCtrl* __restrict__ ctrl) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ctrl->n_kp) return;
+    const int idx = kp_index[i], x = idx % w, y = idx / w;
+    float patch[25], mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 25; ++k) {
+        const int yy = y + k / 5 - 2, xx = x + k % 5 - 2;
+        patch[k] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? score[(size_t)yy * w + xx] : 0.0f;   // unfold zero pad
+        mx = fmaxf(mx, patch[k]);
+    }
+    float se = 0.0f, sx = 0.0f, sy = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 25; ++k) {
+        const float e = expf((patch[k] - mx) / 0.1f);
+        se += e;
+        sx += e * (float)(k % 5 - 2);
+        sy += e * (float)(k / 5 - 2);
+    }
+    const float kx = ((float)x + sx / se) / (float)(w - 1) * 2.0f - 1.0f;
+    const float ky = ((float)y + sy / se) / (float)(h - 1) * 2.0f - 1.0f;
+    kp_norm[2 * i] = kx;
+    kp_norm[2 * i + 1] = ky;
+    // grid_sample(bilinear, align_corners=True, zeros padding)
+    const float ix = (kx + 1.0f) / 2.0f * (float)(w - 1), iy = (ky + 1.0f) / 2.0f * (float)(h - 1);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+    auto at = [&](int yy, int xx) { return (yy >= 0 && yy < h && xx >= 0 && xx < w) ? score[(size_t)yy * w + xx] : 0.0f; };
+    kp_score[i] = at(y0, x0) * (wx0 * wy0) + at(y0, x1) * (wx1 * wy0) + at(y1, x0) * (wx0 * wy1) + at(y1, x1) * (wx1 * wy1);
+}
+
+// ------------------------------------------------------------------------ //
+//  7. SDDH descriptor head
+// ------------------------------------------------------------------------ //
+// 3x3 patch of the normalised feature map around each keypoint -> patch[n][c*9 + tap]
+// (get_patches corner rule); one wave per (keypoint, tap)
+__global__ __launch_bounds__(256) void al_patch_kernel(Pyr P, const float* __restrict__ rnorm, int pl, int pt,
+                                                       int h, int w, const float* __restrict__ kp_norm,
+                                                       float* __restrict__ patch, const ALCtrl* __restrict__ ctrl) {
+    const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = gw / 9, tap = gw % 9;
+    if (n >= ctrl->n_kp) return;
+    const float kx = (kp_norm[2 * n] / 2.0f + 0.5f) * (float)(w - 1);
+    const float ky = (kp_norm[2 * n + 1] / 2.0f + 0.5f) * (float)(h - 1);
+    // corner = (long(kwh) - ps/2 + 1).long(), clamped to [0, w-1-ps] x [0, h-1-ps]
+    int cx = (int)((float)(int)kx - 1.5f + 1.0f), cy = (int)((float)(int)ky - 1.5f + 1.0f);
+    cx = min(max(cx, 0), w - 1 - 3);
+    cy = min(max(cy, 0), h - 1 - 3);
+    const float2 f = feat_pair(P, rnorm, pl, pt, cy + tap / 3, cx + tap % 3, lane);
+    const int c = lane & 31;
+    const int ca = lane < 32 ? c : 32 + c, cb = lane < 32 ? 64 + c : 96 + c;
+    float* dst = patch + (size_t)n * 1152;
+    dst[ca * 9 + tap] = f.x;
+    dst[cb * 9 + tap] = f.y;
+}
+
+// offsets = clamp(conv1x1(selu(h32)) + b) ; sample positions in un-padded pixel coordinates
+__global__ void al_offsets_kernel(const float* __restrict__ h32 /*[n][32] pre-activation incl. bias*/,
+                                  const float* __restrict__ w2 /*[32][32] (o,i)*/, const float* __restrict__ b2,
+                                  const float* __restrict__ kp_norm, int h, int w, float max_off,
+                                  float* __restrict__ pos /*[n][16][2]*/, const ALCtrl* __restrict__ ctrl) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = i / 32, o = i % 32;
+    if (n >= ctrl->n_kp) return;
+    float acc = 0.0f;
+    for (int k = 0; k < 32; ++k) acc = fmaf(selu(h32[n * 32 + k]), w2[o * 32 + k], acc);
+    acc = fminf(fmaxf(acc + b2[o], -max_off), max_off);
+    // offset[:, :, 0, 0].view(n, 2, M).permute(0, 2, 1): channel o < 16 -> x of position o, else y
+    const int p = o & 15, comp = o >> 4;
+    const float k0 = (kp_norm[2 * n + comp] / 2.0f + 0.5f) * (float)((comp ? h : w) - 1);
+    pos[(n * 16 + p) * 2 + comp] = k0 + acc;
+}
+
+// bilinear sample (grid_sample align_corners=True, zeros padding) of the normalised feature map at
+// the 16 positions of each keypoint -> sampled[n*16 + p][128]; one wave per (keypoint, position)
+__global__ __launch_bounds__(256) void al_sample_kernel(Pyr P, const float* __restrict__ rnorm, int pl, int pt,
+                                                        int h, int w, const float* __restrict__ pos,
+                                                        float* __restrict__ sampled, const ALCtrl* __restrict__ ctrl) {
+    const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gw >= ctrl->n_kp * 16) return;
+    // pos -> normalised -> back to pixels exactly as grid_sample does
+    const float gx = 2.0f * pos[gw * 2] / (float)(w - 1) - 1.0f, gy = 2.0f * pos[gw * 2 + 1] / (float)(h - 1) - 1.0f;
+    const float ix = (gx + 1.0f) / 2.0f * (float)(w - 1), iy = (gy + 1.0f) / 2.0f * (float)(h - 1);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+    float ax = 0.0f, bx = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int yy = y0 + (q >> 1), xx = x0 + (q & 1);
+        if (yy >= 0 && yy < h && xx >= 0 && xx < w) {           // wave-uniform
+            const float wgt = ((q & 1) ? wx1 : wx0) * ((q >> 1) ? wy1 : wy0);
+            const float2 f = feat_pair(P, rnorm, pl, pt, yy, xx, lane);
+            ax = fmaf(f.x, wgt, ax);
+            bx = fmaf(f.y, wgt, bx);
+        }
+    }
+    const int c = lane & 31;
+    const int ca = lane < 32 ? c : 32 + c, cb = lane < 32 ? 64 + c : 96 + c;
+    sampled[(size_t)gw * 128 + ca] = ax;
+    sampled[(size_t)gw * 128 + cb] = bx;
+}
+
+// generic row GEMM for the descriptor head: C[M][N] = act(A[M][K] W[N][K]^T + bias)
+template <int BM, int BN, int TM, int TN>
+__global__ __launch_bounds__(256) void al_gemm_kernel(const float* __restrict__ A, int K, const float* __restrict__ Wt,
+                                                      const float* __restrict__ bias, int N, float* __restrict__ C,
+                                                      int rows_per_kp, int row_cap, int do_selu,
+                                                      const ALCtrl* __restrict__ ctrl) {
+    __shared__ GemmSmem<BM, BN> sm;
+    const int M = ctrl->n_kp * rows_per_kp;
+    const int row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
+    if (row0 >= M) return;
+    GemmA ga{A, K, A, K, K};   // (A1 unused: K0 == K; a null A1 trips an InstCombine crash in ROCm 7.2)
+    f32x16 acc[TM][TN];
+    gemm_mainloop<BM, BN, TM, TN>(ga, Wt, K, K, row0, row_cap, col0, N, sm, acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = col0 + wn * 32 * TN + j * 32 + (lane & 31);
+            const float b = (bias && col < N) ? bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wm * 32 * TM + i * 32 + acc_row(r, lane);
+                float v = acc[i][j][r] + b;
+                if (do_selu) v = selu(v);
+                if (row < M && col < N) C[(size_t)row * N + col] = v;
+            }
+        }
+}
+
+// L2 normalise (F.normalize), the reference's second normalisation (features_utils.py:100),
+// and keypoints back to input-image pixels; one wave per keypoint
+__global__ __launch_bounds__(256) void al_finalize_kernel(const float* __restrict__ raw, const float* __restrict__ kp_norm,
+                                                          const float* __restrict__ kp_score, int h, int w, float scale_x,
+                                                          float scale_y, float* __restrict__ xy_out,
+                                                          float* __restrict__ desc_out, float* __restrict__ score_out,
+                                                          int32_t* __restrict__ n_out, const ALCtrl* __restrict__ ctrl) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x == 0) n_out[0] = ctrl->n_kp;
+    if (n >= ctrl->n_kp) return;
+    const float a = raw[(size_t)n * 128 + lane], b = raw[(size_t)n * 128 + 64 + lane];
+    float s = a * a + b * b;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+    const float a1 = a * inv, b1 = b * inv;
+    float s2 = a1 * a1 + b1 * b1;
+    for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+    const float den = sqrtf(s2) + 1e-8f;
+    desc_out[(size_t)n * 128 + lane] = a1 / den;
+    desc_out[(size_t)n * 128 + 64 + lane] = b1 / den;
+    if (lane == 0) {
+        // keypoints = wh * (kp + 1) / 2 ; then (kp + 0.5) / scales - 0.5
+        const float px = (float)(w - 1) * (kp_norm[2 * n] + 1.0f) / 2.0f;
+        const float py = (float)(h - 1) * (kp_norm[2 * n + 1] + 1.0f) / 2.0f;
+        xy_out[2 * n] = (px + 0.5f) / scale_x - 0.5f;
+        xy_out[2 * n + 1] = (py + 0.5f) / scale_y - 0.5f;
+        if (score_out) score_out[n] = kp_score[n];
+    }
+}
+
+}  // namespace
+
+// ======================================================================== //
+//  host side
+// ======================================================================== //
+struct ALConvW { const float *w, *a, *b; };
+struct ALDcnW { const float *ow, *ob, *w, *a, *b; };
+
+struct sslam_aliked {
+    sslam_ctx* ctx = nullptr;
+    int max_h = 0, max_w = 0, max_kpts = 0;
+    int Hp_cap = 0, Wp_cap = 0;
+    sslam::Arena arena;
+    float* blob = nullptr;
+    // weights
+    ALConvW b1c1, b1c2, b2c1, b2c2;
+    const float *b2dw, *b2db;
+    ALDcnW b3c1, b3c2, b4c1, b4c2;
+    const float *b3dw, *b3db, *b4dw, *b4db;
+    const float *gw1, *gw2, *gw3, *gw4;
+    const float *sh0, *sh2, *sh4, *sh6;
+    const float *d_ow, *d_ob, *d_w2, *d_b2, *d_sf, *d_agg;
+    // workspace
+    ALCtrl* ctrl;
+    uint8_t* in_u8;
+    float *fsrc, *img, *x1a, *x1, *t2, *idn2, *x2, *p3, *off, *t3, *x3, *p4, *t4, *x4, *g2, *g3, *g4;
+    float *s8, *rnorm, *score, *nms, *bsum, *gk;
+    unsigned long long* cand;
+    int cand_cap;
+    int* kp_index;
+    float *kp_norm, *kp_score, *patch, *h32, *pos, *sampled, *feats, *raw;
+    float *out_xy, *out_desc, *out_score;
+    int32_t* out_n;
+    Dims last{};
+};
+
+namespace {
+
+size_t al_pad64(size_t n) { return (n + 63) / 64 * 64; }
+
+int al_bind_weights(sslam_aliked* g, size_t n_floats) {
+    size_t off = 0;
+    auto take = [&](size_t n) { const float* p = g->blob + off; off += al_pad64(n); return p; };
+    auto conv = [&](int ci, int co) { ALConvW c; c.w = take((size_t)ci * 9 * co); c.a = take(co); c.b = take(co); return c; };
+    auto dcn = [&](int ci, int co) {
+        ALDcnW c; c.ow = take((size_t)ci * 9 * 18); c.ob = take(18); c.w = take((size_t)ci * 9 * co);
+        c.a = take(co); c.b = take(co); return c;
+    };
+    g->b1c1 = conv(3, 16); g->b1c2 = conv(16, 16);
+    g->b2c1 = conv(16, 32); g->b2c2 = conv(32, 32); g->b2dw = take(16 * 32); g->b2db = take(32);
+    g->b3c1 = dcn(32, 64); g->b3c2 = dcn(64, 64); g->b3dw = take(32 * 64); g->b3db = take(64);
+    g->b4c1 = dcn(64, 128); g->b4c2 = dcn(128, 128); g->b4dw = take(64 * 128); g->b4db = take(128);
+    g->gw1 = take(16 * 32); g->gw2 = take(32 * 32); g->gw3 = take(64 * 32); g->gw4 = take(128 * 32);
+    g->sh0 = take(128 * 8); g->sh2 = take(8 * 9 * 4); g->sh4 = take(4 * 9 * 4); g->sh6 = take(4 * 9);
+    g->d_ow = take(32 * 1152); g->d_ob = take(32); g->d_w2 = take(32 * 32); g->d_b2 = take(32);
+    g->d_sf = take(128 * 128); g->d_agg = take((size_t)128 * 2048);
+    SSLAM_REQUIRE(off == n_floats, "sslam_aliked_create: weight blob has %zu floats, expected %zu", n_floats, off);
+    return 0;
+}
+
+struct ResizePlan { int h, w, blur, ky, kx; float sy, sx; };
+
+ResizePlan resize_plan(int H, int W, int resize) {
+    // kornia resize(side='long'): the long side becomes `resize`, the other int(resize / aspect)
+    ResizePlan p{};
+    const double ar = (double)W / (double)H;
+    if (ar > 1.0) { p.h = (int)(resize / ar); p.w = resize; }
+    else { p.h = resize; p.w = (int)(resize * ar); }
+    const double fy = (double)H / p.h, fx = (double)W / p.w;
+    p.blur = (fy > fx ? fy : fx) > 1.0;
+    p.sy = (float)((fy - 1.0) / 2.0 > 0.001 ? (fy - 1.0) / 2.0 : 0.001);
+    p.sx = (float)((fx - 1.0) / 2.0 > 0.001 ? (fx - 1.0) / 2.0 : 0.001);
+    const double ksy = 2.0 * 2 * ((fy - 1.0) / 2.0 > 0.001 ? (fy - 1.0) / 2.0 : 0.001);
+    const double ksx = 2.0 * 2 * ((fx - 1.0) / 2.0 > 0.001 ? (fx - 1.0) / 2.0 : 0.001);
+    p.ky = (int)(ksy > 3 ? ksy : 3); p.kx = (int)(ksx > 3 ? ksx : 3);
+    if (p.ky % 2 == 0) ++p.ky;
+    if (p.kx % 2 == 0) ++p.kx;
+    return p;
+}
+
+int al_enqueue(sslam_aliked* g, const uint8_t* img_dev, int H, int W, int C, int n_limit, float* xy_out,
+               float* desc_out, float* score_out, int32_t* n_out) {
+    hipStream_t s = g->ctx->stream;
+    const ResizePlan rp = resize_plan(H, W, 1024);
+    Dims d{};
+    d.H = H; d.W = W; d.C = C; d.h = rp.h; d.w = rp.w;
+    const int pad_h = (((d.h / 32) + 1) * 32 - d.h) % 32, pad_w = (((d.w / 32) + 1) * 32 - d.w) % 32;
+    d.Hp = d.h + pad_h; d.Wp = d.w + pad_w; d.pl = pad_w / 2; d.pt = pad_h / 2;
+    SSLAM_REQUIRE(d.Hp <= g->Hp_cap && d.Wp <= g->Wp_cap && d.h >= 8 && d.w >= 8,
+                  "sslam_aliked: network size %dx%d outside the instance capacity %dx%d", d.Hp, d.Wp,
+                  g->Hp_cap, g->Wp_cap);
+    g->last = d;
+    const int Hp = d.Hp, Wp = d.Wp;
+    SSLAM_HIP_CHECK(hipMemsetAsync(g->ctrl, 0, sizeof(ALCtrl), s));
+    SSLAM_REQUIRE(rp.kx <= 31 && rp.ky <= 31, "sslam_aliked: blur kernel too large (%d,%d)", rp.kx, rp.ky);
+    hipLaunchKernelGGL(al_taps_kernel, dim3(1), dim3(64), 0, s, g->gk, rp.kx, rp.sx, rp.ky, rp.sy);
+
+    hipLaunchKernelGGL(al_to_float_kernel, dim3(sslam::cdiv(W, 256), H), dim3(256), 0, s, img_dev, g->fsrc, d,
+                       g->gk, rp.kx, rp.blur);
+    hipLaunchKernelGGL(al_resize_pad_kernel, dim3(sslam::cdiv(Wp, 256), Hp), dim3(256), 0, s, g->fsrc, g->img, d,
+                       g->gk + 32, rp.ky, rp.blur);
+    // block1
+    dim3 g1(sslam::cdiv(Wp, CT_W), sslam::cdiv(Hp, CT_H));
+    hipLaunchKernelGGL((al_conv3x3_kernel<3, 16, 1, false, false>), g1, dim3(256), 0, s, g->img, Hp, Wp, g->x1a, Hp,
+                       Wp, g->b1c1.w, g->b1c1.a, g->b1c1.b, nullptr, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL((al_conv3x3_kernel<16, 16, 1, false, false>), g1, dim3(256), 0, s, g->x1a, Hp, Wp, g->x1, Hp,
+                       Wp, g->b1c2.w, g->b1c2.a, g->b1c2.b, nullptr, nullptr, nullptr, nullptr);
+    // block2 at 1/2: conv1 pools on load and also emits the downsample branch
+    const int H2 = Hp / 2, W2 = Wp / 2;
+    dim3 g2(sslam::cdiv(W2, CT_W), sslam::cdiv(H2, CT_H));
+    hipLaunchKernelGGL((al_conv3x3_kernel<16, 32, 2, true, false>), g2, dim3(256), 0, s, g->x1, Hp, Wp, g->t2, H2, W2,
+                       g->b2c1.w, g->b2c1.a, g->b2c1.b, g->b2dw, g->b2db, g->idn2, nullptr);
+    hipLaunchKernelGGL((al_conv3x3_kernel<32, 32, 1, false, true>), g2, dim3(256), 0, s, g->t2, H2, W2, g->x2, H2, W2,
+                       g->b2c2.w, g->b2c2.a, g->b2c2.b, nullptr, nullptr, nullptr, g->idn2);
+    // block3 at 1/8 (deformable)
+    const int H3 = Hp / 8, W3 = Wp / 8, HW3 = H3 * W3;
+    hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(32 * HW3, 256)), dim3(256), 0, s, g->x2, g->p3, 32, H2, W2, 4);
+    const float mo3 = (float)(H3 > W3 ? H3 : W3) / 4.0f;
+    hipLaunchKernelGGL(al_offset_conv_kernel, dim3(sslam::cdiv(18 * HW3, 256)), dim3(256), 0, s, g->p3, g->off, 32, H3,
+                       W3, g->b3c1.ow, g->b3c1.ob, mo3);
+    hipLaunchKernelGGL((al_deform_conv_kernel<32, 64, false>), dim3(sslam::cdiv(HW3, 4)), dim3(256), 0, s, g->p3, g->off,
+                       g->t3, H3, W3, g->b3c1.w, g->b3c1.a, g->b3c1.b, nullptr, 0, nullptr, nullptr);
+    hipLaunchKernelGGL(al_offset_conv_kernel, dim3(sslam::cdiv(18 * HW3, 256)), dim3(256), 0, s, g->t3, g->off, 64, H3,
+                       W3, g->b3c2.ow, g->b3c2.ob, mo3);
+    hipLaunchKernelGGL((al_deform_conv_kernel<64, 64, true>), dim3(sslam::cdiv(HW3, 4)), dim3(256), 0, s, g->t3, g->off,
+                       g->x3, H3, W3, g->b3c2.w, g->b3c2.a, g->b3c2.b, g->p3, 32, g->b3dw, g->b3db);
+    // block4 at 1/32
+    const int H4 = Hp / 32, W4 = Wp / 32, HW4 = H4 * W4;
+    hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(64 * HW4, 256)), dim3(256), 0, s, g->x3, g->p4, 64, H3, W3, 4);
+    const float mo4 = (float)(H4 > W4 ? H4 : W4) / 4.0f;
+    hipLaunchKernelGGL(al_offset_conv_kernel, dim3(sslam::cdiv(18 * HW4, 256)), dim3(256), 0, s, g->p4, g->off, 64, H4,
+                       W4, g->b4c1.ow, g->b4c1.ob, mo4);
+    hipLaunchKernelGGL((al_deform_conv_kernel<64, 128, false>), dim3(sslam::cdiv(HW4, 2)), dim3(256), 0, s, g->p4, g->off,
+                       g->t4, H4, W4, g->b4c1.w, g->b4c1.a, g->b4c1.b, nullptr, 0, nullptr, nullptr);
+    hipLaunchKernelGGL(al_offset_conv_kernel, dim3(sslam::cdiv(18 * HW4, 256)), dim3(256), 0, s, g->t4, g->off, 128, H4,
+                       W4, g->b4c2.ow, g->b4c2.ob, mo4);
+    hipLaunchKernelGGL((al_deform_conv_kernel<128, 128, true>), dim3(sslam::cdiv(HW4, 2)), dim3(256), 0, s, g->t4, g->off,
+                       g->x4, H4, W4, g->b4c2.w, g->b4c2.a, g->b4c2.b, g->p4, 64, g->b4dw, g->b4db);
+    // gates
+    hipLaunchKernelGGL(al_gate_kernel, dim3(sslam::cdiv(32 * H2 * W2, 256)), dim3(256), 0, s, g->x2, g->g2, 32, H2 * W2, g->gw2);
+    hipLaunchKernelGGL(al_gate_kernel, dim3(sslam::cdiv(32 * HW3, 256)), dim3(256), 0, s, g->x3, g->g3, 64, HW3, g->gw3);
+    hipLaunchKernelGGL(al_gate_kernel, dim3(sslam::cdiv(32 * HW4, 256)), dim3(256), 0, s, g->x4, g->g4, 128, HW4, g->gw4);
+    // aggregation + score head
+    Pyr P{g->x1, g->g2, g->g3, g->g4, g->gw1, Hp, Wp};
+    hipLaunchKernelGGL(al_aggregate_kernel, dim3(sslam::cdiv(Wp, 256), Hp), dim3(256), 0, s, P, g->sh0, g->s8, g->rnorm);
+    hipLaunchKernelGGL(al_score_tail_kernel, dim3(sslam::cdiv(Wp, ST_W), sslam::cdiv(Hp, ST_H)), dim3(256), 0, s, g->s8,
+                       Hp, Wp, g->sh2, g->sh4, g->sh6, g->score, d.h, d.w, d.pl, d.pt);
+    // DKD
+    const int nbx = sslam::cdiv(d.w, NT_W), nby = sslam::cdiv(d.h, NT_H), npx = d.h * d.w;
+    hipLaunchKernelGGL(al_nms_kernel, dim3(nbx, nby), dim3(256), 0, s, g->score, d.h, d.w, g->nms, g->bsum);
+    hipLaunchKernelGGL(al_collect_kernel, dim3(sslam::cdiv(npx, 256)), dim3(256), 0, s, g->nms, npx, 0.2f, 0, g->bsum,
+                       nbx * nby, g->cand, g->cand_cap, g->ctrl);
+    hipLaunchKernelGGL(al_fallback_flag_kernel, dim3(1), dim3(1), 0, s, g->ctrl);
+    hipLaunchKernelGGL(al_collect_kernel, dim3(sslam::cdiv(npx, 256)), dim3(256), 0, s, g->nms, npx, 0.0f, 1, g->bsum,
+                       nbx * nby, g->cand, g->cand_cap, g->ctrl);
+    hipLaunchKernelGGL(al_select_kernel, dim3(1), dim3(1024), SEL_CAP * 8, s, g->cand, g->cand_cap, n_limit, g->kp_index,
+                       g->ctrl);
+    const int NK = g->max_kpts;
+    hipLaunchKernelGGL(al_refine_kernel, dim3(sslam::cdiv(NK, 256)), dim3(256), 0, s, g->score, d.h, d.w, g->kp_index,
+                       g->kp_norm, g->kp_score, g->ctrl);
+    // SDDH
+    hipLaunchKernelGGL(al_patch_kernel, dim3(sslam::cdiv(NK * 9, 4)), dim3(256), 0, s, P, g->rnorm, d.pl, d.pt, d.h, d.w,
+                       g->kp_norm, g->patch, g->ctrl);
+    hipLaunchKernelGGL((al_gemm_kernel<64, 64, 1, 1>), dim3(1, sslam::cdiv(NK, 64)), dim3(256), 0, s, g->patch, 1152,
+                       g->d_ow, g->d_ob, 32, g->h32, 1, NK, 0, g->ctrl);
+    const float mo = (float)(d.h > d.w ? d.h : d.w) / 4.0f;
+    hipLaunchKernelGGL(al_offsets_kernel, dim3(sslam::cdiv(NK * 32, 256)), dim3(256), 0, s, g->h32, g->d_w2, g->d_b2,
+                       g->kp_norm, d.h, d.w, mo, g->pos, g->ctrl);
+    hipLaunchKernelGGL(al_sample_kernel, dim3(sslam::cdiv(NK * 16, 4)), dim3(256), 0, s, P, g->rnorm, d.pl, d.pt, d.h,
+                       d.w, g->pos, g->sampled, g->ctrl);
+    hipLaunchKernelGGL((al_gemm_kernel<64, 128, 1, 2>), dim3(1, sslam::cdiv(NK * 16, 64)), dim3(256), 0, s, g->sampled,
+                       128, g->d_sf, nullptr, 128, g->feats, 16, NK * 16, 1, g->ctrl);
+    hipLaunchKernelGGL((al_gemm_kernel<64, 64, 1, 1>), dim3(2, sslam::cdiv(NK, 64)), dim3(256), 0, s, g->feats, 2048,
+                       g->d_agg, nullptr, 128, g->raw, 1, NK, 0, g->ctrl);
+    const float scale_x = (float)d.w / (float)W, scale_y = (float)d.h / (float)H;
+    hipLaunchKernelGGL(al_finalize_kernel, dim3(sslam::cdiv(NK, 4)), dim3(256), 0, s, g->raw, g->kp_norm, g->kp_score,
+                       d.h, d.w, scale_x, scale_y, xy_out, desc_out, score_out, n_out, g->ctrl);
+    SSLAM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sslam_aliked_create(sslam_ctx* ctx, const float* weights, size_t n_floats, int max_h, int max_w,
+                        int max_kpts, sslam_aliked** out) {
+    SSLAM_REQUIRE(ctx && weights && out, "sslam_aliked_create: NULL argument");
+    SSLAM_REQUIRE(max_h >= 16 && max_w >= 16 && max_h <= 8192 && max_w <= 8192,
+                  "sslam_aliked_create: image size %dx%d unsupported", max_w, max_h);
+    SSLAM_REQUIRE(max_kpts >= 1 && max_kpts <= SEL_CAP, "sslam_aliked_create: max_kpts %d not in [1, %d]", max_kpts,
+                  SEL_CAP);
+    SSLAM_HIP_CHECK(hipSetDevice(ctx->device));
+    sslam_aliked* g = new sslam_aliked();
+    g->ctx = ctx; g->max_h = max_h; g->max_w = max_w; g->max_kpts = max_kpts;
+    // the network never runs larger than 1024 on the long side (+ padding to /32)
+    g->Hp_cap = 1024 + 32; g->Wp_cap = 1024 + 32;
+    const size_t HWp = (size_t)g->Hp_cap * g->Wp_cap, HWi = (size_t)max_h * max_w, NK = (size_t)max_kpts;
+    g->cand_cap = (int)(1024 * 1024);
+    auto carve = [&](sslam::Arena& A) {
+        g->blob = A.take<float>(n_floats);
+        g->ctrl = A.take<ALCtrl>(1);
+        g->in_u8 = A.take<uint8_t>(HWi * 4);
+        g->fsrc = A.take<float>(3 * HWi); g->img = A.take<float>(3 * HWp);
+        g->x1a = A.take<float>(16 * HWp); g->x1 = A.take<float>(16 * HWp);
+        g->t2 = A.take<float>(32 * HWp / 4); g->idn2 = A.take<float>(32 * HWp / 4); g->x2 = A.take<float>(32 * HWp / 4);
+        g->p3 = A.take<float>(32 * HWp / 64); g->off = A.take<float>(18 * HWp / 64);
+        g->t3 = A.take<float>(64 * HWp / 64); g->x3 = A.take<float>(64 * HWp / 64);
+        g->p4 = A.take<float>(64 * HWp / 1024); g->t4 = A.take<float>(128 * HWp / 1024); g->x4 = A.take<float>(128 * HWp / 1024);
+        g->g2 = A.take<float>(32 * HWp / 4); g->g3 = A.take<float>(32 * HWp / 64); g->g4 = A.take<float>(32 * HWp / 1024);
+        g->s8 = A.take<float>(8 * HWp); g->rnorm = A.take<float>(HWp);
+        g->score = A.take<float>(HWp); g->nms = A.take<float>(HWp); g->bsum = A.take<float>(4096); g->gk = A.take<float>(64);
+        g->cand = A.take<unsigned long long>(g->cand_cap);
+        g->kp_index = A.take<int>(SEL_CAP);
+        g->kp_norm = A.take<float>(2 * NK + 64); g->kp_score = A.take<float>(NK + 64);
+        g->patch = A.take<float>((NK + 64) * 1152); g->h32 = A.take<float>((NK + 64) * 32); g->pos = A.take<float>(NK * 32 + 64);
+        g->sampled = A.take<float>((NK * 16 + 64) * 128); g->feats = A.take<float>((NK * 16 + 64) * 128);
+        g->raw = A.take<float>((NK + 64) * 128);
+        g->out_xy = A.take<float>(2 * NK); g->out_desc = A.take<float>(NK * 128); g->out_score = A.take<float>(NK);
+        g->out_n = A.take<int32_t>(16);
+    };
+    sslam::Arena probe;
+    probe.measure();
+    carve(probe);
+    if (g->arena.init(probe.off + 256)) { delete g; return 1; }
+    carve(g->arena);
+    SSLAM_REQUIRE(g->out_n != nullptr, "sslam_aliked_create: workspace arena exhausted");
+    SSLAM_HIP_CHECK(hipMemcpy(g->blob, weights, n_floats * 4, hipMemcpyHostToDevice));
+    if (int rc = al_bind_weights(g, n_floats)) { g->arena.release(); delete g; return rc; }
+    SSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)al_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        SEL_CAP * 8));
+    *out = g;
+    return 0;
+}
+
+int sslam_aliked_destroy(sslam_aliked* g) {
+    if (!g) return 0;
+    (void)hipStreamSynchronize(g->ctx->stream);
+    g->arena.release();
+    delete g;
+    return 0;
+}
+
+static int al_check_image(sslam_aliked* g, int H, int W, int C, int max_kpts) {
+    SSLAM_REQUIRE(C == 1 || C == 3 || C == 4, "sslam_aliked_extract: %d channels (want 1 gray, 3 BGR or 4 BGRA)", C);
+    SSLAM_REQUIRE(H >= 16 && W >= 16 && H <= g->max_h && W <= g->max_w,
+                  "sslam_aliked_extract: image %dx%d outside the instance capacity %dx%d", W, H, g->max_w, g->max_h);
+    SSLAM_REQUIRE(max_kpts >= 1 && max_kpts <= g->max_kpts, "sslam_aliked_extract: max_kpts %d exceeds capacity %d",
+                  max_kpts, g->max_kpts);
+    return 0;
+}
+
+int sslam_aliked_extract_dev(sslam_aliked* g, const uint8_t* img, int H, int W, int C, int max_kpts, float* xy_out,
+                             float* desc_out, float* score_out, int32_t* n_out) {
+    SSLAM_REQUIRE(g && img && xy_out && desc_out && n_out, "sslam_aliked_extract_dev: NULL argument");
+    if (int rc = al_check_image(g, H, W, C, max_kpts)) return rc;
+    return al_enqueue(g, img, H, W, C, max_kpts, xy_out, desc_out, score_out, n_out);
+}
+
+int sslam_aliked_extract_host(sslam_aliked* g, const uint8_t* img, int H, int W, int C, int max_kpts, float* xy_out,
+                              float* desc_out, float* score_out, int32_t* n_out) {
+    SSLAM_REQUIRE(g && img && xy_out && desc_out && n_out, "sslam_aliked_extract_host: NULL argument");
+    if (int rc = al_check_image(g, H, W, C, max_kpts)) return rc;
+    SSLAM_HIP_CHECK(hipSetDevice(g->ctx->device));
+    hipStream_t s = g->ctx->stream;
+    SSLAM_HIP_CHECK(hipMemcpyAsync(g->in_u8, img, (size_t)H * W * C, hipMemcpyHostToDevice, s));
+    if (int rc = al_enqueue(g, g->in_u8, H, W, C, max_kpts, g->out_xy, g->out_desc, g->out_score, g->out_n)) return rc;
+    int32_t n = 0;
+    SSLAM_HIP_CHECK(hipMemcpyAsync(&n, g->out_n, 4, hipMemcpyDeviceToHost, s));
+    SSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    SSLAM_REQUIRE(n >= 0 && n <= max_kpts, "sslam_aliked_extract_host: corrupt keypoint count %d", n);
+    if (n) {
+        SSLAM_HIP_CHECK(hipMemcpyAsync(xy_out, g->out_xy, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+        SSLAM_HIP_CHECK(hipMemcpyAsync(desc_out, g->out_desc, (size_t)n * 512, hipMemcpyDeviceToHost, s));
+        if (score_out) SSLAM_HIP_CHECK(hipMemcpyAsync(score_out, g->out_score, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        SSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    *n_out = n;
+    return 0;
+}
+
+/* Test hook.  which: 0 = score map [h][w], 1 = kp_index [n] (int32), 2 = dims {h,w,Hp,Wp,pl,pt,n_cand,n_kp},
+ * 3 = x1 [16][Hp][Wp], 4 = x2, 5 = x3, 6 = x4, 7 = img [3][Hp][Wp], 8 = nms [h][w], 9 = kp_norm [n][2] */
+int sslam_aliked_debug_read(sslam_aliked* g, int which, void* dst, size_t bytes) {
+    SSLAM_REQUIRE(g && dst, "sslam_aliked_debug_read: NULL argument");
+    SSLAM_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    const Dims& d = g->last;
+    const size_t HWp = (size_t)d.Hp * d.Wp;
+    const void* src = nullptr; size_t cap = 0;
+    int32_t dims[8];
+    switch (which) {
+        case 0: src = g->score; cap = (size_t)d.h * d.w * 4; break;
+        case 1: src = g->kp_index; cap = (size_t)SEL_CAP * 4; break;
+        case 2: {
+            ALCtrl c;
+            SSLAM_HIP_CHECK(hipMemcpy(&c, g->ctrl, sizeof(c), hipMemcpyDeviceToHost));
+            dims[0] = d.h; dims[1] = d.w; dims[2] = d.Hp; dims[3] = d.Wp; dims[4] = d.pl; dims[5] = d.pt;
+            dims[6] = c.n_cand; dims[7] = c.n_kp;
+            SSLAM_REQUIRE(bytes <= sizeof(dims), "sslam_aliked_debug_read: dims is 32 bytes");
+            memcpy(dst, dims, bytes);
+            return 0;
+        }
+        case 3: src = g->x1; cap = 16 * HWp * 4; break;
+        case 4: src = g->x2; cap = 32 * HWp / 4 * 4; break;
+        case 5: src = g->x3; cap = 64 * HWp / 64 * 4; break;
+        case 6: src = g->x4; cap = 128 * HWp / 1024 * 4; break;
+        case 7: src = g->img; cap = 3 * HWp * 4; break;
+        case 8: src = g->nms; cap = (size_t)d.h * d.w * 4; break;
+        case 9: src = g->kp_norm; cap = (size_t)g->max_kpts * 8; break;
+        default: SSLAM_REQUIRE(false, "sslam_aliked_debug_read: unknown buffer %d", which);
+    }
+    SSLAM_REQUIRE(bytes <= cap, "sslam_aliked_debug_read: %zu bytes requested, buffer has %zu", bytes, cap);
+    SSLAM_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"

@@ -146,3 +146,121 @@ def lightglue_order(sd):
 def pack_lightglue(sd) -> np.ndarray:
     sd = to_numpy_state_dict(sd)
     return _pad_cat([a for _, a in lightglue_order(sd)])
+
+
+# --------------------------------------------------------------------------- #
+#  ALIKED-n16
+# --------------------------------------------------------------------------- #
+AL = dict(c1=16, c2=32, c3=64, c4=128, dim=128, K=3, M=16)
+
+
+def random_aliked_state_dict(seed=0, score_gain=0.1):
+    """Seeded random init with upstream key names/shapes:
+    kaiming-uniform convs, BatchNorm with non-trivial running statistics.
+    `score_gain` scales the last score-head conv (spread of the score map)."""
+    rng = np.random.default_rng(seed)
+
+    def conv(co, ci, k, bias=False, gain=1.0):
+        b = abs(gain) * np.sqrt(3.0 / (ci * k * k))
+        w = (np.sign(gain) * rng.uniform(-b, b, (co, ci, k, k))).astype(np.float32)
+        return (w, rng.uniform(-b, b, (co,)).astype(np.float32)) if bias else w
+
+    def bn(p, c, sd):
+        sd[p + ".weight"] = (1.0 + 0.1 * rng.standard_normal(c)).astype(np.float32)
+        sd[p + ".bias"] = (0.1 * rng.standard_normal(c)).astype(np.float32)
+        sd[p + ".running_mean"] = (0.1 * rng.standard_normal(c)).astype(np.float32)
+        sd[p + ".running_var"] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+
+    sd = {}
+    c1, c2, c3, c4, dim = AL["c1"], AL["c2"], AL["c3"], AL["c4"], AL["dim"]
+    sd["block1.conv1.weight"] = conv(c1, 3, 3, gain=1.7)
+    bn("block1.bn1", c1, sd)
+    sd["block1.conv2.weight"] = conv(c1, c1, 3, gain=1.7)
+    bn("block1.bn2", c1, sd)
+    for name, ci, co, dcn in (("block2", c1, c2, False), ("block3", c2, c3, True), ("block4", c3, c4, True)):
+        for cv, cin in (("conv1", ci), ("conv2", co)):
+            if dcn:
+                w, b = conv(18, cin, 3, bias=True, gain=0.5)
+                sd[f"{name}.{cv}.offset_conv.weight"], sd[f"{name}.{cv}.offset_conv.bias"] = w, b
+                sd[f"{name}.{cv}.regular_conv.weight"] = conv(co, cin, 3, gain=1.7)
+            else:
+                sd[f"{name}.{cv}.weight"] = conv(co, cin, 3, gain=1.7)
+        bn(f"{name}.bn1", co, sd)
+        bn(f"{name}.bn2", co, sd)
+        sd[f"{name}.downsample.weight"], sd[f"{name}.downsample.bias"] = conv(co, ci, 1, bias=True)
+    for i, ci in enumerate((c1, c2, c3, c4), 1):
+        sd[f"conv{i}.weight"] = conv(dim // 4, ci, 1, gain=1.7)
+    sd["score_head.0.weight"] = conv(8, dim, 1, gain=1.7)
+    sd["score_head.2.weight"] = conv(4, 8, 3, gain=1.7)
+    sd["score_head.4.weight"] = conv(4, 4, 3, gain=1.7)
+    sd["score_head.6.weight"] = conv(1, 4, 3, gain=1.7 * score_gain)
+    w, b = conv(2 * AL["M"], dim, 3, bias=True, gain=2.0)
+    sd["desc_head.offset_conv.0.weight"], sd["desc_head.offset_conv.0.bias"] = w, b
+    w, b = conv(2 * AL["M"], 2 * AL["M"], 1, bias=True, gain=4.0)
+    sd["desc_head.offset_conv.2.weight"], sd["desc_head.offset_conv.2.bias"] = w, b
+    sd["desc_head.sf_conv.weight"] = conv(dim, dim, 1, gain=1.7)
+    sd["desc_head.agg_weights"] = rng.uniform(0, 1, (AL["M"], dim, dim)).astype(np.float32)
+    return sd
+
+
+BN_EPS = 1e-5
+
+
+def _bn_affine(sd, p):
+    """Inference BatchNorm as torch evaluates it: y = x * alpha + beta with
+    alpha = weight / sqrt(running_var + eps), beta = bias - running_mean * alpha (fp32)."""
+    inv = np.float32(1.0) / np.sqrt(sd[p + ".running_var"].astype(np.float32) + np.float32(BN_EPS))
+    alpha = (sd[p + ".weight"] * inv).astype(np.float32)
+    beta = (sd[p + ".bias"] - sd[p + ".running_mean"] * alpha).astype(np.float32)
+    return alpha, beta
+
+
+def _cito(w):
+    """conv weight [co][ci][kh][kw] -> [ci][tap][co] (wave-uniform scalar loads per (ci, tap))."""
+    co, ci, kh, kw = w.shape
+    return np.ascontiguousarray(w.reshape(co, ci, kh * kw).transpose(1, 2, 0))
+
+
+def aliked_order(sd):
+    out = []
+
+    def conv(p, bnp):
+        a, b = _bn_affine(sd, bnp)
+        out.extend([(p + ".weight", _cito(sd[p + ".weight"])), (bnp + ".alpha", a), (bnp + ".beta", b)])
+
+    def dcn(p, bnp):
+        a, b = _bn_affine(sd, bnp)
+        out.extend([(p + ".offset_conv.weight", _cito(sd[p + ".offset_conv.weight"])),
+                    (p + ".offset_conv.bias", sd[p + ".offset_conv.bias"]),
+                    (p + ".regular_conv.weight", _cito(sd[p + ".regular_conv.weight"])),
+                    (bnp + ".alpha", a), (bnp + ".beta", b)])
+
+    def down(p):
+        w = sd[p + ".downsample.weight"]
+        bias = sd.get(p + ".downsample.bias")
+        if bias is None:
+            bias = np.zeros(w.shape[0], np.float32)
+        out.extend([(p + ".downsample.weight", np.ascontiguousarray(w[:, :, 0, 0].T)), (p + ".downsample.bias", bias)])
+
+    conv("block1.conv1", "block1.bn1"); conv("block1.conv2", "block1.bn2")
+    conv("block2.conv1", "block2.bn1"); conv("block2.conv2", "block2.bn2"); down("block2")
+    dcn("block3.conv1", "block3.bn1"); dcn("block3.conv2", "block3.bn2"); down("block3")
+    dcn("block4.conv1", "block4.bn1"); dcn("block4.conv2", "block4.bn2"); down("block4")
+    for i in range(1, 5):
+        out.append((f"conv{i}.weight", np.ascontiguousarray(sd[f"conv{i}.weight"][:, :, 0, 0].T)))
+    out.append(("score_head.0.weight", np.ascontiguousarray(sd["score_head.0.weight"][:, :, 0, 0].T)))
+    for k in (2, 4, 6):
+        out.append((f"score_head.{k}.weight", _cito(sd[f"score_head.{k}.weight"])))
+    out.append(("desc_head.offset_conv.0.weight", sd["desc_head.offset_conv.0.weight"].reshape(32, -1)))
+    out.append(("desc_head.offset_conv.0.bias", sd["desc_head.offset_conv.0.bias"]))
+    out.append(("desc_head.offset_conv.2.weight", sd["desc_head.offset_conv.2.weight"][:, :, 0, 0]))
+    out.append(("desc_head.offset_conv.2.bias", sd["desc_head.offset_conv.2.bias"]))
+    out.append(("desc_head.sf_conv.weight", sd["desc_head.sf_conv.weight"][:, :, 0, 0]))
+    agg = sd["desc_head.agg_weights"]                       # [p][c][d] -> [d][p*128 + c]
+    out.append(("desc_head.agg_weights^T", np.ascontiguousarray(agg.reshape(-1, agg.shape[2]).T)))
+    return out
+
+
+def pack_aliked(sd) -> np.ndarray:
+    sd = to_numpy_state_dict(sd)
+    return _pad_cat([a for _, a in aliked_order(sd)])

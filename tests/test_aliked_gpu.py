@@ -1,0 +1,149 @@
+"""GPU parity: HIP ALIKED vs the torch-CPU oracle, through the C-ABI.
+
+Bar (BASELINE.json north_star): keypoint xy and descriptors within 1e-3 (fp32).
+Keypoint *identity* is decided by discontinuous operations (NMS equality, score
+threshold, top-k by score); the HIP path and torch-CPU sum in different orders,
+so two pixels whose scores differ by ~1e-7 may swap rank.  The tests therefore
+check identity/order exactly up to such near-ties and say so explicitly."""
+import numpy as np
+import pytest
+
+import frames
+from conftest import load_pkg
+from oracle import aliked_ref as R
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def W():
+    return load_pkg("weights")
+
+
+@pytest.fixture(scope="module")
+def AL():
+    return load_pkg("aliked").AlikedHIP
+
+
+def _dims(al):
+    d = al.debug_read(2, (8,), np.int32)
+    return dict(h=d[0], w=d[1], Hp=d[2], Wp=d[3], pl=d[4], pt=d[5], n_cand=d[6], n_kp=d[7])
+
+
+def _check(al, sd, img, max_kpts, min_overlap=0.995):
+    xy, desc, sc = al.extract(img, max_kpts, return_scores=True)
+    ref = R.aliked_extract(sd, img, max_kpts, return_debug=True)
+    dbg = ref["debug"]
+    d = _dims(al)
+    h, w = dbg["score_map"].shape[-2:]
+    assert (d["h"], d["w"]) == (h, w)
+    # --- dense stages
+    Hp, Wp = d["Hp"], d["Wp"]
+    img_g = al.debug_read(7, (3, Hp, Wp))
+    np.testing.assert_allclose(img_g[:, d["pt"]:d["pt"] + h, d["pl"]:d["pl"] + w], dbg["img"][0].numpy(),
+                               atol=1e-5, rtol=1e-5)
+    for which, name, div, ch in ((3, "x1", 1, 16), (4, "x2", 2, 32), (5, "x3", 8, 64), (6, "x4", 32, 128)):
+        g = al.debug_read(which, (ch, Hp // div, Wp // div))
+        np.testing.assert_allclose(g, dbg[name][0].numpy(), atol=TOL, rtol=TOL, err_msg=name)
+    score_g = al.debug_read(0, (h, w))
+    np.testing.assert_allclose(score_g, dbg["score_map"][0, 0].numpy(), atol=1e-4, rtol=1e-4)
+    # --- DKD, stage-exact: the oracle's detector run on the GPU's own score map must reproduce
+    # the GPU's NMS mask and keypoint list (pixels AND order) exactly - every discontinuous
+    # decision (NMS equality, threshold, top-k, tie order) is then checked on identical inputs.
+    import torch
+    sg = torch.from_numpy(score_g.copy())[None, None]
+    nms_o = R.simple_nms(sg, 2)[0, 0].numpy().copy()
+    nms_o[:2] = 0; nms_o[-2:] = 0; nms_o[:, :2] = 0; nms_o[:, -2:] = 0
+    np.testing.assert_array_equal(al.debug_read(8, (h, w)), nms_o)
+    kp_o, ks_o, idx_o = R.dkd(sg, max_kpts)
+    idx_g = al.debug_read(1, (max(len(xy), 1),), np.int32)[:len(xy)]
+    np.testing.assert_array_equal(idx_g, idx_o.numpy())
+    kpn = al.debug_read(9, (max(len(xy), 1), 2))[:len(xy)]
+    np.testing.assert_allclose(kpn, kp_o.numpy(), atol=2e-6)
+    np.testing.assert_allclose(sc, ks_o.numpy(), atol=1e-5)
+    # --- end to end vs the full oracle run: same pixels except where a ~1e-6 score difference
+    # flips a discontinuous decision; xy / descriptors within 1e-3 on the common keypoints
+    n_ref = len(ref["keypoints"])
+    idx_r = ref["indices"]
+    common, ig, ir = np.intersect1d(idx_g, idx_r, return_indices=True)
+    assert len(common) >= min_overlap * n_ref, (len(common), n_ref)
+    np.testing.assert_allclose(xy[ig], ref["keypoints"][ir], atol=TOL)
+    np.testing.assert_allclose(sc[ig], ref["scores"][ir], atol=1e-4)
+    np.testing.assert_allclose(desc[ig], ref["descriptors"][ir], atol=TOL)
+    np.testing.assert_allclose(np.linalg.norm(desc, axis=1), 1.0, atol=1e-5)
+    assert xy[:, 0].min() >= -0.5 and xy[:, 0].max() <= img.shape[1] - 0.5
+    assert xy[:, 1].min() >= -0.5 and xy[:, 1].max() <= img.shape[0] - 0.5
+    return xy, desc, ref
+
+
+def test_c2_frame_white_noise(W, AL):
+    sd = W.random_aliked_state_dict(0)
+    al = AL(sd, max_num_keypoints=2048, max_h=400, max_w=1300)
+    xy, desc, ref = _check(al, sd, frames.noise_frame(0), 2048)
+    assert len(xy) == 2048                      # top-k by score branch
+    al.close()
+
+
+def test_c2_frame_structured_gray_and_bgra(W, AL):
+    sd = W.random_aliked_state_dict(1)
+    al = AL(sd, max_num_keypoints=2048, max_h=400, max_w=1300)
+    _check(al, sd, frames.structured_frame(2), 2048)
+    g = frames.structured_frame(1, c=1)                      # KITTI PNGs arrive as HxW gray
+    xy_g, desc_g, _ = _check(al, sd, g, 1024)
+    bgra = np.dstack([np.repeat(g[:, :, None], 3, 2), np.full(g.shape, 255, np.uint8)])
+    xy_a, desc_a = al.extract(bgra, 1024)
+    np.testing.assert_array_equal(xy_a, xy_g)
+    al.close()
+
+
+def test_raster_order_branch_small_image(W, AL):
+    """Fewer candidates than max_kpts -> all kept, raster order (the reference test's
+    200x200 four-disc image, tests/test_lightglue_vs_manual.py:16-27)."""
+    sd = W.random_aliked_state_dict(2, score_gain=-0.1)     # scores mostly below the 0.2 threshold
+    al = AL(sd, max_num_keypoints=8192, max_h=400, max_w=1300)
+    xy, desc, ref = _check(al, sd, frames.structured_frame(0), 8192)
+    d = _dims(al)
+    assert 0 < d["n_cand"] == len(xy) < 8192
+    idx = al.debug_read(1, (len(xy),), np.int32)
+    assert np.all(np.diff(idx) > 0)             # raster order
+    al.close()
+
+
+def test_reference_disc_pair_degenerate_ties(W, AL):
+    """The reference test's own input (tests/test_lightglue_vs_manual.py:16-27): 200x200, four
+    white discs on black.  Large constant regions give exactly tied scores; the stage-exact DKD
+    check still has to hold (ties broken by raster order), the end-to-end overlap need not."""
+    sd = W.random_aliked_state_dict(2)
+    al = AL(sd, max_num_keypoints=4096, max_h=256, max_w=256)
+    for img in frames.disc_pair():
+        _check(al, sd, img, 4096, min_overlap=0.0)
+    al.close()
+
+
+def test_c5_size_downscale_with_real_blur(W, AL):
+    """1920x1080 (config C5): resize factor 1.875 -> the antialias blur is a real 3-tap filter."""
+    sd = W.random_aliked_state_dict(3)
+    al = AL(sd, max_num_keypoints=2048, max_h=1080, max_w=1920)
+    img = frames.structured_frame(0, h=1080, w=1920)
+    _check(al, sd, img, 2048)
+    al.close()
+
+
+def test_tall_and_tiny_images(W, AL):
+    sd = W.random_aliked_state_dict(4)
+    al = AL(sd, max_num_keypoints=1024, max_h=700, max_w=500)
+    _check(al, sd, frames.structured_frame(0, h=640, w=480), 1024)     # portrait: long side is the height
+    _check(al, sd, frames.noise_frame(3, h=97, w=131), 1024)           # odd sizes, upscaled, no blur
+    al.close()
+
+
+def test_bad_arguments(W, AL, native):
+    al = AL(W.random_aliked_state_dict(0), max_num_keypoints=256, max_h=128, max_w=128)
+    with pytest.raises(native.NativeError, match="capacity"):
+        al.extract(frames.noise_frame(0, h=200, w=100), 256)
+    with pytest.raises(TypeError):
+        al.extract(np.zeros((64, 64, 3), np.float32))
+    with pytest.raises(native.NativeError, match="channels"):
+        al.extract(np.zeros((64, 64, 2), np.uint8))
+    al.close()
