@@ -124,10 +124,18 @@ int sslam_lightglue_match_host(sslam_lightglue* lg, const float* xy0, const floa
                                const float* xy1, const float* desc1, int N, float min_conf,
                                int32_t* ij_out, float* score_out, int32_t* k_out,
                                int32_t* stop_layer_out);
-/* Device-pointer variant; info_out[4] (device) = {K, stop_layer, n0, n1 after pruning}. */
+/* Device-pointer variant; enqueue only.  M, N bound the rows of the input arrays; m_dev /
+ * n_dev (device int32[1], may be NULL) carry the actual keypoint counts when they are only
+ * known on the device (written by sslam_aliked_extract_dev), so an extract -> match chain
+ * needs no host round trip.  info_out[4] (device) = {K, stop_layer, n0, n1 after pruning}. */
 int sslam_lightglue_match_dev(sslam_lightglue* lg, const float* xy0, const float* desc0, int M,
-                              const float* xy1, const float* desc1, int N, float min_conf,
-                              int32_t* ij_out, float* score_out, int32_t* info_out);
+                              const float* xy1, const float* desc1, int N, const int32_t* m_dev,
+                              const int32_t* n_dev, float min_conf, int32_t* ij_out, float* score_out,
+                              int32_t* info_out);
+/* Measurement hook (bench.py): bracket each attention launch - the dominant kernel - with HIP
+ * events on the context stream; _read synchronises and returns their summed duration and count. */
+int sslam_lightglue_profile(sslam_lightglue* lg, int enable);
+int sslam_lightglue_profile_read(sslam_lightglue* lg, float* total_ms_out, int32_t* launches_out);
 /* Test hook: copy an internal buffer to the host (see lightglue_kernels.hip). */
 int sslam_lightglue_debug_read(sslam_lightglue* lg, int which, void* dst, size_t bytes);
 

@@ -54,11 +54,15 @@ struct LGCtrl {
 //     (lightglue.py normalize_keypoints(size=None), LearnableFourierPositionalEncoding)
 // ------------------------------------------------------------------------ //
 __global__ __launch_bounds__(1024) void lg_prepare_kernel(
-    const float* __restrict__ xy0, const float* __restrict__ xy1, int M, int N, int Kc,
+    const float* __restrict__ xy0, const float* __restrict__ xy1, int M, int N,
+    const int32_t* __restrict__ m_dev, const int32_t* __restrict__ n_dev, int Kc,
     const float* __restrict__ Wr, float* __restrict__ enc_cos, float* __restrict__ enc_sin,
     int* __restrict__ ind, int* __restrict__ prune, LGCtrl* __restrict__ ctrl) {
     const int img = blockIdx.x;
     const float* xy = img ? xy1 : xy0;
+    // device-resident counts (written by the extractor) are clamped to the host-side bound
+    if (m_dev) M = min(max(m_dev[0], 0), M);
+    if (n_dev) N = min(max(n_dev[0], 0), N);
     const int n = img ? N : M;
     __shared__ float red[4][32];
     float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
@@ -812,6 +816,10 @@ struct sslam_lightglue {
     int *ind, *gmap, *prune, *arg0, *arg1;
     float *in_xy, *in_desc, *out_score;
     int32_t *out_ij, *out_info;
+    // optional HIP-event bracketing of the attention launches (bench.py roofline line)
+    bool profile = false;
+    std::vector<hipEvent_t> ev;     // start/stop pairs
+    size_t ev_used = 0;
 };
 
 namespace {
@@ -868,7 +876,16 @@ void launch_attention(const sslam_lightglue* g, hipStream_t s, const float* Q, c
                       const float* V, int cross) {
     AttnArgs a{Q, K, V, cross, g->o_part, g->m_part, g->l_part, g->KS, g->Kc, g->ctrl};
     dim3 grid(sslam::cdiv(g->Kc, AQ), 2 * NH, g->KS);
+    sslam_lightglue* gm = const_cast<sslam_lightglue*>(g);
+    const bool prof = gm->profile;
+    if (prof) {
+        if (gm->ev_used + 2 > gm->ev.size()) {
+            for (int i = 0; i < 64; ++i) { hipEvent_t e; (void)hipEventCreate(&e); gm->ev.push_back(e); }
+        }
+        (void)hipEventRecord(gm->ev[gm->ev_used], s);
+    }
     hipLaunchKernelGGL(lg_attention_kernel, grid, dim3(256), 0, s, a);
+    if (prof) { (void)hipEventRecord(gm->ev[gm->ev_used + 1], s); gm->ev_used += 2; }
     const long n4 = (long)2 * NH * g->Kc * 16;
     hipLaunchKernelGGL(lg_attn_merge_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s,
                        g->o_part, g->m_part, g->l_part, g->msg, g->KS, g->Kc, g->ctrl);
@@ -889,12 +906,12 @@ void launch_ffn(const sslam_lightglue* g, hipStream_t s, const float* message, c
 
 // Enqueue one pair on the context stream.  Inputs are already staged in
 // g->in_xy / g->in_desc ([2][Kc][2] and [2][Kc][128]).
-int lg_enqueue(sslam_lightglue* g, int M, int N, float min_conf, int32_t* ij_out, float* score_out,
-               int32_t* info_out) {
+int lg_enqueue(sslam_lightglue* g, int M, int N, const int32_t* m_dev, const int32_t* n_dev, float min_conf,
+               int32_t* ij_out, float* score_out, int32_t* info_out) {
     hipStream_t s = g->ctx->stream;
     const int Kc = g->Kc;
     hipLaunchKernelGGL(lg_prepare_kernel, dim3(2), dim3(1024), 0, s, g->in_xy, g->in_xy + 2 * Kc, M, N,
-                       Kc, g->w_r, g->enc_cos, g->enc_sin, g->ind, g->prune, g->ctrl);
+                       m_dev, n_dev, Kc, g->w_r, g->enc_cos, g->enc_sin, g->ind, g->prune, g->ctrl);
     {   // input_proj (lightglue.py: desc = self.input_proj(desc))
         LinearArgs a = lin(g, g->in_desc, DIN, nullptr, 0, DIN, DIN, g->w_in, g->b_in, D);
         a.out = g->x; a.ldo = D;
@@ -1034,6 +1051,7 @@ int sslam_lightglue_create(sslam_ctx* ctx, const float* weights, size_t n_floats
 int sslam_lightglue_destroy(sslam_lightglue* g) {
     if (!g) return 0;
     (void)hipStreamSynchronize(g->ctx->stream);
+    for (hipEvent_t e : g->ev) (void)hipEventDestroy(e);
     g->arena.release();
     delete g;
     return 0;
@@ -1048,8 +1066,9 @@ int sslam_lightglue_set_conf(sslam_lightglue* g, float depth_confidence, float w
 }
 
 int sslam_lightglue_match_dev(sslam_lightglue* g, const float* xy0, const float* desc0, int M,
-                              const float* xy1, const float* desc1, int N, float min_conf,
-                              int32_t* ij_out, float* score_out, int32_t* info_out) {
+                              const float* xy1, const float* desc1, int N, const int32_t* m_dev,
+                              const int32_t* n_dev, float min_conf, int32_t* ij_out, float* score_out,
+                              int32_t* info_out) {
     SSLAM_REQUIRE(g && ij_out && score_out && info_out, "sslam_lightglue_match_dev: NULL argument");
     SSLAM_REQUIRE(M >= 0 && N >= 0 && M <= g->Kc && N <= g->Kc,
                   "sslam_lightglue_match_dev: M=%d N=%d exceed max_kpts capacity %d", M, N, g->Kc);
@@ -1065,7 +1084,7 @@ int sslam_lightglue_match_dev(sslam_lightglue* g, const float* xy0, const float*
         SSLAM_HIP_CHECK(hipMemcpyAsync(g->in_xy + 2 * K, xy1, (size_t)N * 8, hipMemcpyDeviceToDevice, s));
         SSLAM_HIP_CHECK(hipMemcpyAsync(g->in_desc + K * DIN, desc1, (size_t)N * DIN * 4, hipMemcpyDeviceToDevice, s));
     }
-    return lg_enqueue(g, M, N, min_conf, ij_out, score_out, info_out);
+    return lg_enqueue(g, M, N, m_dev, n_dev, min_conf, ij_out, score_out, info_out);
 }
 
 int sslam_lightglue_match_host(sslam_lightglue* g, const float* xy0, const float* desc0, int M,
@@ -1086,7 +1105,7 @@ int sslam_lightglue_match_host(sslam_lightglue* g, const float* xy0, const float
     SSLAM_HIP_CHECK(hipMemcpyAsync(g->in_desc, desc0, (size_t)M * DIN * 4, hipMemcpyHostToDevice, s));
     SSLAM_HIP_CHECK(hipMemcpyAsync(g->in_xy + 2 * K, xy1, (size_t)N * 8, hipMemcpyHostToDevice, s));
     SSLAM_HIP_CHECK(hipMemcpyAsync(g->in_desc + K * DIN, desc1, (size_t)N * DIN * 4, hipMemcpyHostToDevice, s));
-    if (int rc = lg_enqueue(g, M, N, min_conf, g->out_ij, g->out_score, g->out_info)) return rc;
+    if (int rc = lg_enqueue(g, M, N, nullptr, nullptr, min_conf, g->out_ij, g->out_score, g->out_info)) return rc;
     int32_t info[4];
     SSLAM_HIP_CHECK(hipMemcpyAsync(info, g->out_info, sizeof(info), hipMemcpyDeviceToHost, s));
     SSLAM_HIP_CHECK(hipStreamSynchronize(s));
@@ -1121,6 +1140,30 @@ int sslam_lightglue_debug_read(sslam_lightglue* g, int which, void* dst, size_t 
     SSLAM_REQUIRE(bytes <= cap, "sslam_lightglue_debug_read: %zu bytes requested, buffer has %zu", bytes, cap);
     SSLAM_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
     SSLAM_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+/* Bracket every attention launch (the dominant kernel) with HIP events on the context stream. */
+int sslam_lightglue_profile(sslam_lightglue* g, int enable) {
+    SSLAM_REQUIRE(g != nullptr, "sslam_lightglue_profile: NULL instance");
+    g->profile = enable != 0;
+    return 0;
+}
+
+/* Synchronise and return the summed duration / number of the bracketed attention launches
+ * since the last read. */
+int sslam_lightglue_profile_read(sslam_lightglue* g, float* total_ms_out, int32_t* launches_out) {
+    SSLAM_REQUIRE(g && total_ms_out && launches_out, "sslam_lightglue_profile_read: NULL argument");
+    SSLAM_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    float tot = 0.0f;
+    for (size_t i = 0; i + 1 < g->ev_used; i += 2) {
+        float ms = 0.0f;
+        SSLAM_HIP_CHECK(hipEventElapsedTime(&ms, g->ev[i], g->ev[i + 1]));
+        tot += ms;
+    }
+    *total_ms_out = tot;
+    *launches_out = (int32_t)(g->ev_used / 2);
+    g->ev_used = 0;
     return 0;
 }
 

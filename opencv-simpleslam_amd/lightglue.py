@@ -75,14 +75,25 @@ class LightGlueHIP:
             C.byref(k), C.byref(stop)), "sslam_lightglue_match_host")
         return ij[:k.value].copy(), sc[:k.value].copy(), int(stop.value)
 
-    def match_dev(self, xy0, desc0, M, xy1, desc1, N, ij_out, score_out, info_out, min_conf=0.7):
-        """Device pointers (ints or torch tensors); enqueues only, no sync."""
+    def match_dev(self, xy0, desc0, M, xy1, desc1, N, ij_out, score_out, info_out, min_conf=0.7,
+                  m_dev=None, n_dev=None):
+        """Device pointers (ints or torch tensors); enqueues only, no sync.  m_dev / n_dev:
+        optional device int32 counts (<= M, N) produced by AlikedHIP.extract_dev."""
         P = _native.ptr
         _native.check(_native.lib().sslam_lightglue_match_dev(
-            self.handle, P(xy0), P(desc0), int(M), P(xy1), P(desc1), int(N), float(min_conf),
-            P(ij_out), P(score_out), P(info_out)), "sslam_lightglue_match_dev")
+            self.handle, P(xy0), P(desc0), int(M), P(xy1), P(desc1), int(N), P(m_dev), P(n_dev),
+            float(min_conf), P(ij_out), P(score_out), P(info_out)), "sslam_lightglue_match_dev")
 
     def debug_read(self, which: int, shape, dtype=np.float32):
         out = np.empty(shape, dtype)
         _native.check(_native.lib().sslam_lightglue_debug_read(self.handle, which, _native.ptr(out), out.nbytes))
         return out
+
+    def profile(self, enable: bool):
+        _native.check(_native.lib().sslam_lightglue_profile(self.handle, int(bool(enable))))
+
+    def profile_read(self):
+        """(summed ms, launches) of the HIP-event-bracketed attention launches since the last read."""
+        ms, n = C.c_float(), C.c_int()
+        _native.check(_native.lib().sslam_lightglue_profile_read(self.handle, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
