@@ -33,9 +33,11 @@ def test_lightglue_invariants(W):
     assert np.all(out["scores"].numpy() > 0.1)
     sc = out["debug"]["log_scores"].numpy()
     assert np.all(sc[:-1, :-1] <= 1e-6)                          # log-probabilities
-    # keypoint normalisation without image_size: bbox of the keypoints themselves
+    # keypoint normalisation without image_size (features_utils.py:158-161 passes none):
+    # size = 1 + max - min of the keypoints themselves, shift = size / 2, scale = max(size) / 2
     kn = out["debug"]["kn0"].numpy()
-    assert kn.max() <= 1.0 + 1e-6 and kn.min() >= -1.0 - 1e-6
+    size = 1 + k0.max(0) - k0.min(0)
+    np.testing.assert_allclose(kn, (k0 - size / 2) / (size.max() / 2), rtol=1e-6, atol=1e-6)
 
 
 def test_lightglue_early_stop_and_pruning_paths(W):
