@@ -115,6 +115,11 @@ int sslam_lightglue_capacity(sslam_lightglue* lg, int* kc_out);
  * evaluated after every layer; pass a value >= max_kpts to disable). */
 int sslam_lightglue_set_conf(sslam_lightglue* lg, float depth_confidence, float width_confidence,
                              float filter_threshold, int prune_min_kpts);
+/* Arithmetic of the 9 transformer layers.  0: every contraction on the exact-fp32 matrix-core
+ * instruction (v_mfma_f32_32x32x2_f32).  1 (default): fp16 hi/lo split operands, three
+ * v_mfma_f32_32x32x16_f16 per product, fp32 accumulation (~2^-22 relative error per product).
+ * The final assignment (final_proj, similarity, dual softmax, arg-max) is fp32 in both modes. */
+int sslam_lightglue_set_precision(sslam_lightglue* lg, int mode);
 /* xy0[M*2], desc0[M*128], xy1[N*2], desc1[N*128] float32.
  * ij_out[2*min(M,N)] int32 (queryIdx, trainIdx) pairs, ascending queryIdx;
  * score_out[min(M,N)]; only matches with score > filter_threshold AND

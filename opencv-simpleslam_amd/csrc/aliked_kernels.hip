@@ -197,22 +197,39 @@ __global__ void al_avgpool_kernel(const float* __restrict__ in, float* __restric
     out[i] = s / (float)(P * P);
 }
 
-// offset conv: 3x3, zero pad, bias, clamp to +-max_off; thread = (co, pixel)
-__global__ void al_offset_conv_kernel(const float* __restrict__ in, float* __restrict__ off, int CIN, int H,
-                                      int W, const float* __restrict__ w /*[ci][tap][18]*/,
-                                      const float* __restrict__ b, float max_off) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 18 * H * W) return;
-    const int co = i / (H * W), y = (i / W) % H, x = i % W;
-    float acc = 0.0f;
-    for (int ci = 0; ci < CIN; ++ci)
-        for (int tap = 0; tap < 9; ++tap) {
-            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-            if (yy >= 0 && yy < H && xx >= 0 && xx < W)
-                acc = fmaf(in[((size_t)ci * H + yy) * W + xx], w[(ci * 9 + tap) * 18 + co], acc);
-        }
-    acc += b[co];
-    off[i] = fminf(fmaxf(acc, -max_off), max_off);
+// offset conv: 3x3, zero pad, bias, clamp to +-max_off.  One wave per pixel: lanes stride over the
+// CIN*9 (ci, tap) products, each lane keeps 18 partial sums, then 18 wave reductions.
+__global__ __launch_bounds__(256) void al_offset_conv_kernel(const float* __restrict__ in, float* __restrict__ off,
+                                                             int CIN, int H, int W,
+                                                             const float* __restrict__ w /*[ci][tap][18]*/,
+                                                             const float* __restrict__ b, float max_off) {
+    const int lane = threadIdx.x & 63, pix = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= H * W) return;
+    const int y = pix / W, x = pix % W;
+    float part[18];
+#pragma unroll
+    for (int o = 0; o < 18; ++o) part[o] = 0.0f;
+    for (int k = lane; k < CIN * 9; k += 64) {
+        const int ci = k / 9, tap = k % 9;
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? in[((size_t)ci * H + yy) * W + xx] : 0.0f;
+        const float* wp = w + (size_t)k * 18;
+#pragma unroll
+        for (int o = 0; o < 18; ++o) part[o] = fmaf(v, wp[o], part[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < 18; ++o) {
+        float v = part[o];
+        for (int sft = 32; sft > 0; sft >>= 1) v += __shfl_xor(v, sft);
+        part[o] = v;
+    }
+    if (lane < 18) {
+        float v = 0.0f;
+#pragma unroll
+        for (int o = 0; o < 18; ++o) v = (lane == o) ? part[o] : v;
+        v += b[lane];
+        off[(size_t)lane * H * W + pix] = fminf(fmaxf(v, -max_off), max_off);
+    }
 }
 
 __device__ __forceinline__ float dcn_sample(const float* __restrict__ p, int H, int W, float y, float x) {
@@ -254,8 +271,15 @@ __global__ __launch_bounds__(256) void al_deform_conv_kernel(
     const int pp = threadIdx.x / COUT, co = threadIdx.x % COUT;
     const int pix = pix0 + pp;
     if (pix >= H * W) return;
-    float acc = 0.0f;
-    for (int k = 0; k < CIN * 9; ++k) acc = fmaf(col[pp][k], w[k * COUT + co], acc);
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;      // independent chains: hide the load latency
+#pragma unroll 4
+    for (int k = 0; k < CIN * 9; k += 4) {
+        a0 = fmaf(col[pp][k], w[k * COUT + co], a0);
+        a1 = fmaf(col[pp][k + 1], w[(k + 1) * COUT + co], a1);
+        a2 = fmaf(col[pp][k + 2], w[(k + 2) * COUT + co], a2);
+        a3 = fmaf(col[pp][k + 3], w[(k + 3) * COUT + co], a3);
+    }
+    const float acc = (a0 + a1) + (a2 + a3);
     float v = fmaf(acc, alpha[co], beta[co]);
     if (RESID) {
         float dn = 0.0f;
@@ -265,15 +289,23 @@ __global__ __launch_bounds__(256) void al_deform_conv_kernel(
     out[(size_t)co * H * W + pix] = selu(v);
 }
 
-// 1x1 conv (no bias) + SELU: thread = (co of 32, pixel)
-__global__ void al_gate_kernel(const float* __restrict__ in, float* __restrict__ out, int CIN, int HW,
-                               const float* __restrict__ w /*[ci][32]*/) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 32 * HW) return;
-    const int co = i / HW, p = i % HW;
-    float acc = 0.0f;
-    for (int ci = 0; ci < CIN; ++ci) acc = fmaf(in[(size_t)ci * HW + p], w[ci * 32 + co], acc);
-    out[i] = selu(acc);
+// 1x1 conv (no bias) + SELU: one thread per pixel produces all 32 outputs (inputs read once,
+// weights [ci][32] as wave-uniform scalar loads)
+__global__ __launch_bounds__(256) void al_gate_kernel(const float* __restrict__ in, float* __restrict__ out, int CIN,
+                                                      int HW, const float* __restrict__ w /*[ci][32]*/) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    float acc[32];
+#pragma unroll
+    for (int o = 0; o < 32; ++o) acc[o] = 0.0f;
+    for (int ci = 0; ci < CIN; ++ci) {
+        const float v = in[(size_t)ci * HW + p];
+        const float* wp = w + ci * 32;
+#pragma unroll
+        for (int o = 0; o < 32; ++o) acc[o] = fmaf(v, wp[o], acc[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < 32; ++o) out[(size_t)o * HW + p] = selu(acc[o]);
 }
 
 // ------------------------------------------------------------------------ //
@@ -441,67 +473,83 @@ __global__ __launch_bounds__(256) void al_score_tail_kernel(const float* __restr
 // ------------------------------------------------------------------------ //
 constexpr int NT_W = 64, NT_H = 16, NHALO = 10;     // dependency radius 2 + 4 + 4
 constexpr int NE_W = NT_W + 2 * NHALO, NE_H = NT_H + 2 * NHALO;
+constexpr int NE = NE_H * NE_W;
+constexpr int NPASS = (NE + 255) / 256;
 
-__device__ __forceinline__ float pool5(const float (*a)[NE_W], int y, int x) {
-    float m = -INFINITY;
+// 5x5 max-pool of an LDS tile, separable: rows into `tmp`, then columns (-inf outside the tile,
+// which is what F.max_pool2d's implicit padding does at the map border)
+__device__ __forceinline__ void pool5_rows(const float* __restrict__ a, float* __restrict__ tmp) {
 #pragma unroll
-    for (int dy = -2; dy <= 2; ++dy)
-#pragma unroll
-        for (int dx = -2; dx <= 2; ++dx) {
-            const int yy = y + dy, xx = x + dx;
-            if (yy >= 0 && yy < NE_H && xx >= 0 && xx < NE_W) m = fmaxf(m, a[yy][xx]);
+    for (int k = 0; k < NPASS; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        if (i < NE) {
+            const int lx = i % NE_W;
+            float m = a[i];
+            if (lx >= 1) m = fmaxf(m, a[i - 1]);
+            if (lx >= 2) m = fmaxf(m, a[i - 2]);
+            if (lx + 1 < NE_W) m = fmaxf(m, a[i + 1]);
+            if (lx + 2 < NE_W) m = fmaxf(m, a[i + 2]);
+            tmp[i] = m;
         }
+    }
+}
+__device__ __forceinline__ float pool5_col(const float* __restrict__ tmp, int i) {
+    const int ly = i / NE_W;
+    float m = tmp[i];
+    if (ly >= 1) m = fmaxf(m, tmp[i - NE_W]);
+    if (ly >= 2) m = fmaxf(m, tmp[i - 2 * NE_W]);
+    if (ly + 1 < NE_H) m = fmaxf(m, tmp[i + NE_W]);
+    if (ly + 2 < NE_H) m = fmaxf(m, tmp[i + 2 * NE_W]);
     return m;
 }
 
 __global__ __launch_bounds__(256) void al_nms_kernel(const float* __restrict__ score, int h, int w,
                                                      float* __restrict__ nms, float* __restrict__ block_sum) {
-    // s: scores (-inf outside the map = max_pool2d's implicit padding); m: max_mask; q: scratch
-    __shared__ float s[NE_H][NE_W], m[NE_H][NE_W], q[NE_H][NE_W];
+    // s: scores (-inf outside the map); m: max_mask (0/1); q: suppressed scores; tmp: row-pooled scratch.
+    // Values at the LDS-tile rim are wrong (missing neighbours) but the 10-pixel halo keeps them out
+    // of the dependency cone of the central NT_H x NT_W outputs.
+    __shared__ float s[NE], m[NE], q[NE], tmp[NE];
     const int x0 = blockIdx.x * NT_W - NHALO, y0 = blockIdx.y * NT_H - NHALO;
-    for (int i = threadIdx.x; i < NE_H * NE_W; i += 256) {
-        const int ly = i / NE_W, lx = i % NE_W, yy = y0 + ly, xx = x0 + lx;
-        s[ly][lx] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? score[(size_t)yy * w + xx] : -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NPASS; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        if (i < NE) {
+            const int yy = y0 + i / NE_W, xx = x0 + i % NE_W;
+            s[i] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? score[(size_t)yy * w + xx] : -INFINITY;
+        }
     }
     __syncthreads();
-    // values at the LDS-tile rim are wrong (missing neighbours) but the 10-pixel halo keeps them
-    // out of the dependency cone of the central NT_H x NT_W outputs
-    for (int i = threadIdx.x; i < NE_H * NE_W; i += 256) {
-        const int ly = i / NE_W, lx = i % NE_W;
-        m[ly][lx] = (s[ly][lx] == pool5(s, ly, lx) && s[ly][lx] > -INFINITY) ? 1.0f : 0.0f;
+    pool5_rows(s, tmp);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NPASS; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        if (i < NE) m[i] = (s[i] == pool5_col(tmp, i) && s[i] > -INFINITY) ? 1.0f : 0.0f;
     }
     __syncthreads();
-    constexpr int NPASS = (NE_H * NE_W + 255) / 256;
     for (int round = 0; round < 2; ++round) {
-        // q = supp ? 0 : s  (supp = maxpool(max_mask) > 0); outside the map stays -inf
+        pool5_rows(m, tmp);
+        __syncthreads();
         bool supp_r[NPASS];
 #pragma unroll
         for (int k = 0; k < NPASS; ++k) {
             const int i = threadIdx.x + 256 * k;
             supp_r[k] = false;
-            if (i < NE_H * NE_W) {
-                const int ly = i / NE_W, lx = i % NE_W;
-                supp_r[k] = pool5(m, ly, lx) > 0.0f;
-                q[ly][lx] = (s[ly][lx] == -INFINITY) ? -INFINITY : (supp_r[k] ? 0.0f : s[ly][lx]);
+            if (i < NE) {
+                supp_r[k] = pool5_col(tmp, i) > 0.0f;                 // supp = maxpool(max_mask) > 0
+                q[i] = (s[i] == -INFINITY) ? -INFINITY : (supp_r[k] ? 0.0f : s[i]);
             }
         }
         __syncthreads();
-        bool upd[NPASS];
-#pragma unroll
-        for (int k = 0; k < NPASS; ++k) {
-            const int i = threadIdx.x + 256 * k;
-            upd[k] = false;
-            if (i < NE_H * NE_W) {
-                const int ly = i / NE_W, lx = i % NE_W;
-                const bool newmax = q[ly][lx] == pool5(q, ly, lx) && q[ly][lx] > -INFINITY;
-                upd[k] = m[ly][lx] > 0.0f || (newmax && !supp_r[k]);
-            }
-        }
+        pool5_rows(q, tmp);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < NPASS; ++k) {
             const int i = threadIdx.x + 256 * k;
-            if (i < NE_H * NE_W) m[i / NE_W][i % NE_W] = upd[k] ? 1.0f : 0.0f;
+            if (i < NE) {
+                const bool newmax = q[i] == pool5_col(tmp, i) && q[i] > -INFINITY;
+                if (newmax && !supp_r[k]) m[i] = 1.0f;                 // max_mask |= new_max & ~supp
+            }
         }
         __syncthreads();
     }
@@ -510,10 +558,11 @@ __global__ __launch_bounds__(256) void al_nms_kernel(const float* __restrict__ s
         const int ly = i / NT_W + NHALO, lx = i % NT_W + NHALO;
         const int yy = y0 + ly, xx = x0 + lx;
         if (yy < h && xx < w) {
-            float v = m[ly][lx] > 0.0f ? s[ly][lx] : 0.0f;
+            const float sv = s[ly * NE_W + lx];
+            float v = m[ly * NE_W + lx] > 0.0f ? sv : 0.0f;
             if (yy < 2 || xx < 2 || yy >= h - 2 || xx >= w - 2) v = 0.0f;      // border of `radius`
             nms[(size_t)yy * w + xx] = v;
-            lsum += s[ly][lx];
+            lsum += sv;
         }
     }
     for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
@@ -536,10 +585,17 @@ __global__ __launch_bounds__(256) void al_collect_kernel(const float* __restrict
         thr = s / (float)n_px;
     }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_px) return;
-    const float v = nms[i];
-    if (v > thr) {
-        const int pos = atomicAdd(&ctrl->n_cand, 1);
+    const float v = i < n_px ? nms[i] : 0.0f;
+    const bool hit = i < n_px && v > thr;
+    // one atomic per wave: leader reserves a run, lanes take consecutive slots
+    const unsigned long long mask = __ballot(hit);
+    if (mask == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(&ctrl->n_cand, __popcll(mask));
+    base = __shfl(base, __ffsll((long long)mask) - 1);
+    if (hit) {
+        const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
         if (pos < cap) cand[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(0xffffffffu - (unsigned)i);
         else ctrl->overflow = 1;
     }
@@ -933,11 +989,11 @@ int al_enqueue(sslam_aliked* g, const uint8_t* img_dev, int H, int W, int C, int
     const int H3 = Hp / 8, W3 = Wp / 8, HW3 = H3 * W3;
     hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(32 * HW3, 256)), dim3(256), 0, s, g->x2, g->p3, 32, H2, W2, 4);
     const float mo3 = (float)(H3 > W3 ? H3 : W3) / 4.0f;
-    hipLaunchKernelGGL(al_offset_conv_kernel, dim3(sslam::cdiv(18 * HW3, 256)), dim3(256), 0, s, g->p3, g->off, 32, H3,
+    hipLaunchKernelGGL(al_offset_conv_kernel, dim3(sslam::cdiv(HW3, 4)), dim3(256), 0, s, g->p3, g->off, 32, H3,
                        W3, g->b3c1.ow, g->b3c1.ob, mo3);
     hipLaunchKernelGGL((al_deform_conv_kernel<32, 64, false>), dim3(sslam::cdiv(HW3, 4)), dim3(256), 0, s, g->p3, g->off,
                        g->t3, H3, W3, g->b3c1.w, g->b3c1.a, g->b3c1.b, nullptr, 0, nullptr, nullptr);
-    hipLaunchKernelGGL(al_offset_conv_kernel, dim3(sslam::cdiv(18 * HW3, 256)), dim3(256), 0, s, g->t3, g->off, 64, H3,
+    hipLaunchKernelGGL(al_offset_conv_kernel, dim3(sslam::cdiv(HW3, 4)), dim3(256), 0, s, g->t3, g->off, 64, H3,
                        W3, g->b3c2.ow, g->b3c2.ob, mo3);
     hipLaunchKernelGGL((al_deform_conv_kernel<64, 64, true>), dim3(sslam::cdiv(HW3, 4)), dim3(256), 0, s, g->t3, g->off,
                        g->x3, H3, W3, g->b3c2.w, g->b3c2.a, g->b3c2.b, g->p3, 32, g->b3dw, g->b3db);
@@ -945,18 +1001,18 @@ int al_enqueue(sslam_aliked* g, const uint8_t* img_dev, int H, int W, int C, int
     const int H4 = Hp / 32, W4 = Wp / 32, HW4 = H4 * W4;
     hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(64 * HW4, 256)), dim3(256), 0, s, g->x3, g->p4, 64, H3, W3, 4);
     const float mo4 = (float)(H4 > W4 ? H4 : W4) / 4.0f;
-    hipLaunchKernelGGL(al_offset_conv_kernel, dim3(sslam::cdiv(18 * HW4, 256)), dim3(256), 0, s, g->p4, g->off, 64, H4,
+    hipLaunchKernelGGL(al_offset_conv_kernel, dim3(sslam::cdiv(HW4, 4)), dim3(256), 0, s, g->p4, g->off, 64, H4,
                        W4, g->b4c1.ow, g->b4c1.ob, mo4);
     hipLaunchKernelGGL((al_deform_conv_kernel<64, 128, false>), dim3(sslam::cdiv(HW4, 2)), dim3(256), 0, s, g->p4, g->off,
                        g->t4, H4, W4, g->b4c1.w, g->b4c1.a, g->b4c1.b, nullptr, 0, nullptr, nullptr);
-    hipLaunchKernelGGL(al_offset_conv_kernel, dim3(sslam::cdiv(18 * HW4, 256)), dim3(256), 0, s, g->t4, g->off, 128, H4,
+    hipLaunchKernelGGL(al_offset_conv_kernel, dim3(sslam::cdiv(HW4, 4)), dim3(256), 0, s, g->t4, g->off, 128, H4,
                        W4, g->b4c2.ow, g->b4c2.ob, mo4);
     hipLaunchKernelGGL((al_deform_conv_kernel<128, 128, true>), dim3(sslam::cdiv(HW4, 2)), dim3(256), 0, s, g->t4, g->off,
                        g->x4, H4, W4, g->b4c2.w, g->b4c2.a, g->b4c2.b, g->p4, 64, g->b4dw, g->b4db);
     // gates
-    hipLaunchKernelGGL(al_gate_kernel, dim3(sslam::cdiv(32 * H2 * W2, 256)), dim3(256), 0, s, g->x2, g->g2, 32, H2 * W2, g->gw2);
-    hipLaunchKernelGGL(al_gate_kernel, dim3(sslam::cdiv(32 * HW3, 256)), dim3(256), 0, s, g->x3, g->g3, 64, HW3, g->gw3);
-    hipLaunchKernelGGL(al_gate_kernel, dim3(sslam::cdiv(32 * HW4, 256)), dim3(256), 0, s, g->x4, g->g4, 128, HW4, g->gw4);
+    hipLaunchKernelGGL(al_gate_kernel, dim3(sslam::cdiv(H2 * W2, 256)), dim3(256), 0, s, g->x2, g->g2, 32, H2 * W2, g->gw2);
+    hipLaunchKernelGGL(al_gate_kernel, dim3(sslam::cdiv(HW3, 64)), dim3(64), 0, s, g->x3, g->g3, 64, HW3, g->gw3);
+    hipLaunchKernelGGL(al_gate_kernel, dim3(sslam::cdiv(HW4, 64)), dim3(64), 0, s, g->x4, g->g4, 128, HW4, g->gw4);
     // aggregation + score head
     Pyr P{g->x1, g->g2, g->g3, g->g4, g->gw1, Hp, Wp};
     hipLaunchKernelGGL(al_aggregate_kernel, dim3(sslam::cdiv(Wp, 256), Hp), dim3(256), 0, s, P, g->sh0, g->s8, g->rnorm);

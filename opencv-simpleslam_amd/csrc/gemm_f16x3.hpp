@@ -1,0 +1,150 @@
+// gemm_f16x3.hpp - split-precision matrix-core GEMM main loop (gfx950 only).
+//
+// An fp32 operand a is carried as two fp16 planes  a = hi + lo * 2^-11  with
+// hi = rne_f16(a), lo = rne_f16((a - hi) * 2^11)  (22 significand bits), and a product is
+//     a.b = hi_a.hi_b + (hi_a.lo_b + lo_a.hi_b) * 2^-11          (lo.lo = 2^-22 dropped)
+// evaluated as three v_mfma_f32_32x32x16_f16 into two fp32 accumulators (c1, c2).  Relative
+// error per product ~2^-22 (fp32: 2^-24), accumulation in fp32 inside the matrix core: the
+// result is fp32-grade at 16/3 of the fp32 matrix-core rate.  Operands arrive PRE-SPLIT from the
+// producer's epilogue (each element is split once, not once per consuming tile), so the main loop
+// has no conversion work: global -> registers -> LDS -> ds_read_b128 fragments -> MFMA.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "gemm_f32.hpp"
+
+namespace sslam {
+
+using half8 = _Float16 __attribute__((ext_vector_type(8)));
+using half4 = _Float16 __attribute__((ext_vector_type(4)));
+using half2v = _Float16 __attribute__((ext_vector_type(2)));
+
+constexpr float SPLIT_SCALE = 2048.0f;          // 2^11
+constexpr float SPLIT_INV = 1.0f / 2048.0f;
+
+__device__ __forceinline__ void split_f32(float a, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)a;
+    lo = (_Float16)((a - (float)hi) * SPLIT_SCALE);
+}
+
+__device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// split planes of a [rows][ld] matrix
+struct SplitPtr {
+    const _Float16* hi;
+    const _Float16* lo;
+};
+
+constexpr int HBK = 32;              // k per LDS tile (halves)
+constexpr int HLD = HBK + 8;         // +16 B pad: 80 B row stride, ds_read_b128 conflict-free
+
+template <int BM, int BN>
+struct __attribute__((aligned(16))) GemmSmemH {
+    _Float16 a_hi[2][BM * HLD];
+    _Float16 a_lo[2][BM * HLD];
+    _Float16 w_hi[2][BN * HLD];
+    _Float16 w_lo[2][BN * HLD];
+};
+
+struct GemmAH {                      // A operand: optional concat of two split sources along K
+    SplitPtr A0;
+    SplitPtr A1;
+    int lda;                         // same leading dimension for both
+    int K0;                          // columns [0,K0) from A0, [K0,K) from A1 (K0 % 32 == 0)
+};
+
+#define LDH8(dst, ptr) dst = *reinterpret_cast<const uint4*>(ptr)
+#define STH8(ptr, src) *reinterpret_cast<uint4*>(ptr) = src
+
+// acc1/acc2: hi.hi and cross-term accumulators; result = acc1 + acc2 * 2^-11
+template <int BM, int BN, int TM, int TN>
+__device__ __forceinline__ void gemm_mainloop_h(const GemmAH& ga, SplitPtr W, int ldw, int K, int row0,
+                                                int row_cap, int col0, int col_cap, GemmSmemH<BM, BN>& sm,
+                                                f32x16 (&acc1)[TM][TN], f32x16 (&acc2)[TM][TN]) {
+    static_assert(BM == 64 * TM && BN == 64 * TN, "2x2 waves of 32*TM x 32*TN");
+    constexpr int NA = BM / 64, NW = BN / 64;     // 16-byte loads per thread per plane per k-tile
+    static_assert(NA <= 2 && NW <= 2, "named prefetch registers cover up to 128-row tiles");
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, lr = lane & 31;
+
+    // named prefetch registers (see gemm_f32.hpp for why not arrays)
+    uint4 ah0, ah1, al0, al1, wh0, wh1, wl0, wl1;
+    ah0 = ah1 = al0 = al1 = wh0 = wh1 = wl0 = wl1 = make_uint4(0, 0, 0, 0);
+    const int lr4 = t >> 2, lc8 = (t & 3) * 8;    // (row, k-offset in halves) inside a 64-row slab
+    size_t oa[2], ow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        oa[j] = (size_t)min(row0 + lr4 + 64 * j, row_cap - 1) * ga.lda + lc8;
+        ow[j] = (size_t)min(col0 + lr4 + 64 * j, col_cap - 1) * ldw + lc8;
+    }
+    const int sto = lr4 * HLD + lc8;
+
+#define GEMMH_GLOAD(kt_)                                                          \
+    {                                                                             \
+        const int k_ = (kt_) * HBK;                                               \
+        const bool f_ = k_ < ga.K0;                                               \
+        const _Float16* pah_ = f_ ? ga.A0.hi + k_ : ga.A1.hi + (k_ - ga.K0);      \
+        const _Float16* pal_ = f_ ? ga.A0.lo + k_ : ga.A1.lo + (k_ - ga.K0);      \
+        LDH8(ah0, pah_ + oa[0]); LDH8(al0, pal_ + oa[0]);                         \
+        if constexpr (NA > 1) { LDH8(ah1, pah_ + oa[1]); LDH8(al1, pal_ + oa[1]); } \
+        LDH8(wh0, W.hi + k_ + ow[0]); LDH8(wl0, W.lo + k_ + ow[0]);               \
+        if constexpr (NW > 1) { LDH8(wh1, W.hi + k_ + ow[1]); LDH8(wl1, W.lo + k_ + ow[1]); } \
+    }
+#define GEMMH_SSTORE(buf_)                                                        \
+    {                                                                             \
+        STH8(&sm.a_hi[buf_][sto], ah0); STH8(&sm.a_lo[buf_][sto], al0);           \
+        if constexpr (NA > 1) { STH8(&sm.a_hi[buf_][sto + 64 * HLD], ah1); STH8(&sm.a_lo[buf_][sto + 64 * HLD], al1); } \
+        STH8(&sm.w_hi[buf_][sto], wh0); STH8(&sm.w_lo[buf_][sto], wl0);           \
+        if constexpr (NW > 1) { STH8(&sm.w_hi[buf_][sto + 64 * HLD], wh1); STH8(&sm.w_lo[buf_][sto + 64 * HLD], wl1); } \
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc1[i][j][r] = 0.0f; acc2[i][j][r] = 0.0f; }
+
+    const int nkt = K / HBK;
+    GEMMH_GLOAD(0);
+    GEMMH_SSTORE(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) GEMMH_GLOAD(kt + 1);
+        const int ra = (wm * 32 * TM + lr) * HLD + 8 * h;
+        const int rw = (wn * 32 * TN + lr) * HLD + 8 * h;
+#pragma unroll
+        for (int st = 0; st < HBK / 16; ++st) {
+            half8 fah[TM], fal[TM], fwh[TN], fwl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                fah[i] = *reinterpret_cast<const half8*>(&sm.a_hi[cur][ra + i * 32 * HLD + st * 16]);
+                fal[i] = *reinterpret_cast<const half8*>(&sm.a_lo[cur][ra + i * 32 * HLD + st * 16]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                fwh[j] = *reinterpret_cast<const half8*>(&sm.w_hi[cur][rw + j * 32 * HLD + st * 16]);
+                fwl[j] = *reinterpret_cast<const half8*>(&sm.w_lo[cur][rw + j * 32 * HLD + st * 16]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc1[i][j] = mfma16(fah[i], fwh[j], acc1[i][j]);
+                    acc2[i][j] = mfma16(fah[i], fwl[j], acc2[i][j]);
+                    acc2[i][j] = mfma16(fal[i], fwh[j], acc2[i][j]);
+                }
+        }
+        if (kt + 1 < nkt) GEMMH_SSTORE(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+#undef GEMMH_GLOAD
+#undef GEMMH_SSTORE
+}
+
+}  // namespace sslam

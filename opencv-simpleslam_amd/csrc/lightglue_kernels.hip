@@ -21,6 +21,7 @@
 // host round trip (graph-capturable).
 #include "common.hpp"
 #include "gemm_f32.hpp"
+#include "gemm_f16x3.hpp"
 
 namespace {
 
@@ -30,6 +31,15 @@ using sslam::acc_row;
 using sslam::GemmSmem;
 using sslam::GemmA;
 using sslam::gemm_mainloop;
+using sslam::half8;
+using sslam::half4;
+using sslam::SplitPtr;
+using sslam::GemmSmemH;
+using sslam::GemmAH;
+using sslam::gemm_mainloop_h;
+using sslam::mfma16;
+using sslam::split_f32;
+using sslam::SPLIT_INV;
 
 constexpr int D = 256;       // descriptor_dim
 constexpr int DH = 64;       // head dim
@@ -784,6 +794,375 @@ __global__ __launch_bounds__(1024) void lg_emit_kernel(
     }
 }
 
+
+// ======================================================================== //
+//  Split-precision path (gemm_f16x3.hpp): activations that feed a contraction
+//  live in HBM as fp16 (hi, lo) plane pairs written by their producer.
+// ======================================================================== //
+struct SplitOut { _Float16* hi; _Float16* lo; };
+
+__global__ void lg_split_kernel(const float* __restrict__ src, _Float16* __restrict__ hi,
+                                _Float16* __restrict__ lo, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) split_f32(src[i], hi[i], lo[i]);
+}
+
+// row-domain split of a [2][Kc][ld] activation (input descriptors / pruned token states)
+__global__ void lg_split_rows_kernel(const float* __restrict__ src, _Float16* __restrict__ hi,
+                                     _Float16* __restrict__ lo, int ld, int Kc,
+                                     const LGCtrl* __restrict__ ctrl) {
+    if (ctrl->stop) return;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per = (size_t)Kc * ld;
+    if (i >= 2 * per) return;
+    const int img = (int)(i / per), row = (int)((i % per) / ld);
+    if (row >= ctrl->n[img]) return;
+    split_f32(src[i], hi[i], lo[i]);
+}
+
+enum { EPH_QKV = 0, EPH_CROSS = 1, EPH_SPLIT = 2, EPH_F32 = 3, EPH_RESID = 4 };
+
+struct LinearArgsH {
+    SplitPtr A0, A1; int lda; int K0; int K;
+    SplitPtr W; const float* bias; int N;
+    float* out; int ldo;               // fp32 destination (F32 / RESID)
+    SplitOut outs;                     // split destination (SPLIT / RESID), ld = ldo
+    SplitOut q, k, vt;                 // QKV / CROSS destinations
+    float q_scale, k_scale;
+    const float* enc_cos; const float* enc_sin;
+    const LGCtrl* ctrl; int Kc;
+};
+
+template <int BM, int BN, int TM, int TN, int EPI>
+__global__ __launch_bounds__(256) void lg_linear_h_kernel(LinearArgsH p) {
+    __shared__ GemmSmemH<BM, BN> sm;
+    if (p.ctrl->stop) return;
+    const RowDom rd = row_domain<BM>(p.ctrl, p.Kc);
+    if (rd.row0 >= rd.n) return;
+    const int col0 = blockIdx.x * BN;
+    const size_t ibase = (size_t)rd.img * p.Kc;
+    GemmAH ga{{p.A0.hi + ibase * p.lda, p.A0.lo + ibase * p.lda},
+              {p.A1.hi ? p.A1.hi + ibase * p.lda : p.A0.hi, p.A1.lo ? p.A1.lo + ibase * p.lda : p.A0.lo},
+              p.lda, p.K0};
+    f32x16 c1[TM][TN], c2[TM][TN];
+    gemm_mainloop_h<BM, BN, TM, TN>(ga, p.W, p.K, p.K, rd.row0, p.Kc, col0, p.N, sm, c1, c2);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = col0 + wn * 32 * TN + j * 32 + (lane & 31);
+            const float b = p.bias[col];
+            float val[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) val[r] = (c1[i][j][r] + c2[i][j][r] * SPLIT_INV) + b;
+            const int rbase = rd.row0 + wm * 32 * TM + i * 32;
+            if constexpr (EPI == EPH_QKV || EPI == EPH_CROSS) {
+                // EPH_QKV cols [q|k|v][head][d]; EPH_CROSS cols [qk|v][head][d]
+                const int s = col >> 8, hd = (col >> 6) & 3, d = col & 63;
+                const bool is_v = (EPI == EPH_QKV) ? (s == 2) : (s == 1);
+                if (!is_v) {
+                    const float scale = (EPI == EPH_QKV && s == 1) ? p.k_scale : p.q_scale;
+                    SplitOut dst = (EPI == EPH_QKV && s == 1) ? p.k : p.q;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rbase + acc_row(r, lane);
+                        float v = val[r];
+                        if constexpr (EPI == EPH_QKV) {
+                            const float partner = __shfl_xor(v, 1);
+                            const int rr = min(row, p.Kc - 1);
+                            const float c = p.enc_cos[(ibase + rr) * ENC + (d >> 1)];
+                            const float sn = p.enc_sin[(ibase + rr) * ENC + (d >> 1)];
+                            v = (d & 1) ? (v * c + partner * sn) : (v * c - partner * sn);
+                        }
+                        v *= scale;
+                        if (row < rd.n) {
+                            const size_t o = (((size_t)rd.img * NH + hd) * p.Kc + row) * DH + d;
+                            split_f32(v, dst.hi[o], dst.lo[o]);
+                        }
+                    }
+                } else {
+                    // V transposed: vt[img][head][d][token]; 4 consecutive tokens per register group
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int row = rbase + 8 * g4 + 4 * (lane >> 5);
+                        half4 h4, l4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            _Float16 hh, ll;
+                            split_f32(val[4 * g4 + e], hh, ll);
+                            h4[e] = hh; l4[e] = ll;
+                        }
+                        const size_t o = (((size_t)rd.img * NH + hd) * DH + d) * p.Kc + row;
+                        if (row + 3 < rd.n) {
+                            *reinterpret_cast<half4*>(p.vt.hi + o) = h4;
+                            *reinterpret_cast<half4*>(p.vt.lo + o) = l4;
+                        } else {
+                            for (int e = 0; e < 4; ++e)
+                                if (row + e < rd.n) { p.vt.hi[o + e] = h4[e]; p.vt.lo[o + e] = l4[e]; }
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + acc_row(r, lane);
+                    if (row < rd.n) {
+                        const size_t o = (ibase + row) * p.ldo + col;
+                        float v = val[r];
+                        if constexpr (EPI == EPH_RESID) v += p.out[o];
+                        if constexpr (EPI == EPH_F32 || EPI == EPH_RESID) p.out[o] = v;
+                        if constexpr (EPI == EPH_SPLIT || EPI == EPH_RESID) split_f32(v, p.outs.hi[o], p.outs.lo[o]);
+                    }
+                }
+            }
+        }
+}
+
+// LayerNorm(512) + exact GELU: fp32 hidden in, split planes out (one wave / row)
+__global__ __launch_bounds__(256) void lg_ln_gelu_h_kernel(const float* __restrict__ hid, SplitOut outs,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const LGCtrl* __restrict__ ctrl, int Kc) {
+    if (ctrl->stop) return;
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int img = gw / Kc, row = gw % Kc;
+    if (img > 1 || row >= ctrl->n[img]) return;
+    const size_t base = ((size_t)img * Kc + row) * 512;
+    const float4 a = *reinterpret_cast<const float4*>(hid + base + lane * 4);
+    const float4 b = *reinterpret_cast<const float4*>(hid + base + 256 + lane * 4);
+    float s = (a.x + a.y) + (a.z + a.w) + (b.x + b.y) + (b.z + b.w);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / 512.0f;
+    float v[8] = {a.x - mean, a.y - mean, a.z - mean, a.w - mean, b.x - mean, b.y - mean, b.z - mean, b.w - mean};
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q += v[i] * v[i];
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / 512.0f + 1e-5f);
+    half4 h0, l0, h1, l1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = (i < 4 ? 0 : 256) + lane * 4 + (i & 3);
+        const float y = v[i] * rstd * gamma[c] + beta[c];
+        const float g = 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
+        _Float16 hh, ll;
+        split_f32(g, hh, ll);
+        if (i < 4) { h0[i] = hh; l0[i] = ll; } else { h1[i - 4] = hh; l1[i - 4] = ll; }
+    }
+    *reinterpret_cast<half4*>(outs.hi + base + lane * 4) = h0;
+    *reinterpret_cast<half4*>(outs.lo + base + lane * 4) = l0;
+    *reinterpret_cast<half4*>(outs.hi + base + 256 + lane * 4) = h1;
+    *reinterpret_cast<half4*>(outs.lo + base + 256 + lane * 4) = l1;
+}
+
+// ---- attention, split precision --------------------------------------------------------
+constexpr int AH_LD = 72;            // halves per LDS row (64 + 8 pad): 144 B, 16 B aligned
+
+struct __attribute__((aligned(16))) AttnSmemH {
+    _Float16 k_hi[2][AK * AH_LD];
+    _Float16 k_lo[2][AK * AH_LD];
+    _Float16 vt_hi[2][DH * AH_LD];
+    _Float16 vt_lo[2][DH * AH_LD];
+};
+
+struct AttnArgsH {
+    SplitPtr Q, K, VT;                                // Q,K [2][4][Kc][64]; VT [2][4][64][Kc]
+    int cross;
+    float* o_part; float* m_part; float* l_part;
+    int KS; int Kc; const LGCtrl* ctrl;
+};
+
+__global__ __launch_bounds__(256) void lg_attention_h_kernel(AttnArgsH p) {
+    __shared__ AttnSmemH sm;
+    if (p.ctrl->stop) return;
+    const int img = blockIdx.y >> 2, head = blockIdx.y & 3;
+    const int kimg = p.cross ? 1 - img : img;
+    const int nq = p.ctrl->n[img], nk = p.ctrl->n[kimg];
+    const int q0 = blockIdx.x * AQ;
+    if (q0 >= nq) return;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, lr = lane & 31;
+    const int z = blockIdx.z;
+    const int ntiles = (nk + AK - 1) / AK;
+    const int t0 = (int)((long)z * ntiles / p.KS), t1 = (int)((long)(z + 1) * ntiles / p.KS);
+
+    const size_t qoff = ((size_t)img * NH + head) * p.Kc * DH;
+    const size_t koff = ((size_t)kimg * NH + head) * p.Kc * DH;   // same size for K and V^T planes
+    const _Float16 *Kh = p.K.hi + koff, *Kl = p.K.lo + koff, *Vh = p.VT.hi + koff, *Vl = p.VT.lo + koff;
+
+    // Q fragments (B operand of S^T = K.Q^T): lane holds Q[query lr][dims 16 s + 8 h .. +7]; the
+    // softmax scale * log2(e) is already folded in by the projection epilogue
+    const int qi = min(q0 + wave * 32 + lr, p.Kc - 1);
+    half8 qh[4], ql[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        qh[s] = *reinterpret_cast<const half8*>(p.Q.hi + qoff + (size_t)qi * DH + 16 * s + 8 * h);
+        ql[s] = *reinterpret_cast<const half8*>(p.Q.lo + qoff + (size_t)qi * DH + 16 * s + 8 * h);
+    }
+
+    f32x16 o1a, o2a, o1b, o2b;       // O^T d-block a (d 0..31) / b (d 32..63): hi.hi and cross terms
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o1a[r] = 0.0f; o2a[r] = 0.0f; o1b[r] = 0.0f; o2b[r] = 0.0f; }
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    uint4 gk0, gk1, gk2, gk3, gv0, gv1, gv2, gv3;    // named prefetch registers
+    gk0 = gk1 = gk2 = gk3 = gv0 = gv1 = gv2 = gv3 = make_uint4(0, 0, 0, 0);
+    const int ar = t >> 3, ac8 = (t & 7) * 8;        // (row, offset in halves) inside a 32-row slab
+#define ATTNH_GLOAD(tile_)                                                                  \
+    {                                                                                       \
+        const size_t k0_ = (size_t)min((tile_) * AK + ar, p.Kc - 1) * DH + ac8;             \
+        const size_t k1_ = (size_t)min((tile_) * AK + ar + 32, p.Kc - 1) * DH + ac8;        \
+        LDH8(gk0, Kh + k0_); LDH8(gk1, Kh + k1_); LDH8(gk2, Kl + k0_); LDH8(gk3, Kl + k1_);  \
+        const size_t v0_ = (size_t)ar * p.Kc + (size_t)(tile_) * AK + ac8;                  \
+        const size_t v1_ = (size_t)(ar + 32) * p.Kc + (size_t)(tile_) * AK + ac8;           \
+        LDH8(gv0, Vh + v0_); LDH8(gv1, Vh + v1_); LDH8(gv2, Vl + v0_); LDH8(gv3, Vl + v1_);  \
+    }
+#define ATTNH_SSTORE(buf_)                                                                  \
+    {                                                                                       \
+        const int o0_ = ar * AH_LD + ac8, o1_ = (ar + 32) * AH_LD + ac8;                    \
+        STH8(&sm.k_hi[buf_][o0_], gk0); STH8(&sm.k_hi[buf_][o1_], gk1);                     \
+        STH8(&sm.k_lo[buf_][o0_], gk2); STH8(&sm.k_lo[buf_][o1_], gk3);                     \
+        STH8(&sm.vt_hi[buf_][o0_], gv0); STH8(&sm.vt_hi[buf_][o1_], gv1);                   \
+        STH8(&sm.vt_lo[buf_][o0_], gv2); STH8(&sm.vt_lo[buf_][o1_], gv3);                   \
+    }
+
+    if (t0 < t1) {
+        ATTNH_GLOAD(t0);
+        ATTNH_SSTORE(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int tile = t0; tile < t1; ++tile) {
+        if (tile + 1 < t1) ATTNH_GLOAD(tile + 1);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            f32x16 s1, s2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s1[r] = 0.0f; s2[r] = 0.0f; }
+            const int kro = (sub * 32 + lr) * AH_LD + 8 * h;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const half8 kh = *reinterpret_cast<const half8*>(&sm.k_hi[cur][kro + 16 * s]);
+                const half8 kl = *reinterpret_cast<const half8*>(&sm.k_lo[cur][kro + 16 * s]);
+                s1 = mfma16(kh, qh[s], s1);
+                s2 = mfma16(kh, ql[s], s2);
+                s2 = mfma16(kl, qh[s], s2);
+            }
+            const int kbase = tile * AK + sub * 32;
+            float sv[16];
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sv[r] = s1[r] + s2[r] * SPLIT_INV;
+                if (kbase + acc_row(r, lane) >= nk) sv[r] = -INFINITY;
+                tmax = fmaxf(tmax, sv[r]);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = exp2f(m_run - m_new);
+            m_run = m_new;
+            float psum = 0.0f;
+            half8 ph[2], pl[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = exp2f(sv[r] - m_new);
+                psum += pv;
+                _Float16 hh, ll;
+                split_f32(pv, hh, ll);
+                ph[r >> 3][r & 7] = hh;                  // k-slot j' of step s2 = accumulator reg 8 s2 + j'
+                pl[r >> 3][r & 7] = ll;
+            }
+            l_run = l_run * alpha + psum;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o1a[r] *= alpha; o2a[r] *= alpha; o1b[r] *= alpha; o2b[r] *= alpha; }
+            // O^T[d][i] += V^T[d][key] P^T[key][i]; k-slot j' of step s2 <-> key 16 s2 + 8 (j'>>2) + 4 h + (j'&3)
+#pragma unroll
+            for (int s2i = 0; s2i < 2; ++s2i) {
+                const int kc = sub * 32 + 16 * s2i + 4 * h;
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const int vo = (db * 32 + lr) * AH_LD + kc;
+                    const half4 vh0 = *reinterpret_cast<const half4*>(&sm.vt_hi[cur][vo]);
+                    const half4 vh1 = *reinterpret_cast<const half4*>(&sm.vt_hi[cur][vo + 8]);
+                    const half4 vl0 = *reinterpret_cast<const half4*>(&sm.vt_lo[cur][vo]);
+                    const half4 vl1 = *reinterpret_cast<const half4*>(&sm.vt_lo[cur][vo + 8]);
+                    const half8 vh = __builtin_shufflevector(vh0, vh1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const half8 vl = __builtin_shufflevector(vl0, vl1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    if (db == 0) {
+                        o1a = mfma16(vh, ph[s2i], o1a);
+                        o2a = mfma16(vh, pl[s2i], o2a);
+                        o2a = mfma16(vl, ph[s2i], o2a);
+                    } else {
+                        o1b = mfma16(vh, ph[s2i], o1b);
+                        o2b = mfma16(vh, pl[s2i], o2b);
+                        o2b = mfma16(vl, ph[s2i], o2b);
+                    }
+                }
+            }
+        }
+        if (tile + 1 < t1) ATTNH_SSTORE(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+#undef ATTNH_GLOAD
+#undef ATTNH_SSTORE
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const int qrow = q0 + wave * 32 + lr;
+    if (qrow < nq) {
+        const size_t pbase = (((size_t)z * 2 + img) * NH + head) * p.Kc + qrow;
+        float* op = p.o_part + pbase * DH;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            float4 a, b;
+            a.x = o1a[4 * g4] + o2a[4 * g4] * SPLIT_INV; a.y = o1a[4 * g4 + 1] + o2a[4 * g4 + 1] * SPLIT_INV;
+            a.z = o1a[4 * g4 + 2] + o2a[4 * g4 + 2] * SPLIT_INV; a.w = o1a[4 * g4 + 3] + o2a[4 * g4 + 3] * SPLIT_INV;
+            b.x = o1b[4 * g4] + o2b[4 * g4] * SPLIT_INV; b.y = o1b[4 * g4 + 1] + o2b[4 * g4 + 1] * SPLIT_INV;
+            b.z = o1b[4 * g4 + 2] + o2b[4 * g4 + 2] * SPLIT_INV; b.w = o1b[4 * g4 + 3] + o2b[4 * g4 + 3] * SPLIT_INV;
+            *reinterpret_cast<float4*>(op + 8 * g4 + 4 * h) = a;
+            *reinterpret_cast<float4*>(op + 32 + 8 * g4 + 4 * h) = b;
+        }
+        if (h == 0) { p.m_part[pbase] = m_run; p.l_part[pbase] = l_tot; }
+    }
+}
+
+// merge key-split partials -> split planes of msg[img][row][head*64 + d]
+__global__ __launch_bounds__(256) void lg_attn_merge_h_kernel(const float* __restrict__ o_part,
+                                                              const float* __restrict__ m_part,
+                                                              const float* __restrict__ l_part, SplitOut msg,
+                                                              int KS, int Kc, const LGCtrl* __restrict__ ctrl) {
+    if (ctrl->stop) return;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c4 = (int)(gid & 15);
+    const long rid = gid >> 4;
+    if (rid >= (long)2 * NH * Kc) return;
+    const int row = (int)(rid % Kc), ih = (int)(rid / Kc), img = ih >> 2, head = ih & 3;
+    if (row >= ctrl->n[img]) return;
+    float M = -INFINITY;
+    for (int z = 0; z < KS; ++z) M = fmaxf(M, m_part[(size_t)z * 2 * NH * Kc + rid]);
+    float4 acc = make_float4(0, 0, 0, 0);
+    float L = 0.0f;
+    for (int z = 0; z < KS; ++z) {
+        const size_t pb = (size_t)z * 2 * NH * Kc + rid;
+        const float mz = m_part[pb];
+        const float wz = (mz == -INFINITY) ? 0.0f : exp2f(mz - M);
+        const float4 o = *reinterpret_cast<const float4*>(o_part + pb * DH + c4 * 4);
+        acc.x += o.x * wz; acc.y += o.y * wz; acc.z += o.z * wz; acc.w += o.w * wz;
+        L += l_part[pb] * wz;
+    }
+    const float inv = 1.0f / L;
+    const float v[4] = {acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv};
+    half4 hh, ll;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { _Float16 a, b; split_f32(v[e], a, b); hh[e] = a; ll[e] = b; }
+    const size_t o = ((size_t)img * Kc + row) * D + head * DH + c4 * 4;
+    *reinterpret_cast<half4*>(msg.hi + o) = hh;
+    *reinterpret_cast<half4*>(msg.lo + o) = ll;
+}
+
 }  // namespace
 
 // ======================================================================== //
@@ -816,6 +1195,12 @@ struct sslam_lightglue {
     int *ind, *gmap, *prune, *arg0, *arg1;
     float *in_xy, *in_desc, *out_score;
     int32_t *out_ij, *out_info;
+    // split-precision planes (precision == 1)
+    int precision = 1;               // 0: fp32 MFMA everywhere; 1: fp16 hi/lo split, 3 MFMA per product
+    _Float16 *w_hi, *w_lo;           // whole weight blob, split
+    _Float16 *xs_hi, *xs_lo, *msgs_hi, *msgs_lo, *msg2s_hi, *msg2s_lo, *hids_hi, *hids_lo;
+    _Float16 *qs_hi, *qs_lo, *ks_hi, *ks_lo, *vts_hi, *vts_lo;
+    size_t n_blob = 0;
     // optional HIP-event bracketing of the attention launches (bench.py roofline line)
     bool profile = false;
     std::vector<hipEvent_t> ev;     // start/stop pairs
@@ -904,6 +1289,88 @@ void launch_ffn(const sslam_lightglue* g, hipStream_t s, const float* message, c
     launch_linear<64, 64, 1, 1, EPI_RESID>(s, c);
 }
 
+SplitPtr wsp(const sslam_lightglue* g, const float* w) {
+    const size_t off = (size_t)(w - g->blob);
+    return SplitPtr{g->w_hi + off, g->w_lo + off};
+}
+
+template <int BM, int BN, int TM, int TN, int EPI>
+void launch_linear_h(hipStream_t s, const LinearArgsH& a) {
+    dim3 grid(a.N / BN, 2 * sslam::cdiv(a.Kc, BM));
+    hipLaunchKernelGGL((lg_linear_h_kernel<BM, BN, TM, TN, EPI>), grid, dim3(256), 0, s, a);
+}
+
+LinearArgsH linh(const sslam_lightglue* g, SplitPtr A0, SplitPtr A1, int lda, int K0, int K, const float* W,
+                 const float* b, int N) {
+    LinearArgsH a{};
+    a.A0 = A0; a.A1 = A1; a.lda = lda; a.K0 = K0; a.K = K;
+    a.W = wsp(g, W); a.bias = b; a.N = N; a.ctrl = g->ctrl; a.Kc = g->Kc;
+    a.enc_cos = g->enc_cos; a.enc_sin = g->enc_sin; a.q_scale = 1.0f; a.k_scale = 1.0f;
+    return a;
+}
+
+void launch_attention_h(sslam_lightglue* g, hipStream_t s, SplitPtr Q, SplitPtr K, SplitPtr VT, int cross) {
+    AttnArgsH a{Q, K, VT, cross, g->o_part, g->m_part, g->l_part, g->KS, g->Kc, g->ctrl};
+    dim3 grid(sslam::cdiv(g->Kc, AQ), 2 * NH, g->KS);
+    const bool prof = g->profile;
+    if (prof) {
+        if (g->ev_used + 2 > g->ev.size())
+            for (int i = 0; i < 64; ++i) { hipEvent_t e; (void)hipEventCreate(&e); g->ev.push_back(e); }
+        (void)hipEventRecord(g->ev[g->ev_used], s);
+    }
+    hipLaunchKernelGGL(lg_attention_h_kernel, grid, dim3(256), 0, s, a);
+    if (prof) { (void)hipEventRecord(g->ev[g->ev_used + 1], s); g->ev_used += 2; }
+    const long n4 = (long)2 * NH * g->Kc * 16;
+    hipLaunchKernelGGL(lg_attn_merge_h_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, g->o_part,
+                       g->m_part, g->l_part, SplitOut{g->msgs_hi, g->msgs_lo}, g->KS, g->Kc, g->ctrl);
+}
+
+// one transformer layer (self + cross block) on the split-precision path
+void lg_layer_h(sslam_lightglue* g, hipStream_t s, const LGLayerW& l) {
+    const SplitPtr xs{g->xs_hi, g->xs_lo}, msgs{g->msgs_hi, g->msgs_lo}, msg2s{g->msg2s_hi, g->msg2s_lo};
+    const SplitPtr hids{g->hids_hi, g->hids_lo}, none{nullptr, nullptr};
+    const SplitPtr qs{g->qs_hi, g->qs_lo}, ks{g->ks_hi, g->ks_lo}, vts{g->vts_hi, g->vts_lo};
+    const unsigned tokblocks = sslam::cdiv(2 * g->Kc, 4);
+    const float sm_scale = 0.125f * 1.4426950408889634f;        // 1/sqrt(64) * log2(e)
+    auto ffn = [&](const float* w1, const float* b1, const float* lnw, const float* lnb, const float* w2,
+                   const float* b2) {
+        LinearArgsH a = linh(g, xs, msg2s, D, D, 2 * D, w1, b1, 2 * D);
+        a.out = g->hid; a.ldo = 2 * D;
+        launch_linear_h<64, 128, 1, 2, EPH_F32>(s, a);
+        hipLaunchKernelGGL(lg_ln_gelu_h_kernel, dim3(tokblocks), dim3(256), 0, s, g->hid,
+                           SplitOut{g->hids_hi, g->hids_lo}, lnw, lnb, g->ctrl, g->Kc);
+        LinearArgsH c = linh(g, hids, none, 2 * D, 2 * D, 2 * D, w2, b2, D);
+        c.out = g->x; c.ldo = D; c.outs = SplitOut{g->xs_hi, g->xs_lo};
+        launch_linear_h<64, 64, 1, 1, EPH_RESID>(s, c);
+    };
+    {   // self block
+        LinearArgsH a = linh(g, xs, none, D, D, D, l.wqkv, l.bqkv, 3 * D);
+        a.q = SplitOut{g->qs_hi, g->qs_lo}; a.k = SplitOut{g->ks_hi, g->ks_lo}; a.vt = SplitOut{g->vts_hi, g->vts_lo};
+        a.q_scale = sm_scale; a.k_scale = 1.0f;
+        launch_linear_h<64, 128, 1, 2, EPH_QKV>(s, a);
+    }
+    launch_attention_h(g, s, qs, ks, vts, 0);
+    {
+        LinearArgsH a = linh(g, msgs, none, D, D, D, l.wo, l.bo, D);
+        a.outs = SplitOut{g->msg2s_hi, g->msg2s_lo}; a.ldo = D;
+        launch_linear_h<64, 64, 1, 1, EPH_SPLIT>(s, a);
+    }
+    ffn(l.w1, l.b1, l.lnw, l.lnb, l.w2, l.b2);
+    {   // cross block: the shared qk projection is both query and key -> sqrt(scale) on it
+        LinearArgsH a = linh(g, xs, none, D, D, D, l.cqkv, l.cbqkv, 2 * D);
+        a.q = SplitOut{g->qs_hi, g->qs_lo}; a.vt = SplitOut{g->vts_hi, g->vts_lo};
+        a.q_scale = sqrtf(sm_scale);
+        launch_linear_h<64, 128, 1, 2, EPH_CROSS>(s, a);
+    }
+    launch_attention_h(g, s, qs, qs, vts, 1);
+    {
+        LinearArgsH a = linh(g, msgs, none, D, D, D, l.cwo, l.cbo, D);
+        a.outs = SplitOut{g->msg2s_hi, g->msg2s_lo}; a.ldo = D;
+        launch_linear_h<64, 64, 1, 1, EPH_SPLIT>(s, a);
+    }
+    ffn(l.cw1, l.cb1, l.clnw, l.clnb, l.cw2, l.cb2);
+}
+
 // Enqueue one pair on the context stream.  Inputs are already staged in
 // g->in_xy / g->in_desc ([2][Kc][2] and [2][Kc][128]).
 int lg_enqueue(sslam_lightglue* g, int M, int N, const int32_t* m_dev, const int32_t* n_dev, float min_conf,
@@ -918,8 +1385,15 @@ int lg_enqueue(sslam_lightglue* g, int M, int N, const int32_t* m_dev, const int
         launch_linear<64, 64, 1, 1, EPI_PLAIN>(s, a);
     }
     const unsigned tokblocks = sslam::cdiv(2 * Kc, 4);
+    const unsigned splitblocks = (unsigned)(((size_t)2 * Kc * D + 255) / 256);
+    if (g->precision == 1)
+        hipLaunchKernelGGL(lg_split_rows_kernel, dim3(splitblocks), dim3(256), 0, s, g->x, g->xs_hi, g->xs_lo, D, Kc,
+                           g->ctrl);
     for (int i = 0; i < NL; ++i) {
         const LGLayerW& l = g->L[i];
+        if (g->precision == 1) {
+            lg_layer_h(g, s, l);
+        } else {
         // ---- self block
         {
             LinearArgs a = lin(g, g->x, D, nullptr, 0, D, D, l.wqkv, l.bqkv, 3 * D);
@@ -946,6 +1420,7 @@ int lg_enqueue(sslam_lightglue* g, int M, int N, const int32_t* m_dev, const int
             launch_linear<64, 64, 1, 1, EPI_PLAIN>(s, a);
         }
         launch_ffn(g, s, g->msg2, l.cw1, l.cb1, l.clnw, l.clnb, l.cw2, l.cb2);
+        }
         if (i == NL - 1) break;
         // ---- early stop + point pruning (lightglue.py check_if_stop / get_pruning_mask)
         const int do_stop = g->depth_conf > 0.0f;
@@ -964,6 +1439,9 @@ int lg_enqueue(sslam_lightglue* g, int M, int N, const int32_t* m_dev, const int
                                g->enc_sin, g->gmap, g->tx, g->tc, g->ts, g->ctrl, Kc, 0);
             hipLaunchKernelGGL(lg_gather_kernel, dim3(tokblocks), dim3(256), 0, s, g->x, g->enc_cos,
                                g->enc_sin, g->gmap, g->tx, g->tc, g->ts, g->ctrl, Kc, 1);
+            if (g->precision == 1)      // token rows moved: refresh their split planes
+                hipLaunchKernelGGL(lg_split_rows_kernel, dim3(splitblocks), dim3(256), 0, s, g->x, g->xs_hi,
+                                   g->xs_lo, D, Kc, g->ctrl);
         }
     }
     // ---- assignment with log_assignment[stop_layer]
@@ -1035,15 +1513,27 @@ int sslam_lightglue_create(sslam_ctx* ctx, const float* weights, size_t n_floats
         g->cpval = A.take<float>(CSLAB * K); g->cparg = A.take<int>(CSLAB * K);
         g->in_xy = A.take<float>(2 * K * 2); g->in_desc = A.take<float>(2 * K * DIN);
         g->out_ij = A.take<int32_t>(2 * K); g->out_score = A.take<float>(K); g->out_info = A.take<int32_t>(8);
+        g->w_hi = A.take<_Float16>(n_floats); g->w_lo = A.take<_Float16>(n_floats);
+        g->xs_hi = A.take<_Float16>(2 * K * D); g->xs_lo = A.take<_Float16>(2 * K * D);
+        g->msgs_hi = A.take<_Float16>(2 * K * D); g->msgs_lo = A.take<_Float16>(2 * K * D);
+        g->msg2s_hi = A.take<_Float16>(2 * K * D); g->msg2s_lo = A.take<_Float16>(2 * K * D);
+        g->hids_hi = A.take<_Float16>(2 * K * 2 * D); g->hids_lo = A.take<_Float16>(2 * K * 2 * D);
+        g->qs_hi = A.take<_Float16>(2 * K * D); g->qs_lo = A.take<_Float16>(2 * K * D);
+        g->ks_hi = A.take<_Float16>(2 * K * D); g->ks_lo = A.take<_Float16>(2 * K * D);
+        g->vts_hi = A.take<_Float16>(2 * K * D); g->vts_lo = A.take<_Float16>(2 * K * D);
     };
     sslam::Arena probe;
     probe.measure();
     carve(probe);
     if (g->arena.init(probe.off + 256)) { delete g; return 1; }
     carve(g->arena);
-    SSLAM_REQUIRE(g->out_info != nullptr, "sslam_lightglue_create: workspace arena exhausted");
+    SSLAM_REQUIRE(g->vts_lo != nullptr, "sslam_lightglue_create: workspace arena exhausted");
     SSLAM_HIP_CHECK(hipMemcpy(g->blob, weights, n_floats * 4, hipMemcpyHostToDevice));
     if (int rc = lg_bind_weights(g, n_floats)) { g->arena.release(); delete g; return rc; }
+    g->n_blob = n_floats;
+    hipLaunchKernelGGL(lg_split_kernel, dim3((unsigned)((n_floats + 255) / 256)), dim3(256), 0, ctx->stream,
+                       g->blob, g->w_hi, g->w_lo, n_floats);
+    SSLAM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     *out = g;
     return 0;
 }
@@ -1164,6 +1654,14 @@ int sslam_lightglue_profile_read(sslam_lightglue* g, float* total_ms_out, int32_
     *total_ms_out = tot;
     *launches_out = (int32_t)(g->ev_used / 2);
     g->ev_used = 0;
+    return 0;
+}
+
+/* 0: every contraction on the exact-fp32 matrix-core instruction; 1 (default): transformer layers on
+ * the fp16 hi/lo split path (3 MFMA per product, ~2^-22 relative error), assignment stays fp32. */
+int sslam_lightglue_set_precision(sslam_lightglue* g, int mode) {
+    SSLAM_REQUIRE(g != nullptr && (mode == 0 || mode == 1), "sslam_lightglue_set_precision: bad argument");
+    g->precision = mode;
     return 0;
 }
 

@@ -31,6 +31,7 @@ class LightGlueHIP:
         self.capacity = int(kc.value)
         self.max_kpts = int(max_kpts)
         self.conf = dict(self.default_conf)
+        self.precision = 1
         self.set_conf(**conf)
 
     def set_conf(self, **conf):
@@ -88,6 +89,12 @@ class LightGlueHIP:
         out = np.empty(shape, dtype)
         _native.check(_native.lib().sslam_lightglue_debug_read(self.handle, which, _native.ptr(out), out.nbytes))
         return out
+
+    def set_precision(self, mode: str | int):
+        """'f32' / 0: exact-fp32 matrix-core path; 'f16x3' / 1 (default): fp16 hi/lo split path."""
+        m = {"f32": 0, "f16x3": 1}.get(mode, mode)
+        _native.check(_native.lib().sslam_lightglue_set_precision(self.handle, int(m)))
+        self.precision = int(m)
 
     def profile(self, enable: bool):
         _native.check(_native.lib().sslam_lightglue_profile(self.handle, int(bool(enable))))
