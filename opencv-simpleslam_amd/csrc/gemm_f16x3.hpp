@@ -147,4 +147,117 @@ __device__ __forceinline__ void gemm_mainloop_h(const GemmAH& ga, SplitPtr W, in
 #undef GEMMH_SSTORE
 }
 
+
+// ------------------------------------------------------------------------------------------
+// LDS-DMA ring version.  BK = 64 halves (128 B rows), NSTAGE-deep ring in dynamic LDS filled by
+// global_load_lds_dwordx4 (no staging registers), tiles stay in flight across raw s_barriers
+// behind a counted s_waitcnt vmcnt.  The LDS image is un-padded (a DMA wave-instruction writes
+// 8 rows x 128 B linearly); the 16-byte chunk index is XOR-swizzled with (row >> 1) & 7 on the
+// SOURCE address and on every fragment read, which makes the ds_read_b128 fragments conflict-free.
+// ------------------------------------------------------------------------------------------
+constexpr int RBK = 64;
+
+template <int BM, int BN>
+constexpr int ring_stage_halves() { return (2 * BM + 2 * BN) * RBK; }
+
+__device__ __forceinline__ void glds16_(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int BM, int BN, int TM, int TN, int NSTAGE>
+__device__ __forceinline__ void gemm_mainloop_ring(const GemmAH& ga, SplitPtr W, int ldw, int K, int row0,
+                                                   int row_cap, int col0, int col_cap, _Float16* smem,
+                                                   f32x16 (&acc1)[TM][TN], f32x16 (&acc2)[TM][TN]) {
+    static_assert(BM == 64 * TM && BN == 64 * TN, "2x2 waves of 32*TM x 32*TN");
+    constexpr int STAGE = ring_stage_halves<BM, BN>();
+    constexpr int GA = BM / 8, GW = BN / 8;            // 8-row DMA groups per plane
+    constexpr int NI = (2 * GA + 2 * GW) / 4;          // DMA instructions per wave per tile
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, lr = lane & 31;
+    const int lrow = lane >> 3, lcp = lane & 7;
+
+    // stage layout (halves): [A_hi BM*64][A_lo BM*64][W_hi BN*64][W_lo BN*64]
+    auto issue = [&](int kt, int stage) {
+        const int k = kt * RBK;
+        const bool first = k < ga.K0;
+        const _Float16* pah = first ? ga.A0.hi + k : ga.A1.hi + (k - ga.K0);
+        const _Float16* pal = first ? ga.A0.lo + k : ga.A1.lo + (k - ga.K0);
+        _Float16* sbase = smem + (size_t)stage * STAGE;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int g = wave + 4 * j;                // wave-uniform group id
+            int plane, grp;
+            if (g < GA) { plane = 0; grp = g; }
+            else if (g < 2 * GA) { plane = 1; grp = g - GA; }
+            else if (g < 2 * GA + GW) { plane = 2; grp = g - 2 * GA; }
+            else { plane = 3; grp = g - 2 * GA - GW; }
+            const int row = grp * 8 + lrow;
+            const int c = lcp ^ ((row >> 1) & 7);
+            const _Float16* src;
+            _Float16* dst;
+            if (plane < 2) {
+                src = (plane == 0 ? pah : pal) + (size_t)min(row0 + row, row_cap - 1) * ga.lda + c * 8;
+                dst = sbase + plane * BM * RBK + grp * 8 * RBK;
+            } else {
+                src = (plane == 2 ? W.hi : W.lo) + k + (size_t)min(col0 + row, col_cap - 1) * ldw + c * 8;
+                dst = sbase + 2 * BM * RBK + (plane - 2) * BN * RBK + grp * 8 * RBK;
+            }
+            glds16_(src, dst);
+        }
+    };
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc1[i][j][r] = 0.0f; acc2[i][j][r] = 0.0f; }
+
+    const int nkt = K / RBK;
+#pragma unroll
+    for (int pre = 0; pre < NSTAGE - 1; ++pre)
+        if (pre < nkt) issue(pre, pre);
+    for (int kt = 0; kt < nkt; ++kt) {
+        // tile kt has landed once at most the (NSTAGE-2) younger tiles of this wave are outstanding
+        const int younger = min(nkt - 1 - kt, NSTAGE - 2);
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                  // every wave's part of tile kt is in LDS, and
+                                                       // everyone is done reading the stage refilled next
+        if (kt + NSTAGE - 1 < nkt) issue(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);
+        const _Float16* st = smem + (size_t)(kt % NSTAGE) * STAGE;
+        const _Float16 *sah = st, *sal = st + BM * RBK, *swh = st + 2 * BM * RBK, *swl = st + 2 * BM * RBK + BN * RBK;
+#pragma unroll
+        for (int s = 0; s < RBK / 16; ++s) {
+            half8 fah[TM], fal[TM], fwh[TN], fwl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * 32 * TM + i * 32 + lr;
+                const int o = row * RBK + (((2 * s + h) ^ ((row >> 1) & 7)) * 8);
+                fah[i] = *reinterpret_cast<const half8*>(sah + o);
+                fal[i] = *reinterpret_cast<const half8*>(sal + o);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn * 32 * TN + j * 32 + lr;
+                const int o = row * RBK + (((2 * s + h) ^ ((row >> 1) & 7)) * 8);
+                fwh[j] = *reinterpret_cast<const half8*>(swh + o);
+                fwl[j] = *reinterpret_cast<const half8*>(swl + o);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc1[i][j] = mfma16(fah[i], fwh[j], acc1[i][j]);
+                    acc2[i][j] = mfma16(fah[i], fwl[j], acc2[i][j]);
+                    acc2[i][j] = mfma16(fal[i], fwh[j], acc2[i][j]);
+                }
+        }
+    }
+}
+
 }  // namespace sslam

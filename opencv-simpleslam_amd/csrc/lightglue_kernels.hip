@@ -37,6 +37,7 @@ using sslam::SplitPtr;
 using sslam::GemmSmemH;
 using sslam::GemmAH;
 using sslam::gemm_mainloop_h;
+using sslam::gemm_mainloop_ring;
 using sslam::mfma16;
 using sslam::split_f32;
 using sslam::SPLIT_INV;
@@ -66,8 +67,8 @@ struct LGCtrl {
 __global__ __launch_bounds__(1024) void lg_prepare_kernel(
     const float* __restrict__ xy0, const float* __restrict__ xy1, int M, int N,
     const int32_t* __restrict__ m_dev, const int32_t* __restrict__ n_dev, int Kc,
-    const float* __restrict__ Wr, float* __restrict__ enc_cos, float* __restrict__ enc_sin,
-    int* __restrict__ ind, int* __restrict__ prune, LGCtrl* __restrict__ ctrl) {
+    float* __restrict__ bbox /*[2][4]: shift x, shift y, scale, -*/, int* __restrict__ ind,
+    int* __restrict__ prune, LGCtrl* __restrict__ ctrl) {
     const int img = blockIdx.x;
     const float* xy = img ? xy1 : xy0;
     // device-resident counts (written by the extractor) are clamped to the host-side bound
@@ -96,25 +97,32 @@ __global__ __launch_bounds__(1024) void lg_prepare_kernel(
     }
     // size = 1 + max - min ; shift = size / 2 ; scale = max(size) / 2
     const float sx = 1.0f + mxx - mnx, sy = 1.0f + mxy - mny;
-    const float shx = sx / 2.0f, shy = sy / 2.0f;
-    const float scale = fmaxf(sx, sy) / 2.0f;
-    for (int i = threadIdx.x; i < n * ENC; i += blockDim.x) {
-        const int tok = i / ENC, f = i % ENC;
-        const float kx = (xy[2 * tok] - shx) / scale;
-        const float ky = (xy[2 * tok + 1] - shy) / scale;
-        const float proj = kx * Wr[2 * f] + ky * Wr[2 * f + 1];
-        enc_cos[((size_t)img * Kc + tok) * ENC + f] = cosf(proj);
-        enc_sin[((size_t)img * Kc + tok) * ENC + f] = sinf(proj);
-    }
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         ind[img * Kc + i] = i;
         prune[img * Kc + i] = 1;
     }
     if (threadIdx.x == 0) {
+        bbox[img * 4 + 0] = sx / 2.0f; bbox[img * 4 + 1] = sy / 2.0f; bbox[img * 4 + 2] = fmaxf(sx, sy) / 2.0f;
         ctrl->n[img] = n; ctrl->n_prev[img] = n; ctrl->n_orig[img] = n;
         if (img == 0) { ctrl->stop = (M == 0 || N == 0) ? 2 : 0; ctrl->stop_layer = NL - 1;
                         ctrl->unconf = 0; ctrl->n_matches = 0; }
     }
+}
+
+// rotary tables: cos / sin of Wr . normalised keypoint (one thread per (token, frequency))
+__global__ __launch_bounds__(256) void lg_posenc_kernel(const float* __restrict__ xy0, const float* __restrict__ xy1,
+                                                        const float* __restrict__ bbox, const float* __restrict__ Wr,
+                                                        float* __restrict__ enc_cos, float* __restrict__ enc_sin,
+                                                        int Kc, const LGCtrl* __restrict__ ctrl) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int img = i / (Kc * ENC), rem = i % (Kc * ENC), tok = rem / ENC, f = rem % ENC;
+    if (img > 1 || tok >= ctrl->n[img]) return;
+    const float* xy = img ? xy1 : xy0;
+    const float kx = (xy[2 * tok] - bbox[img * 4 + 0]) / bbox[img * 4 + 2];
+    const float ky = (xy[2 * tok + 1] - bbox[img * 4 + 1]) / bbox[img * 4 + 2];
+    const float proj = kx * Wr[2 * f] + ky * Wr[2 * f + 1];
+    enc_cos[((size_t)img * Kc + tok) * ENC + f] = cosf(proj);
+    enc_sin[((size_t)img * Kc + tok) * ENC + f] = sinf(proj);
 }
 
 // Row-block -> (image, first row) for the two-image token buffers.
@@ -129,6 +137,21 @@ __device__ __forceinline__ RowDom row_domain(const LGCtrl* ctrl, int Kc) {
     d.row0 = (blockIdx.y % nb) * BM;
     d.n = ctrl->n[d.img];
     return d;
+}
+
+// XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (id % 8 picks the XCD,
+// each with a private 4 MiB L2 that does not survive a kernel boundary).  Tiles that share an
+// operand panel (all column tiles of one row block; all query blocks of one K/V slab) are given
+// ids that are congruent mod 8 and adjacent in dispatch order, so the panel misses L2 once per
+// XCD instead of once per tile.  Placement only changes speed, never results.
+__device__ __forceinline__ void xcd_tile(int n_inner, int& outer, int& inner) {
+    // linear id -> (outer, inner) with all `inner` of one `outer` on the same XCD;
+    // requires gridDim.y (outer count) % 8 == 0, otherwise identity
+    const int b = blockIdx.y * gridDim.x + blockIdx.x;
+    if ((gridDim.y & 7) != 0) { outer = blockIdx.y; inner = blockIdx.x; return; }
+    const int xcd = b & 7, idx = b >> 3;
+    outer = xcd + 8 * (idx / n_inner);
+    inner = idx % n_inner;
 }
 
 enum { EPI_PLAIN = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_CROSSQKV = 3 };
@@ -434,7 +457,11 @@ __device__ __forceinline__ float logsigmoidf_(float x) {   // min(x,0) - log1p(e
     return fminf(x, 0.0f) - log1pf(expf(-fabsf(x)));
 }
 
-// one wave per token: conf = sigmoid(w_c.x + b_c), mat = (w_m.x + b_m)
+// conf = sigmoid(w_c.x + b_c), mat = w_m.x + b_m per token.  One wave handles TOK_PER_WAVE tokens
+// (weights stay in registers); a block adds its count of unconfident tokens with ONE atomic
+// (same-address atomics retire one per ~11 ns, so 1024 blocks x 1 atomic was the kernel's cost).
+constexpr int TOK_PER_WAVE = 16;
+
 __global__ __launch_bounds__(256) void lg_token_heads_kernel(
     const float* __restrict__ x, const float* __restrict__ wc, const float* __restrict__ bc,
     const float* __restrict__ wm, const float* __restrict__ bm, long m_layer_stride, int use_stop_layer,
@@ -444,32 +471,29 @@ __global__ __launch_bounds__(256) void lg_token_heads_kernel(
     if (ctrl->stop == 2) return;
     if (ctrl->stop && !use_stop_layer) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int gw = blockIdx.x * 4 + wave;
-    const int img = gw / Kc, row = gw % Kc;
-    const bool live = img <= 1 && row < ctrl->n[img];
+    if (use_stop_layer) {
+        wm += (size_t)ctrl->stop_layer * m_layer_stride;
+        bm += (size_t)ctrl->stop_layer * m_layer_stride;   // both padded to the same stride
+    }
+    const float4 wmv = *reinterpret_cast<const float4*>(wm + lane * 4);
+    const float4 wcv = wc ? *reinterpret_cast<const float4*>(wc + lane * 4) : make_float4(0, 0, 0, 0);
+    const float bmv = bm[0], bcv = wc ? bc[0] : 0.0f;
     int unconf = 0;
-    if (live) {
-        if (use_stop_layer) {
-            wm += (size_t)ctrl->stop_layer * m_layer_stride;
-            bm += (size_t)ctrl->stop_layer * m_layer_stride;   // both padded to the same stride
-        }
+    const int tok0 = (blockIdx.x * 4 + wave) * TOK_PER_WAVE;
+    for (int j = 0; j < TOK_PER_WAVE; ++j) {
+        const int gt = tok0 + j;
+        const int img = gt / Kc, row = gt % Kc;
+        if (img > 1 || row >= ctrl->n[img]) continue;       // wave-uniform
         const float4 xv = *reinterpret_cast<const float4*>(x + ((size_t)img * Kc + row) * D + lane * 4);
-        float sm_ = 0.0f, sc = 0.0f;
-        {
-            const float4 w = *reinterpret_cast<const float4*>(wm + lane * 4);
-            sm_ = xv.x * w.x + xv.y * w.y + xv.z * w.z + xv.w * w.w;
-        }
-        if (wc) {
-            const float4 w = *reinterpret_cast<const float4*>(wc + lane * 4);
-            sc = xv.x * w.x + xv.y * w.y + xv.z * w.z + xv.w * w.w;
-        }
+        float sm_ = xv.x * wmv.x + xv.y * wmv.y + xv.z * wmv.z + xv.w * wmv.w;
+        float sc = xv.x * wcv.x + xv.y * wcv.y + xv.z * wcv.z + xv.w * wcv.w;
         for (int o = 32; o > 0; o >>= 1) { sm_ += __shfl_xor(sm_, o); sc += __shfl_xor(sc, o); }
         if (lane == 0) {
-            mat[img * Kc + row] = sm_ + bm[0];
+            mat[img * Kc + row] = sm_ + bmv;
             if (wc) {
-                const float c = sigmoidf_(sc + bc[0]);
+                const float c = sigmoidf_(sc + bcv);
                 conf[img * Kc + row] = c;
-                unconf = c < conf_thr;
+                unconf += c < conf_thr;
             }
         }
     }
@@ -833,19 +857,31 @@ struct LinearArgsH {
     const LGCtrl* ctrl; int Kc;
 };
 
+// LDS ring depth of the split-precision GEMM: as deep as 160 KiB allows (tiles in flight = depth - 1)
+template <int BM, int BN>
+constexpr int ring_depth() {
+    constexpr int stage_bytes = sslam::ring_stage_halves<BM, BN>() * 2;
+    constexpr int d = (160 * 1024) / stage_bytes;
+    return d > 4 ? 4 : (d < 2 ? 2 : d);
+}
+
 template <int BM, int BN, int TM, int TN, int EPI>
 __global__ __launch_bounds__(256) void lg_linear_h_kernel(LinearArgsH p) {
-    __shared__ GemmSmemH<BM, BN> sm;
+    extern __shared__ __attribute__((aligned(16))) _Float16 lg_ring[];
     if (p.ctrl->stop) return;
-    const RowDom rd = row_domain<BM>(p.ctrl, p.Kc);
+    int rb, cb;
+    xcd_tile(gridDim.x, rb, cb);
+    const int nb = (p.Kc + BM - 1) / BM;
+    RowDom rd;
+    rd.img = rb / nb; rd.row0 = (rb % nb) * BM; rd.n = p.ctrl->n[rd.img];
     if (rd.row0 >= rd.n) return;
-    const int col0 = blockIdx.x * BN;
+    const int col0 = cb * BN;
     const size_t ibase = (size_t)rd.img * p.Kc;
     GemmAH ga{{p.A0.hi + ibase * p.lda, p.A0.lo + ibase * p.lda},
               {p.A1.hi ? p.A1.hi + ibase * p.lda : p.A0.hi, p.A1.lo ? p.A1.lo + ibase * p.lda : p.A0.lo},
               p.lda, p.K0};
     f32x16 c1[TM][TN], c2[TM][TN];
-    gemm_mainloop_h<BM, BN, TM, TN>(ga, p.W, p.K, p.K, rd.row0, p.Kc, col0, p.N, sm, c1, c2);
+    gemm_mainloop_ring<BM, BN, TM, TN, ring_depth<BM, BN>()>(ga, p.W, p.K, p.K, rd.row0, p.Kc, col0, p.N, lg_ring, c1, c2);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -960,13 +996,15 @@ __global__ __launch_bounds__(256) void lg_ln_gelu_h_kernel(const float* __restri
 }
 
 // ---- attention, split precision --------------------------------------------------------
-constexpr int AH_LD = 72;            // halves per LDS row (64 + 8 pad): 144 B, 16 B aligned
-
+// K / V^T tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no
+// ds_write).  A wave-instruction writes 1 KiB = 8 rows of 128 B linearly, so the LDS image is
+// un-padded; bank conflicts are avoided by XOR-swizzling the 16-byte chunk index with
+// f(row) = (row >> 1) & 7, applied to the per-lane SOURCE address and to every read.
 struct __attribute__((aligned(16))) AttnSmemH {
-    _Float16 k_hi[2][AK * AH_LD];
-    _Float16 k_lo[2][AK * AH_LD];
-    _Float16 vt_hi[2][DH * AH_LD];
-    _Float16 vt_lo[2][DH * AH_LD];
+    _Float16 k_hi[2][AK * DH];
+    _Float16 k_lo[2][AK * DH];
+    _Float16 vt_hi[2][DH * AK];
+    _Float16 vt_lo[2][DH * AK];
 };
 
 struct AttnArgsH {
@@ -976,22 +1014,35 @@ struct AttnArgsH {
     int KS; int Kc; const LGCtrl* ctrl;
 };
 
-__global__ __launch_bounds__(256) void lg_attention_h_kernel(AttnArgsH p) {
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void lg_attention_h_kernel(AttnArgsH p) {
     __shared__ AttnSmemH sm;
     if (p.ctrl->stop) return;
-    const int img = blockIdx.y >> 2, head = blockIdx.y & 3;
+    // XCD-aware order: slab = (img, head, key split); its query blocks are congruent mod 8
+    const int nqb = gridDim.x, nslab = gridDim.y * gridDim.z;
+    int slab, qb;
+    {
+        const int b = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if ((nslab & 7) == 0) { const int xcd = b & 7, idx = b >> 3; slab = xcd + 8 * (idx / nqb); qb = idx % nqb; }
+        else { slab = blockIdx.z * gridDim.y + blockIdx.y; qb = blockIdx.x; }
+    }
+    const int z = slab / gridDim.y, ih = slab % gridDim.y;
+    const int img = ih >> 2, head = ih & 3;
     const int kimg = p.cross ? 1 - img : img;
     const int nq = p.ctrl->n[img], nk = p.ctrl->n[kimg];
-    const int q0 = blockIdx.x * AQ;
+    const int q0 = qb * AQ;
     if (q0 >= nq) return;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, lr = lane & 31;
-    const int z = blockIdx.z;
+    const int t = threadIdx.x, lane = t & 63, h = lane >> 5, lr = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int ntiles = (nk + AK - 1) / AK;
     const int t0 = (int)((long)z * ntiles / p.KS), t1 = (int)((long)(z + 1) * ntiles / p.KS);
 
     const size_t qoff = ((size_t)img * NH + head) * p.Kc * DH;
     const size_t koff = ((size_t)kimg * NH + head) * p.Kc * DH;   // same size for K and V^T planes
-    const _Float16 *Kh = p.K.hi + koff, *Kl = p.K.lo + koff, *Vh = p.VT.hi + koff, *Vl = p.VT.lo + koff;
 
     // Q fragments (B operand of S^T = K.Q^T): lane holds Q[query lr][dims 16 s + 8 h .. +7]; the
     // softmax scale * log2(e) is already folded in by the projection epilogue
@@ -1008,45 +1059,39 @@ __global__ __launch_bounds__(256) void lg_attention_h_kernel(AttnArgsH p) {
     for (int r = 0; r < 16; ++r) { o1a[r] = 0.0f; o2a[r] = 0.0f; o1b[r] = 0.0f; o2b[r] = 0.0f; }
     float m_run = -INFINITY, l_run = 0.0f;
 
-    uint4 gk0, gk1, gk2, gk3, gv0, gv1, gv2, gv3;    // named prefetch registers
-    gk0 = gk1 = gk2 = gk3 = gv0 = gv1 = gv2 = gv3 = make_uint4(0, 0, 0, 0);
-    const int ar = t >> 3, ac8 = (t & 7) * 8;        // (row, offset in halves) inside a 32-row slab
-#define ATTNH_GLOAD(tile_)                                                                  \
-    {                                                                                       \
-        const size_t k0_ = (size_t)min((tile_) * AK + ar, p.Kc - 1) * DH + ac8;             \
-        const size_t k1_ = (size_t)min((tile_) * AK + ar + 32, p.Kc - 1) * DH + ac8;        \
-        LDH8(gk0, Kh + k0_); LDH8(gk1, Kh + k1_); LDH8(gk2, Kl + k0_); LDH8(gk3, Kl + k1_);  \
-        const size_t v0_ = (size_t)ar * p.Kc + (size_t)(tile_) * AK + ac8;                  \
-        const size_t v1_ = (size_t)(ar + 32) * p.Kc + (size_t)(tile_) * AK + ac8;           \
-        LDH8(gv0, Vh + v0_); LDH8(gv1, Vh + v1_); LDH8(gv2, Vl + v0_); LDH8(gv3, Vl + v1_);  \
-    }
-#define ATTNH_SSTORE(buf_)                                                                  \
-    {                                                                                       \
-        const int o0_ = ar * AH_LD + ac8, o1_ = (ar + 32) * AH_LD + ac8;                    \
-        STH8(&sm.k_hi[buf_][o0_], gk0); STH8(&sm.k_hi[buf_][o1_], gk1);                     \
-        STH8(&sm.k_lo[buf_][o0_], gk2); STH8(&sm.k_lo[buf_][o1_], gk3);                     \
-        STH8(&sm.vt_hi[buf_][o0_], gv0); STH8(&sm.vt_hi[buf_][o1_], gv1);                   \
-        STH8(&sm.vt_lo[buf_][o0_], gv2); STH8(&sm.vt_lo[buf_][o1_], gv3);                   \
-    }
+    // tile loader: wave w owns plane w (K hi, K lo, V^T hi, V^T lo): 8 DMA instructions of 8 rows
+    const _Float16* gplane = (wave == 0 ? p.K.hi : wave == 1 ? p.K.lo : wave == 2 ? p.VT.hi : p.VT.lo) + koff;
+    const bool is_v = wave >= 2;
+    const int lrow = lane >> 3, lcp = lane & 7;
+    auto issue_tile = [&](int tile, int buf) {
+        _Float16* dst = wave == 0 ? sm.k_hi[buf] : wave == 1 ? sm.k_lo[buf] : wave == 2 ? sm.vt_hi[buf] : sm.vt_lo[buf];
+#pragma unroll
+        for (int rg = 0; rg < 8; ++rg) {
+            const int row = rg * 8 + lrow;
+            const int c = lcp ^ ((row >> 1) & 7);
+            const _Float16* src = is_v ? gplane + (size_t)row * p.Kc + (size_t)tile * AK + c * 8
+                                       : gplane + (size_t)min(tile * AK + row, p.Kc - 1) * DH + c * 8;
+            glds16(src, dst + rg * 8 * DH);
+        }
+    };
 
-    if (t0 < t1) {
-        ATTNH_GLOAD(t0);
-        ATTNH_SSTORE(0);
-    }
-    __syncthreads();
+    if (t0 < t1) issue_tile(t0, 0);
+    __syncthreads();                 // drains the DMA (vmcnt(0)) and publishes the tile
     int cur = 0;
     for (int tile = t0; tile < t1; ++tile) {
-        if (tile + 1 < t1) ATTNH_GLOAD(tile + 1);
+        if (tile + 1 < t1) issue_tile(tile + 1, cur ^ 1);
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             f32x16 s1, s2;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s1[r] = 0.0f; s2[r] = 0.0f; }
-            const int kro = (sub * 32 + lr) * AH_LD + 8 * h;
+            const int krow = sub * 32 + lr;
+            const int kswz = (krow >> 1) & 7;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const half8 kh = *reinterpret_cast<const half8*>(&sm.k_hi[cur][kro + 16 * s]);
-                const half8 kl = *reinterpret_cast<const half8*>(&sm.k_lo[cur][kro + 16 * s]);
+                const int ko = krow * DH + (((2 * s + h) ^ kswz) * 8);
+                const half8 kh = *reinterpret_cast<const half8*>(&sm.k_hi[cur][ko]);
+                const half8 kl = *reinterpret_cast<const half8*>(&sm.k_lo[cur][ko]);
                 s1 = mfma16(kh, qh[s], s1);
                 s2 = mfma16(kh, ql[s], s2);
                 s2 = mfma16(kl, qh[s], s2);
@@ -1055,40 +1100,50 @@ __global__ __launch_bounds__(256) void lg_attention_h_kernel(AttnArgsH p) {
             float sv[16];
             float tmax = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                sv[r] = s1[r] + s2[r] * SPLIT_INV;
-                if (kbase + acc_row(r, lane) >= nk) sv[r] = -INFINITY;
-                tmax = fmaxf(tmax, sv[r]);
+            for (int r = 0; r < 16; ++r) sv[r] = s1[r] + s2[r] * SPLIT_INV;
+            if (kbase + 32 > nk) {                       // ragged tail only (block-uniform)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kbase + acc_row(r, lane) >= nk) sv[r] = -INFINITY;
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sv[r]);
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
             const float m_new = fmaxf(m_run, tmax);
-            const float alpha = exp2f(m_run - m_new);
+            const bool grow = !__all(m_new == m_run);    // wave-uniform: running max moved for some query
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // raw v_exp_f32: args <= 0
             m_run = m_new;
             float psum = 0.0f;
             half8 ph[2], pl[2];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f(sv[r] - m_new);
+                const float pv = __builtin_amdgcn_exp2f(sv[r] - m_new);
                 psum += pv;
                 _Float16 hh, ll;
                 split_f32(pv, hh, ll);
                 ph[r >> 3][r & 7] = hh;                  // k-slot j' of step s2 = accumulator reg 8 s2 + j'
                 pl[r >> 3][r & 7] = ll;
             }
-            l_run = l_run * alpha + psum;
+            if (grow) {                                  // alpha == 1 exactly otherwise
+                l_run *= alpha;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { o1a[r] *= alpha; o2a[r] *= alpha; o1b[r] *= alpha; o2b[r] *= alpha; }
+                for (int r = 0; r < 16; ++r) { o1a[r] *= alpha; o2a[r] *= alpha; o1b[r] *= alpha; o2b[r] *= alpha; }
+            }
+            l_run += psum;
             // O^T[d][i] += V^T[d][key] P^T[key][i]; k-slot j' of step s2 <-> key 16 s2 + 8 (j'>>2) + 4 h + (j'&3)
 #pragma unroll
             for (int s2i = 0; s2i < 2; ++s2i) {
-                const int kc = sub * 32 + 16 * s2i + 4 * h;
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    const int vo = (db * 32 + lr) * AH_LD + kc;
-                    const half4 vh0 = *reinterpret_cast<const half4*>(&sm.vt_hi[cur][vo]);
-                    const half4 vh1 = *reinterpret_cast<const half4*>(&sm.vt_hi[cur][vo + 8]);
-                    const half4 vl0 = *reinterpret_cast<const half4*>(&sm.vt_lo[cur][vo]);
-                    const half4 vl1 = *reinterpret_cast<const half4*>(&sm.vt_lo[cur][vo + 8]);
+                    const int d = db * 32 + lr;
+                    const int vswz = (d >> 1) & 7;
+                    const int c0 = 4 * sub + 2 * s2i;
+                    const int vo0 = d * AK + ((c0 ^ vswz) * 8) + 4 * h;
+                    const int vo1 = d * AK + (((c0 + 1) ^ vswz) * 8) + 4 * h;
+                    const half4 vh0 = *reinterpret_cast<const half4*>(&sm.vt_hi[cur][vo0]);
+                    const half4 vh1 = *reinterpret_cast<const half4*>(&sm.vt_hi[cur][vo1]);
+                    const half4 vl0 = *reinterpret_cast<const half4*>(&sm.vt_lo[cur][vo0]);
+                    const half4 vl1 = *reinterpret_cast<const half4*>(&sm.vt_lo[cur][vo1]);
                     const half8 vh = __builtin_shufflevector(vh0, vh1, 0, 1, 2, 3, 4, 5, 6, 7);
                     const half8 vl = __builtin_shufflevector(vl0, vl1, 0, 1, 2, 3, 4, 5, 6, 7);
                     if (db == 0) {
@@ -1103,12 +1158,9 @@ __global__ __launch_bounds__(256) void lg_attention_h_kernel(AttnArgsH p) {
                 }
             }
         }
-        if (tile + 1 < t1) ATTNH_SSTORE(cur ^ 1);
-        __syncthreads();
+        __syncthreads();             // next tile landed (vmcnt(0)); everyone is done reading `cur`
         cur ^= 1;
     }
-#undef ATTNH_GLOAD
-#undef ATTNH_SSTORE
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const int qrow = q0 + wave * 32 + lr;
@@ -1168,9 +1220,10 @@ __global__ __launch_bounds__(256) void lg_attn_merge_h_kernel(const float* __res
 // ======================================================================== //
 //  host side
 // ======================================================================== //
+// out_proj / to_out are folded into w1 / cw1 at pack time (weights.py _fold_out_proj)
 struct LGLayerW {
-    const float *wqkv, *bqkv, *wo, *bo, *w1, *b1, *lnw, *lnb, *w2, *b2;
-    const float *cqkv, *cbqkv, *cwo, *cbo, *cw1, *cb1, *clnw, *clnb, *cw2, *cb2;
+    const float *wqkv, *bqkv, *w1, *b1, *lnw, *lnb, *w2, *b2;
+    const float *cqkv, *cbqkv, *cw1, *cb1, *clnw, *clnb, *cw2, *cb2;
 };
 
 struct sslam_lightglue {
@@ -1190,7 +1243,7 @@ struct sslam_lightglue {
     LGCtrl* ctrl;
     float *x, *enc_cos, *enc_sin, *q, *k, *v, *msg, *msg2, *hid, *tx, *tc, *ts;
     float *o_part, *m_part, *l_part, *conf, *mat, *md, *sim, *rmax, *rlog, *cmax, *clog, *best0;
-    float *cpmax, *cpsum, *cpval;
+    float *cpmax, *cpsum, *cpval, *bbox;
     int* cparg;
     int *ind, *gmap, *prune, *arg0, *arg1;
     float *in_xy, *in_desc, *out_score;
@@ -1217,10 +1270,10 @@ int lg_bind_weights(sslam_lightglue* g, size_t n_floats) {
     g->w_in = take((size_t)D * DIN); g->b_in = take(D); g->w_r = take(ENC * 2);
     for (int i = 0; i < NL; ++i) {
         LGLayerW& l = g->L[i];
-        l.wqkv = take(3 * D * D); l.bqkv = take(3 * D); l.wo = take(D * D); l.bo = take(D);
+        l.wqkv = take(3 * D * D); l.bqkv = take(3 * D);
         l.w1 = take(4 * D * D); l.b1 = take(2 * D); l.lnw = take(2 * D); l.lnb = take(2 * D);
         l.w2 = take(2 * D * D); l.b2 = take(D);
-        l.cqkv = take(2 * D * D); l.cbqkv = take(2 * D); l.cwo = take(D * D); l.cbo = take(D);
+        l.cqkv = take(2 * D * D); l.cbqkv = take(2 * D);
         l.cw1 = take(4 * D * D); l.cb1 = take(2 * D); l.clnw = take(2 * D); l.clnb = take(2 * D);
         l.cw2 = take(2 * D * D); l.cb2 = take(D);
     }
@@ -1296,8 +1349,15 @@ SplitPtr wsp(const sslam_lightglue* g, const float* w) {
 
 template <int BM, int BN, int TM, int TN, int EPI>
 void launch_linear_h(hipStream_t s, const LinearArgsH& a) {
+    constexpr size_t lds = (size_t)ring_depth<BM, BN>() * sslam::ring_stage_halves<BM, BN>() * sizeof(_Float16);
+    static bool configured = false;
+    if (!configured) {      // > 64 KiB of dynamic LDS needs the opt-in attribute (once per instantiation)
+        (void)hipFuncSetAttribute((const void*)lg_linear_h_kernel<BM, BN, TM, TN, EPI>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configured = true;
+    }
     dim3 grid(a.N / BN, 2 * sslam::cdiv(a.Kc, BM));
-    hipLaunchKernelGGL((lg_linear_h_kernel<BM, BN, TM, TN, EPI>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((lg_linear_h_kernel<BM, BN, TM, TN, EPI>), grid, dim3(256), lds, s, a);
 }
 
 LinearArgsH linh(const sslam_lightglue* g, SplitPtr A0, SplitPtr A1, int lda, int K0, int K, const float* W,
@@ -1327,14 +1387,14 @@ void launch_attention_h(sslam_lightglue* g, hipStream_t s, SplitPtr Q, SplitPtr 
 
 // one transformer layer (self + cross block) on the split-precision path
 void lg_layer_h(sslam_lightglue* g, hipStream_t s, const LGLayerW& l) {
-    const SplitPtr xs{g->xs_hi, g->xs_lo}, msgs{g->msgs_hi, g->msgs_lo}, msg2s{g->msg2s_hi, g->msg2s_lo};
+    const SplitPtr xs{g->xs_hi, g->xs_lo}, msgs{g->msgs_hi, g->msgs_lo};
     const SplitPtr hids{g->hids_hi, g->hids_lo}, none{nullptr, nullptr};
     const SplitPtr qs{g->qs_hi, g->qs_lo}, ks{g->ks_hi, g->ks_lo}, vts{g->vts_hi, g->vts_lo};
     const unsigned tokblocks = sslam::cdiv(2 * g->Kc, 4);
     const float sm_scale = 0.125f * 1.4426950408889634f;        // 1/sqrt(64) * log2(e)
     auto ffn = [&](const float* w1, const float* b1, const float* lnw, const float* lnb, const float* w2,
                    const float* b2) {
-        LinearArgsH a = linh(g, xs, msg2s, D, D, 2 * D, w1, b1, 2 * D);
+        LinearArgsH a = linh(g, xs, msgs, D, D, 2 * D, w1, b1, 2 * D);      // [x | attention context]
         a.out = g->hid; a.ldo = 2 * D;
         launch_linear_h<64, 128, 1, 2, EPH_F32>(s, a);
         hipLaunchKernelGGL(lg_ln_gelu_h_kernel, dim3(tokblocks), dim3(256), 0, s, g->hid,
@@ -1347,14 +1407,9 @@ void lg_layer_h(sslam_lightglue* g, hipStream_t s, const LGLayerW& l) {
         LinearArgsH a = linh(g, xs, none, D, D, D, l.wqkv, l.bqkv, 3 * D);
         a.q = SplitOut{g->qs_hi, g->qs_lo}; a.k = SplitOut{g->ks_hi, g->ks_lo}; a.vt = SplitOut{g->vts_hi, g->vts_lo};
         a.q_scale = sm_scale; a.k_scale = 1.0f;
-        launch_linear_h<64, 128, 1, 2, EPH_QKV>(s, a);
+        launch_linear_h<64, 192, 1, 3, EPH_QKV>(s, a);       // 768 / 192 = 4 column tiles -> 256 blocks, one round
     }
     launch_attention_h(g, s, qs, ks, vts, 0);
-    {
-        LinearArgsH a = linh(g, msgs, none, D, D, D, l.wo, l.bo, D);
-        a.outs = SplitOut{g->msg2s_hi, g->msg2s_lo}; a.ldo = D;
-        launch_linear_h<64, 64, 1, 1, EPH_SPLIT>(s, a);
-    }
     ffn(l.w1, l.b1, l.lnw, l.lnb, l.w2, l.b2);
     {   // cross block: the shared qk projection is both query and key -> sqrt(scale) on it
         LinearArgsH a = linh(g, xs, none, D, D, D, l.cqkv, l.cbqkv, 2 * D);
@@ -1363,11 +1418,6 @@ void lg_layer_h(sslam_lightglue* g, hipStream_t s, const LGLayerW& l) {
         launch_linear_h<64, 128, 1, 2, EPH_CROSS>(s, a);
     }
     launch_attention_h(g, s, qs, qs, vts, 1);
-    {
-        LinearArgsH a = linh(g, msgs, none, D, D, D, l.cwo, l.cbo, D);
-        a.outs = SplitOut{g->msg2s_hi, g->msg2s_lo}; a.ldo = D;
-        launch_linear_h<64, 64, 1, 1, EPH_SPLIT>(s, a);
-    }
     ffn(l.cw1, l.cb1, l.clnw, l.clnb, l.cw2, l.cb2);
 }
 
@@ -1378,13 +1428,16 @@ int lg_enqueue(sslam_lightglue* g, int M, int N, const int32_t* m_dev, const int
     hipStream_t s = g->ctx->stream;
     const int Kc = g->Kc;
     hipLaunchKernelGGL(lg_prepare_kernel, dim3(2), dim3(1024), 0, s, g->in_xy, g->in_xy + 2 * Kc, M, N,
-                       m_dev, n_dev, Kc, g->w_r, g->enc_cos, g->enc_sin, g->ind, g->prune, g->ctrl);
+                       m_dev, n_dev, Kc, g->bbox, g->ind, g->prune, g->ctrl);
+    hipLaunchKernelGGL(lg_posenc_kernel, dim3(sslam::cdiv(2 * Kc * ENC, 256)), dim3(256), 0, s, g->in_xy,
+                       g->in_xy + 2 * Kc, g->bbox, g->w_r, g->enc_cos, g->enc_sin, Kc, g->ctrl);
     {   // input_proj (lightglue.py: desc = self.input_proj(desc))
         LinearArgs a = lin(g, g->in_desc, DIN, nullptr, 0, DIN, DIN, g->w_in, g->b_in, D);
         a.out = g->x; a.ldo = D;
         launch_linear<64, 64, 1, 1, EPI_PLAIN>(s, a);
     }
     const unsigned tokblocks = sslam::cdiv(2 * Kc, 4);
+    const unsigned headblocks = sslam::cdiv(2 * Kc, 4 * TOK_PER_WAVE);
     const unsigned splitblocks = (unsigned)(((size_t)2 * Kc * D + 255) / 256);
     if (g->precision == 1)
         hipLaunchKernelGGL(lg_split_rows_kernel, dim3(splitblocks), dim3(256), 0, s, g->x, g->xs_hi, g->xs_lo, D, Kc,
@@ -1401,12 +1454,7 @@ int lg_enqueue(sslam_lightglue* g, int M, int N, const int32_t* m_dev, const int
             launch_linear<64, 128, 1, 2, EPI_QKV>(s, a);
         }
         launch_attention(g, s, g->q, g->k, g->v, 0);
-        {
-            LinearArgs a = lin(g, g->msg, D, nullptr, 0, D, D, l.wo, l.bo, D);
-            a.out = g->msg2; a.ldo = D;
-            launch_linear<64, 64, 1, 1, EPI_PLAIN>(s, a);
-        }
-        launch_ffn(g, s, g->msg2, l.w1, l.b1, l.lnw, l.lnb, l.w2, l.b2);
+        launch_ffn(g, s, g->msg, l.w1, l.b1, l.lnw, l.lnb, l.w2, l.b2);
         // ---- cross block
         {
             LinearArgs a = lin(g, g->x, D, nullptr, 0, D, D, l.cqkv, l.cbqkv, 2 * D);
@@ -1414,12 +1462,7 @@ int lg_enqueue(sslam_lightglue* g, int M, int N, const int32_t* m_dev, const int
             launch_linear<64, 128, 1, 2, EPI_CROSSQKV>(s, a);
         }
         launch_attention(g, s, g->q, g->q, g->v, 1);
-        {
-            LinearArgs a = lin(g, g->msg, D, nullptr, 0, D, D, l.cwo, l.cbo, D);
-            a.out = g->msg2; a.ldo = D;
-            launch_linear<64, 64, 1, 1, EPI_PLAIN>(s, a);
-        }
-        launch_ffn(g, s, g->msg2, l.cw1, l.cb1, l.clnw, l.clnb, l.cw2, l.cb2);
+        launch_ffn(g, s, g->msg, l.cw1, l.cb1, l.clnw, l.clnb, l.cw2, l.cb2);
         }
         if (i == NL - 1) break;
         // ---- early stop + point pruning (lightglue.py check_if_stop / get_pruning_mask)
@@ -1427,7 +1470,7 @@ int lg_enqueue(sslam_lightglue* g, int M, int N, const int32_t* m_dev, const int
         const int do_prune = g->width_conf > 0.0f;
         if (!do_stop && !do_prune) continue;
         const float thr = conf_threshold(i);
-        hipLaunchKernelGGL(lg_token_heads_kernel, dim3(tokblocks), dim3(256), 0, s, g->x,
+        hipLaunchKernelGGL(lg_token_heads_kernel, dim3(headblocks), dim3(256), 0, s, g->x,
                            do_stop ? g->tc_w[i] : nullptr, do_stop ? g->tc_b[i] : nullptr,
                            g->mt_w + (size_t)i * g->mt_stride, g->mt_b + (size_t)i * g->mt_stride, 0L, 0,
                            thr, g->conf, g->mat, g->ctrl, Kc, do_stop);
@@ -1452,7 +1495,7 @@ int lg_enqueue(sslam_lightglue* g, int M, int N, const int32_t* m_dev, const int
         a.out_scale = 0.25f;                    // 1 / 256^0.25
         launch_linear<64, 64, 1, 1, EPI_PLAIN>(s, a);
     }
-    hipLaunchKernelGGL(lg_token_heads_kernel, dim3(tokblocks), dim3(256), 0, s, g->x, nullptr, nullptr,
+    hipLaunchKernelGGL(lg_token_heads_kernel, dim3(headblocks), dim3(256), 0, s, g->x, nullptr, nullptr,
                        g->mt_w, g->mt_b, g->mt_stride, 1, 0.0f, g->conf, g->mat, g->ctrl, Kc, 0);
     {
         SimArgs a{g->md, g->sim, Kc, g->ctrl};
@@ -1503,7 +1546,7 @@ int sslam_lightglue_create(sslam_ctx* ctx, const float* weights, size_t n_floats
         g->o_part = A.take<float>((size_t)g->KS * 2 * NH * K * DH);
         g->m_part = A.take<float>((size_t)g->KS * 2 * NH * K);
         g->l_part = A.take<float>((size_t)g->KS * 2 * NH * K);
-        g->conf = A.take<float>(2 * K); g->mat = A.take<float>(2 * K);
+        g->conf = A.take<float>(2 * K); g->mat = A.take<float>(2 * K); g->bbox = A.take<float>(8);
         g->sim = A.take<float>(K * K);
         g->rmax = A.take<float>(K); g->rlog = A.take<float>(K); g->cmax = A.take<float>(K);
         g->clog = A.take<float>(K); g->best0 = A.take<float>(K);

@@ -112,25 +112,39 @@ def _qkv_row_perm():
     return perm
 
 
+def _fold_out_proj(w1, b1, wo, bo):
+    """ffn.0 applied to cat[x, out_proj(ctx)] == ffn.0' applied to cat[x, ctx] with
+    W' = [W1x | W1m @ Wo],  b' = b1 + W1m @ bo  (W1 = [W1x | W1m] over the concat axis).
+    The product is formed in float64 and rounded once; this removes one GEMM per block."""
+    d = wo.shape[0]
+    w1x, w1m = w1[:, :d].astype(np.float64), w1[:, d:].astype(np.float64)
+    wf = np.concatenate([w1x, w1m @ wo.astype(np.float64)], axis=1)
+    bf = b1.astype(np.float64) + w1m @ bo.astype(np.float64)
+    return wf.astype(np.float32), bf.astype(np.float32)
+
+
 def lightglue_order(sd):
-    """(name, array) list in blob order.  Pure re-indexing / concatenation of
-    upstream tensors - no arithmetic, so numerics are untouched."""
+    """(name, array) list in blob order.  Re-indexing / concatenation of upstream tensors, plus
+    one algebraic fold per attention block: the output projection (out_proj / to_out) is
+    multiplied into the message half of the FFN's first Linear (`_fold_out_proj`)."""
     perm = _qkv_row_perm()
     out = [("input_proj.weight", sd["input_proj.weight"]), ("input_proj.bias", sd["input_proj.bias"]),
            ("posenc.Wr.weight", sd["posenc.Wr.weight"])]
     for i in range(LG_LAYERS):
         p = f"transformers.{i}.self_attn"
         out += [(p + ".Wqkv.weight[perm]", sd[p + ".Wqkv.weight"][perm]),
-                (p + ".Wqkv.bias[perm]", sd[p + ".Wqkv.bias"][perm]),
-                (p + ".out_proj.weight", sd[p + ".out_proj.weight"]),
-                (p + ".out_proj.bias", sd[p + ".out_proj.bias"])]
-        out += [(p + f".ffn.{j}.{w}", sd[p + f".ffn.{j}.{w}"]) for j in (0, 1, 3) for w in ("weight", "bias")]
+                (p + ".Wqkv.bias[perm]", sd[p + ".Wqkv.bias"][perm])]
+        wf, bf = _fold_out_proj(sd[p + ".ffn.0.weight"], sd[p + ".ffn.0.bias"],
+                                sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"])
+        out += [(p + ".ffn.0.weight*out_proj", wf), (p + ".ffn.0.bias*out_proj", bf)]
+        out += [(p + f".ffn.{j}.{w}", sd[p + f".ffn.{j}.{w}"]) for j in (1, 3) for w in ("weight", "bias")]
         p = f"transformers.{i}.cross_attn"
         out += [(p + ".to_qk|to_v.weight", np.concatenate([sd[p + ".to_qk.weight"], sd[p + ".to_v.weight"]], 0)),
-                (p + ".to_qk|to_v.bias", np.concatenate([sd[p + ".to_qk.bias"], sd[p + ".to_v.bias"]], 0)),
-                (p + ".to_out.weight", sd[p + ".to_out.weight"]),
-                (p + ".to_out.bias", sd[p + ".to_out.bias"])]
-        out += [(p + f".ffn.{j}.{w}", sd[p + f".ffn.{j}.{w}"]) for j in (0, 1, 3) for w in ("weight", "bias")]
+                (p + ".to_qk|to_v.bias", np.concatenate([sd[p + ".to_qk.bias"], sd[p + ".to_v.bias"]], 0))]
+        wf, bf = _fold_out_proj(sd[p + ".ffn.0.weight"], sd[p + ".ffn.0.bias"],
+                                sd[p + ".to_out.weight"], sd[p + ".to_out.bias"])
+        out += [(p + ".ffn.0.weight*to_out", wf), (p + ".ffn.0.bias*to_out", bf)]
+        out += [(p + f".ffn.{j}.{w}", sd[p + f".ffn.{j}.{w}"]) for j in (1, 3) for w in ("weight", "bias")]
     for i in range(LG_LAYERS):
         p = f"log_assignment.{i}"
         out += [(p + ".final_proj.weight", sd[p + ".final_proj.weight"]),
