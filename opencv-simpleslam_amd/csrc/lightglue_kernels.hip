@@ -857,12 +857,15 @@ struct LinearArgsH {
     const LGCtrl* ctrl; int Kc;
 };
 
-// LDS ring depth of the split-precision GEMM: as deep as 160 KiB allows (tiles in flight = depth - 1)
+// LDS ring depth of the split-precision GEMM.  Depth beyond 2 bought nothing measurable (the k-loop is
+// bound by the per-CU load rate, not by tiles in flight), while a small footprint lets blocks of
+// concurrently running kernels (other pairs / the extractor on other streams) share a CU.
+constexpr int RING_MAX = 2;
 template <int BM, int BN>
 constexpr int ring_depth() {
     constexpr int stage_bytes = sslam::ring_stage_halves<BM, BN>() * 2;
     constexpr int d = (160 * 1024) / stage_bytes;
-    return d > 4 ? 4 : (d < 2 ? 2 : d);
+    return d > RING_MAX ? RING_MAX : (d < 2 ? 2 : d);
 }
 
 template <int BM, int BN, int TM, int TN, int EPI>
