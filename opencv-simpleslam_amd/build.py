@@ -49,10 +49,12 @@ def build_native(force: bool = False, verbose: bool = False) -> Path:
     if not sources:
         raise RuntimeError(f"no .hip sources under {CSRC}")
 
+    extra = os.environ.get("SSLAM_EXTRA_HIPCC_FLAGS", "").split()     # experiments only (e.g. -DSSLAM_DBG=1)
+
     def compile_one(src: Path):
         obj = obj_dir / (src.stem + ".o")
-        if force or _needs_rebuild(obj, [src, *headers]):
-            cmd = [hipcc, *HIPCC_FLAGS, "-c", str(src), "-o", str(obj)]
+        if force or extra or _needs_rebuild(obj, [src, *headers]):
+            cmd = [hipcc, *HIPCC_FLAGS, *extra, "-c", str(src), "-o", str(obj)]
             if verbose:
                 print(" ".join(cmd), flush=True)
             res = subprocess.run(cmd, capture_output=True, text=True)

@@ -38,6 +38,7 @@ using sslam::GemmSmemH;
 using sslam::GemmAH;
 using sslam::gemm_mainloop_h;
 using sslam::gemm_mainloop_ring;
+using sslam::panel_index;
 using sslam::mfma16;
 using sslam::split_f32;
 using sslam::SPLIT_INV;
@@ -825,13 +826,17 @@ __global__ __launch_bounds__(1024) void lg_emit_kernel(
 // ======================================================================== //
 struct SplitOut { _Float16* hi; _Float16* lo; };
 
-__global__ void lg_split_kernel(const float* __restrict__ src, _Float16* __restrict__ hi,
-                                _Float16* __restrict__ lo, size_t n) {
+// weight matrix W[N][K] (row-major fp32) -> split planes in k-panel layout [K/64][N][64]
+__global__ void lg_split_weight_kernel(const float* __restrict__ src, _Float16* __restrict__ hi,
+                                       _Float16* __restrict__ lo, int N, int K) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) split_f32(src[i], hi[i], lo[i]);
+    if (i >= (size_t)N * K) return;
+    const int n = (int)(i / K), k = (int)(i % K);
+    const size_t o = panel_index(n, k, N);
+    split_f32(src[i], hi[o], lo[o]);
 }
 
-// row-domain split of a [2][Kc][ld] activation (input descriptors / pruned token states)
+// token states x[2][Kc][256] -> split planes in k-panel layout over the 2*Kc rows
 __global__ void lg_split_rows_kernel(const float* __restrict__ src, _Float16* __restrict__ hi,
                                      _Float16* __restrict__ lo, int ld, int Kc,
                                      const LGCtrl* __restrict__ ctrl) {
@@ -839,9 +844,10 @@ __global__ void lg_split_rows_kernel(const float* __restrict__ src, _Float16* __
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t per = (size_t)Kc * ld;
     if (i >= 2 * per) return;
-    const int img = (int)(i / per), row = (int)((i % per) / ld);
+    const int img = (int)(i / per), row = (int)((i % per) / ld), col = (int)(i % ld);
     if (row >= ctrl->n[img]) return;
-    split_f32(src[i], hi[i], lo[i]);
+    const size_t o = panel_index(img * Kc + row, col, 2 * Kc);
+    split_f32(src[i], hi[o], lo[o]);
 }
 
 enum { EPH_QKV = 0, EPH_CROSS = 1, EPH_SPLIT = 2, EPH_F32 = 3, EPH_RESID = 4 };
@@ -860,7 +866,7 @@ struct LinearArgsH {
 // LDS ring depth of the split-precision GEMM.  Depth beyond 2 bought nothing measurable (the k-loop is
 // bound by the per-CU load rate, not by tiles in flight), while a small footprint lets blocks of
 // concurrently running kernels (other pairs / the extractor on other streams) share a CU.
-constexpr int RING_MAX = 2;
+constexpr int RING_MAX = 3;
 template <int BM, int BN>
 constexpr int ring_depth() {
     constexpr int stage_bytes = sslam::ring_stage_halves<BM, BN>() * 2;
@@ -869,7 +875,7 @@ constexpr int ring_depth() {
 }
 
 template <int BM, int BN, int TM, int TN, int EPI>
-__global__ __launch_bounds__(256) void lg_linear_h_kernel(LinearArgsH p) {
+__global__ __launch_bounds__(512) void lg_linear_h_kernel(LinearArgsH p) {
     extern __shared__ __attribute__((aligned(16))) _Float16 lg_ring[];
     if (p.ctrl->stop) return;
     int rb, cb;
@@ -880,84 +886,128 @@ __global__ __launch_bounds__(256) void lg_linear_h_kernel(LinearArgsH p) {
     if (rd.row0 >= rd.n) return;
     const int col0 = cb * BN;
     const size_t ibase = (size_t)rd.img * p.Kc;
-    GemmAH ga{{p.A0.hi + ibase * p.lda, p.A0.lo + ibase * p.lda},
-              {p.A1.hi ? p.A1.hi + ibase * p.lda : p.A0.hi, p.A1.lo ? p.A1.lo + ibase * p.lda : p.A0.lo},
-              p.lda, p.K0};
+    GemmAH ga{{p.A0.hi, p.A0.lo}, {p.A1.hi ? p.A1.hi : p.A0.hi, p.A1.lo ? p.A1.lo : p.A0.lo}, p.lda, p.K0};
     f32x16 c1[TM][TN], c2[TM][TN];
-    gemm_mainloop_ring<BM, BN, TM, TN, ring_depth<BM, BN>()>(ga, p.W, p.K, p.K, rd.row0, p.Kc, col0, p.N, lg_ring, c1, c2);
+    // plane rows are global token rows (image-major, 2*Kc per panel); clamp inside this image
+    gemm_mainloop_ring<BM, BN, TM, TN, ring_depth<BM, BN>()>(ga, p.W, 2 * p.Kc, p.K, (int)ibase + rd.row0,
+                                                             (int)ibase + p.Kc, col0, p.N, lg_ring, c1, c2);
+    if (threadIdx.x >= 256) return;                    // producer waves (4-7) are done
+#if defined(SSLAM_DBG_NOEPI)
+    if (c1[0][0][0] != 123456.0f) return;
+#endif
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // ---- epilogue.  The accumulator tile has its columns on lanes and its rows in registers, so a
+    // direct store would be 2-byte (split planes) or 4-byte pieces per lane and is store-issue bound
+    // (measured 5-13 us of a 18-24 us kernel).  Stage the fp32 tile in LDS (the ring is free now),
+    // then every thread owns 8 consecutive columns of one row (or 8 consecutive rows of one V
+    // column) and writes 16-byte pieces.
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    constexpr int ELD = BN + 4;                        // fp32 row stride of the staged tile
+    float* epi = reinterpret_cast<float*>(lg_ring);
+    __syncthreads();                                   // consumers are done with the last k-tile
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = col0 + wn * 32 * TN + j * 32 + (lane & 31);
-            const float b = p.bias[col];
-            float val[16];
+            const int cl = wn * 32 * TN + j * 32 + (lane & 31);
+            const float bv = p.bias[col0 + cl];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) val[r] = (c1[i][j][r] + c2[i][j][r] * SPLIT_INV) + b;
-            const int rbase = rd.row0 + wm * 32 * TM + i * 32;
-            if constexpr (EPI == EPH_QKV || EPI == EPH_CROSS) {
-                // EPH_QKV cols [q|k|v][head][d]; EPH_CROSS cols [qk|v][head][d]
-                const int s = col >> 8, hd = (col >> 6) & 3, d = col & 63;
-                const bool is_v = (EPI == EPH_QKV) ? (s == 2) : (s == 1);
-                if (!is_v) {
-                    const float scale = (EPI == EPH_QKV && s == 1) ? p.k_scale : p.q_scale;
-                    SplitOut dst = (EPI == EPH_QKV && s == 1) ? p.k : p.q;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = rbase + acc_row(r, lane);
-                        float v = val[r];
-                        if constexpr (EPI == EPH_QKV) {
-                            const float partner = __shfl_xor(v, 1);
-                            const int rr = min(row, p.Kc - 1);
-                            const float c = p.enc_cos[(ibase + rr) * ENC + (d >> 1)];
-                            const float sn = p.enc_sin[(ibase + rr) * ENC + (d >> 1)];
-                            v = (d & 1) ? (v * c + partner * sn) : (v * c - partner * sn);
-                        }
-                        v *= scale;
-                        if (row < rd.n) {
-                            const size_t o = (((size_t)rd.img * NH + hd) * p.Kc + row) * DH + d;
-                            split_f32(v, dst.hi[o], dst.lo[o]);
-                        }
-                    }
-                } else {
-                    // V transposed: vt[img][head][d][token]; 4 consecutive tokens per register group
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const int row = rbase + 8 * g4 + 4 * (lane >> 5);
-                        half4 h4, l4;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            _Float16 hh, ll;
-                            split_f32(val[4 * g4 + e], hh, ll);
-                            h4[e] = hh; l4[e] = ll;
-                        }
-                        const size_t o = (((size_t)rd.img * NH + hd) * DH + d) * p.Kc + row;
-                        if (row + 3 < rd.n) {
-                            *reinterpret_cast<half4*>(p.vt.hi + o) = h4;
-                            *reinterpret_cast<half4*>(p.vt.lo + o) = l4;
-                        } else {
-                            for (int e = 0; e < 4; ++e)
-                                if (row + e < rd.n) { p.vt.hi[o + e] = h4[e]; p.vt.lo[o + e] = l4[e]; }
-                        }
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rbase + acc_row(r, lane);
-                    if (row < rd.n) {
-                        const size_t o = (ibase + row) * p.ldo + col;
-                        float v = val[r];
-                        if constexpr (EPI == EPH_RESID) v += p.out[o];
-                        if constexpr (EPI == EPH_F32 || EPI == EPH_RESID) p.out[o] = v;
-                        if constexpr (EPI == EPH_SPLIT || EPI == EPH_RESID) split_f32(v, p.outs.hi[o], p.outs.lo[o]);
-                    }
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wm * 32 * TM + i * 32 + acc_row(r, lane);
+                epi[rl * ELD + cl] = (c1[i][j][r] + c2[i][j][r] * SPLIT_INV) + bv;
             }
         }
+    __syncthreads();
+
+    const int grow0 = (int)ibase + rd.row0;            // global plane row of tile row 0
+    auto split8 = [](const float (&v)[8], uint4& hi, uint4& lo) {
+        half8 hh, ll;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { _Float16 a, b2; split_f32(v[e], a, b2); hh[e] = a; ll[e] = b2; }
+        hi = *reinterpret_cast<uint4*>(&hh);
+        lo = *reinterpret_cast<uint4*>(&ll);
+    };
+    constexpr int CH = BN / 8;                         // 8-column chunks per row
+    for (int u = t; u < BM * CH; u += 256) {
+        const int rl = u / CH, cl = (u % CH) * 8;
+        const int row = rd.row0 + rl, col = col0 + cl;
+        if (row >= rd.n) continue;
+        float v[8];
+        {
+            const float4 a = *reinterpret_cast<const float4*>(&epi[rl * ELD + cl]);
+            const float4 b4 = *reinterpret_cast<const float4*>(&epi[rl * ELD + cl + 4]);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b4.x; v[5] = b4.y; v[6] = b4.z; v[7] = b4.w;
+        }
+        if constexpr (EPI == EPH_QKV || EPI == EPH_CROSS) {
+            const int s = col >> 8, hd = (col >> 6) & 3, d = col & 63;
+            const bool is_v = (EPI == EPH_QKV) ? (s == 2) : (s == 1);
+            if (is_v) continue;                        // V goes out transposed below
+            const bool is_k = (EPI == EPH_QKV) && s == 1;
+            if constexpr (EPI == EPH_QKV) {
+                // rotary: out[2i] = x[2i] cos_i - x[2i+1] sin_i ; out[2i+1] = x[2i+1] cos_i + x[2i] sin_i
+                const float4 c4 = *reinterpret_cast<const float4*>(p.enc_cos + (size_t)(grow0 + rl) * ENC + (d >> 1));
+                const float4 s4 = *reinterpret_cast<const float4*>(p.enc_sin + (size_t)(grow0 + rl) * ENC + (d >> 1));
+                const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x0 = v[2 * e], x1 = v[2 * e + 1];
+                    v[2 * e] = x0 * cc[e] - x1 * ss[e];
+                    v[2 * e + 1] = x1 * cc[e] + x0 * ss[e];
+                }
+            }
+            const float scale = is_k ? p.k_scale : p.q_scale;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= scale;
+            uint4 hi, lo;
+            split8(v, hi, lo);
+            const SplitOut dst = is_k ? p.k : p.q;
+            const size_t o = (((size_t)rd.img * NH + hd) * p.Kc + row) * DH + d;
+            *reinterpret_cast<uint4*>(dst.hi + o) = hi;
+            *reinterpret_cast<uint4*>(dst.lo + o) = lo;
+        } else {
+            const size_t o = (size_t)(grow0 + rl) * p.ldo + col;
+            if constexpr (EPI == EPH_RESID) {
+                const float4 a = *reinterpret_cast<const float4*>(p.out + o);
+                const float4 b4 = *reinterpret_cast<const float4*>(p.out + o + 4);
+                v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b4.x; v[5] += b4.y; v[6] += b4.z; v[7] += b4.w;
+            }
+            if constexpr (EPI == EPH_F32 || EPI == EPH_RESID) {
+                *reinterpret_cast<float4*>(p.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(p.out + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+            if constexpr (EPI == EPH_SPLIT || EPI == EPH_RESID) {
+                uint4 hi, lo;
+                split8(v, hi, lo);
+                const size_t po = panel_index(grow0 + rl, col, 2 * p.Kc);
+                *reinterpret_cast<uint4*>(p.outs.hi + po) = hi;
+                *reinterpret_cast<uint4*>(p.outs.lo + po) = lo;
+            }
+        }
+    }
+    if constexpr (EPI == EPH_QKV || EPI == EPH_CROSS) {
+        // V columns, transposed and key-tile-major: vt[img][head][token / 64][d][token % 64];
+        // a unit = one column x 8 consecutive rows (tokens)
+        constexpr int VCOL0 = (EPI == EPH_QKV) ? 2 * D : D;
+        constexpr int RG = BM / 8;
+        for (int u = t; u < BN * RG; u += 256) {
+            const int cl = u % BN, rg = u / BN;
+            const int col = col0 + cl;
+            if (col < VCOL0) continue;
+            const int hd = (col >> 6) & 3, d = col & 63;
+            const int row = rd.row0 + rg * 8;
+            if (row >= rd.n) continue;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = epi[(rg * 8 + e) * ELD + cl];
+            uint4 hi, lo;
+            split8(v, hi, lo);
+            const size_t o = ((((size_t)rd.img * NH + hd) * (p.Kc / AK) + (row >> 6)) * DH + d) * AK + (row & 63);
+            // rows beyond n inside this 8-group are stale but never read (keys >= n are masked)
+            *reinterpret_cast<uint4*>(p.vt.hi + o) = hi;
+            *reinterpret_cast<uint4*>(p.vt.lo + o) = lo;
+        }
+    }
 }
 
 // LayerNorm(512) + exact GELU: fp32 hidden in, split planes out (one wave / row)
@@ -992,10 +1042,11 @@ __global__ __launch_bounds__(256) void lg_ln_gelu_h_kernel(const float* __restri
         split_f32(g, hh, ll);
         if (i < 4) { h0[i] = hh; l0[i] = ll; } else { h1[i - 4] = hh; l1[i - 4] = ll; }
     }
-    *reinterpret_cast<half4*>(outs.hi + base + lane * 4) = h0;
-    *reinterpret_cast<half4*>(outs.lo + base + lane * 4) = l0;
-    *reinterpret_cast<half4*>(outs.hi + base + 256 + lane * 4) = h1;
-    *reinterpret_cast<half4*>(outs.lo + base + 256 + lane * 4) = l1;
+    const size_t p0 = panel_index(img * Kc + row, lane * 4, 2 * Kc), p1 = panel_index(img * Kc + row, 256 + lane * 4, 2 * Kc);
+    *reinterpret_cast<half4*>(outs.hi + p0) = h0;
+    *reinterpret_cast<half4*>(outs.lo + p0) = l0;
+    *reinterpret_cast<half4*>(outs.hi + p1) = h1;
+    *reinterpret_cast<half4*>(outs.lo + p1) = l1;
 }
 
 // ---- attention, split precision --------------------------------------------------------
@@ -1072,7 +1123,7 @@ __global__ __launch_bounds__(256, 2) void lg_attention_h_kernel(AttnArgsH p) {
         for (int rg = 0; rg < 8; ++rg) {
             const int row = rg * 8 + lrow;
             const int c = lcp ^ ((row >> 1) & 7);
-            const _Float16* src = is_v ? gplane + (size_t)row * p.Kc + (size_t)tile * AK + c * 8
+            const _Float16* src = is_v ? gplane + ((size_t)tile * DH + row) * AK + c * 8     // key-tile-major V^T
                                        : gplane + (size_t)min(tile * AK + row, p.Kc - 1) * DH + c * 8;
             glds16(src, dst + rg * 8 * DH);
         }
@@ -1213,7 +1264,7 @@ __global__ __launch_bounds__(256) void lg_attn_merge_h_kernel(const float* __res
     half4 hh, ll;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { _Float16 a, b; split_f32(v[e], a, b); hh[e] = a; ll[e] = b; }
-    const size_t o = ((size_t)img * Kc + row) * D + head * DH + c4 * 4;
+    const size_t o = panel_index(img * Kc + row, head * DH + c4 * 4, 2 * Kc);
     *reinterpret_cast<half4*>(msg.hi + o) = hh;
     *reinterpret_cast<half4*>(msg.lo + o) = ll;
 }
@@ -1360,7 +1411,7 @@ void launch_linear_h(hipStream_t s, const LinearArgsH& a) {
         configured = true;
     }
     dim3 grid(a.N / BN, 2 * sslam::cdiv(a.Kc, BM));
-    hipLaunchKernelGGL((lg_linear_h_kernel<BM, BN, TM, TN, EPI>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((lg_linear_h_kernel<BM, BN, TM, TN, EPI>), grid, dim3(512), lds, s, a);   // 4 consumer + 4 producer waves
 }
 
 LinearArgsH linh(const sslam_lightglue* g, SplitPtr A0, SplitPtr A1, int lda, int K0, int K, const float* W,
@@ -1577,9 +1628,19 @@ int sslam_lightglue_create(sslam_ctx* ctx, const float* weights, size_t n_floats
     SSLAM_HIP_CHECK(hipMemcpy(g->blob, weights, n_floats * 4, hipMemcpyHostToDevice));
     if (int rc = lg_bind_weights(g, n_floats)) { g->arena.release(); delete g; return rc; }
     g->n_blob = n_floats;
-    hipLaunchKernelGGL(lg_split_kernel, dim3((unsigned)((n_floats + 255) / 256)), dim3(256), 0, ctx->stream,
-                       g->blob, g->w_hi, g->w_lo, n_floats);
-    SSLAM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    {   // split every transformer-layer weight matrix into k-panel fp16 planes (same offsets as the blob)
+        auto splitw = [&](const float* w, int N, int K) {
+            const size_t off = (size_t)(w - g->blob), n = (size_t)N * K;
+            hipLaunchKernelGGL(lg_split_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                               w, g->w_hi + off, g->w_lo + off, N, K);
+        };
+        for (int i = 0; i < NL; ++i) {
+            const LGLayerW& l = g->L[i];
+            splitw(l.wqkv, 3 * D, D); splitw(l.w1, 2 * D, 2 * D); splitw(l.w2, D, 2 * D);
+            splitw(l.cqkv, 2 * D, D); splitw(l.cw1, 2 * D, 2 * D); splitw(l.cw2, D, 2 * D);
+        }
+        SSLAM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
     *out = g;
     return 0;
 }
