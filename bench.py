@@ -99,11 +99,18 @@ def main():
                          f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
+    # one process per GPU; SSLAM_DIST_BACKEND=gloo + fewer GPUs than ranks is a test-only mode that
+    # exercises the N > 1 code path on a single-GPU box (ranks share device local_rank % n_gpus)
+    backend = os.environ.get("SSLAM_DIST_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     pkg = importlib.import_module("opencv-simpleslam_amd")
     W = importlib.import_module("opencv-simpleslam_amd.weights")
@@ -117,8 +124,8 @@ def main():
     with torch.cuda.stream(main):
         streams_e = [torch.cuda.Stream() for _ in range(N_EXT)]
         streams_m = [torch.cuda.Stream() for _ in range(N_MAT)]
-        ctx_e = [pkg._native.Context(local_rank, stream=st.cuda_stream) for st in streams_e]
-        ctx_m = [pkg._native.Context(local_rank, stream=st.cuda_stream) for st in streams_m]
+        ctx_e = [pkg._native.Context(device_index, stream=st.cuda_stream) for st in streams_e]
+        ctx_m = [pkg._native.Context(device_index, stream=st.cuda_stream) for st in streams_m]
         sd_a, sd_l = W.random_aliked_state_dict(0), W.random_lightglue_state_dict(0)
         dets = [AlikedHIP(sd_a, max_num_keypoints=MAX_KPTS, max_h=H_IMG, max_w=W_IMG, ctx=c) for c in ctx_e]
         mats = [LightGlueHIP(sd_l, max_kpts=MAX_KPTS, ctx=c) for c in ctx_m]
@@ -153,6 +160,22 @@ def main():
             ms_, n_ = mat.profile_read()
             attn_ms += ms_; attn_n += n_
         info = pipe.info.cpu().numpy()
+        # Kernel-level figure for the roofline: the same launches replayed on ONE stream with the
+        # other streams idle.  In the timed region up to 8 streams share the chip, so the HIP-event
+        # bracket of a launch there also contains the time its blocks wait for CUs held by other
+        # streams' kernels; the single-stream bracket is the kernel's own duration (it is what
+        # rocprofv3 --kernel-trace reports for the kernel in either mode).
+        torch.cuda.synchronize()
+        m0 = mats[0]
+        m0.profile(True)
+        with torch.cuda.stream(streams_m[0]):
+            for rep in range(4):
+                m0.match_dev(pipe.xy[0], pipe.desc[0], MAX_KPTS, pipe.xy[1], pipe.desc[1], MAX_KPTS,
+                             pipe.ij[1], pipe.msc[1], pipe.info[1], min_conf=MIN_CONF,
+                             m_dev=pipe.count[0], n_dev=pipe.count[1])
+        torch.cuda.synchronize()
+        m0.profile(False)
+        iso_ms, iso_n = m0.profile_read()
 
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -162,7 +185,7 @@ def main():
     if rank == 0:
         frames_total = args.steps * plan.frames_per_round()
         n0, n1, stop = int(info[-1, 2]), int(info[-1, 3]), int(info[-1, 1])
-        ach = attention_flops(n0, n1) / (attn_ms / max(attn_n, 1) * 1e-3) / 1e12 if attn_n else None
+        ach = attention_flops(n0, n1) / (iso_ms / max(iso_n, 1) * 1e-3) / 1e12 if iso_n else None
         out = {
             "metric": "frames/sec ALIKED+LightGlue @1241x376",
             "value": round(frames_total / dt_max, 2),
@@ -177,16 +200,17 @@ def main():
                        "frames_per_step_per_gpu": FRAMES_PER_RANK, "max_kpts": MAX_KPTS,
                        "lightglue_layers_executed": stop, "kpts_matched": [n0, n1],
                        "parallelism": f"frame-shard x{world}; per GPU {N_EXT} extractor + {N_MAT} matcher streams"},
-            # achieved = ALGORITHMIC flops (8 n0 n1 256 per launch) / HIP-event launch duration; the
-            # kernel issues 3 v_mfma_f32_32x32x16_f16 per algorithmic product (executed = 3x), and
-            # its launches share the chip with the other streams' kernels during the timed region
+            # achieved = ALGORITHMIC flops (8 n0 n1 256 per launch) / HIP-event launch duration on one
+            # stream; the kernel issues 3 v_mfma_f32_32x32x16_f16 per algorithmic product (executed = 3x)
             "roofline": {"bound": "mfma", "kernel": "lg_attention_h_kernel (v_mfma_f32_32x32x16_f16 x3 per product)",
                          "achieved": round(ach, 2) if ach else None, "peak": F16_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(ach / F16_MFMA_PEAK_TFLOPS, 4) if ach else None,
                          "traffic": None,
                          "executed_mfma_frac": round(3 * ach / F16_MFMA_PEAK_TFLOPS, 4) if ach else None,
-                         "launches_timed": attn_n,
-                         "avg_launch_us": round(attn_ms / max(attn_n, 1) * 1e3, 2)},
+                         "launches_timed": iso_n,
+                         "avg_launch_us": round(iso_ms / max(iso_n, 1) * 1e3, 2),
+                         "timed_region_launches": attn_n,
+                         "timed_region_avg_bracket_us": round(attn_ms / max(attn_n, 1) * 1e3, 2)},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

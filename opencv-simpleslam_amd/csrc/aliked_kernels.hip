@@ -33,6 +33,8 @@ __device__ __forceinline__ float selu(float x) {
     return SELU_SCALE * (x > 0.0f ? x : SELU_ALPHA * expm1f(x));
 }
 
+constexpr int HBINS = 4096;        // score histogram bins (uniform in score, monotone)
+
 struct ALCtrl {
     int n_cand;       // candidates above threshold
     int n_kp;         // keypoints emitted
@@ -308,6 +310,20 @@ __global__ __launch_bounds__(256) void al_gate_kernel(const float* __restrict__ 
     for (int o = 0; o < 32; ++o) out[(size_t)o * HW + p] = selu(acc[o]);
 }
 
+// small-map variant (1/8, 1/32 resolution): one thread per (co, pixel), more parallelism
+__global__ void al_gate_small_kernel(const float* __restrict__ in, float* __restrict__ out, int CIN, int HW,
+                                     const float* __restrict__ w /*[ci][32]*/) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 32 * HW) return;
+    const int co = i / HW, p = i % HW;
+    float a0 = 0.0f, a1 = 0.0f;
+    for (int ci = 0; ci < CIN; ci += 2) {
+        a0 = fmaf(in[(size_t)ci * HW + p], w[ci * 32 + co], a0);
+        a1 = fmaf(in[(size_t)(ci + 1) * HW + p], w[(ci + 1) * 32 + co], a1);
+    }
+    out[i] = selu(a0 + a1);
+}
+
 // ------------------------------------------------------------------------ //
 //  3. feature aggregation.  F(p) = [ selu(W1 x1(p)) | up2(g2)(p) | up8(g3)(p) | up32(g4)(p) ]
 //     (bilinear, align_corners=True).  The aggregate kernel turns F into the first
@@ -317,6 +333,7 @@ struct Pyr {
     const float* x1; const float* g2; const float* g3; const float* g4;
     const float* w1;      // conv1 [16][32]
     int Hp, Wp;
+    float* g1cl;          // selu(W1 x1) channel-last [Hp][Wp][32], written by the aggregate kernel
 };
 
 struct UpTap { int o00, o01, o10, o11; float w00, w01, w10, w11; };
@@ -339,9 +356,12 @@ __device__ __forceinline__ float up_eval(const float* __restrict__ p, const UpTa
 
 __global__ __launch_bounds__(256) void al_aggregate_kernel(Pyr P, const float* __restrict__ ws0 /*[128][8]*/,
                                                            float* __restrict__ s8, float* __restrict__ rnorm) {
+    // the block's 256 pixels x 32 channels of g1 are one contiguous 32 KiB run of the channel-last
+    // map: stage them in LDS ([pixel][33], conflict-free) and write them out as coalesced float4
+    __shared__ float g1s[256 * 33];
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= P.Wp) return;
-    const size_t HW = (size_t)P.Hp * P.Wp, pix = (size_t)y * P.Wp + x;
+    const bool live = x < P.Wp;
+    const size_t HW = (size_t)P.Hp * P.Wp, pix = (size_t)y * P.Wp + min(x, P.Wp - 1);
     float xv[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) xv[k] = P.x1[k * HW + pix];
@@ -354,6 +374,7 @@ __global__ __launch_bounds__(256) void al_aggregate_kernel(Pyr P, const float* _
 #pragma unroll
         for (int k = 0; k < 16; ++k) a = fmaf(xv[k], P.w1[k * 32 + c], a);
         a = selu(a);
+        g1s[threadIdx.x * 33 + c] = a;     // the descriptor head gathers this instead of redoing the 16x32 product
         n2 = fmaf(a, a, n2);
 #pragma unroll
         for (int o = 0; o < 8; ++o) s[o] = fmaf(a, ws0[c * 8 + o], s[o]);
@@ -379,9 +400,19 @@ __global__ __launch_bounds__(256) void al_aggregate_kernel(Pyr P, const float* _
 #pragma unroll
         for (int o = 0; o < 8; ++o) s[o] = fmaf(a, ws0[(96 + c) * 8 + o], s[o]);
     }
+    if (live) {
 #pragma unroll
-    for (int o = 0; o < 8; ++o) s8[o * HW + pix] = selu(s[o]);
-    rnorm[pix] = 1.0f / fmaxf(sqrtf(n2), 1e-12f);            // F.normalize eps
+        for (int o = 0; o < 8; ++o) s8[o * HW + pix] = selu(s[o]);
+        rnorm[pix] = 1.0f / fmaxf(sqrtf(n2), 1e-12f);            // F.normalize eps
+    }
+    __syncthreads();
+    const int npx = min(256, P.Wp - (int)(blockIdx.x * blockDim.x));
+    float* dst = P.g1cl + ((size_t)y * P.Wp + blockIdx.x * blockDim.x) * 32;
+    for (int i = threadIdx.x; i < npx * 8; i += 256) {           // float4 pieces, fully coalesced
+        const int p = i >> 3, c4 = (i & 7) * 4;
+        *reinterpret_cast<float4*>(dst + (size_t)p * 32 + c4) =
+            make_float4(g1s[p * 33 + c4], g1s[p * 33 + c4 + 1], g1s[p * 33 + c4 + 2], g1s[p * 33 + c4 + 3]);
+    }
 }
 
 // Normalised feature vector at integer pixel (y,x) of the UN-padded map: one wave per pixel,
@@ -393,10 +424,7 @@ __device__ __forceinline__ float2 feat_pair(const Pyr& P, const float* __restric
     float a, b;
     const int c = lane & 31;
     if (lane < 32) {
-        float acc = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc = fmaf(P.x1[k * HW + pix], P.w1[k * 32 + c], acc);
-        a = selu(acc);
+        a = P.g1cl[pix * 32 + c];                      // one coalesced 128 B line per pixel
         b = up_eval(P.g3 + c * (HW / 64), up_tap(yp, xp, P.Hp, P.Wp, 8));
     } else {
         a = up_eval(P.g2 + c * (HW / 4), up_tap(yp, xp, P.Hp, P.Wp, 2));
@@ -577,7 +605,8 @@ __global__ __launch_bounds__(256) void al_nms_kernel(const float* __restrict__ s
 __global__ __launch_bounds__(256) void al_collect_kernel(const float* __restrict__ nms, int n_px, float thr,
                                                          int fallback, const float* __restrict__ block_sum,
                                                          int n_blocks, unsigned long long* __restrict__ cand,
-                                                         int cap, ALCtrl* __restrict__ ctrl) {
+                                                         int cap, ALCtrl* __restrict__ ctrl,
+                                                         unsigned* __restrict__ hist) {
     if (fallback) {
         if (!ctrl->need_fallback) return;           // the normal threshold found keypoints
         float s = 0.0f;                             // mean of the raw score map, fixed summation order
@@ -598,6 +627,7 @@ __global__ __launch_bounds__(256) void al_collect_kernel(const float* __restrict
         const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
         if (pos < cap) cand[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(0xffffffffu - (unsigned)i);
         else ctrl->overflow = 1;
+        atomicAdd(&hist[min((int)(v * (float)HBINS), HBINS - 1)], 1u);     // scores are in (0, 1]
     }
 }
 // decided between the two collect launches so every thread of the fallback launch sees one answer
@@ -641,63 +671,104 @@ __device__ void bitonic_sort_desc(unsigned long long* a, int n_pow2) {
         }
 }
 
+constexpr int EDGE_CAP = 2048;     // candidates allowed in the cut bin before falling back to radix select
+
 __global__ __launch_bounds__(1024) void al_select_kernel(const unsigned long long* __restrict__ cand, int cap,
                                                          int n_limit, int* __restrict__ kp_index,
-                                                         ALCtrl* __restrict__ ctrl) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];   // SEL_CAP
+                                                         ALCtrl* __restrict__ ctrl, const unsigned* __restrict__ hist_g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];   // SEL_CAP + EDGE_CAP
+    unsigned long long* edge = keys + SEL_CAP;
     __shared__ unsigned hist[256];
     __shared__ unsigned s_prefix, s_remaining;
-    __shared__ int s_count;
+    __shared__ int s_count, s_edge, s_cutbin, s_above;
+    __shared__ unsigned wsum[16];
     const int n = min(ctrl->n_cand, cap);
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     int n_sel;
     if (n <= n_limit) {
         // raster order: sort by index ascending = key with score bits cleared, descending on (~index)
         for (int i = t; i < SEL_CAP; i += blockDim.x) keys[i] = i < n ? (cand[i] & 0xffffffffull) : 0ull;
         n_sel = n;
+        __syncthreads();
     } else {
-        // radix-select the n_limit-th largest 64-bit key, 8 bits at a time (keys are unique)
-        unsigned long long prefix = 0ull;
-        int remaining = n_limit;
-        for (int shift = 56; shift >= 0; shift -= 8) {
-            for (int i = t; i < 256; i += blockDim.x) hist[i] = 0;
-            __syncthreads();
-            const unsigned long long mask_hi = shift == 56 ? 0ull : (~0ull << (shift + 8));
-            for (int i = t; i < n; i += blockDim.x) {
-                const unsigned long long k = cand[i];
-                if ((k & mask_hi) == prefix) atomicAdd(&hist[(k >> shift) & 255], 1u);
-            }
-            __syncthreads();
-            if (t == 0) {
-                int rem = remaining, d = 255;
-                for (; d > 0; --d) {
-                    if ((int)hist[d] >= rem) break;
-                    rem -= hist[d];
-                }
-                s_prefix = d; s_remaining = rem;
-            }
-            __syncthreads();
-            prefix |= (unsigned long long)s_prefix << shift;
-            remaining = s_remaining;
-            __syncthreads();
+        // 1. cut bin from the score histogram (filled by al_collect): the largest bin b with
+        //    count(bins > b) < n_limit <= count(bins >= b).  Thread t owns bins 4t..4t+3 (descending scan).
+        unsigned loc[4], tot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { loc[q] = hist_g[HBINS - 1 - (4 * t + q)]; tot += loc[q]; }
+        unsigned incl = tot;
+        for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        unsigned base = 0;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        unsigned run = base + incl - tot;              // candidates in bins above this thread's first bin
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (run < (unsigned)n_limit && run + loc[q] >= (unsigned)n_limit) { s_cutbin = HBINS - 1 - (4 * t + q); s_above = (int)run; }
+            run += loc[q];
         }
-        // prefix == the n_limit-th largest key: keep keys >= prefix
-        if (t == 0) s_count = 0;
+        if (t == 0) { s_count = 0; s_edge = 0; }
         for (int i = t; i < SEL_CAP; i += blockDim.x) keys[i] = 0ull;
         __syncthreads();
+        const int cutbin = s_cutbin, above = s_above;
+        // 2. candidates above the cut bin are in; those in the cut bin go to the edge list
         for (int i = t; i < n; i += blockDim.x) {
             const unsigned long long k = cand[i];
-            if (k >= prefix) {
-                const int pos = atomicAdd(&s_count, 1);
-                if (pos < SEL_CAP) keys[pos] = k;
+            const int bin = min((int)(__uint_as_float((unsigned)(k >> 32)) * (float)HBINS), HBINS - 1);
+            if (bin > cutbin) { const int pos = atomicAdd(&s_count, 1); if (pos < SEL_CAP) keys[pos] = k; }
+            else if (bin == cutbin) { const int pos = atomicAdd(&s_edge, 1); if (pos < EDGE_CAP) edge[pos] = k; }
+        }
+        __syncthreads();
+        const int n_edge = s_edge, need = n_limit - above;
+        if (n_edge <= EDGE_CAP) {
+            // 3. order the edge list, take its best `need` keys
+            for (int i = n_edge + t; i < EDGE_CAP; i += blockDim.x) edge[i] = 0ull;
+            __syncthreads();
+            int p2e = 2;
+            while (p2e < n_edge) p2e <<= 1;
+            bitonic_sort_desc(edge, p2e);
+            for (int i = t; i < need; i += blockDim.x) keys[above + i] = edge[i];
+            __syncthreads();
+        } else {
+            // fallback (degenerate score maps: thousands of ties in one bin): exact 8-pass radix select
+            unsigned long long prefix = 0ull;
+            int remaining = n_limit;
+            for (int shift = 56; shift >= 0; shift -= 8) {
+                for (int i = t; i < 256; i += blockDim.x) hist[i] = 0;
+                __syncthreads();
+                const unsigned long long mask_hi = shift == 56 ? 0ull : (~0ull << (shift + 8));
+                for (int i = t; i < n; i += blockDim.x) {
+                    const unsigned long long k = cand[i];
+                    if ((k & mask_hi) == prefix) atomicAdd(&hist[(k >> shift) & 255], 1u);
+                }
+                __syncthreads();
+                if (t == 0) {
+                    int rem = remaining, d = 255;
+                    for (; d > 0; --d) {
+                        if ((int)hist[d] >= rem) break;
+                        rem -= hist[d];
+                    }
+                    s_prefix = d; s_remaining = rem;
+                }
+                __syncthreads();
+                prefix |= (unsigned long long)s_prefix << shift;
+                remaining = s_remaining;
+                __syncthreads();
             }
+            if (t == 0) s_count = 0;
+            for (int i = t; i < SEL_CAP; i += blockDim.x) keys[i] = 0ull;
+            __syncthreads();
+            for (int i = t; i < n; i += blockDim.x) {
+                const unsigned long long k = cand[i];
+                if (k >= prefix) { const int pos = atomicAdd(&s_count, 1); if (pos < SEL_CAP) keys[pos] = k; }
+            }
+            __syncthreads();
         }
         n_sel = n_limit;
     }
-    __syncthreads();
-    int p2 = 1;
+    int p2 = 2;
     while (p2 < n_sel) p2 <<= 1;
-    p2 = max(p2, 2);
     bitonic_sort_desc(keys, p2);
     for (int i = t; i < n_sel; i += blockDim.x)
         kp_index[i] = (int)(0xffffffffu - (unsigned)(keys[i] & 0xffffffffull));
@@ -897,8 +968,9 @@ struct sslam_aliked {
     ALCtrl* ctrl;
     uint8_t* in_u8;
     float *fsrc, *img, *x1a, *x1, *t2, *idn2, *x2, *p3, *off, *t3, *x3, *p4, *t4, *x4, *g2, *g3, *g4;
-    float *s8, *rnorm, *score, *nms, *bsum, *gk;
+    float *s8, *rnorm, *score, *nms, *bsum, *gk, *g1cl;
     unsigned long long* cand;
+    unsigned* hist;
     int cand_cap;
     int* kp_index;
     float *kp_norm, *kp_score, *patch, *h32, *pos, *sampled, *feats, *raw;
@@ -965,6 +1037,7 @@ int al_enqueue(sslam_aliked* g, const uint8_t* img_dev, int H, int W, int C, int
     g->last = d;
     const int Hp = d.Hp, Wp = d.Wp;
     SSLAM_HIP_CHECK(hipMemsetAsync(g->ctrl, 0, sizeof(ALCtrl), s));
+    SSLAM_HIP_CHECK(hipMemsetAsync(g->hist, 0, HBINS * sizeof(unsigned), s));
     SSLAM_REQUIRE(rp.kx <= 31 && rp.ky <= 31, "sslam_aliked: blur kernel too large (%d,%d)", rp.kx, rp.ky);
     hipLaunchKernelGGL(al_taps_kernel, dim3(1), dim3(64), 0, s, g->gk, rp.kx, rp.sx, rp.ky, rp.sy);
 
@@ -1011,10 +1084,10 @@ int al_enqueue(sslam_aliked* g, const uint8_t* img_dev, int H, int W, int C, int
                        g->x4, H4, W4, g->b4c2.w, g->b4c2.a, g->b4c2.b, g->p4, 64, g->b4dw, g->b4db);
     // gates
     hipLaunchKernelGGL(al_gate_kernel, dim3(sslam::cdiv(H2 * W2, 256)), dim3(256), 0, s, g->x2, g->g2, 32, H2 * W2, g->gw2);
-    hipLaunchKernelGGL(al_gate_kernel, dim3(sslam::cdiv(HW3, 64)), dim3(64), 0, s, g->x3, g->g3, 64, HW3, g->gw3);
-    hipLaunchKernelGGL(al_gate_kernel, dim3(sslam::cdiv(HW4, 64)), dim3(64), 0, s, g->x4, g->g4, 128, HW4, g->gw4);
+    hipLaunchKernelGGL(al_gate_small_kernel, dim3(sslam::cdiv(32 * HW3, 256)), dim3(256), 0, s, g->x3, g->g3, 64, HW3, g->gw3);
+    hipLaunchKernelGGL(al_gate_small_kernel, dim3(sslam::cdiv(32 * HW4, 256)), dim3(256), 0, s, g->x4, g->g4, 128, HW4, g->gw4);
     // aggregation + score head
-    Pyr P{g->x1, g->g2, g->g3, g->g4, g->gw1, Hp, Wp};
+    Pyr P{g->x1, g->g2, g->g3, g->g4, g->gw1, Hp, Wp, g->g1cl};
     hipLaunchKernelGGL(al_aggregate_kernel, dim3(sslam::cdiv(Wp, 256), Hp), dim3(256), 0, s, P, g->sh0, g->s8, g->rnorm);
     hipLaunchKernelGGL(al_score_tail_kernel, dim3(sslam::cdiv(Wp, ST_W), sslam::cdiv(Hp, ST_H)), dim3(256), 0, s, g->s8,
                        Hp, Wp, g->sh2, g->sh4, g->sh6, g->score, d.h, d.w, d.pl, d.pt);
@@ -1022,12 +1095,12 @@ int al_enqueue(sslam_aliked* g, const uint8_t* img_dev, int H, int W, int C, int
     const int nbx = sslam::cdiv(d.w, NT_W), nby = sslam::cdiv(d.h, NT_H), npx = d.h * d.w;
     hipLaunchKernelGGL(al_nms_kernel, dim3(nbx, nby), dim3(256), 0, s, g->score, d.h, d.w, g->nms, g->bsum);
     hipLaunchKernelGGL(al_collect_kernel, dim3(sslam::cdiv(npx, 256)), dim3(256), 0, s, g->nms, npx, 0.2f, 0, g->bsum,
-                       nbx * nby, g->cand, g->cand_cap, g->ctrl);
+                       nbx * nby, g->cand, g->cand_cap, g->ctrl, g->hist);
     hipLaunchKernelGGL(al_fallback_flag_kernel, dim3(1), dim3(1), 0, s, g->ctrl);
     hipLaunchKernelGGL(al_collect_kernel, dim3(sslam::cdiv(npx, 256)), dim3(256), 0, s, g->nms, npx, 0.0f, 1, g->bsum,
-                       nbx * nby, g->cand, g->cand_cap, g->ctrl);
-    hipLaunchKernelGGL(al_select_kernel, dim3(1), dim3(1024), SEL_CAP * 8, s, g->cand, g->cand_cap, n_limit, g->kp_index,
-                       g->ctrl);
+                       nbx * nby, g->cand, g->cand_cap, g->ctrl, g->hist);
+    hipLaunchKernelGGL(al_select_kernel, dim3(1), dim3(1024), (SEL_CAP + EDGE_CAP) * 8, s, g->cand, g->cand_cap, n_limit,
+                       g->kp_index, g->ctrl, g->hist);
     const int NK = g->max_kpts;
     hipLaunchKernelGGL(al_refine_kernel, dim3(sslam::cdiv(NK, 256)), dim3(256), 0, s, g->score, d.h, d.w, g->kp_index,
                        g->kp_norm, g->kp_score, g->ctrl);
@@ -1081,9 +1154,9 @@ int sslam_aliked_create(sslam_ctx* ctx, const float* weights, size_t n_floats, i
         g->t3 = A.take<float>(64 * HWp / 64); g->x3 = A.take<float>(64 * HWp / 64);
         g->p4 = A.take<float>(64 * HWp / 1024); g->t4 = A.take<float>(128 * HWp / 1024); g->x4 = A.take<float>(128 * HWp / 1024);
         g->g2 = A.take<float>(32 * HWp / 4); g->g3 = A.take<float>(32 * HWp / 64); g->g4 = A.take<float>(32 * HWp / 1024);
-        g->s8 = A.take<float>(8 * HWp); g->rnorm = A.take<float>(HWp);
+        g->s8 = A.take<float>(8 * HWp); g->rnorm = A.take<float>(HWp); g->g1cl = A.take<float>(32 * HWp);
         g->score = A.take<float>(HWp); g->nms = A.take<float>(HWp); g->bsum = A.take<float>(4096); g->gk = A.take<float>(64);
-        g->cand = A.take<unsigned long long>(g->cand_cap);
+        g->cand = A.take<unsigned long long>(g->cand_cap); g->hist = A.take<unsigned>(HBINS);
         g->kp_index = A.take<int>(SEL_CAP);
         g->kp_norm = A.take<float>(2 * NK + 64); g->kp_score = A.take<float>(NK + 64);
         g->patch = A.take<float>((NK + 64) * 1152); g->h32 = A.take<float>((NK + 64) * 32); g->pos = A.take<float>(NK * 32 + 64);
@@ -1101,7 +1174,7 @@ int sslam_aliked_create(sslam_ctx* ctx, const float* weights, size_t n_floats, i
     SSLAM_HIP_CHECK(hipMemcpy(g->blob, weights, n_floats * 4, hipMemcpyHostToDevice));
     if (int rc = al_bind_weights(g, n_floats)) { g->arena.release(); delete g; return rc; }
     SSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)al_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        SEL_CAP * 8));
+                                        (SEL_CAP + EDGE_CAP) * 8));
     *out = g;
     return 0;
 }
