@@ -111,75 +111,102 @@ __global__ void al_resize_pad_kernel(const float* __restrict__ src, float* __res
     }
 }
 
-// ------------------------------------------------------------------------ //
-//  1. dense 3x3 conv (zero pad) + BN affine (+ residual) + SELU, planar CHW.
-//     Block = 32x8 output pixels, one pixel per thread, COUT accumulators in
-//     registers; the input tile (+halo, optionally POOLxPOOL average-pooled
-//     while loading) sits in LDS; weights [ci][tap][co] are wave-uniform
-//     scalar loads.  DOWN additionally emits the ResBlock's 1x1 "downsample"
-//     branch of the (pooled) input.
-// ------------------------------------------------------------------------ //
-constexpr int CT_W = 32, CT_H = 8;
+constexpr int CT_W = 32, CT_H = 8;      // output tile of the dense 3x3 convs
 
+// ------------------------------------------------------------------------ //
+//  1. dense 3x3 conv (zero pad) + BN affine (+ residual) + SELU as an implicit GEMM on the exact-fp32 matrix core
+//      (v_mfma_f32_32x32x2_f32):  out[co][pixel] = sum_k W[co][k] * im2col[k][pixel],
+//      k = tap * CIN + ci.  A = weights (rows = co), B = pixels (cols = 32 consecutive x of one
+//      image row), so an accumulator register holds one output channel for 32 consecutive pixels
+//      and stores are coalesced 128 B rows.  The input tile (+halo, optional average pooling on
+//      load) and the [k][co] weights sit in LDS; every operand fetch is a ds_read_b32 with an
+//      immediate offset (the k order puts the two k of one MFMA one channel apart).
+//      Block = 32 x 8 pixels, wave w owns rows 2w, 2w+1.
+// ------------------------------------------------------------------------ //
 template <int CIN, int COUT, int POOL, bool DOWN, bool RESID>
-__global__ __launch_bounds__(256) void al_conv3x3_kernel(
-    const float* __restrict__ in, int inH, int inW,         // source map (before pooling)
-    float* __restrict__ out, int H, int W,                  // output map (= pooled size)
-    const float* __restrict__ w, const float* __restrict__ alpha, const float* __restrict__ beta,
-    const float* __restrict__ wd, const float* __restrict__ bd, float* __restrict__ idn,
+__global__ __launch_bounds__(256) void al_conv3x3_mfma_kernel(
+    const float* __restrict__ in, int inH, int inW, float* __restrict__ out, int H, int W,
+    const float* __restrict__ w /*[ci][tap][COUT]*/, const float* __restrict__ alpha, const float* __restrict__ beta,
+    const float* __restrict__ wd /*[ci][COUT]*/, const float* __restrict__ bd, float* __restrict__ idn,
     const float* __restrict__ resid) {
-    __shared__ float tile[CIN][CT_H + 2][CT_W + 2];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    // CINP: input channels padded to even (a zero channel), output channels padded to the 32 MFMA rows
+    constexpr int CINP = (CIN + 1) & ~1;
+    constexpr int TW = CT_W + 2, TH = CT_H + 2, CHS = TH * TW;       // channel stride of the input tile
+    constexpr int K = 9 * CINP;
+    __shared__ float tile[CINP * CHS];
+    __shared__ float wl[(K + (DOWN ? CINP : 0)) * 32];               // [k = tap*CINP + ci][co] (+ 1x1 rows)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CT_H;
-    for (int i = threadIdx.x; i < CIN * (CT_H + 2) * (CT_W + 2); i += 256) {
-        const int c = i / ((CT_H + 2) * (CT_W + 2)), rem = i % ((CT_H + 2) * (CT_W + 2));
-        const int yy = y0 + rem / (CT_W + 2) - 1, xx = x0 + rem % (CT_W + 2) - 1;
+    for (int i = t; i < CINP * CHS; i += 256) {
+        const int c = i / CHS, rem = i % CHS;
+        const int yy = y0 + rem / TW - 1, xx = x0 + rem % TW - 1;
         float v = 0.0f;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        if (c < CIN && yy >= 0 && yy < H && xx >= 0 && xx < W) {
             if (POOL == 1) {
                 v = in[((size_t)c * inH + yy) * inW + xx];
             } else {
                 float s = 0.0f;
                 for (int a = 0; a < POOL; ++a)
-                    for (int b = 0; b < POOL; ++b)
-                        s += in[((size_t)c * inH + yy * POOL + a) * inW + xx * POOL + b];
+                    for (int b = 0; b < POOL; ++b) s += in[((size_t)c * inH + yy * POOL + a) * inW + xx * POOL + b];
                 v = s / (float)(POOL * POOL);
             }
         }
-        (&tile[0][0][0])[i] = v;
+        tile[i] = v;
     }
+    for (int i = t; i < K * 32; i += 256) {          // global [ci][tap][co] -> LDS [tap][ci][co], zero padded
+        const int co = i & 31, k = i >> 5, tap = k / CINP, ci = k % CINP;
+        wl[i] = (ci < CIN && co < COUT) ? w[(ci * 9 + tap) * COUT + co] : 0.0f;
+    }
+    if (DOWN)
+        for (int i = t; i < CINP * 32; i += 256) {
+            const int co = i & 31, ci = i >> 5;
+            wl[K * 32 + i] = (ci < CIN && co < COUT) ? wd[ci * COUT + co] : 0.0f;
+        }
     __syncthreads();
-    float acc[COUT];
+
+    const int h = lane >> 5, px = lane & 31;
+    f32x16 acc0, acc1, dn0, dn1;
 #pragma unroll
-    for (int o = 0; o < COUT; ++o) acc[o] = 0.0f;
-    for (int ci = 0; ci < CIN; ++ci) {
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; dn0[r] = 0.0f; dn1[r] = 0.0f; }
+    // lane bases: B operand (pixels) = tile[(ci0 + h)][row + dy][px + dx]; A operand = wl[(k0 + h)][co = px]
+    const float* bbase = tile + h * CHS + (2 * wave) * TW + px;
+    const float* abase = wl + h * 32 + px;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const float v = tile[ci][ty + tap / 3][tx + tap % 3];
-            const float* wp = w + (ci * 9 + tap) * COUT;
+    for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
-            for (int o = 0; o < COUT; ++o) acc[o] = fmaf(v, wp[o], acc[o]);
+        for (int c2 = 0; c2 < CINP / 2; ++c2) {
+            const int koff = (tap * CINP + 2 * c2) * 32;                         // A: rows k0, k0+1
+            const int boff = (2 * c2) * CHS + (tap / 3) * TW + (tap % 3);         // B: channels 2c2, 2c2+1
+            const float a = abase[koff];
+            acc0 = sslam::mfma32(a, bbase[boff], acc0);
+            acc1 = sslam::mfma32(a, bbase[boff + TW], acc1);
         }
     }
-    const int x = x0 + tx, y = y0 + ty;
-    if (x >= W || y >= H) return;
     if (DOWN) {
-        float dn[COUT];
 #pragma unroll
-        for (int o = 0; o < COUT; ++o) dn[o] = 0.0f;
-        for (int ci = 0; ci < CIN; ++ci) {
-            const float v = tile[ci][ty + 1][tx + 1];
-#pragma unroll
-            for (int o = 0; o < COUT; ++o) dn[o] = fmaf(v, wd[ci * COUT + o], dn[o]);
+        for (int c2 = 0; c2 < CINP / 2; ++c2) {
+            const float a = abase[(K + 2 * c2) * 32];
+            const int boff = (2 * c2) * CHS + TW + 1;                             // centre tap
+            dn0 = sslam::mfma32(a, bbase[boff], dn0);
+            dn1 = sslam::mfma32(a, bbase[boff + TW], dn1);
         }
-#pragma unroll
-        for (int o = 0; o < COUT; ++o) idn[((size_t)o * H + y) * W + x] = dn[o] + bd[o];
     }
+    const int x = x0 + px;
+    if (x >= W) return;
 #pragma unroll
-    for (int o = 0; o < COUT; ++o) {
-        float v = fmaf(acc[o], alpha[o], beta[o]);
-        if (RESID) v += resid[((size_t)o * H + y) * W + x];
-        out[((size_t)o * H + y) * W + x] = selu(v);
+    for (int rr = 0; rr < 2; ++rr) {
+        const int y = y0 + 2 * wave + rr;
+        if (y >= H) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = acc_row(r, lane);
+            if (co >= COUT) continue;
+            const size_t o = ((size_t)co * H + y) * W + x;
+            float v = fmaf(rr ? acc1[r] : acc0[r], alpha[co], beta[co]);
+            if (RESID) v += resid[o];
+            out[o] = selu(v);
+            if (DOWN) idn[o] = (rr ? dn1[r] : dn0[r]) + bd[co];
+        }
     }
 }
 
@@ -1047,16 +1074,16 @@ int al_enqueue(sslam_aliked* g, const uint8_t* img_dev, int H, int W, int C, int
                        g->gk + 32, rp.ky, rp.blur);
     // block1
     dim3 g1(sslam::cdiv(Wp, CT_W), sslam::cdiv(Hp, CT_H));
-    hipLaunchKernelGGL((al_conv3x3_kernel<3, 16, 1, false, false>), g1, dim3(256), 0, s, g->img, Hp, Wp, g->x1a, Hp,
+    hipLaunchKernelGGL((al_conv3x3_mfma_kernel<3, 16, 1, false, false>), g1, dim3(256), 0, s, g->img, Hp, Wp, g->x1a, Hp,
                        Wp, g->b1c1.w, g->b1c1.a, g->b1c1.b, nullptr, nullptr, nullptr, nullptr);
-    hipLaunchKernelGGL((al_conv3x3_kernel<16, 16, 1, false, false>), g1, dim3(256), 0, s, g->x1a, Hp, Wp, g->x1, Hp,
+    hipLaunchKernelGGL((al_conv3x3_mfma_kernel<16, 16, 1, false, false>), g1, dim3(256), 0, s, g->x1a, Hp, Wp, g->x1, Hp,
                        Wp, g->b1c2.w, g->b1c2.a, g->b1c2.b, nullptr, nullptr, nullptr, nullptr);
     // block2 at 1/2: conv1 pools on load and also emits the downsample branch
     const int H2 = Hp / 2, W2 = Wp / 2;
     dim3 g2(sslam::cdiv(W2, CT_W), sslam::cdiv(H2, CT_H));
-    hipLaunchKernelGGL((al_conv3x3_kernel<16, 32, 2, true, false>), g2, dim3(256), 0, s, g->x1, Hp, Wp, g->t2, H2, W2,
+    hipLaunchKernelGGL((al_conv3x3_mfma_kernel<16, 32, 2, true, false>), g2, dim3(256), 0, s, g->x1, Hp, Wp, g->t2, H2, W2,
                        g->b2c1.w, g->b2c1.a, g->b2c1.b, g->b2dw, g->b2db, g->idn2, nullptr);
-    hipLaunchKernelGGL((al_conv3x3_kernel<32, 32, 1, false, true>), g2, dim3(256), 0, s, g->t2, H2, W2, g->x2, H2, W2,
+    hipLaunchKernelGGL((al_conv3x3_mfma_kernel<32, 32, 1, false, true>), g2, dim3(256), 0, s, g->t2, H2, W2, g->x2, H2, W2,
                        g->b2c2.w, g->b2c2.a, g->b2c2.b, nullptr, nullptr, nullptr, g->idn2);
     // block3 at 1/8 (deformable)
     const int H3 = Hp / 8, W3 = Wp / 8, HW3 = H3 * W3;
