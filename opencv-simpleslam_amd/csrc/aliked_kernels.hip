@@ -111,7 +111,7 @@ __global__ void al_resize_pad_kernel(const float* __restrict__ src, float* __res
     }
 }
 
-constexpr int CT_W = 32, CT_H = 8;      // output tile of the dense 3x3 convs
+constexpr int CT_W = 32;                // output tile width of the dense 3x3 convs (height = 4 * RPW)
 
 // ------------------------------------------------------------------------ //
 //  1. dense 3x3 conv (zero pad) + BN affine (+ residual) + SELU as an implicit GEMM on the exact-fp32 matrix core
@@ -123,7 +123,7 @@ constexpr int CT_W = 32, CT_H = 8;      // output tile of the dense 3x3 convs
 //      immediate offset (the k order puts the two k of one MFMA one channel apart).
 //      Block = 32 x 8 pixels, wave w owns rows 2w, 2w+1.
 // ------------------------------------------------------------------------ //
-template <int CIN, int COUT, int POOL, bool DOWN, bool RESID>
+template <int CIN, int COUT, int POOL, bool DOWN, bool RESID, int RPW>
 __global__ __launch_bounds__(256) void al_conv3x3_mfma_kernel(
     const float* __restrict__ in, int inH, int inW, float* __restrict__ out, int H, int W,
     const float* __restrict__ w /*[ci][tap][COUT]*/, const float* __restrict__ alpha, const float* __restrict__ beta,
@@ -131,12 +131,13 @@ __global__ __launch_bounds__(256) void al_conv3x3_mfma_kernel(
     const float* __restrict__ resid) {
     // CINP: input channels padded to even (a zero channel), output channels padded to the 32 MFMA rows
     constexpr int CINP = (CIN + 1) & ~1;
-    constexpr int TW = CT_W + 2, TH = CT_H + 2, CHS = TH * TW;       // channel stride of the input tile
+    constexpr int CTH = 4 * RPW;                                     // tile height: RPW rows per wave
+    constexpr int TW = CT_W + 2, TH = CTH + 2, CHS = TH * TW;        // channel stride of the input tile
     constexpr int K = 9 * CINP;
     __shared__ float tile[CINP * CHS];
     __shared__ float wl[(K + (DOWN ? CINP : 0)) * 32];               // [k = tap*CINP + ci][co] (+ 1x1 rows)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CT_H;
+    const int x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CTH;
     for (int i = t; i < CINP * CHS; i += 256) {
         const int c = i / CHS, rem = i % CHS;
         const int yy = y0 + rem / TW - 1, xx = x0 + rem % TW - 1;
@@ -165,11 +166,13 @@ __global__ __launch_bounds__(256) void al_conv3x3_mfma_kernel(
     __syncthreads();
 
     const int h = lane >> 5, px = lane & 31;
-    f32x16 acc0, acc1, dn0, dn1;
+    f32x16 acc[RPW], dn[DOWN ? RPW : 1];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; dn0[r] = 0.0f; dn1[r] = 0.0f; }
+    for (int q = 0; q < RPW; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[q][r] = 0.0f; if (DOWN) dn[q][r] = 0.0f; }
     // lane bases: B operand (pixels) = tile[(ci0 + h)][row + dy][px + dx]; A operand = wl[(k0 + h)][co = px]
-    const float* bbase = tile + h * CHS + (2 * wave) * TW + px;
+    const float* bbase = tile + h * CHS + (RPW * wave) * TW + px;
     const float* abase = wl + h * 32 + px;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -178,8 +181,8 @@ __global__ __launch_bounds__(256) void al_conv3x3_mfma_kernel(
             const int koff = (tap * CINP + 2 * c2) * 32;                         // A: rows k0, k0+1
             const int boff = (2 * c2) * CHS + (tap / 3) * TW + (tap % 3);         // B: channels 2c2, 2c2+1
             const float a = abase[koff];
-            acc0 = sslam::mfma32(a, bbase[boff], acc0);
-            acc1 = sslam::mfma32(a, bbase[boff + TW], acc1);
+#pragma unroll
+            for (int q = 0; q < RPW; ++q) acc[q] = sslam::mfma32(a, bbase[boff + q * TW], acc[q]);
         }
     }
     if (DOWN) {
@@ -187,25 +190,25 @@ __global__ __launch_bounds__(256) void al_conv3x3_mfma_kernel(
         for (int c2 = 0; c2 < CINP / 2; ++c2) {
             const float a = abase[(K + 2 * c2) * 32];
             const int boff = (2 * c2) * CHS + TW + 1;                             // centre tap
-            dn0 = sslam::mfma32(a, bbase[boff], dn0);
-            dn1 = sslam::mfma32(a, bbase[boff + TW], dn1);
+#pragma unroll
+            for (int q = 0; q < RPW; ++q) dn[q] = sslam::mfma32(a, bbase[boff + q * TW], dn[q]);
         }
     }
     const int x = x0 + px;
     if (x >= W) return;
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-        const int y = y0 + 2 * wave + rr;
+    for (int q = 0; q < RPW; ++q) {
+        const int y = y0 + RPW * wave + q;
         if (y >= H) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = acc_row(r, lane);
             if (co >= COUT) continue;
             const size_t o = ((size_t)co * H + y) * W + x;
-            float v = fmaf(rr ? acc1[r] : acc0[r], alpha[co], beta[co]);
+            float v = fmaf(acc[q][r], alpha[co], beta[co]);
             if (RESID) v += resid[o];
             out[o] = selu(v);
-            if (DOWN) idn[o] = (rr ? dn1[r] : dn0[r]) + bd[co];
+            if (DOWN) idn[o] = dn[q][r] + bd[co];
         }
     }
 }
@@ -629,32 +632,50 @@ __global__ __launch_bounds__(256) void al_nms_kernel(const float* __restrict__ s
 
 // collect pixels with nms > thr into an (unordered) candidate list of 64-bit keys:
 // key = score_bits << 32 | (0xffffffff - index)  -> larger key = better (score desc, index asc)
+constexpr int COLLECT_PPT = 16;     // pixels per thread: 4096 per block -> ~80 blocks, one same-address atomic each
+
 __global__ __launch_bounds__(256) void al_collect_kernel(const float* __restrict__ nms, int n_px, float thr,
                                                          int fallback, const float* __restrict__ block_sum,
                                                          int n_blocks, unsigned long long* __restrict__ cand,
                                                          int cap, ALCtrl* __restrict__ ctrl,
                                                          unsigned* __restrict__ hist) {
+    __shared__ int wcnt[4];
+    __shared__ int s_base;
     if (fallback) {
         if (!ctrl->need_fallback) return;           // the normal threshold found keypoints
         float s = 0.0f;                             // mean of the raw score map, fixed summation order
         for (int i = 0; i < n_blocks; ++i) s += block_sum[i];
         thr = s / (float)n_px;
     }
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const float v = i < n_px ? nms[i] : 0.0f;
-    const bool hit = i < n_px && v > thr;
-    // one atomic per wave: leader reserves a run, lanes take consecutive slots
-    const unsigned long long mask = __ballot(hit);
-    if (mask == 0ull) return;
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(&ctrl->n_cand, __popcll(mask));
-    base = __shfl(base, __ffsll((long long)mask) - 1);
-    if (hit) {
-        const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
-        if (pos < cap) cand[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(0xffffffffu - (unsigned)i);
-        else ctrl->overflow = 1;
-        atomicAdd(&hist[min((int)(v * (float)HBINS), HBINS - 1)], 1u);     // scores are in (0, 1]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int base_px = blockIdx.x * 256 * COLLECT_PPT;
+    float v[COLLECT_PPT];
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < COLLECT_PPT; ++j) {
+        const int i = base_px + j * 256 + t;
+        v[j] = i < n_px ? nms[i] : 0.0f;
+        cnt += (i < n_px && v[j] > thr);
+    }
+    // exclusive scan of the per-thread counts over the block
+    int incl = cnt;
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+    if (lane == 63) wcnt[wave] = incl;
+    __syncthreads();
+    int woff = 0, total = 0;
+    for (int w = 0; w < 4; ++w) { if (w < wave) woff += wcnt[w]; total += wcnt[w]; }
+    if (t == 0) s_base = total ? atomicAdd(&ctrl->n_cand, total) : 0;
+    __syncthreads();
+    int pos = s_base + woff + incl - cnt;
+#pragma unroll
+    for (int j = 0; j < COLLECT_PPT; ++j) {
+        const int i = base_px + j * 256 + t;
+        if (i < n_px && v[j] > thr) {
+            if (pos < cap) cand[pos] = ((unsigned long long)__float_as_uint(v[j]) << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+            else ctrl->overflow = 1;
+            atomicAdd(&hist[min((int)(v[j] * (float)HBINS), HBINS - 1)], 1u);     // scores are in (0, 1]
+            ++pos;
+        }
     }
 }
 // decided between the two collect launches so every thread of the fallback launch sees one answer
@@ -863,7 +884,10 @@ __global__ __launch_bounds__(256) void al_patch_kernel(Pyr P, const float* __res
 }
 
 // offsets = clamp(conv1x1(selu(h32)) + b) ; sample positions in un-padded pixel coordinates
-__global__ void al_offsets_kernel(const float* __restrict__ h32 /*[n][32] pre-activation incl. bias*/,
+constexpr int SDDH_KSPLIT = 4;
+
+__global__ void al_offsets_kernel(const float* __restrict__ h32 /*[KSPLIT][cap][32] partial pre-activations*/,
+                                  int cap, const float* __restrict__ b1,
                                   const float* __restrict__ w2 /*[32][32] (o,i)*/, const float* __restrict__ b2,
                                   const float* __restrict__ kp_norm, int h, int w, float max_off,
                                   float* __restrict__ pos /*[n][16][2]*/, const ALCtrl* __restrict__ ctrl) {
@@ -871,7 +895,11 @@ __global__ void al_offsets_kernel(const float* __restrict__ h32 /*[n][32] pre-ac
     const int n = i / 32, o = i % 32;
     if (n >= ctrl->n_kp) return;
     float acc = 0.0f;
-    for (int k = 0; k < 32; ++k) acc = fmaf(selu(h32[n * 32 + k]), w2[o * 32 + k], acc);
+    for (int k = 0; k < 32; ++k) {
+        float hv = b1[k];
+        for (int z = 0; z < SDDH_KSPLIT; ++z) hv += h32[((size_t)z * cap + n) * 32 + k];
+        acc = fmaf(selu(hv), w2[o * 32 + k], acc);
+    }
     acc = fminf(fmaxf(acc + b2[o], -max_off), max_off);
     // offset[:, :, 0, 0].view(n, 2, M).permute(0, 2, 1): channel o < 16 -> x of position o, else y
     const int p = o & 15, comp = o >> 4;
@@ -919,9 +947,13 @@ __global__ __launch_bounds__(256) void al_gemm_kernel(const float* __restrict__ 
     const int M = ctrl->n_kp * rows_per_kp;
     const int row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
     if (row0 >= M) return;
-    GemmA ga{A, K, A, K, K};   // (A1 unused: K0 == K; a null A1 trips an InstCombine crash in ROCm 7.2)
+    // split-K over blockIdx.z: these GEMMs have few row blocks (M <= 2048) and a long K; slice z
+    // writes its partial product to C + z * row_cap * N, the consumer adds the slices in order
+    const int kper = K / gridDim.z, koff = blockIdx.z * kper;
+    C += (size_t)blockIdx.z * row_cap * N;
+    GemmA ga{A + koff, K, A + koff, K, kper};   // (A1 unused; a null A1 trips an InstCombine crash in ROCm 7.2)
     f32x16 acc[TM][TN];
-    gemm_mainloop<BM, BN, TM, TN>(ga, Wt, K, K, row0, row_cap, col0, N, sm, acc);
+    gemm_mainloop<BM, BN, TM, TN>(ga, Wt + koff, K, kper, row0, row_cap, col0, N, sm, acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -941,7 +973,8 @@ __global__ __launch_bounds__(256) void al_gemm_kernel(const float* __restrict__ 
 
 // L2 normalise (F.normalize), the reference's second normalisation (features_utils.py:100),
 // and keypoints back to input-image pixels; one wave per keypoint
-__global__ __launch_bounds__(256) void al_finalize_kernel(const float* __restrict__ raw, const float* __restrict__ kp_norm,
+__global__ __launch_bounds__(256) void al_finalize_kernel(const float* __restrict__ raw /*[KSPLIT][cap][128]*/, int cap,
+                                                          const float* __restrict__ kp_norm,
                                                           const float* __restrict__ kp_score, int h, int w, float scale_x,
                                                           float scale_y, float* __restrict__ xy_out,
                                                           float* __restrict__ desc_out, float* __restrict__ score_out,
@@ -949,7 +982,11 @@ __global__ __launch_bounds__(256) void al_finalize_kernel(const float* __restric
     const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (blockIdx.x == 0 && threadIdx.x == 0) n_out[0] = ctrl->n_kp;
     if (n >= ctrl->n_kp) return;
-    const float a = raw[(size_t)n * 128 + lane], b = raw[(size_t)n * 128 + 64 + lane];
+    float a = 0.0f, b = 0.0f;
+    for (int z = 0; z < SDDH_KSPLIT; ++z) {
+        a += raw[((size_t)z * cap + n) * 128 + lane];
+        b += raw[((size_t)z * cap + n) * 128 + 64 + lane];
+    }
     float s = a * a + b * b;
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     const float inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
@@ -1073,17 +1110,17 @@ int al_enqueue(sslam_aliked* g, const uint8_t* img_dev, int H, int W, int C, int
     hipLaunchKernelGGL(al_resize_pad_kernel, dim3(sslam::cdiv(Wp, 256), Hp), dim3(256), 0, s, g->fsrc, g->img, d,
                        g->gk + 32, rp.ky, rp.blur);
     // block1
-    dim3 g1(sslam::cdiv(Wp, CT_W), sslam::cdiv(Hp, CT_H));
-    hipLaunchKernelGGL((al_conv3x3_mfma_kernel<3, 16, 1, false, false>), g1, dim3(256), 0, s, g->img, Hp, Wp, g->x1a, Hp,
+    dim3 g1(sslam::cdiv(Wp, CT_W), sslam::cdiv(Hp, 16));
+    hipLaunchKernelGGL((al_conv3x3_mfma_kernel<3, 16, 1, false, false, 4>), g1, dim3(256), 0, s, g->img, Hp, Wp, g->x1a, Hp,
                        Wp, g->b1c1.w, g->b1c1.a, g->b1c1.b, nullptr, nullptr, nullptr, nullptr);
-    hipLaunchKernelGGL((al_conv3x3_mfma_kernel<16, 16, 1, false, false>), g1, dim3(256), 0, s, g->x1a, Hp, Wp, g->x1, Hp,
+    hipLaunchKernelGGL((al_conv3x3_mfma_kernel<16, 16, 1, false, false, 4>), g1, dim3(256), 0, s, g->x1a, Hp, Wp, g->x1, Hp,
                        Wp, g->b1c2.w, g->b1c2.a, g->b1c2.b, nullptr, nullptr, nullptr, nullptr);
     // block2 at 1/2: conv1 pools on load and also emits the downsample branch
     const int H2 = Hp / 2, W2 = Wp / 2;
-    dim3 g2(sslam::cdiv(W2, CT_W), sslam::cdiv(H2, CT_H));
-    hipLaunchKernelGGL((al_conv3x3_mfma_kernel<16, 32, 2, true, false>), g2, dim3(256), 0, s, g->x1, Hp, Wp, g->t2, H2, W2,
+    dim3 g2(sslam::cdiv(W2, CT_W), sslam::cdiv(H2, 8));
+    hipLaunchKernelGGL((al_conv3x3_mfma_kernel<16, 32, 2, true, false, 2>), g2, dim3(256), 0, s, g->x1, Hp, Wp, g->t2, H2, W2,
                        g->b2c1.w, g->b2c1.a, g->b2c1.b, g->b2dw, g->b2db, g->idn2, nullptr);
-    hipLaunchKernelGGL((al_conv3x3_mfma_kernel<32, 32, 1, false, true>), g2, dim3(256), 0, s, g->t2, H2, W2, g->x2, H2, W2,
+    hipLaunchKernelGGL((al_conv3x3_mfma_kernel<32, 32, 1, false, true, 2>), g2, dim3(256), 0, s, g->t2, H2, W2, g->x2, H2, W2,
                        g->b2c2.w, g->b2c2.a, g->b2c2.b, nullptr, nullptr, nullptr, g->idn2);
     // block3 at 1/8 (deformable)
     const int H3 = Hp / 8, W3 = Wp / 8, HW3 = H3 * W3;
@@ -1121,10 +1158,10 @@ int al_enqueue(sslam_aliked* g, const uint8_t* img_dev, int H, int W, int C, int
     // DKD
     const int nbx = sslam::cdiv(d.w, NT_W), nby = sslam::cdiv(d.h, NT_H), npx = d.h * d.w;
     hipLaunchKernelGGL(al_nms_kernel, dim3(nbx, nby), dim3(256), 0, s, g->score, d.h, d.w, g->nms, g->bsum);
-    hipLaunchKernelGGL(al_collect_kernel, dim3(sslam::cdiv(npx, 256)), dim3(256), 0, s, g->nms, npx, 0.2f, 0, g->bsum,
+    hipLaunchKernelGGL(al_collect_kernel, dim3(sslam::cdiv(npx, 256 * COLLECT_PPT)), dim3(256), 0, s, g->nms, npx, 0.2f, 0, g->bsum,
                        nbx * nby, g->cand, g->cand_cap, g->ctrl, g->hist);
     hipLaunchKernelGGL(al_fallback_flag_kernel, dim3(1), dim3(1), 0, s, g->ctrl);
-    hipLaunchKernelGGL(al_collect_kernel, dim3(sslam::cdiv(npx, 256)), dim3(256), 0, s, g->nms, npx, 0.0f, 1, g->bsum,
+    hipLaunchKernelGGL(al_collect_kernel, dim3(sslam::cdiv(npx, 256 * COLLECT_PPT)), dim3(256), 0, s, g->nms, npx, 0.0f, 1, g->bsum,
                        nbx * nby, g->cand, g->cand_cap, g->ctrl, g->hist);
     hipLaunchKernelGGL(al_select_kernel, dim3(1), dim3(1024), (SEL_CAP + EDGE_CAP) * 8, s, g->cand, g->cand_cap, n_limit,
                        g->kp_index, g->ctrl, g->hist);
@@ -1134,19 +1171,19 @@ int al_enqueue(sslam_aliked* g, const uint8_t* img_dev, int H, int W, int C, int
     // SDDH
     hipLaunchKernelGGL(al_patch_kernel, dim3(sslam::cdiv(NK * 9, 4)), dim3(256), 0, s, P, g->rnorm, d.pl, d.pt, d.h, d.w,
                        g->kp_norm, g->patch, g->ctrl);
-    hipLaunchKernelGGL((al_gemm_kernel<64, 64, 1, 1>), dim3(1, sslam::cdiv(NK, 64)), dim3(256), 0, s, g->patch, 1152,
-                       g->d_ow, g->d_ob, 32, g->h32, 1, NK, 0, g->ctrl);
+    hipLaunchKernelGGL((al_gemm_kernel<64, 64, 1, 1>), dim3(1, sslam::cdiv(NK, 64), SDDH_KSPLIT), dim3(256), 0, s, g->patch,
+                       1152, g->d_ow, nullptr, 32, g->h32, 1, NK, 0, g->ctrl);
     const float mo = (float)(d.h > d.w ? d.h : d.w) / 4.0f;
-    hipLaunchKernelGGL(al_offsets_kernel, dim3(sslam::cdiv(NK * 32, 256)), dim3(256), 0, s, g->h32, g->d_w2, g->d_b2,
+    hipLaunchKernelGGL(al_offsets_kernel, dim3(sslam::cdiv(NK * 32, 256)), dim3(256), 0, s, g->h32, NK, g->d_ob, g->d_w2, g->d_b2,
                        g->kp_norm, d.h, d.w, mo, g->pos, g->ctrl);
     hipLaunchKernelGGL(al_sample_kernel, dim3(sslam::cdiv(NK * 16, 4)), dim3(256), 0, s, P, g->rnorm, d.pl, d.pt, d.h,
                        d.w, g->pos, g->sampled, g->ctrl);
     hipLaunchKernelGGL((al_gemm_kernel<64, 128, 1, 2>), dim3(1, sslam::cdiv(NK * 16, 64)), dim3(256), 0, s, g->sampled,
                        128, g->d_sf, nullptr, 128, g->feats, 16, NK * 16, 1, g->ctrl);
-    hipLaunchKernelGGL((al_gemm_kernel<64, 64, 1, 1>), dim3(2, sslam::cdiv(NK, 64)), dim3(256), 0, s, g->feats, 2048,
-                       g->d_agg, nullptr, 128, g->raw, 1, NK, 0, g->ctrl);
+    hipLaunchKernelGGL((al_gemm_kernel<64, 64, 1, 1>), dim3(2, sslam::cdiv(NK, 64), SDDH_KSPLIT), dim3(256), 0, s, g->feats,
+                       2048, g->d_agg, nullptr, 128, g->raw, 1, NK, 0, g->ctrl);
     const float scale_x = (float)d.w / (float)W, scale_y = (float)d.h / (float)H;
-    hipLaunchKernelGGL(al_finalize_kernel, dim3(sslam::cdiv(NK, 4)), dim3(256), 0, s, g->raw, g->kp_norm, g->kp_score,
+    hipLaunchKernelGGL(al_finalize_kernel, dim3(sslam::cdiv(NK, 4)), dim3(256), 0, s, g->raw, NK, g->kp_norm, g->kp_score,
                        d.h, d.w, scale_x, scale_y, xy_out, desc_out, score_out, n_out, g->ctrl);
     SSLAM_HIP_CHECK(hipGetLastError());
     return 0;
@@ -1186,9 +1223,9 @@ int sslam_aliked_create(sslam_ctx* ctx, const float* weights, size_t n_floats, i
         g->cand = A.take<unsigned long long>(g->cand_cap); g->hist = A.take<unsigned>(HBINS);
         g->kp_index = A.take<int>(SEL_CAP);
         g->kp_norm = A.take<float>(2 * NK + 64); g->kp_score = A.take<float>(NK + 64);
-        g->patch = A.take<float>((NK + 64) * 1152); g->h32 = A.take<float>((NK + 64) * 32); g->pos = A.take<float>(NK * 32 + 64);
+        g->patch = A.take<float>((NK + 64) * 1152); g->h32 = A.take<float>(SDDH_KSPLIT * (NK + 64) * 32); g->pos = A.take<float>(NK * 32 + 64);
         g->sampled = A.take<float>((NK * 16 + 64) * 128); g->feats = A.take<float>((NK * 16 + 64) * 128);
-        g->raw = A.take<float>((NK + 64) * 128);
+        g->raw = A.take<float>(SDDH_KSPLIT * (NK + 64) * 128);
         g->out_xy = A.take<float>(2 * NK); g->out_desc = A.take<float>(NK * 128); g->out_score = A.take<float>(NK);
         g->out_n = A.take<int32_t>(16);
     };
