@@ -866,7 +866,7 @@ struct LinearArgsH {
 // LDS ring depth of the split-precision GEMM.  Depth beyond 2 bought nothing measurable (the k-loop is
 // bound by the per-CU load rate, not by tiles in flight), while a small footprint lets blocks of
 // concurrently running kernels (other pairs / the extractor on other streams) share a CU.
-constexpr int RING_MAX = 3;
+constexpr int RING_MAX = 2;
 template <int BM, int BN>
 constexpr int ring_depth() {
     constexpr int stage_bytes = sslam::ring_stage_halves<BM, BN>() * 2;
@@ -1129,6 +1129,23 @@ __global__ __launch_bounds__(256, 2) void lg_attention_h_kernel(AttnArgsH p) {
         }
     };
 
+    // loop-invariant swizzled LDS offsets (halves) of this lane's K and V^T fragments
+    int koffs[2][4], voffs[2][2][2][2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+        const int krow = sub * 32 + lr, kswz = (krow >> 1) & 7;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) koffs[sub][s] = krow * DH + (((2 * s + h) ^ kswz) * 8);
+#pragma unroll
+        for (int s2i = 0; s2i < 2; ++s2i)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int d = db * 32 + lr, vswz = (d >> 1) & 7, c0 = 4 * sub + 2 * s2i;
+                voffs[sub][s2i][db][0] = d * AK + ((c0 ^ vswz) * 8) + 4 * h;
+                voffs[sub][s2i][db][1] = d * AK + (((c0 + 1) ^ vswz) * 8) + 4 * h;
+            }
+    }
+
     if (t0 < t1) issue_tile(t0, 0);
     __syncthreads();                 // drains the DMA (vmcnt(0)) and publishes the tile
     int cur = 0;
@@ -1137,17 +1154,13 @@ __global__ __launch_bounds__(256, 2) void lg_attention_h_kernel(AttnArgsH p) {
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             f32x16 s1, s2;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s1[r] = 0.0f; s2[r] = 0.0f; }
-            const int krow = sub * 32 + lr;
-            const int kswz = (krow >> 1) & 7;
+            const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const int ko = krow * DH + (((2 * s + h) ^ kswz) * 8);
-                const half8 kh = *reinterpret_cast<const half8*>(&sm.k_hi[cur][ko]);
-                const half8 kl = *reinterpret_cast<const half8*>(&sm.k_lo[cur][ko]);
-                s1 = mfma16(kh, qh[s], s1);
-                s2 = mfma16(kh, ql[s], s2);
+                const half8 kh = *reinterpret_cast<const half8*>(&sm.k_hi[cur][koffs[sub][s]]);
+                const half8 kl = *reinterpret_cast<const half8*>(&sm.k_lo[cur][koffs[sub][s]]);
+                s1 = mfma16(kh, qh[s], s == 0 ? zero16 : s1);      // C = inline 0 on the first step
+                s2 = mfma16(kh, ql[s], s == 0 ? zero16 : s2);
                 s2 = mfma16(kl, qh[s], s2);
             }
             const int kbase = tile * AK + sub * 32;
@@ -1189,11 +1202,7 @@ __global__ __launch_bounds__(256, 2) void lg_attention_h_kernel(AttnArgsH p) {
             for (int s2i = 0; s2i < 2; ++s2i) {
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    const int d = db * 32 + lr;
-                    const int vswz = (d >> 1) & 7;
-                    const int c0 = 4 * sub + 2 * s2i;
-                    const int vo0 = d * AK + ((c0 ^ vswz) * 8) + 4 * h;
-                    const int vo1 = d * AK + (((c0 + 1) ^ vswz) * 8) + 4 * h;
+                    const int vo0 = voffs[sub][s2i][db][0], vo1 = voffs[sub][s2i][db][1];
                     const half4 vh0 = *reinterpret_cast<const half4*>(&sm.vt_hi[cur][vo0]);
                     const half4 vh1 = *reinterpret_cast<const half4*>(&sm.vt_hi[cur][vo1]);
                     const half4 vl0 = *reinterpret_cast<const half4*>(&sm.vt_lo[cur][vo0]);
