@@ -141,7 +141,8 @@ int sslam_lightglue_match_dev(sslam_lightglue* lg, const float* xy0, const float
  * events on the context stream; _read synchronises and returns their summed duration and count. */
 int sslam_lightglue_profile(sslam_lightglue* lg, int enable);
 int sslam_lightglue_profile_read(sslam_lightglue* lg, float* total_ms_out, int32_t* launches_out);
-/* Test hook: copy an internal buffer to the host (see lightglue_kernels.hip). */
+/* Test hooks: limit the executed layers; copy an internal buffer to the host. */
+int sslam_lightglue_debug_layers(sslam_lightglue* lg, int layers, int self_only);
 int sslam_lightglue_debug_read(sslam_lightglue* lg, int which, void* dst, size_t bytes);
 
 #ifdef __cplusplus

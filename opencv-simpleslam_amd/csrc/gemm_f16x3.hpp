@@ -23,7 +23,9 @@ constexpr float SPLIT_SCALE = 2048.0f;          // 2^11
 constexpr float SPLIT_INV = 1.0f / 2048.0f;
 
 __device__ __forceinline__ void split_f32(float a, _Float16& hi, _Float16& lo) {
-    hi = (_Float16)a;
+    // an fp16 subnormal is not a safe MFMA operand (flushed on input): below 2^-14 the whole
+    // value moves into the scaled low plane, which keeps 11 bits down to |a| = 2^-25
+    hi = fabsf(a) < 6.103515625e-5f ? (_Float16)0.0f : (_Float16)a;
     lo = (_Float16)((a - (float)hi) * SPLIT_SCALE);
 }
 

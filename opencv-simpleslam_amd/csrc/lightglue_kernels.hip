@@ -1313,6 +1313,8 @@ struct sslam_lightglue {
     int32_t *out_ij, *out_info;
     // split-precision planes (precision == 1)
     int precision = 1;               // 0: fp32 MFMA everywhere; 1: fp16 hi/lo split, 3 MFMA per product
+    int dbg_layers = NL;             // test hook: run only the first dbg_layers layers
+    int dbg_self_only = 0;           // test hook: stop after the self block of the last executed layer
     _Float16 *w_hi, *w_lo;           // whole weight blob, split
     _Float16 *xs_hi, *xs_lo, *msgs_hi, *msgs_lo, *msg2s_hi, *msg2s_lo, *hids_hi, *hids_lo;
     _Float16 *qs_hi, *qs_lo, *ks_hi, *ks_lo, *vts_hi, *vts_lo;
@@ -1449,7 +1451,7 @@ void launch_attention_h(sslam_lightglue* g, hipStream_t s, SplitPtr Q, SplitPtr 
 }
 
 // one transformer layer (self + cross block) on the split-precision path
-void lg_layer_h(sslam_lightglue* g, hipStream_t s, const LGLayerW& l) {
+void lg_layer_h(sslam_lightglue* g, hipStream_t s, const LGLayerW& l, bool self_only) {
     const SplitPtr xs{g->xs_hi, g->xs_lo}, msgs{g->msgs_hi, g->msgs_lo};
     const SplitPtr hids{g->hids_hi, g->hids_lo}, none{nullptr, nullptr};
     const SplitPtr qs{g->qs_hi, g->qs_lo}, ks{g->ks_hi, g->ks_lo}, vts{g->vts_hi, g->vts_lo};
@@ -1474,6 +1476,7 @@ void lg_layer_h(sslam_lightglue* g, hipStream_t s, const LGLayerW& l) {
     }
     launch_attention_h(g, s, qs, ks, vts, 0);
     ffn(l.w1, l.b1, l.lnw, l.lnb, l.w2, l.b2);
+    if (self_only) return;
     {   // cross block: the shared qk projection is both query and key -> sqrt(scale) on it
         LinearArgsH a = linh(g, xs, none, D, D, D, l.cqkv, l.cbqkv, 2 * D);
         a.q = SplitOut{g->qs_hi, g->qs_lo}; a.vt = SplitOut{g->vts_hi, g->vts_lo};
@@ -1505,10 +1508,11 @@ int lg_enqueue(sslam_lightglue* g, int M, int N, const int32_t* m_dev, const int
     if (g->precision == 1)
         hipLaunchKernelGGL(lg_split_rows_kernel, dim3(splitblocks), dim3(256), 0, s, g->x, g->xs_hi, g->xs_lo, D, Kc,
                            g->ctrl);
-    for (int i = 0; i < NL; ++i) {
+    for (int i = 0; i < g->dbg_layers; ++i) {
         const LGLayerW& l = g->L[i];
+        const bool self_only = g->dbg_self_only && i == g->dbg_layers - 1;
         if (g->precision == 1) {
-            lg_layer_h(g, s, l);
+            lg_layer_h(g, s, l, self_only);
         } else {
         // ---- self block
         {
@@ -1518,6 +1522,7 @@ int lg_enqueue(sslam_lightglue* g, int M, int N, const int32_t* m_dev, const int
         }
         launch_attention(g, s, g->q, g->k, g->v, 0);
         launch_ffn(g, s, g->msg, l.w1, l.b1, l.lnw, l.lnb, l.w2, l.b2);
+        if (!self_only) {
         // ---- cross block
         {
             LinearArgs a = lin(g, g->x, D, nullptr, 0, D, D, l.cqkv, l.cbqkv, 2 * D);
@@ -1527,7 +1532,8 @@ int lg_enqueue(sslam_lightglue* g, int M, int N, const int32_t* m_dev, const int
         launch_attention(g, s, g->q, g->q, g->v, 1);
         launch_ffn(g, s, g->msg, l.cw1, l.cb1, l.clnw, l.clnb, l.cw2, l.cb2);
         }
-        if (i == NL - 1) break;
+        }
+        if (i == NL - 1 || i == g->dbg_layers - 1) break;
         // ---- early stop + point pruning (lightglue.py check_if_stop / get_pruning_mask)
         const int do_stop = g->depth_conf > 0.0f;
         const int do_prune = g->width_conf > 0.0f;
@@ -1778,6 +1784,14 @@ int sslam_lightglue_profile_read(sslam_lightglue* g, float* total_ms_out, int32_
 int sslam_lightglue_set_precision(sslam_lightglue* g, int mode) {
     SSLAM_REQUIRE(g != nullptr && (mode == 0 || mode == 1), "sslam_lightglue_set_precision: bad argument");
     g->precision = mode;
+    return 0;
+}
+
+/* Test hook: execute only the first `layers` transformer layers (and optionally only the self block
+ * of the last one) so intermediate token states can be compared with the oracle. */
+int sslam_lightglue_debug_layers(sslam_lightglue* g, int layers, int self_only) {
+    SSLAM_REQUIRE(g != nullptr && layers >= 1 && layers <= NL, "sslam_lightglue_debug_layers: bad argument");
+    g->dbg_layers = layers; g->dbg_self_only = self_only != 0;
     return 0;
 }
 

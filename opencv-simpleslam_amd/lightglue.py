@@ -96,6 +96,11 @@ class LightGlueHIP:
         _native.check(_native.lib().sslam_lightglue_set_precision(self.handle, int(m)))
         self.precision = int(m)
 
+    def debug_layers(self, layers: int, self_only: bool = False):
+        """Test hook: stop the next matches after `layers` layers (after the self block of the last
+        one when `self_only`), so `debug_read(0, ...)` returns that intermediate token state."""
+        _native.check(_native.lib().sslam_lightglue_debug_layers(self.handle, int(layers), int(bool(self_only))))
+
     def profile(self, enable: bool):
         _native.check(_native.lib().sslam_lightglue_profile(self.handle, int(bool(enable))))
 
