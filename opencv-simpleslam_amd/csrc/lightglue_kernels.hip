@@ -19,6 +19,7 @@
 // point pruning) lives in a device-side control block `LGCtrl`; every kernel
 // reads its row counts from it, so one pair is a fixed launch sequence with no
 // host round trip (graph-capturable).
+#include <type_traits>
 #include "common.hpp"
 #include "gemm_f32.hpp"
 #include "gemm_f16x3.hpp"
@@ -333,6 +334,11 @@ __global__ __launch_bounds__(256) void lg_attention_kernel(AttnArgs p) {
         const size_t o3_ = (size_t)min(rb_ + 48, p.Kc - 1) * DH + ac4;                      \
         LD4(rk0, Kb + o0_); LD4(rk1, Kb + o1_); LD4(rk2, Kb + o2_); LD4(rk3, Kb + o3_);     \
         LD4(rv0, Vb + o0_); LD4(rv1, Vb + o1_); LD4(rv2, Vb + o2_); LD4(rv3, Vb + o3_);     \
+        /* keys >= nk get P = 0; keep their (stale) V rows out: 0 x non-finite is not 0 */  \
+        if (rb_ >= nk) rv0 = make_float4(0, 0, 0, 0);                                       \
+        if (rb_ + 16 >= nk) rv1 = make_float4(0, 0, 0, 0);                                  \
+        if (rb_ + 32 >= nk) rv2 = make_float4(0, 0, 0, 0);                                  \
+        if (rb_ + 48 >= nk) rv3 = make_float4(0, 0, 0, 0);                                  \
     }
 #define ATTN_SSTORE(buf_)                                                                   \
     {                                                                                       \
@@ -778,6 +784,7 @@ __global__ __launch_bounds__(1024) void lg_emit_kernel(
     __shared__ int wsum[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int n0 = ctrl->stop == 2 ? 0 : ctrl->n[0];
+    const int n1 = ctrl->n[1];
     const int per = (Kc + 1023) / 1024;
     int keep[8], jj[8], cnt = 0; float sc[8];
     for (int q = 0; q < per; ++q) {
@@ -786,8 +793,10 @@ __global__ __launch_bounds__(1024) void lg_emit_kernel(
         if (i < n0) {
             const int j = arg0[i];
             const float s = expf(best0[i]);
-            k = (col_argmax_merge(pval, parg, Kc, j) == i) && (s > filter_thr) && (s > min_conf);
-            jj[q] = j; sc[q] = s;
+            // a row whose scores are all NaN (non-finite input) has no arg-max: no match, no lookup
+            const bool valid = (unsigned)j < (unsigned)n1;
+            k = valid && (col_argmax_merge(pval, parg, Kc, j) == i) && (s > filter_thr) && (s > min_conf);
+            jj[q] = valid ? j : 0; sc[q] = s;
         }
         keep[q] = k; cnt += k;
     }
@@ -996,14 +1005,14 @@ __global__ __launch_bounds__(512) void lg_linear_h_kernel(LinearArgsH p) {
             if (col < VCOL0) continue;
             const int hd = (col >> 6) & 3, d = col & 63;
             const int row = rd.row0 + rg * 8;
-            if (row >= rd.n) continue;
             float v[8];
+            // keys >= n of the last 64-key tile are written as exact zeros: attention gives them
+            // P = 0, and 0 x (stale, possibly non-finite) would not be 0
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = epi[(rg * 8 + e) * ELD + cl];
+            for (int e = 0; e < 8; ++e) v[e] = row + e < rd.n ? epi[(rg * 8 + e) * ELD + cl] : 0.0f;
             uint4 hi, lo;
             split8(v, hi, lo);
             const size_t o = ((((size_t)rd.img * NH + hd) * (p.Kc / AK) + (row >> 6)) * DH + d) * AK + (row & 63);
-            // rows beyond n inside this 8-group are stale but never read (keys >= n are masked)
             *reinterpret_cast<uint4*>(p.vt.hi + o) = hi;
             *reinterpret_cast<uint4*>(p.vt.lo + o) = lo;
         }
@@ -1244,6 +1253,276 @@ __global__ __launch_bounds__(256, 2) void lg_attention_h_kernel(AttnArgsH p) {
     }
 }
 
+// ---- attention, split precision, software-pipelined ---------------------------------------
+// Same data layout, fragments and LDS image as lg_attention_h_kernel; the loop is re-timed so that
+// one iteration (a 32-key sub-step j) holds three INDEPENDENT instruction streams the scheduler
+// can interleave inside one basic block:
+//     MFMA   O += V^T(j-1) P(j-1)          (P of the previous sub-step, 12 MFMA)
+//     MFMA   S(j+1) = K(j+1) Q^T           (next sub-step's logits, 12 MFMA)
+//     VALU   softmax + hi/lo split of S(j) (this sub-step)
+// so a wave's matrix-core work runs under its own softmax arithmetic instead of after it.
+// K is read one sub-step ahead and V^T one behind, hence separate double buffers with one barrier
+// per 64-key tile: after the even sub-step of tile t, K(t+2) and V^T(t+1) are issued.
+// P is carried scaled by 2^14 (exp2 argument bias; o and l share the factor, m does not): its fp16
+// high plane then leaves the normal range only below 2^-28 of the row maximum, so the split needs
+// no subnormal guard (MFMA flushes fp16 subnormal operands).
+constexpr float P_BIAS = 14.0f;
+// scheduling recipe for one sub-step's basic block: 24 x { 1 MFMA, ATTN_VALU_PER_MFMA VALU }
+#ifndef ATTN_VALU_PER_MFMA
+#define ATTN_VALU_PER_MFMA 8
+#endif
+#if ATTN_VALU_PER_MFMA > 0
+#define ATTN_INTERLEAVE()                                                     \
+    _Pragma("unroll") for (int ig_ = 0; ig_ < 24; ++ig_) {                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, ATTN_VALU_PER_MFMA, 0);   \
+    }
+#else
+#define ATTN_INTERLEAVE()
+#endif
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+template <bool MASK>
+__device__ __forceinline__ void attn_softmax_step(const f32x16& s1, const f32x16& s2, int kbase, int nk, int lane,
+                                                  float& m_run, float& l_run, half8 (&ph)[2], half8 (&pl)[2],
+                                                  f32x16& o1a, f32x16& o2a, f32x16& o1b, f32x16& o2b) {
+    float2v sv[8];
+    const float2v inv2 = {SPLIT_INV, SPLIT_INV};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const float2v a = {s1[2 * r], s1[2 * r + 1]}, b = {s2[2 * r], s2[2 * r + 1]};
+        sv[r] = __builtin_elementwise_fma(b, inv2, a);
+    }
+    if constexpr (MASK) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (kbase + acc_row(r, lane) >= nk) sv[r >> 1][r & 1] = -INFINITY;
+    }
+    float tmax = fmaxf(sv[0][0], sv[0][1]);
+#pragma unroll
+    for (int r = 1; r < 8; ++r) tmax = fmaxf(fmaxf(tmax, sv[r][0]), sv[r][1]);
+    {   // the other 16 keys of this query live in lane ^ 32
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        tmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    const float mb = m_new - P_BIAS;
+    const float2v mb2 = {mb, mb};
+    float2v psum = {0.0f, 0.0f};
+    const float2v sc2 = {sslam::SPLIT_SCALE, sslam::SPLIT_SCALE};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const float2v d = sv[r] - mb2;
+        float2v pv;
+        pv[0] = __builtin_amdgcn_exp2f(d[0]);
+        pv[1] = __builtin_amdgcn_exp2f(d[1]);
+        psum += pv;
+        const sslam::half2v hh = __builtin_convertvector(pv, sslam::half2v);
+        const float2v back = __builtin_convertvector(hh, float2v);
+        const float2v res = (pv - back) * sc2;
+        const sslam::half2v ll = __builtin_convertvector(res, sslam::half2v);
+        ph[r >> 2][2 * (r & 3)] = hh[0]; ph[r >> 2][2 * (r & 3) + 1] = hh[1];
+        pl[r >> 2][2 * (r & 3)] = ll[0]; pl[r >> 2][2 * (r & 3) + 1] = ll[1];
+    }
+    l_run = l_run * alpha + (psum[0] + psum[1]);
+    o1a *= alpha; o2a *= alpha; o1b *= alpha; o2b *= alpha;
+}
+
+#ifndef ATTN_ABL
+#define ATTN_ABL 0          // experiments: 1 no MFMA, 2 no softmax, 4 no LDS fragment reads, 8 no tile DMA in the loop
+#endif
+#if ATTN_ABL & 1
+__device__ __forceinline__ f32x16 mf_fake(half8 a, half8 b, f32x16 c) { c[0] += (float)a[0] * (float)b[0]; return c; }
+#define MF mf_fake
+#else
+#define MF mfma16
+#endif
+#if ATTN_ABL & 2
+template <bool MASK>
+__device__ __forceinline__ void softmax_fake(const f32x16& s1, const f32x16& s2, int, int, int, float& m_run, float& l_run,
+                                             half8 (&ph)[2], half8 (&pl)[2], f32x16&, f32x16&, f32x16&, f32x16&) {
+    for (int i = 0; i < 2; ++i) for (int e = 0; e < 8; ++e) { ph[i][e] = (_Float16)s1[8 * i + e]; pl[i][e] = (_Float16)s2[8 * i + e]; }
+    m_run = 0.0f; l_run += 1.0f;
+}
+#define SOFTMAX_STEP softmax_fake
+#else
+#define SOFTMAX_STEP attn_softmax_step
+#endif
+__global__ __launch_bounds__(256, 2) void lg_attention_p_kernel(AttnArgsH p) {
+    __shared__ AttnSmemH sm;
+    if (p.ctrl->stop) return;
+    const int nqb = gridDim.x, nslab = gridDim.y * gridDim.z;
+    int slab, qb;
+    {
+        const int b = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if ((nslab & 7) == 0) { const int xcd = b & 7, idx = b >> 3; slab = xcd + 8 * (idx / nqb); qb = idx % nqb; }
+        else { slab = blockIdx.z * gridDim.y + blockIdx.y; qb = blockIdx.x; }
+    }
+    const int z = slab / gridDim.y, ih = slab % gridDim.y;
+    const int img = ih >> 2, head = ih & 3;
+    const int kimg = p.cross ? 1 - img : img;
+    const int nq = p.ctrl->n[img], nk = p.ctrl->n[kimg];
+    const int q0 = qb * AQ;
+    if (q0 >= nq) return;
+    const int t = threadIdx.x, lane = t & 63, h = lane >> 5, lr = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int ntiles = (nk + AK - 1) / AK;
+    const int t0 = (int)((long)z * ntiles / p.KS), t1 = (int)((long)(z + 1) * ntiles / p.KS);
+
+    const size_t qoff = ((size_t)img * NH + head) * p.Kc * DH;
+    const size_t koff = ((size_t)kimg * NH + head) * p.Kc * DH;
+
+    const int qi = min(q0 + wave * 32 + lr, p.Kc - 1);
+    half8 qh[4], ql[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        qh[s] = *reinterpret_cast<const half8*>(p.Q.hi + qoff + (size_t)qi * DH + 16 * s + 8 * h);
+        ql[s] = *reinterpret_cast<const half8*>(p.Q.lo + qoff + (size_t)qi * DH + 16 * s + 8 * h);
+    }
+
+    f32x16 o1a, o2a, o1b, o2b;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o1a[r] = 0.0f; o2a[r] = 0.0f; o1b[r] = 0.0f; o2b[r] = 0.0f; }
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    // wave w owns plane w (K hi, K lo, V^T hi, V^T lo): 8 DMA instructions of 8 rows per tile
+    const _Float16* gplane = (wave == 0 ? p.K.hi : wave == 1 ? p.K.lo : wave == 2 ? p.VT.hi : p.VT.lo) + koff;
+    const bool is_v = wave >= 2;
+    const int lrow = lane >> 3, lcp = lane & 7;
+    auto issue_tile = [&](int tile, int buf) {
+        _Float16* dst = wave == 0 ? sm.k_hi[buf] : wave == 1 ? sm.k_lo[buf] : wave == 2 ? sm.vt_hi[buf] : sm.vt_lo[buf];
+#pragma unroll
+        for (int rg = 0; rg < 8; ++rg) {
+            const int row = rg * 8 + lrow;
+            const int c = lcp ^ ((row >> 1) & 7);
+            const _Float16* src = is_v ? gplane + ((size_t)tile * DH + row) * AK + c * 8
+                                       : gplane + (size_t)min(tile * AK + row, p.Kc - 1) * DH + c * 8;
+            glds16(src, dst + rg * 8 * DH);
+        }
+    };
+
+    int koffs[2][4], voffs[2][2][2][2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+        const int krow = sub * 32 + lr, kswz = (krow >> 1) & 7;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) koffs[sub][s] = krow * DH + (((2 * s + h) ^ kswz) * 8);
+#pragma unroll
+        for (int s2i = 0; s2i < 2; ++s2i)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int d = db * 32 + lr, vswz = (d >> 1) & 7, c0 = 4 * sub + 2 * s2i;
+                voffs[sub][s2i][db][0] = d * AK + ((c0 ^ vswz) * 8) + 4 * h;
+                voffs[sub][s2i][db][1] = d * AK + (((c0 + 1) ^ vswz) * 8) + 4 * h;
+            }
+    }
+
+    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto qk = [&](int buf, int sub, f32x16& s1, f32x16& s2) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#if ATTN_ABL & 4
+            const half8 kh = qh[(s + 1) & 3], kl = ql[(s + 2) & 3];
+#else
+            const half8 kh = *reinterpret_cast<const half8*>(&sm.k_hi[buf][koffs[sub][s]]);
+            const half8 kl = *reinterpret_cast<const half8*>(&sm.k_lo[buf][koffs[sub][s]]);
+#endif
+            s1 = MF(kh, qh[s], s == 0 ? zero16 : s1);
+            s2 = MF(kh, ql[s], s == 0 ? zero16 : s2);
+            s2 = MF(kl, qh[s], s2);
+        }
+    };
+    auto pv = [&](int buf, int sub, const half8 (&ph)[2], const half8 (&pl)[2]) {
+#pragma unroll
+        for (int s2i = 0; s2i < 2; ++s2i) {
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int vo0 = voffs[sub][s2i][db][0], vo1 = voffs[sub][s2i][db][1];
+                const half4 vh0 = *reinterpret_cast<const half4*>(&sm.vt_hi[buf][vo0]);
+                const half4 vh1 = *reinterpret_cast<const half4*>(&sm.vt_hi[buf][vo1]);
+                const half4 vl0 = *reinterpret_cast<const half4*>(&sm.vt_lo[buf][vo0]);
+                const half4 vl1 = *reinterpret_cast<const half4*>(&sm.vt_lo[buf][vo1]);
+#if ATTN_ABL & 4
+                const half8 vh = qh[s2i + db], vl = ql[s2i + db];
+#else
+                const half8 vh = __builtin_shufflevector(vh0, vh1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const half8 vl = __builtin_shufflevector(vl0, vl1, 0, 1, 2, 3, 4, 5, 6, 7);
+#endif
+                if (db == 0) {
+                    o1a = MF(vh, ph[s2i], o1a);
+                    o2a = MF(vh, pl[s2i], o2a);
+                    o2a = MF(vl, ph[s2i], o2a);
+                } else {
+                    o1b = MF(vh, ph[s2i], o1b);
+                    o2b = MF(vh, pl[s2i], o2b);
+                    o2b = MF(vl, ph[s2i], o2b);
+                }
+            }
+        }
+    };
+
+    if (t0 < t1) {
+        issue_tile(t0, 0);                       // K(t0) and V^T(t0)
+        __syncthreads();
+        if (!is_v && t0 + 1 < t1) issue_tile(t0 + 1, 1);          // K(t0+1); V^T(t0+1) follows the first even step
+        f32x16 s1, s2, n1, n2;                   // logits: current / next sub-step (ping-pong)
+        half8 ph[2], pl[2], nh[2], nl[2];        // P: previous / current sub-step (ping-pong)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ph[i][e] = (_Float16)0.0f; pl[i][e] = (_Float16)0.0f; }
+        qk(0, 0, s1, s2);
+        // One tile = two branch-free sub-steps.  First tile: the "previous" P is zero and is
+        // multiplied into the (finite) landed V^T buffer; last tile: the look-ahead logits are
+        // computed on the current K buffer and dropped.
+        auto tile_body = [&](auto mask_c, int tile) {
+            constexpr bool MASK = decltype(mask_c)::value;
+            const int b = (tile - t0) & 1;
+            const bool last = tile + 1 == t1;
+            // even: softmax(S(tile,0)) | S(tile,1) = K.Q^T | O += V^T(tile-1,1) P
+            pv(tile > t0 ? b ^ 1 : b, 1, ph, pl);
+            qk(b, 1, n1, n2);
+            SOFTMAX_STEP<MASK>(s1, s2, tile * AK, nk, lane, m_run, l_run, nh, nl, o1a, o2a, o1b, o2b);
+            ATTN_INTERLEAVE();
+            __syncthreads();     // K(tile+1), V^T(tile) landed; K(tile) and V^T(tile-1) are free
+#if !(ATTN_ABL & 8)
+            if (is_v) { if (tile + 1 < t1) issue_tile(tile + 1, b ^ 1); }
+            else      { if (tile + 2 < t1) issue_tile(tile + 2, b); }
+#endif
+            // odd: softmax(S(tile,1)) | S(tile+1,0) | O += V^T(tile,0) P
+            pv(b, 0, nh, nl);
+            qk(last ? b : b ^ 1, 0, s1, s2);
+            SOFTMAX_STEP<MASK>(n1, n2, tile * AK + 32, nk, lane, m_run, l_run, ph, pl, o1a, o2a, o1b, o2b);
+            ATTN_INTERLEAVE();
+        };
+        const bool ragged = (nk & (AK - 1)) != 0;            // only the last tile of the image can be
+        const int tfull = (ragged && t1 == ntiles) ? t1 - 1 : t1;
+        for (int tile = t0; tile < tfull; ++tile) tile_body(std::false_type{}, tile);
+        if (tfull < t1) tile_body(std::true_type{}, t1 - 1);
+        pv((t1 - 1 - t0) & 1, 1, ph, pl);        // the last sub-step's P
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const int qrow = q0 + wave * 32 + lr;
+    if (qrow < nq) {
+        const size_t pbase = (((size_t)z * 2 + img) * NH + head) * p.Kc + qrow;
+        float* op = p.o_part + pbase * DH;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            float4 a, b;
+            a.x = o1a[4 * g4] + o2a[4 * g4] * SPLIT_INV; a.y = o1a[4 * g4 + 1] + o2a[4 * g4 + 1] * SPLIT_INV;
+            a.z = o1a[4 * g4 + 2] + o2a[4 * g4 + 2] * SPLIT_INV; a.w = o1a[4 * g4 + 3] + o2a[4 * g4 + 3] * SPLIT_INV;
+            b.x = o1b[4 * g4] + o2b[4 * g4] * SPLIT_INV; b.y = o1b[4 * g4 + 1] + o2b[4 * g4 + 1] * SPLIT_INV;
+            b.z = o1b[4 * g4 + 2] + o2b[4 * g4 + 2] * SPLIT_INV; b.w = o1b[4 * g4 + 3] + o2b[4 * g4 + 3] * SPLIT_INV;
+            *reinterpret_cast<float4*>(op + 8 * g4 + 4 * h) = a;
+            *reinterpret_cast<float4*>(op + 32 + 8 * g4 + 4 * h) = b;
+        }
+        if (h == 0) { p.m_part[pbase] = m_run; p.l_part[pbase] = l_tot; }
+    }
+}
+
 // merge key-split partials -> split planes of msg[img][row][head*64 + d]
 __global__ __launch_bounds__(256) void lg_attn_merge_h_kernel(const float* __restrict__ o_part,
                                                               const float* __restrict__ m_part,
@@ -1443,7 +1722,9 @@ void launch_attention_h(sslam_lightglue* g, hipStream_t s, SplitPtr Q, SplitPtr 
             for (int i = 0; i < 64; ++i) { hipEvent_t e; (void)hipEventCreate(&e); g->ev.push_back(e); }
         (void)hipEventRecord(g->ev[g->ev_used], s);
     }
-    hipLaunchKernelGGL(lg_attention_h_kernel, grid, dim3(256), 0, s, a);
+    static const bool pipelined = [] { const char* e = getenv("SSLAM_ATTN"); return !(e && e[0] == '0'); }();
+    if (pipelined) hipLaunchKernelGGL(lg_attention_p_kernel, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(lg_attention_h_kernel, grid, dim3(256), 0, s, a);
     if (prof) { (void)hipEventRecord(g->ev[g->ev_used + 1], s); g->ev_used += 2; }
     const long n4 = (long)2 * NH * g->Kc * 16;
     hipLaunchKernelGGL(lg_attn_merge_h_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, g->o_part,

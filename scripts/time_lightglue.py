@@ -25,4 +25,10 @@ for _ in range(iters):
 ms = ctx.timer_stop() / iters
 inf = np.empty(4, np.int32); ctx.d2h(inf, info)
 gf = (4*N*128*256 + 9*(2*(6*N*256*256+4*N*N*256+2*N*256*256+8*N*256*256+4*N*256*256) + 2*(4*N*256*256+4*N*N*256+2*N*256*256+8*N*256*256+4*N*256*256)) + 4*N*256*256+2*N*N*256)/1e9
+lg.profile(True)
+for _ in range(4):
+    lg.match_dev(dk0, dd0, N, dk1, dd1, N, ij, sc, info)
+ctx.sync(); lg.profile(False)
+ams, an = lg.profile_read()
+print(f"attention: {an} launches, {ams/max(an,1)*1e3:.1f} us avg")
 print(f"N={N} pair {ms:.3f} ms  -> {1000/ms:.1f} pairs/s  {gf/ms:.1f} TFLOP/s algorithmic ({gf:.1f} GF)  info={inf}")

@@ -183,3 +183,30 @@ def test_token_state_per_layer_is_fp32_grade(W, LG, precision):
                 np.testing.assert_allclose(x[img, :n], want, atol=2e-5, rtol=0,
                                            err_msg=f"{precision} layer {layer} {key} image {img}")
     lg.close()
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_non_finite_input_gives_no_fault(W, LG, precision):
+    """NaN / Inf descriptors or keypoints must not crash the device: rows without a finite
+    arg-max simply produce no match, and the instance keeps working afterwards."""
+    sd = W.random_lightglue_state_dict(1, match_gain=4.0, match_bias=3.0)
+    lg = LG(sd, max_kpts=256)
+    lg.set_precision(precision)
+    k0, d0, k1, d1 = lg_inputs.make_pair(200, 180, seed=3)
+    good = lg.match(k0, d0, k1, d1, min_conf=0.1)
+    bad_d = d0.copy(); bad_d[:] = np.nan
+    ij, sc, _ = lg.match(k0, bad_d, k1, d1, min_conf=0.1)
+    assert len(ij) == 0
+    bad_k = k1.copy(); bad_k[5] = np.inf
+    ij, sc, _ = lg.match(k0, d0, bad_k, d1, min_conf=0.1)
+    assert ij.shape[1] == 2 and (len(ij) == 0 or (ij[:, 0].max() < 200 and ij[:, 1].max() < 180))
+    again = lg.match(k0, d0, k1, d1, min_conf=0.1)
+    np.testing.assert_array_equal(good[0], again[0])
+    np.testing.assert_array_equal(good[1], again[1])
+    # stale non-finite rows of a larger, poisoned problem must not leak into a smaller one
+    small = lg.match(k0[:70], d0[:70], k1[:90], d1[:90], min_conf=0.1)
+    lg.match(k0, bad_d, k1, bad_d[:180], min_conf=0.1)
+    small2 = lg.match(k0[:70], d0[:70], k1[:90], d1[:90], min_conf=0.1)
+    np.testing.assert_array_equal(small[0], small2[0])
+    np.testing.assert_array_equal(small[1], small2[1])
+    lg.close()
