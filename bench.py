@@ -46,6 +46,23 @@ def noise_frame(idx):
     return np.random.default_rng(1234 + idx).integers(0, 256, (H_IMG, W_IMG, C_IMG), dtype=np.uint8)
 
 
+_STRUCT_BASE = None
+
+
+def structured_frame(idx):
+    """SURVEY 8(d) second input: the noise low-pass filtered with a 9x9 box (stretched back to
+    0..255) and translated 3 px per frame, so consecutive frames really overlap."""
+    global _STRUCT_BASE
+    if _STRUCT_BASE is None:
+        from scipy.ndimage import uniform_filter
+        base = np.random.default_rng(1234).integers(0, 256, (H_IMG, W_IMG + 512, C_IMG)).astype(np.float32)
+        low = uniform_filter(base, size=(9, 9, 1), mode="reflect")
+        lo, hi = low.min(), low.max()
+        _STRUCT_BASE = np.clip((low - lo) * (255.0 / (hi - lo)), 0, 255).astype(np.uint8)
+    off = (3 * idx) % 512
+    return np.ascontiguousarray(_STRUCT_BASE[:, off:off + W_IMG])
+
+
 def attention_flops(n0, n1):
     """Algorithmic FLOPs of one attention launch (both images, 4 heads x 64): SURVEY 8(d) counts
     4 N^2 D per image per block (QK^T + AV)."""
@@ -177,10 +194,24 @@ def main():
         m0.profile(False)
         iso_ms, iso_n = m0.profile_read()
 
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        # second input of SURVEY 8(d): the structured (low-pass, translating) stream, same pipeline
+        spool = [torch.from_numpy(np.stack([structured_frame(f) for f in plan.frames(r)])).cuda()
+                 for r in range(2)]
+        for i in range(2):
+            pipe.round(spool[i % 2], H_IMG, W_IMG, C_IMG)
+        barrier()
+        s_steps = max(2, args.steps // 2)
+        ts0 = time.perf_counter()
+        for i in range(s_steps):
+            pipe.round(spool[i % 2], H_IMG, W_IMG, C_IMG)
+        barrier()
+        s_dt = time.perf_counter() - ts0
+        s_info = pipe.info.cpu().numpy()
+
+    t = torch.tensor([dt, s_dt], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt_max = float(t.item())
+    dt_max, s_dt_max = float(t[0].item()), float(t[1].item())
 
     if rank == 0:
         frames_total = args.steps * plan.frames_per_round()
@@ -202,7 +233,7 @@ def main():
                        "parallelism": f"frame-shard x{world}; per GPU {N_EXT} extractor + {N_MAT} matcher streams"},
             # achieved = ALGORITHMIC flops (8 n0 n1 256 per launch) / HIP-event launch duration on one
             # stream; the kernel issues 3 v_mfma_f32_32x32x16_f16 per algorithmic product (executed = 3x)
-            "roofline": {"bound": "mfma", "kernel": "lg_attention_h_kernel (v_mfma_f32_32x32x16_f16 x3 per product)",
+            "roofline": {"bound": "mfma", "kernel": "lg_attention_p_kernel (v_mfma_f32_32x32x16_f16 x3 per product)",
                          "achieved": round(ach, 2) if ach else None, "peak": F16_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(ach / F16_MFMA_PEAK_TFLOPS, 4) if ach else None,
                          "traffic": None,
@@ -212,6 +243,11 @@ def main():
                          "timed_region_launches": attn_n,
                          "timed_region_avg_bracket_us": round(attn_ms / max(attn_n, 1) * 1e3, 2)},
         }
+        out["structured_input"] = {
+            "value": round(s_steps * plan.frames_per_round() / s_dt_max, 2), "unit": "frames/s", "steps": s_steps,
+            "what": "same pipeline on the 9x9-box low-pass noise translating 3 px/frame (SURVEY 8(d))",
+            "matches_last_pair": int(s_info[-1, 0]), "lightglue_layers_executed": int(s_info[-1, 1]),
+            "kpts_matched": [int(s_info[-1, 2]), int(s_info[-1, 3])]}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -1369,7 +1369,11 @@ __global__ __launch_bounds__(256, 2) void lg_attention_p_kernel(AttnArgsH p) {
     const int t = threadIdx.x, lane = t & 63, h = lane >> 5, lr = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int ntiles = (nk + AK - 1) / AK;
+#if ATTN_ABL & 32
+    const int t0 = (int)((long)z * ntiles / p.KS), t1 = min(t0 + 1, (int)((long)(z + 1) * ntiles / p.KS));
+#else
     const int t0 = (int)((long)z * ntiles / p.KS), t1 = (int)((long)(z + 1) * ntiles / p.KS);
+#endif
 
     const size_t qoff = ((size_t)img * NH + head) * p.Kc * DH;
     const size_t koff = ((size_t)kimg * NH + head) * p.Kc * DH;
@@ -1516,8 +1520,13 @@ __global__ __launch_bounds__(256, 2) void lg_attention_p_kernel(AttnArgsH p) {
             a.z = o1a[4 * g4 + 2] + o2a[4 * g4 + 2] * SPLIT_INV; a.w = o1a[4 * g4 + 3] + o2a[4 * g4 + 3] * SPLIT_INV;
             b.x = o1b[4 * g4] + o2b[4 * g4] * SPLIT_INV; b.y = o1b[4 * g4 + 1] + o2b[4 * g4 + 1] * SPLIT_INV;
             b.z = o1b[4 * g4 + 2] + o2b[4 * g4 + 2] * SPLIT_INV; b.w = o1b[4 * g4 + 3] + o2b[4 * g4 + 3] * SPLIT_INV;
-            *reinterpret_cast<float4*>(op + 8 * g4 + 4 * h) = a;
-            *reinterpret_cast<float4*>(op + 32 + 8 * g4 + 4 * h) = b;
+#if ATTN_ABL & 16
+            if (a.x == 123.456f && b.y == 654.321f)
+#endif
+            {
+                *reinterpret_cast<float4*>(op + 8 * g4 + 4 * h) = a;
+                *reinterpret_cast<float4*>(op + 32 + 8 * g4 + 4 * h) = b;
+            }
         }
         if (h == 0) { p.m_part[pbase] = m_run; p.l_part[pbase] = l_tot; }
     }
