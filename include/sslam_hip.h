@@ -78,6 +78,26 @@ int sslam_ba_residual_jacobian_dev(sslam_ctx* ctx, int n_obs,
                                    const double* intr, double* r, double* Jq,
                                    double* Jt, double* JX);
 
+/* Whole local-BA solve on the device: replaces `pyceres.solve(opts, problem, summary)` at
+ * slam/core/ba_utils.py:288-293 for the problem `_core_ba` assembles (:220-286): Huber(delta)
+ * on every reprojection block (:236), EigenQuaternionManifold on every quaternion (:245-249),
+ * constant blocks for the gauge keyframes (:250-257) and - with points_const - for the
+ * landmarks (pose_only_ba, :89-140); Ceres' default trust-region constants, at most
+ * `max_iters` iterations (:289-292).  Levenberg-Marquardt with the Schur complement onto the
+ * optimised poses; linearisation, reduction, Cholesky, step evaluation and the accept / reject /
+ * terminate logic all run on the GPU as one enqueue (no host round trip per iteration).
+ *   q[n_poses*4], t[n_poses*3], X[n_points*3] : in = initial values, out = optimised
+ *   pose_const[n_poses] : 1 = held fixed.  At most 12 non-constant poses (more -> rc 2;
+ *                         global BA keeps the host Schur loop around the residual kernel)
+ *   summary[8] : iterations, successful steps, initial cost, final cost (0.5 sum rho),
+ *                termination (0 max iterations, 1 gradient, 2 parameter, 3 function tolerance,
+ *                4 trust region collapsed), final radius, #optimised poses, 0 */
+int sslam_ba_solve_host(sslam_ctx* ctx, int n_obs, const int32_t* pose_idx,
+                        const int32_t* point_idx, const double* uv, int n_poses, double* q,
+                        double* t, const unsigned char* pose_const, int n_points, double* X,
+                        const double* intr, int max_iters, double huber_delta, int points_const,
+                        double* summary);
+
 /* ------------------------------------------------------------------ ALIKED
  * Replaces `ALIKED(max_num_keypoints=...).eval().to(device)` at
  * slam/core/features_utils.py:25 and `_bgr_to_tensor` + `detector.extract` +

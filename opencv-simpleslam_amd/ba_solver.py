@@ -11,8 +11,16 @@ the Schur complement onto the <= window_size poses, LM radius update with
 Ceres' defaults (initial radius 1e4, min_relative_decrease 1e-3,
 function/gradient/parameter tolerances 1e-6 / 1e-10 / 1e-8).
 
-The reduced camera system is at most 6*window wide, so the dense algebra stays
-on the host in numpy for now (SURVEY.md section 8(f) rank 1 moves it on device).
+Two drivers share that algorithm:
+
+* `solve_device` - `sslam_ba_solve_host` (csrc/ba_lm.hip): the whole loop on the GPU, control
+  state in a device control block, one enqueue per solve.
+  Takes up to MAX_DEVICE_POSES optimised poses (local BA: window_size 6 / 10).
+* `solve_host` - the numpy loop below around the HIP residual/Jacobian kernel; used for
+  global BA (hundreds of optimised poses: the dense Schur layout of the device path does
+  not fit) and as the independent restatement the device path is tested against.
+
+`solve` picks by problem size (override: SSLAM_BA_SOLVER=host|device).
 """
 from __future__ import annotations
 
@@ -97,10 +105,51 @@ def _huber(s, delta):
     return rho, w
 
 
+MAX_DEVICE_POSES = 12
+_TERMINATION = {0: "max iterations", 1: "gradient tolerance", 2: "parameter tolerance",
+                3: "function tolerance", 4: "trust region collapsed"}
+
+
+def solve_device(prob: BAProblem, max_iters: int, huber_delta: float = 2.0, ctx=None,
+                 points_const: bool = False) -> BASummary:
+    """Device-resident LM (csrc/ba_lm.hip).  Optimises prob.q/t/X in place."""
+    ctx = ctx or _native.default_context()
+    P = _native.ptr
+    q = np.ascontiguousarray(prob.q, np.float64).copy()
+    t = np.ascontiguousarray(prob.t, np.float64).copy()
+    X = np.ascontiguousarray(prob.X, np.float64).copy()
+    const = np.ascontiguousarray(prob.pose_const, np.uint8)
+    obs_pose = np.ascontiguousarray(prob.obs_pose, np.int32)
+    obs_point = np.ascontiguousarray(prob.obs_point, np.int32)
+    uv = np.ascontiguousarray(prob.obs_uv, np.float64)
+    intr = np.ascontiguousarray(prob.intr, np.float64)
+    out = np.zeros(8, np.float64)
+    _native.check(_native.lib().sslam_ba_solve_host(
+        ctx.handle, len(obs_pose), P(obs_pose), P(obs_point), P(uv), len(q), P(q), P(t), P(const),
+        len(X), P(X), P(intr), int(max_iters), float(huber_delta), int(bool(points_const)), P(out)),
+        "sslam_ba_solve_host")
+    prob.q[:] = q
+    prob.t[:] = t
+    prob.X[:] = X
+    return BASummary(iterations=int(out[0]), successful_steps=int(out[1]), initial_cost=float(out[2]),
+                     final_cost=float(out[3]), termination=_TERMINATION.get(int(out[4]), "?"))
+
+
 def solve(prob: BAProblem, max_iters: int, huber_delta: float = 2.0, ctx=None,
           points_const: bool = False) -> BASummary:
-    """Optimise prob.q/t (non-constant rows) and prob.X in place.  With
-    `points_const` the landmarks are held fixed (pose-only BA)."""
+    """Optimise prob.q/t (non-constant rows) and prob.X in place.  With `points_const` the
+    landmarks are held fixed (pose-only BA).  Device LM when the window fits, else host loop."""
+    import os
+    mode = os.environ.get("SSLAM_BA_SOLVER", "auto")
+    n_opt = int(np.count_nonzero(~np.asarray(prob.pose_const, bool)))
+    if mode == "device" or (mode == "auto" and n_opt <= MAX_DEVICE_POSES and int(max_iters) > 0):
+        return solve_device(prob, max_iters, huber_delta, ctx, points_const)
+    return solve_host(prob, max_iters, huber_delta, ctx, points_const)
+
+
+def solve_host(prob: BAProblem, max_iters: int, huber_delta: float = 2.0, ctx=None,
+               points_const: bool = False) -> BASummary:
+    """numpy LM / Schur loop around the HIP residual + Jacobian kernel."""
     ctx = ctx or _native.default_context()
     ev = _Evaluator(prob, ctx)
     summ = BASummary()

@@ -186,3 +186,92 @@ def assemble_core_ba(points, kf_uv, opt_kf_idx, fix_kf_idx, max_points=None):
         "obs_kf": np.asarray(obs_kf, np.int32),
         "obs_uv": np.asarray(obs_uv, np.float64).reshape(-1, 2),
     }
+
+
+# --------------------------------------------------------------------------- #
+#  Dense trust-region solve (reference: ba_utils.py:288-293 -> pyceres.solve)
+# --------------------------------------------------------------------------- #
+def solve_dense_lm(q, t, pose_const, X, intr, obs_pose, obs_point, obs_uv, max_iters,
+                   huber_delta=2.0, points_const=False):
+    """What `pyceres.solve(opts, problem, summary)` does to the `_core_ba` problem, restated
+    with ONE dense Jacobian and dense normal equations (no Schur elimination, no block
+    structure) - small problems only.  Ceres 2.x defaults the reference leaves untouched
+    (ba_utils.py:289-292 sets only max_num_iterations / linear solver / threads):
+    LEVENBERG_MARQUARDT, initial_trust_region_radius 1e4, min/max_lm_diagonal 1e-6 / 1e32,
+    min_relative_decrease 1e-3, radius update r / max(1/3, 1 - (2 rho - 1)^3) on success,
+    r / decrease (decrease doubling) on failure, function / gradient / parameter tolerances
+    1e-6 / 1e-10 / 1e-8; HuberLoss(delta) applied as sqrt(rho') scaling (corrector with
+    rho'' <= 0); EigenQuaternionManifold on every quaternion.  PARITY UNPINNED (pyceres
+    absent): Ceres' exact iterates depend on its linear solver and are not reproduced, the
+    policy and the fixed point are.  Returns (q, t, X, info)."""
+    q, t, X = np.array(q, np.float64), np.array(t, np.float64), np.array(X, np.float64)
+    pose_const = np.asarray(pose_const, bool)
+    opt_rows = np.flatnonzero(~pose_const)
+    Po, Q, n = len(opt_rows), len(X), len(obs_pose)
+    slot = -np.ones(len(q), int)
+    slot[opt_rows] = np.arange(Po)
+    nX = 0 if points_const else 3 * Q
+    dim = 6 * Po + nX
+
+    def cost_of(qq, tt, XX):
+        r = reproj_residual_jacobian(obs_pose, obs_point, obs_uv, qq, tt, XX, intr)[0]
+        if not np.all(np.isfinite(r)):
+            return np.inf
+        return 0.5 * float(np.sum(huber_rho(np.sum(r * r, axis=1), huber_delta)[0]))
+
+    cost = cost_of(q, t, X)
+    info = {"initial_cost": cost, "iterations": 0, "successful_steps": 0, "termination": "max iterations"}
+    radius, decrease = 1e4, 2.0
+    for it in range(int(max_iters)):
+        info["iterations"] = it + 1
+        r, Jq, Jt, JX = reproj_residual_jacobian(obs_pose, obs_point, obs_uv, q, t, X, intr)
+        sw = np.sqrt(huber_rho(np.sum(r * r, axis=1), huber_delta)[1])
+        J = np.zeros((2 * n, dim))
+        pj = quat_plus_jacobian(q)
+        for i in range(n):
+            s = slot[obs_pose[i]]
+            if s >= 0:
+                J[2 * i:2 * i + 2, 6 * s:6 * s + 3] = sw[i] * (Jq[i] @ pj[obs_pose[i]])
+                J[2 * i:2 * i + 2, 6 * s + 3:6 * s + 6] = sw[i] * Jt[i]
+            if not points_const:
+                c = 6 * Po + 3 * obs_point[i]
+                J[2 * i:2 * i + 2, c:c + 3] = sw[i] * JX[i]
+        f = (r * sw[:, None]).reshape(-1)
+        g = J.T @ f
+        if np.max(np.abs(g), initial=0.0) < 1e-10:
+            info["termination"] = "gradient tolerance"
+            break
+        H = J.T @ J
+        D = np.clip(np.diag(H), 1e-6, 1e32) / radius
+        d = np.linalg.solve(H + np.diag(D), -g)
+        Jd = J @ d
+        model_change = -float(Jd @ (f + 0.5 * Jd))
+        x_norm = np.sqrt(np.sum(X * X) + np.sum(q[opt_rows] ** 2) + np.sum(t[opt_rows] ** 2))
+        if np.linalg.norm(d) <= 1e-8 * (x_norm + 1e-8):
+            info["termination"] = "parameter tolerance"
+            break
+        qn, tn, Xn = q.copy(), t.copy(), X.copy()
+        for s, row in enumerate(opt_rows):
+            qn[row] = quat_plus(q[row], d[6 * s:6 * s + 3])
+            tn[row] = t[row] + d[6 * s + 3:6 * s + 6]
+        if not points_const:
+            Xn = X + d[6 * Po:].reshape(Q, 3)
+        new_cost = cost_of(qn, tn, Xn)
+        rel = (cost - new_cost) / model_change if model_change > 0 else -1.0
+        if rel > 1e-3 and np.isfinite(new_cost):
+            change = cost - new_cost
+            q, t, X, cost = qn, tn, Xn, new_cost
+            info["successful_steps"] += 1
+            radius = min(1e16, radius / max(1.0 / 3.0, 1.0 - (2.0 * rel - 1.0) ** 3))
+            decrease = 2.0
+            if abs(change) < 1e-6 * cost:
+                info["termination"] = "function tolerance"
+                break
+        else:
+            radius /= decrease
+            decrease *= 2.0
+            if radius < 1e-32:
+                info["termination"] = "trust region collapsed"
+                break
+    info["final_cost"] = cost
+    return q, t, X, info

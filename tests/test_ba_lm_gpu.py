@@ -1,0 +1,123 @@
+"""GPU parity of the device-resident LM (csrc/ba_lm.hip, `sslam_ba_solve_host`):
+against the dense-Jacobian oracle (oracle/ba_ref.solve_dense_lm) on small scenes, against the
+host Schur loop (ba_solver.solve_host) at the C3 size, plus determinism and edge cases.
+fp64 throughout; tolerance 1e-8 relative on parameters (summation order differs), identical
+iteration / step counts and termination reason."""
+import copy
+
+import numpy as np
+import pytest
+
+import ba_scenes
+from conftest import load_pkg
+from oracle import ba_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _snapshot(n_frames=10, window=8, noise=True, n_points=50):
+    bau = load_pkg("slam.core.ba_utils")
+    wmap, kfs, K = ba_scenes.reference_test_scene(n_frames, n_points=n_points, add_noise=noise)
+    c = n_frames - 1
+    first = max(1, c - window + 1)
+    prob, _, _ = bau.snapshot_problem(wmap, K, kfs, list(range(first, c + 1)), list(range(0, first)))
+    return prob
+
+
+def _clone(p):
+    return copy.deepcopy(p)
+
+
+def _close(a, b, tol=1e-8):
+    np.testing.assert_allclose(a.q, b.q, rtol=tol, atol=tol)
+    np.testing.assert_allclose(a.t, b.t, rtol=tol, atol=tol)
+    np.testing.assert_allclose(a.X, b.X, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("points_const", [False, True])
+def test_device_lm_matches_dense_oracle(points_const):
+    S = load_pkg("ba_solver")
+    prob = _snapshot()
+    dev = _clone(prob)
+    sd = S.solve_device(dev, 25, 2.0, points_const=points_const)
+    q, t, X, info = ba_ref.solve_dense_lm(prob.q, prob.t, prob.pose_const, prob.X, prob.intr, prob.obs_pose,
+                                          prob.obs_point, prob.obs_uv, 25, 2.0, points_const)
+    assert sd.iterations == info["iterations"] and sd.successful_steps == info["successful_steps"]
+    assert sd.termination == info["termination"]
+    np.testing.assert_allclose(sd.initial_cost, info["initial_cost"], rtol=1e-12)
+    np.testing.assert_allclose(sd.final_cost, info["final_cost"], rtol=1e-9)
+    assert sd.final_cost < 0.5 * sd.initial_cost
+    np.testing.assert_allclose(dev.q, q, rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(dev.t, t, rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(dev.X, X, rtol=1e-7, atol=1e-7)
+    # constant blocks are bit-for-bit untouched
+    np.testing.assert_array_equal(dev.q[prob.pose_const], prob.q[prob.pose_const])
+    np.testing.assert_array_equal(dev.t[prob.pose_const], prob.t[prob.pose_const])
+    if points_const:
+        np.testing.assert_array_equal(dev.X, prob.X)
+
+
+def test_device_lm_matches_host_schur_loop_at_c3_size_and_is_deterministic():
+    """SURVEY 8(d) C3 scene (10 opt + 5 fixed KFs, 5000 points, ~30 k observations)."""
+    S = load_pkg("ba_solver")
+    bau = load_pkg("slam.core.ba_utils")
+    wmap, kfs, K = ba_scenes.scaled_scene()
+    prob, _, _ = bau.snapshot_problem(wmap, K, kfs, list(range(5, 15)), list(range(0, 5)), 5000)
+    assert len(prob.obs_pose) > 20000
+    host, dev, dev2 = _clone(prob), _clone(prob), _clone(prob)
+    sh = S.solve_host(host, 12, 2.0)
+    sd = S.solve_device(dev, 12, 2.0)
+    sd2 = S.solve_device(dev2, 12, 2.0)
+    assert (sd.iterations, sd.successful_steps, sd.termination) == (sh.iterations, sh.successful_steps, sh.termination)
+    np.testing.assert_allclose(sd.final_cost, sh.final_cost, rtol=1e-9)
+    _close(dev, host, 1e-7)
+    # order-fixed reductions: bit-identical from run to run
+    assert sd2.final_cost == sd.final_cost
+    np.testing.assert_array_equal(dev.q, dev2.q)
+    np.testing.assert_array_equal(dev.X, dev2.X)
+
+
+def test_device_lm_perfect_scene_stops_at_once_and_zero_iters():
+    S = load_pkg("ba_solver")
+    prob = _snapshot(noise=False)
+    dev = _clone(prob)
+    sd = S.solve_device(dev, 10, 2.0)
+    assert sd.final_cost <= sd.initial_cost <= 1e-12 * len(prob.obs_pose) + 1e-9
+    _close(dev, prob, 1e-6)
+    dev = _clone(_snapshot())
+    before = _clone(dev)
+    sd = S.solve_device(dev, 0, 2.0)
+    assert sd.iterations == 0 and sd.termination == "max iterations" and sd.final_cost == sd.initial_cost
+    np.testing.assert_array_equal(dev.X, before.X)
+
+
+def test_device_lm_rejects_oversized_window_and_bad_index(native):
+    S = load_pkg("ba_solver")
+    prob = _snapshot(n_frames=10, window=8)
+    big = _clone(prob)
+    big.pose_const = np.zeros(len(big.q), bool)
+    reps = 2
+    big.q = np.tile(big.q, (reps, 1)); big.t = np.tile(big.t, (reps, 1)); big.pose_const = np.zeros(len(big.q), bool)
+    with pytest.raises(native.NativeError, match="optimised poses"):
+        S.solve_device(big, 5, 2.0)
+    bad = _clone(prob)
+    bad.obs_point = bad.obs_point.copy(); bad.obs_point[3] = len(bad.X)
+    with pytest.raises(native.NativeError, match="out of range"):
+        S.solve_device(bad, 5, 2.0)
+
+
+def test_outliers_are_down_weighted_like_the_oracle():
+    """Gross outliers (50 px) on 10 % of the observations: Huber keeps the fixed point of the
+    dense oracle."""
+    S = load_pkg("ba_solver")
+    prob = _snapshot()
+    rng = np.random.default_rng(7)
+    bad = rng.choice(len(prob.obs_uv), len(prob.obs_uv) // 10, replace=False)
+    prob.obs_uv[bad] += rng.normal(0, 50.0, (len(bad), 2))
+    dev = _clone(prob)
+    sd = S.solve_device(dev, 30, 2.0)
+    q, t, X, info = ba_ref.solve_dense_lm(prob.q, prob.t, prob.pose_const, prob.X, prob.intr, prob.obs_pose,
+                                          prob.obs_point, prob.obs_uv, 30, 2.0)
+    np.testing.assert_allclose(sd.final_cost, info["final_cost"], rtol=1e-8)
+    assert sd.successful_steps == info["successful_steps"]
+    np.testing.assert_allclose(dev.t, t, rtol=1e-6, atol=1e-7)

@@ -123,3 +123,40 @@ def test_product_snapshot_matches_reference_trace():
     np.testing.assert_allclose(prob.intr, [G["K"][0, 0], G["K"][1, 1], G["K"][0, 2], G["K"][1, 2]])
     assert int(G["rec_max_iters"]) == int(G["max_iters"])
     assert int(G["few_n_res"]) < 10 and int(G["few_solved"]) == 0
+
+
+def _scene_problem(noise):
+    import ba_scenes
+    bau = load_pkg("slam.core.ba_utils")
+    wmap, kfs, K = ba_scenes.reference_test_scene(8, n_points=40, add_noise=noise)
+    prob, _, _ = bau.snapshot_problem(wmap, K, kfs, list(range(2, 8)), [0, 1])
+    return prob
+
+
+def _rmse(p, q, t, X):
+    r = ba_ref.reproj_residual_jacobian(p.obs_pose, p.obs_point, p.obs_uv, q, t, X, p.intr)[0]
+    return float(np.sqrt(np.mean(np.sum(r * r, axis=1))))
+
+
+def test_dense_lm_has_the_reference_tests_property():
+    """The one numeric property the reference's BA test pins (tests/test_ba_utils_T_c_w.py:264-314
+    on the seeded scene of :116-218): RMSE does not increase on a perfect scene and strictly
+    decreases on the noisy one; constant blocks stay bit-identical."""
+    p = _scene_problem(False)
+    q, t, X, info = ba_ref.solve_dense_lm(p.q, p.t, p.pose_const, p.X, p.intr, p.obs_pose, p.obs_point,
+                                          p.obs_uv, 10)
+    assert _rmse(p, q, t, X) <= _rmse(p, p.q, p.t, p.X) + 1e-9
+    p = _scene_problem(True)
+    q, t, X, info = ba_ref.solve_dense_lm(p.q, p.t, p.pose_const, p.X, p.intr, p.obs_pose, p.obs_point,
+                                          p.obs_uv, 25)
+    assert _rmse(p, q, t, X) < 0.5 * _rmse(p, p.q, p.t, p.X)
+    assert info["successful_steps"] >= 3 and info["final_cost"] < info["initial_cost"]
+    np.testing.assert_array_equal(q[p.pose_const], p.q[p.pose_const])
+    np.testing.assert_array_equal(t[p.pose_const], p.t[p.pose_const])
+    # unit quaternions stay unit under the manifold step
+    np.testing.assert_allclose(np.linalg.norm(q, axis=1), 1.0, atol=1e-12)
+    # pose-only variant leaves the landmarks alone
+    q2, t2, X2, _ = ba_ref.solve_dense_lm(p.q, p.t, p.pose_const, p.X, p.intr, p.obs_pose, p.obs_point,
+                                          p.obs_uv, 10, points_const=True)
+    np.testing.assert_array_equal(X2, p.X)
+    assert _rmse(p, q2, t2, X2) < _rmse(p, p.q, p.t, p.X)
