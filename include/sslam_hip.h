@@ -98,6 +98,19 @@ int sslam_ba_solve_host(sslam_ctx* ctx, int n_obs, const int32_t* pose_idx,
                         const double* intr, int max_iters, double huber_delta, int points_const,
                         double* summary);
 
+/* ------------------------------------------------------- F-matrix RANSAC
+ * Replaces `cv2.findFundamentalMat(pts1, pts2, cv2.FM_RANSAC, thresh, 0.99)` inside
+ * `filter_matches_ransac` (slam/core/features_utils.py:185-200): OpenCV 4.x's classic path
+ * (7-point RANSAC for >= 15 matches, LMedS for 8..14, cv::RNG sample stream), scored on the GPU.
+ *   pts1, pts2 : float32 [n][2] matched pixel coordinates (host), n >= 8
+ *   thresh <= 0 -> 3, confidence outside (0,1) -> 0.99, max_iters <= 0 -> 1000 (cv2 defaults)
+ *   mask_out[n] : 1 = inlier;  F_out[9] (may be NULL): row-major, F[8] = 1 or 0
+ *   info_out[4] (may be NULL): inliers (-1: no model, cv2 would return mask None),
+ *                              iterations the sequential loop runs, 1 if LMedS, winning sample */
+int sslam_fmat_ransac_host(sslam_ctx* ctx, int n, const float* pts1, const float* pts2,
+                           double thresh, double confidence, int max_iters,
+                           unsigned char* mask_out, double* F_out, int* info_out);
+
 /* ------------------------------------------------------------------ ALIKED
  * Replaces `ALIKED(max_num_keypoints=...).eval().to(device)` at
  * slam/core/features_utils.py:25 and `_bgr_to_tensor` + `detector.extract` +

@@ -1,0 +1,428 @@
+// ransac_kernels.hip - fundamental-matrix RANSAC / LMedS outlier filter on the GPU.
+//
+// Replaces `cv2.findFundamentalMat(pts1, pts2, cv2.FM_RANSAC, thresh, 0.99)` as called by
+// `filter_matches_ransac` (slam/core/features_utils.py:185-200; callers main_revamped.py:126,
+// keyframe_utils.py:154, triangulation_utils.py:132) - SURVEY.md section 8(f) rank 2.
+//
+// The algorithm is OpenCV 4.x's classic (non-USAC) path, restated from its published source
+// (modules/calib3d/src/fundam.cpp, ptsetreg.cpp; opencv_python==4.11.0.86 in requirements.txt):
+//   * >= 15 points: RANSAC, 7-point minimal solver (1-3 models per sample), error = max of the two
+//     squared point-to-epipolar-line distances (computed in double, rounded to float), inlier
+//     iff err <= (float)(thresh^2), best = strictly larger inlier count, iteration budget
+//     re-estimated after every improvement (RANSACUpdateNumIters), no refit on the inliers;
+//   * 8..14 points: LMedS (least median of the same error; sigma = 2.5*1.4826*(1+5/(n-7))*
+//     sqrt(median), inliers at sigma), budget from a fixed 45 % outlier ratio;
+//   * samples: cv::RNG (multiply-with-carry, state 2^64-1), getSubset (re-draw duplicates,
+//     reject subsets whose last point is collinear with / too close to an earlier pair).
+// PARITY UNPINNED: cv2 is absent here; the null space comes from Gauss-Jordan elimination with
+// complete pivoting instead of OpenCV's Jacobi SVD (same solutions up to rounding).
+//
+// The sequential loop is data-dependent only through (a) the RNG stream and (b) the running
+// best / iteration budget.  (a) is replayed by one lane (a few thousand integer ops); the
+// expensive part - solving every sample and scoring every model against every match - runs
+// wide (thread per sample, workgroup per model); (b) is then replayed exactly by one lane
+// over the stored scores.  The result is what the sequential loop would have produced.
+#include "common.hpp"
+
+#include <cfloat>
+
+namespace {
+
+constexpr int RS_MAX_ITERS = 1000;       // cv::findFundamentalMat default maxIters
+constexpr int RS_MP = 7;                 // model points
+constexpr int RS_T = 256;
+constexpr int RS_SUBSET_ATTEMPTS = 10000;
+constexpr int RS_LMEDS_MAX = 14;         // < 15 points -> LMedS
+
+struct RSCtrl {
+    int n_subsets;      // samples generated (getSubset may give up)
+    int lmeds;          // 1 = LMedS path
+    int niters;         // iterations the sequential loop would have run
+    int best_h, best_k; // winning sample / model (-1: none)
+    int best_count;     // inliers of the winner (RANSAC) / final count
+    int pad[2];
+    double thresh;      // threshold actually applied by the mask pass (pixels)
+    double F[9];
+};
+
+struct RSArgs {
+    int n; int max_iters;
+    double thresh, confidence;
+    const float* p1; const float* p2;         // [n][2]
+    int* subsets;                             // [max_iters][7]
+    double* models;                           // [max_iters][3][9]
+    int* nmodels;                             // [max_iters]
+    int* counts;                              // [max_iters][3]  RANSAC inlier counts
+    float* medians;                           // [max_iters][3]  LMedS medians
+    unsigned char* mask;                      // [n]
+    RSCtrl* ctrl;
+};
+
+// ---- cv::RNG ------------------------------------------------------------------------------
+struct CvRng {
+    unsigned long long state;
+    __device__ unsigned next() {
+        state = (unsigned long long)(unsigned)state * 4164903690ULL + (unsigned)(state >> 32);
+        return (unsigned)state;
+    }
+    __device__ int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
+};
+
+// haveCollinearPoints(m, count): last point against every earlier pair
+__device__ bool last_point_collinear(const float* p, const int* idx, int count) {
+    const int i = count - 1;
+    const float xi = p[2 * idx[i]], yi = p[2 * idx[i] + 1];
+    for (int j = 0; j < i; ++j) {
+        const double dx1 = p[2 * idx[j]] - xi, dy1 = p[2 * idx[j] + 1] - yi;
+        for (int k = 0; k < j; ++k) {
+            const double dx2 = p[2 * idx[k]] - xi, dy2 = p[2 * idx[k] + 1] - yi;
+            if (fabs(dx2 * dy1 - dy2 * dx1) <= (double)FLT_EPSILON * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2)))
+                return true;
+        }
+    }
+    return false;
+}
+
+// RANSACUpdateNumIters(p, ep, modelPoints, maxIters)
+__device__ int update_num_iters(double p, double ep, int model_points, int max_iters) {
+    p = fmax(p, 0.0); p = fmin(p, 1.0);
+    ep = fmax(ep, 0.0); ep = fmin(ep, 1.0);
+    double num = fmax(1.0 - p, DBL_MIN);
+    double denom = 1.0 - pow(1.0 - ep, (double)model_points);
+    if (denom < DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
+}
+
+// ---- 1. replay the sample stream (one lane) --------------------------------------------------
+__global__ void rs_subsets_kernel(RSArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    RSCtrl* c = a.ctrl;
+    CvRng rng{0xffffffffffffffffULL};
+    const int n = a.n;
+    c->lmeds = n <= RS_LMEDS_MAX;
+    int budget = a.max_iters;
+    if (c->lmeds) budget = max(update_num_iters(a.confidence, 0.45, RS_MP, a.max_iters), 1);   // LMeDS: fixed budget
+    int made = 0;
+    for (int it = 0; it < budget; ++it) {
+        int idx[RS_MP];
+        int attempts = 0;
+        for (; attempts < RS_SUBSET_ATTEMPTS; ++attempts) {
+            for (int i = 0; i < RS_MP; ++i) {
+                int v;
+                bool dup;
+                do {
+                    v = rng.uniform(0, n);
+                    dup = false;
+                    for (int j = 0; j < i; ++j) dup |= idx[j] == v;
+                } while (dup);
+                idx[i] = v;
+            }
+            if (!last_point_collinear(a.p1, idx, RS_MP) && !last_point_collinear(a.p2, idx, RS_MP)) break;
+        }
+        if (attempts == RS_SUBSET_ATTEMPTS) break;       // getSubset failed: the loop ends here
+        for (int i = 0; i < RS_MP; ++i) a.subsets[it * RS_MP + i] = idx[i];
+        ++made;
+    }
+    c->n_subsets = made;
+    c->best_h = c->best_k = -1;
+    c->best_count = 0;
+    c->niters = 0;
+}
+
+// ---- 2. 7-point solver (thread / sample) -------------------------------------------------------
+__device__ __forceinline__ double det3(const double* m) {
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+
+// cv::solveCubic for c[0] x^3 + c[1] x^2 + c[2] x + c[3] = 0; returns the number of real roots
+__device__ int solve_cubic(const double* c, double* r) {
+    double a0 = c[0], a1 = c[1], a2 = c[2], a3 = c[3];
+    int n = 0;
+    double x0 = 0, x1 = 0, x2 = 0;
+    if (a0 == 0) {
+        if (a1 == 0) {
+            if (a2 == 0) n = a3 == 0 ? -1 : 0;
+            else { x0 = -a3 / a2; n = 1; }
+        } else {
+            double d = a2 * a2 - 4 * a1 * a3;
+            if (d >= 0) {
+                d = sqrt(d);
+                const double q1 = (-a2 + d) * 0.5, q2 = (a2 + d) * -0.5;
+                if (fabs(q1) > fabs(q2)) { x0 = q1 / a1; x1 = a3 / q1; }
+                else { x0 = q2 / a1; x1 = a3 / q2; }
+                n = d > 0 ? 2 : 1;
+            }
+        }
+    } else {
+        a0 = 1. / a0; a1 *= a0; a2 *= a0; a3 *= a0;
+        const double Q = (a1 * a1 - 3 * a2) * (1. / 9);
+        const double R = (2 * a1 * a1 * a1 - 9 * a1 * a2 + 27 * a3) * (1. / 54);
+        const double Qcubed = Q * Q * Q;
+        double d = Qcubed - R * R;
+        if (d > 0) {
+            const double theta = acos(R / sqrt(Qcubed));
+            const double sqrtQ = sqrt(Q);
+            const double t0 = -2 * sqrtQ, t1 = theta * (1. / 3), t2 = a1 * (1. / 3);
+            x0 = t0 * cos(t1) - t2;
+            x1 = t0 * cos(t1 + (2. * M_PI / 3)) - t2;
+            x2 = t0 * cos(t1 + (4. * M_PI / 3)) - t2;
+            n = 3;
+        } else if (d == 0) {
+            if (R >= 0) { x0 = -2 * pow(R, 1. / 3) - a1 / 3; x1 = pow(R, 1. / 3) - a1 / 3; }
+            else { x0 = 2 * pow(-R, 1. / 3) - a1 / 3; x1 = -pow(-R, 1. / 3) - a1 / 3; }
+            x2 = 0;
+            n = x0 == x1 ? 1 : 2;
+            x1 = x0 == x1 ? 0 : x1;
+        } else {
+            d = sqrt(-d);
+            double e = pow(d + fabs(R), 1. / 3);
+            if (R > 0) e = -e;
+            x0 = (e + Q / e) - a1 * (1. / 3);
+            n = 1;
+        }
+    }
+    r[0] = x0; r[1] = x1; r[2] = x2;
+    return n;
+}
+
+__global__ __launch_bounds__(64) void rs_models_kernel(RSArgs a) {
+    const int h = blockIdx.x * 64 + threadIdx.x;
+    if (h >= a.ctrl->n_subsets) return;
+    // rows: (m2, 1)^T F (m1, 1) = 0
+    double A[RS_MP][9];
+    for (int i = 0; i < RS_MP; ++i) {
+        const int id = a.subsets[h * RS_MP + i];
+        const double x0 = a.p1[2 * id], y0 = a.p1[2 * id + 1], x1 = a.p2[2 * id], y1 = a.p2[2 * id + 1];
+        A[i][0] = x1 * x0; A[i][1] = x1 * y0; A[i][2] = x1; A[i][3] = y1 * x0; A[i][4] = y1 * y0; A[i][5] = y1;
+        A[i][6] = x0; A[i][7] = y0; A[i][8] = 1;
+    }
+    // Gauss-Jordan with complete pivoting -> two free columns span the null space
+    int colp[9];
+    for (int j = 0; j < 9; ++j) colp[j] = j;
+    bool ok = true;
+    for (int k = 0; k < RS_MP; ++k) {
+        int pr = k, pc = k;
+        double best = -1.0;
+        for (int i = k; i < RS_MP; ++i)
+            for (int j = k; j < 9; ++j) {
+                const double v = fabs(A[i][j]);
+                if (v > best) { best = v; pr = i; pc = j; }
+            }
+        if (!(best > 0.0)) { ok = false; break; }
+        for (int j = 0; j < 9; ++j) { const double tmp = A[k][j]; A[k][j] = A[pr][j]; A[pr][j] = tmp; }
+        for (int i = 0; i < RS_MP; ++i) { const double tmp = A[i][k]; A[i][k] = A[i][pc]; A[i][pc] = tmp; }
+        { const int tmp = colp[k]; colp[k] = colp[pc]; colp[pc] = tmp; }
+        const double inv = 1.0 / A[k][k];
+        for (int j = k; j < 9; ++j) A[k][j] *= inv;
+        for (int i = 0; i < RS_MP; ++i) {
+            if (i == k) continue;
+            const double f = A[i][k];
+            if (f != 0.0)
+                for (int j = k; j < 9; ++j) A[i][j] -= f * A[k][j];
+        }
+    }
+    int nm = 0;
+    double* out = a.models + (size_t)h * 27;
+    if (ok) {
+        double f1[9], f2[9];             // null vectors for free columns 7 and 8 (permuted order)
+        for (int k = 0; k < RS_MP; ++k) { f1[colp[k]] = -A[k][7]; f2[colp[k]] = -A[k][8]; }
+        f1[colp[7]] = 1.0; f1[colp[8]] = 0.0;
+        f2[colp[7]] = 0.0; f2[colp[8]] = 1.0;
+        // F(lambda) = lambda f1 + (1 - lambda) f2 = lambda (f1 - f2) + f2; det F = 0 is a cubic
+        double g[9];
+        for (int i = 0; i < 9; ++i) g[i] = f1[i] - f2[i];
+        double c[4], m[9];
+        c[0] = det3(g);
+        c[3] = det3(f2);
+        c[1] = 0.0; c[2] = 0.0;
+        for (int row = 0; row < 3; ++row) {
+            for (int i = 0; i < 9; ++i) m[i] = g[i];
+            for (int j = 0; j < 3; ++j) m[3 * row + j] = f2[3 * row + j];
+            c[1] += det3(m);                                  // two rows of g, one of f2 -> lambda^2
+            for (int i = 0; i < 9; ++i) m[i] = f2[i];
+            for (int j = 0; j < 3; ++j) m[3 * row + j] = g[3 * row + j];
+            c[2] += det3(m);                                  // one row of g, two of f2 -> lambda
+        }
+        double r[3];
+        const int n = solve_cubic(c, r);
+        if (n >= 1 && n <= 3) {
+            for (int k = 0; k < n; ++k) {
+                double lambda = r[k], mu = 1.0;
+                const double s = g[8] * r[k] + f2[8];
+                double F8;
+                if (fabs(s) > DBL_EPSILON) { mu = 1.0 / s; lambda *= mu; F8 = 1.0; } else F8 = 0.0;
+                for (int i = 0; i < 8; ++i) out[9 * nm + i] = g[i] * lambda + f2[i] * mu;
+                out[9 * nm + 8] = F8;
+                ++nm;
+            }
+        }
+    }
+    a.nmodels[h] = nm;
+}
+
+// symmetric epipolar error of FMEstimatorCallback::computeError (double arithmetic, float result)
+__device__ __forceinline__ float fm_error(const double* F, float x1, float y1, float x2, float y2) {
+    double a = F[0] * x1 + F[1] * y1 + F[2];
+    double b = F[3] * x1 + F[4] * y1 + F[5];
+    double c = F[6] * x1 + F[7] * y1 + F[8];
+    const double s2 = 1. / (a * a + b * b);
+    const double d2 = x2 * a + y2 * b + c;
+    a = F[0] * x2 + F[3] * y2 + F[6];
+    b = F[1] * x2 + F[4] * y2 + F[7];
+    c = F[2] * x2 + F[5] * y2 + F[8];
+    const double s1 = 1. / (a * a + b * b);
+    const double d1 = x1 * a + y1 * b + c;
+    return (float)fmax(d1 * d1 * s1, d2 * d2 * s2);
+}
+
+// ---- 3. score every model against every match (workgroup / model) ---------------------------
+__global__ __launch_bounds__(RS_T) void rs_score_kernel(RSArgs a) {
+    __shared__ int sh[RS_T];
+    const int h = blockIdx.x, k = blockIdx.y;
+    const RSCtrl* c = a.ctrl;
+    if (h >= c->n_subsets || k >= a.nmodels[h]) return;
+    double F[9];
+    for (int i = 0; i < 9; ++i) F[i] = a.models[(size_t)h * 27 + 9 * k + i];
+    if (c->lmeds) {
+        // n <= 14: one lane sorts the errors and takes the median
+        if (threadIdx.x == 0) {
+            float e[RS_LMEDS_MAX];
+            for (int i = 0; i < a.n; ++i) e[i] = fm_error(F, a.p1[2 * i], a.p1[2 * i + 1], a.p2[2 * i], a.p2[2 * i + 1]);
+            for (int i = 1; i < a.n; ++i) {
+                const float v = e[i];
+                int j = i - 1;
+                // NaN-safe insertion: a NaN compares false and stays where it is
+                while (j >= 0 && e[j] > v) { e[j + 1] = e[j]; --j; }
+                e[j + 1] = v;
+            }
+            a.medians[h * 3 + k] = a.n % 2 != 0 ? e[a.n / 2] : (e[a.n / 2 - 1] + e[a.n / 2]) * 0.5f;
+        }
+        return;
+    }
+    const float t = (float)(a.thresh * a.thresh);
+    int good = 0;
+    for (int i = threadIdx.x; i < a.n; i += RS_T)
+        good += fm_error(F, a.p1[2 * i], a.p1[2 * i + 1], a.p2[2 * i], a.p2[2 * i + 1]) <= t;
+    sh[threadIdx.x] = good;
+    __syncthreads();
+    for (int s = RS_T / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.counts[h * 3 + k] = sh[0];
+}
+
+// ---- 4. replay the sequential best / budget logic (one lane) ---------------------------------
+__global__ void rs_select_kernel(RSArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    RSCtrl* c = a.ctrl;
+    const int n = a.n;
+    if (c->lmeds) {
+        double min_median = DBL_MAX;
+        for (int it = 0; it < c->n_subsets; ++it)
+            for (int k = 0; k < a.nmodels[it]; ++k) {
+                const double med = a.medians[it * 3 + k];
+                if (med < min_median) { min_median = med; c->best_h = it; c->best_k = k; }
+            }
+        c->niters = c->n_subsets;
+        if (c->best_h >= 0) {
+            double sigma = 2.5 * 1.4826 * (1 + 5. / (n - RS_MP)) * sqrt(min_median);
+            sigma = fmax(sigma, 0.001);
+            c->thresh = sigma;
+        }
+    } else {
+        int niters = max(a.max_iters, 1), max_good = 0, it = 0;
+        for (; it < niters && it < c->n_subsets; ++it)
+            for (int k = 0; k < a.nmodels[it]; ++k) {
+                const int good = a.counts[it * 3 + k];
+                if (good > max(max_good, RS_MP - 1)) {
+                    max_good = good;
+                    c->best_h = it; c->best_k = k;
+                    niters = update_num_iters(a.confidence, (double)(n - good) / n, RS_MP, niters);
+                }
+            }
+        c->niters = it;
+        c->thresh = a.thresh;
+    }
+    if (c->best_h >= 0)
+        for (int i = 0; i < 9; ++i) c->F[i] = a.models[(size_t)c->best_h * 27 + 9 * c->best_k + i];
+}
+
+// ---- 5. inlier mask of the winner ---------------------------------------------------------------
+__global__ __launch_bounds__(RS_T) void rs_mask_kernel(RSArgs a) {
+    __shared__ int sh[RS_T];
+    RSCtrl* c = a.ctrl;
+    const bool have = c->best_h >= 0;
+    const float t = (float)(c->thresh * c->thresh);
+    int good = 0;
+    for (int i = threadIdx.x; i < a.n; i += RS_T) {
+        const int in = have && fm_error(c->F, a.p1[2 * i], a.p1[2 * i + 1], a.p2[2 * i], a.p2[2 * i + 1]) <= t;
+        a.mask[i] = (unsigned char)in;
+        good += in;
+    }
+    sh[threadIdx.x] = good;
+    __syncthreads();
+    for (int s = RS_T / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) c->best_count = sh[0];
+}
+
+}  // namespace
+
+extern "C" int sslam_fmat_ransac_host(sslam_ctx* ctx, int n, const float* pts1, const float* pts2, double thresh,
+                                      double confidence, int max_iters, unsigned char* mask_out, double* F_out,
+                                      int* info_out) {
+    SSLAM_REQUIRE(ctx != nullptr, "sslam_fmat_ransac_host: ctx is NULL");
+    SSLAM_REQUIRE(n >= 8, "sslam_fmat_ransac_host: %d matches, need >= 8 (the caller returns fewer unchanged)", n);
+    SSLAM_REQUIRE(pts1 && pts2 && mask_out, "sslam_fmat_ransac_host: NULL argument");
+    // cv::findFundamentalMat's own defaulting of bad parameters
+    if (thresh <= 0) thresh = 3;
+    if (confidence < DBL_EPSILON || confidence > 1 - DBL_EPSILON) confidence = 0.99;
+    if (max_iters <= 0 || max_iters > RS_MAX_ITERS) max_iters = RS_MAX_ITERS;
+    SSLAM_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t N = (size_t)n, H = (size_t)max_iters;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = sslam::align_up(off + bytes + 8, 256); return o; };
+    const size_t o_p1 = carve(N * 8), o_p2 = carve(N * 8), o_sub = carve(H * RS_MP * 4), o_mod = carve(H * 27 * 8);
+    const size_t o_nm = carve(H * 4), o_cnt = carve(H * 12), o_med = carve(H * 12), o_mask = carve(N), o_ctrl = carve(sizeof(RSCtrl));
+    if (off > ctx->ba_scratch_bytes) {
+        if (ctx->ba_scratch) SSLAM_HIP_CHECK(hipFree(ctx->ba_scratch));
+        ctx->ba_scratch = nullptr;
+        ctx->ba_scratch_bytes = 0;
+        SSLAM_HIP_CHECK(hipMalloc(&ctx->ba_scratch, off));
+        ctx->ba_scratch_bytes = off;
+    }
+    char* b = (char*)ctx->ba_scratch;
+    hipStream_t s = ctx->stream;
+    SSLAM_HIP_CHECK(hipMemcpyAsync(b + o_p1, pts1, N * 8, hipMemcpyHostToDevice, s));
+    SSLAM_HIP_CHECK(hipMemcpyAsync(b + o_p2, pts2, N * 8, hipMemcpyHostToDevice, s));
+    SSLAM_HIP_CHECK(hipMemsetAsync(b + o_nm, 0, H * 4, s));
+    RSArgs a{};
+    a.n = n; a.max_iters = max_iters; a.thresh = thresh; a.confidence = confidence;
+    a.p1 = (const float*)(b + o_p1); a.p2 = (const float*)(b + o_p2);
+    a.subsets = (int*)(b + o_sub); a.models = (double*)(b + o_mod); a.nmodels = (int*)(b + o_nm);
+    a.counts = (int*)(b + o_cnt); a.medians = (float*)(b + o_med); a.mask = (unsigned char*)(b + o_mask);
+    a.ctrl = (RSCtrl*)(b + o_ctrl);
+    hipLaunchKernelGGL(rs_subsets_kernel, dim3(1), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(rs_models_kernel, dim3(sslam::cdiv(max_iters, 64)), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(rs_score_kernel, dim3(max_iters, 3), dim3(RS_T), 0, s, a);
+    hipLaunchKernelGGL(rs_select_kernel, dim3(1), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(rs_mask_kernel, dim3(1), dim3(RS_T), 0, s, a);
+    SSLAM_HIP_CHECK(hipGetLastError());
+    RSCtrl h{};
+    SSLAM_HIP_CHECK(hipMemcpyAsync(&h, b + o_ctrl, sizeof(RSCtrl), hipMemcpyDeviceToHost, s));
+    SSLAM_HIP_CHECK(hipMemcpyAsync(mask_out, b + o_mask, N, hipMemcpyDeviceToHost, s));
+    SSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    if (F_out) for (int i = 0; i < 9; ++i) F_out[i] = h.best_h >= 0 ? h.F[i] : 0.0;
+    if (info_out) {
+        info_out[0] = h.best_h >= 0 ? h.best_count : -1;      // -1: no model (cv2 returns mask None)
+        info_out[1] = h.niters;
+        info_out[2] = h.lmeds;
+        info_out[3] = h.best_h;
+    }
+    return 0;
+}

@@ -125,18 +125,15 @@ def feature_matcher(args, kp0, kp1, des0, des1, matcher):
 
 
 def filter_matches_ransac(kp1, kp2, matches, thresh=1.0):
-    """Drop outliers with fundamental-matrix RANSAC (cv2.findFundamentalMat, as the reference
-    does at features_utils.py:185-200).  Needs OpenCV: the geometry stages around the hot path
-    are outside this backend's scope (SURVEY.md section 8(f) lists a GPU version as a next row)."""
+    """Drop outliers with fundamental-matrix RANSAC, as the reference does at
+    features_utils.py:185-200 - scored on the GPU (`sslam_fmat_ransac_host`: OpenCV's classic
+    7-point RANSAC / LMedS restated, no cv2 needed)."""
     if len(matches) < 8:
         return matches
-    if not HAVE_CV2:
-        raise ImportError("filter_matches_ransac needs cv2 (cv2.findFundamentalMat)")
-    import cv2
+    from ... import epipolar
     pts1 = np.float32([kp1[m.queryIdx].pt for m in matches])
     pts2 = np.float32([kp2[m.trainIdx].pt for m in matches])
-    _, mask = cv2.findFundamentalMat(pts1, pts2, cv2.FM_RANSAC, thresh, 0.99)
+    _, mask, _ = epipolar.find_fundamental_ransac(pts1, pts2, thresh, 0.99)
     if mask is None:
         return []
-    mask = mask.ravel().astype(bool)
     return [m for m, ok in zip(matches, mask) if ok]
