@@ -24,6 +24,7 @@
 // over the stored scores.  The result is what the sequential loop would have produced.
 #include "common.hpp"
 
+#include <algorithm>
 #include <cfloat>
 
 namespace {
@@ -35,18 +36,24 @@ constexpr int RS_SUBSET_ATTEMPTS = 10000;
 constexpr int RS_LMEDS_MAX = 14;         // < 15 points -> LMedS
 
 struct RSCtrl {
-    int n_subsets;      // samples generated (getSubset may give up)
+    int n_subsets;      // samples generated so far (getSubset may give up: `exhausted`)
     int lmeds;          // 1 = LMedS path
-    int niters;         // iterations the sequential loop would have run
+    int niters;         // iterations the sequential loop has run
     int best_h, best_k; // winning sample / model (-1: none)
     int best_count;     // inliers of the winner (RANSAC) / final count
-    int pad[2];
+    int budget;         // the loop's current iteration budget (`niters` in ptsetreg.cpp)
+    int max_good;       // best inlier count so far (RANSAC)
+    int exhausted;      // getSubset failed: the loop ended
+    int pad;
+    unsigned long long rng_state;
+    double min_median;  // LMedS
     double thresh;      // threshold actually applied by the mask pass (pixels)
     double F[9];
 };
 
 struct RSArgs {
     int n; int max_iters;
+    int h0, h1;                               // sample range of this chunk
     double thresh, confidence;
     const float* p1; const float* p2;         // [n][2]
     int* subsets;                             // [max_iters][7]
@@ -95,17 +102,26 @@ __device__ int update_num_iters(double p, double ep, int model_points, int max_i
     return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
 }
 
-// ---- 1. replay the sample stream (one lane) --------------------------------------------------
+// ---- 1. replay the sample stream for samples [h0, h1) (one lane) ------------------------------
 __global__ void rs_subsets_kernel(RSArgs a) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     RSCtrl* c = a.ctrl;
-    CvRng rng{0xffffffffffffffffULL};
     const int n = a.n;
-    c->lmeds = n <= RS_LMEDS_MAX;
-    int budget = a.max_iters;
-    if (c->lmeds) budget = max(update_num_iters(a.confidence, 0.45, RS_MP, a.max_iters), 1);   // LMeDS: fixed budget
-    int made = 0;
-    for (int it = 0; it < budget; ++it) {
+    if (a.h0 == 0) {
+        c->lmeds = n <= RS_LMEDS_MAX;
+        c->budget = max(a.max_iters, 1);
+        if (c->lmeds) c->budget = max(update_num_iters(a.confidence, 0.45, RS_MP, a.max_iters), 1);   // LMeDS: fixed budget
+        c->rng_state = 0xffffffffffffffffULL;
+        c->n_subsets = 0; c->exhausted = 0;
+        c->best_h = c->best_k = -1;
+        c->best_count = 0; c->niters = 0; c->max_good = 0;
+        c->min_median = DBL_MAX;
+    }
+    if (c->exhausted) return;
+    CvRng rng{c->rng_state};
+    const int end = min(a.h1, c->budget);
+    int made = c->n_subsets;
+    for (int it = a.h0; it < end; ++it) {
         int idx[RS_MP];
         int attempts = 0;
         for (; attempts < RS_SUBSET_ATTEMPTS; ++attempts) {
@@ -121,14 +137,12 @@ __global__ void rs_subsets_kernel(RSArgs a) {
             }
             if (!last_point_collinear(a.p1, idx, RS_MP) && !last_point_collinear(a.p2, idx, RS_MP)) break;
         }
-        if (attempts == RS_SUBSET_ATTEMPTS) break;       // getSubset failed: the loop ends here
+        if (attempts == RS_SUBSET_ATTEMPTS) { c->exhausted = 1; break; }   // getSubset failed: the loop ends here
         for (int i = 0; i < RS_MP; ++i) a.subsets[it * RS_MP + i] = idx[i];
         ++made;
     }
     c->n_subsets = made;
-    c->best_h = c->best_k = -1;
-    c->best_count = 0;
-    c->niters = 0;
+    c->rng_state = rng.state;
 }
 
 // ---- 2. 7-point solver (thread / sample) -------------------------------------------------------
@@ -188,8 +202,8 @@ __device__ int solve_cubic(const double* c, double* r) {
 }
 
 __global__ __launch_bounds__(64) void rs_models_kernel(RSArgs a) {
-    const int h = blockIdx.x * 64 + threadIdx.x;
-    if (h >= a.ctrl->n_subsets) return;
+    const int h = a.h0 + blockIdx.x * 64 + threadIdx.x;
+    if (h >= a.h1 || h >= a.ctrl->n_subsets) return;
     // rows: (m2, 1)^T F (m1, 1) = 0
     double A[RS_MP][9];
     for (int i = 0; i < RS_MP; ++i) {
@@ -280,7 +294,7 @@ __device__ __forceinline__ float fm_error(const double* F, float x1, float y1, f
 // ---- 3. score every model against every match (workgroup / model) ---------------------------
 __global__ __launch_bounds__(RS_T) void rs_score_kernel(RSArgs a) {
     __shared__ int sh[RS_T];
-    const int h = blockIdx.x, k = blockIdx.y;
+    const int h = a.h0 + blockIdx.x, k = blockIdx.y;
     const RSCtrl* c = a.ctrl;
     if (h >= c->n_subsets || k >= a.nmodels[h]) return;
     double F[9];
@@ -314,37 +328,40 @@ __global__ __launch_bounds__(RS_T) void rs_score_kernel(RSArgs a) {
     if (threadIdx.x == 0) a.counts[h * 3 + k] = sh[0];
 }
 
-// ---- 4. replay the sequential best / budget logic (one lane) ---------------------------------
+// ---- 4. replay the sequential best / budget logic over samples [h0, h1) (one lane) -----------
 __global__ void rs_select_kernel(RSArgs a) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     RSCtrl* c = a.ctrl;
     const int n = a.n;
+    int it = a.h0;
+    if (it != c->niters) return;                       // the loop already ended before this chunk
     if (c->lmeds) {
-        double min_median = DBL_MAX;
-        for (int it = 0; it < c->n_subsets; ++it)
+        for (; it < a.h1 && it < c->n_subsets && it < c->budget; ++it)
             for (int k = 0; k < a.nmodels[it]; ++k) {
                 const double med = a.medians[it * 3 + k];
-                if (med < min_median) { min_median = med; c->best_h = it; c->best_k = k; }
+                if (med < c->min_median) { c->min_median = med; c->best_h = it; c->best_k = k; }
             }
-        c->niters = c->n_subsets;
-        if (c->best_h >= 0) {
-            double sigma = 2.5 * 1.4826 * (1 + 5. / (n - RS_MP)) * sqrt(min_median);
-            sigma = fmax(sigma, 0.001);
-            c->thresh = sigma;
-        }
     } else {
-        int niters = max(a.max_iters, 1), max_good = 0, it = 0;
-        for (; it < niters && it < c->n_subsets; ++it)
+        for (; it < a.h1 && it < c->n_subsets && it < c->budget; ++it)
             for (int k = 0; k < a.nmodels[it]; ++k) {
                 const int good = a.counts[it * 3 + k];
-                if (good > max(max_good, RS_MP - 1)) {
-                    max_good = good;
+                if (good > max(c->max_good, RS_MP - 1)) {
+                    c->max_good = good;
                     c->best_h = it; c->best_k = k;
-                    niters = update_num_iters(a.confidence, (double)(n - good) / n, RS_MP, niters);
+                    c->budget = update_num_iters(a.confidence, (double)(n - good) / n, RS_MP, c->budget);
                 }
             }
-        c->niters = it;
-        c->thresh = a.thresh;
+    }
+    c->niters = it;
+}
+
+__global__ void rs_finish_kernel(RSArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    RSCtrl* c = a.ctrl;
+    c->thresh = a.thresh;
+    if (c->lmeds && c->best_h >= 0) {
+        double sigma = 2.5 * 1.4826 * (1 + 5. / (a.n - RS_MP)) * sqrt(c->min_median);
+        c->thresh = fmax(sigma, 0.001);
     }
     if (c->best_h >= 0)
         for (int i = 0; i < 9; ++i) c->F[i] = a.models[(size_t)c->best_h * 27 + 9 * c->best_k + i];
@@ -407,10 +424,17 @@ extern "C" int sslam_fmat_ransac_host(sslam_ctx* ctx, int n, const float* pts1, 
     a.subsets = (int*)(b + o_sub); a.models = (double*)(b + o_mod); a.nmodels = (int*)(b + o_nm);
     a.counts = (int*)(b + o_cnt); a.medians = (float*)(b + o_med); a.mask = (unsigned char*)(b + o_mask);
     a.ctrl = (RSCtrl*)(b + o_ctrl);
-    hipLaunchKernelGGL(rs_subsets_kernel, dim3(1), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(rs_models_kernel, dim3(sslam::cdiv(max_iters, 64)), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(rs_score_kernel, dim3(max_iters, 3), dim3(RS_T), 0, s, a);
-    hipLaunchKernelGGL(rs_select_kernel, dim3(1), dim3(64), 0, s, a);
+    // the sample loop in chunks: a chunk whose first sample lies beyond the (shrinking) budget is a
+    // handful of early-exit launches, so a typical call costs two or three chunks, not max_iters
+    constexpr int CHUNK = 128;
+    for (int h0 = 0; h0 < max_iters; h0 += CHUNK) {
+        a.h0 = h0; a.h1 = std::min(h0 + CHUNK, max_iters);
+        hipLaunchKernelGGL(rs_subsets_kernel, dim3(1), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(rs_models_kernel, dim3(sslam::cdiv(a.h1 - a.h0, 64)), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(rs_score_kernel, dim3(a.h1 - a.h0, 3), dim3(RS_T), 0, s, a);
+        hipLaunchKernelGGL(rs_select_kernel, dim3(1), dim3(64), 0, s, a);
+    }
+    hipLaunchKernelGGL(rs_finish_kernel, dim3(1), dim3(64), 0, s, a);
     hipLaunchKernelGGL(rs_mask_kernel, dim3(1), dim3(RS_T), 0, s, a);
     SSLAM_HIP_CHECK(hipGetLastError());
     RSCtrl h{};
