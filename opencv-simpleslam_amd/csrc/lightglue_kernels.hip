@@ -1360,7 +1360,11 @@ __global__ __launch_bounds__(256, 2) void lg_attention_p_kernel(AttnArgsH p) {
         if ((nslab & 7) == 0) { const int xcd = b & 7, idx = b >> 3; slab = xcd + 8 * (idx / nqb); qb = idx % nqb; }
         else { slab = blockIdx.z * gridDim.y + blockIdx.y; qb = blockIdx.x; }
     }
+#ifdef ATTN_BATCH_EMU      // ubench only: gridDim.y = 8 * batch, every batch entry aliases the same operands
+    const int z = slab / gridDim.y, ih = (slab % gridDim.y) & 7;
+#else
     const int z = slab / gridDim.y, ih = slab % gridDim.y;
+#endif
     const int img = ih >> 2, head = ih & 3;
     const int kimg = p.cross ? 1 - img : img;
     const int nq = p.ctrl->n[img], nk = p.ctrl->n[kimg];
@@ -1510,8 +1514,9 @@ __global__ __launch_bounds__(256, 2) void lg_attention_p_kernel(AttnArgsH p) {
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const int qrow = q0 + wave * 32 + lr;
+    const size_t pbase0 = (((size_t)z * 2 + img) * NH + head) * p.Kc + q0 + wave * 32;   // this wave's first row
     if (qrow < nq) {
-        const size_t pbase = (((size_t)z * 2 + img) * NH + head) * p.Kc + qrow;
+        const size_t pbase = pbase0 + lr;
         float* op = p.o_part + pbase * DH;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
@@ -1520,13 +1525,8 @@ __global__ __launch_bounds__(256, 2) void lg_attention_p_kernel(AttnArgsH p) {
             a.z = o1a[4 * g4 + 2] + o2a[4 * g4 + 2] * SPLIT_INV; a.w = o1a[4 * g4 + 3] + o2a[4 * g4 + 3] * SPLIT_INV;
             b.x = o1b[4 * g4] + o2b[4 * g4] * SPLIT_INV; b.y = o1b[4 * g4 + 1] + o2b[4 * g4 + 1] * SPLIT_INV;
             b.z = o1b[4 * g4 + 2] + o2b[4 * g4 + 2] * SPLIT_INV; b.w = o1b[4 * g4 + 3] + o2b[4 * g4 + 3] * SPLIT_INV;
-#if ATTN_ABL & 16
-            if (a.x == 123.456f && b.y == 654.321f)
-#endif
-            {
-                *reinterpret_cast<float4*>(op + 8 * g4 + 4 * h) = a;
-                *reinterpret_cast<float4*>(op + 32 + 8 * g4 + 4 * h) = b;
-            }
+            *reinterpret_cast<float4*>(op + 8 * g4 + 4 * h) = a;
+            *reinterpret_cast<float4*>(op + 32 + 8 * g4 + 4 * h) = b;
         }
         if (h == 0) { p.m_part[pbase] = m_run; p.l_part[pbase] = l_tot; }
     }

@@ -1,0 +1,7 @@
+for cfg in "24 2 6" "24 2 8" "24 3 6" "32 2 8" "24 1 6" "48 2 6" "24 2 4"; do
+  set -- $cfg
+  SSLAM_BENCH_FRAMES=$1 SSLAM_BENCH_NE=$2 SSLAM_BENCH_NM=$3 python bench.py --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.readline())
+print('B=$1 NE=$2 NM=$3', d['value'], 'fps; structured', d['structured_input']['value'])"
+done

@@ -17,6 +17,7 @@ int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 2048;
     const int KS = argc > 2 ? atoi(argv[2]) : 4;
     const int which = argc > 3 ? atoi(argv[3]) : 1;
+    const int batch = argc > 4 ? atoi(argv[4]) : 1;      // needs -DATTN_BATCH_EMU when > 1
     const int Kc = (N + 127) / 128 * 128;
     const size_t plane = (size_t)2 * NH * Kc * DH;
     _Float16* buf[6];
@@ -29,7 +30,7 @@ int main(int argc, char** argv) {
     hipMalloc(&l_part, (size_t)KS * 2 * NH * Kc * 4); hipMalloc(&ctrl, sizeof(LGCtrl));
     LGCtrl h{}; h.n[0] = h.n[1] = N; hipMemcpy(ctrl, &h, sizeof(h), hipMemcpyHostToDevice);
     AttnArgsH a{{buf[0], buf[1]}, {buf[2], buf[3]}, {buf[4], buf[5]}, 0, o_part, m_part, l_part, KS, Kc, ctrl};
-    dim3 grid(sslam::cdiv(Kc, AQ), 2 * NH, KS);
+    dim3 grid(sslam::cdiv(Kc, AQ), 2 * NH * batch, KS);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     auto launch = [&] {
         if (which) hipLaunchKernelGGL(lg_attention_p_kernel, grid, dim3(256), 0, 0, a);
@@ -49,7 +50,7 @@ int main(int argc, char** argv) {
         float m; hipEventElapsedTime(&m, e0, e1); iso += m;
     }
     const double fl = 8.0 * N * (double)N * 256;
-    printf("N=%d KS=%d kernel=%d abl=%d: back-to-back %.2f us/launch (%.0f TF alg), isolated %.2f us; err=%s\n", N, KS, which,
-           ATTN_ABL, ms / R * 1e3, fl / (ms / R * 1e-3) / 1e12, iso / 20 * 1e3, hipGetErrorString(hipGetLastError()));
+    printf("N=%d KS=%d kernel=%d abl=%d batch=%d: back-to-back %.2f us/launch = %.2f us per pair (%.0f TF alg), isolated %.2f us; err=%s\n", N, KS, which,
+           ATTN_ABL, batch, ms / R * 1e3, ms / R * 1e3 / batch, batch * fl / (ms / R * 1e-3) / 1e12, iso / 20 * 1e3, hipGetErrorString(hipGetLastError()));
     return 0;
 }

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import frames
-from conftest import load_pkg
+from conftest import ROOT, load_pkg
 
 pytestmark = pytest.mark.gpu
 
@@ -52,3 +52,36 @@ def test_pipeline_equals_sequential_api(native):
                 np.testing.assert_array_equal(res[s][0], ref[f][0])
                 np.testing.assert_allclose(res[s][1], ref[f][1], atol=1e-6)
     assert sum(len(r[0]) for r in ref[1:]) >= 0
+
+
+def _run_bench(extra_env, cmd):
+    import json, os, subprocess, sys
+    env = dict(os.environ, SSLAM_BENCH_FRAMES="6", SSLAM_BENCH_NE="1", SSLAM_BENCH_NM="2", **extra_env)
+    out = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]               # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_contract_single_rank():
+    import sys
+    d = _run_bench({}, [sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "structured_input"):
+        assert key in d
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["unit"] == "frames/s"
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+
+
+def test_bench_two_ranks_share_one_gpu_over_gloo():
+    """The N > 1 code path (frame sharding, all-gather collation, boundary pair, max-over-ranks
+    timing) on a 1-GPU box: two ranks on the same device, gloo instead of RCCL."""
+    import sys
+    d = _run_bench({"SSLAM_DIST_BACKEND": "gloo", "MASTER_ADDR": "127.0.0.1"},
+                   [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                    "--master-addr", "127.0.0.1", "--master-port", "29611", "bench.py", "--gpus", "2",
+                    "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert d["config"]["frames_per_step_per_gpu"] == 6
