@@ -846,15 +846,17 @@ __global__ void lg_split_weight_kernel(const float* __restrict__ src, _Float16* 
 }
 
 // token states x[2][Kc][256] -> split planes in k-panel layout over the 2*Kc rows
+// only_moved: refresh after pruning - an image whose rows did not move (n == n_prev) still has
+// the planes its producer's epilogue wrote
 __global__ void lg_split_rows_kernel(const float* __restrict__ src, _Float16* __restrict__ hi,
                                      _Float16* __restrict__ lo, int ld, int Kc,
-                                     const LGCtrl* __restrict__ ctrl) {
+                                     const LGCtrl* __restrict__ ctrl, int only_moved) {
     if (ctrl->stop) return;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t per = (size_t)Kc * ld;
     if (i >= 2 * per) return;
     const int img = (int)(i / per), row = (int)((i % per) / ld), col = (int)(i % ld);
-    if (row >= ctrl->n[img]) return;
+    if (row >= ctrl->n[img] || (only_moved && ctrl->n[img] == ctrl->n_prev[img])) return;
     const size_t o = panel_index(img * Kc + row, col, 2 * Kc);
     split_f32(src[i], hi[o], lo[o]);
 }
@@ -1797,7 +1799,7 @@ int lg_enqueue(sslam_lightglue* g, int M, int N, const int32_t* m_dev, const int
     const unsigned splitblocks = (unsigned)(((size_t)2 * Kc * D + 255) / 256);
     if (g->precision == 1)
         hipLaunchKernelGGL(lg_split_rows_kernel, dim3(splitblocks), dim3(256), 0, s, g->x, g->xs_hi, g->xs_lo, D, Kc,
-                           g->ctrl);
+                           g->ctrl, 0);
     for (int i = 0; i < g->dbg_layers; ++i) {
         const LGLayerW& l = g->L[i];
         const bool self_only = g->dbg_self_only && i == g->dbg_layers - 1;
@@ -1843,7 +1845,7 @@ int lg_enqueue(sslam_lightglue* g, int M, int N, const int32_t* m_dev, const int
                                g->enc_sin, g->gmap, g->tx, g->tc, g->ts, g->ctrl, Kc, 1);
             if (g->precision == 1)      // token rows moved: refresh their split planes
                 hipLaunchKernelGGL(lg_split_rows_kernel, dim3(splitblocks), dim3(256), 0, s, g->x, g->xs_hi,
-                                   g->xs_lo, D, Kc, g->ctrl);
+                                   g->xs_lo, D, Kc, g->ctrl, 1);
         }
     }
     // ---- assignment with log_assignment[stop_layer]
