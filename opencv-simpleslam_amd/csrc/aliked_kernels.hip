@@ -114,101 +114,214 @@ __global__ void al_resize_pad_kernel(const float* __restrict__ src, float* __res
 constexpr int CT_W = 32;                // output tile width of the dense 3x3 convs (height = 4 * RPW)
 
 // ------------------------------------------------------------------------ //
-//  1. dense 3x3 conv (zero pad) + BN affine (+ residual) + SELU as an implicit GEMM on the exact-fp32 matrix core
-//      (v_mfma_f32_32x32x2_f32):  out[co][pixel] = sum_k W[co][k] * im2col[k][pixel],
-//      k = tap * CIN + ci.  A = weights (rows = co), B = pixels (cols = 32 consecutive x of one
-//      image row), so an accumulator register holds one output channel for 32 consecutive pixels
-//      and stores are coalesced 128 B rows.  The input tile (+halo, optional average pooling on
-//      load) and the [k][co] weights sit in LDS; every operand fetch is a ds_read_b32 with an
-//      immediate offset (the k order puts the two k of one MFMA one channel apart).
-//      Block = 32 x 8 pixels, wave w owns rows 2w, 2w+1.
+//  1. dense 3x3 conv (zero pad) + BN affine (+ residual) + SELU as an implicit GEMM on the exact-fp32
+//      matrix core:  out[co][pixel] = sum_k W[co][k] * im2col[k][pixel],  k = tap * CIN + ci.
+//      A = weights (rows = co), B = pixels (cols = consecutive x of one image row), so an
+//      accumulator register holds one output channel for consecutive pixels and stores are
+//      coalesced row pieces.  COUT = 32: v_mfma_f32_32x32x2_f32 (32 co x 32 px, k = 2 channels);
+//      COUT = 16: v_mfma_f32_16x16x4_f32 (16 co x 16 px, k = 4 channels) - no padded rows.
+//      The input tile (+halo, optional 2x2 average pooling on load) and the [k][co] weights sit in
+//      LDS; every operand fetch is a ds_read_b32 with an immediate offset.  The interior of a tile
+//      row is filled from 16-byte global loads; COUT = 16: rows of 40 floats (interior at column 4:
+//      16-byte LDS stores too) and a channel stride == 16 mod 64 banks; COUT = 32: rows of 34 floats
+//      (tile + weights of the 32 -> 32 layer are then 78.5 KB: two workgroups per CU).
+//      Block = 32 x (4 RPW) pixels, wave w owns rows RPW w .. RPW w + RPW - 1.
 // ------------------------------------------------------------------------ //
+#ifndef CONV_ABL
+#define CONV_ABL 0      // experiments: 1 no MFMA loop, 2 no input-tile load, 4 no output stores
+#endif
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 template <int CIN, int COUT, int POOL, bool DOWN, bool RESID, int RPW>
 __global__ __launch_bounds__(256) void al_conv3x3_mfma_kernel(
     const float* __restrict__ in, int inH, int inW, float* __restrict__ out, int H, int W,
     const float* __restrict__ w /*[ci][tap][COUT]*/, const float* __restrict__ alpha, const float* __restrict__ beta,
     const float* __restrict__ wd /*[ci][COUT]*/, const float* __restrict__ bd, float* __restrict__ idn,
     const float* __restrict__ resid) {
-    // CINP: input channels padded to even (a zero channel), output channels padded to the 32 MFMA rows
-    constexpr int CINP = (CIN + 1) & ~1;
+    static_assert(COUT == 16 || COUT == 32, "two matrix-core shapes");
+    static_assert(!(DOWN && COUT == 16), "the 1x1 branch is only built for the 32-row shape");
+    constexpr bool M16 = COUT == 16;
+    constexpr int KG = M16 ? 4 : 2;                                  // channels per MFMA
+    constexpr int CINP = (CIN + KG - 1) / KG * KG;                   // input channels padded with zero channels
     constexpr int CTH = 4 * RPW;                                     // tile height: RPW rows per wave
-    constexpr int TW = CT_W + 2, TH = CTH + 2, CHS = TH * TW;        // channel stride of the input tile
+    constexpr int TH = CTH + 2;
+    constexpr int CT_TW = M16 ? CT_W + 8 : CT_W + 2;                 // tile row stride (floats)
+    constexpr int IC = M16 ? 4 : 1;                                  // column of the first interior pixel
+    constexpr int CHS = M16 ? (TH * CT_TW + 63 - 16) / 64 * 64 + 16 : TH * CT_TW;
     constexpr int K = 9 * CINP;
-    __shared__ float tile[CINP * CHS];
-    __shared__ float wl[(K + (DOWN ? CINP : 0)) * 32];               // [k = tap*CINP + ci][co] (+ 1x1 rows)
+    constexpr int WLD = COUT;                                        // weight row stride in LDS
+    __shared__ __attribute__((aligned(16))) float tile[CINP * CHS];
+    __shared__ float wl[(K + (DOWN ? CINP : 0)) * WLD];              // [k = tap*CINP + ci][co] (+ 1x1 rows)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CTH;
-    for (int i = t; i < CINP * CHS; i += 256) {
-        const int c = i / CHS, rem = i % CHS;
-        const int yy = y0 + rem / TW - 1, xx = x0 + rem % TW - 1;
-        float v = 0.0f;
-        if (c < CIN && yy >= 0 && yy < H && xx >= 0 && xx < W) {
-            if (POOL == 1) {
-                v = in[((size_t)c * inH + yy) * inW + xx];
-            } else {
-                float s = 0.0f;
-                for (int a = 0; a < POOL; ++a)
-                    for (int b = 0; b < POOL; ++b) s += in[((size_t)c * inH + yy * POOL + a) * inW + xx * POOL + b];
-                v = s / (float)(POOL * POOL);
+#if CONV_ABL & 2
+    for (int i = t; i < CINP * CHS; i += 256) tile[i] = 0.5f;
+    if (0)
+#endif
+    {
+        constexpr int ROWS = CINP * TH;
+        // interior: 8 x 16 bytes per tile row
+        for (int idx = t; idx < ROWS * 8; idx += 256) {
+            const int row = idx >> 3, v4 = idx & 7;
+            const int c = row / TH, rr = row % TH;
+            const int yy = y0 + rr - 1, xx = x0 + 4 * v4;
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (c < CIN && yy >= 0 && yy < H && xx < W) {
+                if (POOL == 1) {
+                    const float* src = in + ((size_t)c * inH + yy) * inW + xx;
+                    if (xx + 3 < W) v = *reinterpret_cast<const float4*>(src);
+                    else { v.x = src[0]; if (xx + 1 < W) v.y = src[1]; if (xx + 2 < W) v.z = src[2]; }
+                } else {
+                    // 2x2 average on load, summed in the order (0,0) (0,1) (1,0) (1,1)
+                    const float* r0 = in + ((size_t)c * inH + yy * 2) * inW + xx * 2;
+                    const float* r1 = r0 + inW;
+                    float o[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (xx + 3 < W) {
+                        const float4 a0 = *reinterpret_cast<const float4*>(r0), a1 = *reinterpret_cast<const float4*>(r0 + 4);
+                        const float4 b0 = *reinterpret_cast<const float4*>(r1), b1 = *reinterpret_cast<const float4*>(r1 + 4);
+                        o[0] = (((a0.x + a0.y) + b0.x) + b0.y) / 4.0f; o[1] = (((a0.z + a0.w) + b0.z) + b0.w) / 4.0f;
+                        o[2] = (((a1.x + a1.y) + b1.x) + b1.y) / 4.0f; o[3] = (((a1.z + a1.w) + b1.z) + b1.w) / 4.0f;
+                    } else {
+                        for (int j = 0; j < 4 && xx + j < W; ++j)
+                            o[j] = (((r0[2 * j] + r0[2 * j + 1]) + r1[2 * j]) + r1[2 * j + 1]) / 4.0f;
+                    }
+                    v = make_float4(o[0], o[1], o[2], o[3]);
+                }
             }
+            float* dst = &tile[c * CHS + rr * CT_TW + IC + 4 * v4];
+            if constexpr (M16) *reinterpret_cast<float4*>(dst) = v;
+            else { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
         }
-        tile[i] = v;
+        // halo columns x0 - 1 and x0 + 32
+        for (int idx = t; idx < ROWS * 2; idx += 256) {
+            const int row = idx >> 1, side = idx & 1;
+            const int c = row / TH, rr = row % TH;
+            const int yy = y0 + rr - 1, xx = side ? x0 + CT_W : x0 - 1;
+            float v = 0.0f;
+            if (c < CIN && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                if (POOL == 1) {
+                    v = in[((size_t)c * inH + yy) * inW + xx];
+                } else {
+                    const float* r0 = in + ((size_t)c * inH + yy * 2) * inW + xx * 2;
+                    v = (((r0[0] + r0[1]) + r0[inW]) + r0[inW + 1]) / 4.0f;
+                }
+            }
+            tile[c * CHS + rr * CT_TW + (side ? IC + CT_W : IC - 1)] = v;
+        }
     }
-    for (int i = t; i < K * 32; i += 256) {          // global [ci][tap][co] -> LDS [tap][ci][co], zero padded
-        const int co = i & 31, k = i >> 5, tap = k / CINP, ci = k % CINP;
-        wl[i] = (ci < CIN && co < COUT) ? w[(ci * 9 + tap) * COUT + co] : 0.0f;
+    for (int i = t; i < K * WLD; i += 256) {          // global [ci][tap][co] -> LDS [tap][ci][co], zero padded
+        const int co = i % WLD, k = i / WLD, tap = k / CINP, ci = k % CINP;
+        wl[i] = ci < CIN ? w[(ci * 9 + tap) * COUT + co] : 0.0f;
     }
     if (DOWN)
-        for (int i = t; i < CINP * 32; i += 256) {
-            const int co = i & 31, ci = i >> 5;
-            wl[K * 32 + i] = (ci < CIN && co < COUT) ? wd[ci * COUT + co] : 0.0f;
+        for (int i = t; i < CINP * WLD; i += 256) {
+            const int co = i % WLD, ci = i / WLD;
+            wl[K * WLD + i] = ci < CIN ? wd[ci * COUT + co] : 0.0f;
         }
     __syncthreads();
 
-    const int h = lane >> 5, px = lane & 31;
-    f32x16 acc[RPW], dn[DOWN ? RPW : 1];
+    if constexpr (M16) {
+        // lane = (k = lane >> 4, n = lane & 15): A = wl[k0 + k][co = n], B = tile[ci0 + k][row][px = 16 half + n]
+        const int kk = lane >> 4, n = lane & 15;
+        f32x4 acc[RPW][2];
 #pragma unroll
-    for (int q = 0; q < RPW; ++q)
+        for (int q = 0; q < RPW; ++q)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[q][r] = 0.0f; if (DOWN) dn[q][r] = 0.0f; }
-    // lane bases: B operand (pixels) = tile[(ci0 + h)][row + dy][px + dx]; A operand = wl[(k0 + h)][co = px]
-    const float* bbase = tile + h * CHS + (RPW * wave) * TW + px;
-    const float* abase = wl + h * 32 + px;
+            for (int hf = 0; hf < 2; ++hf) acc[q][hf] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const float* bbase = tile + kk * CHS + (RPW * wave) * CT_TW + (IC - 1) + n;
+        const float* abase = wl + kk * WLD + n;
+#if !(CONV_ABL & 1)
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+        for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
-        for (int c2 = 0; c2 < CINP / 2; ++c2) {
-            const int koff = (tap * CINP + 2 * c2) * 32;                         // A: rows k0, k0+1
-            const int boff = (2 * c2) * CHS + (tap / 3) * TW + (tap % 3);         // B: channels 2c2, 2c2+1
-            const float a = abase[koff];
+            for (int g4 = 0; g4 < CINP / 4; ++g4) {
+                const float a = abase[(tap * CINP + 4 * g4) * WLD];
+                const int boff = (4 * g4) * CHS + (tap / 3) * CT_TW + (tap % 3);
 #pragma unroll
-            for (int q = 0; q < RPW; ++q) acc[q] = sslam::mfma32(a, bbase[boff + q * TW], acc[q]);
+                for (int q = 0; q < RPW; ++q)
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf)
+                        acc[q][hf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bbase[boff + q * CT_TW + 16 * hf], acc[q][hf], 0, 0, 0);
+            }
         }
-    }
-    if (DOWN) {
+#else
+        for (int q = 0; q < RPW; ++q) acc[q][0][0] = bbase[q * CT_TW] * abase[0];
+#endif
+        // accumulator register i of lane (kk, n): co = 4 kk + i, pixel = 16 half + n
 #pragma unroll
-        for (int c2 = 0; c2 < CINP / 2; ++c2) {
-            const float a = abase[(K + 2 * c2) * 32];
-            const int boff = (2 * c2) * CHS + TW + 1;                             // centre tap
+        for (int q = 0; q < RPW; ++q) {
+            const int y = y0 + RPW * wave + q;
+            if (y >= H) continue;
 #pragma unroll
-            for (int q = 0; q < RPW; ++q) dn[q] = sslam::mfma32(a, bbase[boff + q * TW], dn[q]);
+            for (int hf = 0; hf < 2; ++hf) {
+                const int x = x0 + 16 * hf + n;
+                if (x >= W) continue;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int co = 4 * kk + i;
+                    const size_t o = ((size_t)co * H + y) * W + x;
+                    float v = fmaf(acc[q][hf][i], alpha[co], beta[co]);
+                    if (RESID) v += resid[o];
+#if CONV_ABL & 4
+                    if (v == 123.456f)
+#endif
+                    out[o] = selu(v);
+                }
+            }
         }
-    }
-    const int x = x0 + px;
-    if (x >= W) return;
+    } else {
+        const int h = lane >> 5, px = lane & 31;
+        f32x16 acc[RPW], dn[DOWN ? RPW : 1];
 #pragma unroll
-    for (int q = 0; q < RPW; ++q) {
-        const int y = y0 + RPW * wave + q;
-        if (y >= H) continue;
+        for (int q = 0; q < RPW; ++q)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = acc_row(r, lane);
-            if (co >= COUT) continue;
-            const size_t o = ((size_t)co * H + y) * W + x;
-            float v = fmaf(acc[q][r], alpha[co], beta[co]);
-            if (RESID) v += resid[o];
-            out[o] = selu(v);
-            if (DOWN) idn[o] = dn[q][r] + bd[co];
+            for (int r = 0; r < 16; ++r) { acc[q][r] = 0.0f; if (DOWN) dn[q][r] = 0.0f; }
+        // lane bases: B operand (pixels) = tile[(ci0 + h)][row + dy][px + dx]; A operand = wl[(k0 + h)][co = px]
+        const float* bbase = tile + h * CHS + (RPW * wave) * CT_TW + (IC - 1) + px;
+        const float* abase = wl + h * WLD + px;
+#if !(CONV_ABL & 1)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+            for (int c2 = 0; c2 < CINP / 2; ++c2) {
+                const int koff = (tap * CINP + 2 * c2) * WLD;                        // A: rows k0, k0+1
+                const int boff = (2 * c2) * CHS + (tap / 3) * CT_TW + (tap % 3);      // B: channels 2c2, 2c2+1
+                const float a = abase[koff];
+#pragma unroll
+                for (int q = 0; q < RPW; ++q) acc[q] = sslam::mfma32(a, bbase[boff + q * CT_TW], acc[q]);
+            }
+        }
+#else
+        for (int q = 0; q < RPW; ++q) acc[q][0] = bbase[q * CT_TW] * abase[0];
+#endif
+        if (DOWN) {
+#pragma unroll
+            for (int c2 = 0; c2 < CINP / 2; ++c2) {
+                const float a = abase[(K + 2 * c2) * WLD];
+                const int boff = (2 * c2) * CHS + CT_TW + 1;                          // centre tap
+#pragma unroll
+                for (int q = 0; q < RPW; ++q) dn[q] = sslam::mfma32(a, bbase[boff + q * CT_TW], dn[q]);
+            }
+        }
+        const int x = x0 + px;
+        if (x >= W) return;
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            const int y = y0 + RPW * wave + q;
+            if (y >= H) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = acc_row(r, lane);
+                const size_t o = ((size_t)co * H + y) * W + x;
+                float v = fmaf(acc[q][r], alpha[co], beta[co]);
+                if (RESID) v += resid[o];
+#if CONV_ABL & 4
+                if (v == 123.456f)
+#endif
+                out[o] = selu(v);
+                if (DOWN) idn[o] = dn[q][r] + bd[co];
+            }
         }
     }
 }
