@@ -111,6 +111,7 @@ __global__ void al_resize_pad_kernel(const float* __restrict__ src, float* __res
     }
 }
 
+constexpr int DCN_KS_MAX = 18;          // split-K slices of the deformable-conv GEMMs
 constexpr int CT_W = 32;                // output tile width of the dense 3x3 convs (height = 4 * RPW)
 
 // ------------------------------------------------------------------------ //
@@ -377,61 +378,104 @@ __global__ __launch_bounds__(256) void al_offset_conv_kernel(const float* __rest
     }
 }
 
-__device__ __forceinline__ float dcn_sample(const float* __restrict__ p, int H, int W, float y, float x) {
-    if (y <= -1.0f || y >= (float)H || x <= -1.0f || x >= (float)W) return 0.0f;
-    const float fy = floorf(y), fx = floorf(x);
-    const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
-    const float ly = y - fy, lx = x - fx, hy = 1.0f - ly, hx = 1.0f - lx;
-    const float v1 = (y0 >= 0 && x0 >= 0) ? p[y0 * W + x0] : 0.0f;
-    const float v2 = (y0 >= 0 && x1 <= W - 1) ? p[y0 * W + x1] : 0.0f;
-    const float v3 = (y1 <= H - 1 && x0 >= 0) ? p[y1 * W + x0] : 0.0f;
-    const float v4 = (y1 <= H - 1 && x1 <= W - 1) ? p[y1 * W + x1] : 0.0f;
-    return (hy * hx) * v1 + (hy * lx) * v2 + (ly * hx) * v3 + (ly * lx) * v4;
+// ---- deformable conv as im2col + matrix-core GEMM --------------------------------------------
+// A direct kernel (weights streamed per pixel group) re-reads the whole weight tensor for every
+// 2-4 pixels: 189 MB of L2 traffic for the 64 -> 64 layer at 1/8 resolution.  Here the bilinear
+// samples are written once as col[pixel][k = tap*CIN + ci] (+ RC trailing columns holding the
+// block input at that pixel for the ResBlock's 1x1 branch) and out[co][pixel] =
+// W^T[co][:] . col[pixel][:] runs on the exact-fp32 matrix core with both operands LDS-tiled
+// (gemm_f32.hpp): A = weights re-ordered to [co][tap*CIN + ci] at create time, "W" operand = col,
+// so accumulator columns are consecutive pixels and planar [co][H][W] rows are written coalesced.
+// The maps are small (5120 / 320 pixels), so K is split over blockIdx.z to fill the chip; slice z
+// writes its partial product to slab z, the 1x1 branch to slab KS, and al_dcn_epilogue_kernel adds
+// the slabs in order (deterministic) and applies BN affine + residual + SELU.
+__global__ __launch_bounds__(256) void al_dcn_col_kernel(const float* __restrict__ in, const float* __restrict__ off,
+                                                         float* __restrict__ col, int CIN, int H, int W,
+                                                         const float* __restrict__ res_in, int RC) {
+    // thread = (channel quad, tap slot, pixel), pixel fastest: the 16 gathers of a lane and of its
+    // neighbours fall into the same few rows of one channel plane (16 reads vs 1 write per thread)
+    const int K = CIN * 9, KT = K + RC, HW = H * W, slots = RC ? 10 : 9, CQ = CIN / 4;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= HW * slots * CQ) return;
+    const int pix = i % HW, tap = (i / HW) % slots, cq = i / (HW * slots), c = 4 * cq;
+    float* dst = col + (size_t)pix * KT;
+    if (tap == 9) {                                   // block input for the 1x1 branch
+        if (c < RC)
+            *reinterpret_cast<float4*>(dst + K + c) =
+                make_float4(res_in[(size_t)c * HW + pix], res_in[(size_t)(c + 1) * HW + pix],
+                            res_in[(size_t)(c + 2) * HW + pix], res_in[(size_t)(c + 3) * HW + pix]);
+        return;
+    }
+    // torchvision deform_conv2d bilinear sample
+    const int py = pix / W, px = pix % W;
+    const float y = (float)(py - 1 + tap / 3) + off[(size_t)(2 * tap) * HW + pix];
+    const float x = (float)(px - 1 + tap % 3) + off[(size_t)(2 * tap + 1) * HW + pix];
+    float o[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (!(y <= -1.0f || y >= (float)H || x <= -1.0f || x >= (float)W)) {
+        const float fy = floorf(y), fx = floorf(x);
+        const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
+        const float ly = y - fy, lx = x - fx, hy = 1.0f - ly, hx = 1.0f - lx;
+        const bool m1 = y0 >= 0 && x0 >= 0, m2 = y0 >= 0 && x1 <= W - 1, m3 = y1 <= H - 1 && x0 >= 0, m4 = y1 <= H - 1 && x1 <= W - 1;
+        const int i1 = m1 ? y0 * W + x0 : 0, i2 = m2 ? y0 * W + x1 : 0, i3 = m3 ? y1 * W + x0 : 0, i4 = m4 ? y1 * W + x1 : 0;
+        const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float* p = in + (size_t)(c + e) * HW;
+            const float v1 = m1 ? p[i1] : 0.0f, v2 = m2 ? p[i2] : 0.0f, v3 = m3 ? p[i3] : 0.0f, v4 = m4 ? p[i4] : 0.0f;
+            o[e] = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+        }
+    }
+    *reinterpret_cast<float4*>(dst + tap * CIN + c) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
-// block = PIX pixels x COUT threads.  Phase 1: the PIX*CIN*9 bilinear samples go to LDS;
-// phase 2: thread (pixel, co) reduces them against w[ci][tap][co] (coalesced over co).
-template <int CIN, int COUT, bool RESID>
-__global__ __launch_bounds__(256) void al_deform_conv_kernel(
-    const float* __restrict__ in, const float* __restrict__ off, float* __restrict__ out, int H, int W,
-    const float* __restrict__ w, const float* __restrict__ alpha, const float* __restrict__ beta,
-    const float* __restrict__ res_in, int RC, const float* __restrict__ wd, const float* __restrict__ bd) {
-    constexpr int PIX = 256 / COUT;
-    __shared__ float col[PIX][CIN * 9];
-    const int pix0 = blockIdx.x * PIX;
-    for (int i = threadIdx.x; i < PIX * CIN * 9; i += 256) {
-        const int pp = i / (CIN * 9), k = i % (CIN * 9), ci = k / 9, tap = k % 9;
-        const int pix = pix0 + pp;
-        float v = 0.0f;
-        if (pix < H * W) {
-            const int y = pix / W, x = pix % W;
-            const float dy = off[((size_t)(2 * tap) * H + y) * W + x];
-            const float dx = off[((size_t)(2 * tap + 1) * H + y) * W + x];
-            v = dcn_sample(in + (size_t)ci * H * W, H, W, (float)(y - 1 + tap / 3) + dy,
-                           (float)(x - 1 + tap % 3) + dx);
-        }
-        col[pp][k] = v;
+__global__ __launch_bounds__(256) void al_dcn_gemm_kernel(const float* __restrict__ wt /*[COUT][K]*/, int K,
+                                                          const float* __restrict__ col /*[HW][K + RC]*/, int ldc,
+                                                          int HW, int COUT, float* __restrict__ part /*[KS+1][COUT][HW]*/,
+                                                          const float* __restrict__ wdt /*[COUT][RC]*/, int RC) {
+    __shared__ GemmSmem<64, 64> sm;
+    const int pix0 = blockIdx.x * 64, co0 = blockIdx.y * 64, z = blockIdx.z, KS = gridDim.z;
+    const int kper = K / KS, koff = z * kper;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+    const int pix = pix0 + wn * 32 + (lane & 31);
+    f32x16 acc[1][1];
+    {
+        GemmA ga{wt + koff, K, wt + koff, K, kper};
+        gemm_mainloop<64, 64, 1, 1>(ga, col + koff, ldc, kper, co0, COUT, pix0, HW, sm, acc);
+        float* dst = part + (size_t)z * COUT * HW;
+        if (pix < HW)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(size_t)(co0 + wm * 32 + acc_row(r, lane)) * HW + pix] = acc[0][0][r];
     }
-    __syncthreads();
-    const int pp = threadIdx.x / COUT, co = threadIdx.x % COUT;
-    const int pix = pix0 + pp;
-    if (pix >= H * W) return;
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;      // independent chains: hide the load latency
-#pragma unroll 4
-    for (int k = 0; k < CIN * 9; k += 4) {
-        a0 = fmaf(col[pp][k], w[k * COUT + co], a0);
-        a1 = fmaf(col[pp][k + 1], w[(k + 1) * COUT + co], a1);
-        a2 = fmaf(col[pp][k + 2], w[(k + 2) * COUT + co], a2);
-        a3 = fmaf(col[pp][k + 3], w[(k + 3) * COUT + co], a3);
+    if (RC && z == 0) {                               // block-uniform
+        GemmA gd{wdt, RC, wdt, RC, RC};
+        gemm_mainloop<64, 64, 1, 1>(gd, col + K, ldc, RC, co0, COUT, pix0, HW, sm, acc);
+        float* dst = part + (size_t)KS * COUT * HW;
+        if (pix < HW)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(size_t)(co0 + wm * 32 + acc_row(r, lane)) * HW + pix] = acc[0][0][r];
     }
-    const float acc = (a0 + a1) + (a2 + a3);
+}
+
+__global__ __launch_bounds__(256) void al_dcn_epilogue_kernel(const float* __restrict__ part, int KS, int HW, int COUT,
+                                                              float* __restrict__ out, const float* __restrict__ alpha,
+                                                              const float* __restrict__ beta, int resid,
+                                                              const float* __restrict__ bd) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= COUT * HW) return;
+    const int co = i / HW;
+    float acc = part[i];
+    for (int z = 1; z < KS; ++z) acc += part[(size_t)z * COUT * HW + i];
     float v = fmaf(acc, alpha[co], beta[co]);
-    if (RESID) {
-        float dn = 0.0f;
-        for (int ci = 0; ci < RC; ++ci) dn = fmaf(res_in[(size_t)ci * H * W + pix], wd[ci * COUT + co], dn);
-        v += dn + bd[co];
-    }
-    out[(size_t)co * H * W + pix] = selu(v);
+    if (resid) v += part[(size_t)KS * COUT * HW + i] + bd[co];
+    out[i] = selu(v);
+}
+
+// conv weights [ci][tap][co] -> [co][tap*CIN + ci]; 1x1 weights [ci][co] -> [co][ci] (taps = 1)
+__global__ void al_dcn_wt_kernel(const float* __restrict__ src, float* __restrict__ dst, int CIN, int taps, int COUT) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= CIN * taps * COUT) return;
+    const int co = i % COUT, tap = (i / COUT) % taps, ci = i / (COUT * taps);
+    dst[(size_t)co * (taps * CIN) + tap * CIN + ci] = src[i];
 }
 
 // 1x1 conv (no bias) + SELU: one thread per pixel produces all 32 outputs (inputs read once,
@@ -460,6 +504,7 @@ __global__ void al_gate_small_kernel(const float* __restrict__ in, float* __rest
     if (i >= 32 * HW) return;
     const int co = i / HW, p = i % HW;
     float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll 8                 // 16 loads in flight per thread: the loop is pure load latency otherwise
     for (int ci = 0; ci < CIN; ci += 2) {
         a0 = fmaf(in[(size_t)ci * HW + p], w[ci * 32 + co], a0);
         a1 = fmaf(in[(size_t)(ci + 1) * HW + p], w[(ci + 1) * 32 + co], a1);
@@ -1138,6 +1183,7 @@ struct sslam_aliked {
     const float *b2dw, *b2db;
     ALDcnW b3c1, b3c2, b4c1, b4c2;
     const float *b3dw, *b3db, *b4dw, *b4db;
+    float *b3c1t, *b3c2t, *b4c1t, *b4c2t, *b3dwt, *b4dwt, *dcol, *dpart;   // [co][k] copies, im2col buffer, split-K slabs
     const float *gw1, *gw2, *gw3, *gw4;
     const float *sh0, *sh2, *sh4, *sh6;
     const float *d_ow, *d_ob, *d_w2, *d_b2, *d_sf, *d_agg;
@@ -1235,30 +1281,43 @@ int al_enqueue(sslam_aliked* g, const uint8_t* img_dev, int H, int W, int C, int
                        g->b2c1.w, g->b2c1.a, g->b2c1.b, g->b2dw, g->b2db, g->idn2, nullptr);
     hipLaunchKernelGGL((al_conv3x3_mfma_kernel<32, 32, 1, false, true, 2>), g2, dim3(256), 0, s, g->t2, H2, W2, g->x2, H2, W2,
                        g->b2c2.w, g->b2c2.a, g->b2c2.b, nullptr, nullptr, nullptr, g->idn2);
+    // deformable conv = im2col of the bilinear samples + matrix-core GEMM (offsets in g->off)
+    auto dcn = [&](const float* in, int cin, float* outp, int cout, int Hh, int Ww, const float* wt, const float* al_,
+                   const float* be_, const float* res, int rc, const float* wdt, const float* bdp) {
+        const int K = cin * 9, KT = K + rc, HWl = Hh * Ww, slots = rc ? 10 : 9;
+        hipLaunchKernelGGL(al_dcn_col_kernel, dim3(sslam::cdiv(HWl * slots * (cin / 4), 256)), dim3(256), 0, s, in, g->off,
+                           g->dcol, cin, Hh, Ww, res, rc);
+        // split K so that the grid fills the chip: the largest divisor of the k-tile count that
+        // keeps the grid within ~1 workgroup per CU
+        const int base = sslam::cdiv(HWl, 64) * (cout / 64), tiles = K / 32;
+        int ks = 1;
+        for (int d_ = 1; d_ <= tiles && d_ <= DCN_KS_MAX; ++d_)
+            if (tiles % d_ == 0 && base * d_ <= 288) ks = d_;
+        hipLaunchKernelGGL(al_dcn_gemm_kernel, dim3(sslam::cdiv(HWl, 64), cout / 64, ks), dim3(256), 0, s, wt, K, g->dcol, KT,
+                           HWl, cout, g->dpart, wdt, rc);
+        hipLaunchKernelGGL(al_dcn_epilogue_kernel, dim3(sslam::cdiv(cout * HWl, 256)), dim3(256), 0, s, g->dpart, ks, HWl, cout,
+                           outp, al_, be_, res ? 1 : 0, bdp);
+    };
     // block3 at 1/8 (deformable)
     const int H3 = Hp / 8, W3 = Wp / 8, HW3 = H3 * W3;
     hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(32 * HW3, 256)), dim3(256), 0, s, g->x2, g->p3, 32, H2, W2, 4);
     const float mo3 = (float)(H3 > W3 ? H3 : W3) / 4.0f;
     hipLaunchKernelGGL(al_offset_conv_kernel, dim3(sslam::cdiv(HW3, 4)), dim3(256), 0, s, g->p3, g->off, 32, H3,
                        W3, g->b3c1.ow, g->b3c1.ob, mo3);
-    hipLaunchKernelGGL((al_deform_conv_kernel<32, 64, false>), dim3(sslam::cdiv(HW3, 4)), dim3(256), 0, s, g->p3, g->off,
-                       g->t3, H3, W3, g->b3c1.w, g->b3c1.a, g->b3c1.b, nullptr, 0, nullptr, nullptr);
+    dcn(g->p3, 32, g->t3, 64, H3, W3, g->b3c1t, g->b3c1.a, g->b3c1.b, nullptr, 0, nullptr, nullptr);
     hipLaunchKernelGGL(al_offset_conv_kernel, dim3(sslam::cdiv(HW3, 4)), dim3(256), 0, s, g->t3, g->off, 64, H3,
                        W3, g->b3c2.ow, g->b3c2.ob, mo3);
-    hipLaunchKernelGGL((al_deform_conv_kernel<64, 64, true>), dim3(sslam::cdiv(HW3, 4)), dim3(256), 0, s, g->t3, g->off,
-                       g->x3, H3, W3, g->b3c2.w, g->b3c2.a, g->b3c2.b, g->p3, 32, g->b3dw, g->b3db);
+    dcn(g->t3, 64, g->x3, 64, H3, W3, g->b3c2t, g->b3c2.a, g->b3c2.b, g->p3, 32, g->b3dwt, g->b3db);
     // block4 at 1/32
     const int H4 = Hp / 32, W4 = Wp / 32, HW4 = H4 * W4;
     hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(64 * HW4, 256)), dim3(256), 0, s, g->x3, g->p4, 64, H3, W3, 4);
     const float mo4 = (float)(H4 > W4 ? H4 : W4) / 4.0f;
     hipLaunchKernelGGL(al_offset_conv_kernel, dim3(sslam::cdiv(HW4, 4)), dim3(256), 0, s, g->p4, g->off, 64, H4,
                        W4, g->b4c1.ow, g->b4c1.ob, mo4);
-    hipLaunchKernelGGL((al_deform_conv_kernel<64, 128, false>), dim3(sslam::cdiv(HW4, 2)), dim3(256), 0, s, g->p4, g->off,
-                       g->t4, H4, W4, g->b4c1.w, g->b4c1.a, g->b4c1.b, nullptr, 0, nullptr, nullptr);
+    dcn(g->p4, 64, g->t4, 128, H4, W4, g->b4c1t, g->b4c1.a, g->b4c1.b, nullptr, 0, nullptr, nullptr);
     hipLaunchKernelGGL(al_offset_conv_kernel, dim3(sslam::cdiv(HW4, 4)), dim3(256), 0, s, g->t4, g->off, 128, H4,
                        W4, g->b4c2.ow, g->b4c2.ob, mo4);
-    hipLaunchKernelGGL((al_deform_conv_kernel<128, 128, true>), dim3(sslam::cdiv(HW4, 2)), dim3(256), 0, s, g->t4, g->off,
-                       g->x4, H4, W4, g->b4c2.w, g->b4c2.a, g->b4c2.b, g->p4, 64, g->b4dw, g->b4db);
+    dcn(g->t4, 128, g->x4, 128, H4, W4, g->b4c2t, g->b4c2.a, g->b4c2.b, g->p4, 64, g->b4dwt, g->b4db);
     // gates
     hipLaunchKernelGGL(al_gate_kernel, dim3(sslam::cdiv(H2 * W2, 256)), dim3(256), 0, s, g->x2, g->g2, 32, H2 * W2, g->gw2);
     hipLaunchKernelGGL(al_gate_small_kernel, dim3(sslam::cdiv(32 * HW3, 256)), dim3(256), 0, s, g->x3, g->g3, 64, HW3, g->gw3);
@@ -1330,6 +1389,14 @@ int sslam_aliked_create(sslam_ctx* ctx, const float* weights, size_t n_floats, i
         g->p3 = A.take<float>(32 * HWp / 64); g->off = A.take<float>(18 * HWp / 64);
         g->t3 = A.take<float>(64 * HWp / 64); g->x3 = A.take<float>(64 * HWp / 64);
         g->p4 = A.take<float>(64 * HWp / 1024); g->t4 = A.take<float>(128 * HWp / 1024); g->x4 = A.take<float>(128 * HWp / 1024);
+        g->b3c1t = A.take<float>(288 * 64); g->b3c2t = A.take<float>(576 * 64); g->b4c1t = A.take<float>(576 * 128);
+        g->b4c2t = A.take<float>(1152 * 128); g->b3dwt = A.take<float>(32 * 64); g->b4dwt = A.take<float>(64 * 128);
+        {   // im2col rows: 1/8 level (64*9 + 32) floats per pixel, 1/32 level (128*9 + 64)
+            const size_t a = (HWp / 64) * (size_t)(576 + 32), b = (HWp / 1024) * (size_t)(1152 + 64);
+            g->dcol = A.take<float>((a > b ? a : b) + 64);
+            const size_t pa = (size_t)(DCN_KS_MAX + 1) * 64 * (HWp / 64), pb = (size_t)(DCN_KS_MAX + 1) * 128 * (HWp / 1024);
+            g->dpart = A.take<float>((pa > pb ? pa : pb) + 64);
+        }
         g->g2 = A.take<float>(32 * HWp / 4); g->g3 = A.take<float>(32 * HWp / 64); g->g4 = A.take<float>(32 * HWp / 1024);
         g->s8 = A.take<float>(8 * HWp); g->rnorm = A.take<float>(HWp); g->g1cl = A.take<float>(32 * HWp);
         g->score = A.take<float>(HWp); g->nms = A.take<float>(HWp); g->bsum = A.take<float>(4096); g->gk = A.take<float>(64);
@@ -1350,6 +1417,17 @@ int sslam_aliked_create(sslam_ctx* ctx, const float* weights, size_t n_floats, i
     SSLAM_REQUIRE(g->out_n != nullptr, "sslam_aliked_create: workspace arena exhausted");
     SSLAM_HIP_CHECK(hipMemcpy(g->blob, weights, n_floats * 4, hipMemcpyHostToDevice));
     if (int rc = al_bind_weights(g, n_floats)) { g->arena.release(); delete g; return rc; }
+    {   // [ci][tap][co] -> [co][tap*CIN + ci] copies for the GEMM form of the deformable convs
+        hipStream_t s = ctx->stream;
+        auto tr = [&](const float* src, float* dst, int cin, int taps, int cout) {
+            hipLaunchKernelGGL(al_dcn_wt_kernel, dim3(sslam::cdiv(cin * taps * cout, 256)), dim3(256), 0, s, src, dst, cin,
+                               taps, cout);
+        };
+        tr(g->b3c1.w, g->b3c1t, 32, 9, 64); tr(g->b3c2.w, g->b3c2t, 64, 9, 64);
+        tr(g->b4c1.w, g->b4c1t, 64, 9, 128); tr(g->b4c2.w, g->b4c2t, 128, 9, 128);
+        tr(g->b3dw, g->b3dwt, 32, 1, 64); tr(g->b4dw, g->b4dwt, 64, 1, 128);
+        SSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    }
     SSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)al_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (SEL_CAP + EDGE_CAP) * 8));
     *out = g;
