@@ -481,7 +481,8 @@ __global__ void al_dcn_wt_kernel(const float* __restrict__ src, float* __restric
 // 1x1 conv (no bias) + SELU: one thread per pixel produces all 32 outputs (inputs read once,
 // weights [ci][32] as wave-uniform scalar loads)
 __global__ __launch_bounds__(256) void al_gate_kernel(const float* __restrict__ in, float* __restrict__ out, int CIN,
-                                                      int HW, const float* __restrict__ w /*[ci][32]*/) {
+                                                      int HW, const float* __restrict__ w /*[ci][32]*/,
+                                                      float* __restrict__ out_cl /*[HW][32]*/) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= HW) return;
     float acc[32];
@@ -494,12 +495,17 @@ __global__ __launch_bounds__(256) void al_gate_kernel(const float* __restrict__ 
         for (int o = 0; o < 32; ++o) acc[o] = fmaf(v, wp[o], acc[o]);
     }
 #pragma unroll
-    for (int o = 0; o < 32; ++o) out[(size_t)o * HW + p] = selu(acc[o]);
+    for (int o = 0; o < 32; ++o) acc[o] = selu(acc[o]);
+#pragma unroll
+    for (int o = 0; o < 32; ++o) out[(size_t)o * HW + p] = acc[o];
+#pragma unroll
+    for (int o = 0; o < 32; o += 4)
+        *reinterpret_cast<float4*>(out_cl + (size_t)p * 32 + o) = make_float4(acc[o], acc[o + 1], acc[o + 2], acc[o + 3]);
 }
 
 // small-map variant (1/8, 1/32 resolution): one thread per (co, pixel), more parallelism
 __global__ void al_gate_small_kernel(const float* __restrict__ in, float* __restrict__ out, int CIN, int HW,
-                                     const float* __restrict__ w /*[ci][32]*/) {
+                                     const float* __restrict__ w /*[ci][32]*/, float* __restrict__ out_cl) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 32 * HW) return;
     const int co = i / HW, p = i % HW;
@@ -509,7 +515,9 @@ __global__ void al_gate_small_kernel(const float* __restrict__ in, float* __rest
         a0 = fmaf(in[(size_t)ci * HW + p], w[ci * 32 + co], a0);
         a1 = fmaf(in[(size_t)(ci + 1) * HW + p], w[(ci + 1) * 32 + co], a1);
     }
-    out[i] = selu(a0 + a1);
+    const float v = selu(a0 + a1);
+    out[i] = v;
+    out_cl[(size_t)p * 32 + co] = v;
 }
 
 // ------------------------------------------------------------------------ //
@@ -522,13 +530,18 @@ struct Pyr {
     const float* w1;      // conv1 [16][32]
     int Hp, Wp;
     float* g1cl;          // selu(W1 x1) channel-last [Hp][Wp][32], written by the aggregate kernel
+    // align_corners=True source steps (ih - 1) / (Hp - 1) of the three upsampled levels (host-computed:
+    // the same correctly rounded float quotient the kernels would form, without a division per tap)
+    float sy2, sx2, sy8, sx8, sy32, sx32;
+    // channel-last copies [pixel][32] of the three gated levels for the descriptor head: a bilinear
+    // tap of all 32 channels is then ONE 128-byte line instead of 32 lines of 32 planes
+    const float *g2cl, *g3cl, *g4cl;
 };
 
 struct UpTap { int o00, o01, o10, o11; float w00, w01, w10, w11; };
 
-__device__ __forceinline__ UpTap up_tap(int y, int x, int Hp, int Wp, int S) {
+__device__ __forceinline__ UpTap up_tap(int y, int x, int Hp, int Wp, int S, float sy, float sx) {
     const int ih = Hp / S, iw = Wp / S;
-    const float sy = (float)(ih - 1) / (float)(Hp - 1), sx = (float)(iw - 1) / (float)(Wp - 1);
     const float fy = sy * (float)y, fx = sx * (float)x;
     const int y0 = (int)fy, x0 = (int)fx;
     const int y1 = y0 + (y0 < ih - 1), x1 = x0 + (x0 < iw - 1);
@@ -537,6 +550,10 @@ __device__ __forceinline__ UpTap up_tap(int y, int x, int Hp, int Wp, int S) {
     t.o00 = y0 * iw + x0; t.o01 = y0 * iw + x1; t.o10 = y1 * iw + x0; t.o11 = y1 * iw + x1;
     t.w00 = hx; t.w01 = lx; t.w10 = hy; t.w11 = ly;     // combined as hy*(hx*a+lx*b)+ly*(hx*c+lx*d)
     return t;
+}
+__device__ __forceinline__ float up_eval_cl(const float* __restrict__ p, const UpTap& t, int c) {
+    return t.w10 * (t.w00 * p[t.o00 * 32 + c] + t.w01 * p[t.o01 * 32 + c]) +
+           t.w11 * (t.w00 * p[t.o10 * 32 + c] + t.w01 * p[t.o11 * 32 + c]);
 }
 __device__ __forceinline__ float up_eval(const float* __restrict__ p, const UpTap& t) {
     return t.w10 * (t.w00 * p[t.o00] + t.w01 * p[t.o01]) + t.w11 * (t.w00 * p[t.o10] + t.w01 * p[t.o11]);
@@ -567,8 +584,8 @@ __global__ __launch_bounds__(256) void al_aggregate_kernel(Pyr P, const float* _
 #pragma unroll
         for (int o = 0; o < 8; ++o) s[o] = fmaf(a, ws0[c * 8 + o], s[o]);
     }
-    const UpTap t2 = up_tap(y, x, P.Hp, P.Wp, 2), t3 = up_tap(y, x, P.Hp, P.Wp, 8),
-                t4 = up_tap(y, x, P.Hp, P.Wp, 32);
+    const UpTap t2 = up_tap(y, x, P.Hp, P.Wp, 2, P.sy2, P.sx2), t3 = up_tap(y, x, P.Hp, P.Wp, 8, P.sy8, P.sx8),
+                t4 = up_tap(y, x, P.Hp, P.Wp, 32, P.sy32, P.sx32);
     const size_t hw2 = HW / 4, hw3 = HW / 64, hw4 = HW / 1024;
     for (int c = 0; c < 32; ++c) {
         const float a = up_eval(P.g2 + c * hw2, t2);
@@ -608,15 +625,15 @@ __global__ __launch_bounds__(256) void al_aggregate_kernel(Pyr P, const float* _
 __device__ __forceinline__ float2 feat_pair(const Pyr& P, const float* __restrict__ rnorm, int pl, int pt,
                                             int y, int x, int lane) {
     const int yp = y + pt, xp = x + pl;
-    const size_t HW = (size_t)P.Hp * P.Wp, pix = (size_t)yp * P.Wp + xp;
+    const size_t pix = (size_t)yp * P.Wp + xp;
     float a, b;
     const int c = lane & 31;
     if (lane < 32) {
         a = P.g1cl[pix * 32 + c];                      // one coalesced 128 B line per pixel
-        b = up_eval(P.g3 + c * (HW / 64), up_tap(yp, xp, P.Hp, P.Wp, 8));
+        b = up_eval_cl(P.g3cl, up_tap(yp, xp, P.Hp, P.Wp, 8, P.sy8, P.sx8), c);
     } else {
-        a = up_eval(P.g2 + c * (HW / 4), up_tap(yp, xp, P.Hp, P.Wp, 2));
-        b = up_eval(P.g4 + c * (HW / 1024), up_tap(yp, xp, P.Hp, P.Wp, 32));
+        a = up_eval_cl(P.g2cl, up_tap(yp, xp, P.Hp, P.Wp, 2, P.sy2, P.sx2), c);
+        b = up_eval_cl(P.g4cl, up_tap(yp, xp, P.Hp, P.Wp, 32, P.sy32, P.sx32), c);
     }
     const float r = rnorm[pix];
     return make_float2(a * r, b * r);        // channels: lane<32: (c, 64+c) ; lane>=32: (32+c, 96+c)
@@ -1078,17 +1095,19 @@ __global__ __launch_bounds__(256) void al_sample_kernel(Pyr P, const float* __re
     const float fx = floorf(ix), fy = floorf(iy);
     const int x0 = (int)fx, y0 = (int)fy;
     const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
-    float ax = 0.0f, bx = 0.0f;
+    // all four corners are fetched unconditionally (clamped address, zero weight when outside):
+    // 52 independent gathers in flight instead of four dependent groups
+    float2 f[4]; float wgt[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int yy = y0 + (q >> 1), xx = x0 + (q & 1);
-        if (yy >= 0 && yy < h && xx >= 0 && xx < w) {           // wave-uniform
-            const float wgt = ((q & 1) ? wx1 : wx0) * ((q >> 1) ? wy1 : wy0);
-            const float2 f = feat_pair(P, rnorm, pl, pt, yy, xx, lane);
-            ax = fmaf(f.x, wgt, ax);
-            bx = fmaf(f.y, wgt, bx);
-        }
+        const bool inside = yy >= 0 && yy < h && xx >= 0 && xx < w;
+        wgt[q] = inside ? ((q & 1) ? wx1 : wx0) * ((q >> 1) ? wy1 : wy0) : 0.0f;
+        f[q] = feat_pair(P, rnorm, pl, pt, min(max(yy, 0), h - 1), min(max(xx, 0), w - 1), lane);
     }
+    float ax = 0.0f, bx = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { ax = fmaf(f[q].x, wgt[q], ax); bx = fmaf(f[q].y, wgt[q], bx); }
     const int c = lane & 31;
     const int ca = lane < 32 ? c : 32 + c, cb = lane < 32 ? 64 + c : 96 + c;
     sampled[(size_t)gw * 128 + ca] = ax;
@@ -1191,7 +1210,7 @@ struct sslam_aliked {
     ALCtrl* ctrl;
     uint8_t* in_u8;
     float *fsrc, *img, *x1a, *x1, *t2, *idn2, *x2, *p3, *off, *t3, *x3, *p4, *t4, *x4, *g2, *g3, *g4;
-    float *s8, *rnorm, *score, *nms, *bsum, *gk, *g1cl;
+    float *s8, *rnorm, *score, *nms, *bsum, *gk, *g1cl, *g2cl, *g3cl, *g4cl;
     unsigned long long* cand;
     unsigned* hist;
     int cand_cap;
@@ -1319,11 +1338,17 @@ int al_enqueue(sslam_aliked* g, const uint8_t* img_dev, int H, int W, int C, int
                        W4, g->b4c2.ow, g->b4c2.ob, mo4);
     dcn(g->t4, 128, g->x4, 128, H4, W4, g->b4c2t, g->b4c2.a, g->b4c2.b, g->p4, 64, g->b4dwt, g->b4db);
     // gates
-    hipLaunchKernelGGL(al_gate_kernel, dim3(sslam::cdiv(H2 * W2, 256)), dim3(256), 0, s, g->x2, g->g2, 32, H2 * W2, g->gw2);
-    hipLaunchKernelGGL(al_gate_small_kernel, dim3(sslam::cdiv(32 * HW3, 256)), dim3(256), 0, s, g->x3, g->g3, 64, HW3, g->gw3);
-    hipLaunchKernelGGL(al_gate_small_kernel, dim3(sslam::cdiv(32 * HW4, 256)), dim3(256), 0, s, g->x4, g->g4, 128, HW4, g->gw4);
+    hipLaunchKernelGGL(al_gate_kernel, dim3(sslam::cdiv(H2 * W2, 256)), dim3(256), 0, s, g->x2, g->g2, 32, H2 * W2, g->gw2, g->g2cl);
+    hipLaunchKernelGGL(al_gate_small_kernel, dim3(sslam::cdiv(32 * HW3, 256)), dim3(256), 0, s, g->x3, g->g3, 64, HW3, g->gw3, g->g3cl);
+    hipLaunchKernelGGL(al_gate_small_kernel, dim3(sslam::cdiv(32 * HW4, 256)), dim3(256), 0, s, g->x4, g->g4, 128, HW4, g->gw4, g->g4cl);
     // aggregation + score head
     Pyr P{g->x1, g->g2, g->g3, g->g4, g->gw1, Hp, Wp, g->g1cl};
+    {
+        auto step = [](int full, int S) { return (float)(full / S - 1) / (float)(full - 1); };
+        P.sy2 = step(Hp, 2); P.sx2 = step(Wp, 2); P.sy8 = step(Hp, 8); P.sx8 = step(Wp, 8);
+        P.sy32 = step(Hp, 32); P.sx32 = step(Wp, 32);
+        P.g2cl = g->g2cl; P.g3cl = g->g3cl; P.g4cl = g->g4cl;
+    }
     hipLaunchKernelGGL(al_aggregate_kernel, dim3(sslam::cdiv(Wp, 256), Hp), dim3(256), 0, s, P, g->sh0, g->s8, g->rnorm);
     hipLaunchKernelGGL(al_score_tail_kernel, dim3(sslam::cdiv(Wp, ST_W), sslam::cdiv(Hp, ST_H)), dim3(256), 0, s, g->s8,
                        Hp, Wp, g->sh2, g->sh4, g->sh6, g->score, d.h, d.w, d.pl, d.pt);
@@ -1398,6 +1423,7 @@ int sslam_aliked_create(sslam_ctx* ctx, const float* weights, size_t n_floats, i
             g->dpart = A.take<float>((pa > pb ? pa : pb) + 64);
         }
         g->g2 = A.take<float>(32 * HWp / 4); g->g3 = A.take<float>(32 * HWp / 64); g->g4 = A.take<float>(32 * HWp / 1024);
+        g->g2cl = A.take<float>(32 * HWp / 4); g->g3cl = A.take<float>(32 * HWp / 64); g->g4cl = A.take<float>(32 * HWp / 1024);
         g->s8 = A.take<float>(8 * HWp); g->rnorm = A.take<float>(HWp); g->g1cl = A.take<float>(32 * HWp);
         g->score = A.take<float>(HWp); g->nms = A.take<float>(HWp); g->bsum = A.take<float>(4096); g->gk = A.take<float>(64);
         g->cand = A.take<unsigned long long>(g->cand_cap); g->hist = A.take<unsigned>(HBINS);
