@@ -344,10 +344,14 @@ __global__ void al_avgpool_kernel(const float* __restrict__ in, float* __restric
 }
 
 // offset conv: 3x3, zero pad, bias, clamp to +-max_off.  One wave per pixel: lanes stride over the
-// CIN*9 (ci, tap) products, each lane keeps 18 partial sums, then 18 wave reductions.
+// CIN*9 (ci, tap) products, each lane keeps 18 partial sums, then 18 wave reductions.  The weights
+// are read from the [18][CIN*9] copy made at create time, so each of the 18 loads of an iteration
+// is 256 contiguous bytes across the wave (with the packed [k][18] layout every one of them
+// walked the same 36 cache lines again: 648 line look-ups per iteration instead of 36).
+template <int CIN>
 __global__ __launch_bounds__(256) void al_offset_conv_kernel(const float* __restrict__ in, float* __restrict__ off,
-                                                             int CIN, int H, int W,
-                                                             const float* __restrict__ w /*[ci][tap][18]*/,
+                                                             int H, int W,
+                                                             const float* __restrict__ wt /*[18][CIN*9]*/,
                                                              const float* __restrict__ b, float max_off) {
     const int lane = threadIdx.x & 63, pix = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pix >= H * W) return;
@@ -355,27 +359,35 @@ __global__ __launch_bounds__(256) void al_offset_conv_kernel(const float* __rest
     float part[18];
 #pragma unroll
     for (int o = 0; o < 18; ++o) part[o] = 0.0f;
-    for (int k = lane; k < CIN * 9; k += 64) {
+    // fully unrolled (CIN is a template parameter): all (CIN*9/64) x 19 loads are in flight at once;
+    // as a rolled loop every iteration waited out a full memory latency
+#pragma unroll
+    for (int it = 0; it < (CIN * 9 + 63) / 64; ++it) {
+        const int k = lane + 64 * it;
+        if (CIN * 9 % 64 != 0 && k >= CIN * 9) break;
         const int ci = k / 9, tap = k % 9;
         const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
         const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? in[((size_t)ci * H + yy) * W + xx] : 0.0f;
-        const float* wp = w + (size_t)k * 18;
 #pragma unroll
-        for (int o = 0; o < 18; ++o) part[o] = fmaf(v, wp[o], part[o]);
+        for (int o = 0; o < 18; ++o) part[o] = fmaf(v, wt[o * (CIN * 9) + k], part[o]);
     }
+    // 18 sums over the 64 lanes: through LDS, lane (o, third) adds a third of row o, two shuffles
+    // finish it (18 butterfly reductions = 108 cross-lane steps dominated the kernel)
+    __shared__ float red[4][18][65];
+    const int wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int o = 0; o < 18; ++o) {
-        float v = part[o];
-        for (int sft = 32; sft > 0; sft >>= 1) v += __shfl_xor(v, sft);
-        part[o] = v;
+    for (int o = 0; o < 18; ++o) red[wave][o][lane] = part[o];
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's own slab
+    __builtin_amdgcn_wave_barrier();
+    const int o = lane / 3, th = lane % 3;
+    float v = 0.0f;
+    if (lane < 54) {
+        const float* r = red[wave][o];
+        const int j0 = th * 22, j1 = th == 2 ? 64 : j0 + 22;
+        for (int j = j0; j < j1; ++j) v += r[j];
     }
-    if (lane < 18) {
-        float v = 0.0f;
-#pragma unroll
-        for (int o = 0; o < 18; ++o) v = (lane == o) ? part[o] : v;
-        v += b[lane];
-        off[(size_t)lane * H * W + pix] = fminf(fmaxf(v, -max_off), max_off);
-    }
+    v += __shfl_down(v, 1) + __shfl_down(v, 2);
+    if (lane < 54 && th == 0) off[(size_t)o * H * W + pix] = fminf(fmaxf(v + b[o], -max_off), max_off);
 }
 
 // ---- deformable conv as im2col + matrix-core GEMM --------------------------------------------
@@ -468,6 +480,12 @@ __global__ __launch_bounds__(256) void al_dcn_epilogue_kernel(const float* __res
     float v = fmaf(acc, alpha[co], beta[co]);
     if (resid) v += part[(size_t)KS * COUT * HW + i] + bd[co];
     out[i] = selu(v);
+}
+
+__global__ void al_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // src [R][C] -> dst [C][R]
+    if (i >= R * C) return;
+    dst[(size_t)(i % C) * R + i / C] = src[i];
 }
 
 // conv weights [ci][tap][co] -> [co][tap*CIN + ci]; 1x1 weights [ci][co] -> [co][ci] (taps = 1)
@@ -1202,6 +1220,7 @@ struct sslam_aliked {
     const float *b2dw, *b2db;
     ALDcnW b3c1, b3c2, b4c1, b4c2;
     const float *b3dw, *b3db, *b4dw, *b4db;
+    float *b3c1ot, *b3c2ot, *b4c1ot, *b4c2ot;                              // offset-conv weights as [18][CIN*9]
     float *b3c1t, *b3c2t, *b4c1t, *b4c2t, *b3dwt, *b4dwt, *dcol, *dpart;   // [co][k] copies, im2col buffer, split-K slabs
     const float *gw1, *gw2, *gw3, *gw4;
     const float *sh0, *sh2, *sh4, *sh6;
@@ -1321,21 +1340,21 @@ int al_enqueue(sslam_aliked* g, const uint8_t* img_dev, int H, int W, int C, int
     const int H3 = Hp / 8, W3 = Wp / 8, HW3 = H3 * W3;
     hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(32 * HW3, 256)), dim3(256), 0, s, g->x2, g->p3, 32, H2, W2, 4);
     const float mo3 = (float)(H3 > W3 ? H3 : W3) / 4.0f;
-    hipLaunchKernelGGL(al_offset_conv_kernel, dim3(sslam::cdiv(HW3, 4)), dim3(256), 0, s, g->p3, g->off, 32, H3,
-                       W3, g->b3c1.ow, g->b3c1.ob, mo3);
+    hipLaunchKernelGGL(al_offset_conv_kernel<32>, dim3(sslam::cdiv(HW3, 4)), dim3(256), 0, s, g->p3, g->off, H3,
+                       W3, g->b3c1ot, g->b3c1.ob, mo3);
     dcn(g->p3, 32, g->t3, 64, H3, W3, g->b3c1t, g->b3c1.a, g->b3c1.b, nullptr, 0, nullptr, nullptr);
-    hipLaunchKernelGGL(al_offset_conv_kernel, dim3(sslam::cdiv(HW3, 4)), dim3(256), 0, s, g->t3, g->off, 64, H3,
-                       W3, g->b3c2.ow, g->b3c2.ob, mo3);
+    hipLaunchKernelGGL(al_offset_conv_kernel<64>, dim3(sslam::cdiv(HW3, 4)), dim3(256), 0, s, g->t3, g->off, H3,
+                       W3, g->b3c2ot, g->b3c2.ob, mo3);
     dcn(g->t3, 64, g->x3, 64, H3, W3, g->b3c2t, g->b3c2.a, g->b3c2.b, g->p3, 32, g->b3dwt, g->b3db);
     // block4 at 1/32
     const int H4 = Hp / 32, W4 = Wp / 32, HW4 = H4 * W4;
     hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(64 * HW4, 256)), dim3(256), 0, s, g->x3, g->p4, 64, H3, W3, 4);
     const float mo4 = (float)(H4 > W4 ? H4 : W4) / 4.0f;
-    hipLaunchKernelGGL(al_offset_conv_kernel, dim3(sslam::cdiv(HW4, 4)), dim3(256), 0, s, g->p4, g->off, 64, H4,
-                       W4, g->b4c1.ow, g->b4c1.ob, mo4);
+    hipLaunchKernelGGL(al_offset_conv_kernel<64>, dim3(sslam::cdiv(HW4, 4)), dim3(256), 0, s, g->p4, g->off, H4,
+                       W4, g->b4c1ot, g->b4c1.ob, mo4);
     dcn(g->p4, 64, g->t4, 128, H4, W4, g->b4c1t, g->b4c1.a, g->b4c1.b, nullptr, 0, nullptr, nullptr);
-    hipLaunchKernelGGL(al_offset_conv_kernel, dim3(sslam::cdiv(HW4, 4)), dim3(256), 0, s, g->t4, g->off, 128, H4,
-                       W4, g->b4c2.ow, g->b4c2.ob, mo4);
+    hipLaunchKernelGGL(al_offset_conv_kernel<128>, dim3(sslam::cdiv(HW4, 4)), dim3(256), 0, s, g->t4, g->off, H4,
+                       W4, g->b4c2ot, g->b4c2.ob, mo4);
     dcn(g->t4, 128, g->x4, 128, H4, W4, g->b4c2t, g->b4c2.a, g->b4c2.b, g->p4, 64, g->b4dwt, g->b4db);
     // gates
     hipLaunchKernelGGL(al_gate_kernel, dim3(sslam::cdiv(H2 * W2, 256)), dim3(256), 0, s, g->x2, g->g2, 32, H2 * W2, g->gw2, g->g2cl);
@@ -1416,6 +1435,7 @@ int sslam_aliked_create(sslam_ctx* ctx, const float* weights, size_t n_floats, i
         g->p4 = A.take<float>(64 * HWp / 1024); g->t4 = A.take<float>(128 * HWp / 1024); g->x4 = A.take<float>(128 * HWp / 1024);
         g->b3c1t = A.take<float>(288 * 64); g->b3c2t = A.take<float>(576 * 64); g->b4c1t = A.take<float>(576 * 128);
         g->b4c2t = A.take<float>(1152 * 128); g->b3dwt = A.take<float>(32 * 64); g->b4dwt = A.take<float>(64 * 128);
+        g->b3c1ot = A.take<float>(288 * 18); g->b3c2ot = A.take<float>(576 * 18); g->b4c1ot = A.take<float>(576 * 18); g->b4c2ot = A.take<float>(1152 * 18);
         {   // im2col rows: 1/8 level (64*9 + 32) floats per pixel, 1/32 level (128*9 + 64)
             const size_t a = (HWp / 64) * (size_t)(576 + 32), b = (HWp / 1024) * (size_t)(1152 + 64);
             g->dcol = A.take<float>((a > b ? a : b) + 64);
@@ -1452,6 +1472,11 @@ int sslam_aliked_create(sslam_ctx* ctx, const float* weights, size_t n_floats, i
         tr(g->b3c1.w, g->b3c1t, 32, 9, 64); tr(g->b3c2.w, g->b3c2t, 64, 9, 64);
         tr(g->b4c1.w, g->b4c1t, 64, 9, 128); tr(g->b4c2.w, g->b4c2t, 128, 9, 128);
         tr(g->b3dw, g->b3dwt, 32, 1, 64); tr(g->b4dw, g->b4dwt, 64, 1, 128);
+        auto tro = [&](const float* src, float* dst, int K) {      // [k][18] -> [18][k]
+            hipLaunchKernelGGL(al_transpose_kernel, dim3(sslam::cdiv(K * 18, 256)), dim3(256), 0, s, src, dst, K, 18);
+        };
+        tro(g->b3c1.ow, g->b3c1ot, 288); tro(g->b3c2.ow, g->b3c2ot, 576); tro(g->b4c1.ow, g->b4c1ot, 576);
+        tro(g->b4c2.ow, g->b4c2ot, 1152);
         SSLAM_HIP_CHECK(hipStreamSynchronize(s));
     }
     SSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)al_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
