@@ -1084,179 +1084,8 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-__global__ __launch_bounds__(256, 2) void lg_attention_h_kernel(AttnArgsH p) {
-    __shared__ AttnSmemH sm;
-    if (p.ctrl->stop) return;
-    // XCD-aware order: slab = (img, head, key split); its query blocks are congruent mod 8
-    const int nqb = gridDim.x, nslab = gridDim.y * gridDim.z;
-    int slab, qb;
-    {
-        const int b = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        if ((nslab & 7) == 0) { const int xcd = b & 7, idx = b >> 3; slab = xcd + 8 * (idx / nqb); qb = idx % nqb; }
-        else { slab = blockIdx.z * gridDim.y + blockIdx.y; qb = blockIdx.x; }
-    }
-    const int z = slab / gridDim.y, ih = slab % gridDim.y;
-    const int img = ih >> 2, head = ih & 3;
-    const int kimg = p.cross ? 1 - img : img;
-    const int nq = p.ctrl->n[img], nk = p.ctrl->n[kimg];
-    const int q0 = qb * AQ;
-    if (q0 >= nq) return;
-    const int t = threadIdx.x, lane = t & 63, h = lane >> 5, lr = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int ntiles = (nk + AK - 1) / AK;
-    const int t0 = (int)((long)z * ntiles / p.KS), t1 = (int)((long)(z + 1) * ntiles / p.KS);
-
-    const size_t qoff = ((size_t)img * NH + head) * p.Kc * DH;
-    const size_t koff = ((size_t)kimg * NH + head) * p.Kc * DH;   // same size for K and V^T planes
-
-    // Q fragments (B operand of S^T = K.Q^T): lane holds Q[query lr][dims 16 s + 8 h .. +7]; the
-    // softmax scale * log2(e) is already folded in by the projection epilogue
-    const int qi = min(q0 + wave * 32 + lr, p.Kc - 1);
-    half8 qh[4], ql[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        qh[s] = *reinterpret_cast<const half8*>(p.Q.hi + qoff + (size_t)qi * DH + 16 * s + 8 * h);
-        ql[s] = *reinterpret_cast<const half8*>(p.Q.lo + qoff + (size_t)qi * DH + 16 * s + 8 * h);
-    }
-
-    f32x16 o1a, o2a, o1b, o2b;       // O^T d-block a (d 0..31) / b (d 32..63): hi.hi and cross terms
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o1a[r] = 0.0f; o2a[r] = 0.0f; o1b[r] = 0.0f; o2b[r] = 0.0f; }
-    float m_run = -INFINITY, l_run = 0.0f;
-
-    // tile loader: wave w owns plane w (K hi, K lo, V^T hi, V^T lo): 8 DMA instructions of 8 rows
-    const _Float16* gplane = (wave == 0 ? p.K.hi : wave == 1 ? p.K.lo : wave == 2 ? p.VT.hi : p.VT.lo) + koff;
-    const bool is_v = wave >= 2;
-    const int lrow = lane >> 3, lcp = lane & 7;
-    auto issue_tile = [&](int tile, int buf) {
-        _Float16* dst = wave == 0 ? sm.k_hi[buf] : wave == 1 ? sm.k_lo[buf] : wave == 2 ? sm.vt_hi[buf] : sm.vt_lo[buf];
-#pragma unroll
-        for (int rg = 0; rg < 8; ++rg) {
-            const int row = rg * 8 + lrow;
-            const int c = lcp ^ ((row >> 1) & 7);
-            const _Float16* src = is_v ? gplane + ((size_t)tile * DH + row) * AK + c * 8     // key-tile-major V^T
-                                       : gplane + (size_t)min(tile * AK + row, p.Kc - 1) * DH + c * 8;
-            glds16(src, dst + rg * 8 * DH);
-        }
-    };
-
-    // loop-invariant swizzled LDS offsets (halves) of this lane's K and V^T fragments
-    int koffs[2][4], voffs[2][2][2][2];
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-        const int krow = sub * 32 + lr, kswz = (krow >> 1) & 7;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) koffs[sub][s] = krow * DH + (((2 * s + h) ^ kswz) * 8);
-#pragma unroll
-        for (int s2i = 0; s2i < 2; ++s2i)
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                const int d = db * 32 + lr, vswz = (d >> 1) & 7, c0 = 4 * sub + 2 * s2i;
-                voffs[sub][s2i][db][0] = d * AK + ((c0 ^ vswz) * 8) + 4 * h;
-                voffs[sub][s2i][db][1] = d * AK + (((c0 + 1) ^ vswz) * 8) + 4 * h;
-            }
-    }
-
-    if (t0 < t1) issue_tile(t0, 0);
-    __syncthreads();                 // drains the DMA (vmcnt(0)) and publishes the tile
-    int cur = 0;
-    for (int tile = t0; tile < t1; ++tile) {
-        if (tile + 1 < t1) issue_tile(tile + 1, cur ^ 1);
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            f32x16 s1, s2;
-            const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const half8 kh = *reinterpret_cast<const half8*>(&sm.k_hi[cur][koffs[sub][s]]);
-                const half8 kl = *reinterpret_cast<const half8*>(&sm.k_lo[cur][koffs[sub][s]]);
-                s1 = mfma16(kh, qh[s], s == 0 ? zero16 : s1);      // C = inline 0 on the first step
-                s2 = mfma16(kh, ql[s], s == 0 ? zero16 : s2);
-                s2 = mfma16(kl, qh[s], s2);
-            }
-            const int kbase = tile * AK + sub * 32;
-            float sv[16];
-            float tmax = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sv[r] = s1[r] + s2[r] * SPLIT_INV;
-            if (kbase + 32 > nk) {                       // ragged tail only (block-uniform)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (kbase + acc_row(r, lane) >= nk) sv[r] = -INFINITY;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sv[r]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-            const float m_new = fmaxf(m_run, tmax);
-            const bool grow = !__all(m_new == m_run);    // wave-uniform: running max moved for some query
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // raw v_exp_f32: args <= 0
-            m_run = m_new;
-            float psum = 0.0f;
-            half8 ph[2], pl[2];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(sv[r] - m_new);
-                psum += pv;
-                _Float16 hh, ll;
-                split_f32(pv, hh, ll);
-                ph[r >> 3][r & 7] = hh;                  // k-slot j' of step s2 = accumulator reg 8 s2 + j'
-                pl[r >> 3][r & 7] = ll;
-            }
-            if (grow) {                                  // alpha == 1 exactly otherwise
-                l_run *= alpha;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { o1a[r] *= alpha; o2a[r] *= alpha; o1b[r] *= alpha; o2b[r] *= alpha; }
-            }
-            l_run += psum;
-            // O^T[d][i] += V^T[d][key] P^T[key][i]; k-slot j' of step s2 <-> key 16 s2 + 8 (j'>>2) + 4 h + (j'&3)
-#pragma unroll
-            for (int s2i = 0; s2i < 2; ++s2i) {
-#pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    const int vo0 = voffs[sub][s2i][db][0], vo1 = voffs[sub][s2i][db][1];
-                    const half4 vh0 = *reinterpret_cast<const half4*>(&sm.vt_hi[cur][vo0]);
-                    const half4 vh1 = *reinterpret_cast<const half4*>(&sm.vt_hi[cur][vo1]);
-                    const half4 vl0 = *reinterpret_cast<const half4*>(&sm.vt_lo[cur][vo0]);
-                    const half4 vl1 = *reinterpret_cast<const half4*>(&sm.vt_lo[cur][vo1]);
-                    const half8 vh = __builtin_shufflevector(vh0, vh1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    const half8 vl = __builtin_shufflevector(vl0, vl1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    if (db == 0) {
-                        o1a = mfma16(vh, ph[s2i], o1a);
-                        o2a = mfma16(vh, pl[s2i], o2a);
-                        o2a = mfma16(vl, ph[s2i], o2a);
-                    } else {
-                        o1b = mfma16(vh, ph[s2i], o1b);
-                        o2b = mfma16(vh, pl[s2i], o2b);
-                        o2b = mfma16(vl, ph[s2i], o2b);
-                    }
-                }
-            }
-        }
-        __syncthreads();             // next tile landed (vmcnt(0)); everyone is done reading `cur`
-        cur ^= 1;
-    }
-
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const int qrow = q0 + wave * 32 + lr;
-    if (qrow < nq) {
-        const size_t pbase = (((size_t)z * 2 + img) * NH + head) * p.Kc + qrow;
-        float* op = p.o_part + pbase * DH;
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            float4 a, b;
-            a.x = o1a[4 * g4] + o2a[4 * g4] * SPLIT_INV; a.y = o1a[4 * g4 + 1] + o2a[4 * g4 + 1] * SPLIT_INV;
-            a.z = o1a[4 * g4 + 2] + o2a[4 * g4 + 2] * SPLIT_INV; a.w = o1a[4 * g4 + 3] + o2a[4 * g4 + 3] * SPLIT_INV;
-            b.x = o1b[4 * g4] + o2b[4 * g4] * SPLIT_INV; b.y = o1b[4 * g4 + 1] + o2b[4 * g4 + 1] * SPLIT_INV;
-            b.z = o1b[4 * g4 + 2] + o2b[4 * g4 + 2] * SPLIT_INV; b.w = o1b[4 * g4 + 3] + o2b[4 * g4 + 3] * SPLIT_INV;
-            *reinterpret_cast<float4*>(op + 8 * g4 + 4 * h) = a;
-            *reinterpret_cast<float4*>(op + 32 + 8 * g4 + 4 * h) = b;
-        }
-        if (h == 0) { p.m_part[pbase] = m_run; p.l_part[pbase] = l_tot; }
-    }
-}
-
 // ---- attention, split precision, software-pipelined ---------------------------------------
-// Same data layout, fragments and LDS image as lg_attention_h_kernel; the loop is re-timed so that
+// Flash-style loop over 64-key tiles, re-timed so that
 // one iteration (a 32-key sub-step j) holds three INDEPENDENT instruction streams the scheduler
 // can interleave inside one basic block:
 //     MFMA   O += V^T(j-1) P(j-1)          (P of the previous sub-step, 12 MFMA)
@@ -1733,9 +1562,7 @@ void launch_attention_h(sslam_lightglue* g, hipStream_t s, SplitPtr Q, SplitPtr 
             for (int i = 0; i < 64; ++i) { hipEvent_t e; (void)hipEventCreate(&e); g->ev.push_back(e); }
         (void)hipEventRecord(g->ev[g->ev_used], s);
     }
-    static const bool pipelined = [] { const char* e = getenv("SSLAM_ATTN"); return !(e && e[0] == '0'); }();
-    if (pipelined) hipLaunchKernelGGL(lg_attention_p_kernel, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(lg_attention_h_kernel, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(lg_attention_p_kernel, grid, dim3(256), 0, s, a);
     if (prof) { (void)hipEventRecord(g->ev[g->ev_used + 1], s); g->ev_used += 2; }
     const long n4 = (long)2 * NH * g->Kc * 16;
     hipLaunchKernelGGL(lg_attn_merge_h_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, g->o_part,
@@ -1743,6 +1570,9 @@ void launch_attention_h(sslam_lightglue* g, hipStream_t s, SplitPtr Q, SplitPtr 
 }
 
 // one transformer layer (self + cross block) on the split-precision path
+#ifndef LG_TILE64
+#define LG_TILE64 0      // experiments: 1 ffn0, 2 cross projection, 4 qkv as 64x64 tiles (two workgroups per CU)
+#endif
 void lg_layer_h(sslam_lightglue* g, hipStream_t s, const LGLayerW& l, bool self_only) {
     const SplitPtr xs{g->xs_hi, g->xs_lo}, msgs{g->msgs_hi, g->msgs_lo};
     const SplitPtr hids{g->hids_hi, g->hids_lo}, none{nullptr, nullptr};
@@ -1753,7 +1583,11 @@ void lg_layer_h(sslam_lightglue* g, hipStream_t s, const LGLayerW& l, bool self_
                    const float* b2) {
         LinearArgsH a = linh(g, xs, msgs, D, D, 2 * D, w1, b1, 2 * D);      // [x | attention context]
         a.out = g->hid; a.ldo = 2 * D;
+#if LG_TILE64 & 1
+        launch_linear_h<64, 64, 1, 1, EPH_F32>(s, a);
+#else
         launch_linear_h<64, 128, 1, 2, EPH_F32>(s, a);
+#endif
         hipLaunchKernelGGL(lg_ln_gelu_h_kernel, dim3(tokblocks), dim3(256), 0, s, g->hid,
                            SplitOut{g->hids_hi, g->hids_lo}, lnw, lnb, g->ctrl, g->Kc);
         LinearArgsH c = linh(g, hids, none, 2 * D, 2 * D, 2 * D, w2, b2, D);
@@ -1764,7 +1598,11 @@ void lg_layer_h(sslam_lightglue* g, hipStream_t s, const LGLayerW& l, bool self_
         LinearArgsH a = linh(g, xs, none, D, D, D, l.wqkv, l.bqkv, 3 * D);
         a.q = SplitOut{g->qs_hi, g->qs_lo}; a.k = SplitOut{g->ks_hi, g->ks_lo}; a.vt = SplitOut{g->vts_hi, g->vts_lo};
         a.q_scale = sm_scale; a.k_scale = 1.0f;
+#if LG_TILE64 & 4
+        launch_linear_h<64, 64, 1, 1, EPH_QKV>(s, a);
+#else
         launch_linear_h<64, 192, 1, 3, EPH_QKV>(s, a);       // 768 / 192 = 4 column tiles -> 256 blocks, one round
+#endif
     }
     launch_attention_h(g, s, qs, ks, vts, 0);
     ffn(l.w1, l.b1, l.lnw, l.lnb, l.w2, l.b2);
@@ -1773,7 +1611,11 @@ void lg_layer_h(sslam_lightglue* g, hipStream_t s, const LGLayerW& l, bool self_
         LinearArgsH a = linh(g, xs, none, D, D, D, l.cqkv, l.cbqkv, 2 * D);
         a.q = SplitOut{g->qs_hi, g->qs_lo}; a.vt = SplitOut{g->vts_hi, g->vts_lo};
         a.q_scale = sqrtf(sm_scale);
+#if LG_TILE64 & 2
+        launch_linear_h<64, 64, 1, 1, EPH_CROSS>(s, a);
+#else
         launch_linear_h<64, 128, 1, 2, EPH_CROSS>(s, a);
+#endif
     }
     launch_attention_h(g, s, qs, qs, vts, 1);
     ffn(l.cw1, l.cb1, l.clnw, l.clnb, l.cw2, l.cb2);

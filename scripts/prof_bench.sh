@@ -1,11 +1,11 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_v4 -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof_v4_bench.log 2>&1
-find gpurun_out/prof_v4 -name '*kernel_stats.csv' -exec cp {} gpurun_out/r01_bench_n1_kernel_stats_v4.csv \;
-find gpurun_out/prof_v4 -name '*kernel_trace.csv' -exec cp {} gpurun_out/ktrace_v4.csv \;
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_v5 -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof_v5_bench.log 2>&1
+find gpurun_out/prof_v5 -name '*kernel_stats.csv' -exec cp {} gpurun_out/r01_bench_n1_kernel_stats_v5.csv \;
+find gpurun_out/prof_v5 -name '*kernel_trace.csv' -exec cp {} gpurun_out/ktrace_v5.csv \;
 python - <<'PY'
 import csv, collections
-rows = list(csv.DictReader(open('gpurun_out/ktrace_v4.csv')))
+rows = list(csv.DictReader(open('gpurun_out/ktrace_v5.csv')))
 print(len(rows), 'launches')
 t0 = min(int(r['Start_Timestamp']) for r in rows); t1 = max(int(r['End_Timestamp']) for r in rows)
 # last 5 steps only: take last 5*24 frames worth -> approximate using the last 60% of time
@@ -24,5 +24,5 @@ for k in sorted(conc): print(f'  {k} kernels in flight: {conc[k]/tot:.3f}')
 busy = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in rows if int(r['Start_Timestamp']) > lo)
 print('sum kernel time / wall =', busy / (t1 - lo))
 PY
-rm -rf gpurun_out/prof_v4 gpurun_out/ktrace_v4.csv
-tail -2 gpurun_out/prof_v4_bench.log
+rm -rf gpurun_out/prof_v5 gpurun_out/ktrace_v5.csv
+tail -2 gpurun_out/prof_v5_bench.log
