@@ -111,6 +111,24 @@ int sslam_fmat_ransac_host(sslam_ctx* ctx, int n, const float* pts1, const float
                            double thresh, double confidence, int max_iters,
                            unsigned char* mask_out, double* F_out, int* info_out);
 
+/* ------------------------------------------- 2D-3D association for tracking
+ * Replaces the per-point loop of `reproject_and_match_2d3d` (slam/core/pnp_utils.py:224-304) for
+ * float descriptors: projection (`_project_points` :127-141), radius search (cKDTree :238, :265),
+ * min L2 over the point's last six observation descriptors (:107-120) and the greedy `used_kps`
+ * pass in map order (:260-286).
+ *   pts3d[n_points*3] float64 world points in `world_map.points` order
+ *   obs_cnt[n_points]: 0..6 = descriptors among the point's last six observations; 0 also for a point
+ *     whose LAST observation has none (the reference skips it, :270-272)
+ *   obs_desc[n_points*6*128]: those descriptors, valid ones first
+ *   K9 row-major 3x3, Tcw16 row-major 4x4 (camera-from-world), kp_xy[n_kp*2], des[n_kp*128] float32
+ *   kp_of_point[n_points]: out, matched keypoint index or -1;  uv_out[n_points*2] (may be NULL)
+ *   info_out[2] (may be NULL): matches, candidate points */
+int sslam_reproject_match_host(sslam_ctx* ctx, int n_points, const double* pts3d,
+                               const int32_t* obs_cnt, const float* obs_desc, const double* K9,
+                               const double* Tcw16, int n_kp, const float* kp_xy, const float* des,
+                               int img_w, int img_h, double radius_px, double max_dist,
+                               int32_t* kp_of_point, float* uv_out, int32_t* info_out);
+
 /* ------------------------------------------------------------------ ALIKED
  * Replaces `ALIKED(max_num_keypoints=...).eval().to(device)` at
  * slam/core/features_utils.py:25 and `_bgr_to_tensor` + `detector.extract` +
