@@ -464,16 +464,19 @@ __device__ __forceinline__ float logsigmoidf_(float x) {   // min(x,0) - log1p(e
     return fminf(x, 0.0f) - log1pf(expf(-fabsf(x)));
 }
 
-// conf = sigmoid(w_c.x + b_c), mat = w_m.x + b_m per token.  One wave handles TOK_PER_WAVE tokens
-// (weights stay in registers); a block adds its count of unconfident tokens with ONE atomic
-// (same-address atomics retire one per ~11 ns, so 1024 blocks x 1 atomic was the kernel's cost).
-constexpr int TOK_PER_WAVE = 16;
+// conf = sigmoid(w_c.x + b_c), mat = w_m.x + b_m per token; a block adds its count of unconfident
+// tokens with ONE atomic (same-address atomics retire one per ~11 ns).  The kernel's ~12 us are the
+// launch, the dependent read of the control block written by the previous kernel and the atomic:
+// a wave-per-16-tokens layout and this lane-per-token one measure the same.
 
 __global__ __launch_bounds__(256) void lg_token_heads_kernel(
     const float* __restrict__ x, const float* __restrict__ wc, const float* __restrict__ bc,
     const float* __restrict__ wm, const float* __restrict__ bm, long m_layer_stride, int use_stop_layer,
     float conf_thr, float* __restrict__ conf, float* __restrict__ mat, LGCtrl* __restrict__ ctrl, int Kc,
     int count_unconf) {
+    // one lane per token: the two 256-long dot products run down the lane's own row (weights are
+    // wave-uniform scalar loads), so there is no cross-lane reduction at all; a wave-per-token
+    // layout spent its time in 12 dependent shuffles per token
     __shared__ int s_unconf[4];
     if (ctrl->stop == 2) return;
     if (ctrl->stop && !use_stop_layer) return;
@@ -482,30 +485,33 @@ __global__ __launch_bounds__(256) void lg_token_heads_kernel(
         wm += (size_t)ctrl->stop_layer * m_layer_stride;
         bm += (size_t)ctrl->stop_layer * m_layer_stride;   // both padded to the same stride
     }
-    const float4 wmv = *reinterpret_cast<const float4*>(wm + lane * 4);
-    const float4 wcv = wc ? *reinterpret_cast<const float4*>(wc + lane * 4) : make_float4(0, 0, 0, 0);
-    const float bmv = bm[0], bcv = wc ? bc[0] : 0.0f;
-    int unconf = 0;
-    const int tok0 = (blockIdx.x * 4 + wave) * TOK_PER_WAVE;
-    for (int j = 0; j < TOK_PER_WAVE; ++j) {
-        const int gt = tok0 + j;
-        const int img = gt / Kc, row = gt % Kc;
-        if (img > 1 || row >= ctrl->n[img]) continue;       // wave-uniform
-        const float4 xv = *reinterpret_cast<const float4*>(x + ((size_t)img * Kc + row) * D + lane * 4);
-        float sm_ = xv.x * wmv.x + xv.y * wmv.y + xv.z * wmv.z + xv.w * wmv.w;
-        float sc = xv.x * wcv.x + xv.y * wcv.y + xv.z * wcv.z + xv.w * wcv.w;
-        for (int o = 32; o > 0; o >>= 1) { sm_ += __shfl_xor(sm_, o); sc += __shfl_xor(sc, o); }
-        if (lane == 0) {
-            mat[img * Kc + row] = sm_ + bmv;
-            if (wc) {
-                const float c = sigmoidf_(sc + bcv);
-                conf[img * Kc + row] = c;
-                unconf += c < conf_thr;
-            }
+    const int gt = blockIdx.x * 256 + threadIdx.x;
+    const int img = min(gt / Kc, 1), row = gt % Kc;
+    const bool live = gt < 2 * Kc && row < ctrl->n[img];
+    const float* xr = x + ((size_t)img * Kc + (live ? row : 0)) * D;
+    float sm0 = 0.0f, sm1 = 0.0f, sc0 = 0.0f, sc1 = 0.0f;
+#pragma unroll 8
+    for (int k = 0; k < D; k += 8) {
+        const float4 a = *reinterpret_cast<const float4*>(xr + k), b = *reinterpret_cast<const float4*>(xr + k + 4);
+        sm0 += a.x * wm[k] + a.y * wm[k + 1] + a.z * wm[k + 2] + a.w * wm[k + 3];
+        sm1 += b.x * wm[k + 4] + b.y * wm[k + 5] + b.z * wm[k + 6] + b.w * wm[k + 7];
+        if (wc) {
+            sc0 += a.x * wc[k] + a.y * wc[k + 1] + a.z * wc[k + 2] + a.w * wc[k + 3];
+            sc1 += b.x * wc[k + 4] + b.y * wc[k + 5] + b.z * wc[k + 6] + b.w * wc[k + 7];
+        }
+    }
+    bool unconf = false;
+    if (live) {
+        mat[img * Kc + row] = (sm0 + sm1) + bm[0];
+        if (wc) {
+            const float c = sigmoidf_((sc0 + sc1) + bc[0]);
+            conf[img * Kc + row] = c;
+            unconf = c < conf_thr;
         }
     }
     if (!count_unconf) return;
-    if (lane == 0) s_unconf[wave] = unconf;
+    const int wcount = __popcll(__ballot(unconf));
+    if (lane == 0) s_unconf[wave] = wcount;
     __syncthreads();
     if (threadIdx.x == 0) {
         const int tot = s_unconf[0] + s_unconf[1] + s_unconf[2] + s_unconf[3];
@@ -1637,7 +1643,7 @@ int lg_enqueue(sslam_lightglue* g, int M, int N, const int32_t* m_dev, const int
         launch_linear<64, 64, 1, 1, EPI_PLAIN>(s, a);
     }
     const unsigned tokblocks = sslam::cdiv(2 * Kc, 4);
-    const unsigned headblocks = sslam::cdiv(2 * Kc, 4 * TOK_PER_WAVE);
+    const unsigned headblocks = sslam::cdiv(2 * Kc, 256);          // one lane per token
     const unsigned splitblocks = (unsigned)(((size_t)2 * Kc * D + 255) / 256);
     if (g->precision == 1)
         hipLaunchKernelGGL(lg_split_rows_kernel, dim3(splitblocks), dim3(256), 0, s, g->x, g->xs_hi, g->xs_lo, D, Kc,
