@@ -210,3 +210,15 @@ def test_non_finite_input_gives_no_fault(W, LG, precision):
     np.testing.assert_array_equal(small[0], small2[0])
     np.testing.assert_array_equal(small[1], small2[1])
     lg.close()
+
+
+def test_reference_default_size_4000_keypoints(W, LG):
+    """`max_features` defaults to 4000 in the reference (features_utils.py:25): capacity 4096, ragged
+    3 700 x 4 000 pair, index arrays against the oracle."""
+    sd = W.random_lightglue_state_dict(9, match_gain=4.0, match_bias=3.0)
+    lg = LG(sd, max_kpts=4000)
+    assert lg.capacity == 4096
+    k0, d0, k1, d1 = lg_inputs.make_pair(3700, 4000, seed=31)
+    ij, ref = _compare(lg, sd, k0, d0, k1, d1, min_conf=0.7, check_state=False)
+    assert len(ij) > 500
+    lg.close()
