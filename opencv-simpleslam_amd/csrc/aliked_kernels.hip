@@ -592,6 +592,9 @@ __global__ __launch_bounds__(256) void al_aggregate_kernel(Pyr P, const float* _
 #pragma unroll
     for (int o = 0; o < 8; ++o) s[o] = 0.0f;
     float n2 = 0.0f;
+    // channel loops stay rolled (2 channels per iteration): fully unrolled, their ~1500 wave-uniform
+    // weights overflow the SGPR file and return through v_readlane
+#pragma unroll 2
     for (int c = 0; c < 32; ++c) {
         float a = 0.0f;
 #pragma unroll
@@ -605,18 +608,21 @@ __global__ __launch_bounds__(256) void al_aggregate_kernel(Pyr P, const float* _
     const UpTap t2 = up_tap(y, x, P.Hp, P.Wp, 2, P.sy2, P.sx2), t3 = up_tap(y, x, P.Hp, P.Wp, 8, P.sy8, P.sx8),
                 t4 = up_tap(y, x, P.Hp, P.Wp, 32, P.sy32, P.sx32);
     const size_t hw2 = HW / 4, hw3 = HW / 64, hw4 = HW / 1024;
+#pragma unroll 2
     for (int c = 0; c < 32; ++c) {
         const float a = up_eval(P.g2 + c * hw2, t2);
         n2 = fmaf(a, a, n2);
 #pragma unroll
         for (int o = 0; o < 8; ++o) s[o] = fmaf(a, ws0[(32 + c) * 8 + o], s[o]);
     }
+#pragma unroll 2
     for (int c = 0; c < 32; ++c) {
         const float a = up_eval(P.g3 + c * hw3, t3);
         n2 = fmaf(a, a, n2);
 #pragma unroll
         for (int o = 0; o < 8; ++o) s[o] = fmaf(a, ws0[(64 + c) * 8 + o], s[o]);
     }
+#pragma unroll 2
     for (int c = 0; c < 32; ++c) {
         const float a = up_eval(P.g4 + c * hw4, t4);
         n2 = fmaf(a, a, n2);
@@ -685,9 +691,15 @@ __global__ __launch_bounds__(256) void al_score_tail_kernel(const float* __restr
         const int yy = y0 + ly - 2, xx = x0 + lx - 2;
         float a[4] = {0, 0, 0, 0};
         if (yy >= 0 && yy < Hp && xx >= 0 && xx < Wp) {
+            // one input channel per (rolled) iteration: its 36 wave-uniform weights fit the SGPR file.
+            // Fully unrolled, the 288 scalar weights overflow it and come back through ~1000
+            // v_readlane per thread - more than the kernel's FMAs.
+#pragma unroll 1
             for (int ci = 0; ci < 8; ++ci)
+#pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     const float v = t0[ci][ly + tap / 3][lx + tap % 3];
+#pragma unroll
                     for (int o = 0; o < 4; ++o) a[o] = fmaf(v, w2[(ci * 9 + tap) * 4 + o], a[o]);
                 }
             for (int o = 0; o < 4; ++o) a[o] = selu(a[o]);
@@ -700,9 +712,12 @@ __global__ __launch_bounds__(256) void al_score_tail_kernel(const float* __restr
         const int yy = y0 + ly - 1, xx = x0 + lx - 1;
         float a[4] = {0, 0, 0, 0};
         if (yy >= 0 && yy < Hp && xx >= 0 && xx < Wp) {
+#pragma unroll 1
             for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     const float v = t1[ci][ly + tap / 3][lx + tap % 3];
+#pragma unroll
                     for (int o = 0; o < 4; ++o) a[o] = fmaf(v, w4[(ci * 9 + tap) * 4 + o], a[o]);
                 }
             for (int o = 0; o < 4; ++o) a[o] = selu(a[o]);
