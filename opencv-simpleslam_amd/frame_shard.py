@@ -174,14 +174,14 @@ class FrameStreamPipeline:
                 self.ev_mdone[m].record(self.sm[m])
             self.have_halo = True
             return
-        # ---- multi-GPU: collate on the current stream once every local stream has drained
+        # ---- multi-GPU: collate on the current stream as soon as the EXTRACTS are done; this round's
+        # matches keep running on their own streams underneath the all-gather
         cur = torch.cuda.current_stream()
-        for st in set(self.se) | set(self.sm):
+        for st in set(self.se):
             cur.wait_stream(st)
-        for s in range(B):
-            self.blocks[s, 0, 0] = self.count[s, 0].to(torch.float32)
-            self.blocks[s, 1:, :2] = self.xy[s]
-            self.blocks[s, 1:, 2:] = self.desc[s]
+        self.blocks[:B, 0, 0] = self.count[:B, 0].to(torch.float32)      # three fused copies, not 3 B
+        self.blocks[:B, 1:, :2] = self.xy[:B]
+        self.blocks[:B, 1:, 2:] = self.desc[:B]
         self.shared_map = collate(self.blocks[:B], plan)
         # boundary pair: my first frame vs the previous chunk's last frame
         prev = plan.rank * B - 1                     # index inside the gathered round
@@ -192,6 +192,10 @@ class FrameStreamPipeline:
         else:
             src = None
         if src is not None:
+            # slot B may still be read by the previous round's boundary match on sm[0]: same stream
+            # order protects it, the copy below is ordered after that match through the event
+            ev0 = torch.cuda.Event(); ev0.record(self.sm[0])
+            cur.wait_event(ev0)
             self.xy[B].copy_(src[1:, :2]); self.desc[B].copy_(src[1:, 2:])
             self.count[B, 0] = src[0, 0].to(torch.int32)
             ev = torch.cuda.Event(); ev.record(cur)
@@ -200,10 +204,10 @@ class FrameStreamPipeline:
                 self._match(0, B, 0, 0)
         self.prev_round_last = self.shared_map[plan.world * B - 1].clone()
         self.have_halo = True
-        ev = torch.cuda.Event(); ev.record(cur)
         for m in range(NM):
-            self.sm[m].wait_event(ev)
             self.ev_mdone[m].record(self.sm[m])
+        # the next round's packing overwrites `blocks`: it is issued on `cur` after this gather
+        # (stream order), and `shared_map` is a fresh tensor per round
 
     def results(self):
         """Host copy of the last round's matches: list of (ij [K,2], scores [K]) per local frame."""

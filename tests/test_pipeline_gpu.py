@@ -85,3 +85,14 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
                     "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
     assert d["n_gpus"] == 2 and d["value"] > 0
     assert d["config"]["frames_per_step_per_gpu"] == 6
+
+
+def test_two_rank_pipeline_equals_sequential_api():
+    """N > 1 data path: tests/dist_pipeline_check.py under torch.distributed.run, 2 gloo ranks on one GPU."""
+    import os, subprocess, sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29613", "tests/dist_pipeline_check.py"],
+                         cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert out.stdout.count("pairs identical to the sequential API") == 2
