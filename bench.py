@@ -44,6 +44,16 @@ F32_MFMA_PEAK_TFLOPS = 157.3           # same table: v_mfma_f32_32x32x2_f32, the
 ALIKED_GFLOP_PER_FRAME = 8.9           # 6.56 dense conv + 2.34 SDDH at 2048 keypoints
 
 
+def _pmc_traffic():
+    """Per-launch HBM-side bytes of the attention kernel at the bench size, from profiles/ (None when absent)."""
+    f = ROOT / "profiles" / "r01_attention_traffic.json"
+    try:
+        d = json.loads(f.read_text())
+        return int(d["fetch_bytes_per_launch"]) + int(d["write_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def lightglue_gflop(n, layers):
     """SURVEY 8(d) F(N, L): algorithmic FLOPs of one pair with M = N = n keypoints, L layers executed."""
     D, d_in = 256, 128
@@ -246,7 +256,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "lg_attention_p_kernel (v_mfma_f32_32x32x16_f16 x3 per product)",
                          "achieved": round(ach, 2) if ach else None, "peak": F16_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(ach / F16_MFMA_PEAK_TFLOPS, 4) if ach else None,
-                         "traffic": None,
+                         # HBM-side bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+                         # scripts/pmc_traffic.sh); not re-measured here: PMC collection needs rocprofv3
+                         "traffic": _pmc_traffic(),
                          "executed_mfma_frac": round(3 * ach / F16_MFMA_PEAK_TFLOPS, 4) if ach else None,
                          "launches_timed": iso_n,
                          "avg_launch_us": round(iso_ms / max(iso_n, 1) * 1e3, 2),
