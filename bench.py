@@ -155,8 +155,11 @@ def main():
     LightGlueHIP = importlib.import_module("opencv-simpleslam_amd.lightglue").LightGlueHIP
     fs = importlib.import_module("opencv-simpleslam_amd.frame_shard")
 
-    N_EXT = int(os.environ.get("SSLAM_BENCH_NE", 2))      # extractor / matcher instances,
-    N_MAT = int(os.environ.get("SSLAM_BENCH_NM", 6))      # one HIP stream each
+    # extractor / matcher instances, one HIP stream each.  The GPU serves 8 hardware queues: 1 + 7
+    # streams on one GPU (566 frames/s vs 552 for 2 + 6; a ninth stream drops it to 490); with
+    # N > 1 one queue is left to RCCL's own stream
+    N_EXT = int(os.environ.get("SSLAM_BENCH_NE", 1))
+    N_MAT = int(os.environ.get("SSLAM_BENCH_NM", 7 if world == 1 else 6))
     main = torch.cuda.Stream()
     with torch.cuda.stream(main):
         streams_e = [torch.cuda.Stream() for _ in range(N_EXT)]      # default priority: prioritised

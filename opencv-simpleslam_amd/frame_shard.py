@@ -19,8 +19,9 @@ Inside one GPU several frames are in flight as well: NE extractor and NM
 matcher instances, each on its own HIP stream, chained by events
 (match(t-1, t) waits for extract(t-1) and extract(t)).  Each pair / frame is a
 chain of ~130 / ~35 short kernels that is bound by per-block latency, not by
-the chip, so independent chains overlap almost freely (measured: 4 matcher
-streams = 1.5x the pairs/s of one).  Counts stay device-resident, so a round
+the chip, so independent chains overlap almost freely (measured: 6-7 matcher
+streams = 1.5x the pairs/s of one; keep the process at <= 8 active streams, the
+GPU's hardware queue count - a ninth costs > 10 %).  Counts stay device-resident, so a round
 has no host synchronisation.
 
 `ShardPlan` and `collate` are pure host/tensor logic and are covered by the
@@ -174,40 +175,41 @@ class FrameStreamPipeline:
                 self.ev_mdone[m].record(self.sm[m])
             self.have_halo = True
             return
-        # ---- multi-GPU: collate on the current stream as soon as the EXTRACTS are done; this round's
-        # matches keep running on their own streams underneath the all-gather
-        cur = torch.cuda.current_stream()
-        for st in set(self.se):
-            cur.wait_stream(st)
-        self.blocks[:B, 0, 0] = self.count[:B, 0].to(torch.float32)      # three fused copies, not 3 B
-        self.blocks[:B, 1:, :2] = self.xy[:B]
-        self.blocks[:B, 1:, 2:] = self.desc[:B]
-        self.shared_map = collate(self.blocks[:B], plan)
-        # boundary pair: my first frame vs the previous chunk's last frame
-        prev = plan.rank * B - 1                     # index inside the gathered round
-        if prev >= 0:
-            src = self.shared_map[prev]
-        elif self.have_halo:
-            src = self.prev_round_last
-        else:
-            src = None
-        if src is not None:
-            # slot B may still be read by the previous round's boundary match on sm[0]: same stream
-            # order protects it, the copy below is ordered after that match through the event
-            ev0 = torch.cuda.Event(); ev0.record(self.sm[0])
-            cur.wait_event(ev0)
-            self.xy[B].copy_(src[1:, :2]); self.desc[B].copy_(src[1:, 2:])
-            self.count[B, 0] = src[0, 0].to(torch.int32)
-            ev = torch.cuda.Event(); ev.record(cur)
-            self.sm[0].wait_event(ev)
-            with torch.cuda.stream(self.sm[0]):
-                self._match(0, B, 0, 0)
-        self.prev_round_last = self.shared_map[plan.world * B - 1].clone()
+        # ---- multi-GPU: collate as soon as the EXTRACTS are done; this round's matches keep running
+        # on their own streams underneath the all-gather.  The collation is issued on the last
+        # extractor stream, not on a stream of its own: the GPU serves 8 hardware queues, and a ninth
+        # active stream costs more than 10 % of the throughput (measured: 2 + 7 streams 490 frames/s
+        # against 552 for 2 + 6).
+        cst = self.se[-1]
+        for st in set(self.se) - {cst}:
+            cst.wait_stream(st)
+        with torch.cuda.stream(cst):
+            self.blocks[:B, 0, 0] = self.count[:B, 0].to(torch.float32)      # three fused copies, not 3 B
+            self.blocks[:B, 1:, :2] = self.xy[:B]
+            self.blocks[:B, 1:, 2:] = self.desc[:B]
+            self.shared_map = collate(self.blocks[:B], plan)
+            # boundary pair: my first frame vs the previous chunk's last frame
+            prev = plan.rank * B - 1                     # index inside the gathered round
+            if prev >= 0:
+                src = self.shared_map[prev]
+            elif self.have_halo:
+                src = self.prev_round_last
+            else:
+                src = None
+            if src is not None:
+                # slot B may still be read by the previous round's boundary match on sm[0]
+                ev0 = torch.cuda.Event(); ev0.record(self.sm[0])
+                cst.wait_event(ev0)
+                self.xy[B].copy_(src[1:, :2]); self.desc[B].copy_(src[1:, 2:])
+                self.count[B, 0] = src[0, 0].to(torch.int32)
+                ev = torch.cuda.Event(); ev.record(cst)
+                self.sm[0].wait_event(ev)
+                with torch.cuda.stream(self.sm[0]):
+                    self._match(0, B, 0, 0)
+            self.prev_round_last = self.shared_map[plan.world * B - 1].clone()
         self.have_halo = True
         for m in range(NM):
             self.ev_mdone[m].record(self.sm[m])
-        # the next round's packing overwrites `blocks`: it is issued on `cur` after this gather
-        # (stream order), and `shared_map` is a fresh tensor per round
 
     def results(self):
         """Host copy of the last round's matches: list of (ij [K,2], scores [K]) per local frame."""
