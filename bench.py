@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # the ROCm default, pinned: 8 streams on 4 hardware queues is the measured optimum
+    # (scripts/sweep_queues.sh: 5 queues -30 %, 3 queues -11 %); must be set before HIP initialises
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
     import torch
     import torch.distributed as dist
 
@@ -155,9 +158,10 @@ def main():
     LightGlueHIP = importlib.import_module("opencv-simpleslam_amd.lightglue").LightGlueHIP
     fs = importlib.import_module("opencv-simpleslam_amd.frame_shard")
 
-    # extractor / matcher instances, one HIP stream each.  The GPU serves 8 hardware queues: 1 + 7
-    # streams on one GPU (566 frames/s vs 552 for 2 + 6; a ninth stream drops it to 490); with
-    # N > 1 one queue is left to RCCL's own stream
+    # extractor / matcher instances, one HIP stream each.  Streams are multiplexed onto
+    # GPU_MAX_HW_QUEUES (= 4, pinned in main()) hardware queues: 1 + 7 streams on one GPU (566
+    # frames/s vs 552 for 2 + 6; a ninth stream drops it to 490); with N > 1 one stream fewer,
+    # RCCL brings its own
     N_EXT = int(os.environ.get("SSLAM_BENCH_NE", 1))
     N_MAT = int(os.environ.get("SSLAM_BENCH_NM", 7 if world == 1 else 6))
     main = torch.cuda.Stream()

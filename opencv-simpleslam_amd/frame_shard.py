@@ -20,8 +20,8 @@ matcher instances, each on its own HIP stream, chained by events
 (match(t-1, t) waits for extract(t-1) and extract(t)).  Each pair / frame is a
 chain of ~130 / ~35 short kernels that is bound by per-block latency, not by
 the chip, so independent chains overlap almost freely (measured: 6-7 matcher
-streams = 1.5x the pairs/s of one; keep the process at <= 8 active streams, the
-GPU's hardware queue count - a ninth costs > 10 %).  Counts stay device-resident, so a round
+streams = 1.5x the pairs/s of one; 8 streams on the runtime's 4 hardware queues is
+the measured optimum - a ninth stream unbalances the queues and costs > 10 %).  Counts stay device-resident, so a round
 has no host synchronisation.
 
 `ShardPlan` and `collate` are pure host/tensor logic and are covered by the
@@ -177,9 +177,9 @@ class FrameStreamPipeline:
             return
         # ---- multi-GPU: collate as soon as the EXTRACTS are done; this round's matches keep running
         # on their own streams underneath the all-gather.  The collation is issued on the last
-        # extractor stream, not on a stream of its own: the GPU serves 8 hardware queues, and a ninth
-        # active stream costs more than 10 % of the throughput (measured: 2 + 7 streams 490 frames/s
-        # against 552 for 2 + 6).
+        # extractor stream, not on a stream of its own: streams share 4 hardware queues round-robin,
+        # and one more active stream unbalances them (measured: 2 + 7 streams 490 frames/s against
+        # 552 for 2 + 6).
         cst = self.se[-1]
         for st in set(self.se) - {cst}:
             cst.wait_stream(st)
