@@ -222,3 +222,23 @@ def test_reference_default_size_4000_keypoints(W, LG):
     ij, ref = _compare(lg, sd, k0, d0, k1, d1, min_conf=0.7, check_state=False)
     assert len(ij) > 500
     lg.close()
+
+
+def test_c2_size_with_pruning_active(W, LG):
+    """2048 x 1900 keypoints with point pruning shrinking both token sets layer by layer (ragged,
+    changing row counts through every GEMM / attention launch of the split path): compaction
+    order, prune counters and match indices against the oracle."""
+    sd = W.random_lightglue_state_dict(4, match_gain=4.0, match_bias=-4.6, conf_bias=2.3)
+    lg = LG(sd, max_kpts=2048)
+    k0, d0, k1, d1 = lg_inputs.make_pair(2048, 1900, seed=8)
+    ij, ref = _compare(lg, sd, k0, d0, k1, d1, min_conf=0.0, check_state=False)
+    n0, n1 = ref["debug"]["x_out0"].shape[0], ref["debug"]["x_out1"].shape[0]
+    assert n0 < 2048 and n1 < 1900, "pruning did not trigger in the oracle - test is vacuous"
+    Kc = lg.capacity
+    ind = lg.debug_read(2, (2, Kc), np.int32)
+    np.testing.assert_array_equal(ind[0, :n0], ref["debug"]["ind0"].numpy())
+    np.testing.assert_array_equal(ind[1, :n1], ref["debug"]["ind1"].numpy())
+    pr = lg.debug_read(3, (2, Kc), np.int32)
+    np.testing.assert_array_equal(pr[0, :2048], ref["prune0"].numpy())
+    np.testing.assert_array_equal(pr[1, :1900], ref["prune1"].numpy())
+    lg.close()
