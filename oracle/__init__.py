@@ -21,4 +21,14 @@ Parity status (see DESIGN.md section "Oracle pinning"):
                              vectors for them.  These modules restate the
                              published algorithms and are anchored on the
                              reference's call sites.
+  * `oracle.ba_ref.solve_dense_lm` - PARITY UNPINNED (pyceres absent): Ceres'
+                             trust-region policy over one dense Jacobian; holds the
+                             property the reference's own BA test pins.
+  * `oracle.ransac_ref`    - PARITY UNPINNED (opencv_python==4.11.0.86 absent):
+                             OpenCV's classic findFundamentalMat path restated.
+  * `oracle.reproject_ref` - PINNED against the reference's own
+                             `slam/core/pnp_utils.py::reproject_and_match_2d3d` run
+                             under a cv2 stub (tests/golden/reproject_match.npz).
+  The product-side `slam/core/trajectory_eval.py::sim3_align` is pinned the same way
+  on the reference viewer's alignment (tests/golden/trajectory_alignment.npz).
 """
