@@ -1576,9 +1576,6 @@ void launch_attention_h(sslam_lightglue* g, hipStream_t s, SplitPtr Q, SplitPtr 
 }
 
 // one transformer layer (self + cross block) on the split-precision path
-#ifndef LG_TILE64
-#define LG_TILE64 0      // experiments: 1 ffn0, 2 cross projection, 4 qkv as 64x64 tiles (two workgroups per CU)
-#endif
 void lg_layer_h(sslam_lightglue* g, hipStream_t s, const LGLayerW& l, bool self_only) {
     const SplitPtr xs{g->xs_hi, g->xs_lo}, msgs{g->msgs_hi, g->msgs_lo};
     const SplitPtr hids{g->hids_hi, g->hids_lo}, none{nullptr, nullptr};
@@ -1589,11 +1586,7 @@ void lg_layer_h(sslam_lightglue* g, hipStream_t s, const LGLayerW& l, bool self_
                    const float* b2) {
         LinearArgsH a = linh(g, xs, msgs, D, D, 2 * D, w1, b1, 2 * D);      // [x | attention context]
         a.out = g->hid; a.ldo = 2 * D;
-#if LG_TILE64 & 1
-        launch_linear_h<64, 64, 1, 1, EPH_F32>(s, a);
-#else
         launch_linear_h<64, 128, 1, 2, EPH_F32>(s, a);
-#endif
         hipLaunchKernelGGL(lg_ln_gelu_h_kernel, dim3(tokblocks), dim3(256), 0, s, g->hid,
                            SplitOut{g->hids_hi, g->hids_lo}, lnw, lnb, g->ctrl, g->Kc);
         LinearArgsH c = linh(g, hids, none, 2 * D, 2 * D, 2 * D, w2, b2, D);
@@ -1604,11 +1597,7 @@ void lg_layer_h(sslam_lightglue* g, hipStream_t s, const LGLayerW& l, bool self_
         LinearArgsH a = linh(g, xs, none, D, D, D, l.wqkv, l.bqkv, 3 * D);
         a.q = SplitOut{g->qs_hi, g->qs_lo}; a.k = SplitOut{g->ks_hi, g->ks_lo}; a.vt = SplitOut{g->vts_hi, g->vts_lo};
         a.q_scale = sm_scale; a.k_scale = 1.0f;
-#if LG_TILE64 & 4
-        launch_linear_h<64, 64, 1, 1, EPH_QKV>(s, a);
-#else
         launch_linear_h<64, 192, 1, 3, EPH_QKV>(s, a);       // 768 / 192 = 4 column tiles -> 256 blocks, one round
-#endif
     }
     launch_attention_h(g, s, qs, ks, vts, 0);
     ffn(l.w1, l.b1, l.lnw, l.lnb, l.w2, l.b2);
@@ -1617,11 +1606,7 @@ void lg_layer_h(sslam_lightglue* g, hipStream_t s, const LGLayerW& l, bool self_
         LinearArgsH a = linh(g, xs, none, D, D, D, l.cqkv, l.cbqkv, 2 * D);
         a.q = SplitOut{g->qs_hi, g->qs_lo}; a.vt = SplitOut{g->vts_hi, g->vts_lo};
         a.q_scale = sqrtf(sm_scale);
-#if LG_TILE64 & 2
-        launch_linear_h<64, 64, 1, 1, EPH_CROSS>(s, a);
-#else
         launch_linear_h<64, 128, 1, 2, EPH_CROSS>(s, a);
-#endif
     }
     launch_attention_h(g, s, qs, qs, vts, 1);
     ffn(l.cw1, l.cb1, l.clnw, l.clnb, l.cw2, l.cb2);
