@@ -15,17 +15,31 @@ try:                                       # pragma: no cover - cv2 absent in th
 except Exception:                          # noqa: BLE001
     HAVE_CV2 = False
 
-    class KeyPoint:
-        """Duck type of cv2.KeyPoint(x, y, size)."""
-        __slots__ = ("pt", "size", "angle", "response", "octave", "class_id")
+    class _KeyPointDefaults:
+        __slots__ = ()
+        size = 1.0
+        angle = -1.0
+        response = 0.0
+        octave = 0
+        class_id = -1
+
+    class KeyPoint(_KeyPointDefaults):
+        """Duck type of cv2.KeyPoint(x, y, size).  Only `pt` is stored per instance unless another
+        field is set: the reference reads nothing else downstream, and a frame builds thousands."""
+        __slots__ = ("pt", "__dict__")
 
         def __init__(self, x=0.0, y=0.0, size=1.0, angle=-1.0, response=0.0, octave=0, class_id=-1):
             self.pt = (float(x), float(y))
-            self.size = float(size)
-            self.angle = float(angle)
-            self.response = float(response)
-            self.octave = int(octave)
-            self.class_id = int(class_id)
+            if size != 1.0:
+                self.size = float(size)
+            if angle != -1.0:
+                self.angle = float(angle)
+            if response != 0.0:
+                self.response = float(response)
+            if octave != 0:
+                self.octave = int(octave)
+            if class_id != -1:
+                self.class_id = int(class_id)
 
         def __repr__(self):
             return f"KeyPoint(pt={self.pt})"
@@ -42,3 +56,35 @@ except Exception:                          # noqa: BLE001
 
         def __repr__(self):
             return f"DMatch({self.queryIdx}->{self.trainIdx})"
+
+
+class KeyPointList(list):
+    """A plain list of keypoints that also remembers the [N,2] float32 array it was built from, so
+    `feature_matcher` does not have to walk 2 x N `.pt` tuples again on every call (the reference
+    rebuilds the tensors each time, features_utils.py:143-144).  Any list operation that builds a
+    new list (slicing, comprehension, +) drops back to a plain list and the array is rebuilt."""
+    __slots__ = ("xy",)
+
+
+def keypoints_from_xy(xy):
+    """[N,2] float array -> list of KeyPoint (size 1), the bulk form of the reference's
+    `[cv2.KeyPoint(x, y, 1) for x, y in kps]` (features_utils.py:62)."""
+    pts = xy.tolist()                       # python floats in one C pass
+    out = KeyPointList()
+    if HAVE_CV2:
+        out.extend(KeyPoint(x, y, 1) for x, y in pts)
+    else:
+        new = KeyPoint.__new__
+        for x, y in pts:
+            k = new(KeyPoint)
+            k.pt = (x, y)
+            out.append(k)
+    import numpy as _np
+    out.xy = _np.array(xy, dtype=_np.float32, copy=True).reshape(-1, 2)
+    out.xy.setflags(write=False)
+    return out
+
+
+def matches_from_ij(ij):
+    """[K,2] int array -> list of DMatch(queryIdx, trainIdx, 0, 0.0) (features_utils.py:80-83)."""
+    return [DMatch(i, j, 0, 0.0) for i, j in ij.tolist()]
