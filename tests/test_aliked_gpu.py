@@ -147,3 +147,20 @@ def test_bad_arguments(W, AL, native):
     with pytest.raises(native.NativeError, match="channels"):
         al.extract(np.zeros((64, 64, 2), np.uint8))
     al.close()
+
+
+def test_extraction_is_bit_reproducible_and_stateless(W, AL):
+    """The same frame gives bit-identical keypoints / descriptors / scores on repeated calls and
+    after other frames (different size, different keypoint count) went through the same instance:
+    the candidate collection uses atomics, the selection must not depend on their arrival order."""
+    sd = W.random_aliked_state_dict(0)
+    al = AL(sd, max_num_keypoints=2048, max_h=480, max_w=1241)
+    img = frames.structured_frame(4)
+    a = al.extract(img, 2048)
+    al.extract(frames.noise_frame(1, h=200, w=333), 512)
+    al.extract(frames.structured_frame(5), 1000)
+    for _ in range(3):
+        b = al.extract(img, 2048)
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+    al.close()
