@@ -242,3 +242,15 @@ def test_c2_size_with_pruning_active(W, LG):
     np.testing.assert_array_equal(pr[0, :2048], ref["prune0"].numpy())
     np.testing.assert_array_equal(pr[1, :1900], ref["prune1"].numpy())
     lg.close()
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106])
+def test_index_parity_over_seeds(W, LG, seed):
+    """Breadth: different random weights AND inputs at 1024 x 960 keypoints; the match-index arrays
+    must equal the oracle's every time (near-ties are where a non-fp32-grade path would flip)."""
+    sd = W.random_lightglue_state_dict(seed, match_gain=4.0, match_bias=3.0)
+    lg = LG(sd, max_kpts=1024)
+    k0, d0, k1, d1 = lg_inputs.make_pair(1024, 960, seed=seed)
+    ij, ref = _compare(lg, sd, k0, d0, k1, d1, min_conf=0.2, check_state=False)
+    assert len(ij) > 100
+    lg.close()
