@@ -286,7 +286,7 @@ def main():
             "what": "same pipeline on the 9x9-box low-pass noise translating 3 px/frame (SURVEY 8(d))",
             "matches_last_pair": int(s_info[-1, 0]), "lightglue_layers_executed": int(s_info[-1, 1]),
             "kpts_matched": [int(s_info[-1, 2]), int(s_info[-1, 3])]}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:        # the CPU leg is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
 
