@@ -18,7 +18,8 @@ Two drivers share that algorithm:
   Takes up to MAX_DEVICE_POSES optimised poses (local BA: window_size 6 / 10).
 * `solve_host` - the numpy loop below around the HIP residual/Jacobian kernel; used for
   global BA (hundreds of optimised poses: the dense Schur layout of the device path does
-  not fit) and as the independent restatement the device path is tested against.
+  not fit) and as the independent restatement the device path is tested against.  Its Schur
+  complement is accumulated sparsely, per pair of observations of one landmark.
 
 `solve` picks by problem size (override: SSLAM_BA_SOLVER=host|device).
 """
@@ -106,6 +107,7 @@ def _huber(s, delta):
 
 
 MAX_DEVICE_POSES = 12
+_PAIR_CHUNK = 1 << 18        # (a, b) observation pairs per accumulation chunk of the host Schur loop
 _TERMINATION = {0: "max iterations", 1: "gradient tolerance", 2: "parameter tolerance",
                 3: "function tolerance", 4: "trust region collapsed"}
 
@@ -162,6 +164,21 @@ def solve_host(prob: BAProblem, max_iters: int, huber_delta: float = 2.0, ctx=No
     has_pose = obs_slot >= 0
     oi = np.flatnonzero(has_pose)
 
+    # observations of optimised poses sorted by landmark, and every ordered pair (a, b) of them that
+    # shares a landmark: the Schur complement couples exactly those (sum_j k_j^2 pairs)
+    so = oi[np.argsort(prob.obs_point[oi], kind="stable")]
+    so_point = prob.obs_point[so].astype(np.int64)
+    so_slot = obs_slot[so]
+    if len(so):
+        k_of_point = np.bincount(so_point, minlength=Q)
+        start_of_point = np.concatenate([[0], np.cumsum(k_of_point)[:-1]])
+        k_a = k_of_point[so_point]
+        pair_a = np.repeat(np.arange(len(so)), k_a)
+        first = np.concatenate([[0], np.cumsum(k_a)[:-1]])
+        pair_b = np.repeat(start_of_point[so_point], k_a) + (np.arange(len(pair_a)) - np.repeat(first, k_a))
+    else:
+        pair_a = pair_b = np.zeros(0, np.int64)
+
     q, t, X = prob.q.copy(), prob.t.copy(), prob.X.copy()
 
     def cost_of(r):
@@ -201,12 +218,12 @@ def solve_host(prob: BAProblem, max_iters: int, huber_delta: float = 2.0, ctx=No
         np.add.at(gX, prob.obs_point, np.einsum("nia,ni->na", JXw, rw))
         U = np.zeros((Po, 6, 6))
         gP = np.zeros((Po, 6))
-        W = np.zeros((Po, Q, 6, 3))
         if Po:
             np.add.at(U, obs_slot[oi], np.einsum("nia,nib->nab", Jp[oi], Jp[oi]))
             np.add.at(gP, obs_slot[oi], np.einsum("nia,ni->na", Jp[oi], rw[oi]))
-            np.add.at(W, (obs_slot[oi], prob.obs_point[oi]),
-                      np.einsum("nia,nib->nab", Jp[oi], JXw[oi]))
+            # off-diagonal blocks W = Jp^T JX are kept PER OBSERVATION (sorted by landmark), never
+            # as a dense [pose, point] array: memory and work follow the sparsity of the problem
+            Wo = np.einsum("nia,nib->nab", Jp[so], JXw[so])       # [m,6,3]
 
         gmax = max(np.abs(gX).max(initial=0.0), np.abs(gP).max(initial=0.0))
         if gmax < 1e-10:
@@ -219,18 +236,26 @@ def solve_host(prob: BAProblem, max_iters: int, huber_delta: float = 2.0, ctx=No
         Vd = V + np.einsum("qa,ab->qab", dV, np.eye(3))
         Vinv = np.linalg.inv(Vd)
         if Po:
-            Y = W @ Vinv[None]                                   # [Po,Q,6,3]
-            S = -np.einsum("pjab,qjcb->paqc", Y, W).reshape(6 * Po, 6 * Po)
+            Yo = Wo @ Vinv[so_point]                              # [m,6,3]  Y = W V^-1
+            # S = U - sum_j sum_{a,b in obs(j)} Y_a W_b^T, accumulated pair by pair in chunks
+            S4 = np.zeros((Po, Po, 6, 6))
+            for c0 in range(0, len(pair_a), _PAIR_CHUNK):
+                pa, pb = pair_a[c0:c0 + _PAIR_CHUNK], pair_b[c0:c0 + _PAIR_CHUNK]
+                np.subtract.at(S4, (so_slot[pa], so_slot[pb]), np.einsum("nab,ncb->nac", Yo[pa], Wo[pb]))
             Ud = U + np.einsum("pa,ab->pab", dU, np.eye(6))
-            for k in range(Po):
-                S[6 * k:6 * k + 6, 6 * k:6 * k + 6] += Ud[k]
-            rhs = -(gP - np.einsum("pjab,jb->pa", Y, gX)).reshape(-1)
+            S4[np.arange(Po), np.arange(Po)] += Ud
+            S = S4.transpose(0, 2, 1, 3).reshape(6 * Po, 6 * Po)
+            YgX = np.zeros((Po, 6))
+            np.add.at(YgX, so_slot, np.einsum("nab,nb->na", Yo, gX[so_point]))
+            rhs = -(gP - YgX).reshape(-1)
             try:
                 c = np.linalg.cholesky(S)
                 dP = np.linalg.solve(c.T, np.linalg.solve(c, rhs)).reshape(Po, 6)
             except np.linalg.LinAlgError:
                 dP = np.linalg.lstsq(S, rhs, rcond=None)[0].reshape(Po, 6)
-            dX = np.einsum("jab,jb->ja", Vinv, -gX - np.einsum("pjab,pa->jb", W, dP))
+            WtdP = np.zeros((Q, 3))
+            np.add.at(WtdP, so_point, np.einsum("nab,na->nb", Wo, dP[so_slot]))
+            dX = np.einsum("jab,jb->ja", Vinv, -gX - WtdP)
         else:
             dP = np.zeros((0, 6))
             dX = np.einsum("jab,jb->ja", Vinv, -gX)

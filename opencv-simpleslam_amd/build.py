@@ -6,6 +6,7 @@ GPU box with the repo snapshot).  hipcc cross-compiles without a GPU.
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -32,14 +33,19 @@ def _hipcc() -> str:
     return exe
 
 
-def _needs_rebuild(out: Path, deps) -> bool:
-    if not out.exists():
-        return True
-    t = out.stat().st_mtime
-    return any(Path(d).stat().st_mtime > t for d in deps)
+def _digest(*parts) -> str:
+    h = hashlib.sha256()
+    for p in parts:
+        h.update(p if isinstance(p, bytes) else str(p).encode())
+        h.update(b"\0")
+    return h.hexdigest()
 
 
 def build_native(force: bool = False, verbose: bool = False) -> Path:
+    """Incremental build keyed on CONTENT, not mtimes: an object is reused only if its key file
+    holds the hash of (compiler, flags, extra flags, the source, every header).  So an experiment
+    build (SSLAM_EXTRA_HIPCC_FLAGS=-DSSLAM_DBG_NOMFMA=1 ...) can never survive into a default build,
+    a source edit always rebuilds, and a snapshot copy that scrambles mtimes rebuilds nothing."""
     hipcc = _hipcc()
     LIB_DIR.mkdir(exist_ok=True)
     obj_dir = LIB_DIR / "obj"
@@ -50,10 +56,14 @@ def build_native(force: bool = False, verbose: bool = False) -> Path:
         raise RuntimeError(f"no .hip sources under {CSRC}")
 
     extra = os.environ.get("SSLAM_EXTRA_HIPCC_FLAGS", "").split()     # experiments only (e.g. -DSSLAM_DBG=1)
+    base_key = _digest(hipcc, *HIPCC_FLAGS, "|", *extra, *[h.read_bytes() for h in headers])
 
     def compile_one(src: Path):
         obj = obj_dir / (src.stem + ".o")
-        if force or extra or _needs_rebuild(obj, [src, *headers]):
+        keyf = obj_dir / (src.stem + ".key")
+        key = _digest(base_key, src.read_bytes())
+        if force or not obj.exists() or not keyf.exists() or keyf.read_text().strip() != key:
+            keyf.unlink(missing_ok=True)
             cmd = [hipcc, *HIPCC_FLAGS, *extra, "-c", str(src), "-o", str(obj)]
             if verbose:
                 print(" ".join(cmd), flush=True)
@@ -62,12 +72,17 @@ def build_native(force: bool = False, verbose: bool = False) -> Path:
                 raise RuntimeError(f"hipcc failed for {src.name}:\n{res.stdout}\n{res.stderr}")
             if verbose and res.stderr.strip():
                 print(res.stderr)
-        return obj
+            keyf.write_text(key + "\n")
+        return obj, key
 
     with ThreadPoolExecutor(max_workers=min(4, len(sources))) as ex:
-        objs = list(ex.map(compile_one, sources))
+        built = list(ex.map(compile_one, sources))
+    objs = [o for o, _ in built]
 
-    if force or _needs_rebuild(LIB_PATH, objs):
+    lib_keyf = LIB_DIR / "libsslam_hip.key"
+    lib_key = _digest(*[k for _, k in built])
+    if force or not LIB_PATH.exists() or not lib_keyf.exists() or lib_keyf.read_text().strip() != lib_key:
+        lib_keyf.unlink(missing_ok=True)
         cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB_PATH),
                *map(str, objs)]
         if verbose:
@@ -75,6 +90,7 @@ def build_native(force: bool = False, verbose: bool = False) -> Path:
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError(f"link failed:\n{res.stdout}\n{res.stderr}")
+        lib_keyf.write_text(lib_key + "\n")
     return LIB_PATH
 
 

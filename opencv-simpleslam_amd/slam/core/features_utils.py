@@ -26,7 +26,7 @@ from typing import List
 
 import numpy as np
 
-from .types import DMatch, KeyPoint, HAVE_CV2, keypoints_from_xy, matches_from_ij
+from .types import DMatch, KeyPoint, HAVE_CV2, keypoints_from_xy, matches_from_ij, xy_from_keypoints
 from ... import _native, weights as _weights
 from ...aliked import AlikedHIP
 from ...lightglue import LightGlueHIP
@@ -84,15 +84,7 @@ def _convert_lg_kps_to_opencv(xy: np.ndarray) -> List[KeyPoint]:
 
 
 def _convert_opencv_to_lg_kps(kps) -> np.ndarray:
-    if len(kps) == 0:
-        return np.empty((0, 2), np.float32)
-    xy = getattr(kps, "xy", None)             # list built by feature_extractor and not modified since
-    if xy is not None and len(xy) == len(kps):
-        # cheap guard against in-place edits (same length): both ends must still agree
-        a, b = kps[0].pt, kps[-1].pt
-        if a[0] == xy[0, 0] and a[1] == xy[0, 1] and b[0] == xy[-1, 0] and b[1] == xy[-1, 1]:
-            return xy
-    return np.asarray([kp.pt for kp in kps], dtype=np.float32).reshape(-1, 2)
+    return xy_from_keypoints(kps)
 
 
 def _convert_lg_matches_to_opencv(ij: np.ndarray) -> List[DMatch]:

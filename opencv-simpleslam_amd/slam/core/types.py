@@ -58,31 +58,39 @@ except Exception:                          # noqa: BLE001
             return f"DMatch({self.queryIdx}->{self.trainIdx})"
 
 
-class KeyPointList(list):
-    """A plain list of keypoints that also remembers the [N,2] float32 array it was built from, so
-    `feature_matcher` does not have to walk 2 x N `.pt` tuples again on every call (the reference
-    rebuilds the tensors each time, features_utils.py:143-144).  Any list operation that builds a
-    new list (slicing, comprehension, +) drops back to a plain list and the array is rebuilt."""
-    __slots__ = ("xy",)
-
-
 def keypoints_from_xy(xy):
     """[N,2] float array -> list of KeyPoint (size 1), the bulk form of the reference's
     `[cv2.KeyPoint(x, y, 1) for x, y in kps]` (features_utils.py:62)."""
     pts = xy.tolist()                       # python floats in one C pass
-    out = KeyPointList()
     if HAVE_CV2:
-        out.extend(KeyPoint(x, y, 1) for x, y in pts)
-    else:
-        new = KeyPoint.__new__
-        for x, y in pts:
-            k = new(KeyPoint)
-            k.pt = (x, y)
-            out.append(k)
-    import numpy as _np
-    out.xy = _np.array(xy, dtype=_np.float32, copy=True).reshape(-1, 2)
-    out.xy.setflags(write=False)
+        return [KeyPoint(x, y, 1) for x, y in pts]
+    out = []
+    new = KeyPoint.__new__
+    for x, y in pts:
+        k = new(KeyPoint)
+        k.pt = (x, y)
+        out.append(k)
     return out
+
+
+_pt_of = None
+
+
+def xy_from_keypoints(kps):
+    """list of KeyPoint -> [N,2] float32, rebuilt from `.pt` on EVERY call like the reference does
+    (features_utils.py:65-77): the list is caller-owned and may have been edited in place
+    (kps[i] = ..., sort(), a new .pt), so nothing about it is cached.  One C-level pass
+    (np.fromiter over a chained attrgetter), 0.26 ms for 2048 keypoints."""
+    global _pt_of
+    import itertools
+    import operator
+    import numpy as _np
+    if _pt_of is None:
+        _pt_of = operator.attrgetter("pt")
+    n = len(kps)
+    if n == 0:
+        return _np.empty((0, 2), _np.float32)
+    return _np.fromiter(itertools.chain.from_iterable(map(_pt_of, kps)), _np.float32, 2 * n).reshape(n, 2)
 
 
 def matches_from_ij(ij):

@@ -192,7 +192,7 @@ def assemble_core_ba(points, kf_uv, opt_kf_idx, fix_kf_idx, max_points=None):
 #  Dense trust-region solve (reference: ba_utils.py:288-293 -> pyceres.solve)
 # --------------------------------------------------------------------------- #
 def solve_dense_lm(q, t, pose_const, X, intr, obs_pose, obs_point, obs_uv, max_iters,
-                   huber_delta=2.0, points_const=False):
+                   huber_delta=2.0, points_const=False, sparse=False):
     """What `pyceres.solve(opts, problem, summary)` does to the `_core_ba` problem, restated
     with ONE dense Jacobian and dense normal equations (no Schur elimination, no block
     structure) - small problems only.  Ceres 2.x defaults the reference leaves untouched
@@ -203,7 +203,10 @@ def solve_dense_lm(q, t, pose_const, X, intr, obs_pose, obs_point, obs_uv, max_i
     1e-6 / 1e-10 / 1e-8; HuberLoss(delta) applied as sqrt(rho') scaling (corrector with
     rho'' <= 0); EigenQuaternionManifold on every quaternion.  PARITY UNPINNED (pyceres
     absent): Ceres' exact iterates depend on its linear solver and are not reproduced, the
-    policy and the fixed point are.  Returns (q, t, X, info)."""
+    policy and the fixed point are.  `sparse=True` stores the SAME single Jacobian in
+    scipy.sparse CSR form and factorises the full normal equations with SuperLU (still no Schur
+    elimination): that is what lets the C3-size problem (~48 k rows x 14 k columns) be checked
+    against this formulation.  Returns (q, t, X, info)."""
     q, t, X = np.array(q, np.float64), np.array(t, np.float64), np.array(X, np.float64)
     pose_const = np.asarray(pose_const, bool)
     opt_rows = np.flatnonzero(~pose_const)
@@ -226,24 +229,46 @@ def solve_dense_lm(q, t, pose_const, X, intr, obs_pose, obs_point, obs_uv, max_i
         info["iterations"] = it + 1
         r, Jq, Jt, JX = reproj_residual_jacobian(obs_pose, obs_point, obs_uv, q, t, X, intr)
         sw = np.sqrt(huber_rho(np.sum(r * r, axis=1), huber_delta)[1])
-        J = np.zeros((2 * n, dim))
         pj = quat_plus_jacobian(q)
-        for i in range(n):
-            s = slot[obs_pose[i]]
-            if s >= 0:
-                J[2 * i:2 * i + 2, 6 * s:6 * s + 3] = sw[i] * (Jq[i] @ pj[obs_pose[i]])
-                J[2 * i:2 * i + 2, 6 * s + 3:6 * s + 6] = sw[i] * Jt[i]
+        if sparse:
+            import scipy.sparse as sp
+            from scipy.sparse.linalg import spsolve
+            rows_, cols_, vals_ = [], [], []
+            s_of = slot[np.asarray(obs_pose)]
+            op = np.flatnonzero(s_of >= 0)
+            Jp = np.concatenate([Jq[op] @ pj[np.asarray(obs_pose)[op]], Jt[op]], axis=2) * sw[op, None, None]
+            rr = (2 * op[:, None, None] + np.arange(2)[None, :, None]) + np.zeros((1, 1, 6), int)
+            cc = (6 * s_of[op][:, None, None] + np.arange(6)[None, None, :]) + np.zeros((1, 2, 1), int)
+            rows_.append(rr.ravel()); cols_.append(cc.ravel()); vals_.append(Jp.ravel())
             if not points_const:
-                c = 6 * Po + 3 * obs_point[i]
-                J[2 * i:2 * i + 2, c:c + 3] = sw[i] * JX[i]
+                JXs = JX * sw[:, None, None]
+                rr = (2 * np.arange(n)[:, None, None] + np.arange(2)[None, :, None]) + np.zeros((1, 1, 3), int)
+                cc = (6 * Po + 3 * np.asarray(obs_point)[:, None, None] + np.arange(3)[None, None, :]) + np.zeros((1, 2, 1), int)
+                rows_.append(rr.ravel()); cols_.append(cc.ravel()); vals_.append(JXs.ravel())
+            J = sp.csr_matrix((np.concatenate(vals_), (np.concatenate(rows_), np.concatenate(cols_))),
+                              shape=(2 * n, dim))
+        else:
+            J = np.zeros((2 * n, dim))
+            for i in range(n):
+                s = slot[obs_pose[i]]
+                if s >= 0:
+                    J[2 * i:2 * i + 2, 6 * s:6 * s + 3] = sw[i] * (Jq[i] @ pj[obs_pose[i]])
+                    J[2 * i:2 * i + 2, 6 * s + 3:6 * s + 6] = sw[i] * Jt[i]
+                if not points_const:
+                    c = 6 * Po + 3 * obs_point[i]
+                    J[2 * i:2 * i + 2, c:c + 3] = sw[i] * JX[i]
         f = (r * sw[:, None]).reshape(-1)
         g = J.T @ f
         if np.max(np.abs(g), initial=0.0) < 1e-10:
             info["termination"] = "gradient tolerance"
             break
         H = J.T @ J
-        D = np.clip(np.diag(H), 1e-6, 1e32) / radius
-        d = np.linalg.solve(H + np.diag(D), -g)
+        if sparse:
+            D = np.clip(H.diagonal(), 1e-6, 1e32) / radius
+            d = spsolve((H + sp.diags(D)).tocsc(), -g)
+        else:
+            D = np.clip(np.diag(H), 1e-6, 1e32) / radius
+            d = np.linalg.solve(H + np.diag(D), -g)
         Jd = J @ d
         model_change = -float(Jd @ (f + 0.5 * Jd))
         x_norm = np.sqrt(np.sum(X * X) + np.sum(q[opt_rows] ** 2) + np.sum(t[opt_rows] ** 2))

@@ -12,3 +12,4 @@ for r in csv.DictReader(open(f)):
 PY
   cd $GRAFT_REPO_ROOT
 done
+SSLAM_EXTRA_HIPCC_FLAGS="" python opencv-simpleslam_amd/build.py --force > /dev/null   # never leave an experiment build behind

@@ -1,6 +1,7 @@
-"""GPU parity of the device-resident LM (csrc/ba_lm.hip, `sslam_ba_solve_host`):
-against the dense-Jacobian oracle (oracle/ba_ref.solve_dense_lm) on small scenes, against the
-host Schur loop (ba_solver.solve_host) at the C3 size, plus determinism and edge cases.
+"""GPU parity of the device-resident LM (csrc/ba_lm.hip, `sslam_ba_solve_host`) and of the host
+Schur loop used for global BA (ba_solver.solve_host): both against the single-Jacobian oracle
+(oracle/ba_ref.solve_dense_lm; its scipy.sparse form at the C3 size and for > 12 free poses),
+plus determinism and edge cases.
 fp64 throughout; tolerance 1e-8 relative on parameters (summation order differs), identical
 iteration / step counts and termination reason."""
 import copy
@@ -57,24 +58,88 @@ def test_device_lm_matches_dense_oracle(points_const):
         np.testing.assert_array_equal(dev.X, prob.X)
 
 
-def test_device_lm_matches_host_schur_loop_at_c3_size_and_is_deterministic():
-    """SURVEY 8(d) C3 scene (10 opt + 5 fixed KFs, 5000 points, ~30 k observations)."""
+def _oracle(prob, iters, sparse=True):
+    return ba_ref.solve_dense_lm(prob.q, prob.t, prob.pose_const, prob.X, prob.intr, prob.obs_pose,
+                                 prob.obs_point, prob.obs_uv, iters, 2.0, False, sparse=sparse)
+
+
+def test_device_lm_matches_oracle_at_c3_size_and_is_deterministic():
+    """SURVEY 8(d) C3 scene (10 opt + 5 fixed KFs, 5000 points, ~30 k observations): the device
+    LM against the single-Jacobian oracle (no Schur, SuperLU on the full normal equations), and
+    the host Schur loop against the same oracle."""
     S = load_pkg("ba_solver")
     bau = load_pkg("slam.core.ba_utils")
     wmap, kfs, K = ba_scenes.scaled_scene()
     prob, _, _ = bau.snapshot_problem(wmap, K, kfs, list(range(5, 15)), list(range(0, 5)), 5000)
     assert len(prob.obs_pose) > 20000
     host, dev, dev2 = _clone(prob), _clone(prob), _clone(prob)
-    sh = S.solve_host(host, 12, 2.0)
+    q, t, X, info = _oracle(prob, 12)
     sd = S.solve_device(dev, 12, 2.0)
     sd2 = S.solve_device(dev2, 12, 2.0)
-    assert (sd.iterations, sd.successful_steps, sd.termination) == (sh.iterations, sh.successful_steps, sh.termination)
-    np.testing.assert_allclose(sd.final_cost, sh.final_cost, rtol=1e-9)
-    _close(dev, host, 1e-7)
+    sh = S.solve_host(host, 12, 2.0)
+    for summ, got in ((sd, dev), (sh, host)):
+        assert (summ.iterations, summ.successful_steps, summ.termination) == (
+            info["iterations"], info["successful_steps"], info["termination"])
+        np.testing.assert_allclose(summ.initial_cost, info["initial_cost"], rtol=1e-12)
+        np.testing.assert_allclose(summ.final_cost, info["final_cost"], rtol=1e-8)
+        np.testing.assert_allclose(got.q, q, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(got.t, t, rtol=1e-7, atol=1e-7)
+        np.testing.assert_allclose(got.X, X, rtol=1e-6, atol=1e-6)
+    assert sd.final_cost < 0.2 * sd.initial_cost
     # order-fixed reductions: bit-identical from run to run
     assert sd2.final_cost == sd.final_cost
     np.testing.assert_array_equal(dev.q, dev2.q)
     np.testing.assert_array_equal(dev.X, dev2.X)
+
+
+def test_host_schur_loop_with_more_than_12_free_poses_matches_oracle():
+    """Global-BA shape: 29 free poses (> MAX_DEVICE_POSES, so `solve` takes the host loop), one
+    gauge keyframe.  The loop accumulates the Schur complement per pair of observations of a
+    landmark; the oracle never forms a Schur complement."""
+    S = load_pkg("ba_solver")
+    bau = load_pkg("slam.core.ba_utils")
+    wmap, kfs, K = ba_scenes.scaled_scene(n_kf=30, n_points=1500)
+    prob, _, _ = bau.snapshot_problem(wmap, K, kfs, list(range(30)), [0], 30000)
+    assert int(np.count_nonzero(~prob.pose_const)) == 29 > S.MAX_DEVICE_POSES
+    got = _clone(prob)
+    summ = S.solve(got, 10, 2.0)
+    q, t, X, info = _oracle(prob, 10)
+    assert (summ.iterations, summ.successful_steps, summ.termination) == (
+        info["iterations"], info["successful_steps"], info["termination"])
+    np.testing.assert_allclose(summ.final_cost, info["final_cost"], rtol=1e-8)
+    assert summ.final_cost < 0.2 * summ.initial_cost
+    np.testing.assert_allclose(got.q, q, rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(got.t, t, rtol=1e-7, atol=1e-7)
+    # a landmark seen twice under a small baseline is weakly determined along its ray
+    np.testing.assert_allclose(got.X, X, rtol=1e-4, atol=1e-3)
+
+
+def test_global_bundle_adjustment_through_the_driver_name():
+    """`global_bundle_adjustment` as main_revamped.py:81 imports it (reference ba_utils.py:170-214):
+    >= 13 keyframes, KF 0 fixed, in-place mutation contract, RMSE strictly decreases (the
+    property the reference's own BA test pins, tests/test_ba_utils_T_c_w.py:264-314)."""
+    bau = load_pkg("slam.core.ba_utils")
+    wmap, kfs, K = ba_scenes.scaled_scene(n_kf=16, n_points=800)
+    pos_ids = {pid: id(mp.position) for pid, mp in wmap.points.items()}
+    pose0 = kfs[0].pose.copy()
+    old_pose_objs = [kf.pose for kf in kfs]
+    before = ba_scenes.reproj_rmse(wmap, kfs, K)
+    bau.global_bundle_adjustment(wmap, K, kfs, max_iters=15)
+    after = ba_scenes.reproj_rmse(wmap, kfs, K)
+    assert after < 0.5 * before and after < 1.6          # 1 px pixel noise
+    np.testing.assert_array_equal(kfs[0].pose, pose0)    # gauge keyframe untouched (fix_first)
+    for pid, mp in wmap.points.items():                  # landmarks mutated in place
+        assert id(mp.position) == pos_ids[pid]
+    for k in range(1, len(kfs)):                         # poses replaced + trajectory slot overwritten
+        assert kfs[k].pose is not old_pose_objs[k]
+        np.testing.assert_array_equal(wmap.poses[k], kfs[k].pose)
+    # fix_first=False leaves the gauge free and must still run (Ceres would, too)
+    wmap2, kfs2, _ = ba_scenes.scaled_scene(n_kf=14, n_points=400)
+    b2 = ba_scenes.reproj_rmse(wmap2, kfs2, K)
+    bau.global_bundle_adjustment(wmap2, K, kfs2, fix_first=False, max_iters=5)
+    assert ba_scenes.reproj_rmse(wmap2, kfs2, K) < b2
+    # fewer than two keyframes: warning + return
+    bau.global_bundle_adjustment(wmap2, K, kfs2[:1])
 
 
 def test_device_lm_perfect_scene_stops_at_once_and_zero_iters():

@@ -65,3 +65,32 @@ def test_umeyama_recovers_any_similarity(seed, s):
     np.testing.assert_allclose(s2, s, rtol=1e-8)
     np.testing.assert_allclose(R2, R, atol=1e-8)
     assert T.ate_rmse(gt, est) < 1e-7 * (1 + s * 20)
+
+
+@settings(max_examples=100, deadline=None)
+@given(n=st.integers(1, 300), seed=st.integers(0, 10000), op=st.sampled_from(["setitem", "pt", "sort", "swap", "pop", "none"]))
+def test_keypoint_coordinates_are_rebuilt_after_any_in_place_edit(n, seed, op):
+    """The keypoint list handed back by feature_extractor is caller-owned; feature_matcher must see
+    whatever is in it NOW (the reference rebuilds the tensor from .pt on every call,
+    features_utils.py:65-77, :143-144)."""
+    T = load_pkg("slam.core.types")
+    rng = np.random.default_rng(seed)
+    xy = (rng.random((n, 2)) * 1000).astype(np.float32)
+    kps = T.keypoints_from_xy(xy)
+    np.testing.assert_array_equal(T.xy_from_keypoints(kps), xy)
+    i = int(rng.integers(0, n))
+    if op == "setitem":
+        kps[i] = T.KeyPoint(1.5, -2.5, 1)
+    elif op == "pt" and not T.HAVE_CV2:
+        kps[i].pt = (7.25, 8.5)
+    elif op == "sort":
+        kps.sort(key=lambda k: k.pt[1])
+    elif op == "swap":
+        j = int(rng.integers(0, n))
+        kps[i], kps[j] = kps[j], kps[i]
+    elif op == "pop":
+        kps.pop(i)
+    want = np.array([k.pt for k in kps], np.float32).reshape(-1, 2)
+    got = T.xy_from_keypoints(kps)
+    assert got.dtype == np.float32 and got.shape == want.shape
+    np.testing.assert_array_equal(got, want)
