@@ -159,8 +159,13 @@ int sslam_aliked_debug_read(sslam_aliked* al, int which, void* dst, size_t bytes
  * (host pointer, copied).  max_kpts bounds M and N of every later call. */
 int sslam_lightglue_create(sslam_ctx* ctx, const float* weights, size_t n_floats, int max_kpts,
                            sslam_lightglue** out);
+/* Same, with workspace for up to max_pairs (1..16) pairs per sslam_lightglue_match_batch_dev call.
+ * sslam_lightglue_create == max_pairs 1.  Workspace is ~60 MB per pair at max_kpts 2048. */
+int sslam_lightglue_create_batched(sslam_ctx* ctx, const float* weights, size_t n_floats, int max_kpts,
+                                   int max_pairs, sslam_lightglue** out);
 int sslam_lightglue_destroy(sslam_lightglue* lg);
 int sslam_lightglue_capacity(sslam_lightglue* lg, int* kc_out);
+int sslam_lightglue_batch_capacity(sslam_lightglue* lg, int* pairs_out);
 /* Upstream conf: depth_confidence 0.95, width_confidence 0.99, filter_threshold
  * 0.1; prune_min_kpts = pruning_keypoint_thresholds[device] (-1 on CPU: pruning
  * evaluated after every layer; pass a value >= max_kpts to disable). */
@@ -188,12 +193,26 @@ int sslam_lightglue_match_dev(sslam_lightglue* lg, const float* xy0, const float
                               const float* xy1, const float* desc1, int N, const int32_t* m_dev,
                               const int32_t* n_dev, float min_conf, int32_t* ij_out, float* score_out,
                               int32_t* info_out);
+/* Batch variant: n_pairs independent pairs in ONE enqueue (every launch covers all pairs, so the chip
+ * is filled without splitting the keys of a pair and the launch sequence is paid once per batch).
+ * This is what a frame stream calls: the reference matches one (t-1, t) pair per frame
+ * (slam/monocular/main_revamped.py:321-328); consecutive pairs are independent.
+ * Host arrays of n_pairs entries: xy0[p] / desc0[p] / xy1[p] / desc1[p] device pointers, M[p] / N[p]
+ * row bounds, m_dev[p] / n_dev[p] device counts (the arrays or single entries may be NULL).
+ * Outputs (device): pair p writes ij_out + p*out_stride*2, score_out + p*out_stride, info_out + 4p;
+ * out_stride >= min(M[p], N[p]).  Each pair's result is the one sslam_lightglue_match_dev gives. */
+int sslam_lightglue_match_batch_dev(sslam_lightglue* lg, int n_pairs, const float* const* xy0,
+                                    const float* const* desc0, const int32_t* const* m_dev, const int32_t* M,
+                                    const float* const* xy1, const float* const* desc1,
+                                    const int32_t* const* n_dev, const int32_t* N, float min_conf,
+                                    int32_t* ij_out, float* score_out, int32_t* info_out, int out_stride);
 /* Measurement hook (bench.py): bracket each attention launch - the dominant kernel - with HIP
  * events on the context stream; _read synchronises and returns their summed duration and count. */
 int sslam_lightglue_profile(sslam_lightglue* lg, int enable);
 int sslam_lightglue_profile_read(sslam_lightglue* lg, float* total_ms_out, int32_t* launches_out);
 /* Test hooks: limit the executed layers; copy an internal buffer to the host. */
 int sslam_lightglue_debug_layers(sslam_lightglue* lg, int layers, int self_only);
+int sslam_lightglue_debug_key_split(sslam_lightglue* lg, int ks);
 int sslam_lightglue_debug_read(sslam_lightglue* lg, int which, void* dst, size_t bytes);
 
 #ifdef __cplusplus

@@ -54,8 +54,12 @@ def _signatures():
         "sslam_aliked_extract_dev": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
         "sslam_aliked_debug_read": (i32, [vp, i32, vp, sz]),
         "sslam_lightglue_create": (i32, [vp, vp, sz, i32, c_void_pp]),
+        "sslam_lightglue_create_batched": (i32, [vp, vp, sz, i32, i32, c_void_pp]),
         "sslam_lightglue_destroy": (i32, [vp]),
         "sslam_lightglue_capacity": (i32, [vp, c_int_p]),
+        "sslam_lightglue_batch_capacity": (i32, [vp, c_int_p]),
+        "sslam_lightglue_match_batch_dev": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, i32]),
+        "sslam_lightglue_debug_key_split": (i32, [vp, i32]),
         "sslam_lightglue_set_conf": (i32, [vp, f32, f32, f32, i32]),
         "sslam_lightglue_match_host": (i32, [vp, vp, vp, i32, vp, vp, i32, f32, vp, vp, c_int_p, c_int_p]),
         "sslam_lightglue_match_dev": (i32, [vp, vp, vp, i32, vp, vp, i32, vp, vp, f32, vp, vp, vp]),

@@ -8,16 +8,21 @@
 // v_mfma_f32_32x32x2_f32, so results differ from a torch-CPU fp32 run only by
 // summation order; the roofline is the fp32 MFMA peak (157.3 TFLOP/s).
 //
-// Data layout in HBM (per instance, sized for max_kpts = Kc rows per image):
-//   x      [2][Kc][256]   token states, image-major (image 1 at row Kc)
-//   enc    [2][Kc][32]    cos / sin of the Fourier positional projection
-//   q,k,v  [2][4][Kc][64] head-major, rotary already applied to q,k
-//   msg    [2][Kc][256]   attention context / message
-//   hid    [2][Kc][512]   FFN hidden
-//   sim    [Kc][Kc]       final similarity
+// BATCH.  One enqueue processes up to NB pairs at once (`sslam_lightglue_match_batch_dev`): pair p
+// owns images 2p (query side) and 2p+1; every token buffer is image-major over NI = 2 NB images and
+// every launch covers all pairs, so a launch fills the 256 CUs without splitting the keys of one
+// pair and the ~170 launches of a forward are paid once per batch, not once per pair.
+//
+// Data layout in HBM (per instance, sized for max_kpts = Kc rows per image, NI images):
+//   x      [NI][Kc][256]   token states, image-major (image i at row i*Kc)
+//   enc    [NI][Kc][32]    cos / sin of the Fourier positional projection
+//   q,k,v  [NI][4][Kc][64] head-major, rotary already applied to q,k
+//   msg    [NI][Kc][256]   attention context / message
+//   hid    [NI][Kc][512]   FFN hidden
+//   sim    [NB][Kc][Kc]    final similarity
 // Control flow that the reference decides on the host per layer (early stop,
-// point pruning) lives in a device-side control block `LGCtrl`; every kernel
-// reads its row counts from it, so one pair is a fixed launch sequence with no
+// point pruning) lives in a device-side control block `LGCtrl` PER PAIR; every kernel
+// reads its row counts from it, so a batch is a fixed launch sequence with no
 // host round trip (graph-capturable).
 #include <type_traits>
 #include "common.hpp"
@@ -61,28 +66,49 @@ struct LGCtrl {
     int n_matches;   // K
     int pad[6];
 };
+constexpr int MAX_PAIRS = 16;    // batch capacity bound (kernel-argument tables are sized for it)
+
+__device__ __forceinline__ LGCtrl& ctrl_of(LGCtrl* c, int img) { return c[img >> 1]; }
+__device__ __forceinline__ const LGCtrl& ctrl_of(const LGCtrl* c, int img) { return c[img >> 1]; }
+__device__ __forceinline__ int n_of(const LGCtrl* c, int img) { return c[img >> 1].n[img & 1]; }
+
+// Per-image input sources of one call (host-built table passed by value): where the keypoints /
+// descriptors of image i live, the host-side bound on their count and, optionally, the device
+// count written by the extractor.
+struct StageSrc {
+    const float* xy[2 * MAX_PAIRS];
+    const float* desc[2 * MAX_PAIRS];
+    const int32_t* cnt[2 * MAX_PAIRS];
+    int bound[2 * MAX_PAIRS];
+};
 
 // ------------------------------------------------------------------------ //
 //  0. prepare: bbox-normalise keypoints, rotary tables, control block
 //     (lightglue.py normalize_keypoints(size=None), LearnableFourierPositionalEncoding)
 // ------------------------------------------------------------------------ //
 __global__ __launch_bounds__(1024) void lg_prepare_kernel(
-    const float* __restrict__ xy0, const float* __restrict__ xy1, int M, int N,
-    const int32_t* __restrict__ m_dev, const int32_t* __restrict__ n_dev, int Kc,
-    float* __restrict__ bbox /*[2][4]: shift x, shift y, scale, -*/, int* __restrict__ ind,
+    StageSrc src, int Kc, float* __restrict__ in_xy /*[NI][Kc][2]*/, float* __restrict__ in_desc /*[NI][Kc][128]*/,
+    float* __restrict__ bbox /*[NI][4]: shift x, shift y, scale, -*/, int* __restrict__ ind,
     int* __restrict__ prune, LGCtrl* __restrict__ ctrl) {
-    const int img = blockIdx.x;
-    const float* xy = img ? xy1 : xy0;
+    const int img = blockIdx.x, side = img & 1;
+    const float* xy = src.xy[img];
     // device-resident counts (written by the extractor) are clamped to the host-side bound
-    if (m_dev) M = min(max(m_dev[0], 0), M);
-    if (n_dev) N = min(max(n_dev[0], 0), N);
-    const int n = img ? N : M;
+    int n = src.bound[img], n_other = src.bound[img ^ 1];
+    if (src.cnt[img]) n = min(max(src.cnt[img][0], 0), n);
+    if (src.cnt[img ^ 1]) n_other = min(max(src.cnt[img ^ 1][0], 0), n_other);
     __shared__ float red[4][32];
     float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+    float* dxy = in_xy + (size_t)img * Kc * 2;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const float x = xy[2 * i], y = xy[2 * i + 1];
+        dxy[2 * i] = x; dxy[2 * i + 1] = y;
         mnx = fminf(mnx, x); mxx = fmaxf(mxx, x);
         mny = fminf(mny, y); mxy = fmaxf(mxy, y);
+    }
+    {   // descriptors into the staging rows the input projection reads (16-byte pieces)
+        const float4* sd = reinterpret_cast<const float4*>(src.desc[img]);
+        float4* dd = reinterpret_cast<float4*>(in_desc + (size_t)img * Kc * DIN);
+        for (int i = threadIdx.x; i < n * (DIN / 4); i += blockDim.x) dd[i] = sd[i];
     }
     for (int o = 32; o > 0; o >>= 1) {
         mnx = fminf(mnx, __shfl_xor(mnx, o)); mxx = fmaxf(mxx, __shfl_xor(mxx, o));
@@ -104,22 +130,23 @@ __global__ __launch_bounds__(1024) void lg_prepare_kernel(
         prune[img * Kc + i] = 1;
     }
     if (threadIdx.x == 0) {
+        LGCtrl& c = ctrl_of(ctrl, img);
         bbox[img * 4 + 0] = sx / 2.0f; bbox[img * 4 + 1] = sy / 2.0f; bbox[img * 4 + 2] = fmaxf(sx, sy) / 2.0f;
-        ctrl->n[img] = n; ctrl->n_prev[img] = n; ctrl->n_orig[img] = n;
-        if (img == 0) { ctrl->stop = (M == 0 || N == 0) ? 2 : 0; ctrl->stop_layer = NL - 1;
-                        ctrl->unconf = 0; ctrl->n_matches = 0; }
+        c.n[side] = n; c.n_prev[side] = n; c.n_orig[side] = n;
+        if (side == 0) { c.stop = (n == 0 || n_other == 0) ? 2 : 0; c.stop_layer = NL - 1;
+                         c.unconf = 0; c.n_matches = 0; }
     }
 }
 
 // rotary tables: cos / sin of Wr . normalised keypoint (one thread per (token, frequency))
-__global__ __launch_bounds__(256) void lg_posenc_kernel(const float* __restrict__ xy0, const float* __restrict__ xy1,
+__global__ __launch_bounds__(256) void lg_posenc_kernel(const float* __restrict__ in_xy,
                                                         const float* __restrict__ bbox, const float* __restrict__ Wr,
                                                         float* __restrict__ enc_cos, float* __restrict__ enc_sin,
-                                                        int Kc, const LGCtrl* __restrict__ ctrl) {
+                                                        int Kc, int NI, const LGCtrl* __restrict__ ctrl) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int img = i / (Kc * ENC), rem = i % (Kc * ENC), tok = rem / ENC, f = rem % ENC;
-    if (img > 1 || tok >= ctrl->n[img]) return;
-    const float* xy = img ? xy1 : xy0;
+    if (img >= NI || tok >= n_of(ctrl, img)) return;
+    const float* xy = in_xy + (size_t)img * Kc * 2;
     const float kx = (xy[2 * tok] - bbox[img * 4 + 0]) / bbox[img * 4 + 2];
     const float ky = (xy[2 * tok + 1] - bbox[img * 4 + 1]) / bbox[img * 4 + 2];
     const float proj = kx * Wr[2 * f] + ky * Wr[2 * f + 1];
@@ -137,7 +164,7 @@ __device__ __forceinline__ RowDom row_domain(const LGCtrl* ctrl, int Kc) {
     RowDom d;
     d.img = blockIdx.y / nb;
     d.row0 = (blockIdx.y % nb) * BM;
-    d.n = ctrl->n[d.img];
+    d.n = n_of(ctrl, d.img);
     return d;
 }
 
@@ -168,16 +195,17 @@ struct LinearArgs {
     float* out; int ldo;  // PLAIN / RESID destination (per-image stride Kc*ldo); RESID adds `out` itself
     float* q; float* k; float* v;           // QKV destinations [2][4][Kc][64]
     const float* enc_cos; const float* enc_sin;
-    const LGCtrl* ctrl; int Kc;
+    const LGCtrl* ctrl; int Kc; int NI;
     int ignore_stop;      // final_proj runs after the stop
 };
 
 template <int BM, int BN, int TM, int TN, int EPI>
 __global__ __launch_bounds__(256) void lg_linear_kernel(LinearArgs p) {
     __shared__ GemmSmem<BM, BN> sm;
-    if (p.ctrl->stop && !p.ignore_stop) return;
-    if (p.ctrl->stop == 2) return;
     const RowDom rd = row_domain<BM>(p.ctrl, p.Kc);
+    const LGCtrl& pc = ctrl_of(p.ctrl, rd.img);
+    if (pc.stop && !p.ignore_stop) return;
+    if (pc.stop == 2) return;
     if (rd.row0 >= rd.n) return;
     const int col0 = blockIdx.x * BN;
     const size_t ibase = (size_t)rd.img * p.Kc;
@@ -185,8 +213,8 @@ __global__ __launch_bounds__(256) void lg_linear_kernel(LinearArgs p) {
     const float* W = p.W;
     const float* bias = p.bias;
     if (p.by_stop_layer) {
-        W += (size_t)p.ctrl->stop_layer * p.w_layer_stride;
-        bias += (size_t)p.ctrl->stop_layer * p.b_layer_stride;
+        W += (size_t)pc.stop_layer * p.w_layer_stride;
+        bias += (size_t)pc.stop_layer * p.b_layer_stride;
     }
     f32x16 acc[TM][TN];
     gemm_mainloop<BM, BN, TM, TN>(ga, W, p.K, p.K, rd.row0, p.Kc, col0, p.N, sm, acc);
@@ -237,12 +265,11 @@ __global__ __launch_bounds__(256) void lg_linear_kernel(LinearArgs p) {
 __global__ __launch_bounds__(256) void lg_ln_gelu_kernel(float* __restrict__ hid,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta,
-                                                         const LGCtrl* __restrict__ ctrl, int Kc) {
-    if (ctrl->stop) return;
+                                                         const LGCtrl* __restrict__ ctrl, int Kc, int NI) {
     const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);     // global wave = row over both images
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);     // global wave = row over all images
     const int img = gw / Kc, row = gw % Kc;
-    if (img > 1 || row >= ctrl->n[img]) return;
+    if (img >= NI || ctrl_of(ctrl, img).stop || row >= n_of(ctrl, img)) return;
     float* p = hid + ((size_t)img * Kc + row) * 512;
     float4 a = *reinterpret_cast<float4*>(p + lane * 4);
     float4 b = *reinterpret_cast<float4*>(p + 256 + lane * 4);
@@ -282,18 +309,19 @@ struct __attribute__((aligned(16))) AttnSmem {
 };
 
 struct AttnArgs {
-    const float* Q; const float* K; const float* V;   // [2][4][Kc][64]
-    int cross;                                        // keys/values come from the other image
-    float* o_part; float* m_part; float* l_part;      // [KS][2][4][Kc][64] / [KS][2][4][Kc]
-    int KS; int Kc; const LGCtrl* ctrl;
+    const float* Q; const float* K; const float* V;   // [NI][4][Kc][64]
+    int cross;                                        // keys/values come from the other image of the pair
+    float* o_part; float* m_part; float* l_part;      // [KS][NIc][4][Kc][64] / [KS][NIc][4][Kc]
+    int KS; int Kc; int NIc;                          // NIc: image capacity of the instance (partial strides)
+    const LGCtrl* ctrl;
 };
 
 __global__ __launch_bounds__(256) void lg_attention_kernel(AttnArgs p) {
     __shared__ AttnSmem sm;
-    if (p.ctrl->stop) return;
     const int img = blockIdx.y >> 2, head = blockIdx.y & 3;
-    const int kimg = p.cross ? 1 - img : img;
-    const int nq = p.ctrl->n[img], nk = p.ctrl->n[kimg];
+    if (ctrl_of(p.ctrl, img).stop) return;
+    const int kimg = p.cross ? (img ^ 1) : img;
+    const int nq = n_of(p.ctrl, img), nk = n_of(p.ctrl, kimg);
     const int q0 = blockIdx.x * AQ;
     if (q0 >= nq) return;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, lr = lane & 31;
@@ -412,7 +440,7 @@ __global__ __launch_bounds__(256) void lg_attention_kernel(AttnArgs p) {
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const int qrow = q0 + wave * 32 + lr;
     if (qrow < nq) {
-        const size_t pbase = (((size_t)z * 2 + img) * NH + head) * p.Kc + qrow;
+        const size_t pbase = (((size_t)z * p.NIc + img) * NH + head) * p.Kc + qrow;
         float* op = p.o_part + pbase * DH;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
@@ -429,22 +457,22 @@ __global__ __launch_bounds__(256) void lg_attention_kernel(AttnArgs p) {
 __global__ __launch_bounds__(256) void lg_attn_merge_kernel(const float* __restrict__ o_part,
                                                             const float* __restrict__ m_part,
                                                             const float* __restrict__ l_part,
-                                                            float* __restrict__ msg, int KS, int Kc,
-                                                            const LGCtrl* __restrict__ ctrl) {
-    if (ctrl->stop) return;
+                                                            float* __restrict__ msg, int KS, int Kc, int NI,
+                                                            int NIc, const LGCtrl* __restrict__ ctrl) {
     // one thread = one float4 of one (img, head, row)
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int c4 = (int)(gid & 15);
     const long rid = gid >> 4;                      // (img*4+head)*Kc + row
-    if (rid >= (long)2 * NH * Kc) return;
+    if (rid >= (long)NI * NH * Kc) return;
     const int row = (int)(rid % Kc), ih = (int)(rid / Kc), img = ih >> 2, head = ih & 3;
-    if (row >= ctrl->n[img]) return;
+    if (ctrl_of(ctrl, img).stop || row >= n_of(ctrl, img)) return;
+    const size_t zs = (size_t)NIc * NH * Kc;        // partial stride of one key slab
     float M = -INFINITY;
-    for (int z = 0; z < KS; ++z) M = fmaxf(M, m_part[(size_t)z * 2 * NH * Kc + rid]);
+    for (int z = 0; z < KS; ++z) M = fmaxf(M, m_part[(size_t)z * zs + rid]);
     float4 acc = make_float4(0, 0, 0, 0);
     float L = 0.0f;
     for (int z = 0; z < KS; ++z) {
-        const size_t pb = (size_t)z * 2 * NH * Kc + rid;
+        const size_t pb = (size_t)z * zs + rid;
         const float mz = m_part[pb];
         const float wz = (mz == -INFINITY) ? 0.0f : exp2f(mz - M);
         const float4 o = *reinterpret_cast<const float4*>(o_part + pb * DH + c4 * 4);
@@ -478,16 +506,17 @@ __global__ __launch_bounds__(256) void lg_token_heads_kernel(
     // wave-uniform scalar loads), so there is no cross-lane reduction at all; a wave-per-token
     // layout spent its time in 12 dependent shuffles per token
     __shared__ int s_unconf[4];
-    if (ctrl->stop == 2) return;
-    if (ctrl->stop && !use_stop_layer) return;
+    const int img = blockIdx.y;                              // one image per grid row: a block never
+    LGCtrl& pc = ctrl_of(ctrl, img);                         // mixes the counts of two pairs
+    if (pc.stop == 2) return;
+    if (pc.stop && !use_stop_layer) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (use_stop_layer) {
-        wm += (size_t)ctrl->stop_layer * m_layer_stride;
-        bm += (size_t)ctrl->stop_layer * m_layer_stride;   // both padded to the same stride
+        wm += (size_t)pc.stop_layer * m_layer_stride;
+        bm += (size_t)pc.stop_layer * m_layer_stride;   // both padded to the same stride
     }
-    const int gt = blockIdx.x * 256 + threadIdx.x;
-    const int img = min(gt / Kc, 1), row = gt % Kc;
-    const bool live = gt < 2 * Kc && row < ctrl->n[img];
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    const bool live = row < Kc && row < pc.n[img & 1];
     const float* xr = x + ((size_t)img * Kc + (live ? row : 0)) * D;
     float sm0 = 0.0f, sm1 = 0.0f, sc0 = 0.0f, sc1 = 0.0f;
 #pragma unroll 8
@@ -515,7 +544,7 @@ __global__ __launch_bounds__(256) void lg_token_heads_kernel(
     __syncthreads();
     if (threadIdx.x == 0) {
         const int tot = s_unconf[0] + s_unconf[1] + s_unconf[2] + s_unconf[3];
-        if (tot) atomicAdd(&ctrl->unconf, tot);
+        if (tot) atomicAdd(&pc.unconf, tot);
     }
 }
 
@@ -526,6 +555,10 @@ __global__ __launch_bounds__(1024) void lg_decide_kernel(
     int* __restrict__ gmap, int* __restrict__ prune, LGCtrl* __restrict__ ctrl, int Kc) {
     __shared__ int wsum[16];
     __shared__ int s_stop;
+    const int pair = blockIdx.x;
+    ctrl += pair;                                    // this pair's control block and 2 Kc-row slices
+    conf += (size_t)pair * 2 * Kc; mat += (size_t)pair * 2 * Kc; ind += (size_t)pair * 2 * Kc;
+    gmap += (size_t)pair * 2 * Kc; prune += (size_t)pair * 2 * Kc;
     if (ctrl->stop) return;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (t == 0) {
@@ -598,12 +631,13 @@ __global__ __launch_bounds__(256) void lg_gather_kernel(const float* __restrict_
                                                         const int* __restrict__ gmap,
                                                         float* __restrict__ tx, float* __restrict__ tc,
                                                         float* __restrict__ ts,
-                                                        const LGCtrl* __restrict__ ctrl, int Kc, int back) {
-    if (ctrl->stop) return;
+                                                        const LGCtrl* __restrict__ ctrl, int Kc, int NI, int back) {
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int img = gw / Kc, row = gw % Kc;
-    if (img > 1 || ctrl->n[img] == ctrl->n_prev[img] || row >= ctrl->n[img]) return;
+    if (img >= NI) return;
+    const LGCtrl& pc = ctrl_of(ctrl, img);
+    if (pc.stop || pc.n[img & 1] == pc.n_prev[img & 1] || row >= pc.n[img & 1]) return;
     const size_t dst = (size_t)img * Kc + row;
     const size_t src = back ? dst : (size_t)img * Kc + gmap[img * Kc + row];
     // back == 1: tmp -> x (plain copy); back == 0: x[gmap] -> tmp
@@ -623,13 +657,17 @@ struct SimArgs { const float* md; float* sim; int Kc; const LGCtrl* ctrl; };
 template <int BM, int BN, int TM, int TN>
 __global__ __launch_bounds__(256) void lg_sim_kernel(SimArgs p) {
     __shared__ GemmSmem<BM, BN> sm;
-    if (p.ctrl->stop == 2) return;
-    const int n0 = p.ctrl->n[0], n1 = p.ctrl->n[1];
+    const int pair = blockIdx.z;
+    const LGCtrl& pc = p.ctrl[pair];
+    if (pc.stop == 2) return;
+    const int n0 = pc.n[0], n1 = pc.n[1];
     const int row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
     if (row0 >= n0 || col0 >= n1) return;
-    GemmA ga{p.md, D, nullptr, 0, D};
+    const float* md0 = p.md + (size_t)pair * 2 * p.Kc * D;      // image 2 pair; image 2 pair + 1 follows
+    float* simp = p.sim + (size_t)pair * p.Kc * p.Kc;
+    GemmA ga{md0, D, nullptr, 0, D};
     f32x16 acc[TM][TN];
-    gemm_mainloop<BM, BN, TM, TN>(ga, p.md + (size_t)p.Kc * D, D, D, row0, p.Kc, col0, p.Kc, sm, acc);
+    gemm_mainloop<BM, BN, TM, TN>(ga, md0 + (size_t)p.Kc * D, D, D, row0, p.Kc, col0, p.Kc, sm, acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -639,7 +677,7 @@ __global__ __launch_bounds__(256) void lg_sim_kernel(SimArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = row0 + wm * 32 * TM + i * 32 + acc_row(r, lane);
-                if (row < n0 && col < n1) p.sim[(size_t)row * p.Kc + col] = acc[i][j][r];
+                if (row < n0 && col < n1) simp[(size_t)row * p.Kc + col] = acc[i][j][r];
             }
         }
 }
@@ -648,6 +686,8 @@ __global__ __launch_bounds__(256) void lg_sim_kernel(SimArgs p) {
 __global__ __launch_bounds__(256) void lg_row_stats_kernel(const float* __restrict__ sim,
                                                            float* __restrict__ rmax, float* __restrict__ rlog,
                                                            int Kc, const LGCtrl* __restrict__ ctrl) {
+    const int pair = blockIdx.y;
+    ctrl += pair; sim += (size_t)pair * Kc * Kc; rmax += (size_t)pair * Kc; rlog += (size_t)pair * Kc;
     if (ctrl->stop == 2) return;
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n0 = ctrl->n[0], n1 = ctrl->n[1];
@@ -671,6 +711,9 @@ __global__ __launch_bounds__(256) void lg_col_stats_kernel(const float* __restri
                                                            float* __restrict__ pmax, float* __restrict__ psum,
                                                            int Kc, const LGCtrl* __restrict__ ctrl) {
     __shared__ float sh[4][64];
+    const int pair = blockIdx.z;
+    ctrl += pair; sim += (size_t)pair * Kc * Kc;
+    pmax += (size_t)pair * CSLAB * Kc; psum += (size_t)pair * CSLAB * Kc;
     if (ctrl->stop == 2) return;
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
@@ -699,6 +742,9 @@ __global__ __launch_bounds__(256) void lg_col_stats_merge_kernel(const float* __
                                                                  const float* __restrict__ psum,
                                                                  float* __restrict__ cmax, float* __restrict__ clog,
                                                                  int Kc, const LGCtrl* __restrict__ ctrl) {
+    const int pair = blockIdx.y;
+    ctrl += pair; pmax += (size_t)pair * CSLAB * Kc; psum += (size_t)pair * CSLAB * Kc;
+    cmax += (size_t)pair * Kc; clog += (size_t)pair * Kc;
     if (ctrl->stop == 2) return;
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= ctrl->n[1]) return;
@@ -722,6 +768,10 @@ __global__ __launch_bounds__(256) void lg_row_argmax_kernel(
     const float* __restrict__ sim, const float* __restrict__ rmax, const float* __restrict__ rlog,
     const float* __restrict__ cmax, const float* __restrict__ clog, const float* __restrict__ z,
     float* __restrict__ best0, int* __restrict__ arg0, int Kc, const LGCtrl* __restrict__ ctrl) {
+    const int pair = blockIdx.y;
+    ctrl += pair; sim += (size_t)pair * Kc * Kc; rmax += (size_t)pair * Kc; rlog += (size_t)pair * Kc;
+    cmax += (size_t)pair * Kc; clog += (size_t)pair * Kc; z += (size_t)pair * 2 * Kc;
+    best0 += (size_t)pair * Kc; arg0 += (size_t)pair * Kc;
     if (ctrl->stop == 2) return;
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n0 = ctrl->n[0], n1 = ctrl->n[1];
@@ -745,6 +795,10 @@ __global__ __launch_bounds__(256) void lg_col_argmax_kernel(
     float* __restrict__ pval, int* __restrict__ parg, int Kc, const LGCtrl* __restrict__ ctrl) {
     __shared__ float shv[4][64];
     __shared__ int shi[4][64];
+    const int pair = blockIdx.z;
+    ctrl += pair; sim += (size_t)pair * Kc * Kc; rmax += (size_t)pair * Kc; rlog += (size_t)pair * Kc;
+    cmax += (size_t)pair * Kc; clog += (size_t)pair * Kc; z += (size_t)pair * 2 * Kc;
+    pval += (size_t)pair * CSLAB * Kc; parg += (size_t)pair * CSLAB * Kc;
     if (ctrl->stop == 2) return;
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
@@ -786,8 +840,13 @@ __device__ __forceinline__ int col_argmax_merge(const float* __restrict__ pval, 
 __global__ __launch_bounds__(1024) void lg_emit_kernel(
     const float* __restrict__ best0, const int* __restrict__ arg0, const float* __restrict__ pval,
     const int* __restrict__ parg, const int* __restrict__ ind, float filter_thr, float min_conf, int32_t* __restrict__ ij_out,
-    float* __restrict__ score_out, int32_t* __restrict__ info_out, LGCtrl* __restrict__ ctrl, int Kc) {
+    float* __restrict__ score_out, int32_t* __restrict__ info_out, LGCtrl* __restrict__ ctrl, int Kc,
+    long out_stride) {
     __shared__ int wsum[16];
+    const int pair = blockIdx.x;
+    ctrl += pair; best0 += (size_t)pair * Kc; arg0 += (size_t)pair * Kc;
+    pval += (size_t)pair * CSLAB * Kc; parg += (size_t)pair * CSLAB * Kc; ind += (size_t)pair * 2 * Kc;
+    ij_out += (size_t)pair * out_stride * 2; score_out += (size_t)pair * out_stride; info_out += pair * 4;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int n0 = ctrl->stop == 2 ? 0 : ctrl->n[0];
     const int n1 = ctrl->n[1];
@@ -855,15 +914,15 @@ __global__ void lg_split_weight_kernel(const float* __restrict__ src, _Float16* 
 // only_moved: refresh after pruning - an image whose rows did not move (n == n_prev) still has
 // the planes its producer's epilogue wrote
 __global__ void lg_split_rows_kernel(const float* __restrict__ src, _Float16* __restrict__ hi,
-                                     _Float16* __restrict__ lo, int ld, int Kc,
+                                     _Float16* __restrict__ lo, int ld, int Kc, int NI, int NIc,
                                      const LGCtrl* __restrict__ ctrl, int only_moved) {
-    if (ctrl->stop) return;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t per = (size_t)Kc * ld;
-    if (i >= 2 * per) return;
+    if (i >= (size_t)NI * per) return;
     const int img = (int)(i / per), row = (int)((i % per) / ld), col = (int)(i % ld);
-    if (row >= ctrl->n[img] || (only_moved && ctrl->n[img] == ctrl->n_prev[img])) return;
-    const size_t o = panel_index(img * Kc + row, col, 2 * Kc);
+    const LGCtrl& pc = ctrl_of(ctrl, img);
+    if (pc.stop || row >= pc.n[img & 1] || (only_moved && pc.n[img & 1] == pc.n_prev[img & 1])) return;
+    const size_t o = panel_index(img * Kc + row, col, NIc * Kc);
     split_f32(src[i], hi[o], lo[o]);
 }
 
@@ -877,7 +936,7 @@ struct LinearArgsH {
     SplitOut q, k, vt;                 // QKV / CROSS destinations
     float q_scale, k_scale;
     const float* enc_cos; const float* enc_sin;
-    const LGCtrl* ctrl; int Kc;
+    const LGCtrl* ctrl; int Kc; int NIc;   // NIc: image capacity of the instance (plane rows = NIc * Kc)
 };
 
 // LDS ring depth of the split-precision GEMM.  Depth beyond 2 bought nothing measurable (the k-loop is
@@ -894,19 +953,19 @@ constexpr int ring_depth() {
 template <int BM, int BN, int TM, int TN, int EPI>
 __global__ __launch_bounds__(512) void lg_linear_h_kernel(LinearArgsH p) {
     extern __shared__ __attribute__((aligned(16))) _Float16 lg_ring[];
-    if (p.ctrl->stop) return;
     int rb, cb;
     xcd_tile(gridDim.x, rb, cb);
     const int nb = (p.Kc + BM - 1) / BM;
     RowDom rd;
-    rd.img = rb / nb; rd.row0 = (rb % nb) * BM; rd.n = p.ctrl->n[rd.img];
+    rd.img = rb / nb; rd.row0 = (rb % nb) * BM; rd.n = n_of(p.ctrl, rd.img);
+    if (ctrl_of(p.ctrl, rd.img).stop) return;
     if (rd.row0 >= rd.n) return;
     const int col0 = cb * BN;
     const size_t ibase = (size_t)rd.img * p.Kc;
     GemmAH ga{{p.A0.hi, p.A0.lo}, {p.A1.hi ? p.A1.hi : p.A0.hi, p.A1.lo ? p.A1.lo : p.A0.lo}, p.lda, p.K0};
     f32x16 c1[TM][TN], c2[TM][TN];
     // plane rows are global token rows (image-major, 2*Kc per panel); clamp inside this image
-    gemm_mainloop_ring<BM, BN, TM, TN, ring_depth<BM, BN>()>(ga, p.W, 2 * p.Kc, p.K, (int)ibase + rd.row0,
+    gemm_mainloop_ring<BM, BN, TM, TN, ring_depth<BM, BN>()>(ga, p.W, p.NIc * p.Kc, p.K, (int)ibase + rd.row0,
                                                              (int)ibase + p.Kc, col0, p.N, lg_ring, c1, c2);
     if (threadIdx.x >= 256) return;                    // producer waves (4-7) are done
 #if defined(SSLAM_DBG_NOEPI)
@@ -996,7 +1055,7 @@ __global__ __launch_bounds__(512) void lg_linear_h_kernel(LinearArgsH p) {
             if constexpr (EPI == EPH_SPLIT || EPI == EPH_RESID) {
                 uint4 hi, lo;
                 split8(v, hi, lo);
-                const size_t po = panel_index(grow0 + rl, col, 2 * p.Kc);
+                const size_t po = panel_index(grow0 + rl, col, p.NIc * p.Kc);
                 *reinterpret_cast<uint4*>(p.outs.hi + po) = hi;
                 *reinterpret_cast<uint4*>(p.outs.lo + po) = lo;
             }
@@ -1031,12 +1090,11 @@ __global__ __launch_bounds__(512) void lg_linear_h_kernel(LinearArgsH p) {
 __global__ __launch_bounds__(256) void lg_ln_gelu_h_kernel(const float* __restrict__ hid, SplitOut outs,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta,
-                                                           const LGCtrl* __restrict__ ctrl, int Kc) {
-    if (ctrl->stop) return;
+                                                           const LGCtrl* __restrict__ ctrl, int Kc, int NI, int NIc) {
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int img = gw / Kc, row = gw % Kc;
-    if (img > 1 || row >= ctrl->n[img]) return;
+    if (img >= NI || ctrl_of(ctrl, img).stop || row >= n_of(ctrl, img)) return;
     const size_t base = ((size_t)img * Kc + row) * 512;
     const float4 a = *reinterpret_cast<const float4*>(hid + base + lane * 4);
     const float4 b = *reinterpret_cast<const float4*>(hid + base + 256 + lane * 4);
@@ -1059,7 +1117,7 @@ __global__ __launch_bounds__(256) void lg_ln_gelu_h_kernel(const float* __restri
         split_f32(g, hh, ll);
         if (i < 4) { h0[i] = hh; l0[i] = ll; } else { h1[i - 4] = hh; l1[i - 4] = ll; }
     }
-    const size_t p0 = panel_index(img * Kc + row, lane * 4, 2 * Kc), p1 = panel_index(img * Kc + row, 256 + lane * 4, 2 * Kc);
+    const size_t p0 = panel_index(img * Kc + row, lane * 4, NIc * Kc), p1 = panel_index(img * Kc + row, 256 + lane * 4, NIc * Kc);
     *reinterpret_cast<half4*>(outs.hi + p0) = h0;
     *reinterpret_cast<half4*>(outs.lo + p0) = l0;
     *reinterpret_cast<half4*>(outs.hi + p1) = h1;
@@ -1079,10 +1137,11 @@ struct __attribute__((aligned(16))) AttnSmemH {
 };
 
 struct AttnArgsH {
-    SplitPtr Q, K, VT;                                // Q,K [2][4][Kc][64]; VT [2][4][64][Kc]
+    SplitPtr Q, K, VT;                                // Q,K [NI][4][Kc][64]; VT [NI][4][Kc/64][64][64]
     int cross;
-    float* o_part; float* m_part; float* l_part;
-    int KS; int Kc; const LGCtrl* ctrl;
+    float* o_part; float* m_part; float* l_part;      // key-split partials (KS > 1)
+    SplitOut msg;                                     // KS == 1: the normalised context goes straight to the split planes
+    int KS; int Kc; int NIc; const LGCtrl* ctrl;
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
@@ -1189,7 +1248,6 @@ __device__ __forceinline__ void softmax_fake(const f32x16& s1, const f32x16& s2,
 #endif
 __global__ __launch_bounds__(256, 2) void lg_attention_p_kernel(AttnArgsH p) {
     __shared__ AttnSmemH sm;
-    if (p.ctrl->stop) return;
     const int nqb = gridDim.x, nslab = gridDim.y * gridDim.z;
     int slab, qb;
     {
@@ -1203,8 +1261,9 @@ __global__ __launch_bounds__(256, 2) void lg_attention_p_kernel(AttnArgsH p) {
     const int z = slab / gridDim.y, ih = slab % gridDim.y;
 #endif
     const int img = ih >> 2, head = ih & 3;
-    const int kimg = p.cross ? 1 - img : img;
-    const int nq = p.ctrl->n[img], nk = p.ctrl->n[kimg];
+    if (ctrl_of(p.ctrl, img).stop) return;
+    const int kimg = p.cross ? (img ^ 1) : img;
+    const int nq = n_of(p.ctrl, img), nk = n_of(p.ctrl, kimg);
     const int q0 = qb * AQ;
     if (q0 >= nq) return;
     const int t = threadIdx.x, lane = t & 63, h = lane >> 5, lr = lane & 31;
@@ -1351,7 +1410,34 @@ __global__ __launch_bounds__(256, 2) void lg_attention_p_kernel(AttnArgsH p) {
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const int qrow = q0 + wave * 32 + lr;
-    const size_t pbase0 = (((size_t)z * 2 + img) * NH + head) * p.Kc + q0 + wave * 32;   // this wave's first row
+    if (p.KS == 1) {
+        // the block saw every key of its queries: normalise, split and write the context planes
+        // (k-panel layout: 4 consecutive d of one token = 8 bytes per plane)
+        if (qrow < nq) {
+            const float inv = 1.0f / l_tot;
+            const int prow = img * p.Kc + qrow;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    half4 hh, ll;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = half ? (o1b[4 * g4 + e] + o2b[4 * g4 + e] * SPLIT_INV)
+                                             : (o1a[4 * g4 + e] + o2a[4 * g4 + e] * SPLIT_INV);
+                        _Float16 a, b;
+                        split_f32(v * inv, a, b);
+                        hh[e] = a; ll[e] = b;
+                    }
+                    const size_t o = panel_index(prow, head * DH + 32 * half + 8 * g4 + 4 * h, p.NIc * p.Kc);
+                    *reinterpret_cast<half4*>(p.msg.hi + o) = hh;
+                    *reinterpret_cast<half4*>(p.msg.lo + o) = ll;
+                }
+            }
+        }
+        return;
+    }
+    const size_t pbase0 = (((size_t)z * p.NIc + img) * NH + head) * p.Kc + q0 + wave * 32;   // this wave's first row
     if (qrow < nq) {
         const size_t pbase = pbase0 + lr;
         float* op = p.o_part + pbase * DH;
@@ -1373,20 +1459,21 @@ __global__ __launch_bounds__(256, 2) void lg_attention_p_kernel(AttnArgsH p) {
 __global__ __launch_bounds__(256) void lg_attn_merge_h_kernel(const float* __restrict__ o_part,
                                                               const float* __restrict__ m_part,
                                                               const float* __restrict__ l_part, SplitOut msg,
-                                                              int KS, int Kc, const LGCtrl* __restrict__ ctrl) {
-    if (ctrl->stop) return;
+                                                              int KS, int Kc, int NI, int NIc,
+                                                              const LGCtrl* __restrict__ ctrl) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int c4 = (int)(gid & 15);
     const long rid = gid >> 4;
-    if (rid >= (long)2 * NH * Kc) return;
+    if (rid >= (long)NI * NH * Kc) return;
     const int row = (int)(rid % Kc), ih = (int)(rid / Kc), img = ih >> 2, head = ih & 3;
-    if (row >= ctrl->n[img]) return;
+    if (ctrl_of(ctrl, img).stop || row >= n_of(ctrl, img)) return;
+    const size_t zs = (size_t)NIc * NH * Kc;
     float M = -INFINITY;
-    for (int z = 0; z < KS; ++z) M = fmaxf(M, m_part[(size_t)z * 2 * NH * Kc + rid]);
+    for (int z = 0; z < KS; ++z) M = fmaxf(M, m_part[(size_t)z * zs + rid]);
     float4 acc = make_float4(0, 0, 0, 0);
     float L = 0.0f;
     for (int z = 0; z < KS; ++z) {
-        const size_t pb = (size_t)z * 2 * NH * Kc + rid;
+        const size_t pb = (size_t)z * zs + rid;
         const float mz = m_part[pb];
         const float wz = (mz == -INFINITY) ? 0.0f : exp2f(mz - M);
         const float4 o = *reinterpret_cast<const float4*>(o_part + pb * DH + c4 * 4);
@@ -1398,7 +1485,7 @@ __global__ __launch_bounds__(256) void lg_attn_merge_h_kernel(const float* __res
     half4 hh, ll;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { _Float16 a, b; split_f32(v[e], a, b); hh[e] = a; ll[e] = b; }
-    const size_t o = panel_index(img * Kc + row, head * DH + c4 * 4, 2 * Kc);
+    const size_t o = panel_index(img * Kc + row, head * DH + c4 * 4, NIc * Kc);
     *reinterpret_cast<half4*>(msg.hi + o) = hh;
     *reinterpret_cast<half4*>(msg.lo + o) = ll;
 }
@@ -1416,7 +1503,10 @@ struct LGLayerW {
 
 struct sslam_lightglue {
     sslam_ctx* ctx = nullptr;
-    int Kc = 0, KS = 4;
+    int Kc = 0;
+    int NB = 1;                      // batch capacity in pairs; NIc = 2 NB images
+    int NIc = 2;
+    int KSmax = 4;                   // key split the attention partial buffers are sized for
     float depth_conf = 0.95f, width_conf = 0.99f, filter_thr = 0.1f;
     int prune_min = -1;
     sslam::Arena arena;
@@ -1429,25 +1519,27 @@ struct sslam_lightglue {
     const float* tc_b[NL - 1];
     // workspace
     LGCtrl* ctrl;
-    float *x, *enc_cos, *enc_sin, *q, *k, *v, *msg, *msg2, *hid, *tx, *tc, *ts;
+    float *x, *enc_cos, *enc_sin, *q, *k, *v, *msg, *hid, *tx, *tc, *ts;
     float *o_part, *m_part, *l_part, *conf, *mat, *md, *sim, *rmax, *rlog, *cmax, *clog, *best0;
     float *cpmax, *cpsum, *cpval, *bbox;
     int* cparg;
-    int *ind, *gmap, *prune, *arg0, *arg1;
-    float *in_xy, *in_desc, *out_score;
+    int *ind, *gmap, *prune, *arg0;
+    float *in_xy, *in_desc, *up_xy, *up_desc, *out_score;
     int32_t *out_ij, *out_info;
     // split-precision planes (precision == 1)
     int precision = 1;               // 0: fp32 MFMA everywhere; 1: fp16 hi/lo split, 3 MFMA per product
     int dbg_layers = NL;             // test hook: run only the first dbg_layers layers
     int dbg_self_only = 0;           // test hook: stop after the self block of the last executed layer
+    int force_ks = 0;                // test hook: key split of the attention launches (0 = by batch size)
     _Float16 *w_hi, *w_lo;           // whole weight blob, split
-    _Float16 *xs_hi, *xs_lo, *msgs_hi, *msgs_lo, *msg2s_hi, *msg2s_lo, *hids_hi, *hids_lo;
+    _Float16 *xs_hi, *xs_lo, *msgs_hi, *msgs_lo, *hids_hi, *hids_lo;
     _Float16 *qs_hi, *qs_lo, *ks_hi, *ks_lo, *vts_hi, *vts_lo;
     size_t n_blob = 0;
     // optional HIP-event bracketing of the attention launches (bench.py roofline line)
     bool profile = false;
     std::vector<hipEvent_t> ev;     // start/stop pairs
     size_t ev_used = 0;
+    int last_pairs = 1;             // pairs of the bracketed launches
 };
 
 namespace {
@@ -1485,49 +1577,63 @@ float conf_threshold(int layer) {   // np.clip(0.8 + 0.1 * exp(-4 i / n_layers),
     return (float)v;
 }
 
+// key split of one attention launch: enough (image, head, query-block) units to give every CU two
+// workgroups without it, otherwise split the keys (partials + merge launch)
+int attn_key_split(const sslam_lightglue* g, int NI) {
+    int ks = 1;
+    if (g->force_ks > 0) ks = g->force_ks;
+    else {
+        const int units = NI * NH * (g->Kc / AQ);
+        while (ks < 4 && units * ks < 512 && g->Kc / AK >= 2 * ks * 4) ks *= 2;
+    }
+    return ks > g->KSmax ? g->KSmax : ks;
+}
+
 template <int BM, int BN, int TM, int TN, int EPI>
 void launch_linear(hipStream_t s, const LinearArgs& a) {
-    dim3 grid(a.N / BN, 2 * sslam::cdiv(a.Kc, BM));
+    dim3 grid(a.N / BN, a.NI * sslam::cdiv(a.Kc, BM));
     hipLaunchKernelGGL((lg_linear_kernel<BM, BN, TM, TN, EPI>), grid, dim3(256), 0, s, a);
 }
 
-LinearArgs lin(const sslam_lightglue* g, const float* A0, int lda0, const float* A1, int lda1, int K0,
+LinearArgs lin(const sslam_lightglue* g, int NI, const float* A0, int lda0, const float* A1, int lda1, int K0,
                int K, const float* W, const float* b, int N) {
     LinearArgs a{};
     a.A0 = A0; a.lda0 = lda0; a.A1 = A1; a.lda1 = lda1; a.K0 = K0; a.K = K;
-    a.W = W; a.bias = b; a.N = N; a.out_scale = 1.0f; a.ctrl = g->ctrl; a.Kc = g->Kc;
+    a.W = W; a.bias = b; a.N = N; a.out_scale = 1.0f; a.ctrl = g->ctrl; a.Kc = g->Kc; a.NI = NI;
     a.enc_cos = g->enc_cos; a.enc_sin = g->enc_sin;
     return a;
 }
 
-void launch_attention(const sslam_lightglue* g, hipStream_t s, const float* Q, const float* K,
-                      const float* V, int cross) {
-    AttnArgs a{Q, K, V, cross, g->o_part, g->m_part, g->l_part, g->KS, g->Kc, g->ctrl};
-    dim3 grid(sslam::cdiv(g->Kc, AQ), 2 * NH, g->KS);
-    sslam_lightglue* gm = const_cast<sslam_lightglue*>(g);
-    const bool prof = gm->profile;
-    if (prof) {
-        if (gm->ev_used + 2 > gm->ev.size()) {
-            for (int i = 0; i < 64; ++i) { hipEvent_t e; (void)hipEventCreate(&e); gm->ev.push_back(e); }
-        }
-        (void)hipEventRecord(gm->ev[gm->ev_used], s);
-    }
-    hipLaunchKernelGGL(lg_attention_kernel, grid, dim3(256), 0, s, a);
-    if (prof) { (void)hipEventRecord(gm->ev[gm->ev_used + 1], s); gm->ev_used += 2; }
-    const long n4 = (long)2 * NH * g->Kc * 16;
-    hipLaunchKernelGGL(lg_attn_merge_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s,
-                       g->o_part, g->m_part, g->l_part, g->msg, g->KS, g->Kc, g->ctrl);
+void attn_event(sslam_lightglue* g, hipStream_t s, bool start) {
+    if (!g->profile) return;
+    if (start && g->ev_used + 2 > g->ev.size())
+        for (int i = 0; i < 64; ++i) { hipEvent_t e; (void)hipEventCreate(&e); g->ev.push_back(e); }
+    (void)hipEventRecord(g->ev[g->ev_used + (start ? 0 : 1)], s);
+    if (!start) g->ev_used += 2;
 }
 
-void launch_ffn(const sslam_lightglue* g, hipStream_t s, const float* message, const float* w1,
+void launch_attention(sslam_lightglue* g, hipStream_t s, int NI, const float* Q, const float* K,
+                      const float* V, int cross) {
+    const int KS = attn_key_split(g, NI);
+    AttnArgs a{Q, K, V, cross, g->o_part, g->m_part, g->l_part, KS, g->Kc, g->NIc, g->ctrl};
+    dim3 grid(sslam::cdiv(g->Kc, AQ), NI * NH, KS);
+    attn_event(g, s, true);
+    hipLaunchKernelGGL(lg_attention_kernel, grid, dim3(256), 0, s, a);
+    attn_event(g, s, false);
+    const long n4 = (long)NI * NH * g->Kc * 16;
+    hipLaunchKernelGGL(lg_attn_merge_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s,
+                       g->o_part, g->m_part, g->l_part, g->msg, KS, g->Kc, NI, g->NIc, g->ctrl);
+}
+
+void launch_ffn(sslam_lightglue* g, hipStream_t s, int NI, const float* message, const float* w1,
                 const float* b1, const float* lnw, const float* lnb, const float* w2, const float* b2) {
     // hid = [x | message] W1^T + b1 ; LN + GELU ; x += hid W2^T + b2
-    LinearArgs a = lin(g, g->x, D, message, D, D, 2 * D, w1, b1, 2 * D);
+    LinearArgs a = lin(g, NI, g->x, D, message, D, D, 2 * D, w1, b1, 2 * D);
     a.out = g->hid; a.ldo = 2 * D;
     launch_linear<64, 128, 1, 2, EPI_PLAIN>(s, a);
-    hipLaunchKernelGGL(lg_ln_gelu_kernel, dim3(sslam::cdiv(2 * g->Kc, 4)), dim3(256), 0, s, g->hid, lnw,
-                       lnb, g->ctrl, g->Kc);
-    LinearArgs c = lin(g, g->hid, 2 * D, nullptr, 0, 2 * D, 2 * D, w2, b2, D);
+    hipLaunchKernelGGL(lg_ln_gelu_kernel, dim3(sslam::cdiv(NI * g->Kc, 4)), dim3(256), 0, s, g->hid, lnw,
+                       lnb, g->ctrl, g->Kc, NI);
+    LinearArgs c = lin(g, NI, g->hid, 2 * D, nullptr, 0, 2 * D, 2 * D, w2, b2, D);
     c.out = g->x; c.ldo = D;
     launch_linear<64, 64, 1, 1, EPI_RESID>(s, c);
 }
@@ -1538,7 +1644,7 @@ SplitPtr wsp(const sslam_lightglue* g, const float* w) {
 }
 
 template <int BM, int BN, int TM, int TN, int EPI>
-void launch_linear_h(hipStream_t s, const LinearArgsH& a) {
+void launch_linear_h(hipStream_t s, int NI, const LinearArgsH& a) {
     constexpr size_t lds = (size_t)ring_depth<BM, BN>() * sslam::ring_stage_halves<BM, BN>() * sizeof(_Float16);
     static bool configured = false;
     if (!configured) {      // > 64 KiB of dynamic LDS needs the opt-in attribute (once per instantiation)
@@ -1546,7 +1652,7 @@ void launch_linear_h(hipStream_t s, const LinearArgsH& a) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         configured = true;
     }
-    dim3 grid(a.N / BN, 2 * sslam::cdiv(a.Kc, BM));
+    dim3 grid(a.N / BN, NI * sslam::cdiv(a.Kc, BM));
     hipLaunchKernelGGL((lg_linear_h_kernel<BM, BN, TM, TN, EPI>), grid, dim3(512), lds, s, a);   // 4 consumer + 4 producer waves
 }
 
@@ -1554,109 +1660,109 @@ LinearArgsH linh(const sslam_lightglue* g, SplitPtr A0, SplitPtr A1, int lda, in
                  const float* b, int N) {
     LinearArgsH a{};
     a.A0 = A0; a.A1 = A1; a.lda = lda; a.K0 = K0; a.K = K;
-    a.W = wsp(g, W); a.bias = b; a.N = N; a.ctrl = g->ctrl; a.Kc = g->Kc;
+    a.W = wsp(g, W); a.bias = b; a.N = N; a.ctrl = g->ctrl; a.Kc = g->Kc; a.NIc = g->NIc;
     a.enc_cos = g->enc_cos; a.enc_sin = g->enc_sin; a.q_scale = 1.0f; a.k_scale = 1.0f;
     return a;
 }
 
-void launch_attention_h(sslam_lightglue* g, hipStream_t s, SplitPtr Q, SplitPtr K, SplitPtr VT, int cross) {
-    AttnArgsH a{Q, K, VT, cross, g->o_part, g->m_part, g->l_part, g->KS, g->Kc, g->ctrl};
-    dim3 grid(sslam::cdiv(g->Kc, AQ), 2 * NH, g->KS);
-    const bool prof = g->profile;
-    if (prof) {
-        if (g->ev_used + 2 > g->ev.size())
-            for (int i = 0; i < 64; ++i) { hipEvent_t e; (void)hipEventCreate(&e); g->ev.push_back(e); }
-        (void)hipEventRecord(g->ev[g->ev_used], s);
-    }
+void launch_attention_h(sslam_lightglue* g, hipStream_t s, int NI, SplitPtr Q, SplitPtr K, SplitPtr VT, int cross) {
+    const int KS = attn_key_split(g, NI);
+    AttnArgsH a{Q, K, VT, cross, g->o_part, g->m_part, g->l_part, SplitOut{g->msgs_hi, g->msgs_lo}, KS, g->Kc,
+                g->NIc, g->ctrl};
+    dim3 grid(sslam::cdiv(g->Kc, AQ), NI * NH, KS);
+    attn_event(g, s, true);
     hipLaunchKernelGGL(lg_attention_p_kernel, grid, dim3(256), 0, s, a);
-    if (prof) { (void)hipEventRecord(g->ev[g->ev_used + 1], s); g->ev_used += 2; }
-    const long n4 = (long)2 * NH * g->Kc * 16;
+    attn_event(g, s, false);
+    if (KS == 1) return;                   // the kernel wrote the context planes itself
+    const long n4 = (long)NI * NH * g->Kc * 16;
     hipLaunchKernelGGL(lg_attn_merge_h_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, g->o_part,
-                       g->m_part, g->l_part, SplitOut{g->msgs_hi, g->msgs_lo}, g->KS, g->Kc, g->ctrl);
+                       g->m_part, g->l_part, SplitOut{g->msgs_hi, g->msgs_lo}, KS, g->Kc, NI, g->NIc, g->ctrl);
 }
 
 // one transformer layer (self + cross block) on the split-precision path
-void lg_layer_h(sslam_lightglue* g, hipStream_t s, const LGLayerW& l, bool self_only) {
+void lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, bool self_only) {
     const SplitPtr xs{g->xs_hi, g->xs_lo}, msgs{g->msgs_hi, g->msgs_lo};
     const SplitPtr hids{g->hids_hi, g->hids_lo}, none{nullptr, nullptr};
     const SplitPtr qs{g->qs_hi, g->qs_lo}, ks{g->ks_hi, g->ks_lo}, vts{g->vts_hi, g->vts_lo};
-    const unsigned tokblocks = sslam::cdiv(2 * g->Kc, 4);
+    const unsigned tokblocks = sslam::cdiv(NI * g->Kc, 4);
     const float sm_scale = 0.125f * 1.4426950408889634f;        // 1/sqrt(64) * log2(e)
     auto ffn = [&](const float* w1, const float* b1, const float* lnw, const float* lnb, const float* w2,
                    const float* b2) {
         LinearArgsH a = linh(g, xs, msgs, D, D, 2 * D, w1, b1, 2 * D);      // [x | attention context]
         a.out = g->hid; a.ldo = 2 * D;
-        launch_linear_h<64, 128, 1, 2, EPH_F32>(s, a);
+        launch_linear_h<64, 128, 1, 2, EPH_F32>(s, NI, a);
         hipLaunchKernelGGL(lg_ln_gelu_h_kernel, dim3(tokblocks), dim3(256), 0, s, g->hid,
-                           SplitOut{g->hids_hi, g->hids_lo}, lnw, lnb, g->ctrl, g->Kc);
+                           SplitOut{g->hids_hi, g->hids_lo}, lnw, lnb, g->ctrl, g->Kc, NI, g->NIc);
         LinearArgsH c = linh(g, hids, none, 2 * D, 2 * D, 2 * D, w2, b2, D);
         c.out = g->x; c.ldo = D; c.outs = SplitOut{g->xs_hi, g->xs_lo};
-        launch_linear_h<64, 64, 1, 1, EPH_RESID>(s, c);
+        launch_linear_h<64, 64, 1, 1, EPH_RESID>(s, NI, c);
     };
     {   // self block
         LinearArgsH a = linh(g, xs, none, D, D, D, l.wqkv, l.bqkv, 3 * D);
         a.q = SplitOut{g->qs_hi, g->qs_lo}; a.k = SplitOut{g->ks_hi, g->ks_lo}; a.vt = SplitOut{g->vts_hi, g->vts_lo};
         a.q_scale = sm_scale; a.k_scale = 1.0f;
-        launch_linear_h<64, 192, 1, 3, EPH_QKV>(s, a);       // 768 / 192 = 4 column tiles -> 256 blocks, one round
+        launch_linear_h<64, 192, 1, 3, EPH_QKV>(s, NI, a);       // 768 / 192 = 4 column tiles
     }
-    launch_attention_h(g, s, qs, ks, vts, 0);
+    launch_attention_h(g, s, NI, qs, ks, vts, 0);
     ffn(l.w1, l.b1, l.lnw, l.lnb, l.w2, l.b2);
     if (self_only) return;
     {   // cross block: the shared qk projection is both query and key -> sqrt(scale) on it
         LinearArgsH a = linh(g, xs, none, D, D, D, l.cqkv, l.cbqkv, 2 * D);
         a.q = SplitOut{g->qs_hi, g->qs_lo}; a.vt = SplitOut{g->vts_hi, g->vts_lo};
         a.q_scale = sqrtf(sm_scale);
-        launch_linear_h<64, 128, 1, 2, EPH_CROSS>(s, a);
+        launch_linear_h<64, 128, 1, 2, EPH_CROSS>(s, NI, a);
     }
-    launch_attention_h(g, s, qs, qs, vts, 1);
+    launch_attention_h(g, s, NI, qs, qs, vts, 1);
     ffn(l.cw1, l.cb1, l.clnw, l.clnb, l.cw2, l.cb2);
 }
 
-// Enqueue one pair on the context stream.  Inputs are already staged in
-// g->in_xy / g->in_desc ([2][Kc][2] and [2][Kc][128]).
-int lg_enqueue(sslam_lightglue* g, int M, int N, const int32_t* m_dev, const int32_t* n_dev, float min_conf,
-               int32_t* ij_out, float* score_out, int32_t* info_out) {
+// Enqueue one batch of `pairs` pairs on the context stream.  `src` names the inputs of image
+// 2p (query side) and 2p+1 of every pair; outputs of pair p go to ij_out + p*out_stride*2,
+// score_out + p*out_stride, info_out + 4p.
+int lg_enqueue(sslam_lightglue* g, int pairs, const StageSrc& src, float min_conf, int32_t* ij_out,
+               float* score_out, int32_t* info_out, long out_stride) {
     hipStream_t s = g->ctx->stream;
-    const int Kc = g->Kc;
-    hipLaunchKernelGGL(lg_prepare_kernel, dim3(2), dim3(1024), 0, s, g->in_xy, g->in_xy + 2 * Kc, M, N,
-                       m_dev, n_dev, Kc, g->bbox, g->ind, g->prune, g->ctrl);
-    hipLaunchKernelGGL(lg_posenc_kernel, dim3(sslam::cdiv(2 * Kc * ENC, 256)), dim3(256), 0, s, g->in_xy,
-                       g->in_xy + 2 * Kc, g->bbox, g->w_r, g->enc_cos, g->enc_sin, Kc, g->ctrl);
+    const int Kc = g->Kc, NI = 2 * pairs;
+    g->last_pairs = pairs;
+    hipLaunchKernelGGL(lg_prepare_kernel, dim3(NI), dim3(1024), 0, s, src, Kc, g->in_xy, g->in_desc, g->bbox,
+                       g->ind, g->prune, g->ctrl);
+    hipLaunchKernelGGL(lg_posenc_kernel, dim3(sslam::cdiv(NI * Kc * ENC, 256)), dim3(256), 0, s, g->in_xy,
+                       g->bbox, g->w_r, g->enc_cos, g->enc_sin, Kc, NI, g->ctrl);
     {   // input_proj (lightglue.py: desc = self.input_proj(desc))
-        LinearArgs a = lin(g, g->in_desc, DIN, nullptr, 0, DIN, DIN, g->w_in, g->b_in, D);
+        LinearArgs a = lin(g, NI, g->in_desc, DIN, nullptr, 0, DIN, DIN, g->w_in, g->b_in, D);
         a.out = g->x; a.ldo = D;
         launch_linear<64, 64, 1, 1, EPI_PLAIN>(s, a);
     }
-    const unsigned tokblocks = sslam::cdiv(2 * Kc, 4);
-    const unsigned headblocks = sslam::cdiv(2 * Kc, 256);          // one lane per token
-    const unsigned splitblocks = (unsigned)(((size_t)2 * Kc * D + 255) / 256);
+    const unsigned tokblocks = sslam::cdiv(NI * Kc, 4);
+    const dim3 headgrid(sslam::cdiv(Kc, 256), NI);               // one lane per token, one image per grid row
+    const unsigned splitblocks = (unsigned)(((size_t)NI * Kc * D + 255) / 256);
     if (g->precision == 1)
         hipLaunchKernelGGL(lg_split_rows_kernel, dim3(splitblocks), dim3(256), 0, s, g->x, g->xs_hi, g->xs_lo, D, Kc,
-                           g->ctrl, 0);
+                           NI, g->NIc, g->ctrl, 0);
     for (int i = 0; i < g->dbg_layers; ++i) {
         const LGLayerW& l = g->L[i];
         const bool self_only = g->dbg_self_only && i == g->dbg_layers - 1;
         if (g->precision == 1) {
-            lg_layer_h(g, s, l, self_only);
+            lg_layer_h(g, s, NI, l, self_only);
         } else {
-        // ---- self block
-        {
-            LinearArgs a = lin(g, g->x, D, nullptr, 0, D, D, l.wqkv, l.bqkv, 3 * D);
-            a.q = g->q; a.k = g->k; a.v = g->v;
-            launch_linear<64, 128, 1, 2, EPI_QKV>(s, a);
-        }
-        launch_attention(g, s, g->q, g->k, g->v, 0);
-        launch_ffn(g, s, g->msg, l.w1, l.b1, l.lnw, l.lnb, l.w2, l.b2);
-        if (!self_only) {
-        // ---- cross block
-        {
-            LinearArgs a = lin(g, g->x, D, nullptr, 0, D, D, l.cqkv, l.cbqkv, 2 * D);
-            a.q = g->q; a.v = g->v;
-            launch_linear<64, 128, 1, 2, EPI_CROSSQKV>(s, a);
-        }
-        launch_attention(g, s, g->q, g->q, g->v, 1);
-        launch_ffn(g, s, g->msg, l.cw1, l.cb1, l.clnw, l.clnb, l.cw2, l.cb2);
-        }
+            // ---- self block
+            {
+                LinearArgs a = lin(g, NI, g->x, D, nullptr, 0, D, D, l.wqkv, l.bqkv, 3 * D);
+                a.q = g->q; a.k = g->k; a.v = g->v;
+                launch_linear<64, 128, 1, 2, EPI_QKV>(s, a);
+            }
+            launch_attention(g, s, NI, g->q, g->k, g->v, 0);
+            launch_ffn(g, s, NI, g->msg, l.w1, l.b1, l.lnw, l.lnb, l.w2, l.b2);
+            if (!self_only) {
+                // ---- cross block
+                {
+                    LinearArgs a = lin(g, NI, g->x, D, nullptr, 0, D, D, l.cqkv, l.cbqkv, 2 * D);
+                    a.q = g->q; a.v = g->v;
+                    launch_linear<64, 128, 1, 2, EPI_CROSSQKV>(s, a);
+                }
+                launch_attention(g, s, NI, g->q, g->q, g->v, 1);
+                launch_ffn(g, s, NI, g->msg, l.cw1, l.cb1, l.clnw, l.clnb, l.cw2, l.cb2);
+            }
         }
         if (i == NL - 1 || i == g->dbg_layers - 1) break;
         // ---- early stop + point pruning (lightglue.py check_if_stop / get_pruning_mask)
@@ -1664,50 +1770,50 @@ int lg_enqueue(sslam_lightglue* g, int M, int N, const int32_t* m_dev, const int
         const int do_prune = g->width_conf > 0.0f;
         if (!do_stop && !do_prune) continue;
         const float thr = conf_threshold(i);
-        hipLaunchKernelGGL(lg_token_heads_kernel, dim3(headblocks), dim3(256), 0, s, g->x,
+        hipLaunchKernelGGL(lg_token_heads_kernel, headgrid, dim3(256), 0, s, g->x,
                            do_stop ? g->tc_w[i] : nullptr, do_stop ? g->tc_b[i] : nullptr,
                            g->mt_w + (size_t)i * g->mt_stride, g->mt_b + (size_t)i * g->mt_stride, 0L, 0,
                            thr, g->conf, g->mat, g->ctrl, Kc, do_stop);
-        hipLaunchKernelGGL(lg_decide_kernel, dim3(1), dim3(1024), 0, s, i, thr, g->depth_conf,
+        hipLaunchKernelGGL(lg_decide_kernel, dim3(pairs), dim3(1024), 0, s, i, thr, g->depth_conf,
                            g->width_conf, g->prune_min, do_stop, g->conf, g->mat, g->ind, g->gmap,
                            g->prune, g->ctrl, Kc);
         if (do_prune) {
             hipLaunchKernelGGL(lg_gather_kernel, dim3(tokblocks), dim3(256), 0, s, g->x, g->enc_cos,
-                               g->enc_sin, g->gmap, g->tx, g->tc, g->ts, g->ctrl, Kc, 0);
+                               g->enc_sin, g->gmap, g->tx, g->tc, g->ts, g->ctrl, Kc, NI, 0);
             hipLaunchKernelGGL(lg_gather_kernel, dim3(tokblocks), dim3(256), 0, s, g->x, g->enc_cos,
-                               g->enc_sin, g->gmap, g->tx, g->tc, g->ts, g->ctrl, Kc, 1);
+                               g->enc_sin, g->gmap, g->tx, g->tc, g->ts, g->ctrl, Kc, NI, 1);
             if (g->precision == 1)      // token rows moved: refresh their split planes
                 hipLaunchKernelGGL(lg_split_rows_kernel, dim3(splitblocks), dim3(256), 0, s, g->x, g->xs_hi,
-                                   g->xs_lo, D, Kc, g->ctrl, 1);
+                                   g->xs_lo, D, Kc, NI, g->NIc, g->ctrl, 1);
         }
     }
     // ---- assignment with log_assignment[stop_layer]
     {
-        LinearArgs a = lin(g, g->x, D, nullptr, 0, D, D, g->fp_w, g->fp_b, D);
+        LinearArgs a = lin(g, NI, g->x, D, nullptr, 0, D, D, g->fp_w, g->fp_b, D);
         a.by_stop_layer = 1; a.w_layer_stride = g->fp_stride; a.b_layer_stride = g->fp_stride;
         a.ignore_stop = 1; a.out = g->md; a.ldo = D;
         a.out_scale = 0.25f;                    // 1 / 256^0.25
         launch_linear<64, 64, 1, 1, EPI_PLAIN>(s, a);
     }
-    hipLaunchKernelGGL(lg_token_heads_kernel, dim3(headblocks), dim3(256), 0, s, g->x, nullptr, nullptr,
+    hipLaunchKernelGGL(lg_token_heads_kernel, headgrid, dim3(256), 0, s, g->x, nullptr, nullptr,
                        g->mt_w, g->mt_b, g->mt_stride, 1, 0.0f, g->conf, g->mat, g->ctrl, Kc, 0);
     {
         SimArgs a{g->md, g->sim, Kc, g->ctrl};
-        dim3 grid(sslam::cdiv(Kc, 128), sslam::cdiv(Kc, 64));
+        dim3 grid(sslam::cdiv(Kc, 128), sslam::cdiv(Kc, 64), pairs);
         hipLaunchKernelGGL((lg_sim_kernel<64, 128, 1, 2>), grid, dim3(256), 0, s, a);
     }
-    hipLaunchKernelGGL(lg_row_stats_kernel, dim3(sslam::cdiv(Kc, 4)), dim3(256), 0, s, g->sim, g->rmax,
+    hipLaunchKernelGGL(lg_row_stats_kernel, dim3(sslam::cdiv(Kc, 4), pairs), dim3(256), 0, s, g->sim, g->rmax,
                        g->rlog, Kc, g->ctrl);
-    hipLaunchKernelGGL(lg_col_stats_kernel, dim3(sslam::cdiv(Kc, 64), CSLAB), dim3(256), 0, s, g->sim,
+    hipLaunchKernelGGL(lg_col_stats_kernel, dim3(sslam::cdiv(Kc, 64), CSLAB, pairs), dim3(256), 0, s, g->sim,
                        g->cpmax, g->cpsum, Kc, g->ctrl);
-    hipLaunchKernelGGL(lg_col_stats_merge_kernel, dim3(sslam::cdiv(Kc, 256)), dim3(256), 0, s, g->cpmax,
+    hipLaunchKernelGGL(lg_col_stats_merge_kernel, dim3(sslam::cdiv(Kc, 256), pairs), dim3(256), 0, s, g->cpmax,
                        g->cpsum, g->cmax, g->clog, Kc, g->ctrl);
-    hipLaunchKernelGGL(lg_row_argmax_kernel, dim3(sslam::cdiv(Kc, 4)), dim3(256), 0, s, g->sim, g->rmax,
+    hipLaunchKernelGGL(lg_row_argmax_kernel, dim3(sslam::cdiv(Kc, 4), pairs), dim3(256), 0, s, g->sim, g->rmax,
                        g->rlog, g->cmax, g->clog, g->mat, g->best0, g->arg0, Kc, g->ctrl);
-    hipLaunchKernelGGL(lg_col_argmax_kernel, dim3(sslam::cdiv(Kc, 64), CSLAB), dim3(256), 0, s, g->sim,
+    hipLaunchKernelGGL(lg_col_argmax_kernel, dim3(sslam::cdiv(Kc, 64), CSLAB, pairs), dim3(256), 0, s, g->sim,
                        g->rmax, g->rlog, g->cmax, g->clog, g->mat, g->cpval, g->cparg, Kc, g->ctrl);
-    hipLaunchKernelGGL(lg_emit_kernel, dim3(1), dim3(1024), 0, s, g->best0, g->arg0, g->cpval, g->cparg, g->ind,
-                       g->filter_thr, min_conf, ij_out, score_out, info_out, g->ctrl, Kc);
+    hipLaunchKernelGGL(lg_emit_kernel, dim3(pairs), dim3(1024), 0, s, g->best0, g->arg0, g->cpval, g->cparg, g->ind,
+                       g->filter_thr, min_conf, ij_out, score_out, info_out, g->ctrl, Kc, out_stride);
     SSLAM_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1716,48 +1822,51 @@ int lg_enqueue(sslam_lightglue* g, int M, int N, const int32_t* m_dev, const int
 
 extern "C" {
 
-int sslam_lightglue_create(sslam_ctx* ctx, const float* weights, size_t n_floats, int max_kpts,
-                           sslam_lightglue** out) {
+int sslam_lightglue_create_batched(sslam_ctx* ctx, const float* weights, size_t n_floats, int max_kpts,
+                                   int max_pairs, sslam_lightglue** out) {
     SSLAM_REQUIRE(ctx && weights && out, "sslam_lightglue_create: NULL argument");
     SSLAM_REQUIRE(max_kpts >= 1 && max_kpts <= 8192, "sslam_lightglue_create: max_kpts %d not in [1, 8192]",
                   max_kpts);
+    SSLAM_REQUIRE(max_pairs >= 1 && max_pairs <= MAX_PAIRS, "sslam_lightglue_create: max_pairs %d not in [1, %d]",
+                  max_pairs, MAX_PAIRS);
     SSLAM_HIP_CHECK(hipSetDevice(ctx->device));
     sslam_lightglue* g = new sslam_lightglue();
     g->ctx = ctx;
     const int Kc = (max_kpts + 127) / 128 * 128;     // whole attention / GEMM row blocks
     g->Kc = Kc;
-    g->KS = Kc >= 1024 ? 4 : (Kc >= 512 ? 2 : 1);
-    const size_t K = (size_t)Kc;
+    g->NB = max_pairs; g->NIc = 2 * max_pairs;
+    g->KSmax = Kc >= 1024 ? 4 : (Kc >= 512 ? 2 : 1);
+    const size_t K = (size_t)Kc, NI = (size_t)g->NIc, NB = (size_t)max_pairs;
     auto carve = [&](sslam::Arena& A) {
         g->blob = A.take<float>(n_floats);
-        g->ctrl = A.take<LGCtrl>(1);
-        g->x = A.take<float>(2 * K * D); g->msg = A.take<float>(2 * K * D); g->msg2 = A.take<float>(2 * K * D);
-        g->tx = A.take<float>(2 * K * D); g->md = A.take<float>(2 * K * D);
-        g->hid = A.take<float>(2 * K * 2 * D);
-        g->q = A.take<float>(2 * K * D); g->k = A.take<float>(2 * K * D); g->v = A.take<float>(2 * K * D);
-        g->enc_cos = A.take<float>(2 * K * ENC); g->enc_sin = A.take<float>(2 * K * ENC);
-        g->tc = A.take<float>(2 * K * ENC); g->ts = A.take<float>(2 * K * ENC);
-        g->o_part = A.take<float>((size_t)g->KS * 2 * NH * K * DH);
-        g->m_part = A.take<float>((size_t)g->KS * 2 * NH * K);
-        g->l_part = A.take<float>((size_t)g->KS * 2 * NH * K);
-        g->conf = A.take<float>(2 * K); g->mat = A.take<float>(2 * K); g->bbox = A.take<float>(8);
-        g->sim = A.take<float>(K * K);
-        g->rmax = A.take<float>(K); g->rlog = A.take<float>(K); g->cmax = A.take<float>(K);
-        g->clog = A.take<float>(K); g->best0 = A.take<float>(K);
-        g->ind = A.take<int>(2 * K); g->gmap = A.take<int>(2 * K); g->prune = A.take<int>(2 * K);
-        g->arg0 = A.take<int>(K); g->arg1 = A.take<int>(K);
-        g->cpmax = A.take<float>(CSLAB * K); g->cpsum = A.take<float>(CSLAB * K);
-        g->cpval = A.take<float>(CSLAB * K); g->cparg = A.take<int>(CSLAB * K);
-        g->in_xy = A.take<float>(2 * K * 2); g->in_desc = A.take<float>(2 * K * DIN);
+        g->ctrl = A.take<LGCtrl>(NB);
+        g->x = A.take<float>(NI * K * D); g->msg = A.take<float>(NI * K * D);
+        g->tx = A.take<float>(NI * K * D); g->md = A.take<float>(NI * K * D);
+        g->hid = A.take<float>(NI * K * 2 * D);
+        g->q = A.take<float>(NI * K * D); g->k = A.take<float>(NI * K * D); g->v = A.take<float>(NI * K * D);
+        g->enc_cos = A.take<float>(NI * K * ENC); g->enc_sin = A.take<float>(NI * K * ENC);
+        g->tc = A.take<float>(NI * K * ENC); g->ts = A.take<float>(NI * K * ENC);
+        g->o_part = A.take<float>((size_t)g->KSmax * NI * NH * K * DH);
+        g->m_part = A.take<float>((size_t)g->KSmax * NI * NH * K);
+        g->l_part = A.take<float>((size_t)g->KSmax * NI * NH * K);
+        g->conf = A.take<float>(NI * K); g->mat = A.take<float>(NI * K); g->bbox = A.take<float>(NI * 4);
+        g->sim = A.take<float>(NB * K * K);
+        g->rmax = A.take<float>(NB * K); g->rlog = A.take<float>(NB * K); g->cmax = A.take<float>(NB * K);
+        g->clog = A.take<float>(NB * K); g->best0 = A.take<float>(NB * K);
+        g->ind = A.take<int>(NI * K); g->gmap = A.take<int>(NI * K); g->prune = A.take<int>(NI * K);
+        g->arg0 = A.take<int>(NB * K);
+        g->cpmax = A.take<float>(NB * CSLAB * K); g->cpsum = A.take<float>(NB * CSLAB * K);
+        g->cpval = A.take<float>(NB * CSLAB * K); g->cparg = A.take<int>(NB * CSLAB * K);
+        g->in_xy = A.take<float>(NI * K * 2); g->in_desc = A.take<float>(NI * K * DIN);
+        g->up_xy = A.take<float>(2 * K * 2); g->up_desc = A.take<float>(2 * K * DIN);
         g->out_ij = A.take<int32_t>(2 * K); g->out_score = A.take<float>(K); g->out_info = A.take<int32_t>(8);
         g->w_hi = A.take<_Float16>(n_floats); g->w_lo = A.take<_Float16>(n_floats);
-        g->xs_hi = A.take<_Float16>(2 * K * D); g->xs_lo = A.take<_Float16>(2 * K * D);
-        g->msgs_hi = A.take<_Float16>(2 * K * D); g->msgs_lo = A.take<_Float16>(2 * K * D);
-        g->msg2s_hi = A.take<_Float16>(2 * K * D); g->msg2s_lo = A.take<_Float16>(2 * K * D);
-        g->hids_hi = A.take<_Float16>(2 * K * 2 * D); g->hids_lo = A.take<_Float16>(2 * K * 2 * D);
-        g->qs_hi = A.take<_Float16>(2 * K * D); g->qs_lo = A.take<_Float16>(2 * K * D);
-        g->ks_hi = A.take<_Float16>(2 * K * D); g->ks_lo = A.take<_Float16>(2 * K * D);
-        g->vts_hi = A.take<_Float16>(2 * K * D); g->vts_lo = A.take<_Float16>(2 * K * D);
+        g->xs_hi = A.take<_Float16>(NI * K * D); g->xs_lo = A.take<_Float16>(NI * K * D);
+        g->msgs_hi = A.take<_Float16>(NI * K * D); g->msgs_lo = A.take<_Float16>(NI * K * D);
+        g->hids_hi = A.take<_Float16>(NI * K * 2 * D); g->hids_lo = A.take<_Float16>(NI * K * 2 * D);
+        g->qs_hi = A.take<_Float16>(NI * K * D); g->qs_lo = A.take<_Float16>(NI * K * D);
+        g->ks_hi = A.take<_Float16>(NI * K * D); g->ks_lo = A.take<_Float16>(NI * K * D);
+        g->vts_hi = A.take<_Float16>(NI * K * D); g->vts_lo = A.take<_Float16>(NI * K * D);
     };
     sslam::Arena probe;
     probe.measure();
@@ -1785,6 +1894,11 @@ int sslam_lightglue_create(sslam_ctx* ctx, const float* weights, size_t n_floats
     return 0;
 }
 
+int sslam_lightglue_create(sslam_ctx* ctx, const float* weights, size_t n_floats, int max_kpts,
+                           sslam_lightglue** out) {
+    return sslam_lightglue_create_batched(ctx, weights, n_floats, max_kpts, 1, out);
+}
+
 int sslam_lightglue_destroy(sslam_lightglue* g) {
     if (!g) return 0;
     (void)hipStreamSynchronize(g->ctx->stream);
@@ -1802,6 +1916,34 @@ int sslam_lightglue_set_conf(sslam_lightglue* g, float depth_confidence, float w
     return 0;
 }
 
+int sslam_lightglue_match_batch_dev(sslam_lightglue* g, int n_pairs, const float* const* xy0,
+                                    const float* const* desc0, const int32_t* const* m_dev, const int32_t* M,
+                                    const float* const* xy1, const float* const* desc1,
+                                    const int32_t* const* n_dev, const int32_t* N, float min_conf,
+                                    int32_t* ij_out, float* score_out, int32_t* info_out, int out_stride) {
+    SSLAM_REQUIRE(g && xy0 && desc0 && xy1 && desc1 && M && N && ij_out && score_out && info_out,
+                  "sslam_lightglue_match_batch_dev: NULL argument");
+    SSLAM_REQUIRE(n_pairs >= 1 && n_pairs <= g->NB, "sslam_lightglue_match_batch_dev: %d pairs, capacity %d",
+                  n_pairs, g->NB);
+    SSLAM_REQUIRE(out_stride >= 1, "sslam_lightglue_match_batch_dev: out_stride %d", out_stride);
+    StageSrc src{};
+    for (int p = 0; p < n_pairs; ++p) {
+        SSLAM_REQUIRE(M[p] >= 0 && N[p] >= 0 && M[p] <= g->Kc && N[p] <= g->Kc,
+                      "sslam_lightglue_match_batch_dev: pair %d: M=%d N=%d exceed max_kpts capacity %d", p, M[p],
+                      N[p], g->Kc);
+        SSLAM_REQUIRE((M[p] == 0 || (xy0[p] && desc0[p])) && (N[p] == 0 || (xy1[p] && desc1[p])),
+                      "sslam_lightglue_match_batch_dev: pair %d: NULL input", p);
+        SSLAM_REQUIRE((M[p] < N[p] ? M[p] : N[p]) <= out_stride,
+                      "sslam_lightglue_match_batch_dev: pair %d can emit %d matches, out_stride is %d", p,
+                      M[p] < N[p] ? M[p] : N[p], out_stride);
+        src.xy[2 * p] = xy0[p]; src.desc[2 * p] = desc0[p]; src.bound[2 * p] = M[p];
+        src.cnt[2 * p] = m_dev ? m_dev[p] : nullptr;
+        src.xy[2 * p + 1] = xy1[p]; src.desc[2 * p + 1] = desc1[p]; src.bound[2 * p + 1] = N[p];
+        src.cnt[2 * p + 1] = n_dev ? n_dev[p] : nullptr;
+    }
+    return lg_enqueue(g, n_pairs, src, min_conf, ij_out, score_out, info_out, out_stride);
+}
+
 int sslam_lightglue_match_dev(sslam_lightglue* g, const float* xy0, const float* desc0, int M,
                               const float* xy1, const float* desc1, int N, const int32_t* m_dev,
                               const int32_t* n_dev, float min_conf, int32_t* ij_out, float* score_out,
@@ -1811,17 +1953,10 @@ int sslam_lightglue_match_dev(sslam_lightglue* g, const float* xy0, const float*
                   "sslam_lightglue_match_dev: M=%d N=%d exceed max_kpts capacity %d", M, N, g->Kc);
     SSLAM_REQUIRE((M == 0 || (xy0 && desc0)) && (N == 0 || (xy1 && desc1)),
                   "sslam_lightglue_match_dev: NULL input");
-    hipStream_t s = g->ctx->stream;
-    const size_t K = (size_t)g->Kc;
-    if (M) {
-        SSLAM_HIP_CHECK(hipMemcpyAsync(g->in_xy, xy0, (size_t)M * 8, hipMemcpyDeviceToDevice, s));
-        SSLAM_HIP_CHECK(hipMemcpyAsync(g->in_desc, desc0, (size_t)M * DIN * 4, hipMemcpyDeviceToDevice, s));
-    }
-    if (N) {
-        SSLAM_HIP_CHECK(hipMemcpyAsync(g->in_xy + 2 * K, xy1, (size_t)N * 8, hipMemcpyDeviceToDevice, s));
-        SSLAM_HIP_CHECK(hipMemcpyAsync(g->in_desc + K * DIN, desc1, (size_t)N * DIN * 4, hipMemcpyDeviceToDevice, s));
-    }
-    return lg_enqueue(g, M, N, m_dev, n_dev, min_conf, ij_out, score_out, info_out);
+    StageSrc src{};
+    src.xy[0] = xy0; src.desc[0] = desc0; src.cnt[0] = m_dev; src.bound[0] = M;
+    src.xy[1] = xy1; src.desc[1] = desc1; src.cnt[1] = n_dev; src.bound[1] = N;
+    return lg_enqueue(g, 1, src, min_conf, ij_out, score_out, info_out, g->Kc);
 }
 
 int sslam_lightglue_match_host(sslam_lightglue* g, const float* xy0, const float* desc0, int M,
@@ -1838,11 +1973,14 @@ int sslam_lightglue_match_host(sslam_lightglue* g, const float* xy0, const float
     SSLAM_HIP_CHECK(hipSetDevice(g->ctx->device));
     hipStream_t s = g->ctx->stream;
     const size_t K = (size_t)g->Kc;
-    SSLAM_HIP_CHECK(hipMemcpyAsync(g->in_xy, xy0, (size_t)M * 8, hipMemcpyHostToDevice, s));
-    SSLAM_HIP_CHECK(hipMemcpyAsync(g->in_desc, desc0, (size_t)M * DIN * 4, hipMemcpyHostToDevice, s));
-    SSLAM_HIP_CHECK(hipMemcpyAsync(g->in_xy + 2 * K, xy1, (size_t)N * 8, hipMemcpyHostToDevice, s));
-    SSLAM_HIP_CHECK(hipMemcpyAsync(g->in_desc + K * DIN, desc1, (size_t)N * DIN * 4, hipMemcpyHostToDevice, s));
-    if (int rc = lg_enqueue(g, M, N, nullptr, nullptr, min_conf, g->out_ij, g->out_score, g->out_info)) return rc;
+    SSLAM_HIP_CHECK(hipMemcpyAsync(g->up_xy, xy0, (size_t)M * 8, hipMemcpyHostToDevice, s));
+    SSLAM_HIP_CHECK(hipMemcpyAsync(g->up_desc, desc0, (size_t)M * DIN * 4, hipMemcpyHostToDevice, s));
+    SSLAM_HIP_CHECK(hipMemcpyAsync(g->up_xy + 2 * K, xy1, (size_t)N * 8, hipMemcpyHostToDevice, s));
+    SSLAM_HIP_CHECK(hipMemcpyAsync(g->up_desc + K * DIN, desc1, (size_t)N * DIN * 4, hipMemcpyHostToDevice, s));
+    StageSrc src{};
+    src.xy[0] = g->up_xy; src.desc[0] = g->up_desc; src.bound[0] = M;
+    src.xy[1] = g->up_xy + 2 * K; src.desc[1] = g->up_desc + K * DIN; src.bound[1] = N;
+    if (int rc = lg_enqueue(g, 1, src, min_conf, g->out_ij, g->out_score, g->out_info, (long)K)) return rc;
     int32_t info[4];
     SSLAM_HIP_CHECK(hipMemcpyAsync(info, g->out_info, sizeof(info), hipMemcpyDeviceToHost, s));
     SSLAM_HIP_CHECK(hipStreamSynchronize(s));
@@ -1858,20 +1996,25 @@ int sslam_lightglue_match_host(sslam_lightglue* g, const float* xy0, const float
     return 0;
 }
 
-/* Test hook: copy an internal buffer to the host after a match call.
+/* Test hook: copy an internal buffer to the host after a match call (pair 0 of the last batch
+ * unless `which` has 0x100 * pair added).
  * which: 0 = x (token states) [2][Kc][256], 1 = sim [Kc][Kc], 2 = ind [2][Kc] (int32),
- *        3 = prune counters [2][Kc] (int32), 4 = info {K, stop, n0, n1}, 5 = enc_cos [2][Kc][32] */
+ *        3 = prune counters [2][Kc] (int32), 4 = info {K, stop, n0, n1} (single-pair host call),
+ *        5 = enc_cos [2][Kc][32] */
 int sslam_lightglue_debug_read(sslam_lightglue* g, int which, void* dst, size_t bytes) {
     SSLAM_REQUIRE(g && dst, "sslam_lightglue_debug_read: NULL argument");
     const size_t K = (size_t)g->Kc;
-    const void* src = nullptr; size_t cap = 0;
+    const int pair = which >> 8;
+    which &= 0xff;
+    SSLAM_REQUIRE(pair >= 0 && pair < g->NB, "sslam_lightglue_debug_read: pair %d out of range", pair);
+    const char* src = nullptr; size_t cap = 0;
     switch (which) {
-        case 0: src = g->x; cap = 2 * K * D * 4; break;
-        case 1: src = g->sim; cap = K * K * 4; break;
-        case 2: src = g->ind; cap = 2 * K * 4; break;
-        case 3: src = g->prune; cap = 2 * K * 4; break;
-        case 4: src = g->out_info; cap = 16; break;
-        case 5: src = g->enc_cos; cap = 2 * K * ENC * 4; break;
+        case 0: cap = 2 * K * D * 4; src = (const char*)g->x + pair * cap; break;
+        case 1: cap = K * K * 4; src = (const char*)g->sim + pair * cap; break;
+        case 2: cap = 2 * K * 4; src = (const char*)g->ind + pair * cap; break;
+        case 3: cap = 2 * K * 4; src = (const char*)g->prune + pair * cap; break;
+        case 4: cap = 16; src = (const char*)g->out_info; break;
+        case 5: cap = 2 * K * ENC * 4; src = (const char*)g->enc_cos + pair * cap; break;
         default: SSLAM_REQUIRE(false, "sslam_lightglue_debug_read: unknown buffer %d", which);
     }
     SSLAM_REQUIRE(bytes <= cap, "sslam_lightglue_debug_read: %zu bytes requested, buffer has %zu", bytes, cap);
@@ -1920,9 +2063,23 @@ int sslam_lightglue_debug_layers(sslam_lightglue* g, int layers, int self_only) 
     return 0;
 }
 
+/* Test hook: force the key split of the attention launches (0 = chosen by batch size). */
+int sslam_lightglue_debug_key_split(sslam_lightglue* g, int ks) {
+    SSLAM_REQUIRE(g != nullptr && (ks == 0 || ks == 1 || ks == 2 || ks == 4),
+                  "sslam_lightglue_debug_key_split: ks must be 0, 1, 2 or 4");
+    g->force_ks = ks;
+    return 0;
+}
+
 int sslam_lightglue_capacity(sslam_lightglue* g, int* kc_out) {
     SSLAM_REQUIRE(g && kc_out, "sslam_lightglue_capacity: NULL argument");
     *kc_out = g->Kc;
+    return 0;
+}
+
+int sslam_lightglue_batch_capacity(sslam_lightglue* g, int* pairs_out) {
+    SSLAM_REQUIRE(g && pairs_out, "sslam_lightglue_batch_capacity: NULL argument");
+    *pairs_out = g->NB;
     return 0;
 }
 

@@ -17,15 +17,16 @@ class LightGlueHIP:
     default_conf = dict(depth_confidence=0.95, width_confidence=0.99, filter_threshold=0.1,
                         prune_min_kpts=-1)
 
-    def __init__(self, state_dict=None, max_kpts: int = 4096, ctx=None, **conf):
+    def __init__(self, state_dict=None, max_kpts: int = 4096, ctx=None, max_pairs: int = 1, **conf):
         self.ctx = ctx or _native.default_context()
         self.state_dict = state_dict if state_dict is not None else W.random_lightglue_state_dict(0)
         blob = W.pack_lightglue(self.state_dict)
         h = C.c_void_p()
-        _native.check(_native.lib().sslam_lightglue_create(
-            self.ctx.handle, _native.ptr(blob), blob.size, int(max_kpts), C.byref(h)),
-            "sslam_lightglue_create")
+        _native.check(_native.lib().sslam_lightglue_create_batched(
+            self.ctx.handle, _native.ptr(blob), blob.size, int(max_kpts), int(max_pairs), C.byref(h)),
+            "sslam_lightglue_create_batched")
         self.handle = h
+        self.max_pairs = int(max_pairs)
         kc = C.c_int()
         _native.check(_native.lib().sslam_lightglue_capacity(h, C.byref(kc)))
         self.capacity = int(kc.value)
@@ -84,6 +85,32 @@ class LightGlueHIP:
         _native.check(_native.lib().sslam_lightglue_match_dev(
             self.handle, P(xy0), P(desc0), int(M), P(xy1), P(desc1), int(N), P(m_dev), P(n_dev),
             float(min_conf), P(ij_out), P(score_out), P(info_out)), "sslam_lightglue_match_dev")
+
+    def match_batch_dev(self, pairs, ij_out, score_out, info_out, out_stride, min_conf=0.7):
+        """One enqueue for a list of pairs.  pairs: sequence of (xy0, desc0, M, xy1, desc1, N[, m_dev,
+        n_dev]) with device pointers (ints or torch tensors).  Outputs: device buffers holding
+        [n_pairs][out_stride][2] int32, [n_pairs][out_stride] float32, [n_pairs][4] int32."""
+        n = len(pairs)
+        if not 1 <= n <= self.max_pairs:
+            raise ValueError(f"{n} pairs, instance capacity is {self.max_pairs}")
+        vp = C.c_void_p * n
+
+        def col(i):
+            vals = []
+            for pr in pairs:
+                v = pr[i] if len(pr) > i else None
+                vals.append(None if v is None else _native.ptr(v))
+            return vp(*vals)
+        ia = C.c_int32 * n
+        _native.check(_native.lib().sslam_lightglue_match_batch_dev(
+            self.handle, n, col(0), col(1), col(6), ia(*[int(pr[2]) for pr in pairs]),
+            col(3), col(4), col(7), ia(*[int(pr[5]) for pr in pairs]), float(min_conf),
+            _native.ptr(ij_out), _native.ptr(score_out), _native.ptr(info_out), int(out_stride)),
+            "sslam_lightglue_match_batch_dev")
+
+    def debug_key_split(self, ks: int):
+        """Test hook: force the key split of the attention launches (0 = by batch size)."""
+        _native.check(_native.lib().sslam_lightglue_debug_key_split(self.handle, int(ks)))
 
     def debug_read(self, which: int, shape, dtype=np.float32):
         out = np.empty(shape, dtype)

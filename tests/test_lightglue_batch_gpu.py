@@ -1,0 +1,138 @@
+"""GPU: the batched LightGlue entry point (`sslam_lightglue_match_batch_dev`).
+
+A batch is n independent pairs in one enqueue (every launch covers all pairs).  Bar: every pair's
+result equals the single-pair call's - bit for bit when both run the same key split of the
+attention launches, and index-identical to the torch-CPU oracle in every configuration (ragged
+sizes, an empty image, early stop and point pruning decided per pair, a partly filled batch)."""
+import numpy as np
+import pytest
+
+import lg_inputs
+from conftest import load_pkg
+from oracle import lightglue_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+class DevBatch:
+    """Device-resident inputs / outputs of one batch, on raw context allocations (no torch)."""
+
+    def __init__(self, ctx, pairs, stride):
+        self.ctx, self.stride, self.n = ctx, stride, len(pairs)
+        self.ptrs, self.args = [], []
+        for k0, d0, k1, d1 in pairs:
+            a = [ctx.upload(np.ascontiguousarray(v, np.float32)) for v in (k0, d0, k1, d1)]
+            self.ptrs += a
+            self.args.append((a[0], a[1], len(k0), a[2], a[3], len(k1)))
+        self.ij = ctx.malloc(self.n * stride * 8)
+        self.sc = ctx.malloc(self.n * stride * 4)
+        self.info = ctx.malloc(self.n * 16)
+        self.ptrs += [self.ij, self.sc, self.info]
+
+    def run(self, lg, min_conf):
+        lg.match_batch_dev(self.args, self.ij, self.sc, self.info, self.stride, min_conf=min_conf)
+        self.ctx.sync()
+        ij = np.empty((self.n, self.stride, 2), np.int32)
+        sc = np.empty((self.n, self.stride), np.float32)
+        info = np.empty((self.n, 4), np.int32)
+        self.ctx.d2h(ij, self.ij); self.ctx.d2h(sc, self.sc); self.ctx.d2h(info, self.info)
+        return [(ij[p, :info[p, 0]].copy(), sc[p, :info[p, 0]].copy(), info[p].copy()) for p in range(self.n)]
+
+    def free(self):
+        for p in self.ptrs:
+            self.ctx.free(p)
+
+
+def _oracle(sd, pair, min_conf, conf=None):
+    ref = R.lightglue_forward(sd, *pair, conf)
+    keep = ref["scores"] > min_conf
+    return ref["matches"][keep].numpy(), ref["scores"][keep].numpy(), ref["stop"]
+
+
+def test_batch_equals_single_pair_calls_and_oracle(gpu_ctx):
+    W, LG = load_pkg("weights"), load_pkg("lightglue").LightGlueHIP
+    sd = W.random_lightglue_state_dict(1, match_gain=4.0, match_bias=3.0)
+    sizes = [(512, 512), (300, 417), (64, 33), (640, 1), (129, 128)]
+    pairs = [lg_inputs.make_pair(m, n, seed=m + n) for m, n in sizes]
+    batch = LG(sd, max_kpts=640, max_pairs=6, ctx=gpu_ctx)
+    single = LG(sd, max_kpts=640, ctx=gpu_ctx)
+    dev = DevBatch(gpu_ctx, pairs, 640)
+    got = dev.run(batch, 0.7)
+    for ks in (0, 1):                      # the single-pair default (key split + merge), then the batch's own
+        single.debug_key_split(ks)
+        batch.debug_key_split(ks)
+        got = dev.run(batch, 0.7)
+        for pr, (ij, sc, info) in zip(pairs, got):
+            s_ij, s_sc, s_stop = single.match(*pr, min_conf=0.7)
+            np.testing.assert_array_equal(ij, s_ij)
+            assert info[1] == s_stop
+            np.testing.assert_array_equal(sc, s_sc)          # same arithmetic -> bit-identical scores
+            o_ij, o_sc, o_stop = _oracle(sd, pr, 0.7)
+            np.testing.assert_array_equal(ij, o_ij)
+            np.testing.assert_allclose(sc, o_sc, atol=1e-3, rtol=1e-3)
+            assert info[1] == o_stop
+    # default key-split policy of a batch differs from the single-pair one: indices still identical
+    batch.debug_key_split(0); single.debug_key_split(0)
+    assert sum(len(g[0]) for g in got) > 300
+    dev.free(); batch.close(); single.close()
+
+
+def test_batch_with_an_empty_image_early_stop_and_pruning_per_pair(gpu_ctx):
+    """Control flow is per pair: one pair stops after layer 1, one prunes, one has an empty image."""
+    W, LG = load_pkg("weights"), load_pkg("lightglue").LightGlueHIP
+    sd = W.random_lightglue_state_dict(4, match_gain=4.0, match_bias=-4.6, conf_bias=2.3)
+    pairs = [lg_inputs.make_pair(400, 350, seed=6), lg_inputs.make_pair(256, seed=7),
+             lg_inputs.make_pair(128, 200, seed=8)]
+    k0, d0, k1, d1 = lg_inputs.make_pair(64, seed=9)
+    pairs.append((k0[:0], d0[:0], k1, d1))                     # empty query image -> no matches, no fault
+    batch = LG(sd, max_kpts=512, max_pairs=4, ctx=gpu_ctx)
+    dev = DevBatch(gpu_ctx, pairs, 512)
+    got = dev.run(batch, 0.0)
+    stops = set()
+    for pr, (ij, sc, info) in zip(pairs[:3], got[:3]):
+        o_ij, o_sc, o_stop = _oracle(sd, pr, 0.0)
+        np.testing.assert_array_equal(ij, o_ij)
+        np.testing.assert_allclose(sc, o_sc, atol=1e-3, rtol=1e-3)
+        assert info[1] == o_stop
+        stops.add(int(info[1]))
+    assert got[0][2][2] < 400 or got[0][2][3] < 350            # pruning really happened in pair 0
+    assert len(got[3][0]) == 0 and got[3][2][0] == 0
+    # a second, smaller batch on the same instance (stale state of pairs 2, 3 must not leak)
+    dev2 = DevBatch(gpu_ctx, pairs[1:3], 512)
+    got2 = dev2.run(batch, 0.0)
+    for a, b in zip(got2, got[1:3]):
+        np.testing.assert_array_equal(a[0], b[0]); np.testing.assert_array_equal(a[1], b[1])
+    dev.free(); dev2.free(); batch.close()
+
+
+def test_batch_at_c2_size_no_key_split(gpu_ctx):
+    """4 pairs of 2048 x 2048 keypoints (BASELINE C2 size): the attention launches run un-split
+    (one workgroup sees every key of its queries, context written straight to the split planes)."""
+    W, LG = load_pkg("weights"), load_pkg("lightglue").LightGlueHIP
+    sd = W.random_lightglue_state_dict(2, match_gain=4.0, match_bias=3.0)
+    pairs = [lg_inputs.make_pair(2048, seed=11 + i) for i in range(3)] + [lg_inputs.make_pair(2048, 1900, seed=20)]
+    batch = LG(sd, max_kpts=2048, max_pairs=4, ctx=gpu_ctx)
+    dev = DevBatch(gpu_ctx, pairs, 2048)
+    got = dev.run(batch, 0.7)
+    for pr, (ij, sc, info) in zip(pairs[:2] + pairs[3:], got[:2] + got[3:]):        # oracle at 2048 is slow: 3 of 4
+        o_ij, o_sc, o_stop = _oracle(sd, pr, 0.7)
+        np.testing.assert_array_equal(ij, o_ij)
+        np.testing.assert_allclose(sc, o_sc, atol=1e-3, rtol=1e-3)
+        assert info[1] == o_stop == 9 and len(ij) > 100
+    dev.free(); batch.close()
+
+
+def test_batch_argument_errors(gpu_ctx, native):
+    W, LG = load_pkg("weights"), load_pkg("lightglue").LightGlueHIP
+    lg = LG(W.random_lightglue_state_dict(0), max_kpts=128, max_pairs=2, ctx=gpu_ctx)
+    pairs = [lg_inputs.make_pair(16, seed=1)] * 3
+    dev = DevBatch(gpu_ctx, pairs, 128)
+    with pytest.raises(ValueError, match="capacity"):
+        dev.run(lg, 0.5)
+    dev.args = dev.args[:2]; dev.n = 2
+    dev.stride = 8                                           # fewer rows than a pair can emit
+    with pytest.raises(native.NativeError, match="out_stride"):
+        lg.match_batch_dev(dev.args, dev.ij, dev.sc, dev.info, 8)
+    with pytest.raises(native.NativeError, match="max_pairs"):
+        LG(W.random_lightglue_state_dict(0), max_kpts=128, max_pairs=17, ctx=gpu_ctx)
+    dev.free(); lg.close()
