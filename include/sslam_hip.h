@@ -213,6 +213,7 @@ int sslam_lightglue_profile_read(sslam_lightglue* lg, float* total_ms_out, int32
 /* Test hooks: limit the executed layers; copy an internal buffer to the host. */
 int sslam_lightglue_debug_layers(sslam_lightglue* lg, int layers, int self_only);
 int sslam_lightglue_debug_key_split(sslam_lightglue* lg, int ks);
+int sslam_lightglue_debug_big_gemm(sslam_lightglue* lg, int mode);
 int sslam_lightglue_debug_read(sslam_lightglue* lg, int which, void* dst, size_t bytes);
 
 #ifdef __cplusplus

@@ -28,6 +28,7 @@
 #include "common.hpp"
 #include "gemm_f32.hpp"
 #include "gemm_f16x3.hpp"
+#include "gemm_f16x3_big.hpp"
 
 namespace {
 
@@ -950,37 +951,21 @@ constexpr int ring_depth() {
     return d > RING_MAX ? RING_MAX : (d < 2 ? 2 : d);
 }
 
-template <int BM, int BN, int TM, int TN, int EPI>
-__global__ __launch_bounds__(512) void lg_linear_h_kernel(LinearArgsH p) {
-    extern __shared__ __attribute__((aligned(16))) _Float16 lg_ring[];
-    int rb, cb;
-    xcd_tile(gridDim.x, rb, cb);
-    const int nb = (p.Kc + BM - 1) / BM;
-    RowDom rd;
-    rd.img = rb / nb; rd.row0 = (rb % nb) * BM; rd.n = n_of(p.ctrl, rd.img);
-    if (ctrl_of(p.ctrl, rd.img).stop) return;
-    if (rd.row0 >= rd.n) return;
-    const int col0 = cb * BN;
-    const size_t ibase = (size_t)rd.img * p.Kc;
-    GemmAH ga{{p.A0.hi, p.A0.lo}, {p.A1.hi ? p.A1.hi : p.A0.hi, p.A1.lo ? p.A1.lo : p.A0.lo}, p.lda, p.K0};
-    f32x16 c1[TM][TN], c2[TM][TN];
-    // plane rows are global token rows (image-major, 2*Kc per panel); clamp inside this image
-    gemm_mainloop_ring<BM, BN, TM, TN, ring_depth<BM, BN>()>(ga, p.W, p.NIc * p.Kc, p.K, (int)ibase + rd.row0,
-                                                             (int)ibase + p.Kc, col0, p.N, lg_ring, c1, c2);
-    if (threadIdx.x >= 256) return;                    // producer waves (4-7) are done
-#if defined(SSLAM_DBG_NOEPI)
-    if (c1[0][0][0] != 123456.0f) return;
-#endif
-
+// ---- shared epilogue of the split-precision linears (ring kernel: 4 consumer waves as 2 x 2; big-tile
+// kernel: 8 waves as WM x WN).  `lds` is the (now free) operand ring, NT the threads taking part.
+template <int BM, int BN, int TM, int TN, int WN, int NT, int EPI>
+__device__ __forceinline__ void linear_h_epilogue(const LinearArgsH& p, const RowDom& rd, int col0, size_t ibase,
+                                                  const f32x16 (&c1)[TM][TN], const f32x16 (&c2)[TM][TN],
+                                                  _Float16* lds) {
     // ---- epilogue.  The accumulator tile has its columns on lanes and its rows in registers, so a
     // direct store would be 2-byte (split planes) or 4-byte pieces per lane and is store-issue bound
     // (measured 5-13 us of a 18-24 us kernel).  Stage the fp32 tile in LDS (the ring is free now),
     // then every thread owns 8 consecutive columns of one row (or 8 consecutive rows of one V
     // column) and writes 16-byte pieces.
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     constexpr int ELD = BN + 4;                        // fp32 row stride of the staged tile
-    float* epi = reinterpret_cast<float*>(lg_ring);
+    float* epi = reinterpret_cast<float*>(lds);
     __syncthreads();                                   // consumers are done with the last k-tile
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1005,7 +990,7 @@ __global__ __launch_bounds__(512) void lg_linear_h_kernel(LinearArgsH p) {
         lo = *reinterpret_cast<uint4*>(&ll);
     };
     constexpr int CH = BN / 8;                         // 8-column chunks per row
-    for (int u = t; u < BM * CH; u += 256) {
+    for (int u = t; u < BM * CH; u += NT) {
         const int rl = u / CH, cl = (u % CH) * 8;
         const int row = rd.row0 + rl, col = col0 + cl;
         if (row >= rd.n) continue;
@@ -1066,7 +1051,7 @@ __global__ __launch_bounds__(512) void lg_linear_h_kernel(LinearArgsH p) {
         // a unit = one column x 8 consecutive rows (tokens)
         constexpr int VCOL0 = (EPI == EPH_QKV) ? 2 * D : D;
         constexpr int RG = BM / 8;
-        for (int u = t; u < BN * RG; u += 256) {
+        for (int u = t; u < BN * RG; u += NT) {
             const int cl = u % BN, rg = u / BN;
             const int col = col0 + cl;
             if (col < VCOL0) continue;
@@ -1084,6 +1069,51 @@ __global__ __launch_bounds__(512) void lg_linear_h_kernel(LinearArgsH p) {
             *reinterpret_cast<uint4*>(p.vt.lo + o) = lo;
         }
     }
+}
+
+template <int BM, int BN, int TM, int TN, int EPI>
+__global__ __launch_bounds__(512) void lg_linear_h_kernel(LinearArgsH p) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lg_ring[];
+    int rb, cb;
+    xcd_tile(gridDim.x, rb, cb);
+    const int nb = (p.Kc + BM - 1) / BM;
+    RowDom rd;
+    rd.img = rb / nb; rd.row0 = (rb % nb) * BM; rd.n = n_of(p.ctrl, rd.img);
+    if (ctrl_of(p.ctrl, rd.img).stop) return;
+    if (rd.row0 >= rd.n) return;
+    const int col0 = cb * BN;
+    const size_t ibase = (size_t)rd.img * p.Kc;
+    GemmAH ga{{p.A0.hi, p.A0.lo}, {p.A1.hi ? p.A1.hi : p.A0.hi, p.A1.lo ? p.A1.lo : p.A0.lo}, p.lda, p.K0};
+    f32x16 c1[TM][TN], c2[TM][TN];
+    // plane rows are global token rows (image-major, NIc*Kc per panel); clamp inside this image
+    gemm_mainloop_ring<BM, BN, TM, TN, ring_depth<BM, BN>()>(ga, p.W, p.NIc * p.Kc, p.K, (int)ibase + rd.row0,
+                                                             (int)ibase + p.Kc, col0, p.N, lg_ring, c1, c2);
+    if (threadIdx.x >= 256) return;                    // producer waves (4-7) are done
+#if defined(SSLAM_DBG_NOEPI)
+    if (c1[0][0][0] != 123456.0f) return;
+#endif
+    linear_h_epilogue<BM, BN, TM, TN, 2, 256, EPI>(p, rd, col0, ibase, c1, c2, lg_ring);
+}
+
+// Big-tile form for batched token sets (gemm_f16x3_big.hpp): 8 waves, each loads and multiplies.
+template <int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(512, 2) void lg_linear_big_kernel(LinearArgsH p) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lg_ring[];
+    constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+    int rb, cb;
+    xcd_tile(gridDim.x, rb, cb);
+    const int nb = (p.Kc + BM - 1) / BM;
+    RowDom rd;
+    rd.img = rb / nb; rd.row0 = (rb % nb) * BM; rd.n = n_of(p.ctrl, rd.img);
+    if (ctrl_of(p.ctrl, rd.img).stop) return;
+    if (rd.row0 >= rd.n) return;
+    const int col0 = cb * BN;
+    const size_t ibase = (size_t)rd.img * p.Kc;
+    GemmAH ga{{p.A0.hi, p.A0.lo}, {p.A1.hi ? p.A1.hi : p.A0.hi, p.A1.lo ? p.A1.lo : p.A0.lo}, p.lda, p.K0};
+    f32x16 c1[TM][TN], c2[TM][TN];
+    sslam::gemm_mainloop_big<BM, BN, WM, WN, 3>(ga, p.W, p.NIc * p.Kc, p.K, (int)ibase + rd.row0,
+                                                (int)ibase + p.Kc, col0, p.N, lg_ring, c1, c2);
+    linear_h_epilogue<BM, BN, TM, TN, WN, 512, EPI>(p, rd, col0, ibase, c1, c2, lg_ring);
 }
 
 // LayerNorm(512) + exact GELU: fp32 hidden in, split planes out (one wave / row)
@@ -1531,6 +1561,7 @@ struct sslam_lightglue {
     int dbg_layers = NL;             // test hook: run only the first dbg_layers layers
     int dbg_self_only = 0;           // test hook: stop after the self block of the last executed layer
     int force_ks = 0;                // test hook: key split of the attention launches (0 = by batch size)
+    int big_gemm = -1;               // test hook: -1 by batch size, 0 / 1 force the ring / big-tile linears
     _Float16 *w_hi, *w_lo;           // whole weight blob, split
     _Float16 *xs_hi, *xs_lo, *msgs_hi, *msgs_lo, *hids_hi, *hids_lo;
     _Float16 *qs_hi, *qs_lo, *ks_hi, *ks_lo, *vts_hi, *vts_lo;
@@ -1643,6 +1674,23 @@ SplitPtr wsp(const sslam_lightglue* g, const float* w) {
     return SplitPtr{g->w_hi + off, g->w_lo + off};
 }
 
+// big-tile launch (batched token sets): 128 x 256 tiles, 8 waves
+template <int BM, int BN, int WM, int WN, int EPI>
+void launch_linear_big(hipStream_t s, int NI, const LinearArgsH& a) {
+    constexpr size_t stage = (size_t)sslam::BIG_STAGES * sslam::big_stage_halves<BM, BN>() * sizeof(_Float16);
+    constexpr size_t epi = (size_t)BM * (BN + 4) * sizeof(float);
+    constexpr size_t lds = stage > epi ? stage : epi;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute((const void*)lg_linear_big_kernel<BM, BN, WM, WN, EPI>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configured = true;
+    }
+    dim3 grid(a.N / BN, NI * sslam::cdiv(a.Kc, BM));
+    hipLaunchKernelGGL((lg_linear_big_kernel<BM, BN, WM, WN, EPI>), grid, dim3(512), lds, s, a);
+}
+
 template <int BM, int BN, int TM, int TN, int EPI>
 void launch_linear_h(hipStream_t s, int NI, const LinearArgsH& a) {
     constexpr size_t lds = (size_t)ring_depth<BM, BN>() * sslam::ring_stage_halves<BM, BN>() * sizeof(_Float16);
@@ -1686,22 +1734,28 @@ void lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, bo
     const SplitPtr qs{g->qs_hi, g->qs_lo}, ks{g->ks_hi, g->ks_lo}, vts{g->vts_hi, g->vts_lo};
     const unsigned tokblocks = sslam::cdiv(NI * g->Kc, 4);
     const float sm_scale = 0.125f * 1.4426950408889634f;        // 1/sqrt(64) * log2(e)
+    // enough token rows for 128-row tiles to fill the chip: the big-tile GEMM (twice the flop per
+    // operand byte taken in by a CU); a single pair keeps the 64-row ring kernel
+    const bool big = g->big_gemm >= 0 ? g->big_gemm != 0 : (long)NI * g->Kc >= 16384 && g->Kc % 128 == 0;
     auto ffn = [&](const float* w1, const float* b1, const float* lnw, const float* lnb, const float* w2,
                    const float* b2) {
         LinearArgsH a = linh(g, xs, msgs, D, D, 2 * D, w1, b1, 2 * D);      // [x | attention context]
         a.out = g->hid; a.ldo = 2 * D;
-        launch_linear_h<64, 128, 1, 2, EPH_F32>(s, NI, a);
+        if (big) launch_linear_big<128, 256, 2, 4, EPH_F32>(s, NI, a);
+        else launch_linear_h<64, 128, 1, 2, EPH_F32>(s, NI, a);
         hipLaunchKernelGGL(lg_ln_gelu_h_kernel, dim3(tokblocks), dim3(256), 0, s, g->hid,
                            SplitOut{g->hids_hi, g->hids_lo}, lnw, lnb, g->ctrl, g->Kc, NI, g->NIc);
         LinearArgsH c = linh(g, hids, none, 2 * D, 2 * D, 2 * D, w2, b2, D);
         c.out = g->x; c.ldo = D; c.outs = SplitOut{g->xs_hi, g->xs_lo};
-        launch_linear_h<64, 64, 1, 1, EPH_RESID>(s, NI, c);
+        if (big) launch_linear_big<128, 256, 2, 4, EPH_RESID>(s, NI, c);
+        else launch_linear_h<64, 64, 1, 1, EPH_RESID>(s, NI, c);
     };
     {   // self block
         LinearArgsH a = linh(g, xs, none, D, D, D, l.wqkv, l.bqkv, 3 * D);
         a.q = SplitOut{g->qs_hi, g->qs_lo}; a.k = SplitOut{g->ks_hi, g->ks_lo}; a.vt = SplitOut{g->vts_hi, g->vts_lo};
         a.q_scale = sm_scale; a.k_scale = 1.0f;
-        launch_linear_h<64, 192, 1, 3, EPH_QKV>(s, NI, a);       // 768 / 192 = 4 column tiles
+        if (big) launch_linear_big<128, 256, 2, 4, EPH_QKV>(s, NI, a);
+        else launch_linear_h<64, 192, 1, 3, EPH_QKV>(s, NI, a);  // 768 / 192 = 4 column tiles
     }
     launch_attention_h(g, s, NI, qs, ks, vts, 0);
     ffn(l.w1, l.b1, l.lnw, l.lnb, l.w2, l.b2);
@@ -1710,7 +1764,8 @@ void lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, bo
         LinearArgsH a = linh(g, xs, none, D, D, D, l.cqkv, l.cbqkv, 2 * D);
         a.q = SplitOut{g->qs_hi, g->qs_lo}; a.vt = SplitOut{g->vts_hi, g->vts_lo};
         a.q_scale = sqrtf(sm_scale);
-        launch_linear_h<64, 128, 1, 2, EPH_CROSS>(s, NI, a);
+        if (big) launch_linear_big<128, 256, 2, 4, EPH_CROSS>(s, NI, a);
+        else launch_linear_h<64, 128, 1, 2, EPH_CROSS>(s, NI, a);
     }
     launch_attention_h(g, s, NI, qs, qs, vts, 1);
     ffn(l.cw1, l.cb1, l.clnw, l.clnb, l.cw2, l.cb2);
@@ -2068,6 +2123,14 @@ int sslam_lightglue_debug_key_split(sslam_lightglue* g, int ks) {
     SSLAM_REQUIRE(g != nullptr && (ks == 0 || ks == 1 || ks == 2 || ks == 4),
                   "sslam_lightglue_debug_key_split: ks must be 0, 1, 2 or 4");
     g->force_ks = ks;
+    return 0;
+}
+
+/* Test hook: -1 = linears chosen by batch size, 0 = always the 64-row ring kernel, 1 = always the
+ * 128 x 256 big-tile kernel. */
+int sslam_lightglue_debug_big_gemm(sslam_lightglue* g, int mode) {
+    SSLAM_REQUIRE(g != nullptr && mode >= -1 && mode <= 1, "sslam_lightglue_debug_big_gemm: bad argument");
+    g->big_gemm = mode;
     return 0;
 }
 

@@ -112,6 +112,10 @@ class LightGlueHIP:
         """Test hook: force the key split of the attention launches (0 = by batch size)."""
         _native.check(_native.lib().sslam_lightglue_debug_key_split(self.handle, int(ks)))
 
+    def debug_big_gemm(self, mode: int):
+        """Test hook: -1 linears by batch size, 0 always the ring kernel, 1 always the big-tile kernel."""
+        _native.check(_native.lib().sslam_lightglue_debug_big_gemm(self.handle, int(mode)))
+
     def debug_read(self, which: int, shape, dtype=np.float32):
         out = np.empty(shape, dtype)
         _native.check(_native.lib().sslam_lightglue_debug_read(self.handle, which, _native.ptr(out), out.nbytes))

@@ -77,6 +77,32 @@ def test_batch_equals_single_pair_calls_and_oracle(gpu_ctx):
     dev.free(); batch.close(); single.close()
 
 
+def test_big_tile_linears_give_the_ring_kernel_results_bit_for_bit(gpu_ctx):
+    """The 128 x 256 big-tile GEMM (batched token sets) and the 64-row ring GEMM accumulate every
+    output in the same k order (ascending k16 steps, hi.hi then the two cross terms), so forcing one
+    or the other changes nothing, down to the last bit of the scores - including ragged row counts,
+    pruning and an early stop."""
+    W, LG = load_pkg("weights"), load_pkg("lightglue").LightGlueHIP
+    for seed, kw in ((1, dict(match_gain=4.0, match_bias=3.0)), (4, dict(match_gain=4.0, match_bias=-4.6, conf_bias=2.3))):
+        sd = W.random_lightglue_state_dict(seed, **kw)
+        pairs = [lg_inputs.make_pair(m, n, seed=m + n) for m, n in [(512, 512), (300, 417), (640, 77), (129, 128)]]
+        batch = LG(sd, max_kpts=640, max_pairs=4, ctx=gpu_ctx)
+        dev = DevBatch(gpu_ctx, pairs, 640)
+        batch.debug_big_gemm(0)
+        ring = dev.run(batch, 0.0)
+        batch.debug_big_gemm(1)
+        big = dev.run(batch, 0.0)
+        for (a_ij, a_sc, a_info), (b_ij, b_sc, b_info), pr in zip(ring, big, pairs):
+            np.testing.assert_array_equal(a_ij, b_ij)
+            np.testing.assert_array_equal(a_sc, b_sc)
+            np.testing.assert_array_equal(a_info, b_info)
+            o_ij, o_sc, o_stop = _oracle(sd, pr, 0.0)
+            np.testing.assert_array_equal(b_ij, o_ij)
+            assert b_info[1] == o_stop
+        assert sum(len(r[0]) for r in big) > 100
+        dev.free(); batch.close()
+
+
 def test_batch_with_an_empty_image_early_stop_and_pruning_per_pair(gpu_ctx):
     """Control flow is per pair: one pair stops after layer 1, one prunes, one has an empty image."""
     W, LG = load_pkg("weights"), load_pkg("lightglue").LightGlueHIP
