@@ -54,6 +54,15 @@ int sslam_malloc(sslam_ctx* ctx, size_t bytes, void** dptr_out);
 int sslam_free(sslam_ctx* ctx, void* dptr);
 int sslam_memcpy_h2d(sslam_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int sslam_memcpy_d2h(sslam_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* Enqueue-only helpers on the context's stream, and events to order one context's stream behind
+ * another's: what the frame pipeline (several extractor / matcher contexts on one GPU) needs, so
+ * the single-GPU product path runs without any other GPU runtime. */
+int sslam_memcpy_d2d_async(sslam_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
+int sslam_memset_async(sslam_ctx* ctx, void* dst_dev, int value, size_t bytes);
+int sslam_event_create(sslam_ctx* ctx, void** event_out);
+int sslam_event_destroy(void* event);
+int sslam_event_record(sslam_ctx* ctx, void* event);      /* on ctx's stream */
+int sslam_ctx_wait_event(sslam_ctx* ctx, void* event);    /* ctx's stream waits, host does not */
 
 /* ------------------------------------------------------------------ local BA
  * Batched reprojection residual + Jacobian.  Replaces the per-observation

@@ -42,6 +42,12 @@ def _signatures():
         "sslam_free": (i32, [vp, vp]),
         "sslam_memcpy_h2d": (i32, [vp, vp, vp, sz]),
         "sslam_memcpy_d2h": (i32, [vp, vp, vp, sz]),
+        "sslam_memcpy_d2d_async": (i32, [vp, vp, vp, sz]),
+        "sslam_memset_async": (i32, [vp, vp, i32, sz]),
+        "sslam_event_create": (i32, [vp, c_void_pp]),
+        "sslam_event_destroy": (i32, [vp]),
+        "sslam_event_record": (i32, [vp, vp]),
+        "sslam_ctx_wait_event": (i32, [vp, vp]),
         "sslam_ba_residual_jacobian_host": (i32, [vp, i32] + [vp] * 3 + [i32, vp, vp, i32, vp, vp] + [vp] * 4),
         "sslam_ba_residual_jacobian_dev": (i32, [vp, i32] + [vp] * 3 + [i32, vp, vp, i32, vp, vp] + [vp] * 4),
         "sslam_ba_solve_host": (i32, [vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, C.c_double, i32, vp]),
@@ -175,6 +181,25 @@ class Context:
 
     def d2h(self, arr: np.ndarray, dptr: int):
         check(lib().sslam_memcpy_d2h(self.handle, ptr(arr), C.c_void_p(dptr), arr.nbytes), "d2h")
+
+    def d2d_async(self, dst: int, src: int, nbytes: int):
+        check(lib().sslam_memcpy_d2d_async(self.handle, C.c_void_p(dst), C.c_void_p(src), int(nbytes)), "d2d")
+
+    def memset_async(self, dst: int, value: int, nbytes: int):
+        check(lib().sslam_memset_async(self.handle, C.c_void_p(dst), int(value), int(nbytes)), "memset")
+
+    def event(self) -> int:
+        e = C.c_void_p()
+        check(lib().sslam_event_create(self.handle, C.byref(e)), "sslam_event_create")
+        return int(e.value)
+
+    def record(self, event: int):
+        """Record `event` on this context's stream."""
+        check(lib().sslam_event_record(self.handle, C.c_void_p(event)), "sslam_event_record")
+
+    def wait(self, event: int):
+        """This context's stream waits for `event` (the host does not block)."""
+        check(lib().sslam_ctx_wait_event(self.handle, C.c_void_p(event)), "sslam_ctx_wait_event")
 
     def upload(self, arr: np.ndarray) -> int:
         arr = np.ascontiguousarray(arr)

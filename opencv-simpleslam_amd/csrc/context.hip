@@ -120,4 +120,44 @@ int sslam_memcpy_d2h(sslam_ctx* ctx, void* dst_host, const void* src_dev, size_t
     return 0;
 }
 
+/* ---- stream ordering without any other GPU runtime (the frame pipeline chains extractor and
+ * matcher contexts with these; nothing here synchronises the host) */
+int sslam_event_create(sslam_ctx* ctx, void** event_out) {
+    SSLAM_REQUIRE(ctx != nullptr && event_out != nullptr, "sslam_event_create: NULL argument");
+    SSLAM_HIP_CHECK(hipSetDevice(ctx->device));
+    hipEvent_t e;
+    SSLAM_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *event_out = (void*)e;
+    return 0;
+}
+
+int sslam_event_destroy(void* event) {
+    if (event) SSLAM_HIP_CHECK(hipEventDestroy((hipEvent_t)event));
+    return 0;
+}
+
+int sslam_event_record(sslam_ctx* ctx, void* event) {
+    SSLAM_REQUIRE(ctx != nullptr && event != nullptr, "sslam_event_record: NULL argument");
+    SSLAM_HIP_CHECK(hipEventRecord((hipEvent_t)event, ctx->stream));
+    return 0;
+}
+
+int sslam_ctx_wait_event(sslam_ctx* ctx, void* event) {
+    SSLAM_REQUIRE(ctx != nullptr && event != nullptr, "sslam_ctx_wait_event: NULL argument");
+    SSLAM_HIP_CHECK(hipStreamWaitEvent(ctx->stream, (hipEvent_t)event, 0));
+    return 0;
+}
+
+int sslam_memcpy_d2d_async(sslam_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes) {
+    SSLAM_REQUIRE(ctx != nullptr && (bytes == 0 || (dst_dev && src_dev)), "sslam_memcpy_d2d_async: NULL argument");
+    if (bytes) SSLAM_HIP_CHECK(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+
+int sslam_memset_async(sslam_ctx* ctx, void* dst_dev, int value, size_t bytes) {
+    SSLAM_REQUIRE(ctx != nullptr && (bytes == 0 || dst_dev), "sslam_memset_async: NULL argument");
+    if (bytes) SSLAM_HIP_CHECK(hipMemsetAsync(dst_dev, value, bytes, ctx->stream));
+    return 0;
+}
+
 }  // extern "C"

@@ -9,23 +9,29 @@ with no data-path collective: in every round rank r owns the contiguous chunk
     frames [ (round * world + r) * B , ... + B )
 
 and matches each of its frames against the previous one.  The only exchange
-is the collation of {count, keypoints, descriptors} of all frames back into
+is the collation of the per-frame feature records of all frames back into
 the shared map every rank keeps (RCCL all-gather over xGMI through
-torch.distributed, padded to max_features rows + one header row); the pair
-that straddles a chunk boundary is matched after that gather against the
-neighbour's last frame.
+torch.distributed); the pair that straddles a chunk boundary is matched after
+that gather against the neighbour's last frame.
 
-Inside one GPU several frames are in flight as well: NE extractor and NM
-matcher instances, each on its own HIP stream, chained by events
-(match(t-1, t) waits for extract(t-1) and extract(t)).  Each pair / frame is a
-chain of ~130 / ~35 short kernels that is bound by per-block latency, not by
-the chip, so independent chains overlap almost freely (measured: 6-7 matcher
-streams = 1.5x the pairs/s of one; 8 streams on the runtime's 4 hardware queues is
-the measured optimum - a ninth stream unbalances the queues and costs > 10 %).  Counts stay device-resident, so a round
-has no host synchronisation.
+Inside one GPU a round is
+  * B extracts, dealt round-robin over the extractor instances (each on its own HIP stream:
+    a frame is a chain of ~45 short kernels that does not fill the chip), and
+  * ceil(B / P) BATCHED matches of P pairs each (`sslam_lightglue_match_batch_dev`: every launch
+    of the forward covers all P pairs, which is what fills the 256 CUs), dealt over the matcher
+    instances, chained to the extracts by events.
+Counts stay device-resident, so a round has no host synchronisation.
 
-`ShardPlan` and `collate` are pure host/tensor logic and are covered by the
-world_size-2 gloo tests on CPU.
+Per-frame feature record (the unit of the exchange, device resident, float32 words):
+
+    [ xy : K x 2 | descriptors : K x 128 | count (int32 bits) | 3 pad ]       REC = 130 K + 4
+
+The extractor writes straight into the record of its slot and the matcher reads straight from it,
+so collation is ONE all-gather of the round's B records with no packing pass.
+
+On one GPU the pipeline runs on the C-ABI alone (streams, events, buffers through
+`_native.Context`); torch is imported only for the N > 1 collective.  `ShardPlan`, the record
+helpers and `collate` are pure host logic and are covered by the world_size-2 gloo tests on CPU.
 """
 from __future__ import annotations
 
@@ -35,6 +41,11 @@ import numpy as np
 
 DESC_DIM = 128
 ROW = 2 + DESC_DIM            # x, y, descriptor
+REC_TAIL = 4                  # count + padding (keeps records 16-byte multiples)
+
+
+def record_floats(max_kpts: int) -> int:
+    return int(max_kpts) * ROW + REC_TAIL
 
 
 @dataclass(frozen=True)
@@ -63,158 +74,215 @@ class ShardPlan:
         return self.world * self.frames_per_rank
 
 
-def pack_rows(count, xy, desc, max_kpts):
-    """[max_kpts+1, 130] float32 block: row 0 = header (count), rows 1.. = (x, y, desc)."""
-    import torch
-    blk = torch.zeros((max_kpts + 1, ROW), dtype=torch.float32, device=xy.device)
-    blk[0, 0] = count.to(torch.float32) if hasattr(count, "to") else float(count)
-    blk[1:, :2] = xy[:max_kpts]
-    blk[1:, 2:] = desc[:max_kpts]
-    return blk
+def pack_record(count, xy, desc, max_kpts):
+    """Host-side construction of one record (tests / tools): numpy float32 [REC]."""
+    K = int(max_kpts)
+    rec = np.zeros(record_floats(K), np.float32)
+    xy = np.asarray(xy, np.float32).reshape(-1, 2)[:K]
+    desc = np.asarray(desc, np.float32).reshape(-1, DESC_DIM)[:K]
+    rec[:2 * len(xy)] = xy.ravel()
+    rec[2 * K:2 * K + DESC_DIM * len(desc)] = desc.ravel()
+    rec[K * ROW:K * ROW + 1].view(np.int32)[0] = int(count)
+    return rec
 
 
-def unpack_rows(blk):
-    n = int(blk[0, 0].item())
-    return n, blk[1:1 + n, :2], blk[1:1 + n, 2:]
+def unpack_record(rec, max_kpts):
+    """(count, xy [count,2], desc [count,128]) views of one record (numpy array or torch tensor)."""
+    K = int(max_kpts)
+    if hasattr(rec, "detach"):
+        rec = rec.detach().cpu().numpy()
+    rec = np.ascontiguousarray(rec, np.float32)
+    n = int(rec[K * ROW:K * ROW + 1].view(np.int32)[0])
+    return n, rec[:2 * K].reshape(K, 2)[:n], rec[2 * K:K * ROW].reshape(K, DESC_DIM)[:n]
 
 
-def collate(local_blocks, plan: ShardPlan, group=None):
-    """All-gather the per-frame blocks of one round.
+def collate(local_records, plan: ShardPlan, group=None):
+    """All-gather the per-frame records of one round.
 
-    local_blocks: [B, max_kpts+1, 130] tensor of this rank's frames (frame order).
-    Returns [world*B, max_kpts+1, 130] in GLOBAL frame order of the round.  With
-    world == 1 this is the input (no collective)."""
-    import torch
+    local_records: [B, REC] float32 tensor of this rank's frames (frame order).
+    Returns [world*B, REC] in GLOBAL frame order of the round.  With world == 1 this is the
+    input (no collective)."""
     if plan.world == 1:
-        return local_blocks
+        return local_records
+    import torch
     import torch.distributed as dist
-    out = torch.empty((plan.world * local_blocks.shape[0],) + tuple(local_blocks.shape[1:]),
-                      dtype=local_blocks.dtype, device=local_blocks.device)
-    dist.all_gather_into_tensor(out, local_blocks.contiguous(), group=group)   # rank-major = frame order
+    out = torch.empty((plan.world * local_records.shape[0],) + tuple(local_records.shape[1:]),
+                      dtype=local_records.dtype, device=local_records.device)
+    dist.all_gather_into_tensor(out, local_records.contiguous(), group=group)   # rank-major = frame order
     return out
 
 
 class FrameStreamPipeline:
     """Device-resident extract(t) + match(t-1 -> t) over this rank's frame chunks.
 
-    `detectors` / `matchers` are lists of instances, each created on its own Context / HIP
-    stream (`streams_e[i]`, `streams_m[j]` are the matching torch streams).  Frame s of a round
-    is extracted on extractor s % NE and pair (s-1, s) is matched on matcher s % NM, chained by
-    events, so several frames and pairs are in flight on one GPU."""
+    `detectors` / `matchers` are lists of AlikedHIP / LightGlueHIP instances, each created on its
+    own `_native.Context` (= its own HIP stream).  Frame s of a round is extracted on extractor
+    s % NE; pairs are matched in batches of `batch_pairs` on matcher (batch index) % NM (each
+    matcher needs max_pairs >= batch_pairs)."""
 
     def __init__(self, detectors, matchers, plan: ShardPlan, max_kpts: int, min_conf: float = 0.7,
-                 streams_e=None, streams_m=None):
-        import torch
-        self.torch = torch
+                 batch_pairs: int | None = None, group=None):
         self.dets = list(detectors) if isinstance(detectors, (list, tuple)) else [detectors]
         self.mats = list(matchers) if isinstance(matchers, (list, tuple)) else [matchers]
-        self.plan = plan
-        cur = torch.cuda.current_stream()
-        self.se = list(streams_e) if streams_e else [cur] * len(self.dets)
-        self.sm = list(streams_m) if streams_m else [cur] * len(self.mats)
-        assert len(self.se) == len(self.dets) and len(self.sm) == len(self.mats)
+        self.plan, self.group = plan, group
         self.K = int(max_kpts)
+        if self.K % 2:
+            raise ValueError("max_kpts must be even (16-byte aligned descriptor rows inside a record)")
         self.min_conf = float(min_conf)
-        dev = torch.device("cuda", torch.cuda.current_device())
+        self.P = int(batch_pairs or min(m.max_pairs for m in self.mats))
+        if any(m.max_pairs < self.P for m in self.mats):
+            raise ValueError(f"batch_pairs={self.P} exceeds a matcher's max_pairs")
         B, K = plan.frames_per_rank, self.K
-        # per-frame feature slots of the current round (+ slot B: the halo frame)
-        self.blocks = torch.zeros((B + 1, K + 1, ROW), dtype=torch.float32, device=dev)
-        self.xy = torch.zeros((B + 1, K, 2), dtype=torch.float32, device=dev)
-        self.desc = torch.zeros((B + 1, K, DESC_DIM), dtype=torch.float32, device=dev)
-        self.score = torch.zeros((B + 1, K), dtype=torch.float32, device=dev)
-        self.count = torch.zeros((B + 1, 1), dtype=torch.int32, device=dev)
-        self.ij = torch.zeros((B, K, 2), dtype=torch.int32, device=dev)
-        self.msc = torch.zeros((B, K), dtype=torch.float32, device=dev)
-        self.info = torch.zeros((B, 4), dtype=torch.int32, device=dev)
-        self.ev_ext = [torch.cuda.Event() for _ in range(B)]
-        self.ev_mdone = [torch.cuda.Event() for _ in self.sm]
+        self.REC = record_floats(K)
+        self.ctx = self.dets[0].ctx                      # allocations / copies that belong to no instance
+        dev_bytes = (B + 2) * self.REC * 4               # B slots + two halo slots (alternate by round)
+        self.torch = None
+        if plan.world > 1:
+            # the exchange goes through torch.distributed: its tensors own the record slab
+            import torch
+            self.torch = torch
+            self._slab_t = torch.zeros(((B + 2), self.REC), dtype=torch.float32,
+                                       device=torch.device("cuda", self.ctx.device))
+            self.slab = int(self._slab_t.data_ptr())
+            self._cstream = torch.cuda.ExternalStream(self.ctx.stream, device=self.ctx.device)
+            self._prev_last = torch.zeros(self.REC, dtype=torch.float32, device=self._slab_t.device)
+        else:
+            self.slab = self.ctx.malloc(dev_bytes)
+            self.ctx.memset_async(self.slab, 0, dev_bytes)
+        self.score = self.ctx.malloc(B * K * 4)
+        self.ij = self.ctx.malloc(B * K * 8)
+        self.msc = self.ctx.malloc(B * K * 4)
+        self.info = self.ctx.malloc(B * 16)
+        self.ctx.memset_async(self.info, 0, B * 16)
+        self.ctx.sync()
+        self.ev_ext = [self.ctx.event() for _ in range(B)]
+        self.ev_halo = [self.ctx.event(), self.ctx.event()]        # halo slot (round & 1) is in place
+        self.ev_mdone = [self.ctx.event() for _ in self.mats]
+        self.ev_collated = self.ctx.event()
         self.have_halo = False
         self.started = False
-        self.shared_map = None          # last collated round [world*B, K+1, 130]
+        self.rounds = 0
+        self.shared_map = None          # last collated round [world*B, REC] (torch tensor; N > 1 only)
 
-    def _match(self, m, a, b, out):
-        self.mats[m].match_dev(self.xy[a], self.desc[a], self.K, self.xy[b], self.desc[b], self.K,
-                               self.ij[out], self.msc[out], self.info[out], min_conf=self.min_conf,
-                               m_dev=self.count[a], n_dev=self.count[b])
+    # ---- record addressing
+    def rec_ptr(self, slot: int) -> int:
+        return self.slab + slot * self.REC * 4
+
+    def xy_ptr(self, slot: int) -> int:
+        return self.rec_ptr(slot)
+
+    def desc_ptr(self, slot: int) -> int:
+        return self.rec_ptr(slot) + self.K * 2 * 4
+
+    def count_ptr(self, slot: int) -> int:
+        return self.rec_ptr(slot) + self.K * ROW * 4
+
+    def _halo_slot(self, rnd: int) -> int:
+        return self.plan.frames_per_rank + (rnd & 1)
 
     def round(self, frames_dev, H, W, C):
-        """frames_dev: uint8 [B, H, W, C] device tensor holding this rank's chunk.
-        Enqueues B extracts + B matches (+ the collation when world > 1)."""
-        torch, plan, B = self.torch, self.plan, self.plan.frames_per_rank
-        NE, NM = len(self.dets), len(self.mats)
-        if self.started:     # slots are overwritten: the previous round's readers must be done
-            for st in set(self.se):
+        """frames_dev: device pointer (int, or any object with data_ptr()) of this rank's chunk,
+        uint8 [B, H, W, C].  Enqueues B extracts + the batched matches (+ the collation when
+        world > 1); returns without synchronising."""
+        plan, B, K = self.plan, self.plan.frames_per_rank, self.K
+        NE, NM, P = len(self.dets), len(self.mats), self.P
+        base = frames_dev if isinstance(frames_dev, int) else int(frames_dev.data_ptr())
+        fbytes = int(H) * int(W) * int(C)
+        rnd = self.rounds
+        halo_r, halo_w = self._halo_slot(rnd), self._halo_slot(rnd + 1)
+        single = plan.world == 1
+        if self.started:
+            # slots are overwritten: the previous round's readers (matchers, collation) must be done
+            for d in self.dets:
                 for ev in self.ev_mdone:
-                    st.wait_event(ev)
+                    d.ctx.wait(ev)
+                if not single:
+                    d.ctx.wait(self.ev_collated)
         self.started = True
         for s in range(B):
-            e = s % NE
-            with torch.cuda.stream(self.se[e]):
-                self.dets[e].extract_dev(frames_dev[s], H, W, C, self.xy[s], self.desc[s], self.score[s],
-                                         self.count[s], max_kpts=self.K)
-                self.ev_ext[s].record(self.se[e])
-        single = plan.world == 1
-        for s in range(B):
-            m = s % NM
-            st = self.sm[m]
-            st.wait_event(self.ev_ext[s])
-            if s > 0:
-                st.wait_event(self.ev_ext[s - 1])
-            with torch.cuda.stream(st):
-                if s > 0:
-                    self._match(m, s - 1, s, s)
-                elif single and self.have_halo:      # previous round's last frame -> this round's first
-                    self._match(m, B, 0, 0)          # (slot B was filled on this same stream, sm[0])
+            d = self.dets[s % NE]
+            d.extract_dev(base + s * fbytes, H, W, C, self.xy_ptr(s), self.desc_ptr(s), self.score + s * K * 4,
+                          self.count_ptr(s), max_kpts=K)
+            d.ctx.record(self.ev_ext[s])
+        have_halo = self.have_halo
         if single:
-            st = self.sm[0]
-            st.wait_event(self.ev_ext[B - 1])
-            with torch.cuda.stream(st):
-                self.xy[B].copy_(self.xy[B - 1]); self.desc[B].copy_(self.desc[B - 1])
-                self.count[B].copy_(self.count[B - 1])
-            for m in range(NM):
-                self.ev_mdone[m].record(self.sm[m])
-            self.have_halo = True
-            return
-        # ---- multi-GPU: collate as soon as the EXTRACTS are done; this round's matches keep running
-        # on their own streams underneath the all-gather.  The collation is issued on the last
-        # extractor stream, not on a stream of its own: streams share 4 hardware queues round-robin,
-        # and one more active stream unbalances them (measured: 2 + 7 streams 490 frames/s against
-        # 552 for 2 + 6).
-        cst = self.se[-1]
-        for st in set(self.se) - {cst}:
-            cst.wait_stream(st)
-        with torch.cuda.stream(cst):
-            self.blocks[:B, 0, 0] = self.count[:B, 0].to(torch.float32)      # three fused copies, not 3 B
-            self.blocks[:B, 1:, :2] = self.xy[:B]
-            self.blocks[:B, 1:, 2:] = self.desc[:B]
-            self.shared_map = collate(self.blocks[:B], plan)
-            # boundary pair: my first frame vs the previous chunk's last frame
-            prev = plan.rank * B - 1                     # index inside the gathered round
-            if prev >= 0:
-                src = self.shared_map[prev]
-            elif self.have_halo:
-                src = self.prev_round_last
+            # next round's halo = this round's last frame (copied on that frame's extractor stream)
+            dl = self.dets[(B - 1) % NE]
+            dl.ctx.d2d_async(self.rec_ptr(halo_w), self.rec_ptr(B - 1), self.REC * 4)
+            dl.ctx.record(self.ev_halo[(rnd + 1) & 1])
+        else:
+            # ---- multi-GPU: collate as soon as the EXTRACTS are done; the matches of this round run
+            # on their own streams underneath the all-gather.  The collation rides on the first
+            # extractor's stream (self.ctx), seen by torch as an external stream.
+            torch = self.torch
+            for s in range(B):
+                self.ctx.wait(self.ev_ext[s])
+            with torch.cuda.stream(self._cstream):
+                self.shared_map = collate(self._slab_t[:B], plan, self.group)
+                prev = plan.rank * B - 1                     # index inside the gathered round
+                if prev >= 0:
+                    src = self.shared_map[prev]
+                elif have_halo:
+                    src = self._prev_last
+                else:
+                    src = None
+                if src is not None:
+                    self._slab_t[halo_r].copy_(src)
+                    have_halo = True
+                else:
+                    have_halo = False
+                self._prev_last = self.shared_map[plan.world * B - 1].clone()
+            self.ctx.record(self.ev_halo[rnd & 1])           # halo of THIS round is in place
+            self.ctx.record(self.ev_collated)
+        # ---- batched matches: pair s = (s-1, s); pair 0 = (halo, 0)
+        first = 0 if have_halo else 1
+        j = 0
+        s0 = first
+        while s0 < B:
+            s1 = min(B, (s0 // P + 1) * P) if s0 else min(B, P)
+            m = self.mats[j % NM]
+            pairs = []
+            for s in range(s0, s1):
+                a = halo_r if s == 0 else s - 1
+                pairs.append((self.xy_ptr(a), self.desc_ptr(a), K, self.xy_ptr(s), self.desc_ptr(s), K,
+                              self.count_ptr(a), self.count_ptr(s)))
+                m.ctx.wait(self.ev_ext[s])
+            if s0 == 0:
+                # the halo record: copied behind the previous round's last extract (one GPU) or
+                # written by this round's collation (N > 1)
+                m.ctx.wait(self.ev_halo[rnd & 1])
             else:
-                src = None
-            if src is not None:
-                # slot B may still be read by the previous round's boundary match on sm[0]
-                ev0 = torch.cuda.Event(); ev0.record(self.sm[0])
-                cst.wait_event(ev0)
-                self.xy[B].copy_(src[1:, :2]); self.desc[B].copy_(src[1:, 2:])
-                self.count[B, 0] = src[0, 0].to(torch.int32)
-                ev = torch.cuda.Event(); ev.record(cst)
-                self.sm[0].wait_event(ev)
-                with torch.cuda.stream(self.sm[0]):
-                    self._match(0, B, 0, 0)
-            self.prev_round_last = self.shared_map[plan.world * B - 1].clone()
+                m.ctx.wait(self.ev_ext[s0 - 1])
+            m.match_batch_dev(pairs, self.ij + s0 * K * 8, self.msc + s0 * K * 4, self.info + s0 * 16, K,
+                              min_conf=self.min_conf)
+            m.ctx.record(self.ev_mdone[j % NM])
+            j += 1
+            s0 = s1
         self.have_halo = True
-        for m in range(NM):
-            self.ev_mdone[m].record(self.sm[m])
+        self.rounds += 1
+
+    def sync(self):
+        for c in {id(x.ctx): x.ctx for x in self.dets + self.mats}.values():
+            c.sync()
 
     def results(self):
         """Host copy of the last round's matches: list of (ij [K,2], scores [K]) per local frame."""
-        self.torch.cuda.synchronize()
-        info = self.info.cpu().numpy()
-        ij = self.ij.cpu().numpy()
-        sc = self.msc.cpu().numpy()
-        return [(ij[s, :info[s, 0]].copy(), sc[s, :info[s, 0]].copy()) for s in range(len(info))]
+        self.sync()
+        B, K = self.plan.frames_per_rank, self.K
+        info = np.empty((B, 4), np.int32); ij = np.empty((B, K, 2), np.int32); sc = np.empty((B, K), np.float32)
+        self.ctx.d2h(info, self.info); self.ctx.d2h(ij, self.ij); self.ctx.d2h(sc, self.msc)
+        return [(ij[s, :info[s, 0]].copy(), sc[s, :info[s, 0]].copy()) for s in range(B)]
+
+    def infos(self):
+        self.sync()
+        info = np.empty((self.plan.frames_per_rank, 4), np.int32)
+        self.ctx.d2h(info, self.info)
+        return info
+
+    def features(self):
+        """Host copy of the last round's features: list of (xy [n,2], desc [n,128]) per local frame."""
+        self.sync()
+        B = self.plan.frames_per_rank
+        slab = np.empty((B, self.REC), np.float32)
+        self.ctx.d2h(slab, self.slab)
+        return [unpack_record(slab[s], self.K)[1:] for s in range(B)]

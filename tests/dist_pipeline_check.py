@@ -36,36 +36,32 @@ feats = [det0.extract(im, K) for im in imgs]
 ref = [None] + [mat0.match(feats[i - 1][0], feats[i - 1][1], feats[i][0], feats[i][1], min_conf=0.2)
                 for i in range(1, n_frames)]
 plan = fs.ShardPlan(world, rank, B)
-main = torch.cuda.Stream()
 checked = 0
-with torch.cuda.stream(main):
-    se = [torch.cuda.Stream() for _ in range(2)]
-    sm = [torch.cuda.Stream() for _ in range(2)]
-    dets = [AL(sd_a, max_num_keypoints=K, max_h=H, max_w=Wd, ctx=nat.Context(0, stream=s.cuda_stream)) for s in se]
-    mats = [LG(sd_l, max_kpts=K, ctx=nat.Context(0, stream=s.cuda_stream)) for s in sm]
-    pipe = fs.FrameStreamPipeline(dets, mats, plan, K, 0.2, streams_e=se, streams_m=sm)
-    for rnd in range(ROUNDS):
-        mine = list(plan.frames(rnd))
-        chunk = torch.from_numpy(np.stack([imgs[f] for f in mine])).cuda()
-        torch.cuda.synchronize()
-        pipe.round(chunk, H, Wd, 3)
-        res = pipe.results()
-        cnt = pipe.count.cpu().numpy()[:, 0]
-        xy = pipe.xy.cpu().numpy()
-        for s, f in enumerate(mine):
-            assert cnt[s] == len(feats[f][0]), (rank, f)
-            np.testing.assert_array_equal(xy[s, :cnt[s]], feats[f][0])
-            if f == 0:
-                continue
-            np.testing.assert_array_equal(res[s][0], ref[f][0], err_msg=f"rank {rank} frame {f}")
-            checked += 1
-        # the collated map holds every rank's features of this round, in global frame order
-        sm_all = pipe.shared_map.cpu().numpy()
-        for j in range(world * B):
-            f = rnd * world * B + j
-            n = int(sm_all[j, 0, 0])
-            assert n == len(feats[f][0])
-            np.testing.assert_array_equal(sm_all[j, 1:1 + n, :2], feats[f][0])
+dets = [AL(sd_a, max_num_keypoints=K, max_h=H, max_w=Wd, ctx=nat.Context(0)) for _ in range(2)]
+mats = [LG(sd_l, max_kpts=K, ctx=nat.Context(0), max_pairs=2) for _ in range(2)]
+pipe = fs.FrameStreamPipeline(dets, mats, plan, K, 0.2, batch_pairs=2)
+for rnd in range(ROUNDS):
+    mine = list(plan.frames(rnd))
+    chunk = pipe.ctx.upload(np.stack([imgs[f] for f in mine]))
+    pipe.round(chunk, H, Wd, 3)
+    res = pipe.results()
+    got = pipe.features()
+    for s, f in enumerate(mine):
+        assert len(got[s][0]) == len(feats[f][0]), (rank, f)
+        np.testing.assert_array_equal(got[s][0], feats[f][0])
+        if f == 0:
+            continue
+        np.testing.assert_array_equal(res[s][0], ref[f][0], err_msg=f"rank {rank} frame {f}")
+        checked += 1
+    # the collated map holds every rank's features of this round, in global frame order
+    torch.cuda.synchronize()
+    sm_all = pipe.shared_map.cpu().numpy()
+    for j in range(world * B):
+        f = rnd * world * B + j
+        n, xy, desc = fs.unpack_record(sm_all[j], K)
+        assert n == len(feats[f][0])
+        np.testing.assert_array_equal(xy, feats[f][0])
+        np.testing.assert_array_equal(desc, feats[f][1])
 dist.barrier()
 print(f"rank {rank}: {checked} pairs identical to the sequential API", flush=True)
 dist.destroy_process_group()

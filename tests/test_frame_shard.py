@@ -34,13 +34,22 @@ def test_shard_plan_covers_stream_once():
     assert plans[2].frames_per_round() == 12
 
 
-def test_pack_unpack_roundtrip():
+def test_record_roundtrip():
     fs = load_pkg("frame_shard")
     K = 16
-    xy = torch.rand(K, 2); desc = torch.rand(K, 128)
-    blk = fs.pack_rows(torch.tensor(11, dtype=torch.int32), xy, desc, K)
-    n, x2, d2 = fs.unpack_rows(blk)
-    assert n == 11 and torch.equal(x2, xy[:11]) and torch.equal(d2, desc[:11])
+    rng = np.random.default_rng(0)
+    xy = rng.random((K, 2), np.float32); desc = rng.random((K, 128), np.float32)
+    rec = fs.pack_record(11, xy, desc, K)
+    assert rec.shape == (fs.record_floats(K),) and rec.nbytes % 16 == 0
+    n, x2, d2 = fs.unpack_record(rec, K)
+    assert n == 11 and np.array_equal(x2, xy[:11]) and np.array_equal(d2, desc[:11])
+    n, x2, d2 = fs.unpack_record(torch.from_numpy(rec), K)           # a gathered torch tensor unpacks the same
+    assert n == 11 and np.array_equal(x2, xy[:11])
+
+
+def _frame_record(fs, f, K):
+    rng = np.random.default_rng(1000 + f)
+    return fs.pack_record(1 + f % K, rng.random((K, 2), np.float32), rng.random((K, 128), np.float32), K)
 
 
 def _worker(rank, world, port, out_dir):
@@ -52,12 +61,8 @@ def _worker(rank, world, port, out_dir):
     B, K = 3, 8
     plan = fs.ShardPlan(world, rank, B)
     for rnd in range(2):
-        blocks = torch.zeros(B, K + 1, fs.ROW)
-        for s, f in enumerate(plan.frames(rnd)):
-            g = torch.Generator().manual_seed(1000 + f)
-            n = 1 + f % K
-            blocks[s] = fs.pack_rows(n, torch.rand(K, 2, generator=g), torch.rand(K, 128, generator=g), K)
-        full = fs.collate(blocks, plan)
+        records = torch.from_numpy(np.stack([_frame_record(fs, f, K) for f in plan.frames(rnd)]))
+        full = fs.collate(records, plan)
         torch.save(full, Path(out_dir) / f"r{rank}_round{rnd}.pt")
     dist.barrier()
     dist.destroy_process_group()
@@ -71,16 +76,16 @@ def test_collate_world2_gloo(tmp_path):
     for rnd in range(2):
         maps = [torch.load(tmp_path / f"r{r}_round{rnd}.pt") for r in range(world)]
         assert torch.equal(maps[0], maps[1])
-        assert maps[0].shape == (world * B, K + 1, fs.ROW)
+        assert maps[0].shape == (world * B, fs.record_floats(K))
         for i in range(world * B):
             f = rnd * world * B + i
-            g = torch.Generator().manual_seed(1000 + f)
-            xy, desc = torch.rand(K, 2, generator=g), torch.rand(K, 128, generator=g)
-            n, x2, d2 = fs.unpack_rows(maps[0][i])
-            assert n == 1 + f % K and torch.equal(x2, xy[:n]) and torch.equal(d2, desc[:n])
+            want = _frame_record(fs, f, K)
+            assert np.array_equal(maps[0][i].numpy().view(np.int32), want.view(np.int32))     # bit for bit
+            n, _, _ = fs.unpack_record(maps[0][i], K)
+            assert n == 1 + f % K
 
 
 def test_collate_single_rank_is_identity():
     fs = load_pkg("frame_shard")
-    x = torch.rand(2, 5, fs.ROW)
+    x = torch.rand(2, fs.record_floats(5))
     assert fs.collate(x, fs.ShardPlan(1, 0, 2)) is x

@@ -11,52 +11,84 @@ from conftest import ROOT, load_pkg
 pytestmark = pytest.mark.gpu
 
 
-def test_pipeline_equals_sequential_api(native):
-    torch = pytest.importorskip("torch")
-    assert torch.cuda.is_available()
-    W = load_pkg("weights"); fs = load_pkg("frame_shard")
+def _sequential_reference(native, imgs, K, H, Wd, sd_a, sd_l, min_conf):
+    W = load_pkg("weights")
     AL = load_pkg("aliked").AlikedHIP; LG = load_pkg("lightglue").LightGlueHIP
-    K, B, H, Wd = 512, 4, 200, 320
-    sd_a = W.random_aliked_state_dict(0)
-    sd_l = W.random_lightglue_state_dict(1, match_gain=4.0, match_bias=3.0)
-    imgs = [frames.structured_frame(i, h=H, w=Wd) for i in range(2 * B)]
-
-    # sequential reference through the host entry points
     ctx0 = native.default_context(0)
     det0 = AL(sd_a, max_num_keypoints=K, max_h=H, max_w=Wd, ctx=ctx0)
     mat0 = LG(sd_l, max_kpts=K, ctx=ctx0)
     feats = [det0.extract(im, K) for im in imgs]
-    ref = [None] + [mat0.match(feats[i - 1][0], feats[i - 1][1], feats[i][0], feats[i][1], min_conf=0.2)
+    ref = [None] + [mat0.match(feats[i - 1][0], feats[i - 1][1], feats[i][0], feats[i][1], min_conf=min_conf)
                     for i in range(1, len(imgs))]
+    det0.close(); mat0.close()
+    return feats, ref
 
-    main = torch.cuda.Stream()
-    with torch.cuda.stream(main):
-        se = [torch.cuda.Stream() for _ in range(2)]
-        sm = [torch.cuda.Stream() for _ in range(3)]
-        dets = [AL(sd_a, max_num_keypoints=K, max_h=H, max_w=Wd, ctx=native.Context(0, stream=s.cuda_stream)) for s in se]
-        mats = [LG(sd_l, max_kpts=K, ctx=native.Context(0, stream=s.cuda_stream)) for s in sm]
-        pipe = fs.FrameStreamPipeline(dets, mats, fs.ShardPlan(1, 0, B), K, 0.2, streams_e=se, streams_m=sm)
-        for rnd in range(2):
-            chunk = torch.from_numpy(np.stack(imgs[rnd * B:(rnd + 1) * B])).cuda()
-            torch.cuda.synchronize()
-            pipe.round(chunk, H, Wd, 3)
-            res = pipe.results()
-            cnt = pipe.count.cpu().numpy()[:, 0]
-            xy = pipe.xy.cpu().numpy()
-            for s in range(B):
-                f = rnd * B + s
-                assert cnt[s] == len(feats[f][0])
-                np.testing.assert_array_equal(xy[s, :cnt[s]], feats[f][0])
-                if f == 0:
-                    continue
-                np.testing.assert_array_equal(res[s][0], ref[f][0])
-                np.testing.assert_allclose(res[s][1], ref[f][1], atol=1e-6)
-    assert sum(len(r[0]) for r in ref[1:]) >= 0
+
+@pytest.mark.parametrize("B,P,NE,NM,sync_each_round", [(4, 2, 2, 3, True), (5, 3, 2, 2, False), (4, 4, 1, 1, False)])
+def test_pipeline_equals_sequential_api(native, B, P, NE, NM, sync_each_round):
+    """Extracts on NE streams, batched matches (P pairs per enqueue) on NM streams, on the C-ABI
+    alone (no torch).  With sync_each_round=False three rounds are enqueued back to back with NO
+    host synchronisation in between (per-round results are copied on-stream into a history buffer),
+    so every cross-round ordering edge - slot reuse, the alternating halo record, matcher events -
+    is exercised the way bench.py drives the pipeline."""
+    W = load_pkg("weights"); fs = load_pkg("frame_shard")
+    AL = load_pkg("aliked").AlikedHIP; LG = load_pkg("lightglue").LightGlueHIP
+    K, H, Wd, ROUNDS = 512, 200, 320, 3
+    sd_a = W.random_aliked_state_dict(0)
+    sd_l = W.random_lightglue_state_dict(1, match_gain=4.0, match_bias=3.0)
+    imgs = [frames.structured_frame(i, h=H, w=Wd) for i in range(ROUNDS * B)]
+    feats, ref = _sequential_reference(native, imgs, K, H, Wd, sd_a, sd_l, 0.2)
+
+    dets = [AL(sd_a, max_num_keypoints=K, max_h=H, max_w=Wd, ctx=native.Context(0)) for _ in range(NE)]
+    mats = [LG(sd_l, max_kpts=K, ctx=native.Context(0), max_pairs=P) for _ in range(NM)]
+    pipe = fs.FrameStreamPipeline(dets, mats, fs.ShardPlan(1, 0, B), K, 0.2, batch_pairs=P)
+    ctx = pipe.ctx
+    chunks = [ctx.upload(np.stack(imgs[r * B:(r + 1) * B])) for r in range(ROUNDS)]
+    hist = []                                   # per round: device copies of (records, ij, info)
+    col = native.Context(0)                     # collector stream of the no-sync mode
+    for rnd in range(ROUNDS):
+        pipe.round(chunks[rnd], H, Wd, 3)
+        if sync_each_round:
+            pipe.sync()
+        else:
+            # snapshot this round's outputs ON-STREAM: a collector context waits for the matchers
+            # and the extractors of this round, copies, and the next round is enqueued at once
+            for ev in pipe.ev_mdone + pipe.ev_ext:
+                col.wait(ev)
+        c = ctx if sync_each_round else col
+        h = dict(rec=c.malloc(B * pipe.REC * 4), ij=c.malloc(B * K * 8), info=c.malloc(B * 16))
+        c.d2d_async(h["rec"], pipe.slab, B * pipe.REC * 4)
+        c.d2d_async(h["ij"], pipe.ij, B * K * 8)
+        c.d2d_async(h["info"], pipe.info, B * 16)
+        if not sync_each_round:
+            # the pipeline's next round must not overwrite before the snapshot copies ran
+            ev = col.event(); col.record(ev)
+            for d in pipe.dets:
+                d.ctx.wait(ev)
+        hist.append(h)
+    pipe.sync()
+    if not sync_each_round:
+        col.sync()
+    for rnd, h in enumerate(hist):
+        rec = np.empty((B, pipe.REC), np.float32); ij = np.empty((B, K, 2), np.int32); info = np.empty((B, 4), np.int32)
+        ctx.d2h(rec, h["rec"]); ctx.d2h(ij, h["ij"]); ctx.d2h(info, h["info"])
+        for s in range(B):
+            f = rnd * B + s
+            n, xy, desc = fs.unpack_record(rec[s], K)
+            assert n == len(feats[f][0])
+            np.testing.assert_array_equal(xy, feats[f][0])
+            np.testing.assert_array_equal(desc, feats[f][1])
+            if f == 0:
+                continue
+            np.testing.assert_array_equal(ij[s, :info[s, 0]], ref[f][0], err_msg=f"round {rnd} frame {f}")
+    assert sum(len(r[0]) for r in ref[1:]) > 50
+    for x in dets + mats:
+        x.close()
 
 
 def _run_bench(extra_env, cmd):
     import json, os, subprocess, sys
-    env = dict(os.environ, SSLAM_BENCH_FRAMES="6", SSLAM_BENCH_NE="1", SSLAM_BENCH_NM="2", **extra_env)
+    env = dict(os.environ, SSLAM_BENCH_FRAMES="6", SSLAM_BENCH_NE="1", SSLAM_BENCH_NM="2", SSLAM_BENCH_PAIRS="4", **extra_env)
     out = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -68,11 +100,25 @@ def test_bench_contract_single_rank():
     import sys
     d = _run_bench({}, [sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
-                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "structured_input"):
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "structured_input",
+                "exact_f32", "ba", "reproject"):
         assert key in d
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["unit"] == "frames/s"
     r = d["roofline"]
     assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert 0 < r["timed_region_frac"] <= r["frac"] * 1.2
+    assert 0 < d["exact_f32"]["value"] < d["value"] * 1.05
+    assert d["ba"]["device_lm_ms"] > 0 and 0 < d["ba"]["residual_kernel"]["frac"] < 1 and d["reproject"]["wall_ms"] > 0
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` outside torch.distributed.run starts its ranks as a child process
+    (same command shape as --gpus 1); gloo + one shared GPU on this box."""
+    import sys
+    d = _run_bench({"SSLAM_DIST_BACKEND": "gloo", "MASTER_PORT": "29617"},
+                   [sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                    "--no-extras"])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["frames_per_step_per_gpu"] == 6
 
 
 def test_bench_two_ranks_share_one_gpu_over_gloo():
@@ -82,7 +128,7 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     d = _run_bench({"SSLAM_DIST_BACKEND": "gloo", "MASTER_ADDR": "127.0.0.1"},
                    [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                     "--master-addr", "127.0.0.1", "--master-port", "29611", "bench.py", "--gpus", "2",
-                    "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+                    "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"])
     assert d["n_gpus"] == 2 and d["value"] > 0
     assert d["config"]["frames_per_step_per_gpu"] == 6
 
