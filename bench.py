@@ -285,6 +285,25 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    dist = torch = None
+    if world > 1:
+        # one process per GPU; SSLAM_DIST_BACKEND=gloo + fewer GPUs than ranks is a test-only mode that
+        # exercises the N > 1 code path on a single-GPU box (ranks share device local_rank % n_gpus).
+        # torch brings its own HIP runtime: it must initialise BEFORE libsslam_hip.so touches the
+        # device (the other order leaves torch with "No HIP GPUs are available").
+        import torch
+        import torch.distributed as dist
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+        backend = os.environ.get("SSLAM_DIST_BACKEND", "nccl")
+        device_index = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(device_index)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
     pkg = importlib.import_module("opencv-simpleslam_amd")
     nat = pkg._native
     W = importlib.import_module("opencv-simpleslam_amd.weights")
@@ -293,21 +312,8 @@ def main():
     fs = importlib.import_module("opencv-simpleslam_amd.frame_shard")
     if nat.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-
-    dist = torch = None
-    device_index = local_rank % nat.device_count()
-    if world > 1:
-        # one process per GPU; SSLAM_DIST_BACKEND=gloo + fewer GPUs than ranks is a test-only mode that
-        # exercises the N > 1 code path on a single-GPU box (ranks share device local_rank % n_gpus)
-        import torch
-        import torch.distributed as dist
-        backend = os.environ.get("SSLAM_DIST_BACKEND", "nccl")
-        torch.cuda.set_device(device_index)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    if world == 1:
+        device_index = 0
 
     # extractor / matcher instances, one HIP stream (context) each.  The matcher runs BATCHES of
     # pairs, every launch over the whole batch: two matcher streams overlap the under-filled tail

