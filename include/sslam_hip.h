@@ -215,6 +215,12 @@ int sslam_lightglue_match_batch_dev(sslam_lightglue* lg, int n_pairs, const floa
                                     const float* const* xy1, const float* const* desc1,
                                     const int32_t* const* n_dev, const int32_t* N, float min_conf,
                                     int32_t* ij_out, float* score_out, int32_t* info_out, int out_stride);
+/* The split-precision path carries fp32 values as fp16 plane pairs: a FINITE activation with
+ * |value| >= 65520 does not fit (the exact-fp32 path, precision 0, has no such limit).  Such a value
+ * is saturated and flagged on the device; sslam_lightglue_match_host fails with a message when the
+ * flag is set, callers of the _dev / _batch_dev entries poll it here (synchronises the stream,
+ * returns and clears the flag). */
+int sslam_lightglue_range_overflow(sslam_lightglue* lg, int* flag_out);
 /* Measurement hook (bench.py): bracket each attention launch - the dominant kernel - with HIP
  * events on the context stream; _read synchronises and returns their summed duration and count. */
 int sslam_lightglue_profile(sslam_lightglue* lg, int enable);

@@ -22,10 +22,24 @@ using half2v = _Float16 __attribute__((ext_vector_type(2)));
 constexpr float SPLIT_SCALE = 2048.0f;          // 2^11
 constexpr float SPLIT_INV = 1.0f / 2048.0f;
 
+// Set (never cleared by device code) when a FINITE value outside the fp16 range reaches a split:
+// |a| >= 65520 rounds to +-inf in the high plane and the product silently becomes inf / NaN.  The
+// split saturates instead and raises this flag; the host entry points report it as an error
+// (the exact-fp32 path, precision 0, has no such limit).  Non-finite inputs are not flagged: they
+// stay NaN / inf as in any fp32 evaluation.
+static __device__ int g_split_range_overflow;
+
 __device__ __forceinline__ void split_f32(float a, _Float16& hi, _Float16& lo) {
     // an fp16 subnormal is not a safe MFMA operand (flushed on input): below 2^-14 the whole
     // value moves into the scaled low plane, which keeps 11 bits down to |a| = 2^-25
-    hi = fabsf(a) < 6.103515625e-5f ? (_Float16)0.0f : (_Float16)a;
+    const float aa = fabsf(a);
+    if (aa >= 65520.0f && aa < INFINITY) {
+        g_split_range_overflow = 1;
+        hi = (_Float16)copysignf(65504.0f, a);
+        lo = (_Float16)fminf(fmaxf((a - (float)hi) * SPLIT_SCALE, -65504.0f), 65504.0f);
+        return;
+    }
+    hi = aa < 6.103515625e-5f ? (_Float16)0.0f : (_Float16)a;
     lo = (_Float16)((a - (float)hi) * SPLIT_SCALE);
 }
 

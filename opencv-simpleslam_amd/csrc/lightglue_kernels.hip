@@ -1602,6 +1602,21 @@ int lg_bind_weights(sslam_lightglue* g, size_t n_floats) {
     return 0;
 }
 
+// read and clear the device-side range flag of the split-precision path (gemm_f16x3.hpp)
+int lg_take_range_flag(hipStream_t s, int* flag_out) {
+    int flag = 0, zero = 0;
+    SSLAM_HIP_CHECK(hipMemcpyFromSymbolAsync(&flag, HIP_SYMBOL(sslam::g_split_range_overflow), sizeof(int), 0,
+                                             hipMemcpyDeviceToHost, s));
+    SSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    if (flag) {
+        SSLAM_HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(sslam::g_split_range_overflow), &zero, sizeof(int), 0,
+                                               hipMemcpyHostToDevice, s));
+        SSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    *flag_out = flag;
+    return 0;
+}
+
 float conf_threshold(int layer) {   // np.clip(0.8 + 0.1 * exp(-4 i / n_layers), 0, 1), cast to fp32
     double v = 0.8 + 0.1 * exp(-4.0 * layer / (double)NL);
     v = v < 0 ? 0 : (v > 1 ? 1 : v);
@@ -2039,6 +2054,12 @@ int sslam_lightglue_match_host(sslam_lightglue* g, const float* xy0, const float
     int32_t info[4];
     SSLAM_HIP_CHECK(hipMemcpyAsync(info, g->out_info, sizeof(info), hipMemcpyDeviceToHost, s));
     SSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    if (g->precision == 1) {
+        int flag = 0;
+        if (int rc = lg_take_range_flag(s, &flag)) return rc;
+        SSLAM_REQUIRE(flag == 0, "sslam_lightglue_match_host: an activation left the fp16 range of the split-precision "
+                                 "path (|value| >= 65520); rescale the descriptors or use sslam_lightglue_set_precision(lg, 0)");
+    }
     const int Kn = info[0];
     SSLAM_REQUIRE(Kn >= 0 && Kn <= (M < N ? M : N), "sslam_lightglue_match_host: corrupt match count %d", Kn);
     if (Kn) {
@@ -2132,6 +2153,14 @@ int sslam_lightglue_debug_big_gemm(sslam_lightglue* g, int mode) {
     SSLAM_REQUIRE(g != nullptr && mode >= -1 && mode <= 1, "sslam_lightglue_debug_big_gemm: bad argument");
     g->big_gemm = mode;
     return 0;
+}
+
+/* Synchronise and report (then clear) the range flag of the split-precision path: 1 if, since the
+ * last call, a finite activation with |value| >= 65520 reached an fp16 split (its results are then
+ * not fp32-grade).  The _host entry points check it themselves; _dev / batch callers poll here. */
+int sslam_lightglue_range_overflow(sslam_lightglue* g, int* flag_out) {
+    SSLAM_REQUIRE(g && flag_out, "sslam_lightglue_range_overflow: NULL argument");
+    return lg_take_range_flag(g->ctx->stream, flag_out);
 }
 
 int sslam_lightglue_capacity(sslam_lightglue* g, int* kc_out) {

@@ -108,6 +108,13 @@ class LightGlueHIP:
             _native.ptr(ij_out), _native.ptr(score_out), _native.ptr(info_out), int(out_stride)),
             "sslam_lightglue_match_batch_dev")
 
+    def range_overflow(self) -> bool:
+        """True if, since the last call, a finite activation left the fp16 range of the split-precision
+        path (results of those calls are not fp32-grade).  Synchronises; clears the flag."""
+        f = C.c_int(0)
+        _native.check(_native.lib().sslam_lightglue_range_overflow(self.handle, C.byref(f)))
+        return bool(f.value)
+
     def debug_key_split(self, ks: int):
         """Test hook: force the key split of the attention launches (0 = by batch size)."""
         _native.check(_native.lib().sslam_lightglue_debug_key_split(self.handle, int(ks)))

@@ -1,0 +1,113 @@
+"""Golden vectors from the independent port of LightGlue that ships in `transformers`
+(transformers/models/lightglue/modeling_lightglue.py), run in the BUILD container.
+
+The HF port is NOT the dependency the reference pins (cvg/LightGlue) - it is a second, separately
+written implementation of the same published network.  Where its arithmetic coincides with
+upstream's it gives an independent check of the restatement in oracle/lightglue_ref.py (and of the
+HIP path) that nothing in this repository wrote:
+
+    positional encoder   LightGluePositionalEncoder          == posenc (Wr, cos / sin, interleave)
+    self block           LightGlueAttention + LightGlueMLP   == Wqkv (de-interleaved into q/k/v),
+                                                                rotary, softmax(q k^T / 8) v, out_proj,
+                                                                ffn = Linear, LayerNorm, GELU, Linear
+    cross block          LightGlueAttention(encoder states)  == shared to_qk (loaded as q_proj AND
+                                                                k_proj), to_v, to_out, ffn
+    assignment           LightGlueMatchAssignmentLayer       == final_proj / 256^.25, similarity,
+                                                                matchability, sigmoid_log_double_softmax
+    match filter         get_matches_from_scores             == filter_matches (mutual arg-max, 0.1)
+    token confidence     LightGlueTokenConfidenceLayer       == token_confidence
+
+What does NOT coincide and is therefore bypassed: keypoint normalisation (HF: image size; the
+reference's call passes no image size, so upstream uses the keypoints' bounding box - the oracle's
+normalised keypoints are fed to the HF encoder directly), padding masks / early stopping / pruning
+(M = N, all layers, both switched off in the oracle for this comparison).
+
+Weights: oracle state dict `weights.random_lightglue_state_dict(SEED, ...)` mapped onto the HF
+modules.  Stored: the inputs, per-stage outputs of the HF modules, and a checksum of the weights.
+
+    python tests/golden/make_hf_lightglue_golden.py        # writes tests/golden/hf_lightglue.npz
+"""
+import importlib
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+import lg_inputs                                                     # noqa: E402
+from oracle import lightglue_ref as L                                # noqa: E402
+
+SEED, N, LAYERS = 5, 64, 9
+KEEP = {'self_0', 'cross_0', 'cross_3', 'self_8', 'cross_8', 'conf_0', 'conf_7'}     # stages stored (fixture size)
+SD_KW = dict(match_gain=4.0, match_bias=3.0)
+
+
+def build_hf_layer(hf, cfg, sd, i):
+    t = lambda k: torch.as_tensor(sd[k], dtype=torch.float32)       # noqa: E731
+    layer = hf.LightGlueTransformerLayer(cfg, i).eval()
+    wqkv, bqkv = t(f"transformers.{i}.self_attn.Wqkv.weight"), t(f"transformers.{i}.self_attn.Wqkv.bias")
+    # upstream: qkv.unflatten(-1, (heads, -1, 3)) -> output row (h*64 + d)*3 + s belongs to s in {q,k,v}
+    sa = layer.self_attention
+    for s, proj in enumerate((sa.q_proj, sa.k_proj, sa.v_proj)):
+        proj.weight.data = wqkv[s::3].clone(); proj.bias.data = bqkv[s::3].clone()
+    sa.o_proj.weight.data = t(f"transformers.{i}.self_attn.out_proj.weight"); sa.o_proj.bias.data = t(f"transformers.{i}.self_attn.out_proj.bias")
+    ca = layer.cross_attention
+    for proj in (ca.q_proj, ca.k_proj):                               # the shared to_qk projection
+        proj.weight.data = t(f"transformers.{i}.cross_attn.to_qk.weight").clone()
+        proj.bias.data = t(f"transformers.{i}.cross_attn.to_qk.bias").clone()
+    ca.v_proj.weight.data = t(f"transformers.{i}.cross_attn.to_v.weight"); ca.v_proj.bias.data = t(f"transformers.{i}.cross_attn.to_v.bias")
+    ca.o_proj.weight.data = t(f"transformers.{i}.cross_attn.to_out.weight"); ca.o_proj.bias.data = t(f"transformers.{i}.cross_attn.to_out.bias")
+    for mlp, name in ((layer.self_mlp, "self_attn"), (layer.cross_mlp, "cross_attn")):
+        mlp.fc1.weight.data = t(f"transformers.{i}.{name}.ffn.0.weight"); mlp.fc1.bias.data = t(f"transformers.{i}.{name}.ffn.0.bias")
+        mlp.layer_norm.weight.data = t(f"transformers.{i}.{name}.ffn.1.weight"); mlp.layer_norm.bias.data = t(f"transformers.{i}.{name}.ffn.1.bias")
+        mlp.fc2.weight.data = t(f"transformers.{i}.{name}.ffn.3.weight"); mlp.fc2.bias.data = t(f"transformers.{i}.{name}.ffn.3.bias")
+    return layer
+
+
+def main():
+    hf = importlib.import_module("transformers.models.lightglue.modeling_lightglue")
+    from transformers import LightGlueConfig
+    W = importlib.import_module("opencv-simpleslam_amd.weights")
+    sd = W.random_lightglue_state_dict(SEED, **SD_KW)
+    cfg = LightGlueConfig(descriptor_dim=256, num_hidden_layers=LAYERS, num_attention_heads=4)
+    cfg._attn_implementation = "eager"
+    k0, d0, k1, d1 = lg_inputs.make_pair(N, seed=21)
+    t = lambda k: torch.as_tensor(sd[k], dtype=torch.float32)       # noqa: E731
+    out = {"seed": SEED, "n": N, "k0": k0, "d0": d0, "k1": k1, "d1": d1,
+           "weight_checksum": np.float64(sum(float(np.abs(np.asarray(v, np.float64)).sum()) for v in sd.values()))}
+    with torch.no_grad():
+        # keypoint normalisation + input projection are NOT HF's (see module docstring)
+        kn = torch.stack([L.normalize_keypoints(torch.as_tensor(k)[None])[0] for k in (k0, k1)])      # [2, N, 2]
+        x = torch.nn.functional.linear(torch.as_tensor(np.stack([d0, d1])), t("input_proj.weight"), t("input_proj.bias"))
+        pe = hf.LightGluePositionalEncoder(cfg).eval()
+        pe.projector.weight.data = t("posenc.Wr.weight")
+        (emb,) = pe(kn)
+        out["kn"] = kn.numpy(); out["cos"] = emb[0].numpy(); out["sin"] = emb[1].numpy(); out["x_in"] = x.numpy()
+        for i in range(LAYERS):
+            layer = build_hf_layer(hf, cfg, sd, i)
+            x, hidden, _ = layer(x, emb, None, output_hidden_states=True)
+            if f"self_{i}" in KEEP:
+                out[f"self_{i}"] = hidden[1].numpy()    # descriptors after the self block
+            if f"cross_{i}" in KEEP:
+                out[f"cross_{i}"] = x.numpy()           # after the cross block
+            tc = hf.LightGlueTokenConfidenceLayer(cfg).eval()
+            if i < LAYERS - 1 and f"conf_{i}" in KEEP:
+                tc.token.weight.data = t(f"token_confidence.{i}.token.0.weight"); tc.token.bias.data = t(f"token_confidence.{i}.token.0.bias")
+                out[f"conf_{i}"] = tc(x).numpy()
+        ma = hf.LightGlueMatchAssignmentLayer(cfg).eval()
+        i = LAYERS - 1
+        ma.final_projection.weight.data = t(f"log_assignment.{i}.final_proj.weight"); ma.final_projection.bias.data = t(f"log_assignment.{i}.final_proj.bias")
+        ma.matchability.weight.data = t(f"log_assignment.{i}.matchability.weight"); ma.matchability.bias.data = t(f"log_assignment.{i}.matchability.bias")
+        scores = ma(x, None)
+        out["log_scores"] = scores[0].numpy()
+        matches, mscores = hf.get_matches_from_scores(scores, 0.1)
+        out["matches0"] = matches[0].numpy(); out["mscores0"] = mscores[0].numpy()
+    dst = ROOT / "tests" / "golden" / "hf_lightglue.npz"
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, dst.stat().st_size, "bytes;", int((out["matches0"] > -1).sum()), "matches")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,92 @@
+"""The names slam/monocular/main_revamped.py:48-52 imports, driven the way the reference drives them
+(reference slam/core/features_utils.py:18-30, :85-124, :136-171), on the GPU."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+import frames
+from conftest import load_pkg
+from oracle import aliked_ref, lightglue_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fu():
+    return load_pkg("slam.core.features_utils")
+
+
+@pytest.fixture(scope="module")
+def pipeline(fu, gpu_ctx):
+    """init_feature_pipeline(args) with the reference's default max_features (4000, features_utils.py:25)."""
+    args = SimpleNamespace(use_lightglue=True, min_conf=0.05)            # no max_features: the default applies
+    det, mat = fu.init_feature_pipeline(args)
+    yield args, det, mat
+    det.close(); mat.close()
+
+
+def test_init_feature_pipeline_defaults(pipeline):
+    args, det, mat = pipeline
+    assert det.max_num_keypoints == 4000 and mat.max_kpts == 4000 and mat.capacity == 4096
+    assert list(mat.parameters()) == []                                  # the reference probes matcher.parameters()
+
+
+def test_extractor_and_matcher_conventions(fu, pipeline):
+    args, det, mat = pipeline
+    W = load_pkg("weights")
+    T = load_pkg("slam.core.types")
+    img0, img1 = frames.structured_frame(0), frames.structured_frame(1)
+    kp0, des0 = fu.feature_extractor(args, img0, det)
+    kp1, des1 = fu.feature_extractor(args, img1, det)
+    assert isinstance(kp0, list) and des0.dtype == np.float32 and des0.shape == (len(kp0), 128)
+    assert all(hasattr(k, "pt") and isinstance(k.pt[0], float) for k in kp0[:5])
+    np.testing.assert_allclose(np.linalg.norm(des0, axis=1), 1.0, atol=1e-5)      # unit rows (:100)
+    ref = aliked_ref.aliked_extract(W.random_aliked_state_dict(0), img0, 4000)
+    assert abs(len(kp0) - len(ref["keypoints"])) <= 0.005 * len(ref["keypoints"]) + 2
+    # returned arrays are the caller's: a second extraction must not alias them
+    keep = des0.copy()
+    fu.feature_extractor(args, img1, det)
+    np.testing.assert_array_equal(des0, keep)
+
+    m = fu.feature_matcher(args, kp0, kp1, des0, des1, mat)
+    assert isinstance(m, list) and len(m) > 0 and all(hasattr(x, "queryIdx") and hasattr(x, "trainIdx") for x in m[:5])
+    q = [x.queryIdx for x in m]
+    assert q == sorted(q) and len(set(q)) == len(q)                       # ascending queryIdx, one match per query
+    xy0 = np.array([k.pt for k in kp0], np.float32); xy1 = np.array([k.pt for k in kp1], np.float32)
+    rij, _, _ = lightglue_ref.reference_feature_matcher(W.random_lightglue_state_dict(0), xy0, xy1, des0, des1, args.min_conf)
+    np.testing.assert_array_equal(np.array([(x.queryIdx, x.trainIdx) for x in m], np.int64).reshape(-1, 2), rij)
+
+    # None / empty inputs -> [] (features_utils.py:118-124); ([], []) is what the ORB branch returns (:105-106)
+    assert fu.feature_matcher(args, None, kp1, des0, des1, mat) == []
+    assert fu.feature_matcher(args, kp0, kp1, None, des1, mat) == []
+    assert fu.feature_matcher(args, [], kp1, des0[:0], des1, mat) == []
+    assert fu.feature_matcher(args, kp0, kp1, des0, np.zeros((0, 128), np.float32), mat) == []
+
+    # torch-tensor descriptors are accepted like numpy ones (features_utils.py:136-154)
+    torch = pytest.importorskip("torch")
+    m_t = fu.feature_matcher(args, kp0, kp1, torch.from_numpy(des0), torch.from_numpy(des1), mat)
+    assert [(x.queryIdx, x.trainIdx) for x in m_t] == [(x.queryIdx, x.trainIdx) for x in m]
+
+    # the keypoint list is the caller's: an in-place edit of an INTERIOR keypoint must be seen
+    kp0_mut = list(kp0)
+    i = len(kp0_mut) // 2
+    kp0_mut[i] = T.KeyPoint(kp0[i].pt[0] + 200.0, kp0[i].pt[1], 1)
+    xy0m = np.array([k.pt for k in kp0_mut], np.float32)
+    rij_m, _, _ = lightglue_ref.reference_feature_matcher(W.random_lightglue_state_dict(0), xy0m, xy1, des0, des1, args.min_conf)
+    m_m = fu.feature_matcher(args, kp0_mut, kp1, des0, des1, mat)
+    np.testing.assert_array_equal(np.array([(x.queryIdx, x.trainIdx) for x in m_m], np.int64).reshape(-1, 2), rij_m)
+
+    # min_conf is read from args on every call, default 0.7 (features_utils.py:168)
+    strict = fu.feature_matcher(SimpleNamespace(use_lightglue=True), kp0, kp1, des0, des1, mat)
+    r7, _, _ = lightglue_ref.reference_feature_matcher(W.random_lightglue_state_dict(0), xy0, xy1, des0, des1, 0.7)
+    assert len(strict) == len(r7) <= len(m)
+
+
+def test_grayscale_and_float_images(fu, pipeline):
+    args, det, mat = pipeline
+    g = frames.structured_frame(2, c=1)
+    kp, des = fu.feature_extractor(args, g, det)
+    assert len(kp) > 0 and des.shape[1] == 128
+    with pytest.raises(TypeError):
+        fu.feature_extractor(args, g.astype(np.float32), det)

@@ -1,0 +1,77 @@
+"""End to end on identical frames: image -> HIP extract -> HIP match, against image -> oracle
+extract -> oracle match (north_star: "outputs must match the reference's own torch-CPU
+ALIKED/LightGlue on identical frames"; reference call chain slam/monocular/main_revamped.py:321-328
+-> features_utils.py:85-171).
+
+The two extractions may disagree on a handful of keypoints (a ~1e-6 score difference can flip an
+NMS / threshold / top-k decision, tests/test_aliked_gpu.py), and LightGlue's assignment of every
+keypoint depends on the whole set, so the comparison is made in the oracle's keypoint numbering:
+HIP keypoint i is identified with the oracle keypoint at the same pixel (1e-3 px), HIP matches are
+renumbered through that map, and the test asserts
+  * when the two keypoint sets coincide: the index arrays are IDENTICAL;
+  * otherwise: every HIP match between common keypoints that the oracle also scores clearly
+    (> min_conf + margin) is the oracle's match, and at least 97 % of the oracle's matches survive.
+The surviving fraction is printed (pytest -s) and returned for the record."""
+import numpy as np
+import pytest
+
+import frames
+from conftest import load_pkg
+from oracle import aliked_ref, lightglue_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _ident(xy_h, xy_o):
+    """hip index -> oracle index (or -1) by pixel position (unique within 1e-3 px)."""
+    from scipy.spatial import cKDTree
+    d, j = cKDTree(xy_o).query(xy_h, k=1)
+    return np.where(d < 1e-3, j, -1)
+
+
+@pytest.mark.parametrize("kind,K", [("structured", 2048), ("noise", 1024)])
+def test_image_to_match_indices_against_the_oracle(gpu_ctx, kind, K):
+    W = load_pkg("weights")
+    AL, LG = load_pkg("aliked").AlikedHIP, load_pkg("lightglue").LightGlueHIP
+    sd_a = W.random_aliked_state_dict(0)
+    sd_l = W.random_lightglue_state_dict(1, match_gain=4.0, match_bias=3.0)
+    f = frames.structured_frame if kind == "structured" else frames.noise_frame
+    img0, img1 = f(0), f(1)
+    det = AL(sd_a, max_num_keypoints=K, max_h=376, max_w=1241, ctx=gpu_ctx)
+    mat = LG(sd_l, max_kpts=K, ctx=gpu_ctx, filter_threshold=0.0)
+    min_conf = 0.05
+    xy0, de0 = det.extract(img0, K); xy1, de1 = det.extract(img1, K)
+    ij_h, sc_h, stop_h = mat.match(xy0, de0, xy1, de1, min_conf=min_conf)
+
+    r0 = aliked_ref.aliked_extract(sd_a, img0, K); r1 = aliked_ref.aliked_extract(sd_a, img1, K)
+    out = lightglue_ref.lightglue_forward(sd_l, r0["keypoints"], r0["descriptors"], r1["keypoints"], r1["descriptors"],
+                                          {"filter_threshold": 0.0})
+    keep = out["scores"].numpy() > min_conf
+    ij_o, sc_o = out["matches"].numpy()[keep], out["scores"].numpy()[keep]
+
+    m0, m1 = _ident(xy0, r0["keypoints"]), _ident(xy1, r1["keypoints"])
+    same_sets = (len(xy0) == len(r0["keypoints"]) and len(xy1) == len(r1["keypoints"])
+                 and np.array_equal(m0, np.arange(len(xy0))) and np.array_equal(m1, np.arange(len(xy1))))
+    common0, common1 = (m0 >= 0).mean(), (m1 >= 0).mean()
+    assert common0 > 0.99 and common1 > 0.99, (common0, common1)
+    assert len(ij_o) > 20, "vacuous: the oracle found no matches on these frames"
+    if same_sets:
+        np.testing.assert_array_equal(ij_h, ij_o)
+        np.testing.assert_allclose(sc_h, sc_o, atol=1e-3)
+        assert stop_h == out["stop"]
+        frac = 1.0
+    else:
+        ren = np.stack([m0[ij_h[:, 0]], m1[ij_h[:, 1]]], 1)
+        ren = ren[(ren >= 0).all(1)]
+        got = {tuple(p) for p in ren.tolist()}
+        want = {tuple(p) for p in ij_o.tolist()}
+        frac = len(got & want) / max(len(want), 1)
+        assert frac >= 0.97, frac
+        # a HIP match between common keypoints never contradicts a CLEAR oracle match of the same query
+        clear = {int(i): int(j) for (i, j), s in zip(ij_o.tolist(), sc_o.tolist()) if s > min_conf + 0.05}
+        for i, j in ren.tolist():
+            if i in clear:
+                assert clear[i] == j, (i, j, clear[i])
+    print(f"\n[end-to-end {kind} K={K}] keypoints common {common0:.4f}/{common1:.4f}, identical sets: {same_sets}, "
+          f"oracle matches {len(ij_o)}, HIP matches {len(ij_h)}, surviving fraction {frac:.4f}")
+    det.close(); mat.close()
