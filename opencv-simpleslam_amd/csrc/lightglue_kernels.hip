@@ -1208,10 +1208,20 @@ constexpr float P_BIAS = 14.0f;
 #endif
 typedef float float2v __attribute__((ext_vector_type(2)));
 
+// Deferred rescale (flash-attention "lazy max"): the running maximum - and with it the 64
+// accumulator registers of O - is only updated when some query of the wave sees a logit more than
+// RESCALE_THR (log2 units) above its current reference; otherwise P is simply taken against the old
+// reference (P <= 2^(P_BIAS + RESCALE_THR) = 2^15.5 < 65504, still an fp16 normal) and the O rescale
+// (a quarter of the softmax arithmetic of a sub-step, on a kernel that is VALU-issue bound) is
+// skipped.  After the first few key tiles almost every sub-step takes the cheap path.  The caller
+// applies `alpha` to O when `rescale` is set, AFTER the P.V of the previous sub-step (those P were
+// taken against the old reference) - both halves of the wave decide together (wave-uniform branch).
+constexpr float RESCALE_THR = 1.5f;
+
 template <bool MASK>
 __device__ __forceinline__ void attn_softmax_step(const f32x16& s1, const f32x16& s2, int kbase, int nk, int lane,
                                                   float& m_run, float& l_run, half8 (&ph)[2], half8 (&pl)[2],
-                                                  f32x16& o1a, f32x16& o2a, f32x16& o1b, f32x16& o2b) {
+                                                  float& alpha, bool& rescale) {
     float2v sv[8];
     const float2v inv2 = {SPLIT_INV, SPLIT_INV};
 #pragma unroll
@@ -1231,10 +1241,17 @@ __device__ __forceinline__ void attn_softmax_step(const f32x16& s1, const f32x16
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
         tmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
     }
-    const float m_new = fmaxf(m_run, tmax);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    const float mb = m_new - P_BIAS;
+    // (m_run = -inf on the first sub-step: tmax is finite there - every block's first sub-tile holds at
+    // least one valid key - so the comparison is true and the reference is initialised)
+    rescale = __any(tmax > m_run + RESCALE_THR);
+    if (rescale) {
+        const float m_new = fmaxf(m_run, tmax);
+        alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+    } else {
+        alpha = 1.0f;
+    }
+    const float mb = m_run - P_BIAS;
     const float2v mb2 = {mb, mb};
     float2v psum = {0.0f, 0.0f};
     const float2v sc2 = {sslam::SPLIT_SCALE, sslam::SPLIT_SCALE};
@@ -1253,7 +1270,6 @@ __device__ __forceinline__ void attn_softmax_step(const f32x16& s1, const f32x16
         pl[r >> 2][2 * (r & 3)] = ll[0]; pl[r >> 2][2 * (r & 3) + 1] = ll[1];
     }
     l_run = l_run * alpha + (psum[0] + psum[1]);
-    o1a *= alpha; o2a *= alpha; o1b *= alpha; o2b *= alpha;
 }
 
 #ifndef ATTN_ABL
@@ -1268,9 +1284,9 @@ __device__ __forceinline__ f32x16 mf_fake(half8 a, half8 b, f32x16 c) { c[0] += 
 #if ATTN_ABL & 2
 template <bool MASK>
 __device__ __forceinline__ void softmax_fake(const f32x16& s1, const f32x16& s2, int, int, int, float& m_run, float& l_run,
-                                             half8 (&ph)[2], half8 (&pl)[2], f32x16&, f32x16&, f32x16&, f32x16&) {
+                                             half8 (&ph)[2], half8 (&pl)[2], float& alpha, bool& rescale) {
     for (int i = 0; i < 2; ++i) for (int e = 0; e < 8; ++e) { ph[i][e] = (_Float16)s1[8 * i + e]; pl[i][e] = (_Float16)s2[8 * i + e]; }
-    m_run = 0.0f; l_run += 1.0f;
+    m_run = 0.0f; l_run += 1.0f; alpha = 1.0f; rescale = false;
 }
 #define SOFTMAX_STEP softmax_fake
 #else
@@ -1415,11 +1431,13 @@ __global__ __launch_bounds__(256, 2) void lg_attention_p_kernel(AttnArgsH p) {
             constexpr bool MASK = decltype(mask_c)::value;
             const int b = (tile - t0) & 1;
             const bool last = tile + 1 == t1;
+            float alpha; bool rescale;
             // even: softmax(S(tile,0)) | S(tile,1) = K.Q^T | O += V^T(tile-1,1) P
             pv(tile > t0 ? b ^ 1 : b, 1, ph, pl);
             qk(b, 1, n1, n2);
-            SOFTMAX_STEP<MASK>(s1, s2, tile * AK, nk, lane, m_run, l_run, nh, nl, o1a, o2a, o1b, o2b);
+            SOFTMAX_STEP<MASK>(s1, s2, tile * AK, nk, lane, m_run, l_run, nh, nl, alpha, rescale);
             ATTN_INTERLEAVE();
+            if (rescale) { o1a *= alpha; o2a *= alpha; o1b *= alpha; o2b *= alpha; }
             __syncthreads();     // K(tile+1), V^T(tile) landed; K(tile) and V^T(tile-1) are free
 #if !(ATTN_ABL & 8)
             if (is_v) { if (tile + 1 < t1) issue_tile(tile + 1, b ^ 1); }
@@ -1428,8 +1446,9 @@ __global__ __launch_bounds__(256, 2) void lg_attention_p_kernel(AttnArgsH p) {
             // odd: softmax(S(tile,1)) | S(tile+1,0) | O += V^T(tile,0) P
             pv(b, 0, nh, nl);
             qk(last ? b : b ^ 1, 0, s1, s2);
-            SOFTMAX_STEP<MASK>(n1, n2, tile * AK + 32, nk, lane, m_run, l_run, ph, pl, o1a, o2a, o1b, o2b);
+            SOFTMAX_STEP<MASK>(n1, n2, tile * AK + 32, nk, lane, m_run, l_run, ph, pl, alpha, rescale);
             ATTN_INTERLEAVE();
+            if (rescale) { o1a *= alpha; o2a *= alpha; o1b *= alpha; o2b *= alpha; }
         };
         const bool ragged = (nk & (AK - 1)) != 0;            // only the last tile of the image can be
         const int tfull = (ragged && t1 == ntiles) ? t1 - 1 : t1;
