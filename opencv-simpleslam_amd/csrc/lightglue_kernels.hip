@@ -1221,7 +1221,7 @@ constexpr float RESCALE_THR = 1.5f;
 template <bool MASK>
 __device__ __forceinline__ void attn_softmax_step(const f32x16& s1, const f32x16& s2, int kbase, int nk, int lane,
                                                   float& m_run, float& l_run, half8 (&ph)[2], half8 (&pl)[2],
-                                                  float& alpha, bool& rescale) {
+                                                  float& alpha, bool& rescale, bool qvalid) {
     float2v sv[8];
     const float2v inv2 = {SPLIT_INV, SPLIT_INV};
 #pragma unroll
@@ -1243,7 +1243,9 @@ __device__ __forceinline__ void attn_softmax_step(const f32x16& s1, const f32x16
     }
     // (m_run = -inf on the first sub-step: tmax is finite there - every block's first sub-tile holds at
     // least one valid key - so the comparison is true and the reference is initialised)
-    rescale = __any(tmax > m_run + RESCALE_THR);
+    // only lanes that own a real query vote: the rows beyond n hold whatever an earlier, larger problem
+    // left there, and the path taken (hence the last bits of the result) must not depend on it
+    rescale = __any(qvalid && tmax > m_run + RESCALE_THR);
     if (rescale) {
         const float m_new = fmaxf(m_run, tmax);
         alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -1251,7 +1253,11 @@ __device__ __forceinline__ void attn_softmax_step(const f32x16& s1, const f32x16
     } else {
         alpha = 1.0f;
     }
-    const float mb = m_run - P_BIAS;
+    // P = 2^(s - m + P_BIAS).  (m - P_BIAS) is rounded ONCE: for |m| >= 2^23 its rounding error reaches
+    // half a unit and larger and 2^(15.5 + error) leaves fp16 (inf in the high plane, then NaN).  Logits
+    // that large only come from absurdly scaled inputs, but the answer must still be a softmax: the
+    // bias is dropped there (P <= 2^1.5; the common factor cancels in o / l either way).
+    const float mb = fabsf(m_run) < 4.0e6f ? m_run - P_BIAS : m_run;
     const float2v mb2 = {mb, mb};
     float2v psum = {0.0f, 0.0f};
     const float2v sc2 = {sslam::SPLIT_SCALE, sslam::SPLIT_SCALE};
@@ -1284,7 +1290,7 @@ __device__ __forceinline__ f32x16 mf_fake(half8 a, half8 b, f32x16 c) { c[0] += 
 #if ATTN_ABL & 2
 template <bool MASK>
 __device__ __forceinline__ void softmax_fake(const f32x16& s1, const f32x16& s2, int, int, int, float& m_run, float& l_run,
-                                             half8 (&ph)[2], half8 (&pl)[2], float& alpha, bool& rescale) {
+                                             half8 (&ph)[2], half8 (&pl)[2], float& alpha, bool& rescale, bool) {
     for (int i = 0; i < 2; ++i) for (int e = 0; e < 8; ++e) { ph[i][e] = (_Float16)s1[8 * i + e]; pl[i][e] = (_Float16)s2[8 * i + e]; }
     m_run = 0.0f; l_run += 1.0f; alpha = 1.0f; rescale = false;
 }
@@ -1325,6 +1331,7 @@ __global__ __launch_bounds__(256, 2) void lg_attention_p_kernel(AttnArgsH p) {
     const size_t koff = ((size_t)kimg * NH + head) * p.Kc * DH;
 
     const int qi = min(q0 + wave * 32 + lr, p.Kc - 1);
+    const bool qvalid = q0 + wave * 32 + lr < nq;
     half8 qh[4], ql[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -1435,7 +1442,7 @@ __global__ __launch_bounds__(256, 2) void lg_attention_p_kernel(AttnArgsH p) {
             // even: softmax(S(tile,0)) | S(tile,1) = K.Q^T | O += V^T(tile-1,1) P
             pv(tile > t0 ? b ^ 1 : b, 1, ph, pl);
             qk(b, 1, n1, n2);
-            SOFTMAX_STEP<MASK>(s1, s2, tile * AK, nk, lane, m_run, l_run, nh, nl, alpha, rescale);
+            SOFTMAX_STEP<MASK>(s1, s2, tile * AK, nk, lane, m_run, l_run, nh, nl, alpha, rescale, qvalid);
             ATTN_INTERLEAVE();
             if (rescale) { o1a *= alpha; o2a *= alpha; o1b *= alpha; o2b *= alpha; }
             __syncthreads();     // K(tile+1), V^T(tile) landed; K(tile) and V^T(tile-1) are free
@@ -1446,7 +1453,7 @@ __global__ __launch_bounds__(256, 2) void lg_attention_p_kernel(AttnArgsH p) {
             // odd: softmax(S(tile,1)) | S(tile+1,0) | O += V^T(tile,0) P
             pv(b, 0, nh, nl);
             qk(last ? b : b ^ 1, 0, s1, s2);
-            SOFTMAX_STEP<MASK>(n1, n2, tile * AK + 32, nk, lane, m_run, l_run, ph, pl, alpha, rescale);
+            SOFTMAX_STEP<MASK>(n1, n2, tile * AK + 32, nk, lane, m_run, l_run, ph, pl, alpha, rescale, qvalid);
             ATTN_INTERLEAVE();
             if (rescale) { o1a *= alpha; o2a *= alpha; o1b *= alpha; o2b *= alpha; }
         };
@@ -2095,7 +2102,8 @@ int sslam_lightglue_match_host(sslam_lightglue* g, const float* xy0, const float
  * unless `which` has 0x100 * pair added).
  * which: 0 = x (token states) [2][Kc][256], 1 = sim [Kc][Kc], 2 = ind [2][Kc] (int32),
  *        3 = prune counters [2][Kc] (int32), 4 = info {K, stop, n0, n1} (single-pair host call),
- *        5 = enc_cos [2][Kc][32] */
+ *        5 = enc_cos [2][Kc][32], 6 = FFN hidden fp32 [2][Kc][512], 7 / 8 / 9 = hi planes (fp16) of the
+ *        attention context / q / k */
 int sslam_lightglue_debug_read(sslam_lightglue* g, int which, void* dst, size_t bytes) {
     SSLAM_REQUIRE(g && dst, "sslam_lightglue_debug_read: NULL argument");
     const size_t K = (size_t)g->Kc;
@@ -2110,6 +2118,10 @@ int sslam_lightglue_debug_read(sslam_lightglue* g, int which, void* dst, size_t 
         case 3: cap = 2 * K * 4; src = (const char*)g->prune + pair * cap; break;
         case 4: cap = 16; src = (const char*)g->out_info; break;
         case 5: cap = 2 * K * ENC * 4; src = (const char*)g->enc_cos + pair * cap; break;
+        case 6: cap = 2 * K * 2 * D * 4; src = (const char*)g->hid + pair * cap; break;          // FFN hidden (pre-LN), fp32
+        case 7: cap = 2 * K * D * 2; src = (const char*)g->msgs_hi; break;                       // context planes (k-panel layout), pair 0
+        case 8: cap = 2 * K * D * 2; src = (const char*)g->qs_hi + pair * cap; break;            // q hi plane [2][4][Kc][64]
+        case 9: cap = 2 * K * D * 2; src = (const char*)g->ks_hi + pair * cap; break;
         default: SSLAM_REQUIRE(false, "sslam_lightglue_debug_read: unknown buffer %d", which);
     }
     SSLAM_REQUIRE(bytes <= cap, "sslam_lightglue_debug_read: %zu bytes requested, buffer has %zu", bytes, cap);

@@ -17,11 +17,31 @@ def fu():
     return load_pkg("slam.core.features_utils")
 
 
+SD_L = dict(seed=1, match_gain=4.0, match_bias=3.0)      # random-init weights that produce matches (not vacuous)
+
+
+_SD_CACHE = {}
+
+
+def _sd_l():
+    if "sd" in _SD_CACHE:
+        return _SD_CACHE["sd"]
+    W = load_pkg("weights")
+    _SD_CACHE["sd"] = W.random_lightglue_state_dict(SD_L["seed"], match_gain=SD_L["match_gain"], match_bias=SD_L["match_bias"])
+    return _SD_CACHE["sd"]
+
+
 @pytest.fixture(scope="module")
 def pipeline(fu, gpu_ctx):
-    """init_feature_pipeline(args) with the reference's default max_features (4000, features_utils.py:25)."""
+    """init_feature_pipeline(args) with the reference's default max_features (4000, features_utils.py:25).
+    No checkpoint exists in the image, so the overlay falls back to seeded random weights; the seed is
+    steered to a set that yields matches on the synthetic frames."""
+    mp = pytest.MonkeyPatch()
+    sd = _sd_l()                                                      # built BEFORE the function is patched
+    mp.setattr(fu._weights, "random_lightglue_state_dict", lambda seed=0: sd)
     args = SimpleNamespace(use_lightglue=True, min_conf=0.05)            # no max_features: the default applies
     det, mat = fu.init_feature_pipeline(args)
+    mp.undo()
     yield args, det, mat
     det.close(); mat.close()
 
@@ -54,7 +74,7 @@ def test_extractor_and_matcher_conventions(fu, pipeline):
     q = [x.queryIdx for x in m]
     assert q == sorted(q) and len(set(q)) == len(q)                       # ascending queryIdx, one match per query
     xy0 = np.array([k.pt for k in kp0], np.float32); xy1 = np.array([k.pt for k in kp1], np.float32)
-    rij, _, _ = lightglue_ref.reference_feature_matcher(W.random_lightglue_state_dict(0), xy0, xy1, des0, des1, args.min_conf)
+    rij, _, _ = lightglue_ref.reference_feature_matcher(_sd_l(), xy0, xy1, des0, des1, args.min_conf)
     np.testing.assert_array_equal(np.array([(x.queryIdx, x.trainIdx) for x in m], np.int64).reshape(-1, 2), rij)
 
     # None / empty inputs -> [] (features_utils.py:118-124); ([], []) is what the ORB branch returns (:105-106)
@@ -73,13 +93,13 @@ def test_extractor_and_matcher_conventions(fu, pipeline):
     i = len(kp0_mut) // 2
     kp0_mut[i] = T.KeyPoint(kp0[i].pt[0] + 200.0, kp0[i].pt[1], 1)
     xy0m = np.array([k.pt for k in kp0_mut], np.float32)
-    rij_m, _, _ = lightglue_ref.reference_feature_matcher(W.random_lightglue_state_dict(0), xy0m, xy1, des0, des1, args.min_conf)
+    rij_m, _, _ = lightglue_ref.reference_feature_matcher(_sd_l(), xy0m, xy1, des0, des1, args.min_conf)
     m_m = fu.feature_matcher(args, kp0_mut, kp1, des0, des1, mat)
     np.testing.assert_array_equal(np.array([(x.queryIdx, x.trainIdx) for x in m_m], np.int64).reshape(-1, 2), rij_m)
 
     # min_conf is read from args on every call, default 0.7 (features_utils.py:168)
     strict = fu.feature_matcher(SimpleNamespace(use_lightglue=True), kp0, kp1, des0, des1, mat)
-    r7, _, _ = lightglue_ref.reference_feature_matcher(W.random_lightglue_state_dict(0), xy0, xy1, des0, des1, 0.7)
+    r7, _, _ = lightglue_ref.reference_feature_matcher(_sd_l(), xy0, xy1, des0, des1, 0.7)
     assert len(strict) == len(r7) <= len(m)
 
 

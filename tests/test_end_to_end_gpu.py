@@ -34,13 +34,26 @@ def test_image_to_match_indices_against_the_oracle(gpu_ctx, kind, K):
     W = load_pkg("weights")
     AL, LG = load_pkg("aliked").AlikedHIP, load_pkg("lightglue").LightGlueHIP
     sd_a = W.random_aliked_state_dict(0)
-    sd_l = W.random_lightglue_state_dict(1, match_gain=4.0, match_bias=3.0)
+    sd_l = None      # built below from the frames' own descriptors
     f = frames.structured_frame if kind == "structured" else frames.noise_frame
     img0, img1 = f(0), f(1)
     det = AL(sd_a, max_num_keypoints=K, max_h=376, max_w=1241, ctx=gpu_ctx)
-    mat = LG(sd_l, max_kpts=K, ctx=gpu_ctx, filter_threshold=0.0)
-    min_conf = 0.05
     xy0, de0 = det.extract(img0, K); xy1, de1 = det.extract(img1, K)
+    # Random-weight ALIKED descriptors share one dominant direction (cosine 0.998 between unrelated
+    # keypoints) and random transformer weights scramble what is left: one mutual match in
+    # 2048 x 2048.  The LightGlue test weights therefore (i) project that common direction out in
+    # input_proj and amplify the rest, (ii) damp the output Linear of every FFN (x 0.05) so the
+    # descriptor similarity of the two overlapping frames reaches the assignment, (iii) sharpen
+    # final_proj (gain 30).  The whole network still runs; ~100 mutual matches are compared.
+    sd_l = W.random_lightglue_state_dict(1, match_gain=30.0, match_bias=3.0)
+    for k in sd_l:
+        if ".ffn.3." in k:
+            sd_l[k] = (np.asarray(sd_l[k]) * 0.05).astype(np.float32)
+    u = de0.astype(np.float64).mean(0); u /= np.linalg.norm(u)
+    sd_l["input_proj.weight"] = (30.0 * np.asarray(sd_l["input_proj.weight"], np.float64)
+                                 @ (np.eye(128) - np.outer(u, u))).astype(np.float32)
+    mat = LG(sd_l, max_kpts=K, ctx=gpu_ctx, filter_threshold=0.0)
+    min_conf = 0.0                 # every mutual arg-max pair is emitted and compared
     ij_h, sc_h, stop_h = mat.match(xy0, de0, xy1, de1, min_conf=min_conf)
 
     r0 = aliked_ref.aliked_extract(sd_a, img0, K); r1 = aliked_ref.aliked_extract(sd_a, img1, K)
@@ -68,7 +81,7 @@ def test_image_to_match_indices_against_the_oracle(gpu_ctx, kind, K):
         frac = len(got & want) / max(len(want), 1)
         assert frac >= 0.97, frac
         # a HIP match between common keypoints never contradicts a CLEAR oracle match of the same query
-        clear = {int(i): int(j) for (i, j), s in zip(ij_o.tolist(), sc_o.tolist()) if s > min_conf + 0.05}
+        clear = {int(i): int(j) for (i, j), s in zip(ij_o.tolist(), sc_o.tolist()) if s > 1e-3}
         for i, j in ren.tolist():
             if i in clear:
                 assert clear[i] == j, (i, j, clear[i])
