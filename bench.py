@@ -385,8 +385,9 @@ def main():
     # --kernel-trace reports for the kernel in either mode).  Both are printed.
     P = min(BATCH_PAIRS, FRAMES_PER_RANK - 1)
     K = MAX_KPTS
-    pairs = [(pipe.xy_ptr(s - 1), pipe.desc_ptr(s - 1), K, pipe.xy_ptr(s), pipe.desc_ptr(s), K,
-              pipe.count_ptr(s - 1), pipe.count_ptr(s)) for s in range(1, P + 1)]
+    sb = pipe.last_set * FRAMES_PER_RANK                 # record set of the last round
+    pairs = [(pipe.xy_ptr(sb + s - 1), pipe.desc_ptr(sb + s - 1), K, pipe.xy_ptr(sb + s), pipe.desc_ptr(sb + s), K,
+              pipe.count_ptr(sb + s - 1), pipe.count_ptr(sb + s)) for s in range(1, P + 1)]
     m0 = mats[0]
     m0.profile(True)
     for rep in range(3):

@@ -135,36 +135,42 @@ class FrameStreamPipeline:
         B, K = plan.frames_per_rank, self.K
         self.REC = record_floats(K)
         self.ctx = self.dets[0].ctx                      # allocations / copies that belong to no instance
-        dev_bytes = (B + 2) * self.REC * 4               # B slots + two halo slots (alternate by round)
+        # Two record sets (round parity) so that the extracts of round r+1 run underneath the matches of
+        # round r; + two halo slots for the N > 1 boundary record.  Outputs are double-buffered alike.
+        self.NSLOT = 2 * B + 2
+        dev_bytes = self.NSLOT * self.REC * 4
         self.torch = None
         if plan.world > 1:
             # the exchange goes through torch.distributed: its tensors own the record slab
             import torch
             self.torch = torch
-            self._slab_t = torch.zeros(((B + 2), self.REC), dtype=torch.float32,
+            self._slab_t = torch.zeros((self.NSLOT, self.REC), dtype=torch.float32,
                                        device=torch.device("cuda", self.ctx.device))
             self.slab = int(self._slab_t.data_ptr())
             self._cstream = torch.cuda.ExternalStream(self.ctx.stream, device=self.ctx.device)
             self._prev_last = torch.zeros(self.REC, dtype=torch.float32, device=self._slab_t.device)
+            torch.cuda.synchronize()
         else:
             self.slab = self.ctx.malloc(dev_bytes)
             self.ctx.memset_async(self.slab, 0, dev_bytes)
-        self.score = self.ctx.malloc(B * K * 4)
-        self.ij = self.ctx.malloc(B * K * 8)
-        self.msc = self.ctx.malloc(B * K * 4)
-        self.info = self.ctx.malloc(B * 16)
-        self.ctx.memset_async(self.info, 0, B * 16)
+        self.score = self.ctx.malloc(2 * B * K * 4)
+        self._ij = self.ctx.malloc(2 * B * K * 8)
+        self._msc = self.ctx.malloc(2 * B * K * 4)
+        self._info = self.ctx.malloc(2 * B * 16)
+        self.ctx.memset_async(self._info, 0, 2 * B * 16)
         self.ctx.sync()
-        self.ev_ext = [self.ctx.event() for _ in range(B)]
-        self.ev_halo = [self.ctx.event(), self.ctx.event()]        # halo slot (round & 1) is in place
-        self.ev_mdone = [self.ctx.event() for _ in self.mats]
-        self.ev_collated = self.ctx.event()
+        self.NBATCH = (B + self.P - 1) // self.P + 1            # (+1: a round without halo starts at pair 1)
+        self.ev_ext = [[self.ctx.event() for _ in range(B)] for _ in range(2)]
+        self.ev_batch = [[self.ctx.event() for _ in range(self.NBATCH)] for _ in range(2)]
+        self.n_batches = [0, 0]                                  # batches enqueued in the last round of each parity
+        self.ev_halo = [self.ctx.event(), self.ctx.event()]      # N > 1: halo slot (round & 1) is in place
+        self.ev_collated = [self.ctx.event(), self.ctx.event()]  # N > 1: the all-gather of that parity has read its set
         self.have_halo = False
-        self.started = False
         self.rounds = 0
+        self.batches = 0                                         # global batch counter (matcher round-robin)
         self.shared_map = None          # last collated round [world*B, REC] (torch tensor; N > 1 only)
 
-    # ---- record addressing
+    # ---- record addressing (slot = index into the slab; set p holds slots p*B .. p*B + B-1)
     def rec_ptr(self, slot: int) -> int:
         return self.slab + slot * self.REC * 4
 
@@ -177,48 +183,61 @@ class FrameStreamPipeline:
     def count_ptr(self, slot: int) -> int:
         return self.rec_ptr(slot) + self.K * ROW * 4
 
-    def _halo_slot(self, rnd: int) -> int:
-        return self.plan.frames_per_rank + (rnd & 1)
+    @property
+    def last_set(self) -> int:
+        return (self.rounds - 1) & 1
+
+    @property
+    def ij(self) -> int:                  # outputs of the last enqueued round
+        return self._ij + self.last_set * self.plan.frames_per_rank * self.K * 8
+
+    @property
+    def msc(self) -> int:
+        return self._msc + self.last_set * self.plan.frames_per_rank * self.K * 4
+
+    @property
+    def info(self) -> int:
+        return self._info + self.last_set * self.plan.frames_per_rank * 16
 
     def round(self, frames_dev, H, W, C):
         """frames_dev: device pointer (int, or any object with data_ptr()) of this rank's chunk,
         uint8 [B, H, W, C].  Enqueues B extracts + the batched matches (+ the collation when
-        world > 1); returns without synchronising."""
+        world > 1); returns without synchronising.  Round r uses record set r & 1: its extracts wait
+        only for the readers of that set (the matches and collation of round r-2, and pair 0 of
+        round r-1, which reads the last record of round r-2), so they overlap the matches of r-1."""
         plan, B, K = self.plan, self.plan.frames_per_rank, self.K
         NE, NM, P = len(self.dets), len(self.mats), self.P
         base = frames_dev if isinstance(frames_dev, int) else int(frames_dev.data_ptr())
         fbytes = int(H) * int(W) * int(C)
         rnd = self.rounds
-        halo_r, halo_w = self._halo_slot(rnd), self._halo_slot(rnd + 1)
+        p = rnd & 1
+        s_base = p * B                                   # first slot of this round's set
+        halo_slot = 2 * B + p
         single = plan.world == 1
-        if self.started:
-            # slots are overwritten: the previous round's readers (matchers, collation) must be done
-            for d in self.dets:
-                for ev in self.ev_mdone:
-                    d.ctx.wait(ev)
+        for d in self.dets:
+            if rnd >= 2:
+                for j in range(self.n_batches[p]):
+                    d.ctx.wait(self.ev_batch[p][j])
                 if not single:
-                    d.ctx.wait(self.ev_collated)
-        self.started = True
+                    d.ctx.wait(self.ev_collated[p])
+            if rnd >= 1 and self.n_batches[1 - p]:
+                d.ctx.wait(self.ev_batch[1 - p][0])
         for s in range(B):
             d = self.dets[s % NE]
-            d.extract_dev(base + s * fbytes, H, W, C, self.xy_ptr(s), self.desc_ptr(s), self.score + s * K * 4,
-                          self.count_ptr(s), max_kpts=K)
-            d.ctx.record(self.ev_ext[s])
+            d.extract_dev(base + s * fbytes, H, W, C, self.xy_ptr(s_base + s), self.desc_ptr(s_base + s),
+                          self.score + (s_base + s) * K * 4, self.count_ptr(s_base + s), max_kpts=K)
+            d.ctx.record(self.ev_ext[p][s])
         have_halo = self.have_halo
-        if single:
-            # next round's halo = this round's last frame (copied on that frame's extractor stream)
-            dl = self.dets[(B - 1) % NE]
-            dl.ctx.d2d_async(self.rec_ptr(halo_w), self.rec_ptr(B - 1), self.REC * 4)
-            dl.ctx.record(self.ev_halo[(rnd + 1) & 1])
-        else:
+        prev_slot = (1 - p) * B + B - 1                  # last frame of the previous round (one GPU)
+        if not single:
             # ---- multi-GPU: collate as soon as the EXTRACTS are done; the matches of this round run
             # on their own streams underneath the all-gather.  The collation rides on the first
             # extractor's stream (self.ctx), seen by torch as an external stream.
             torch = self.torch
             for s in range(B):
-                self.ctx.wait(self.ev_ext[s])
+                self.ctx.wait(self.ev_ext[p][s])
             with torch.cuda.stream(self._cstream):
-                self.shared_map = collate(self._slab_t[:B], plan, self.group)
+                self.shared_map = collate(self._slab_t[s_base:s_base + B], plan, self.group)
                 prev = plan.rank * B - 1                     # index inside the gathered round
                 if prev >= 0:
                     src = self.shared_map[prev]
@@ -227,37 +246,41 @@ class FrameStreamPipeline:
                 else:
                     src = None
                 if src is not None:
-                    self._slab_t[halo_r].copy_(src)
+                    self._slab_t[halo_slot].copy_(src)
                     have_halo = True
                 else:
                     have_halo = False
                 self._prev_last = self.shared_map[plan.world * B - 1].clone()
-            self.ctx.record(self.ev_halo[rnd & 1])           # halo of THIS round is in place
-            self.ctx.record(self.ev_collated)
-        # ---- batched matches: pair s = (s-1, s); pair 0 = (halo, 0)
-        first = 0 if have_halo else 1
+            self.ctx.record(self.ev_halo[p])                 # halo of THIS round is in place
+            self.ctx.record(self.ev_collated[p])
+            prev_slot = halo_slot
+        # ---- batched matches: pair s = (s-1, s); pair 0 = (previous frame, 0)
+        out_base = p * B
+        s0 = 0 if have_halo else 1
         j = 0
-        s0 = first
         while s0 < B:
-            s1 = min(B, (s0 // P + 1) * P) if s0 else min(B, P)
-            m = self.mats[j % NM]
+            s1 = min(B, (s0 // P + 1) * P)
+            m = self.mats[self.batches % NM]
             pairs = []
             for s in range(s0, s1):
-                a = halo_r if s == 0 else s - 1
-                pairs.append((self.xy_ptr(a), self.desc_ptr(a), K, self.xy_ptr(s), self.desc_ptr(s), K,
-                              self.count_ptr(a), self.count_ptr(s)))
-                m.ctx.wait(self.ev_ext[s])
+                a = prev_slot if s == 0 else s_base + s - 1
+                b = s_base + s
+                pairs.append((self.xy_ptr(a), self.desc_ptr(a), K, self.xy_ptr(b), self.desc_ptr(b), K,
+                              self.count_ptr(a), self.count_ptr(b)))
+                m.ctx.wait(self.ev_ext[p][s])
             if s0 == 0:
-                # the halo record: copied behind the previous round's last extract (one GPU) or
-                # written by this round's collation (N > 1)
-                m.ctx.wait(self.ev_halo[rnd & 1])
+                # the previous frame's record: the last extract of the previous round (one GPU) or
+                # this round's collation (N > 1)
+                m.ctx.wait(self.ev_ext[1 - p][B - 1] if single else self.ev_halo[p])
             else:
-                m.ctx.wait(self.ev_ext[s0 - 1])
-            m.match_batch_dev(pairs, self.ij + s0 * K * 8, self.msc + s0 * K * 4, self.info + s0 * 16, K,
-                              min_conf=self.min_conf)
-            m.ctx.record(self.ev_mdone[j % NM])
+                m.ctx.wait(self.ev_ext[p][s0 - 1])
+            m.match_batch_dev(pairs, self._ij + (out_base + s0) * K * 8, self._msc + (out_base + s0) * K * 4,
+                              self._info + (out_base + s0) * 16, K, min_conf=self.min_conf)
+            m.ctx.record(self.ev_batch[p][j])
+            self.batches += 1
             j += 1
             s0 = s1
+        self.n_batches[p] = j
         self.have_halo = True
         self.rounds += 1
 
@@ -284,5 +307,5 @@ class FrameStreamPipeline:
         self.sync()
         B = self.plan.frames_per_rank
         slab = np.empty((B, self.REC), np.float32)
-        self.ctx.d2h(slab, self.slab)
+        self.ctx.d2h(slab, self.rec_ptr(self.last_set * B))
         return [unpack_record(slab[s], self.K)[1:] for s in range(B)]

@@ -53,11 +53,12 @@ def test_pipeline_equals_sequential_api(native, B, P, NE, NM, sync_each_round):
         else:
             # snapshot this round's outputs ON-STREAM: a collector context waits for the matchers
             # and the extractors of this round, copies, and the next round is enqueued at once
-            for ev in pipe.ev_mdone + pipe.ev_ext:
+            pset = pipe.last_set
+            for ev in pipe.ev_batch[pset][:pipe.n_batches[pset]] + pipe.ev_ext[pset]:
                 col.wait(ev)
         c = ctx if sync_each_round else col
         h = dict(rec=c.malloc(B * pipe.REC * 4), ij=c.malloc(B * K * 8), info=c.malloc(B * 16))
-        c.d2d_async(h["rec"], pipe.slab, B * pipe.REC * 4)
+        c.d2d_async(h["rec"], pipe.rec_ptr(pipe.last_set * B), B * pipe.REC * 4)
         c.d2d_async(h["ij"], pipe.ij, B * K * 8)
         c.d2d_async(h["info"], pipe.info, B * 16)
         if not sync_each_round:
