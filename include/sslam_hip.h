@@ -157,6 +157,10 @@ int sslam_aliked_extract_host(sslam_aliked* al, const uint8_t* img, int H, int W
 /* Device-pointer variant (all pointers device, n_out[1] device int32); enqueue only. */
 int sslam_aliked_extract_dev(sslam_aliked* al, const uint8_t* img, int H, int W, int C, int max_kpts,
                              float* xy_out, float* desc_out, float* score_out, int32_t* n_out);
+/* Replay the launch sequence of sslam_aliked_extract_dev as a cached hipGraph (one graph per distinct
+ * argument tuple; for callers that cycle through a fixed set of buffers).  Same results, ~10 us of
+ * host time per call instead of ~45 launches. */
+int sslam_aliked_use_graphs(sslam_aliked* al, int enable);
 /* Test hook: copy an internal buffer to the host (see aliked_kernels.hip). */
 int sslam_aliked_debug_read(sslam_aliked* al, int which, void* dst, size_t bytes);
 
@@ -215,6 +219,9 @@ int sslam_lightglue_match_batch_dev(sslam_lightglue* lg, int n_pairs, const floa
                                     const float* const* xy1, const float* const* desc1,
                                     const int32_t* const* n_dev, const int32_t* N, float min_conf,
                                     int32_t* ij_out, float* score_out, int32_t* info_out, int out_stride);
+/* Replay the launch sequence of sslam_lightglue_match_dev / _batch_dev as a cached hipGraph (one graph
+ * per distinct argument tuple; ~190 launches become one hipGraphLaunch).  Same results. */
+int sslam_lightglue_use_graphs(sslam_lightglue* lg, int enable);
 /* The split-precision path carries fp32 values as fp16 plane pairs: a FINITE activation with
  * |value| >= 65520 does not fit (the exact-fp32 path, precision 0, has no such limit).  Such a value
  * is saturated and flagged on the device; sslam_lightglue_match_host fails with a message when the

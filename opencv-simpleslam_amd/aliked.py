@@ -70,6 +70,10 @@ class AlikedHIP:
             self.handle, P(img_dev), int(H), int(Wd), int(Cn), int(max_kpts or self.max_num_keypoints),
             P(xy_out), P(desc_out), P(score_out), P(n_out)), "sslam_aliked_extract_dev")
 
+    def use_graphs(self, enable: bool = True):
+        """Replay `extract_dev` as a cached hipGraph per distinct argument tuple (same results)."""
+        _native.check(_native.lib().sslam_aliked_use_graphs(self.handle, int(bool(enable))))
+
     def debug_read(self, which: int, shape, dtype=np.float32):
         out = np.empty(shape, dtype)
         _native.check(_native.lib().sslam_aliked_debug_read(self.handle, which, _native.ptr(out), out.nbytes))

@@ -1253,6 +1253,8 @@ struct sslam_aliked {
     float *out_xy, *out_desc, *out_score;
     int32_t* out_n;
     Dims last{};
+    bool use_graphs = false;          // replay the per-call launch sequence as a cached hipGraph
+    sslam::GraphCache graphs;
 };
 
 namespace {
@@ -1503,6 +1505,7 @@ int sslam_aliked_create(sslam_ctx* ctx, const float* weights, size_t n_floats, i
 int sslam_aliked_destroy(sslam_aliked* g) {
     if (!g) return 0;
     (void)hipStreamSynchronize(g->ctx->stream);
+    g->graphs.clear();
     g->arena.release();
     delete g;
     return 0;
@@ -1521,7 +1524,21 @@ int sslam_aliked_extract_dev(sslam_aliked* g, const uint8_t* img, int H, int W, 
                              float* desc_out, float* score_out, int32_t* n_out) {
     SSLAM_REQUIRE(g && img && xy_out && desc_out && n_out, "sslam_aliked_extract_dev: NULL argument");
     if (int rc = al_check_image(g, H, W, C, max_kpts)) return rc;
-    return al_enqueue(g, img, H, W, C, max_kpts, xy_out, desc_out, score_out, n_out);
+    if (!g->use_graphs) return al_enqueue(g, img, H, W, C, max_kpts, xy_out, desc_out, score_out, n_out);
+    const std::vector<uint64_t> key{(uint64_t)img, (uint64_t)H, (uint64_t)W, (uint64_t)C, (uint64_t)max_kpts,
+                                    (uint64_t)xy_out, (uint64_t)desc_out, (uint64_t)score_out, (uint64_t)n_out};
+    return sslam::run_cached(g->graphs, g->ctx->stream, key,
+                             [&] { return al_enqueue(g, img, H, W, C, max_kpts, xy_out, desc_out, score_out, n_out); });
+}
+
+/* Replay the launch sequence of sslam_aliked_extract_dev as a cached hipGraph (one graph per
+ * distinct argument tuple, LRU of 128): for callers that cycle through a fixed set of buffers,
+ * as the frame pipeline does.  Results are identical; only the host cost of a call changes. */
+int sslam_aliked_use_graphs(sslam_aliked* g, int enable) {
+    SSLAM_REQUIRE(g != nullptr, "sslam_aliked_use_graphs: NULL instance");
+    if (!enable) { (void)hipStreamSynchronize(g->ctx->stream); g->graphs.clear(); }
+    g->use_graphs = enable != 0;
+    return 0;
 }
 
 int sslam_aliked_extract_host(sslam_aliked* g, const uint8_t* img, int H, int W, int C, int max_kpts, float* xy_out,

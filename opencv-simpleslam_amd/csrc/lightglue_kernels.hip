@@ -1047,8 +1047,12 @@ __device__ __forceinline__ void linear_h_epilogue(const LinearArgsH& p, const Ro
         }
     }
     if constexpr (EPI == EPH_QKV || EPI == EPH_CROSS) {
-        // V columns, transposed and key-tile-major: vt[img][head][token / 64][d][token % 64];
-        // a unit = one column x 8 consecutive rows (tokens)
+        // V columns, transposed and key-tile-major: vt[img][head][token / 64][d][pos(token % 64)].
+        // Inside every group of 16 keys the two middle quads are swapped (pos = key with bits 2 and 3
+        // exchanged): the P.V MFMA takes its k-slots in the order of the accumulator rows of S^T -
+        // keys {4h..4h+3, 8+4h..8+4h+3} of the group for lane half h - and in this order those eight
+        // keys are ONE 16-byte run, i.e. one ds_read_b128 per operand instead of two ds_read_b64 plus
+        // register shuffling.  A unit = one column x the 8 tokens {b..b+3, b+8..b+11} of such a run.
         constexpr int VCOL0 = (EPI == EPH_QKV) ? 2 * D : D;
         constexpr int RG = BM / 8;
         for (int u = t; u < BN * RG; u += NT) {
@@ -1056,15 +1060,20 @@ __device__ __forceinline__ void linear_h_epilogue(const LinearArgsH& p, const Ro
             const int col = col0 + cl;
             if (col < VCOL0) continue;
             const int hd = (col >> 6) & 3, d = col & 63;
-            const int row = rd.row0 + rg * 8;
+            const int rl0 = (rg >> 1) * 16 + (rg & 1) * 4;     // first token of the run inside the tile
+            const int row = rd.row0 + rl0;
             float v[8];
             // keys >= n of the last 64-key tile are written as exact zeros: attention gives them
             // P = 0, and 0 x (stale, possibly non-finite) would not be 0
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = row + e < rd.n ? epi[(rg * 8 + e) * ELD + cl] : 0.0f;
+            for (int e = 0; e < 8; ++e) {
+                const int dr = (e & 3) + 8 * (e >> 2);         // token offset of run element e
+                v[e] = row + dr < rd.n ? epi[(rl0 + dr) * ELD + cl] : 0.0f;
+            }
             uint4 hi, lo;
             split8(v, hi, lo);
-            const size_t o = ((((size_t)rd.img * NH + hd) * (p.Kc / AK) + (row >> 6)) * DH + d) * AK + (row & 63);
+            const int pos = ((row & 63) & ~15) + (rg & 1) * 8; // run position inside the 64-key tile
+            const size_t o = ((((size_t)rd.img * NH + hd) * (p.Kc / AK) + (row >> 6)) * DH + d) * AK + pos;
             *reinterpret_cast<uint4*>(p.vt.hi + o) = hi;
             *reinterpret_cast<uint4*>(p.vt.lo + o) = lo;
         }
@@ -1198,11 +1207,26 @@ constexpr float P_BIAS = 14.0f;
 #define ATTN_VALU_PER_MFMA 8
 #endif
 #if ATTN_VALU_PER_MFMA > 0
+// ATTN_SCHED (experiments, scripts/ubench/attn_bench.hip): 0 = {1 MFMA, V VALU} x 24 (fragment reads
+// left to the scheduler), 1 = the 16 fragment reads of a sub-step asked for one MFMA ahead of their consumer
+#ifndef ATTN_SCHED
+#define ATTN_SCHED 0
+#endif
+#if ATTN_SCHED == 1
+#define ATTN_INTERLEAVE()                                                     \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                        \
+    _Pragma("unroll") for (int ig_ = 0; ig_ < 24; ++ig_) {                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    \
+        if (ig_ < 14) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      \
+        __builtin_amdgcn_sched_group_barrier(0x002, ATTN_VALU_PER_MFMA, 0);   \
+    }
+#else
 #define ATTN_INTERLEAVE()                                                     \
     _Pragma("unroll") for (int ig_ = 0; ig_ < 24; ++ig_) {                    \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    \
         __builtin_amdgcn_sched_group_barrier(0x002, ATTN_VALU_PER_MFMA, 0);   \
     }
+#endif
 #else
 #define ATTN_INTERLEAVE()
 #endif
@@ -1360,7 +1384,7 @@ __global__ __launch_bounds__(256, 2) void lg_attention_p_kernel(AttnArgsH p) {
         }
     };
 
-    int koffs[2][4], voffs[2][2][2][2];
+    int koffs[2][4], voffs[2][2][2];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
         const int krow = sub * 32 + lr, kswz = (krow >> 1) & 7;
@@ -1370,9 +1394,10 @@ __global__ __launch_bounds__(256, 2) void lg_attention_p_kernel(AttnArgsH p) {
         for (int s2i = 0; s2i < 2; ++s2i)
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                const int d = db * 32 + lr, vswz = (d >> 1) & 7, c0 = 4 * sub + 2 * s2i;
-                voffs[sub][s2i][db][0] = d * AK + ((c0 ^ vswz) * 8) + 4 * h;
-                voffs[sub][s2i][db][1] = d * AK + (((c0 + 1) ^ vswz) * 8) + 4 * h;
+                // V^T keys are stored with the middle quads of every 16 swapped (linear epilogue): the
+                // eight k-slots of lane half h are the 16-byte chunk 4 sub + 2 s2i + h of row d
+                const int d = db * 32 + lr, vswz = (d >> 1) & 7, c0 = 4 * sub + 2 * s2i + h;
+                voffs[sub][s2i][db] = d * AK + ((c0 ^ vswz) * 8);
             }
     }
 
@@ -1396,16 +1421,12 @@ __global__ __launch_bounds__(256, 2) void lg_attention_p_kernel(AttnArgsH p) {
         for (int s2i = 0; s2i < 2; ++s2i) {
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                const int vo0 = voffs[sub][s2i][db][0], vo1 = voffs[sub][s2i][db][1];
-                const half4 vh0 = *reinterpret_cast<const half4*>(&sm.vt_hi[buf][vo0]);
-                const half4 vh1 = *reinterpret_cast<const half4*>(&sm.vt_hi[buf][vo1]);
-                const half4 vl0 = *reinterpret_cast<const half4*>(&sm.vt_lo[buf][vo0]);
-                const half4 vl1 = *reinterpret_cast<const half4*>(&sm.vt_lo[buf][vo1]);
 #if ATTN_ABL & 4
                 const half8 vh = qh[s2i + db], vl = ql[s2i + db];
 #else
-                const half8 vh = __builtin_shufflevector(vh0, vh1, 0, 1, 2, 3, 4, 5, 6, 7);
-                const half8 vl = __builtin_shufflevector(vl0, vl1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const int vo = voffs[sub][s2i][db];
+                const half8 vh = *reinterpret_cast<const half8*>(&sm.vt_hi[buf][vo]);
+                const half8 vl = *reinterpret_cast<const half8*>(&sm.vt_lo[buf][vo]);
 #endif
                 if (db == 0) {
                     o1a = MF(vh, ph[s2i], o1a);
@@ -1597,6 +1618,9 @@ struct sslam_lightglue {
     std::vector<hipEvent_t> ev;     // start/stop pairs
     size_t ev_used = 0;
     int last_pairs = 1;             // pairs of the bracketed launches
+    bool use_graphs = false;        // replay the launch sequence of a (batched) device call as a cached hipGraph
+    sslam::GraphCache graphs;
+    void settings_changed() { if (!graphs.entries.empty()) { (void)hipStreamSynchronize(ctx->stream); graphs.clear(); } }
 };
 
 namespace {
@@ -1722,11 +1746,10 @@ void launch_linear_big(hipStream_t s, int NI, const LinearArgsH& a) {
     constexpr size_t epi = (size_t)BM * (BN + 4) * sizeof(float);
     constexpr size_t lds = stage > epi ? stage : epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool configured = false;
-    if (!configured) {
+    if (!a.ctrl) {          // configuration call (instance creation): > 64 KiB of dynamic LDS needs the opt-in
         (void)hipFuncSetAttribute((const void*)lg_linear_big_kernel<BM, BN, WM, WN, EPI>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        configured = true;
+        return;
     }
     dim3 grid(a.N / BN, NI * sslam::cdiv(a.Kc, BM));
     hipLaunchKernelGGL((lg_linear_big_kernel<BM, BN, WM, WN, EPI>), grid, dim3(512), lds, s, a);
@@ -1735,11 +1758,10 @@ void launch_linear_big(hipStream_t s, int NI, const LinearArgsH& a) {
 template <int BM, int BN, int TM, int TN, int EPI>
 void launch_linear_h(hipStream_t s, int NI, const LinearArgsH& a) {
     constexpr size_t lds = (size_t)ring_depth<BM, BN>() * sslam::ring_stage_halves<BM, BN>() * sizeof(_Float16);
-    static bool configured = false;
-    if (!configured) {      // > 64 KiB of dynamic LDS needs the opt-in attribute (once per instantiation)
+    if (!a.ctrl) {          // configuration call (instance creation): > 64 KiB of dynamic LDS needs the opt-in
         (void)hipFuncSetAttribute((const void*)lg_linear_h_kernel<BM, BN, TM, TN, EPI>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        configured = true;
+        return;
     }
     dim3 grid(a.N / BN, NI * sslam::cdiv(a.Kc, BM));
     hipLaunchKernelGGL((lg_linear_h_kernel<BM, BN, TM, TN, EPI>), grid, dim3(512), lds, s, a);   // 4 consumer + 4 producer waves
@@ -1914,6 +1936,38 @@ int lg_enqueue(sslam_lightglue* g, int pairs, const StageSrc& src, float min_con
     return 0;
 }
 
+// function attributes of every linear instantiation, set once at instance creation (never inside a
+// stream capture)
+void lg_configure_kernels() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    const LinearArgsH cfg{};            // ctrl == nullptr: the launchers only configure
+    hipStream_t s = nullptr;
+    launch_linear_h<64, 128, 1, 2, EPH_F32>(s, 0, cfg);   launch_linear_big<128, 256, 2, 4, EPH_F32>(s, 0, cfg);
+    launch_linear_h<64, 64, 1, 1, EPH_RESID>(s, 0, cfg);  launch_linear_big<128, 256, 2, 4, EPH_RESID>(s, 0, cfg);
+    launch_linear_h<64, 192, 1, 3, EPH_QKV>(s, 0, cfg);   launch_linear_big<128, 256, 2, 4, EPH_QKV>(s, 0, cfg);
+    launch_linear_h<64, 128, 1, 2, EPH_CROSS>(s, 0, cfg); launch_linear_big<128, 256, 2, 4, EPH_CROSS>(s, 0, cfg);
+}
+
+// lg_enqueue through the graph cache (device entry points only; never while profiling: the
+// bracketing events are host-side records)
+int lg_enqueue_cached(sslam_lightglue* g, int pairs, const StageSrc& src, float min_conf, int32_t* ij_out,
+                      float* score_out, int32_t* info_out, long out_stride) {
+    if (!g->use_graphs || g->profile)
+        return lg_enqueue(g, pairs, src, min_conf, ij_out, score_out, info_out, out_stride);
+    std::vector<uint64_t> key{(uint64_t)pairs, (uint64_t)ij_out, (uint64_t)score_out, (uint64_t)info_out,
+                              (uint64_t)out_stride, 0};
+    memcpy(&key[5], &min_conf, sizeof(float));
+    for (int i = 0; i < 2 * pairs; ++i) {
+        key.push_back((uint64_t)src.xy[i]); key.push_back((uint64_t)src.desc[i]);
+        key.push_back((uint64_t)src.cnt[i]); key.push_back((uint64_t)src.bound[i]);
+    }
+    return sslam::run_cached(g->graphs, g->ctx->stream, key, [&] {
+        return lg_enqueue(g, pairs, src, min_conf, ij_out, score_out, info_out, out_stride);
+    });
+}
+
 }  // namespace
 
 extern "C" {
@@ -1926,6 +1980,7 @@ int sslam_lightglue_create_batched(sslam_ctx* ctx, const float* weights, size_t 
     SSLAM_REQUIRE(max_pairs >= 1 && max_pairs <= MAX_PAIRS, "sslam_lightglue_create: max_pairs %d not in [1, %d]",
                   max_pairs, MAX_PAIRS);
     SSLAM_HIP_CHECK(hipSetDevice(ctx->device));
+    lg_configure_kernels();
     sslam_lightglue* g = new sslam_lightglue();
     g->ctx = ctx;
     const int Kc = (max_kpts + 127) / 128 * 128;     // whole attention / GEMM row blocks
@@ -1998,6 +2053,7 @@ int sslam_lightglue_create(sslam_ctx* ctx, const float* weights, size_t n_floats
 int sslam_lightglue_destroy(sslam_lightglue* g) {
     if (!g) return 0;
     (void)hipStreamSynchronize(g->ctx->stream);
+    g->graphs.clear();
     for (hipEvent_t e : g->ev) (void)hipEventDestroy(e);
     g->arena.release();
     delete g;
@@ -2007,6 +2063,7 @@ int sslam_lightglue_destroy(sslam_lightglue* g) {
 int sslam_lightglue_set_conf(sslam_lightglue* g, float depth_confidence, float width_confidence,
                              float filter_threshold, int prune_min_kpts) {
     SSLAM_REQUIRE(g != nullptr, "sslam_lightglue_set_conf: NULL instance");
+    g->settings_changed();
     g->depth_conf = depth_confidence; g->width_conf = width_confidence;
     g->filter_thr = filter_threshold; g->prune_min = prune_min_kpts;
     return 0;
@@ -2037,7 +2094,7 @@ int sslam_lightglue_match_batch_dev(sslam_lightglue* g, int n_pairs, const float
         src.xy[2 * p + 1] = xy1[p]; src.desc[2 * p + 1] = desc1[p]; src.bound[2 * p + 1] = N[p];
         src.cnt[2 * p + 1] = n_dev ? n_dev[p] : nullptr;
     }
-    return lg_enqueue(g, n_pairs, src, min_conf, ij_out, score_out, info_out, out_stride);
+    return lg_enqueue_cached(g, n_pairs, src, min_conf, ij_out, score_out, info_out, out_stride);
 }
 
 int sslam_lightglue_match_dev(sslam_lightglue* g, const float* xy0, const float* desc0, int M,
@@ -2052,7 +2109,7 @@ int sslam_lightglue_match_dev(sslam_lightglue* g, const float* xy0, const float*
     StageSrc src{};
     src.xy[0] = xy0; src.desc[0] = desc0; src.cnt[0] = m_dev; src.bound[0] = M;
     src.xy[1] = xy1; src.desc[1] = desc1; src.cnt[1] = n_dev; src.bound[1] = N;
-    return lg_enqueue(g, 1, src, min_conf, ij_out, score_out, info_out, g->Kc);
+    return lg_enqueue_cached(g, 1, src, min_conf, ij_out, score_out, info_out, g->Kc);
 }
 
 int sslam_lightglue_match_host(sslam_lightglue* g, const float* xy0, const float* desc0, int M,
@@ -2158,6 +2215,7 @@ int sslam_lightglue_profile_read(sslam_lightglue* g, float* total_ms_out, int32_
  * the fp16 hi/lo split path (3 MFMA per product, ~2^-22 relative error), assignment stays fp32. */
 int sslam_lightglue_set_precision(sslam_lightglue* g, int mode) {
     SSLAM_REQUIRE(g != nullptr && (mode == 0 || mode == 1), "sslam_lightglue_set_precision: bad argument");
+    g->settings_changed();
     g->precision = mode;
     return 0;
 }
@@ -2166,6 +2224,7 @@ int sslam_lightglue_set_precision(sslam_lightglue* g, int mode) {
  * of the last one) so intermediate token states can be compared with the oracle. */
 int sslam_lightglue_debug_layers(sslam_lightglue* g, int layers, int self_only) {
     SSLAM_REQUIRE(g != nullptr && layers >= 1 && layers <= NL, "sslam_lightglue_debug_layers: bad argument");
+    g->settings_changed();
     g->dbg_layers = layers; g->dbg_self_only = self_only != 0;
     return 0;
 }
@@ -2174,6 +2233,7 @@ int sslam_lightglue_debug_layers(sslam_lightglue* g, int layers, int self_only) 
 int sslam_lightglue_debug_key_split(sslam_lightglue* g, int ks) {
     SSLAM_REQUIRE(g != nullptr && (ks == 0 || ks == 1 || ks == 2 || ks == 4),
                   "sslam_lightglue_debug_key_split: ks must be 0, 1, 2 or 4");
+    g->settings_changed();
     g->force_ks = ks;
     return 0;
 }
@@ -2182,7 +2242,19 @@ int sslam_lightglue_debug_key_split(sslam_lightglue* g, int ks) {
  * 128 x 256 big-tile kernel. */
 int sslam_lightglue_debug_big_gemm(sslam_lightglue* g, int mode) {
     SSLAM_REQUIRE(g != nullptr && mode >= -1 && mode <= 1, "sslam_lightglue_debug_big_gemm: bad argument");
+    g->settings_changed();
     g->big_gemm = mode;
+    return 0;
+}
+
+/* Replay the launch sequence of sslam_lightglue_match_dev / _batch_dev as a cached hipGraph (one
+ * graph per distinct argument tuple, LRU of 128; ~190 launches become one hipGraphLaunch): for
+ * callers that cycle through a fixed set of buffers, as the frame pipeline does.  Results are
+ * identical.  Changing any instance setting drops the cache. */
+int sslam_lightglue_use_graphs(sslam_lightglue* g, int enable) {
+    SSLAM_REQUIRE(g != nullptr, "sslam_lightglue_use_graphs: NULL instance");
+    if (!enable) g->settings_changed();
+    g->use_graphs = enable != 0;
     return 0;
 }
 

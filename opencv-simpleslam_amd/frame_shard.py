@@ -121,10 +121,14 @@ class FrameStreamPipeline:
     matcher needs max_pairs >= batch_pairs)."""
 
     def __init__(self, detectors, matchers, plan: ShardPlan, max_kpts: int, min_conf: float = 0.7,
-                 batch_pairs: int | None = None, group=None):
+                 batch_pairs: int | None = None, group=None, use_graphs: bool = True):
         self.dets = list(detectors) if isinstance(detectors, (list, tuple)) else [detectors]
         self.mats = list(matchers) if isinstance(matchers, (list, tuple)) else [matchers]
         self.plan, self.group = plan, group
+        # every round cycles through the same record slots: each extractor / matcher call sequence is
+        # replayed as a cached hipGraph (one hipGraphLaunch instead of 45 / 190 launches per call)
+        for x in self.dets + self.mats:
+            x.use_graphs(bool(use_graphs))
         self.K = int(max_kpts)
         if self.K % 2:
             raise ValueError("max_kpts must be even (16-byte aligned descriptor rows inside a record)")

@@ -108,6 +108,10 @@ class LightGlueHIP:
             _native.ptr(ij_out), _native.ptr(score_out), _native.ptr(info_out), int(out_stride)),
             "sslam_lightglue_match_batch_dev")
 
+    def use_graphs(self, enable: bool = True):
+        """Replay `match_dev` / `match_batch_dev` as a cached hipGraph per distinct argument tuple."""
+        _native.check(_native.lib().sslam_lightglue_use_graphs(self.handle, int(bool(enable))))
+
     def range_overflow(self) -> bool:
         """True if, since the last call, a finite activation left the fp16 range of the split-precision
         path (results of those calls are not fp32-grade).  Synchronises; clears the flag."""

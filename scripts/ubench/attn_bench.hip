@@ -1,10 +1,13 @@
 // Stand-alone timing of the LightGlue attention kernel (same TU as the product kernels, synthetic
-// operands, no downstream kernels): used for ablations that would poison a full match.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I opencv-simpleslam_amd/csrc [-DATTN_ABL=..] \
-//         scripts/ubench/attn_bench.hip -o /tmp/attn_bench && /tmp/attn_bench [N] [KS] [kernel 0|1]
+// operands, no downstream kernels): used for A/B of schedule variants and for ablations that would
+// poison a full match.  Variants are separate builds (-D flags) run back to back on the same device.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I opencv-simpleslam_amd/csrc [-DATTN_ABL=..] [-DATTN_SCHED=..] \
+//         scripts/ubench/attn_bench.hip -o /tmp/attn_bench && /tmp/attn_bench [N=2048] [pairs=8] [KS=1] [rounds=5]
 #include "../../opencv-simpleslam_amd/csrc/lightglue_kernels.hip"
 #include <cstdio>
 #include <vector>
+#include <algorithm>
+namespace sslam { void set_error(const char*, ...) {} }
 
 __global__ void fill_half(_Float16* p, size_t n, unsigned seed, float scale) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -15,42 +18,46 @@ __global__ void fill_half(_Float16* p, size_t n, unsigned seed, float scale) {
 
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 2048;
-    const int KS = argc > 2 ? atoi(argv[2]) : 4;
-    const int which = argc > 3 ? atoi(argv[3]) : 1;
-    const int batch = argc > 4 ? atoi(argv[4]) : 1;      // needs -DATTN_BATCH_EMU when > 1
-    const int Kc = (N + 127) / 128 * 128;
-    const size_t plane = (size_t)2 * NH * Kc * DH;
-    _Float16* buf[6];
-    for (int i = 0; i < 6; ++i) {
+    const int B = argc > 2 ? atoi(argv[2]) : 8;
+    const int KS = argc > 3 ? atoi(argv[3]) : 1;
+    const int rounds = argc > 4 ? atoi(argv[4]) : 5;
+    const int Kc = (N + 127) / 128 * 128, NI = 2 * B;
+    const size_t plane = (size_t)NI * NH * Kc * DH;
+    _Float16* buf[8];
+    for (int i = 0; i < 8; ++i) {
         hipMalloc(&buf[i], plane * 2);
         fill_half<<<(plane + 255) / 256, 256>>>(buf[i], plane, 17 * i + 1, (i & 1) ? 0.01f : 2.0f);
     }
     float *o_part, *m_part, *l_part; LGCtrl* ctrl;
-    hipMalloc(&o_part, (size_t)KS * plane * 4); hipMalloc(&m_part, (size_t)KS * 2 * NH * Kc * 4);
-    hipMalloc(&l_part, (size_t)KS * 2 * NH * Kc * 4); hipMalloc(&ctrl, sizeof(LGCtrl));
-    LGCtrl h{}; h.n[0] = h.n[1] = N; hipMemcpy(ctrl, &h, sizeof(h), hipMemcpyHostToDevice);
-    AttnArgsH a{{buf[0], buf[1]}, {buf[2], buf[3]}, {buf[4], buf[5]}, 0, o_part, m_part, l_part, KS, Kc, ctrl};
-    dim3 grid(sslam::cdiv(Kc, AQ), 2 * NH * batch, KS);
+    hipMalloc(&o_part, (size_t)KS * plane * 4); hipMalloc(&m_part, (size_t)KS * NI * NH * Kc * 4);
+    hipMalloc(&l_part, (size_t)KS * NI * NH * Kc * 4); hipMalloc(&ctrl, sizeof(LGCtrl) * B);
+    std::vector<LGCtrl> h(B); for (auto& c : h) { c = LGCtrl{}; c.n[0] = c.n[1] = N; }
+    hipMemcpy(ctrl, h.data(), sizeof(LGCtrl) * B, hipMemcpyHostToDevice);
+    AttnArgsH a{{buf[0], buf[1]}, {buf[2], buf[3]}, {buf[4], buf[5]}, 0, o_part, m_part, l_part, SplitOut{buf[6], buf[7]}, KS, Kc, NI, ctrl};
+    dim3 grid(sslam::cdiv(Kc, AQ), NI * NH, KS);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    auto launch = [&] {
-        (void)which;
-        hipLaunchKernelGGL(lg_attention_p_kernel, grid, dim3(256), 0, 0, a);
-    };
+    auto launch = [&] { hipLaunchKernelGGL(lg_attention_p_kernel, grid, dim3(256), 0, 0, a); };
     for (int i = 0; i < 5; ++i) launch();
     hipDeviceSynchronize();
-    const int R = 50;
-    hipEventRecord(e0);
-    for (int i = 0; i < R; ++i) launch();
-    hipEventRecord(e1); hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
-    // isolated launches (event pair around each)
-    float iso = 0;
-    for (int i = 0; i < 20; ++i) {
-        hipEventRecord(e0); launch(); hipEventRecord(e1); hipEventSynchronize(e1);
-        float m; hipEventElapsedTime(&m, e0, e1); iso += m;
+    std::vector<float> t;
+    for (int r = 0; r < rounds; ++r) {
+        const int R = 20;
+        hipEventRecord(e0);
+        for (int i = 0; i < R; ++i) launch();
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        t.push_back(ms / R * 1e3f);
     }
-    const double fl = 8.0 * N * (double)N * 256;
-    printf("N=%d KS=%d kernel=%d abl=%d batch=%d: back-to-back %.2f us/launch = %.2f us per pair (%.0f TF alg), isolated %.2f us; err=%s\n", N, KS, which,
-           ATTN_ABL, batch, ms / R * 1e3, ms / R * 1e3 / batch, batch * fl / (ms / R * 1e-3) / 1e12, iso / 20 * 1e3, hipGetErrorString(hipGetLastError()));
+    std::sort(t.begin(), t.end());
+    const double fl = 8.0 * N * (double)N * 256 * B;
+    printf("N=%d pairs=%d KS=%d abl=%d sched=%d: median %.1f us/launch (min %.1f) = %.2f us per pair, %.0f TF alg, executed %.1f%% of the f16 peak; err=%s\n",
+           N, B, KS, ATTN_ABL,
+#ifdef ATTN_SCHED
+           ATTN_SCHED,
+#else
+           -1,
+#endif
+           t[t.size() / 2], t[0], t[t.size() / 2] / B, fl / (t[t.size() / 2] * 1e-6) / 1e12, 3 * fl / (t[t.size() / 2] * 1e-6) / 2.5e15 * 100,
+           hipGetErrorString(hipGetLastError()));
     return 0;
 }
