@@ -138,6 +138,17 @@ int sslam_reproject_match_host(sslam_ctx* ctx, int n_points, const double* pts3d
                                int img_w, int img_h, double radius_px, double max_dist,
                                int32_t* kp_of_point, float* uv_out, int32_t* info_out);
 
+/* Device-resident variant (enqueue only): map arrays and keypoints / descriptors are device pointers
+ * (an incrementally maintained SoA map - slam/core/landmark_utils.py of the overlay - keeps the
+ * former on the GPU, sslam_aliked_extract_dev writes the latter); K9 / Tcw16 stay host values.
+ * kp_of_point[n_points], uv_out (may be NULL), info_out[4] = {matches, candidate-list overflow flag,
+ * candidate points, 0} are device buffers. */
+int sslam_reproject_match_dev(sslam_ctx* ctx, int n_points, const double* pts3d,
+                              const int32_t* obs_cnt, const float* obs_desc, const double* K9,
+                              const double* Tcw16, int n_kp, const float* kp_xy, const float* des,
+                              int img_w, int img_h, double radius_px, double max_dist,
+                              int32_t* kp_of_point, float* uv_out, int32_t* info_out);
+
 /* ------------------------------------------------------------------ ALIKED
  * Replaces `ALIKED(max_num_keypoints=...).eval().to(device)` at
  * slam/core/features_utils.py:25 and `_bgr_to_tensor` + `detector.extract` +

@@ -127,6 +127,75 @@ __global__ __launch_bounds__(64) void rp_assign_kernel(RPArgs a) {
 
 }  // namespace
 
+namespace {
+
+// scratch of one association call, carved from the context's scratch slab
+struct RPScratch { char* base; size_t K, T, uv, cn, ck, cd, out, info, pts, cnt, od, kp, des; };
+
+int rp_scratch(sslam_ctx* ctx, size_t Q, size_t N, bool host_inputs, RPScratch& sc) {
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = sslam::align_up(off + bytes + 8, 256); return o; };
+    sc.K = carve(72); sc.T = carve(128); sc.uv = carve(Q * 8); sc.cn = carve(Q * 4);
+    sc.ck = carve(Q * RP_MAXC * 4); sc.cd = carve(Q * RP_MAXC * 4); sc.out = carve(Q * 4); sc.info = carve(16);
+    if (host_inputs) {
+        sc.pts = carve(Q * 24); sc.cnt = carve(Q * 4); sc.od = carve(Q * 6 * RP_DIM * 4);
+        sc.kp = carve(N * 8); sc.des = carve(N * RP_DIM * 4);
+    }
+    if (off > ctx->ba_scratch_bytes) {
+        (void)hipStreamSynchronize(ctx->stream);          // earlier enqueued work may still use the old slab
+        if (ctx->ba_scratch) SSLAM_HIP_CHECK(hipFree(ctx->ba_scratch));
+        ctx->ba_scratch = nullptr;
+        ctx->ba_scratch_bytes = 0;
+        SSLAM_HIP_CHECK(hipMalloc(&ctx->ba_scratch, off));
+        ctx->ba_scratch_bytes = off;
+    }
+    sc.base = (char*)ctx->ba_scratch;
+    return 0;
+}
+
+// enqueue the two kernels on device-resident inputs; K9 / Tcw16 are host values
+int rp_enqueue(sslam_ctx* ctx, const RPScratch& sc, int n_points, const double* pts_d, const int32_t* cnt_d,
+               const float* desc_d, const double* K9, const double* Tcw16, int n_kp, const float* kp_d, const float* des_d,
+               int img_w, int img_h, double radius_px, double max_dist, int32_t* out_d, float* uv_d, int32_t* info_d) {
+    hipStream_t s = ctx->stream;
+    char* b = sc.base;
+    SSLAM_HIP_CHECK(hipMemcpyAsync(b + sc.K, K9, 72, hipMemcpyHostToDevice, s));
+    SSLAM_HIP_CHECK(hipMemcpyAsync(b + sc.T, Tcw16, 128, hipMemcpyHostToDevice, s));
+    SSLAM_HIP_CHECK(hipMemsetAsync(info_d, 0, 16, s));
+    RPArgs a{};
+    a.Q = n_points; a.N = n_kp; a.img_w = img_w; a.img_h = img_h; a.radius2 = radius_px * radius_px; a.thr = max_dist;
+    a.pts = pts_d; a.obs_cnt = cnt_d; a.obs_desc = desc_d;
+    a.K = (const double*)(b + sc.K); a.Tcw = (const double*)(b + sc.T); a.kp = kp_d; a.des = des_d;
+    a.uv = uv_d ? uv_d : (float*)(b + sc.uv); a.cand_n = (int32_t*)(b + sc.cn);
+    a.cand_kp = (int32_t*)(b + sc.ck); a.cand_d = (float*)(b + sc.cd); a.kp_of_point = out_d; a.info = info_d;
+    hipLaunchKernelGGL(rp_pairs_kernel, dim3(sslam::cdiv(n_points, 4)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(rp_assign_kernel, dim3(1), dim3(64), (((size_t)n_kp + 31) / 32) * 4, s, a);
+    SSLAM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+/* Device-resident variant: the map arrays (an incrementally maintained SoA map keeps them on the GPU)
+ * and the current frame's keypoints / descriptors (straight from sslam_aliked_extract_dev) are device
+ * pointers; K9 / Tcw16 are host values.  Enqueue only.  kp_of_point[n_points], uv_out[n_points*2]
+ * (may be NULL) and info_out[4] = {matches, overflow flag, candidate points, 0} are device buffers. */
+extern "C" int sslam_reproject_match_dev(sslam_ctx* ctx, int n_points, const double* pts3d, const int32_t* obs_cnt,
+                                         const float* obs_desc, const double* K9, const double* Tcw16, int n_kp,
+                                         const float* kp_xy, const float* des, int img_w, int img_h, double radius_px,
+                                         double max_dist, int32_t* kp_of_point, float* uv_out, int32_t* info_out) {
+    SSLAM_REQUIRE(ctx != nullptr, "sslam_reproject_match_dev: ctx is NULL");
+    SSLAM_REQUIRE(n_points > 0 && n_kp > 0, "sslam_reproject_match_dev: empty input (the caller returns early)");
+    SSLAM_REQUIRE(pts3d && obs_cnt && obs_desc && K9 && Tcw16 && kp_xy && des && kp_of_point && info_out,
+                  "sslam_reproject_match_dev: NULL argument");
+    SSLAM_REQUIRE(radius_px >= 0.0 && img_w > 0 && img_h > 0, "sslam_reproject_match_dev: bad radius / image size");
+    SSLAM_HIP_CHECK(hipSetDevice(ctx->device));
+    RPScratch sc{};
+    if (int rc = rp_scratch(ctx, (size_t)n_points, (size_t)n_kp, false, sc)) return rc;
+    return rp_enqueue(ctx, sc, n_points, pts3d, obs_cnt, obs_desc, K9, Tcw16, n_kp, kp_xy, des, img_w, img_h, radius_px,
+                      max_dist, kp_of_point, uv_out, info_out);
+}
+
 extern "C" int sslam_reproject_match_host(sslam_ctx* ctx, int n_points, const double* pts3d, const int32_t* obs_cnt,
                                           const float* obs_desc, const double* K9, const double* Tcw16, int n_kp,
                                           const float* kp_xy, const float* des, int img_w, int img_h, double radius_px,
@@ -140,39 +209,23 @@ extern "C" int sslam_reproject_match_host(sslam_ctx* ctx, int n_points, const do
         SSLAM_REQUIRE(obs_cnt[q] >= 0 && obs_cnt[q] <= 6, "sslam_reproject_match_host: obs_cnt[%d]=%d not in [0,6]", q, obs_cnt[q]);
     SSLAM_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t Q = (size_t)n_points, N = (size_t)n_kp;
-    size_t off = 0;
-    auto carve = [&](size_t bytes) { size_t o = off; off = sslam::align_up(off + bytes + 8, 256); return o; };
-    const size_t o_pts = carve(Q * 24), o_cnt = carve(Q * 4), o_od = carve(Q * 6 * RP_DIM * 4), o_K = carve(72), o_T = carve(128);
-    const size_t o_kp = carve(N * 8), o_des = carve(N * RP_DIM * 4), o_uv = carve(Q * 8), o_cn = carve(Q * 4);
-    const size_t o_ck = carve(Q * RP_MAXC * 4), o_cd = carve(Q * RP_MAXC * 4), o_out = carve(Q * 4), o_info = carve(16);
-    if (off > ctx->ba_scratch_bytes) {
-        if (ctx->ba_scratch) SSLAM_HIP_CHECK(hipFree(ctx->ba_scratch));
-        ctx->ba_scratch = nullptr;
-        ctx->ba_scratch_bytes = 0;
-        SSLAM_HIP_CHECK(hipMalloc(&ctx->ba_scratch, off));
-        ctx->ba_scratch_bytes = off;
-    }
-    char* b = (char*)ctx->ba_scratch;
+    RPScratch sc{};
+    if (int rc = rp_scratch(ctx, Q, N, true, sc)) return rc;
+    char* b = sc.base;
     hipStream_t s = ctx->stream;
     auto up = [&](size_t o, const void* src, size_t bytes) { return hipMemcpyAsync(b + o, src, bytes, hipMemcpyHostToDevice, s); };
-    SSLAM_HIP_CHECK(up(o_pts, pts3d, Q * 24)); SSLAM_HIP_CHECK(up(o_cnt, obs_cnt, Q * 4));
-    SSLAM_HIP_CHECK(up(o_od, obs_desc, Q * 6 * RP_DIM * 4)); SSLAM_HIP_CHECK(up(o_K, K9, 72)); SSLAM_HIP_CHECK(up(o_T, Tcw16, 128));
-    SSLAM_HIP_CHECK(up(o_kp, kp_xy, N * 8)); SSLAM_HIP_CHECK(up(o_des, des, N * RP_DIM * 4));
-    SSLAM_HIP_CHECK(hipMemsetAsync(b + o_info, 0, 16, s));
-    RPArgs a{};
-    a.Q = n_points; a.N = n_kp; a.img_w = img_w; a.img_h = img_h; a.radius2 = radius_px * radius_px; a.thr = max_dist;
-    a.pts = (const double*)(b + o_pts); a.obs_cnt = (const int32_t*)(b + o_cnt); a.obs_desc = (const float*)(b + o_od);
-    a.K = (const double*)(b + o_K); a.Tcw = (const double*)(b + o_T); a.kp = (const float*)(b + o_kp);
-    a.des = (const float*)(b + o_des); a.uv = (float*)(b + o_uv); a.cand_n = (int32_t*)(b + o_cn);
-    a.cand_kp = (int32_t*)(b + o_ck); a.cand_d = (float*)(b + o_cd); a.kp_of_point = (int32_t*)(b + o_out);
-    a.info = (int32_t*)(b + o_info);
-    hipLaunchKernelGGL(rp_pairs_kernel, dim3(sslam::cdiv(n_points, 4)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(rp_assign_kernel, dim3(1), dim3(64), ((N + 31) / 32) * 4, s, a);
-    SSLAM_HIP_CHECK(hipGetLastError());
+    SSLAM_HIP_CHECK(up(sc.pts, pts3d, Q * 24)); SSLAM_HIP_CHECK(up(sc.cnt, obs_cnt, Q * 4));
+    SSLAM_HIP_CHECK(up(sc.od, obs_desc, Q * 6 * RP_DIM * 4));
+    SSLAM_HIP_CHECK(up(sc.kp, kp_xy, N * 8)); SSLAM_HIP_CHECK(up(sc.des, des, N * RP_DIM * 4));
+    if (int rc = rp_enqueue(ctx, sc, n_points, (const double*)(b + sc.pts), (const int32_t*)(b + sc.cnt),
+                            (const float*)(b + sc.od), K9, Tcw16, n_kp, (const float*)(b + sc.kp), (const float*)(b + sc.des),
+                            img_w, img_h, radius_px, max_dist, (int32_t*)(b + sc.out), (float*)(b + sc.uv),
+                            (int32_t*)(b + sc.info)))
+        return rc;
     int32_t info[4] = {0, 0, 0, 0};
-    SSLAM_HIP_CHECK(hipMemcpyAsync(kp_of_point, b + o_out, Q * 4, hipMemcpyDeviceToHost, s));
-    if (uv_out) SSLAM_HIP_CHECK(hipMemcpyAsync(uv_out, b + o_uv, Q * 8, hipMemcpyDeviceToHost, s));
-    SSLAM_HIP_CHECK(hipMemcpyAsync(info, b + o_info, 16, hipMemcpyDeviceToHost, s));
+    SSLAM_HIP_CHECK(hipMemcpyAsync(kp_of_point, b + sc.out, Q * 4, hipMemcpyDeviceToHost, s));
+    if (uv_out) SSLAM_HIP_CHECK(hipMemcpyAsync(uv_out, b + sc.uv, Q * 8, hipMemcpyDeviceToHost, s));
+    SSLAM_HIP_CHECK(hipMemcpyAsync(info, b + sc.info, 16, hipMemcpyDeviceToHost, s));
     SSLAM_HIP_CHECK(hipStreamSynchronize(s));
     SSLAM_REQUIRE(info[1] == 0, "sslam_reproject_match_host: more than %d keypoints within %.1f px of one projection",
                   RP_MAXC, radius_px);

@@ -99,18 +99,54 @@ def reproject_and_match_2d3d(world_map, K, Tcw_pred, kps_cur, des_cur, img_w, im
     des = np.ascontiguousarray(des, np.float32).reshape(len(pts2d), -1)
     if des.shape[1] != DESC_DIM:
         raise ValueError("reproject_and_match_2d3d expects 128-d descriptors")
-    ids, pts, cnt, desc = snapshot_map_points(world_map)
     ctx = ctx or _native.default_context()
     Kd = np.ascontiguousarray(K, np.float64).reshape(9)
     Td = np.ascontiguousarray(Tcw_pred, np.float64).reshape(16)
-    out = np.full(len(ids), -1, np.int32)
-    info = (C.c_int32 * 2)()
     P = _native.ptr
-    _native.check(_native.lib().sslam_reproject_match_host(
-        ctx.handle, len(ids), P(pts), P(cnt), P(desc), P(Kd), P(Td), len(pts2d), P(pts2d), P(des), int(img_w), int(img_h),
-        float(radius_px), float(max_l2), P(out), None, info), "sslam_reproject_match_host")
+    if hasattr(world_map, "device_arrays"):
+        # SoA map (slam/core/landmark_utils.py of this overlay): its arrays already live on the GPU,
+        # only the rows touched since the last call travel; no walk over the dict of objects
+        ids, pts, _, _ = world_map.soa()
+        Q = len(ids)
+        d_pos, d_cnt, d_desc = world_map.device_arrays(ctx)
+        scr = _dev_scratch(ctx, Q, len(pts2d))
+        ctx.h2d(scr["kp"], pts2d); ctx.h2d(scr["des"], des)
+        _native.check(_native.lib().sslam_reproject_match_dev(
+            ctx.handle, Q, P(d_pos), P(d_cnt), P(d_desc), P(Kd), P(Td), len(pts2d), P(scr["kp"]), P(scr["des"]),
+            int(img_w), int(img_h), float(radius_px), float(max_l2), P(scr["out"]), None, P(scr["info"])),
+            "sslam_reproject_match_dev")
+        out = np.empty(Q, np.int32); info4 = np.empty(4, np.int32)
+        ctx.d2h(out, scr["out"]); ctx.d2h(info4, scr["info"])
+        if info4[1]:
+            raise _native.NativeError(f"more than the candidate capacity of keypoints within {radius_px} px of one projection")
+    else:
+        ids, pts, cnt, desc = snapshot_map_points(world_map)
+        out = np.full(len(ids), -1, np.int32)
+        info = (C.c_int32 * 2)()
+        _native.check(_native.lib().sslam_reproject_match_host(
+            ctx.handle, len(ids), P(pts), P(cnt), P(desc), P(Kd), P(Td), len(pts2d), P(pts2d), P(des), int(img_w), int(img_h),
+            float(radius_px), float(max_l2), P(out), None, info), "sslam_reproject_match_host")
     hit = np.flatnonzero(out >= 0)
     if len(hit) == 0:
         return empty
     return Matches2D3D(pts[hit].astype(np.float32), pts2d[out[hit]].copy(), [int(i) for i in out[hit]],
                        [int(i) for i in ids[hit]])
+
+
+_SCRATCH = {}
+
+
+def _dev_scratch(ctx, Q, N):
+    """Per-context device buffers of the current-frame inputs / outputs of the association (grown on demand)."""
+    key = id(ctx)
+    cur = _SCRATCH.get(key)
+    if cur is None or cur["Q"] < Q or cur["N"] < N:
+        if cur is not None:
+            ctx.sync()
+            for k in ("kp", "des", "out", "info"):
+                ctx.free(cur[k])
+        Qc, Nc = max(Q, 2 * (cur["Q"] if cur else 0), 1024), max(N, (cur["N"] if cur else 0), 1024)
+        cur = {"Q": Qc, "N": Nc, "kp": ctx.malloc(Nc * 8), "des": ctx.malloc(Nc * DESC_DIM * 4),
+               "out": ctx.malloc(Qc * 4), "info": ctx.malloc(16)}
+        _SCRATCH[key] = cur
+    return cur

@@ -107,7 +107,7 @@ def test_bench_contract_single_rank():
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["unit"] == "frames/s"
     r = d["roofline"]
     assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert 0 < r["timed_region_frac"] <= r["frac"] * 1.2
+    assert 0 < r["in_pipeline_frac"] <= r["frac"] * 1.2
     assert 0 < d["exact_f32"]["value"] < d["value"] * 1.05
     assert d["ba"]["device_lm_ms"] > 0 and 0 < d["ba"]["residual_kernel"]["frac"] < 1 and d["reproject"]["wall_ms"] > 0
 

@@ -54,3 +54,65 @@ def test_c2_size_against_oracle_and_edge_cases(P, native):
     # a huge radius overflows the per-point candidate list: reported, not truncated silently
     with pytest.raises(native.NativeError, match="keypoints within"):
         P.reproject_and_match_2d3d(sc["wmap"], sc["K"], sc["Tcw"], sc["kp"], sc["des"], sc["W"], sc["H"], radius_px=400.0)
+
+
+@pytest.mark.parametrize("c", range(len(RS.CASES)))
+def test_soa_map_path_matches_reference_outputs(P, c):
+    """The same golden outputs through the overlay's SoA map: no walk over the dict of objects, the
+    map arrays are device resident (`sslam_reproject_match_dev`)."""
+    L = load_pkg("slam.core.landmark_utils")
+    sc = RS.make_case(*RS.CASES[c])
+    m = L.Map.from_reference(sc["wmap"])
+    r = P.reproject_and_match_2d3d(m, sc["K"], sc["Tcw"], sc["kp"], sc["des"], sc["W"], sc["H"],
+                                   radius_px=sc["radius"], max_l2=sc["max_l2"], use_cosine=sc["use_cosine"])
+    np.testing.assert_array_equal(r.kp_indices, G[f"kp{c}"])
+    np.testing.assert_array_equal(r.mp_ids, G[f"mp{c}"])
+    np.testing.assert_array_equal(r.pts3d, G[f"pts3d{c}"])
+    np.testing.assert_array_equal(r.pts2d, G[f"pts2d{c}"])
+
+
+def test_soa_map_stays_in_step_with_mutations(P, native):
+    """Incremental device mirror: after new points, new observations, a BA-style in-place position
+    update, a duplicate merge and growth past the allocated capacity, the device-resident path still
+    equals the host path run on a fresh walk over the objects."""
+    import time
+    L = load_pkg("slam.core.landmark_utils")
+    sc = RS.make_case(11, 5000, 2048, 12.0, 0.8, False)
+    m = L.Map.from_reference(sc["wmap"])
+    args = (sc["K"], sc["Tcw"], sc["kp"], sc["des"], sc["W"], sc["H"])
+
+    def same():
+        a = P.reproject_and_match_2d3d(m, *args)
+        ids, pts, cnt, desc = P.snapshot_map_points(m)                 # a walk over the objects, then the host entry
+        import types as _t
+        walk = _t.SimpleNamespace(points={int(i): _t.SimpleNamespace(position=m.points[int(i)].position.copy(),
+                                                                     observations=m.points[int(i)].observations)
+                                          for i in ids})
+        b = P.reproject_and_match_2d3d(walk, *args)
+        assert a.kp_indices == b.kp_indices and a.mp_ids == b.mp_ids
+        return a
+    first = same()
+    assert len(first.kp_indices) > 500
+    rng = np.random.default_rng(3)
+    ids = m.point_ids()
+    for pid in ids[::7]:                                              # new observations on scattered points
+        m.points[pid].add_observation(99, 0, rng.standard_normal(128).astype(np.float32))
+    for pid in ids[::5]:                                              # BA writes positions in place
+        m.points[pid].position[:] = m.points[pid].position + rng.normal(0, 0.01, 3)
+    same()
+    new = m.add_points(rng.uniform(-20, 20, (4000, 3)) + [0, 0, 30])  # growth past the device capacity
+    for pid in new[::2]:
+        m.points[pid].add_observation(100, 1, rng.standard_normal(128).astype(np.float32))
+    same()
+    m.fuse_closeby_duplicate_landmarks(radius=0.2)
+    same()
+    # wall time of the drop-in call on the SoA map vs on a dict-of-objects map (C2 size)
+    t = []
+    for mm in (m, sc["wmap"]):
+        P.reproject_and_match_2d3d(mm, *args)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            P.reproject_and_match_2d3d(mm, *args)
+        t.append((time.perf_counter() - t0) / 5 * 1e3)
+    print(f"\n[reproject_and_match_2d3d, ~9000 / 5000 points x 2048 keypoints] SoA map {t[0]:.2f} ms, dict-of-objects map {t[1]:.2f} ms")
+    assert t[0] < t[1]
