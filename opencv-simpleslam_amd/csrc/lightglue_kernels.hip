@@ -1104,9 +1104,12 @@ __global__ __launch_bounds__(512) void lg_linear_h_kernel(LinearArgsH p) {
     linear_h_epilogue<BM, BN, TM, TN, 2, 256, EPI>(p, rd, col0, ibase, c1, c2, lg_ring);
 }
 
-// Big-tile form for batched token sets (gemm_f16x3_big.hpp): 8 waves, each loads and multiplies.
+// Big-tile form for batched token sets (gemm_f16x3_big.hpp): WM x WN waves, each loads and multiplies.
+// 8 waves: 128 x 256 tile, 3-stage ring, DMA spread between MFMAs, one workgroup per CU.
+// 4 waves: 128 x 128 tile, 2-stage ring, TWO workgroups per CU (one's epilogue runs under the other's
+// main loop).
 template <int BM, int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__(512, 2) void lg_linear_big_kernel(LinearArgsH p) {
+__global__ __launch_bounds__(WM * WN * 64, 2) void lg_linear_big_kernel(LinearArgsH p) {
     extern __shared__ __attribute__((aligned(16))) _Float16 lg_ring[];
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     int rb, cb;
@@ -1120,9 +1123,10 @@ __global__ __launch_bounds__(512, 2) void lg_linear_big_kernel(LinearArgsH p) {
     const size_t ibase = (size_t)rd.img * p.Kc;
     GemmAH ga{{p.A0.hi, p.A0.lo}, {p.A1.hi ? p.A1.hi : p.A0.hi, p.A1.lo ? p.A1.lo : p.A0.lo}, p.lda, p.K0};
     f32x16 c1[TM][TN], c2[TM][TN];
-    sslam::gemm_mainloop_big<BM, BN, WM, WN, 3>(ga, p.W, p.NIc * p.Kc, p.K, (int)ibase + rd.row0,
-                                                (int)ibase + p.Kc, col0, p.N, lg_ring, c1, c2);
-    linear_h_epilogue<BM, BN, TM, TN, WN, 512, EPI>(p, rd, col0, ibase, c1, c2, lg_ring);
+    constexpr int NW = WM * WN;
+    sslam::gemm_mainloop_big<BM, BN, WM, WN, NW == 8 ? 3 : 0, NW == 8 ? 3 : 2>(
+        ga, p.W, p.NIc * p.Kc, p.K, (int)ibase + rd.row0, (int)ibase + p.Kc, col0, p.N, lg_ring, c1, c2);
+    linear_h_epilogue<BM, BN, TM, TN, WN, NW * 64, EPI>(p, rd, col0, ibase, c1, c2, lg_ring);
 }
 
 // LayerNorm(512) + exact GELU: fp32 hidden in, split planes out (one wave / row)
@@ -1742,7 +1746,8 @@ SplitPtr wsp(const sslam_lightglue* g, const float* w) {
 // big-tile launch (batched token sets): 128 x 256 tiles, 8 waves
 template <int BM, int BN, int WM, int WN, int EPI>
 void launch_linear_big(hipStream_t s, int NI, const LinearArgsH& a) {
-    constexpr size_t stage = (size_t)sslam::BIG_STAGES * sslam::big_stage_halves<BM, BN>() * sizeof(_Float16);
+    constexpr int NW = WM * WN;
+    constexpr size_t stage = (size_t)(NW == 8 ? 3 : 2) * sslam::big_stage_halves<BM, BN>() * sizeof(_Float16);
     constexpr size_t epi = (size_t)BM * (BN + 4) * sizeof(float);
     constexpr size_t lds = stage > epi ? stage : epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
@@ -1752,7 +1757,7 @@ void launch_linear_big(hipStream_t s, int NI, const LinearArgsH& a) {
         return;
     }
     dim3 grid(a.N / BN, NI * sslam::cdiv(a.Kc, BM));
-    hipLaunchKernelGGL((lg_linear_big_kernel<BM, BN, WM, WN, EPI>), grid, dim3(512), lds, s, a);
+    hipLaunchKernelGGL((lg_linear_big_kernel<BM, BN, WM, WN, EPI>), grid, dim3(NW * 64), lds, s, a);
 }
 
 template <int BM, int BN, int TM, int TN, int EPI>
@@ -1797,27 +1802,33 @@ void lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, bo
     const SplitPtr qs{g->qs_hi, g->qs_lo}, ks{g->ks_hi, g->ks_lo}, vts{g->vts_hi, g->vts_lo};
     const unsigned tokblocks = sslam::cdiv(NI * g->Kc, 4);
     const float sm_scale = 0.125f * 1.4426950408889634f;        // 1/sqrt(64) * log2(e)
-    // enough token rows for 128-row tiles to fill the chip: the big-tile GEMM (twice the flop per
-    // operand byte taken in by a CU); a single pair keeps the 64-row ring kernel
-    const bool big = g->big_gemm >= 0 ? g->big_gemm != 0 : (long)NI * g->Kc >= 16384 && g->Kc % 128 == 0;
+    // enough token rows for 128-row tiles to fill the chip: the big-tile GEMM (1.5 - 2x the flop per
+    // operand byte taken in by a CU); a single pair keeps the 64-row ring kernel.  Of the two big
+    // forms the 128 x 128 / 4-wave one (two workgroups per CU: one's epilogue under the other's main
+    // loop) measures 2 % under the 128 x 256 / 8-wave one on the whole forward (9.14 vs 9.36 ms for
+    // 8 pairs) although its main loop alone is no faster (scripts/ubench/gemm_big_bench.hip)
+    const int big = g->big_gemm >= 0 ? g->big_gemm : ((long)NI * g->Kc >= 16384 && g->Kc % 128 == 0 ? 2 : 0);
     auto ffn = [&](const float* w1, const float* b1, const float* lnw, const float* lnb, const float* w2,
                    const float* b2) {
         LinearArgsH a = linh(g, xs, msgs, D, D, 2 * D, w1, b1, 2 * D);      // [x | attention context]
         a.out = g->hid; a.ldo = 2 * D;
-        if (big) launch_linear_big<128, 256, 2, 4, EPH_F32>(s, NI, a);
+        if (big == 2) launch_linear_big<128, 128, 2, 2, EPH_F32>(s, NI, a);
+        else if (big) launch_linear_big<128, 256, 2, 4, EPH_F32>(s, NI, a);
         else launch_linear_h<64, 128, 1, 2, EPH_F32>(s, NI, a);
         hipLaunchKernelGGL(lg_ln_gelu_h_kernel, dim3(tokblocks), dim3(256), 0, s, g->hid,
                            SplitOut{g->hids_hi, g->hids_lo}, lnw, lnb, g->ctrl, g->Kc, NI, g->NIc);
         LinearArgsH c = linh(g, hids, none, 2 * D, 2 * D, 2 * D, w2, b2, D);
         c.out = g->x; c.ldo = D; c.outs = SplitOut{g->xs_hi, g->xs_lo};
-        if (big) launch_linear_big<128, 256, 2, 4, EPH_RESID>(s, NI, c);
+        if (big == 2) launch_linear_big<128, 128, 2, 2, EPH_RESID>(s, NI, c);
+        else if (big) launch_linear_big<128, 256, 2, 4, EPH_RESID>(s, NI, c);
         else launch_linear_h<64, 64, 1, 1, EPH_RESID>(s, NI, c);
     };
     {   // self block
         LinearArgsH a = linh(g, xs, none, D, D, D, l.wqkv, l.bqkv, 3 * D);
         a.q = SplitOut{g->qs_hi, g->qs_lo}; a.k = SplitOut{g->ks_hi, g->ks_lo}; a.vt = SplitOut{g->vts_hi, g->vts_lo};
         a.q_scale = sm_scale; a.k_scale = 1.0f;
-        if (big) launch_linear_big<128, 256, 2, 4, EPH_QKV>(s, NI, a);
+        if (big == 2) launch_linear_big<128, 128, 2, 2, EPH_QKV>(s, NI, a);
+        else if (big) launch_linear_big<128, 256, 2, 4, EPH_QKV>(s, NI, a);
         else launch_linear_h<64, 192, 1, 3, EPH_QKV>(s, NI, a);  // 768 / 192 = 4 column tiles
     }
     launch_attention_h(g, s, NI, qs, ks, vts, 0);
@@ -1827,7 +1838,8 @@ void lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, bo
         LinearArgsH a = linh(g, xs, none, D, D, D, l.cqkv, l.cbqkv, 2 * D);
         a.q = SplitOut{g->qs_hi, g->qs_lo}; a.vt = SplitOut{g->vts_hi, g->vts_lo};
         a.q_scale = sqrtf(sm_scale);
-        if (big) launch_linear_big<128, 256, 2, 4, EPH_CROSS>(s, NI, a);
+        if (big == 2) launch_linear_big<128, 128, 2, 2, EPH_CROSS>(s, NI, a);
+        else if (big) launch_linear_big<128, 256, 2, 4, EPH_CROSS>(s, NI, a);
         else launch_linear_h<64, 128, 1, 2, EPH_CROSS>(s, NI, a);
     }
     launch_attention_h(g, s, NI, qs, qs, vts, 1);
@@ -1948,6 +1960,8 @@ void lg_configure_kernels() {
     launch_linear_h<64, 64, 1, 1, EPH_RESID>(s, 0, cfg);  launch_linear_big<128, 256, 2, 4, EPH_RESID>(s, 0, cfg);
     launch_linear_h<64, 192, 1, 3, EPH_QKV>(s, 0, cfg);   launch_linear_big<128, 256, 2, 4, EPH_QKV>(s, 0, cfg);
     launch_linear_h<64, 128, 1, 2, EPH_CROSS>(s, 0, cfg); launch_linear_big<128, 256, 2, 4, EPH_CROSS>(s, 0, cfg);
+    launch_linear_big<128, 128, 2, 2, EPH_F32>(s, 0, cfg); launch_linear_big<128, 128, 2, 2, EPH_RESID>(s, 0, cfg);
+    launch_linear_big<128, 128, 2, 2, EPH_QKV>(s, 0, cfg); launch_linear_big<128, 128, 2, 2, EPH_CROSS>(s, 0, cfg);
 }
 
 // lg_enqueue through the graph cache (device entry points only; never while profiling: the
@@ -2241,7 +2255,7 @@ int sslam_lightglue_debug_key_split(sslam_lightglue* g, int ks) {
 /* Test hook: -1 = linears chosen by batch size, 0 = always the 64-row ring kernel, 1 = always the
  * 128 x 256 big-tile kernel. */
 int sslam_lightglue_debug_big_gemm(sslam_lightglue* g, int mode) {
-    SSLAM_REQUIRE(g != nullptr && mode >= -1 && mode <= 1, "sslam_lightglue_debug_big_gemm: bad argument");
+    SSLAM_REQUIRE(g != nullptr && mode >= -1 && mode <= 2, "sslam_lightglue_debug_big_gemm: bad argument");
     g->settings_changed();
     g->big_gemm = mode;
     return 0;

@@ -16,6 +16,9 @@ LG = importlib.import_module("opencv-simpleslam_amd.lightglue").LightGlueHIP
 ctx = pkg._native.default_context()
 lg = LG(W.random_lightglue_state_dict(2, match_gain=4.0, match_bias=3.0), max_kpts=N, max_pairs=B)
 lg.set_precision(prec)
+import os
+if os.environ.get("SSLAM_BIG_GEMM"):
+    lg.debug_big_gemm(int(os.environ["SSLAM_BIG_GEMM"]))
 pairs = []
 for b in range(B):
     k0, d0, k1, d1 = lg_inputs.make_pair(N, seed=11 + b)
