@@ -914,18 +914,33 @@ __global__ void lg_split_weight_kernel(const float* __restrict__ src, _Float16* 
 // token states x[2][Kc][256] -> split planes in k-panel layout over the 2*Kc rows
 // only_moved: refresh after pruning - an image whose rows did not move (n == n_prev) still has
 // the planes its producer's epilogue wrote
-__global__ void lg_split_rows_kernel(const float* __restrict__ src, _Float16* __restrict__ hi,
-                                     _Float16* __restrict__ lo, int ld, int Kc, int NI, int NIc,
-                                     const LGCtrl* __restrict__ ctrl, int only_moved) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t per = (size_t)Kc * ld;
-    if (i >= (size_t)NI * per) return;
-    const int img = (int)(i / per), row = (int)((i % per) / ld), col = (int)(i % ld);
+__global__ __launch_bounds__(256) void lg_split_rows_kernel(const float* __restrict__ src, _Float16* __restrict__ hi,
+                                                            _Float16* __restrict__ lo, int ld, int Kc, int NI, int NIc,
+                                                            const LGCtrl* __restrict__ ctrl, int only_moved) {
+    // grid (SPLIT_BLOCKS_PER_IMAGE, NI): a block owns a slice of ONE image and leaves at once when that
+    // image has nothing to refresh (the common case after a pruning step that removed nothing: a
+    // per-element grid of 32 k blocks spent 20 us just being dispatched)
+    const int img = blockIdx.y;
     const LGCtrl& pc = ctrl_of(ctrl, img);
-    if (pc.stop || row >= pc.n[img & 1] || (only_moved && pc.n[img & 1] == pc.n_prev[img & 1])) return;
-    const size_t o = panel_index(img * Kc + row, col, NIc * Kc);
-    split_f32(src[i], hi[o], lo[o]);
+    const int n = pc.n[img & 1];
+    if (pc.stop || (only_moved && n == pc.n_prev[img & 1])) return;
+    const int cpr = ld / 8;                                // 8-column units per row (ld % 8 == 0)
+    const size_t total = (size_t)n * cpr;
+    const float* s = src + (size_t)img * Kc * ld;
+    for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(u / cpr), col = (int)(u % cpr) * 8;
+        const float4 a = *reinterpret_cast<const float4*>(s + (size_t)row * ld + col);
+        const float4 b = *reinterpret_cast<const float4*>(s + (size_t)row * ld + col + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        half8 hh, ll;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { _Float16 x, y; split_f32(v[e], x, y); hh[e] = x; ll[e] = y; }
+        const size_t o = panel_index(img * Kc + row, col, NIc * Kc);
+        *reinterpret_cast<half8*>(hi + o) = hh;
+        *reinterpret_cast<half8*>(lo + o) = ll;
+    }
 }
+constexpr int SPLIT_BLOCKS_PER_IMAGE = 64;
 
 enum { EPH_QKV = 0, EPH_CROSS = 1, EPH_SPLIT = 2, EPH_F32 = 3, EPH_RESID = 4 };
 
@@ -1129,7 +1144,23 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void lg_linear_big_kernel(LinearAr
     linear_h_epilogue<BM, BN, TM, TN, WN, NW * 64, EPI>(p, rd, col0, ibase, c1, c2, lg_ring);
 }
 
-// LayerNorm(512) + exact GELU: fp32 hidden in, split planes out (one wave / row)
+// erf for the GELU of the split-precision path: Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 absolute
+// (+ fp32 rounding), branch-free: one v_rcp, one v_exp, five fma.  The libm erff the exact-fp32 path
+// keeps is two divergent polynomial branches (~27 exec-mask switches per 8 elements in the ISA) and
+// made this kernel VALU-bound; GELU(y) = y/2 (1 + erf(y / sqrt 2)) carries the absolute error times
+// |y| / 2, i.e. below the fp32 rounding of the O(1) values it is added to downstream.
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
+    return copysignf(fmaf(-p * t, e, 1.0f), x);
+}
+
+// LayerNorm(512) + GELU: fp32 hidden in, split planes out (one wave / row)
 __global__ __launch_bounds__(256) void lg_ln_gelu_h_kernel(const float* __restrict__ hid, SplitOut outs,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta,
@@ -1141,10 +1172,14 @@ __global__ __launch_bounds__(256) void lg_ln_gelu_h_kernel(const float* __restri
     const size_t base = ((size_t)img * Kc + row) * 512;
     const float4 a = *reinterpret_cast<const float4*>(hid + base + lane * 4);
     const float4 b = *reinterpret_cast<const float4*>(hid + base + 256 + lane * 4);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + lane * 4), gb = *reinterpret_cast<const float4*>(gamma + 256 + lane * 4);
+    const float4 ba = *reinterpret_cast<const float4*>(beta + lane * 4), bb = *reinterpret_cast<const float4*>(beta + 256 + lane * 4);
     float s = (a.x + a.y) + (a.z + a.w) + (b.x + b.y) + (b.z + b.w);
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     const float mean = s / 512.0f;
     float v[8] = {a.x - mean, a.y - mean, a.z - mean, a.w - mean, b.x - mean, b.y - mean, b.z - mean, b.w - mean};
+    const float gm[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+    const float bt[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
     float q = 0.0f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) q += v[i] * v[i];
@@ -1153,9 +1188,8 @@ __global__ __launch_bounds__(256) void lg_ln_gelu_h_kernel(const float* __restri
     half4 h0, l0, h1, l1;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int c = (i < 4 ? 0 : 256) + lane * 4 + (i & 3);
-        const float y = v[i] * rstd * gamma[c] + beta[c];
-        const float g = 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
+        const float y = v[i] * rstd * gm[i] + bt[i];
+        const float g = 0.5f * y * (1.0f + erf_as(y * 0.70710678118654752440f));
         _Float16 hh, ll;
         split_f32(g, hh, ll);
         if (i < 4) { h0[i] = hh; l0[i] = ll; } else { h1[i - 4] = hh; l1[i - 4] = ll; }
@@ -1865,9 +1899,9 @@ int lg_enqueue(sslam_lightglue* g, int pairs, const StageSrc& src, float min_con
     }
     const unsigned tokblocks = sslam::cdiv(NI * Kc, 4);
     const dim3 headgrid(sslam::cdiv(Kc, 256), NI);               // one lane per token, one image per grid row
-    const unsigned splitblocks = (unsigned)(((size_t)NI * Kc * D + 255) / 256);
+    const dim3 splitblocks(SPLIT_BLOCKS_PER_IMAGE, NI);
     if (g->precision == 1)
-        hipLaunchKernelGGL(lg_split_rows_kernel, dim3(splitblocks), dim3(256), 0, s, g->x, g->xs_hi, g->xs_lo, D, Kc,
+        hipLaunchKernelGGL(lg_split_rows_kernel, splitblocks, dim3(256), 0, s, g->x, g->xs_hi, g->xs_lo, D, Kc,
                            NI, g->NIc, g->ctrl, 0);
     for (int i = 0; i < g->dbg_layers; ++i) {
         const LGLayerW& l = g->L[i];
@@ -1913,7 +1947,7 @@ int lg_enqueue(sslam_lightglue* g, int pairs, const StageSrc& src, float min_con
             hipLaunchKernelGGL(lg_gather_kernel, dim3(tokblocks), dim3(256), 0, s, g->x, g->enc_cos,
                                g->enc_sin, g->gmap, g->tx, g->tc, g->ts, g->ctrl, Kc, NI, 1);
             if (g->precision == 1)      // token rows moved: refresh their split planes
-                hipLaunchKernelGGL(lg_split_rows_kernel, dim3(splitblocks), dim3(256), 0, s, g->x, g->xs_hi,
+                hipLaunchKernelGGL(lg_split_rows_kernel, splitblocks, dim3(256), 0, s, g->x, g->xs_hi,
                                    g->xs_lo, D, Kc, NI, g->NIc, g->ctrl, 1);
         }
     }
