@@ -19,6 +19,8 @@ lg.set_precision(prec)
 import os
 if os.environ.get("SSLAM_BIG_GEMM"):
     lg.debug_big_gemm(int(os.environ["SSLAM_BIG_GEMM"]))
+if os.environ.get("SSLAM_KEY_SPLIT"):          # 1 = the 4-wave attention kernel without key split (A/B against the ping-pong form)
+    lg.debug_key_split(int(os.environ["SSLAM_KEY_SPLIT"]))
 pairs = []
 for b in range(B):
     k0, d0, k1, d1 = lg_inputs.make_pair(N, seed=11 + b)

@@ -26,7 +26,8 @@ int main(int argc, char** argv) {
     _Float16* buf[8];
     for (int i = 0; i < 8; ++i) {
         hipMalloc(&buf[i], plane * 2);
-        fill_half<<<(plane + 255) / 256, 256>>>(buf[i], plane, 17 * i + 1, (i & 1) ? 0.01f : 2.0f);
+        const float amp = getenv("ATTN_ZERO") && atoi(getenv("ATTN_ZERO")) ? 0.0f : 1.0f;   // zero operands: the DVFS / power check
+        fill_half<<<(plane + 255) / 256, 256>>>(buf[i], plane, 17 * i + 1, amp * ((i & 1) ? 0.01f : 2.0f));
     }
     float *o_part, *m_part, *l_part; LGCtrl* ctrl;
     hipMalloc(&o_part, (size_t)KS * plane * 4); hipMalloc(&m_part, (size_t)KS * NI * NH * Kc * 4);
@@ -36,7 +37,11 @@ int main(int argc, char** argv) {
     AttnArgsH a{{buf[0], buf[1]}, {buf[2], buf[3]}, {buf[4], buf[5]}, 0, o_part, m_part, l_part, SplitOut{buf[6], buf[7]}, KS, Kc, NI, ctrl};
     dim3 grid(sslam::cdiv(Kc, AQ), NI * NH, KS);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    auto launch = [&] { hipLaunchKernelGGL(lg_attention_p_kernel, grid, dim3(256), 0, 0, a); };
+    const bool pp = getenv("ATTN_PP") && atoi(getenv("ATTN_PP")) && KS == 1;     // 8-wave ping-pong form
+    auto launch = [&] {
+        if (pp) hipLaunchKernelGGL(lg_attention_pp_kernel, dim3(sslam::cdiv(Kc, AQ2), NI * NH), dim3(512), 0, 0, a);
+        else hipLaunchKernelGGL(lg_attention_p_kernel, grid, dim3(256), 0, 0, a);
+    };
     for (int i = 0; i < 5; ++i) launch();
     hipDeviceSynchronize();
     std::vector<float> t;
@@ -50,8 +55,8 @@ int main(int argc, char** argv) {
     }
     std::sort(t.begin(), t.end());
     const double fl = 8.0 * N * (double)N * 256 * B;
-    printf("N=%d pairs=%d KS=%d abl=%d sched=%d: median %.1f us/launch (min %.1f) = %.2f us per pair, %.0f TF alg, executed %.1f%% of the f16 peak; err=%s\n",
-           N, B, KS, ATTN_ABL,
+    printf("%s N=%d pairs=%d KS=%d abl=%d sched=%d: median %.1f us/launch (min %.1f) = %.2f us per pair, %.0f TF alg, executed %.1f%% of the f16 peak; err=%s\n",
+           pp ? "[pp]" : "[p4]", N, B, KS, ATTN_ABL,
 #ifdef ATTN_SCHED
            ATTN_SCHED,
 #else

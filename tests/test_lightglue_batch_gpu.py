@@ -71,6 +71,12 @@ def test_batch_equals_single_pair_calls_and_oracle(gpu_ctx):
             np.testing.assert_array_equal(ij, o_ij)
             np.testing.assert_allclose(sc, o_sc, atol=1e-3, rtol=1e-3)
             assert info[1] == o_stop
+    # the 8-wave ping-pong attention kernel (an experiment kept selectable: DESIGN section 3) multiplies
+    # the same products in the same order as the 4-wave kernel without key split: bit-identical
+    batch.debug_key_split(-1)
+    for (ij, sc, info), (p_ij, p_sc, p_info) in zip(got, dev.run(batch, 0.7)):
+        np.testing.assert_array_equal(ij, p_ij)
+        np.testing.assert_array_equal(sc, p_sc)
     # default key-split policy of a batch differs from the single-pair one: indices still identical
     batch.debug_key_split(0); single.debug_key_split(0)
     assert sum(len(g[0]) for g in got) > 300
