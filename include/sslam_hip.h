@@ -120,6 +120,23 @@ int sslam_fmat_ransac_host(sslam_ctx* ctx, int n, const float* pts1, const float
                            double thresh, double confidence, int max_iters,
                            unsigned char* mask_out, double* F_out, int* info_out);
 
+/* Device-resident form of the same filter, for a tracking step that keeps the matcher's output on the
+ * GPU: consumes what `sslam_lightglue_match_dev` wrote and leaves what `filter_matches_ransac` would
+ * return (features_utils.py:185-200) on the device; enqueued on ctx's stream, no host round trip.
+ *   n_max: bound on the match count;  n_dev: device int32 count (e.g. the matcher's info[0]), clamped to
+ *   [0, n_max]; NULL = exactly n_max matches
+ *   xy1_dev, xy2_dev: keypoints [*][2] float32;  ij_dev: int32 [n][2] (query, train) index pairs
+ *   mask_out_dev[n_max] (may be NULL): 1 = kept;  ij_out_dev[n_max][2] (may be NULL): the kept pairs, in order
+ *   F_out_dev[9] double (may be NULL);  info_out_dev[4] int32: pairs kept, iterations, 1 if LMedS,
+ *   winning sample (-1: no model -> nothing kept, as the reference's `mask is None`; -2: fewer than 8
+ *   matches, all kept unfiltered as the reference does)
+ * The context's scratch buffer is (re)allocated when n_max grows: call once with the largest n_max
+ * before capturing or pipelining. */
+int sslam_fmat_ransac_dev(sslam_ctx* ctx, int n_max, const int32_t* n_dev, const float* xy1_dev,
+                          const float* xy2_dev, const int32_t* ij_dev, double thresh, double confidence,
+                          int max_iters, unsigned char* mask_out_dev, int32_t* ij_out_dev,
+                          double* F_out_dev, int32_t* info_out_dev);
+
 /* ------------------------------------------- 2D-3D association for tracking
  * Replaces the per-point loop of `reproject_and_match_2d3d` (slam/core/pnp_utils.py:224-304) for
  * float descriptors: projection (`_project_points` :127-141), radius search (cKDTree :238, :265),

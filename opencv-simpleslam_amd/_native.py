@@ -52,6 +52,7 @@ def _signatures():
         "sslam_ba_residual_jacobian_dev": (i32, [vp, i32] + [vp] * 3 + [i32, vp, vp, i32, vp, vp] + [vp] * 4),
         "sslam_ba_solve_host": (i32, [vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, C.c_double, i32, vp]),
         "sslam_fmat_ransac_host": (i32, [vp, i32, vp, vp, C.c_double, C.c_double, i32, vp, vp, vp]),
+        "sslam_fmat_ransac_dev": (i32, [vp, i32, vp, vp, vp, vp, C.c_double, C.c_double, i32, vp, vp, vp, vp]),
         "sslam_reproject_match_host": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, C.c_double, C.c_double,
                                              vp, vp, vp]),
         "sslam_reproject_match_dev": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, C.c_double, C.c_double,

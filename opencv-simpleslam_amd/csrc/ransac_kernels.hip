@@ -52,7 +52,10 @@ struct RSCtrl {
 };
 
 struct RSArgs {
-    int n; int max_iters;
+    int n; int max_iters;                     // n: match count, or its bound when n_dev is given
+    const int32_t* n_dev;                     // device-resident count (the matcher's), clamped to [0, n]; may be NULL
+    const float* xy1; const float* xy2;       // _dev entry: keypoint arrays the index pairs refer to
+    const int32_t* ij; int32_t* ij_out; int32_t* info_out; double* F_out;
     int h0, h1;                               // sample range of this chunk
     double thresh, confidence;
     const float* p1; const float* p2;         // [n][2]
@@ -64,6 +67,8 @@ struct RSArgs {
     unsigned char* mask;                      // [n]
     RSCtrl* ctrl;
 };
+
+__device__ __forceinline__ int rs_n(const RSArgs& a) { return a.n_dev ? min(max(a.n_dev[0], 0), a.n) : a.n; }
 
 // ---- cv::RNG ------------------------------------------------------------------------------
 struct CvRng {
@@ -106,7 +111,7 @@ __device__ int update_num_iters(double p, double ep, int model_points, int max_i
 __global__ void rs_subsets_kernel(RSArgs a) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     RSCtrl* c = a.ctrl;
-    const int n = a.n;
+    const int n = rs_n(a);
     if (a.h0 == 0) {
         c->lmeds = n <= RS_LMEDS_MAX;
         c->budget = max(a.max_iters, 1);
@@ -116,6 +121,7 @@ __global__ void rs_subsets_kernel(RSArgs a) {
         c->best_h = c->best_k = -1;
         c->best_count = 0; c->niters = 0; c->max_good = 0;
         c->min_median = DBL_MAX;
+        if (n < 8) c->exhausted = 1;          // _dev entry with a device count: fewer than 8 matches pass through unfiltered
     }
     if (c->exhausted) return;
     CvRng rng{c->rng_state};
@@ -297,27 +303,28 @@ __global__ __launch_bounds__(RS_T) void rs_score_kernel(RSArgs a) {
     const int h = a.h0 + blockIdx.x, k = blockIdx.y;
     const RSCtrl* c = a.ctrl;
     if (h >= c->n_subsets || k >= a.nmodels[h]) return;
+    const int n = rs_n(a);
     double F[9];
     for (int i = 0; i < 9; ++i) F[i] = a.models[(size_t)h * 27 + 9 * k + i];
     if (c->lmeds) {
         // n <= 14: one lane sorts the errors and takes the median
         if (threadIdx.x == 0) {
             float e[RS_LMEDS_MAX];
-            for (int i = 0; i < a.n; ++i) e[i] = fm_error(F, a.p1[2 * i], a.p1[2 * i + 1], a.p2[2 * i], a.p2[2 * i + 1]);
-            for (int i = 1; i < a.n; ++i) {
+            for (int i = 0; i < n; ++i) e[i] = fm_error(F, a.p1[2 * i], a.p1[2 * i + 1], a.p2[2 * i], a.p2[2 * i + 1]);
+            for (int i = 1; i < n; ++i) {
                 const float v = e[i];
                 int j = i - 1;
                 // NaN-safe insertion: a NaN compares false and stays where it is
                 while (j >= 0 && e[j] > v) { e[j + 1] = e[j]; --j; }
                 e[j + 1] = v;
             }
-            a.medians[h * 3 + k] = a.n % 2 != 0 ? e[a.n / 2] : (e[a.n / 2 - 1] + e[a.n / 2]) * 0.5f;
+            a.medians[h * 3 + k] = n % 2 != 0 ? e[n / 2] : (e[n / 2 - 1] + e[n / 2]) * 0.5f;
         }
         return;
     }
     const float t = (float)(a.thresh * a.thresh);
     int good = 0;
-    for (int i = threadIdx.x; i < a.n; i += RS_T)
+    for (int i = threadIdx.x; i < n; i += RS_T)
         good += fm_error(F, a.p1[2 * i], a.p1[2 * i + 1], a.p2[2 * i], a.p2[2 * i + 1]) <= t;
     sh[threadIdx.x] = good;
     __syncthreads();
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(RS_T) void rs_score_kernel(RSArgs a) {
 __global__ void rs_select_kernel(RSArgs a) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     RSCtrl* c = a.ctrl;
-    const int n = a.n;
+    const int n = rs_n(a);
     int it = a.h0;
     if (it != c->niters) return;                       // the loop already ended before this chunk
     if (c->lmeds) {
@@ -360,7 +367,7 @@ __global__ void rs_finish_kernel(RSArgs a) {
     RSCtrl* c = a.ctrl;
     c->thresh = a.thresh;
     if (c->lmeds && c->best_h >= 0) {
-        double sigma = 2.5 * 1.4826 * (1 + 5. / (a.n - RS_MP)) * sqrt(c->min_median);
+        double sigma = 2.5 * 1.4826 * (1 + 5. / (rs_n(a) - RS_MP)) * sqrt(c->min_median);
         c->thresh = fmax(sigma, 0.001);
     }
     if (c->best_h >= 0)
@@ -373,9 +380,11 @@ __global__ __launch_bounds__(RS_T) void rs_mask_kernel(RSArgs a) {
     RSCtrl* c = a.ctrl;
     const bool have = c->best_h >= 0;
     const float t = (float)(c->thresh * c->thresh);
+    const int n = rs_n(a);
+    const bool pass = n < 8;                   // features_utils.py:189-190: fewer than 8 matches are returned as they are
     int good = 0;
-    for (int i = threadIdx.x; i < a.n; i += RS_T) {
-        const int in = have && fm_error(c->F, a.p1[2 * i], a.p1[2 * i + 1], a.p2[2 * i], a.p2[2 * i + 1]) <= t;
+    for (int i = threadIdx.x; i < n; i += RS_T) {
+        const int in = pass || (have && fm_error(c->F, a.p1[2 * i], a.p1[2 * i + 1], a.p2[2 * i], a.p2[2 * i + 1]) <= t);
         a.mask[i] = (unsigned char)in;
         good += in;
     }
@@ -388,42 +397,57 @@ __global__ __launch_bounds__(RS_T) void rs_mask_kernel(RSArgs a) {
     if (threadIdx.x == 0) c->best_count = sh[0];
 }
 
-}  // namespace
-
-extern "C" int sslam_fmat_ransac_host(sslam_ctx* ctx, int n, const float* pts1, const float* pts2, double thresh,
-                                      double confidence, int max_iters, unsigned char* mask_out, double* F_out,
-                                      int* info_out) {
-    SSLAM_REQUIRE(ctx != nullptr, "sslam_fmat_ransac_host: ctx is NULL");
-    SSLAM_REQUIRE(n >= 8, "sslam_fmat_ransac_host: %d matches, need >= 8 (the caller returns fewer unchanged)", n);
-    SSLAM_REQUIRE(pts1 && pts2 && mask_out, "sslam_fmat_ransac_host: NULL argument");
-    // cv::findFundamentalMat's own defaulting of bad parameters
-    if (thresh <= 0) thresh = 3;
-    if (confidence < DBL_EPSILON || confidence > 1 - DBL_EPSILON) confidence = 0.99;
-    if (max_iters <= 0 || max_iters > RS_MAX_ITERS) max_iters = RS_MAX_ITERS;
-    SSLAM_HIP_CHECK(hipSetDevice(ctx->device));
-    const size_t N = (size_t)n, H = (size_t)max_iters;
-    size_t off = 0;
-    auto carve = [&](size_t bytes) { size_t o = off; off = sslam::align_up(off + bytes + 8, 256); return o; };
-    const size_t o_p1 = carve(N * 8), o_p2 = carve(N * 8), o_sub = carve(H * RS_MP * 4), o_mod = carve(H * 27 * 8);
-    const size_t o_nm = carve(H * 4), o_cnt = carve(H * 12), o_med = carve(H * 12), o_mask = carve(N), o_ctrl = carve(sizeof(RSCtrl));
-    if (off > ctx->ba_scratch_bytes) {
-        if (ctx->ba_scratch) SSLAM_HIP_CHECK(hipFree(ctx->ba_scratch));
-        ctx->ba_scratch = nullptr;
-        ctx->ba_scratch_bytes = 0;
-        SSLAM_HIP_CHECK(hipMalloc(&ctx->ba_scratch, off));
-        ctx->ba_scratch_bytes = off;
+// ---- device-resident front and back end (sslam_fmat_ransac_dev) -------------------------------------
+// matched pixel pairs from the matcher's index pairs
+__global__ __launch_bounds__(RS_T) void rs_gather_kernel(RSArgs a, float* p1, float* p2) {
+    const int n = rs_n(a);
+    for (int i = blockIdx.x * RS_T + threadIdx.x; i < n; i += gridDim.x * RS_T) {
+        const int q = a.ij[2 * i], t = a.ij[2 * i + 1];
+        p1[2 * i] = a.xy1[2 * q]; p1[2 * i + 1] = a.xy1[2 * q + 1];
+        p2[2 * i] = a.xy2[2 * t]; p2[2 * i + 1] = a.xy2[2 * t + 1];
     }
-    char* b = (char*)ctx->ba_scratch;
-    hipStream_t s = ctx->stream;
-    SSLAM_HIP_CHECK(hipMemcpyAsync(b + o_p1, pts1, N * 8, hipMemcpyHostToDevice, s));
-    SSLAM_HIP_CHECK(hipMemcpyAsync(b + o_p2, pts2, N * 8, hipMemcpyHostToDevice, s));
-    SSLAM_HIP_CHECK(hipMemsetAsync(b + o_nm, 0, H * 4, s));
-    RSArgs a{};
-    a.n = n; a.max_iters = max_iters; a.thresh = thresh; a.confidence = confidence;
-    a.p1 = (const float*)(b + o_p1); a.p2 = (const float*)(b + o_p2);
-    a.subsets = (int*)(b + o_sub); a.models = (double*)(b + o_mod); a.nmodels = (int*)(b + o_nm);
-    a.counts = (int*)(b + o_cnt); a.medians = (float*)(b + o_med); a.mask = (unsigned char*)(b + o_mask);
-    a.ctrl = (RSCtrl*)(b + o_ctrl);
+}
+
+// what filter_matches_ransac returns (features_utils.py:185-200): the pairs whose mask is set, in
+// order; all of them below 8 matches; none when OpenCV finds no model (mask None)
+__global__ __launch_bounds__(1024) void rs_compact_kernel(RSArgs a) {
+    __shared__ int wsum[16], base;
+    const RSCtrl* c = a.ctrl;
+    const int n = rs_n(a), lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool pass = n < 8;
+    const bool none = !pass && (c->best_h < 0 || (c->lmeds && c->best_count < RS_MP));
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + threadIdx.x;
+        const bool keep = i < n && !none && a.mask[i];
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) wsum[w] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int j = 0; j < w; ++j) off += wsum[j];
+        if (keep && a.ij_out) {
+            const int o = off + __popcll(bal & ((1ull << lane) - 1));
+            a.ij_out[2 * o] = a.ij[2 * i];
+            a.ij_out[2 * o + 1] = a.ij[2 * i + 1];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { int tsum = 0; for (int j = 0; j < 16; ++j) tsum += wsum[j]; base += tsum; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (a.info_out) {
+            a.info_out[0] = base;                                   // matches kept
+            a.info_out[1] = c->niters;
+            a.info_out[2] = c->lmeds;
+            a.info_out[3] = pass ? -2 : (none ? -1 : c->best_h);   // -2: passed through, -1: no model
+        }
+        if (a.F_out) for (int i = 0; i < 9; ++i) a.F_out[i] = (!pass && !none) ? c->F[i] : 0.0;
+    }
+}
+
+// the sample loop + finish + mask (shared by the two entries)
+void rs_enqueue(hipStream_t s, RSArgs a, int max_iters) {
     // the sample loop in chunks: a chunk whose first sample lies beyond the (shrinking) budget is a
     // handful of early-exit launches, so a typical call costs two or three chunks, not max_iters
     constexpr int CHUNK = 128;
@@ -436,6 +460,91 @@ extern "C" int sslam_fmat_ransac_host(sslam_ctx* ctx, int n, const float* pts1, 
     }
     hipLaunchKernelGGL(rs_finish_kernel, dim3(1), dim3(64), 0, s, a);
     hipLaunchKernelGGL(rs_mask_kernel, dim3(1), dim3(RS_T), 0, s, a);
+}
+
+struct RSScratch { size_t p1, p2, sub, mod, nm, cnt, med, mask, ctrl, total; };
+RSScratch rs_layout(size_t N, size_t H) {
+    RSScratch L{};
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = sslam::align_up(off + bytes + 8, 256); return o; };
+    L.p1 = carve(N * 8); L.p2 = carve(N * 8); L.sub = carve(H * RS_MP * 4); L.mod = carve(H * 27 * 8);
+    L.nm = carve(H * 4); L.cnt = carve(H * 12); L.med = carve(H * 12); L.mask = carve(N); L.ctrl = carve(sizeof(RSCtrl));
+    L.total = off;
+    return L;
+}
+
+int rs_reserve(sslam_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->ba_scratch_bytes) return 0;
+    // (re)allocation synchronises the device: a pipeline sizes the scratch once, with its largest problem
+    if (ctx->ba_scratch) SSLAM_HIP_CHECK(hipFree(ctx->ba_scratch));
+    ctx->ba_scratch = nullptr;
+    ctx->ba_scratch_bytes = 0;
+    SSLAM_HIP_CHECK(hipMalloc(&ctx->ba_scratch, bytes));
+    ctx->ba_scratch_bytes = bytes;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int sslam_fmat_ransac_dev(sslam_ctx* ctx, int n_max, const int32_t* n_dev, const float* xy1_dev,
+                                     const float* xy2_dev, const int32_t* ij_dev, double thresh, double confidence,
+                                     int max_iters, unsigned char* mask_out_dev, int32_t* ij_out_dev,
+                                     double* F_out_dev, int32_t* info_out_dev) {
+    SSLAM_REQUIRE(ctx != nullptr, "sslam_fmat_ransac_dev: ctx is NULL");
+    SSLAM_REQUIRE(n_max >= 1, "sslam_fmat_ransac_dev: n_max %d < 1", n_max);
+    SSLAM_REQUIRE(xy1_dev && xy2_dev && ij_dev, "sslam_fmat_ransac_dev: NULL argument");
+    if (thresh <= 0) thresh = 3;
+    if (confidence < DBL_EPSILON || confidence > 1 - DBL_EPSILON) confidence = 0.99;
+    if (max_iters <= 0 || max_iters > RS_MAX_ITERS) max_iters = RS_MAX_ITERS;
+    SSLAM_HIP_CHECK(hipSetDevice(ctx->device));
+    const RSScratch L = rs_layout((size_t)n_max, (size_t)max_iters);
+    if (int rc = rs_reserve(ctx, L.total)) return rc;
+    char* b = (char*)ctx->ba_scratch;
+    hipStream_t s = ctx->stream;
+    SSLAM_HIP_CHECK(hipMemsetAsync(b + L.nm, 0, (size_t)max_iters * 4, s));
+    RSArgs a{};
+    a.n = n_max; a.n_dev = n_dev; a.max_iters = max_iters; a.thresh = thresh; a.confidence = confidence;
+    a.xy1 = xy1_dev; a.xy2 = xy2_dev; a.ij = ij_dev; a.ij_out = ij_out_dev; a.info_out = info_out_dev; a.F_out = F_out_dev;
+    a.p1 = (const float*)(b + L.p1); a.p2 = (const float*)(b + L.p2);
+    a.subsets = (int*)(b + L.sub); a.models = (double*)(b + L.mod); a.nmodels = (int*)(b + L.nm);
+    a.counts = (int*)(b + L.cnt); a.medians = (float*)(b + L.med);
+    a.mask = mask_out_dev ? mask_out_dev : (unsigned char*)(b + L.mask);
+    a.ctrl = (RSCtrl*)(b + L.ctrl);
+    hipLaunchKernelGGL(rs_gather_kernel, dim3(std::min(sslam::cdiv(n_max, RS_T), 64)), dim3(RS_T), 0, s, a,
+                       (float*)(b + L.p1), (float*)(b + L.p2));
+    rs_enqueue(s, a, max_iters);
+    hipLaunchKernelGGL(rs_compact_kernel, dim3(1), dim3(1024), 0, s, a);
+    SSLAM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int sslam_fmat_ransac_host(sslam_ctx* ctx, int n, const float* pts1, const float* pts2, double thresh,
+                                      double confidence, int max_iters, unsigned char* mask_out, double* F_out,
+                                      int* info_out) {
+    SSLAM_REQUIRE(ctx != nullptr, "sslam_fmat_ransac_host: ctx is NULL");
+    SSLAM_REQUIRE(n >= 8, "sslam_fmat_ransac_host: %d matches, need >= 8 (the caller returns fewer unchanged)", n);
+    SSLAM_REQUIRE(pts1 && pts2 && mask_out, "sslam_fmat_ransac_host: NULL argument");
+    // cv::findFundamentalMat's own defaulting of bad parameters
+    if (thresh <= 0) thresh = 3;
+    if (confidence < DBL_EPSILON || confidence > 1 - DBL_EPSILON) confidence = 0.99;
+    if (max_iters <= 0 || max_iters > RS_MAX_ITERS) max_iters = RS_MAX_ITERS;
+    SSLAM_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t N = (size_t)n;
+    const RSScratch L = rs_layout(N, (size_t)max_iters);
+    if (int rc = rs_reserve(ctx, L.total)) return rc;
+    char* b = (char*)ctx->ba_scratch;
+    const size_t o_p1 = L.p1, o_p2 = L.p2, o_mask = L.mask, o_ctrl = L.ctrl;
+    hipStream_t s = ctx->stream;
+    SSLAM_HIP_CHECK(hipMemcpyAsync(b + o_p1, pts1, N * 8, hipMemcpyHostToDevice, s));
+    SSLAM_HIP_CHECK(hipMemcpyAsync(b + o_p2, pts2, N * 8, hipMemcpyHostToDevice, s));
+    SSLAM_HIP_CHECK(hipMemsetAsync(b + L.nm, 0, (size_t)max_iters * 4, s));
+    RSArgs a{};
+    a.n = n; a.max_iters = max_iters; a.thresh = thresh; a.confidence = confidence;
+    a.p1 = (const float*)(b + o_p1); a.p2 = (const float*)(b + o_p2);
+    a.subsets = (int*)(b + L.sub); a.models = (double*)(b + L.mod); a.nmodels = (int*)(b + L.nm);
+    a.counts = (int*)(b + L.cnt); a.medians = (float*)(b + L.med); a.mask = (unsigned char*)(b + o_mask);
+    a.ctrl = (RSCtrl*)(b + o_ctrl);
+    rs_enqueue(s, a, max_iters);
     SSLAM_HIP_CHECK(hipGetLastError());
     RSCtrl h{};
     SSLAM_HIP_CHECK(hipMemcpyAsync(&h, b + o_ctrl, sizeof(RSCtrl), hipMemcpyDeviceToHost, s));

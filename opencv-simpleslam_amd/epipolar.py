@@ -35,3 +35,15 @@ def find_fundamental_ransac(pts1, pts2, thresh: float = 1.0, confidence: float =
     if info[0] < 0 or (meta["lmeds"] and info[0] < 7):
         return None, None, meta
     return F.reshape(3, 3), mask.astype(bool), meta
+
+
+def filter_matches_dev(ctx, n_max: int, n_dev, xy1_dev, xy2_dev, ij_dev, ij_out_dev, info_out_dev,
+                       thresh: float = 1.0, confidence: float = 0.99, max_iters: int = 1000,
+                       mask_out_dev=None, F_out_dev=None):
+    """Device-resident `filter_matches_ransac` (slam/core/features_utils.py:185-200): all arguments are
+    device pointers (ints); consumes the matcher's `(ij, info[0])` and leaves the kept pairs and their
+    count on the device.  Enqueued on ctx's stream; nothing is read back here."""
+    _native.check(_native.lib().sslam_fmat_ransac_dev(
+        ctx.handle, int(n_max), _native.ptr(n_dev), _native.ptr(xy1_dev), _native.ptr(xy2_dev), _native.ptr(ij_dev),
+        float(thresh), float(confidence), int(max_iters), _native.ptr(mask_out_dev), _native.ptr(ij_out_dev),
+        _native.ptr(F_out_dev), _native.ptr(info_out_dev)), "sslam_fmat_ransac_dev")

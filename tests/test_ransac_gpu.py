@@ -93,3 +93,56 @@ def test_filter_matches_ransac_drop_in(E):
     assert [m.queryIdx for m in kept] == list(np.flatnonzero(mr))
     assert all(m.trainIdx == perm[m.queryIdx] for m in kept)
     assert fu.filter_matches_ransac(kp1, kp2, matches[:5], 1.0) == matches[:5]      # < 8: unchanged (reference :189)
+
+
+def _dev_filter(E, ctx, kp1, kp2, ij, n_used, thresh=1.0):
+    """Run sslam_fmat_ransac_dev on device copies of (kp1, kp2, ij[, count]) and read its outputs back."""
+    n_max = len(ij)
+    d = [ctx.upload(np.ascontiguousarray(a)) for a in (kp1.astype(np.float32), kp2.astype(np.float32),
+                                                        ij.astype(np.int32), np.array([n_used], np.int32))]
+    out_ij, info, mask, F = ctx.malloc(n_max * 8), ctx.malloc(16), ctx.malloc(n_max), ctx.malloc(72)
+    E.filter_matches_dev(ctx, n_max, d[3], d[0], d[1], d[2], out_ij, info, thresh=thresh, mask_out_dev=mask, F_out_dev=F)
+    h_ij, h_info = np.empty((n_max, 2), np.int32), np.empty(4, np.int32)
+    h_mask, h_F = np.empty(n_max, np.uint8), np.empty(9)
+    ctx.d2h(h_ij, out_ij); ctx.d2h(h_info, info); ctx.d2h(h_mask, mask); ctx.d2h(h_F, F)
+    for p in d + [out_ij, info, mask, F]:
+        ctx.free(p)
+    return h_ij[:h_info[0]], h_info, h_mask[:n_used].astype(bool), h_F.reshape(3, 3)
+
+
+@pytest.mark.parametrize("n,frac,seed,spare", [(2048, 0.3, 0, 0), (400, 0.5, 1, 37), (15, 0.2, 3, 5), (14, 0.15, 2, 0)])
+def test_device_resident_filter_equals_the_host_entry(E, gpu_ctx, n, frac, seed, spare):
+    """sslam_fmat_ransac_dev consumes the matcher's device outputs (keypoints, index pairs, a device
+    count that may be below the buffer bound) and must leave exactly what the host entry returns for
+    the gathered points: same mask, same F, same winning sample, the kept pairs in order."""
+    p1, p2, _ = two_view.make_matches(n, outlier_frac=frac, noise=0.3, seed=seed)
+    rng = np.random.default_rng(seed)
+    # scatter the matched points into two keypoint arrays, as a matcher would index them
+    n1, n2 = n + 50, n + 80
+    q, t = rng.permutation(n1)[:n], rng.permutation(n2)[:n]
+    kp1 = rng.uniform(0, 1000, (n1, 2)).astype(np.float32); kp1[q] = p1
+    kp2 = rng.uniform(0, 1000, (n2, 2)).astype(np.float32); kp2[t] = p2
+    ij = np.stack([q, t], 1).astype(np.int32)
+    ij_buf = np.concatenate([ij, np.zeros((spare, 2), np.int32)])          # capacity beyond the device count
+    kept, info, mask, F = _dev_filter(E, gpu_ctx, kp1, kp2, ij_buf, n)
+    F_h, mask_h, info_h = E.find_fundamental_ransac(p1, p2, 1.0, 0.99, ctx=gpu_ctx)
+    assert mask_h is not None
+    np.testing.assert_array_equal(mask, mask_h)
+    np.testing.assert_array_equal(kept, ij[mask_h])
+    assert info[0] == mask_h.sum() and info[1] == info_h["iterations"] and info[3] == info_h["sample"]
+    assert bool(info[2]) == info_h["lmeds"]
+    np.testing.assert_array_equal(F, F_h)
+
+
+def test_device_resident_filter_conventions(E, gpu_ctx):
+    """features_utils.py:189-190: fewer than 8 matches come back unfiltered; :196-197: no model -> []."""
+    rng = np.random.default_rng(0)
+    kp = rng.uniform(0, 500, (40, 2)).astype(np.float32)
+    ij = np.stack([np.arange(20), np.arange(20)], 1).astype(np.int32)
+    for n_used in (0, 1, 7):
+        kept, info, mask, _ = _dev_filter(E, gpu_ctx, kp, kp + 3, ij, n_used)
+        assert info[0] == n_used and info[3] == -2 and mask.all()
+        np.testing.assert_array_equal(kept, ij[:n_used])
+    z = np.zeros((40, 2), np.float32)                                       # no admissible subset: cv2 returns mask None
+    kept, info, _, F = _dev_filter(E, gpu_ctx, z, z, ij, 20)
+    assert info[0] == 0 and info[3] == -1 and len(kept) == 0 and not F.any()
