@@ -252,7 +252,7 @@ int sslam_lightglue_match_batch_dev(sslam_lightglue* lg, int n_pairs, const floa
 int sslam_lightglue_use_graphs(sslam_lightglue* lg, int enable);
 /* The split-precision path carries fp32 values as fp16 plane pairs: a FINITE activation with
  * |value| >= 65520 does not fit (the exact-fp32 path, precision 0, has no such limit).  Such a value
- * is saturated and flagged on the device; sslam_lightglue_match_host fails with a message when the
+ * is flagged on the device (and saturated or turned non-finite, never silently wrapped); sslam_lightglue_match_host fails with a message when the
  * flag is set, callers of the _dev / _batch_dev entries poll it here (synchronises the stream,
  * returns and clears the flag). */
 int sslam_lightglue_range_overflow(sslam_lightglue* lg, int* flag_out);

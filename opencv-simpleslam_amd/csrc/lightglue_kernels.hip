@@ -979,8 +979,44 @@ __device__ __forceinline__ void linear_h_epilogue(const LinearArgsH& p, const Ro
     // column) and writes 16-byte pieces.
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    constexpr int ELD = BN + 4;                        // fp32 row stride of the staged tile
+    // fp32 row stride of the staged tile: BN + 4 keeps the float4 row reads aligned; a V column tile
+    // (read by columns, 8 tokens of one column per unit) uses BN + 1 so the 16 token runs of a
+    // column fall on different banks
+    constexpr int VCOL_FIRST = (EPI == EPH_QKV) ? 2 * D : D;
+    const bool v_tile = (EPI == EPH_QKV || EPI == EPH_CROSS) && col0 >= VCOL_FIRST;          // wholly V columns
+    const bool has_v = (EPI == EPH_QKV || EPI == EPH_CROSS) && col0 + BN > VCOL_FIRST;     // (a 192-wide tile can straddle k | v)
+    const int ELD = v_tile ? BN + 1 : BN + 4;
     float* epi = reinterpret_cast<float*>(lds);
+    // Row pass: thread t owns unit u = t + it NT = (row u / CH, 8-column chunk u % CH), ITERS units in all.
+    // What a unit needs from HBM (the rotary table of its row, the residual it adds to) is asked for
+    // HERE, before the tile is staged through LDS: inside the unit loop each load would be an exposed
+    // ~1.5 us round trip per iteration (QKV: 83 us per 8-pair launch against 48 for the main loop alone).
+    constexpr int CH = BN / 8;                         // 8-column chunks per row
+    static_assert((BM * CH) % NT == 0, "units divide over the threads");
+    constexpr int ITERS = BM * CH / NT;
+    const int grow0 = (int)ibase + rd.row0;            // global plane row of tile row 0
+    float4 pre_a[(EPI == EPH_QKV || EPI == EPH_RESID) ? ITERS : 1], pre_b[(EPI == EPH_QKV || EPI == EPH_RESID) ? ITERS : 1];
+#ifndef LG_EPI_PREFETCH
+#define LG_EPI_PREFETCH 1      // A/B switch (scripts/ab_lib.sh): 0 = load inside the unit loop
+#endif
+    auto pre_load = [&](int it) {
+        const int u = t + it * NT, rl = u / CH, cl = (u % CH) * 8;
+        if constexpr (EPI == EPH_QKV) {
+            const int d = (col0 + cl) & 63;
+            pre_a[it] = *reinterpret_cast<const float4*>(p.enc_cos + (size_t)(grow0 + rl) * ENC + (d >> 1));
+            pre_b[it] = *reinterpret_cast<const float4*>(p.enc_sin + (size_t)(grow0 + rl) * ENC + (d >> 1));
+        } else if constexpr (EPI == EPH_RESID) {
+            const size_t o = (size_t)(grow0 + rl) * p.ldo + col0 + cl;
+            pre_a[it] = *reinterpret_cast<const float4*>(p.out + o);
+            pre_b[it] = *reinterpret_cast<const float4*>(p.out + o + 4);
+        }
+    };
+    if constexpr (LG_EPI_PREFETCH && (EPI == EPH_QKV || EPI == EPH_RESID)) {
+        if (!v_tile) {
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) pre_load(it);
+        }
+    }
     __syncthreads();                                   // consumers are done with the last k-tile
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -996,19 +1032,29 @@ __device__ __forceinline__ void linear_h_epilogue(const LinearArgsH& p, const Ro
         }
     __syncthreads();
 
-    const int grow0 = (int)ibase + rd.row0;            // global plane row of tile row 0
-    auto split8 = [](const float (&v)[8], uint4& hi, uint4& lo) {
+#ifndef LG_EPI_FAST_SPLIT
+#define LG_EPI_FAST_SPLIT 1    // A/B switch (scripts/ab_lib.sh): 0 = the branchy scalar split_f32 per value
+#endif
+    float amax = 0.0f;
+    auto split8 = [&amax](const float (&v)[8], uint4& hi, uint4& lo) {
+#if LG_EPI_FAST_SPLIT
+        sslam::split8_fast(v, hi, lo, amax);
+#else
         half8 hh, ll;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { _Float16 a, b2; split_f32(v[e], a, b2); hh[e] = a; ll[e] = b2; }
         hi = *reinterpret_cast<uint4*>(&hh);
         lo = *reinterpret_cast<uint4*>(&ll);
+#endif
     };
-    constexpr int CH = BN / 8;                         // 8-column chunks per row
-    for (int u = t; u < BM * CH; u += NT) {
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        if (v_tile) break;
+        const int u = t + it * NT;
         const int rl = u / CH, cl = (u % CH) * 8;
         const int row = rd.row0 + rl, col = col0 + cl;
         if (row >= rd.n) continue;
+        if constexpr (!LG_EPI_PREFETCH && (EPI == EPH_QKV || EPI == EPH_RESID)) pre_load(it);
         float v[8];
         {
             const float4 a = *reinterpret_cast<const float4*>(&epi[rl * ELD + cl]);
@@ -1022,8 +1068,7 @@ __device__ __forceinline__ void linear_h_epilogue(const LinearArgsH& p, const Ro
             const bool is_k = (EPI == EPH_QKV) && s == 1;
             if constexpr (EPI == EPH_QKV) {
                 // rotary: out[2i] = x[2i] cos_i - x[2i+1] sin_i ; out[2i+1] = x[2i+1] cos_i + x[2i] sin_i
-                const float4 c4 = *reinterpret_cast<const float4*>(p.enc_cos + (size_t)(grow0 + rl) * ENC + (d >> 1));
-                const float4 s4 = *reinterpret_cast<const float4*>(p.enc_sin + (size_t)(grow0 + rl) * ENC + (d >> 1));
+                const float4 c4 = pre_a[it], s4 = pre_b[it];
                 const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -1044,8 +1089,7 @@ __device__ __forceinline__ void linear_h_epilogue(const LinearArgsH& p, const Ro
         } else {
             const size_t o = (size_t)(grow0 + rl) * p.ldo + col;
             if constexpr (EPI == EPH_RESID) {
-                const float4 a = *reinterpret_cast<const float4*>(p.out + o);
-                const float4 b4 = *reinterpret_cast<const float4*>(p.out + o + 4);
+                const float4 a = pre_a[it], b4 = pre_b[it];
                 v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b4.x; v[5] += b4.y; v[6] += b4.z; v[7] += b4.w;
             }
             if constexpr (EPI == EPH_F32 || EPI == EPH_RESID) {
@@ -1068,12 +1112,15 @@ __device__ __forceinline__ void linear_h_epilogue(const LinearArgsH& p, const Ro
         // keys {4h..4h+3, 8+4h..8+4h+3} of the group for lane half h - and in this order those eight
         // keys are ONE 16-byte run, i.e. one ds_read_b128 per operand instead of two ds_read_b64 plus
         // register shuffling.  A unit = one column x the 8 tokens {b..b+3, b+8..b+11} of such a run.
-        constexpr int VCOL0 = (EPI == EPH_QKV) ? 2 * D : D;
+        // Unit order: the 16 runs of a column on consecutive lanes - 8 runs are one whole 128-byte line
+        // of V^T (64 key positions of one d), and the next column's lines follow contiguously, so a
+        // wave stores two 512-byte segments per plane instead of 64 separate 16-byte pieces.
         constexpr int RG = BM / 8;
+        if (!has_v) { sslam::split_range_check(amax); return; }
         for (int u = t; u < BN * RG; u += NT) {
-            const int cl = u % BN, rg = u / BN;
+            const int rg = u % RG, cl = u / RG;
             const int col = col0 + cl;
-            if (col < VCOL0) continue;
+            if (col < VCOL_FIRST) continue;
             const int hd = (col >> 6) & 3, d = col & 63;
             const int rl0 = (rg >> 1) * 16 + (rg & 1) * 4;     // first token of the run inside the tile
             const int row = rd.row0 + rl0;
@@ -1093,6 +1140,7 @@ __device__ __forceinline__ void linear_h_epilogue(const LinearArgsH& p, const Ro
             *reinterpret_cast<uint4*>(p.vt.lo + o) = lo;
         }
     }
+    sslam::split_range_check(amax);
 }
 
 template <int BM, int BN, int TM, int TN, int EPI>
