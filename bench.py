@@ -345,6 +345,9 @@ def main():
     sd_a, sd_l = W.random_aliked_state_dict(0), W.random_lightglue_state_dict(0)
     dets = [AlikedHIP(sd_a, max_num_keypoints=MAX_KPTS, max_h=H_IMG, max_w=W_IMG, ctx=c) for c in ctx_e]
     mats = [LightGlueHIP(sd_l, max_kpts=MAX_KPTS, ctx=c, max_pairs=BATCH_PAIRS) for c in ctx_m]
+    if os.environ.get("SSLAM_BIG_GEMM"):                 # A/B hook (scripts/): linear-kernel form of the batched forward
+        for mat in mats:
+            mat.debug_big_gemm(int(os.environ["SSLAM_BIG_GEMM"]))
     plan = fs.ShardPlan(world, rank, FRAMES_PER_RANK)
     pipe = fs.FrameStreamPipeline(dets, mats, plan, MAX_KPTS, MIN_CONF, batch_pairs=BATCH_PAIRS)
     c0 = ctx_e[0]

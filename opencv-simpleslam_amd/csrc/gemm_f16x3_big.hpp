@@ -51,6 +51,7 @@ __device__ __forceinline__ void gemm_mainloop_big(const GemmAH& ga, SplitPtr W, 
     constexpr int NPIECE = 2 * PA + 2 * PW;
     static_assert(NPIECE % NWAVE == 0, "pieces divide over the waves");
     constexpr int NPW = NPIECE / NWAVE;                 // DMA instructions per wave per k-tile
+    static_assert(VARIANT == 0 || PA % NWAVE == 0, "a short A tile (2 PA = NWAVE) only in the lock-step form");
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int nkt = K / BBK;
@@ -66,16 +67,40 @@ __device__ __forceinline__ void gemm_mainloop_big(const GemmAH& ga, SplitPtr W, 
     // g = w + NWAVE j of the list [A hi | A lo | W hi | W lo]; PA and PW are multiples of NWAVE, so
     // the plane of piece j is a compile-time property and the issue path has no branches (the
     // scheduler can then place each DMA instruction between MFMAs).
-    static_assert(PA % NWAVE == 0 && PW % NWAVE == 0, "plane boundaries fall on multiples of the wave count");
-    constexpr int JA = PA / NWAVE, JW = PW / NWAVE;     // pieces per wave per A plane / per W plane
+    // (SHORT_A: a 64-row A tile has only 2 PA = NWAVE pieces - wave w takes piece w of [A hi | A lo],
+    // a wave-uniform plane choice - and the W planes divide over the waves as usual)
+    constexpr bool SHORT_A = (PA % NWAVE) != 0;
+    static_assert(SHORT_A ? (2 * PA == NWAVE && PW % NWAVE == 0) : (PA % NWAVE == 0 && PW % NWAVE == 0),
+                  "plane boundaries fall on multiples of the wave count");
+    constexpr int JA = SHORT_A ? 1 : PA / NWAVE, JW = PW / NWAVE;     // pieces per wave per A plane / per W plane
     const int prow = lane >> 2, pc = lane & 3;
     const int psw = (pc ^ ((prow >> 2) & 3)) * 8;        // logical chunk (halves) this lane fetches
     int aoff[JA], woff[JW];                              // per-lane source offsets (halves) inside a k-panel
 #pragma unroll
-    for (int q = 0; q < JA; ++q) aoff[q] = min(row0 + (wave + NWAVE * q) * 16 + prow, row_cap - 1) * 64 + psw;
+    for (int q = 0; q < JA; ++q)
+        aoff[q] = min(row0 + (SHORT_A ? wave % PA : wave + NWAVE * q) * 16 + prow, row_cap - 1) * 64 + psw;
 #pragma unroll
     for (int q = 0; q < JW; ++q) woff[q] = min(col0 + (wave + NWAVE * q) * 16 + prow, col_cap - 1) * 64 + psw;
+    const bool lo_plane = SHORT_A && wave >= PA;        // (short A tile: this wave's A piece is of the lo plane)
+    const _Float16* const a0w = lo_plane ? ga.A0.lo : ga.A0.hi;
+    const _Float16* const a1w = lo_plane ? ga.A1.lo : ga.A1.hi;
     auto issue = [&](int kt, int stage, int j0 = 0, int j1 = 1 << 20) {
+        if constexpr (SHORT_A) {
+            const int k = kt * BBK;
+            const bool first = k < ga.K0;
+            const int ka = first ? k : k - ga.K0;
+            const size_t apan = (size_t)(ka >> 6) * a_rows * 64 + (ka & 32);
+            const _Float16* pa = (first ? a0w : a1w) + apan;
+            const size_t wpan = (size_t)(k >> 6) * col_cap * 64 + (k & 32);
+            _Float16* st = smem + (size_t)stage * STAGE;
+            glds16_(pa + aoff[0], st + (lo_plane ? BM * BBK : 0) + (wave % PA) * 16 * BBK);
+            _Float16* wb = st + 2 * BM * BBK + wave * 16 * BBK;
+#pragma unroll
+            for (int q = 0; q < JW; ++q) glds16_(W.hi + wpan + woff[q], wb + q * NWAVE * 16 * BBK);
+#pragma unroll
+            for (int q = 0; q < JW; ++q) glds16_(W.lo + wpan + woff[q], wb + BN * BBK + q * NWAVE * 16 * BBK);
+            return;
+        }
 #if GEMM_ABL & 2
         if (kt > 2) return;
 #endif

@@ -942,7 +942,7 @@ __global__ __launch_bounds__(256) void lg_split_rows_kernel(const float* __restr
 }
 constexpr int SPLIT_BLOCKS_PER_IMAGE = 64;
 
-enum { EPH_QKV = 0, EPH_CROSS = 1, EPH_SPLIT = 2, EPH_F32 = 3, EPH_RESID = 4 };
+enum { EPH_QKV = 0, EPH_CROSS = 1, EPH_SPLIT = 2, EPH_F32 = 3, EPH_RESID = 4, EPH_LNGELU = 5 };
 
 struct LinearArgsH {
     SplitPtr A0, A1; int lda; int K0; int K;
@@ -952,6 +952,7 @@ struct LinearArgsH {
     SplitOut q, k, vt;                 // QKV / CROSS destinations
     float q_scale, k_scale;
     const float* enc_cos; const float* enc_sin;
+    const float* ln_w; const float* ln_b;  // LNGELU: LayerNorm(512) affine of the fused FFN epilogue
     const LGCtrl* ctrl; int Kc; int NIc;   // NIc: image capacity of the instance (plane rows = NIc * Kc)
 };
 
@@ -964,6 +965,22 @@ constexpr int ring_depth() {
     constexpr int stage_bytes = sslam::ring_stage_halves<BM, BN>() * 2;
     constexpr int d = (160 * 1024) / stage_bytes;
     return d > RING_MAX ? RING_MAX : (d < 2 ? 2 : d);
+}
+
+// erf for the GELU of the split-precision path: Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 absolute
+// (+ fp32 rounding), branch-free: one v_rcp, one v_exp, five fma.  The libm erff the exact-fp32 path
+// keeps is two divergent polynomial branches (~27 exec-mask switches per 8 elements in the ISA) and
+// made this kernel VALU-bound; GELU(y) = y/2 (1 + erf(y / sqrt 2)) carries the absolute error times
+// |y| / 2, i.e. below the fp32 rounding of the O(1) values it is added to downstream.
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
+    return copysignf(fmaf(-p * t, e, 1.0f), x);
 }
 
 // ---- shared epilogue of the split-precision linears (ring kernel: 4 consumer waves as 2 x 2; big-tile
@@ -1031,6 +1048,49 @@ __device__ __forceinline__ void linear_h_epilogue(const LinearArgsH& p, const Ro
             }
         }
     __syncthreads();
+
+    if constexpr (EPI == EPH_LNGELU) {
+        // The tile holds WHOLE rows of the FFN hidden (BN = 512): LayerNorm + GELU + split right here,
+        // one wave per row, the arithmetic of lg_ln_gelu_h_kernel in its order (bit-identical planes);
+        // the fp32 hidden never goes to HBM (67 MB written + 67 MB read back per 8-pair launch before).
+        static_assert(EPI != EPH_LNGELU || BN == 512, "LayerNorm needs the whole 512-wide row in one tile");
+        const int nw = NT / 64;
+        const float4 ga = *reinterpret_cast<const float4*>(p.ln_w + lane * 4), gb = *reinterpret_cast<const float4*>(p.ln_w + 256 + lane * 4);
+        const float4 ba = *reinterpret_cast<const float4*>(p.ln_b + lane * 4), bb = *reinterpret_cast<const float4*>(p.ln_b + 256 + lane * 4);
+        const float gm[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+        const float bt[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
+        for (int rl = wave; rl < BM; rl += nw) {
+            const int row = rd.row0 + rl;
+            if (row >= rd.n) break;                    // wave-uniform
+            const float4 a = *reinterpret_cast<const float4*>(&epi[rl * ELD + lane * 4]);
+            const float4 b = *reinterpret_cast<const float4*>(&epi[rl * ELD + 256 + lane * 4]);
+            float sum = (a.x + a.y) + (a.z + a.w) + (b.x + b.y) + (b.z + b.w);
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            const float mean = sum / 512.0f;
+            float v[8] = {a.x - mean, a.y - mean, a.z - mean, a.w - mean, b.x - mean, b.y - mean, b.z - mean, b.w - mean};
+            float q = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q += v[i] * v[i];
+            for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+            const float rstd = 1.0f / sqrtf(q / 512.0f + 1e-5f);
+            half4 h0, l0, h1, l1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float y = v[i] * rstd * gm[i] + bt[i];
+                const float gl = 0.5f * y * (1.0f + erf_as(y * 0.70710678118654752440f));
+                _Float16 hh, ll;
+                split_f32(gl, hh, ll);
+                if (i < 4) { h0[i] = hh; l0[i] = ll; } else { h1[i - 4] = hh; l1[i - 4] = ll; }
+            }
+            const int prow = (int)ibase + row;
+            const size_t p0 = panel_index(prow, lane * 4, p.NIc * p.Kc), p1 = panel_index(prow, 256 + lane * 4, p.NIc * p.Kc);
+            *reinterpret_cast<half4*>(p.outs.hi + p0) = h0;
+            *reinterpret_cast<half4*>(p.outs.lo + p0) = l0;
+            *reinterpret_cast<half4*>(p.outs.hi + p1) = h1;
+            *reinterpret_cast<half4*>(p.outs.lo + p1) = l1;
+        }
+        return;
+    }
 
 #ifndef LG_EPI_FAST_SPLIT
 #define LG_EPI_FAST_SPLIT 1    // A/B switch (scripts/ab_lib.sh): 0 = the branchy scalar split_f32 per value
@@ -1171,6 +1231,12 @@ __global__ __launch_bounds__(512) void lg_linear_h_kernel(LinearArgsH p) {
 // 8 waves: 128 x 256 tile, 3-stage ring, DMA spread between MFMAs, one workgroup per CU.
 // 4 waves: 128 x 128 tile, 2-stage ring, TWO workgroups per CU (one's epilogue runs under the other's
 // main loop).
+// main-loop form / ring depth by tile: 8 waves on a 128-row tile run the DMA-spread form on 3 stages,
+// 4 waves the lock-step form on 2; the 64 x 512 whole-row tile (fused LayerNorm) has a short A tile
+// (lock-step form) and 74 KB stages (2 of them)
+template <int BM, int WM, int WN> constexpr int big_variant() { return (WM * WN == 8 && BM >= 128) ? 3 : 0; }
+template <int BM, int WM, int WN> constexpr int big_stages() { return (WM * WN == 8 && BM >= 128) ? 3 : 2; }
+
 template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(WM * WN * 64, 2) void lg_linear_big_kernel(LinearArgsH p) {
     extern __shared__ __attribute__((aligned(16))) _Float16 lg_ring[];
@@ -1187,25 +1253,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void lg_linear_big_kernel(LinearAr
     GemmAH ga{{p.A0.hi, p.A0.lo}, {p.A1.hi ? p.A1.hi : p.A0.hi, p.A1.lo ? p.A1.lo : p.A0.lo}, p.lda, p.K0};
     f32x16 c1[TM][TN], c2[TM][TN];
     constexpr int NW = WM * WN;
-    sslam::gemm_mainloop_big<BM, BN, WM, WN, NW == 8 ? 3 : 0, NW == 8 ? 3 : 2>(
+    sslam::gemm_mainloop_big<BM, BN, WM, WN, big_variant<BM, WM, WN>(), big_stages<BM, WM, WN>()>(
         ga, p.W, p.NIc * p.Kc, p.K, (int)ibase + rd.row0, (int)ibase + p.Kc, col0, p.N, lg_ring, c1, c2);
     linear_h_epilogue<BM, BN, TM, TN, WN, NW * 64, EPI>(p, rd, col0, ibase, c1, c2, lg_ring);
-}
-
-// erf for the GELU of the split-precision path: Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 absolute
-// (+ fp32 rounding), branch-free: one v_rcp, one v_exp, five fma.  The libm erff the exact-fp32 path
-// keeps is two divergent polynomial branches (~27 exec-mask switches per 8 elements in the ISA) and
-// made this kernel VALU-bound; GELU(y) = y/2 (1 + erf(y / sqrt 2)) carries the absolute error times
-// |y| / 2, i.e. below the fp32 rounding of the O(1) values it is added to downstream.
-__device__ __forceinline__ float erf_as(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-    float p = fmaf(t, 1.061405429f, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
-    return copysignf(fmaf(-p * t, e, 1.0f), x);
 }
 
 // LayerNorm(512) + GELU: fp32 hidden in, split planes out (one wave / row)
@@ -2138,7 +2188,7 @@ SplitPtr wsp(const sslam_lightglue* g, const float* w) {
 template <int BM, int BN, int WM, int WN, int EPI>
 void launch_linear_big(hipStream_t s, int NI, const LinearArgsH& a) {
     constexpr int NW = WM * WN;
-    constexpr size_t stage = (size_t)(NW == 8 ? 3 : 2) * sslam::big_stage_halves<BM, BN>() * sizeof(_Float16);
+    constexpr size_t stage = (size_t)big_stages<BM, WM, WN>() * sslam::big_stage_halves<BM, BN>() * sizeof(_Float16);
     constexpr size_t epi = (size_t)BM * (BN + 4) * sizeof(float);
     constexpr size_t lds = stage > epi ? stage : epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
@@ -2205,19 +2255,26 @@ void lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, bo
     // forms the 128 x 128 / 4-wave one (two workgroups per CU: one's epilogue under the other's main
     // loop) measures 2 % under the 128 x 256 / 8-wave one on the whole forward (9.14 vs 9.36 ms for
     // 8 pairs) although its main loop alone is no faster (scripts/ubench/gemm_big_bench.hip)
-    const int big = g->big_gemm >= 0 ? g->big_gemm : ((long)NI * g->Kc >= 16384 && g->Kc % 128 == 0 ? 2 : 0);
+    // (3 = the 128 x 128 form with the FFN's LayerNorm + GELU fused into a 64 x 512 whole-row GEMM)
+    const int big = g->big_gemm >= 0 ? g->big_gemm : ((long)NI * g->Kc >= 16384 && g->Kc % 128 == 0 ? 3 : 0);
     auto ffn = [&](const float* w1, const float* b1, const float* lnw, const float* lnb, const float* w2,
                    const float* b2) {
         LinearArgsH a = linh(g, xs, msgs, D, D, 2 * D, w1, b1, 2 * D);      // [x | attention context]
         a.out = g->hid; a.ldo = 2 * D;
+        if (big == 3) {
+            // whole 512-wide rows per workgroup: LayerNorm + GELU + split in the GEMM's epilogue
+            a.outs = SplitOut{g->hids_hi, g->hids_lo}; a.ln_w = lnw; a.ln_b = lnb;
+            launch_linear_big<64, 512, 1, 8, EPH_LNGELU>(s, NI, a);
+        } else {
         if (big == 2) launch_linear_big<128, 128, 2, 2, EPH_F32>(s, NI, a);
         else if (big) launch_linear_big<128, 256, 2, 4, EPH_F32>(s, NI, a);
         else launch_linear_h<64, 128, 1, 2, EPH_F32>(s, NI, a);
         hipLaunchKernelGGL(lg_ln_gelu_h_kernel, dim3(tokblocks), dim3(256), 0, s, g->hid,
                            SplitOut{g->hids_hi, g->hids_lo}, lnw, lnb, g->ctrl, g->Kc, NI, g->NIc);
+        }
         LinearArgsH c = linh(g, hids, none, 2 * D, 2 * D, 2 * D, w2, b2, D);
         c.out = g->x; c.ldo = D; c.outs = SplitOut{g->xs_hi, g->xs_lo};
-        if (big == 2) launch_linear_big<128, 128, 2, 2, EPH_RESID>(s, NI, c);
+        if (big >= 2) launch_linear_big<128, 128, 2, 2, EPH_RESID>(s, NI, c);
         else if (big) launch_linear_big<128, 256, 2, 4, EPH_RESID>(s, NI, c);
         else launch_linear_h<64, 64, 1, 1, EPH_RESID>(s, NI, c);
     };
@@ -2225,7 +2282,7 @@ void lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, bo
         LinearArgsH a = linh(g, xs, none, D, D, D, l.wqkv, l.bqkv, 3 * D);
         a.q = SplitOut{g->qs_hi, g->qs_lo}; a.k = SplitOut{g->ks_hi, g->ks_lo}; a.vt = SplitOut{g->vts_hi, g->vts_lo};
         a.q_scale = sm_scale; a.k_scale = 1.0f;
-        if (big == 2) launch_linear_big<128, 128, 2, 2, EPH_QKV>(s, NI, a);
+        if (big >= 2) launch_linear_big<128, 128, 2, 2, EPH_QKV>(s, NI, a);
         else if (big) launch_linear_big<128, 256, 2, 4, EPH_QKV>(s, NI, a);
         else launch_linear_h<64, 192, 1, 3, EPH_QKV>(s, NI, a);  // 768 / 192 = 4 column tiles
     }
@@ -2236,7 +2293,7 @@ void lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, bo
         LinearArgsH a = linh(g, xs, none, D, D, D, l.cqkv, l.cbqkv, 2 * D);
         a.q = SplitOut{g->qs_hi, g->qs_lo}; a.vt = SplitOut{g->vts_hi, g->vts_lo};
         a.q_scale = sqrtf(sm_scale);
-        if (big == 2) launch_linear_big<128, 128, 2, 2, EPH_CROSS>(s, NI, a);
+        if (big >= 2) launch_linear_big<128, 128, 2, 2, EPH_CROSS>(s, NI, a);
         else if (big) launch_linear_big<128, 256, 2, 4, EPH_CROSS>(s, NI, a);
         else launch_linear_h<64, 128, 1, 2, EPH_CROSS>(s, NI, a);
     }
@@ -2360,6 +2417,7 @@ void lg_configure_kernels() {
     launch_linear_h<64, 128, 1, 2, EPH_CROSS>(s, 0, cfg); launch_linear_big<128, 256, 2, 4, EPH_CROSS>(s, 0, cfg);
     launch_linear_big<128, 128, 2, 2, EPH_F32>(s, 0, cfg); launch_linear_big<128, 128, 2, 2, EPH_RESID>(s, 0, cfg);
     launch_linear_big<128, 128, 2, 2, EPH_QKV>(s, 0, cfg); launch_linear_big<128, 128, 2, 2, EPH_CROSS>(s, 0, cfg);
+    launch_linear_big<64, 512, 1, 8, EPH_LNGELU>(s, 0, cfg);
 }
 
 // lg_enqueue through the graph cache (device entry points only; never while profiling: the
@@ -2653,7 +2711,7 @@ int sslam_lightglue_debug_key_split(sslam_lightglue* g, int ks) {
 /* Test hook: -1 = linears chosen by batch size, 0 = always the 64-row ring kernel, 1 = always the
  * 128 x 256 big-tile kernel. */
 int sslam_lightglue_debug_big_gemm(sslam_lightglue* g, int mode) {
-    SSLAM_REQUIRE(g != nullptr && mode >= -1 && mode <= 2, "sslam_lightglue_debug_big_gemm: bad argument");
+    SSLAM_REQUIRE(g != nullptr && mode >= -1 && mode <= 3, "sslam_lightglue_debug_big_gemm: bad argument");
     g->settings_changed();
     g->big_gemm = mode;
     return 0;

@@ -124,7 +124,8 @@ class LightGlueHIP:
         _native.check(_native.lib().sslam_lightglue_debug_key_split(self.handle, int(ks)))
 
     def debug_big_gemm(self, mode: int):
-        """Test hook: -1 linears by batch size, 0 always the ring kernel, 1 always the big-tile kernel."""
+        """Test hook: -1 linears by batch size, 0 always the ring kernel, 1 the 128 x 256 big-tile kernel,
+        2 the 128 x 128 one, 3 the 128 x 128 one with LayerNorm + GELU fused into the first FFN GEMM."""
         _native.check(_native.lib().sslam_lightglue_debug_big_gemm(self.handle, int(mode)))
 
     def debug_read(self, which: int, shape, dtype=np.float32):

@@ -100,8 +100,11 @@ def test_big_tile_linears_give_the_ring_kernel_results_bit_for_bit(gpu_ctx):
         big = dev.run(batch, 0.0)
         batch.debug_big_gemm(2)                       # 128 x 128 tiles, 4 waves, two workgroups per CU
         big2 = dev.run(batch, 0.0)
-        for a, b in zip(big, big2):
+        batch.debug_big_gemm(3)                       # + LayerNorm / GELU inside the first FFN GEMM (64 x 512 whole-row tiles)
+        big3 = dev.run(batch, 0.0)
+        for a, b, c in zip(big, big2, big3):
             np.testing.assert_array_equal(a[0], b[0]); np.testing.assert_array_equal(a[1], b[1])
+            np.testing.assert_array_equal(a[0], c[0]); np.testing.assert_array_equal(a[1], c[1])
         for (a_ij, a_sc, a_info), (b_ij, b_sc, b_info), pr in zip(ring, big, pairs):
             np.testing.assert_array_equal(a_ij, b_ij)
             np.testing.assert_array_equal(a_sc, b_sc)
