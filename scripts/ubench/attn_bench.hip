@@ -37,7 +37,8 @@ int main(int argc, char** argv) {
     AttnArgsH a{{buf[0], buf[1]}, {buf[2], buf[3]}, {buf[4], buf[5]}, 0, o_part, m_part, l_part, SplitOut{buf[6], buf[7]}, KS, Kc, NI, ctrl};
     dim3 grid(sslam::cdiv(Kc, AQ), NI * NH, KS);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const bool pp = getenv("ATTN_PP") && atoi(getenv("ATTN_PP")) && KS == 1;     // 8-wave ping-pong form
+    const int ppm = getenv("ATTN_PP") ? atoi(getenv("ATTN_PP")) : 0;
+    const bool pp = ppm == 1 && KS == 1;     // 8-wave ping-pong form
     auto launch = [&] {
         if (pp) hipLaunchKernelGGL(lg_attention_pp_kernel, dim3(sslam::cdiv(Kc, AQ2), NI * NH), dim3(512), 0, 0, a);
         else hipLaunchKernelGGL(lg_attention_p_kernel, grid, dim3(256), 0, 0, a);
