@@ -286,7 +286,19 @@ def ba_and_reproject_records(ctx, with_cpu):
     for _ in range(5):
         t0 = time.perf_counter(); m = pnp.reproject_and_match_2d3d(*args); ts.append(time.perf_counter() - t0)
     rp = {"scene": "5000 map points x 2048 keypoints (C2 size)", "wall_ms": round(float(np.median(ts)) * 1e3, 3),
-          "matches": int(len(m.kp_indices))}
+          "matches": int(len(m.kp_indices)),
+          "what": "reproject_and_match_2d3d, host arrays in and out; wall_ms with the reference's dict-of-objects Map "
+                  "(a Python walk rebuilds the arrays per call), soa_map_wall_ms with the overlay's array-backed Map "
+                  "(slam/core/landmark_utils.py, device mirror, sslam_reproject_match_dev)"}
+    lm = importlib.import_module("opencv-simpleslam_amd.slam.core.landmark_utils")
+    soa = lm.Map.from_reference(sc["wmap"])
+    sargs = (soa,) + args[1:]
+    m2 = pnp.reproject_and_match_2d3d(*sargs)
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter(); m2 = pnp.reproject_and_match_2d3d(*sargs); ts.append(time.perf_counter() - t0)
+    rp["soa_map_wall_ms"] = round(float(np.median(ts)) * 1e3, 3)
+    rp["soa_map_matches"] = int(len(m2.kp_indices))
     return ba, rp
 
 

@@ -186,3 +186,38 @@ def test_outliers_are_down_weighted_like_the_oracle():
     np.testing.assert_allclose(sd.final_cost, info["final_cost"], rtol=1e-8)
     assert sd.successful_steps == info["successful_steps"]
     np.testing.assert_allclose(dev.t, t, rtol=1e-6, atol=1e-7)
+
+
+def test_ill_conditioned_windows_terminate_finite_and_never_increase_the_cost():
+    """Where Ceres would fall back inside its linear solver, this LM rejects a step whose reduced
+    system fails the Cholesky factorisation and shrinks the trust region.  What a
+    caller must be able to rely on either way: the solve terminates, parameters stay finite, the cost
+    never goes up.  (a) no constant pose at all - the 7-dimensional gauge freedom makes the reduced
+    system singular up to the damping; (b) a free pose that no residual observes - a zero 6 x 6
+    diagonal block; (c) a landmark seen once - rank-deficient 3 x 3 point block."""
+    S = load_pkg("ba_solver")
+    base = _snapshot(n_frames=8, window=6)
+    # (a) gauge-free
+    a = _clone(base); a.pose_const = np.zeros(len(a.q), bool)
+    # (b) drop every observation of one free pose
+    b = _clone(base)
+    victim = int(np.flatnonzero(~b.pose_const)[0])
+    keep = b.obs_pose != victim
+    b.obs_pose, b.obs_point, b.obs_uv = b.obs_pose[keep].copy(), b.obs_point[keep].copy(), b.obs_uv[keep].copy()
+    # (c) a point with a single observation
+    c = _clone(base)
+    lone = int(c.obs_point[0])
+    first = np.flatnonzero(c.obs_point == lone)[1:]
+    keep = np.ones(len(c.obs_point), bool); keep[first] = False
+    c.obs_pose, c.obs_point, c.obs_uv = c.obs_pose[keep].copy(), c.obs_point[keep].copy(), c.obs_uv[keep].copy()
+    for name, prob in (("gauge-free", a), ("unobserved pose", b), ("single-view point", c)):
+        before = _clone(prob)
+        sd = S.solve_device(prob, 20, 2.0)
+        assert sd.iterations <= 20, name
+        assert np.isfinite(sd.final_cost) and sd.final_cost <= sd.initial_cost * (1 + 1e-12), (name, sd)
+        for arr in (prob.q, prob.t, prob.X):
+            assert np.isfinite(arr).all(), name
+        np.testing.assert_allclose(np.linalg.norm(prob.q, axis=1), 1.0, atol=1e-9, err_msg=name)
+        if name == "unobserved pose":                      # nothing pulls on it: it must not move
+            np.testing.assert_allclose(prob.q[victim], before.q[victim], atol=1e-12)
+            np.testing.assert_allclose(prob.t[victim], before.t[victim], atol=1e-12)
