@@ -59,7 +59,7 @@ ALIKED_GFLOP_PER_FRAME = 8.9           # 6.56 dense conv + 2.34 SDD
 
 def _pmc_traffic():
     """Per-launch HBM-side bytes of the attention kernel at the bench size, from profiles/ (None when absent)."""
-    for name in ("r02_attention_traffic.json", "r01_attention_traffic.json"):
+    for name in ("r02final_attention_traffic.json", "r02_attention_traffic.json", "r01_attention_traffic.json"):
         try:
             d = json.loads((ROOT / "profiles" / name).read_text())
             return int(d["fetch_bytes_per_launch"]) + int(d["write_bytes_per_launch"]), name
@@ -487,6 +487,9 @@ def main():
                                    "LightGlue match (t-1,t), 2048 kpts/frame, min_conf 0.7, random-init weights",
                        "frames_per_step_per_gpu": FRAMES_PER_RANK, "max_kpts": MAX_KPTS,
                        "lightglue_layers_executed": stop, "kpts_matched": [n0, n1],
+                       # depth is data dependent (early stop) - layers executed over the pairs of the last round
+                       "lightglue_layers_histogram": {str(int(k)): int(v) for k, v in
+                                                      zip(*np.unique(info[info[:, 2] > 0, 1], return_counts=True))},
                        "pairs_per_lightglue_launch": BATCH_PAIRS,
                        "parallelism": f"frame-shard x{world}; per GPU {N_EXT} extractor + {N_MAT} matcher streams, "
                                       f"LightGlue in batches of {BATCH_PAIRS} pairs"},
@@ -515,6 +518,8 @@ def main():
             "value": round(s_steps * plan.frames_per_round() / s_dt_max, 2), "unit": "frames/s", "steps": s_steps,
             "what": "same pipeline on the 9x9-box low-pass noise translating 3 px/frame (SURVEY 8(d))",
             "matches_last_pair": int(s_info[-1, 0]), "lightglue_layers_executed": int(s_info[-1, 1]),
+            "lightglue_layers_histogram": {str(int(k)): int(v) for k, v in
+                                           zip(*np.unique(s_info[s_info[:, 2] > 0, 1], return_counts=True))},
             "kpts_matched": [int(s_info[-1, 2]), int(s_info[-1, 3])]}
         if x_dt is not None:
             x_steps = max(2, args.steps // 4)
