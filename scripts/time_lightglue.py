@@ -13,6 +13,13 @@ LG = importlib.import_module("opencv-simpleslam_amd.lightglue").LightGlueHIP
 nat = pkg._native
 ctx = nat.default_context()
 lg = LG(W.random_lightglue_state_dict(2, match_gain=4.0, match_bias=3.0), max_kpts=N)
+import os
+if os.environ.get("SSLAM_BIG_GEMM"):
+    lg.debug_big_gemm(int(os.environ["SSLAM_BIG_GEMM"]))
+if os.environ.get("SSLAM_KEY_SPLIT"):
+    lg.debug_key_split(int(os.environ["SSLAM_KEY_SPLIT"]))
+if os.environ.get("SSLAM_GRAPHS"):
+    lg.use_graphs(True)
 k0, d0, k1, d1 = lg_inputs.make_pair(N, seed=11)
 dk0, dd0, dk1, dd1 = (ctx.upload(a) for a in (k0, d0, k1, d1))
 ij = ctx.malloc(N * 8); sc = ctx.malloc(N * 4); info = ctx.malloc(32)
