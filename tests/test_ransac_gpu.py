@@ -146,3 +146,22 @@ def test_device_resident_filter_conventions(E, gpu_ctx):
     z = np.zeros((40, 2), np.float32)                                       # no admissible subset: cv2 returns mask None
     kept, info, _, F = _dev_filter(E, gpu_ctx, z, z, ij, 20)
     assert info[0] == 0 and info[3] == -1 and len(kept) == 0 and not F.any()
+
+
+def test_device_resident_filter_optional_outputs_and_fixed_count(E, gpu_ctx, native):
+    """n_dev = NULL means exactly n_max matches; mask / F / pair outputs are optional; bad arguments fail loudly."""
+    p1, p2, _ = two_view.make_matches(200, outlier_frac=0.3, noise=0.3, seed=8)
+    ij = np.stack([np.arange(200), np.arange(200)], 1).astype(np.int32)
+    ctx = gpu_ctx
+    d = [ctx.upload(np.ascontiguousarray(a)) for a in (p1.astype(np.float32), p2.astype(np.float32), ij)]
+    info = ctx.malloc(16)
+    E.filter_matches_dev(ctx, 200, None, d[0], d[1], d[2], None, info)          # count only
+    h = np.empty(4, np.int32); ctx.d2h(h, info)
+    _, mask_h, info_h = E.find_fundamental_ransac(p1, p2, 1.0, 0.99, ctx=ctx)
+    assert h[0] == mask_h.sum() and h[1] == info_h["iterations"] and h[3] == info_h["sample"]
+    with pytest.raises(native.NativeError, match="NULL"):
+        E.filter_matches_dev(ctx, 200, None, d[0], d[1], None, None, info)
+    with pytest.raises(native.NativeError, match="n_max"):
+        E.filter_matches_dev(ctx, 0, None, d[0], d[1], d[2], None, info)
+    for p_ in d + [info]:
+        ctx.free(p_)
