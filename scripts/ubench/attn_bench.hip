@@ -4,6 +4,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I opencv-simpleslam_amd/csrc [-DATTN_ABL=..] [-DATTN_SCHED=..] \
 //         scripts/ubench/attn_bench.hip -o /tmp/attn_bench && /tmp/attn_bench [N=2048] [pairs=8] [KS=1] [rounds=5]
 #include "../../opencv-simpleslam_amd/csrc/lightglue_kernels.hip"
+#include "attn_w1_experiment.hpp"
 #include <cstdio>
 #include <vector>
 #include <algorithm>
@@ -39,8 +40,41 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int ppm = getenv("ATTN_PP") ? atoi(getenv("ATTN_PP")) : 0;
     const bool pp = ppm == 1 && KS == 1;     // 8-wave ping-pong form
+    const bool w1 = ppm == 2 && KS == 1;     // one wave per SIMD, hand-placed gaps
+    if (getenv("ATTN_CMP") && KS == 1) {
+        // compare the hi / lo context planes of the variant against the 4-wave kernel on the same operands
+        std::vector<_Float16> ref_hi(plane), ref_lo(plane), got_hi(plane), got_lo(plane);
+        hipMemset(buf[6], 0, plane * 2); hipMemset(buf[7], 0, plane * 2);
+        hipLaunchKernelGGL(lg_attention_p_kernel, grid, dim3(256), 0, 0, a);
+        hipDeviceSynchronize();
+        hipMemcpy(ref_hi.data(), buf[6], plane * 2, hipMemcpyDeviceToHost); hipMemcpy(ref_lo.data(), buf[7], plane * 2, hipMemcpyDeviceToHost);
+        hipMemset(buf[6], 0, plane * 2); hipMemset(buf[7], 0, plane * 2);
+        if (w1) hipLaunchKernelGGL(lg_attention_w1_kernel, dim3(sslam::cdiv(Kc, AQ2), NI * NH), dim3(256), 0, 0, a);
+        else hipLaunchKernelGGL(lg_attention_pp_kernel, dim3(sslam::cdiv(Kc, AQ2), NI * NH), dim3(512), 0, 0, a);
+        hipDeviceSynchronize();
+        printf("variant launch: %s\n", hipGetErrorString(hipGetLastError()));
+        hipMemcpy(got_hi.data(), buf[6], plane * 2, hipMemcpyDeviceToHost); hipMemcpy(got_lo.data(), buf[7], plane * 2, hipMemcpyDeviceToHost);
+        // panel layout: plane[k / 64][row][k % 64] over NI * Kc rows, k = head * 64 + d
+        size_t bad = 0; double worst = 0; int shown = 0;
+        const size_t rows = (size_t)NI * Kc;
+        for (size_t pnl = 0; pnl < 4; ++pnl)
+            for (size_t row = 0; row < rows; ++row)
+                for (int d = 0; d < 64; ++d) {
+                    const size_t o = (pnl * rows + row) * 64 + d;
+                    const double r = (double)ref_hi[o] + (double)ref_lo[o] / 2048.0, g = (double)got_hi[o] + (double)got_lo[o] / 2048.0;
+                    const double e = fabs(r - g);
+                    if (!(e <= 1e-6 + 1e-5 * fabs(r))) {
+                        ++bad;
+                        if (shown < 24) { printf("  head %zu img %zu row %zu d %d: ref %.7g got %.7g\n", pnl, row / Kc, row % Kc, d, r, g); ++shown; }
+                    }
+                    if (e == e) worst = fmax(worst, e);
+                }
+        printf("compare: %zu of %zu values differ, worst |diff| %.3g\n", bad, plane, worst);
+        return 0;
+    }
     auto launch = [&] {
-        if (pp) hipLaunchKernelGGL(lg_attention_pp_kernel, dim3(sslam::cdiv(Kc, AQ2), NI * NH), dim3(512), 0, 0, a);
+        if (w1) hipLaunchKernelGGL(lg_attention_w1_kernel, dim3(sslam::cdiv(Kc, AQ2), NI * NH), dim3(256), 0, 0, a);
+        else if (pp) hipLaunchKernelGGL(lg_attention_pp_kernel, dim3(sslam::cdiv(Kc, AQ2), NI * NH), dim3(512), 0, 0, a);
         else hipLaunchKernelGGL(lg_attention_p_kernel, grid, dim3(256), 0, 0, a);
     };
     for (int i = 0; i < 5; ++i) launch();
@@ -57,7 +91,7 @@ int main(int argc, char** argv) {
     std::sort(t.begin(), t.end());
     const double fl = 8.0 * N * (double)N * 256 * B;
     printf("%s N=%d pairs=%d KS=%d abl=%d sched=%d: median %.1f us/launch (min %.1f) = %.2f us per pair, %.0f TF alg, executed %.1f%% of the f16 peak; err=%s\n",
-           pp ? "[pp]" : "[p4]", N, B, KS, ATTN_ABL,
+           w1 ? "[w1]" : pp ? "[pp]" : "[p4]", N, B, KS, ATTN_ABL,
 #ifdef ATTN_SCHED
            ATTN_SCHED,
 #else

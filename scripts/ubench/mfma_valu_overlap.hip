@@ -1,0 +1,56 @@
+// Does VALU work issue under a running MFMA, and does it depend on which register file the MFMA's
+// operands live in?  One wave per SIMD (512-register budget), a loop of { 1 MFMA ; F independent v_fma },
+// four independent accumulators in rotation.  Variants: C/D in arch VGPRs vs AGPRs, A/B in VGPRs vs AGPRs.
+//   hipcc --offload-arch=gfx950 -O3 scripts/ubench/mfma_valu_overlap.hip -o /tmp/mvo && /tmp/mvo
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+template <int CD_AGPR, int AB_AGPR, int F>
+__global__ __launch_bounds__(256, 1) void k(float* out, int iters, long long* cyc) {
+    f32x16 c0, c1, c2, c3;
+    for (int r = 0; r < 16; ++r) { c0[r] = r; c1[r] = r + 1; c2[r] = r + 2; c3[r] = r + 3; }
+    half8 a, b;
+    for (int e = 0; e < 8; ++e) { a[e] = (_Float16)(threadIdx.x * 0.001f + e); b[e] = (_Float16)(e * 0.5f); }
+    float v[8];
+    for (int i = 0; i < 8; ++i) v[i] = threadIdx.x + i;
+    const float m = 1.0001f, ad = 0.5f;
+    const long long t0 = __builtin_amdgcn_s_memtime();
+#define MF(c_) do { \
+        if (CD_AGPR && AB_AGPR) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c_) : "a"(a), "a"(b)); \
+        else if (CD_AGPR) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c_) : "v"(a), "v"(b)); \
+        else if (AB_AGPR) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c_) : "a"(a), "a"(b)); \
+        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c_) : "v"(a), "v"(b)); } while (0)
+#define FILL() do { _Pragma("unroll") for (int f = 0; f < F; ++f) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[f & 7]) : "v"(m), "v"(ad)); } while (0)
+    for (int it = 0; it < iters; ++it) {
+        MF(c0); FILL(); MF(c1); FILL(); MF(c2); FILL(); MF(c3); FILL();
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0;
+    for (int r = 0; r < 16; ++r) s += c0[r] + c1[r] + c2[r] + c3[r];
+    for (int i = 0; i < 8; ++i) s += v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+
+template <int CD, int AB, int F>
+void run(float* out, long long* cyc) {
+    const int iters = 2000;
+    hipLaunchKernelGGL((k<CD, AB, F>), dim3(256), dim3(256), 0, 0, out, iters, cyc);
+    hipLaunchKernelGGL((k<CD, AB, F>), dim3(256), dim3(256), 0, 0, out, iters, cyc);
+    hipDeviceSynchronize();
+    long long h; hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+    printf("C/D in %s, A/B in %s, %d fillers per MFMA: %.1f cycles per MFMA (s_memtime ticks)\n", CD ? "AGPR" : "VGPR", AB ? "AGPR" : "VGPR", F,
+           (double)h / (iters * 4.0));
+}
+
+int main() {
+    float* out; long long* cyc;
+    hipMalloc(&out, 256 * 256 * 4); hipMalloc(&cyc, 8);
+    run<0, 0, 0>(out, cyc); run<0, 0, 3>(out, cyc); run<0, 0, 5>(out, cyc); run<0, 0, 8>(out, cyc);
+    run<1, 0, 0>(out, cyc); run<1, 0, 3>(out, cyc); run<1, 0, 5>(out, cyc); run<1, 0, 8>(out, cyc);
+    run<1, 1, 0>(out, cyc); run<1, 1, 3>(out, cyc); run<1, 1, 5>(out, cyc); run<1, 1, 8>(out, cyc);
+    run<0, 1, 5>(out, cyc);
+    return 0;
+}
