@@ -532,7 +532,12 @@ __global__ __launch_bounds__(256) void lg_token_heads_kernel(
     }
     bool unconf = false;
     if (live) {
-        mat[img * Kc + row] = (sm0 + sm1) + bm[0];
+        const float zm = (sm0 + sm1) + bm[0];
+        mat[img * Kc + row] = zm;
+        // final call (assignment): log sigmoid of the matchability once per token, here - the two arg-max
+        // passes evaluated it per (row, column) ELEMENT (log1p + exp on 4 M elements per pair: they ran at
+        // 1.1 TB/s of `sim` instead of HBM speed)
+        if (use_stop_layer) conf[img * Kc + row] = logsigmoidf_(zm);
         if (wc) {
             const float c = sigmoidf_((sc0 + sc1) + bc[0]);
             conf[img * Kc + row] = c;
@@ -777,10 +782,10 @@ __global__ __launch_bounds__(256) void lg_row_argmax_kernel(
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n0 = ctrl->n[0], n1 = ctrl->n[1];
     if (row >= n0) return;
-    const float rm = rmax[row], rl = rlog[row], a = logsigmoidf_(z[row]);
+    const float rm = rmax[row], rl = rlog[row], a = z[row];          // z: log sigmoid(matchability), per token
     float bv = -INFINITY; int bj = 0x7fffffff;
     for (int j = lane; j < n1; j += 64) {
-        const float v = score_ij(sim[(size_t)row * Kc + j], rm, rl, cmax[j], clog[j], a, logsigmoidf_(z[Kc + j]));
+        const float v = score_ij(sim[(size_t)row * Kc + j], rm, rl, cmax[j], clog[j], a, z[Kc + j]);
         if (v > bv) { bv = v; bj = j; }          // ascending j per lane: first maximum kept
     }
     for (int o = 32; o > 0; o >>= 1) {
@@ -809,9 +814,9 @@ __global__ __launch_bounds__(256) void lg_col_argmax_kernel(
     const int r0 = blockIdx.y * rows_per, r1 = min(n0, r0 + rows_per);
     float bv = -INFINITY; int bi = 0x7fffffff;
     if (col < n1) {
-        const float cm = cmax[col], cl = clog[col], b = logsigmoidf_(z[Kc + col]);
+        const float cm = cmax[col], cl = clog[col], b = z[Kc + col];
         for (int i = r0 + part; i < r1; i += 4) {
-            const float v = score_ij(sim[(size_t)i * Kc + col], rmax[i], rlog[i], cm, cl, logsigmoidf_(z[i]), b);
+            const float v = score_ij(sim[(size_t)i * Kc + col], rmax[i], rlog[i], cm, cl, z[i], b);
             if (v > bv) { bv = v; bi = i; }
         }
     }
@@ -2394,9 +2399,9 @@ int lg_enqueue(sslam_lightglue* g, int pairs, const StageSrc& src, float min_con
     hipLaunchKernelGGL(lg_col_stats_merge_kernel, dim3(sslam::cdiv(Kc, 256), pairs), dim3(256), 0, s, g->cpmax,
                        g->cpsum, g->cmax, g->clog, Kc, g->ctrl);
     hipLaunchKernelGGL(lg_row_argmax_kernel, dim3(sslam::cdiv(Kc, 4), pairs), dim3(256), 0, s, g->sim, g->rmax,
-                       g->rlog, g->cmax, g->clog, g->mat, g->best0, g->arg0, Kc, g->ctrl);
+                       g->rlog, g->cmax, g->clog, g->conf, g->best0, g->arg0, Kc, g->ctrl);
     hipLaunchKernelGGL(lg_col_argmax_kernel, dim3(sslam::cdiv(Kc, 64), CSLAB, pairs), dim3(256), 0, s, g->sim,
-                       g->rmax, g->rlog, g->cmax, g->clog, g->mat, g->cpval, g->cparg, Kc, g->ctrl);
+                       g->rmax, g->rlog, g->cmax, g->clog, g->conf, g->cpval, g->cparg, Kc, g->ctrl);
     hipLaunchKernelGGL(lg_emit_kernel, dim3(pairs), dim3(1024), 0, s, g->best0, g->arg0, g->cpval, g->cparg, g->ind,
                        g->filter_thr, min_conf, ij_out, score_out, info_out, g->ctrl, Kc, out_stride);
     SSLAM_HIP_CHECK(hipGetLastError());
