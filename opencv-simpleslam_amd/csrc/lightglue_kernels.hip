@@ -688,6 +688,8 @@ __global__ __launch_bounds__(256) void lg_sim_kernel(SimArgs p) {
         }
 }
 
+constexpr int STAT_CACHE = 32;    // values of `sim` a thread keeps between the max and the sum pass (rows / column slabs up to 2048)
+
 // row statistics: one wave per row i: max_j, log(sum_j exp(sim - max))
 __global__ __launch_bounds__(256) void lg_row_stats_kernel(const float* __restrict__ sim,
                                                            float* __restrict__ rmax, float* __restrict__ rlog,
@@ -699,11 +701,25 @@ __global__ __launch_bounds__(256) void lg_row_stats_kernel(const float* __restri
     const int n0 = ctrl->n[0], n1 = ctrl->n[1];
     if (row >= n0) return;
     const float* p = sim + (size_t)row * Kc;
-    float m = -INFINITY;
-    for (int j = lane; j < n1; j += 64) m = fmaxf(m, p[j]);
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    float s = 0.0f;
-    for (int j = lane; j < n1; j += 64) s += expf(p[j] - m);
+    float m = -INFINITY, s = 0.0f;
+    if (n1 <= 64 * STAT_CACHE) {
+        // the row fits the wave's registers (32 values per lane): ONE read of `sim`, same per-lane order
+        float v[STAT_CACHE];
+#pragma unroll
+        for (int k = 0; k < STAT_CACHE; ++k) {
+            const int j = lane + 64 * k;
+            v[k] = j < n1 ? p[j] : -INFINITY;
+            m = fmaxf(m, v[k]);
+        }
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+#pragma unroll
+        for (int k = 0; k < STAT_CACHE; ++k)
+            if (lane + 64 * k < n1) s += expf(v[k] - m);
+    } else {
+        for (int j = lane; j < n1; j += 64) m = fmaxf(m, p[j]);
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        for (int j = lane; j < n1; j += 64) s += expf(p[j] - m);
+    }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) { rmax[row] = m; rlog[row] = logf(s); }
 }
@@ -728,14 +744,33 @@ __global__ __launch_bounds__(256) void lg_col_stats_kernel(const float* __restri
     const int rows_per = (n0 + CSLAB - 1) / CSLAB;
     const int r0 = blockIdx.y * rows_per, r1 = min(n0, r0 + rows_per);
     const bool ok = col < n1;
+    const bool cached = rows_per <= 4 * STAT_CACHE;          // block-uniform: the slab's values stay in registers
+    float v[STAT_CACHE];
     float m = -INFINITY;
-    if (ok) for (int i = r0 + part; i < r1; i += 4) m = fmaxf(m, sim[(size_t)i * Kc + col]);
+    if (cached) {
+#pragma unroll
+        for (int k = 0; k < STAT_CACHE; ++k) {
+            const int i = r0 + part + 4 * k;
+            v[k] = (ok && i < r1) ? sim[(size_t)i * Kc + col] : -INFINITY;
+            m = fmaxf(m, v[k]);
+        }
+    } else if (ok) {
+        for (int i = r0 + part; i < r1; i += 4) m = fmaxf(m, sim[(size_t)i * Kc + col]);
+    }
     sh[part][lane] = m;
     __syncthreads();
     m = fmaxf(fmaxf(sh[0][lane], sh[1][lane]), fmaxf(sh[2][lane], sh[3][lane]));
     __syncthreads();
     float s = 0.0f;
-    if (ok && m > -INFINITY) for (int i = r0 + part; i < r1; i += 4) s += expf(sim[(size_t)i * Kc + col] - m);
+    if (ok && m > -INFINITY) {
+        if (cached) {
+#pragma unroll
+            for (int k = 0; k < STAT_CACHE; ++k)
+                if (r0 + part + 4 * k < r1) s += expf(v[k] - m);
+        } else {
+            for (int i = r0 + part; i < r1; i += 4) s += expf(sim[(size_t)i * Kc + col] - m);
+        }
+    }
     sh[part][lane] = s;
     __syncthreads();
     if (part == 0 && ok) {
