@@ -145,9 +145,14 @@ class Context:
               "sslam_ctx_create")
         self.handle = h
         self.device = int(device)
+        self.scratch = {}                 # named device buffers owned by this context (freed in close)
 
     def close(self):
         if getattr(self, "handle", None):
+            for buf in getattr(self, "scratch", {}).values():
+                for ptr_ in buf.get("_ptrs", ()):
+                    lib().sslam_free(self.handle, C.c_void_p(ptr_))
+            self.scratch = {}
             lib().sslam_ctx_destroy(self.handle)
             self.handle = None
 

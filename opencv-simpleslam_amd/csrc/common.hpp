@@ -68,6 +68,9 @@ struct Arena {
 // whole sequence is one hipGraph: the first call with a key captures the stream into a graph,
 // later calls replay it with one hipGraphLaunch (~10 us of host time instead of ~2.6 us per
 // launch for 45 - 190 launches).  Bounded LRU; cleared whenever an instance setting changes.
+// The key holds every pointer argument: a caller that passes FRESH buffers on every call never
+// hits (capture + instantiate per call, slower than plain launches) - graphs are for callers that
+// cycle through a fixed set of buffers, as the frame pipeline does.
 struct GraphCache {
     struct Entry { std::vector<uint64_t> key; hipGraph_t graph; hipGraphExec_t exec; uint64_t stamp; };
     std::vector<Entry> entries;
@@ -80,10 +83,13 @@ struct GraphCache {
         ++misses;
         return nullptr;
     }
-    void insert(const std::vector<uint64_t>& key, hipGraph_t g, hipGraphExec_t x) {
+    // `s`: the stream the cached graphs are launched on - an evicted exec may still be queued there,
+    // and HIP does not promise the lifetime of an in-flight exec, so the stream is drained first
+    void insert(const std::vector<uint64_t>& key, hipGraph_t g, hipGraphExec_t x, hipStream_t s) {
         if (entries.size() >= cap) {
             size_t old = 0;
             for (size_t i = 1; i < entries.size(); ++i) if (entries[i].stamp < entries[old].stamp) old = i;
+            (void)hipStreamSynchronize(s);
             (void)hipGraphExecDestroy(entries[old].exec); (void)hipGraphDestroy(entries[old].graph);
             entries.erase(entries.begin() + old);
         }
@@ -110,8 +116,12 @@ int run_cached(GraphCache& cache, hipStream_t s, const std::vector<uint64_t>& ke
     if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
     if (e != hipSuccess) { set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return 1; }
     hipGraphExec_t x = nullptr;
-    SSLAM_HIP_CHECK(hipGraphInstantiate(&x, g, nullptr, nullptr, 0));
-    cache.insert(key, g, x);
+    if (const hipError_t ei = hipGraphInstantiate(&x, g, nullptr, nullptr, 0); ei != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        set_error("hipGraphInstantiate: %s", hipGetErrorString(ei));
+        return 1;
+    }
+    cache.insert(key, g, x, s);
     SSLAM_HIP_CHECK(hipGraphLaunch(x, s));
     return 0;
 }

@@ -198,12 +198,25 @@ __device__ __forceinline__ void gemm_mainloop_h(const GemmAH& ga, SplitPtr W, in
 
 
 // ------------------------------------------------------------------------------------------
-// K-PANEL LAYOUT of every split plane that feeds the ring GEMM: plane[k / 64][row][k % 64].
-// A 64-wide k-tile of 64 rows is then ONE contiguous 8 KiB run (each DMA wave-instruction reads
-// 1 KiB contiguous), instead of 64 segments of 128 B at a row stride of 512-1024 B, which
-// concentrates the requests of all CUs on a quarter of the L2 channels.
+// K-PANEL LAYOUT of every split plane that feeds a GEMM: plane[k / PANEL_K][row][k % PANEL_K].
+// PANEL_K = 32 halves = the k depth of the batched GEMM's LDS tile (gemm_f16x3_big.hpp), so the
+// 16 rows x 64 B a DMA wave-instruction fetches are ONE contiguous 1 KiB run of whole 128-byte
+// lines.  (r01/r02 used 64-wide panels: a 32-deep k-tile then took HALF of every 128-byte line and
+// the other half one tile later - every line crossed L2 -> L1 twice, and the per-CU LDS-DMA intake,
+// which bounds these loops, carried 50 % useful bytes.)  The 64-deep ring GEMM of the single-pair
+// path reads two adjacent panels per k-tile (2 x 512 B runs per DMA instruction).
+#ifndef SSLAM_PANEL_K
+#define SSLAM_PANEL_K 32
+#endif
+constexpr int PANEL_K = SSLAM_PANEL_K;
+static_assert(PANEL_K == 32 || PANEL_K == 64, "k-panel width");
 __device__ __forceinline__ size_t panel_index(int row, int col, int rows_total) {
-    return ((size_t)(col >> 6) * rows_total + row) * 64 + (col & 63);
+    return ((size_t)(col / PANEL_K) * rows_total + row) * PANEL_K + (col % PANEL_K);
+}
+// offset (halves) of 16-byte chunk `c8` (0..7) of `row` inside the 64-deep k-tile `kt64`
+__device__ __forceinline__ size_t panel_tile64_offset(int kt64, int row, int c8, int rows_total) {
+    if constexpr (PANEL_K == 64) return ((size_t)kt64 * rows_total + row) * 64 + c8 * 8;
+    else return ((size_t)(2 * kt64 + (c8 >> 2)) * rows_total + row) * 32 + (c8 & 3) * 8;
 }
 
 // LDS-DMA ring version.  BK = 64 halves (128 B rows), NSTAGE-deep ring in dynamic LDS filled by
@@ -260,10 +273,9 @@ __device__ __forceinline__ void gemm_mainloop_ring(const GemmAH& ga, SplitPtr W,
         auto issue = [&](int kt, int stage) {
             const int k = kt * RBK;
             const bool first = k < ga.K0;
-            const size_t apanel = (size_t)(first ? kt : kt - ga.K0 / RBK) * a_rows * RBK;
-            const _Float16* pah = (first ? ga.A0.hi : ga.A1.hi) + apanel;
-            const _Float16* pal = (first ? ga.A0.lo : ga.A1.lo) + apanel;
-            const size_t wpanel = (size_t)kt * col_cap * RBK;
+            const int akt = first ? kt : kt - ga.K0 / RBK;
+            const _Float16* pah = first ? ga.A0.hi : ga.A1.hi;
+            const _Float16* pal = first ? ga.A0.lo : ga.A1.lo;
             _Float16* sbase = smem + (size_t)stage * STAGE;
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
@@ -278,10 +290,10 @@ __device__ __forceinline__ void gemm_mainloop_ring(const GemmAH& ga, SplitPtr W,
                 const _Float16* src;
                 _Float16* dst;
                 if (plane < 2) {
-                    src = (plane == 0 ? pah : pal) + (size_t)min(row0 + row, row_cap - 1) * RBK + c * 8;
+                    src = (plane == 0 ? pah : pal) + sslam::panel_tile64_offset(akt, min(row0 + row, row_cap - 1), c, a_rows);
                     dst = sbase + plane * BM * RBK + grp * 8 * RBK;
                 } else {
-                    src = (plane == 2 ? W.hi : W.lo) + wpanel + (size_t)min(col0 + row, col_cap - 1) * RBK + c * 8;
+                    src = (plane == 2 ? W.hi : W.lo) + sslam::panel_tile64_offset(kt, min(col0 + row, col_cap - 1), c, col_cap);
                     dst = sbase + 2 * BM * RBK + (plane - 2) * BN * RBK + grp * 8 * RBK;
                 }
                 glds16_(src, dst);

@@ -35,8 +35,13 @@ constexpr int BIG_STAGES = 3;
 template <int BM, int BN>
 constexpr int big_stage_halves() { return (2 * BM + 2 * BN) * BBK; }
 
+// offset (halves) of row 0 of the 32-deep k-tile that starts at column k (k % 32 == 0) of a plane
+__device__ __forceinline__ size_t panel_base(int k, int rows_total) {
+    return (size_t)(k / PANEL_K) * rows_total * PANEL_K + (k % PANEL_K);
+}
+
 // A planes: k-panel layout over `a_rows` rows; W planes: k-panel layout over `col_cap` rows.
-// row0/row_cap, col0/col_cap in plane-row units.  K % 32 == 0, ga.K0 % 64 == 0.
+// row0/row_cap, col0/col_cap in plane-row units.  K % 32 == 0, ga.K0 % PANEL_K == 0.
 template <int BM, int BN, int WM, int WN, int VARIANT = 1, int NSTAGE = BIG_STAGES>
 __device__ __forceinline__ void gemm_mainloop_big(const GemmAH& ga, SplitPtr W, int a_rows, int K, int row0,
                                                   int row_cap, int col0, int col_cap, _Float16* smem,
@@ -78,9 +83,9 @@ __device__ __forceinline__ void gemm_mainloop_big(const GemmAH& ga, SplitPtr W, 
     int aoff[JA], woff[JW];                              // per-lane source offsets (halves) inside a k-panel
 #pragma unroll
     for (int q = 0; q < JA; ++q)
-        aoff[q] = min(row0 + (SHORT_A ? wave % PA : wave + NWAVE * q) * 16 + prow, row_cap - 1) * 64 + psw;
+        aoff[q] = min(row0 + (SHORT_A ? wave % PA : wave + NWAVE * q) * 16 + prow, row_cap - 1) * PANEL_K + psw;
 #pragma unroll
-    for (int q = 0; q < JW; ++q) woff[q] = min(col0 + (wave + NWAVE * q) * 16 + prow, col_cap - 1) * 64 + psw;
+    for (int q = 0; q < JW; ++q) woff[q] = min(col0 + (wave + NWAVE * q) * 16 + prow, col_cap - 1) * PANEL_K + psw;
     const bool lo_plane = SHORT_A && wave >= PA;        // (short A tile: this wave's A piece is of the lo plane)
     const _Float16* const a0w = lo_plane ? ga.A0.lo : ga.A0.hi;
     const _Float16* const a1w = lo_plane ? ga.A1.lo : ga.A1.hi;
@@ -89,9 +94,9 @@ __device__ __forceinline__ void gemm_mainloop_big(const GemmAH& ga, SplitPtr W, 
             const int k = kt * BBK;
             const bool first = k < ga.K0;
             const int ka = first ? k : k - ga.K0;
-            const size_t apan = (size_t)(ka >> 6) * a_rows * 64 + (ka & 32);
+            const size_t apan = panel_base(ka, a_rows);
             const _Float16* pa = (first ? a0w : a1w) + apan;
-            const size_t wpan = (size_t)(k >> 6) * col_cap * 64 + (k & 32);
+            const size_t wpan = panel_base(k, col_cap);
             _Float16* st = smem + (size_t)stage * STAGE;
             glds16_(pa + aoff[0], st + (lo_plane ? BM * BBK : 0) + (wave % PA) * 16 * BBK);
             _Float16* wb = st + 2 * BM * BBK + wave * 16 * BBK;
@@ -107,10 +112,10 @@ __device__ __forceinline__ void gemm_mainloop_big(const GemmAH& ga, SplitPtr W, 
         const int k = kt * BBK;
         const bool first = k < ga.K0;
         const int ka = first ? k : k - ga.K0;
-        const size_t apan = (size_t)(ka >> 6) * a_rows * 64 + (ka & 32);
+        const size_t apan = panel_base(ka, a_rows);
         const _Float16* pah = (first ? ga.A0.hi : ga.A1.hi) + apan;
         const _Float16* pal = (first ? ga.A0.lo : ga.A1.lo) + apan;
-        const size_t wpan = (size_t)(k >> 6) * col_cap * 64 + (k & 32);
+        const size_t wpan = panel_base(k, col_cap);
         const _Float16* pwh = W.hi + wpan;
         const _Float16* pwl = W.lo + wpan;
         _Float16* sbase = smem + (size_t)stage * STAGE + wave * 16 * BBK;

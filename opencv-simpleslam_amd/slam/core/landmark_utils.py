@@ -17,6 +17,12 @@ ARE the storage:
                                                                      count 0 when the LAST has none:
                                                                      the reference's skip rule)
 
+`points` is a dict subclass that tells the map about every DIRECT mutation - `points.pop(pid)`
+(triangulation_utils.py:105), `points[pid] = MapPoint(id=.., position=..)` (the reference's tests),
+`del`, `clear`, `update` - so the arrays never go out of step with the dict: a removed landmark is
+detached (it keeps its own copy of position / colour), its row becomes a hole that the next array
+consumer compacts away; an assigned landmark is attached to a fresh row at once.
+
 `MapPoint.position` is a property over row `_pos[row]`: `mp.position[:] = X` (what BA does,
 ba_utils.py:269) and `mp.position = X` (what the duplicate merge does, :157) both write the array
 in place.  `add_observation` refreshes the point's descriptor rows.  `device_arrays(ctx)` returns
@@ -48,47 +54,135 @@ def _canon_desc(desc):
 
 
 class MapPoint:
-    """One landmark: a row of the owning map's arrays plus its observation list."""
-    __slots__ = ("id", "keyframe_idx", "observations", "_map", "_row")
+    """One landmark.  Attached to a map it is a row of that map's arrays plus its observation list;
+    built on its own - `MapPoint(id=0, position=np.zeros(3))`, the reference's dataclass signature
+    (landmark_utils.py:47-70) - it carries its own position / colour until a map adopts it."""
+    __slots__ = ("id", "keyframe_idx", "observations", "_map", "_row", "_own_pos", "_own_col")
 
-    def __init__(self, pid: int, owner: "Map", row: int, keyframe_idx: int = -1):
-        self.id = int(pid)
+    def __init__(self, id: int, position, keyframe_idx: int = -1, colour=None, observations=None):
+        self.id = int(id)
         self.keyframe_idx = int(keyframe_idx)
-        self.observations: List[Tuple[int, int, np.ndarray]] = []
-        self._map = owner
-        self._row = row
+        self.observations: List[Tuple[int, int, np.ndarray]] = [] if observations is None else observations
+        self._map = None
+        self._row = -1
+        self._own_pos = np.asarray(position, np.float64).reshape(3)
+        self._own_col = np.ones(3, np.float32) if colour is None else np.asarray(colour, np.float32).reshape(3)
+
+    @classmethod
+    def _attached(cls, pid: int, owner: "Map", row: int, keyframe_idx: int = -1) -> "MapPoint":
+        mp = cls.__new__(cls)
+        mp.id = int(pid)
+        mp.keyframe_idx = int(keyframe_idx)
+        mp.observations = []
+        mp._map = owner
+        mp._row = row
+        mp._own_pos = mp._own_col = None
+        return mp
+
+    def _detach(self) -> None:
+        """Leave the map keeping the current values (the caller of `points.pop` may still use the object)."""
+        if self._map is not None:
+            self._own_pos = self._map._pos[self._row].copy()
+            self._own_col = self._map._col[self._row].copy()
+            self._map, self._row = None, -1
 
     @property
     def position(self) -> np.ndarray:
+        if self._map is None:
+            return self._own_pos
         return self._map._pos[self._row]                 # a view: in-place writes land in the array
 
     @position.setter
     def position(self, value) -> None:
-        self._map._pos[self._row] = np.asarray(value, np.float64).reshape(3)
+        if self._map is None:
+            self._own_pos = np.asarray(value, np.float64).reshape(3)
+        else:
+            self._map._pos[self._row] = np.asarray(value, np.float64).reshape(3)
 
     @property
     def colour(self) -> np.ndarray:
+        if self._map is None:
+            return self._own_col
         return self._map._col[self._row]
 
     @colour.setter
     def colour(self, value) -> None:
-        self._map._col[self._row] = np.asarray(value, np.float32).reshape(3)
+        if self._map is None:
+            self._own_col = np.asarray(value, np.float32).reshape(3)
+        else:
+            self._map._col[self._row] = np.asarray(value, np.float32).reshape(3)
 
     def add_observation(self, keyframe_idx: int, kp_idx: int, descriptor) -> None:
         """Register that *kp_idx* in *keyframe_idx* observes this landmark (reference :72-74)."""
         self.observations.append((keyframe_idx, kp_idx, _canon_desc(descriptor)))
-        self._map._refresh_desc(self)
+        if self._map is not None:
+            self._map._refresh_desc(self)
+
+    def __repr__(self) -> str:
+        return f"MapPoint(id={self.id}, position={self.position!r}, keyframe_idx={self.keyframe_idx}, " \
+               f"observations={len(self.observations)})"
+
+
+class _PointDict(dict):
+    """`Map.points`: a dict in insertion order whose direct mutations keep the owning map's arrays in
+    step (the reference mutates it directly: triangulation_utils.py:105, tests/test_landmark_utils.py)."""
+    __slots__ = ("_owner",)
+
+    def __init__(self, owner: "Map"):
+        super().__init__()
+        self._owner = owner
+
+    def __setitem__(self, pid, mp) -> None:
+        dict.__setitem__(self, pid, self._owner._adopt(pid, mp, dict.get(self, pid)))
+
+    def __delitem__(self, pid) -> None:
+        mp = dict.__getitem__(self, pid)
+        dict.__delitem__(self, pid)
+        self._owner._release(mp)
+
+    def pop(self, pid, *default):
+        if pid in self:
+            mp = dict.pop(self, pid)
+            self._owner._release(mp)
+            return mp
+        if default:
+            return default[0]
+        raise KeyError(pid)
+
+    def popitem(self):
+        pid, mp = dict.popitem(self)
+        self._owner._release(mp)
+        return pid, mp
+
+    def clear(self) -> None:
+        for mp in list(self.values()):
+            self._owner._release(mp)
+        dict.clear(self)
+
+    def update(self, *args, **kwargs) -> None:
+        for pid, mp in dict(*args, **kwargs).items():
+            self[pid] = mp
+
+    def setdefault(self, pid, default=None):
+        if pid not in self:
+            self[pid] = default
+        return dict.__getitem__(self, pid)
+
+    def __ior__(self, other):
+        self.update(other)
+        return self
 
 
 class Map:
     """3-D points + camera trajectory (reference :80-161), SoA inside."""
 
     def __init__(self) -> None:
-        self.points: Dict[int, MapPoint] = {}
+        self.points: Dict[int, MapPoint] = _PointDict(self)
         self.keyframe_indices: List[int] = []
         self.poses: List[np.ndarray] = []
         self._next_pid = 0
-        self._n = 0
+        self._n = 0                                      # rows in use (holes of removed landmarks included)
+        self._holes = False                              # a landmark was removed directly: compact before the arrays are read
         cap = 1024
         self._ids = np.zeros(cap, np.int64)
         self._pos = np.zeros((cap, 3), np.float64)
@@ -113,9 +207,9 @@ class Map:
             col = getattr(src, "colour", None)
             if col is not None:
                 m._col[r] = np.asarray(col, np.float32).reshape(3)
-            mp = MapPoint(int(pid), m, r, getattr(src, "keyframe_idx", -1))
+            mp = MapPoint._attached(int(pid), m, r, getattr(src, "keyframe_idx", -1))
             mp.observations = list(src.observations)
-            m.points[int(pid)] = mp
+            dict.__setitem__(m.points, int(pid), mp)
         m._n = k
         m._next_pid = getattr(ref_map, "_next_pid", (max((int(p) for p, _ in items), default=-1) + 1))
         m.poses = [np.array(p, copy=True) for p in getattr(ref_map, "poses", [])]
@@ -156,6 +250,7 @@ class Map:
         if pts3d.ndim != 2 or pts3d.shape[1] != 3:
             raise ValueError("pts3d must be (N,3)")
         k = len(pts3d)
+        self._compact()
         self._grow(self._n + k)
         r0 = self._n
         self._pos[r0:r0 + k] = pts3d.astype(np.float64)
@@ -164,11 +259,61 @@ class Map:
         new_ids = list(range(self._next_pid, self._next_pid + k))
         self._ids[r0:r0 + k] = new_ids
         for j, pid in enumerate(new_ids):
-            self.points[pid] = MapPoint(pid, self, r0 + j, keyframe_idx)
+            dict.__setitem__(self.points, pid, MapPoint._attached(pid, self, r0 + j, keyframe_idx))
         self._next_pid += k
         self._n += k
         self._touch(r0, r0 + k)
         return new_ids
+
+    # ---- direct mutations of `points` (called by _PointDict)
+    def _adopt(self, pid, mp, old):
+        """`points[pid] = mp`: the landmark becomes a row of the arrays.  A new key is appended (dict
+        insertion order = row order); an existing key keeps its place, so its row is reused."""
+        if not hasattr(mp, "observations") or not hasattr(mp, "position"):
+            raise TypeError("Map.points values must be MapPoint-like (position, observations)")
+        if old is mp and getattr(mp, "_map", None) is self:
+            return mp
+        if not isinstance(mp, MapPoint):                 # a foreign landmark object (e.g. the reference's dataclass):
+            src = mp                                     # the map stores its own MapPoint with the same values
+            mp = MapPoint(getattr(src, "id", pid), src.position, getattr(src, "keyframe_idx", -1),
+                          getattr(src, "colour", None), list(src.observations))
+        if mp._map is not None:                          # attached elsewhere (or to another key): move a copy of its values
+            mp._detach()
+        if old is not None:
+            row = old._row
+            old._detach()
+        else:
+            self._grow(self._n + 1)
+            row = self._n
+            self._n += 1
+        self._ids[row] = int(pid)
+        self._pos[row] = mp._own_pos
+        self._col[row] = mp._own_col
+        mp._map, mp._row = self, row
+        mp._own_pos = mp._own_col = None
+        self._refresh_desc(mp)
+        return mp
+
+    def _release(self, mp) -> None:
+        """`points.pop(pid)` / `del points[pid]`: the row becomes a hole until the next compaction."""
+        if isinstance(mp, MapPoint) and mp._map is self:
+            mp._detach()
+            self._holes = True
+
+    def _compact(self) -> None:
+        """Close the holes left by directly removed landmarks: rows back in dict order, `_n == len(points)`."""
+        if not self._holes:
+            return
+        keep = np.fromiter((mp._row for mp in self.points.values()), np.int64, len(self.points))
+        n = len(keep)
+        for name in ("_ids", "_pos", "_col", "_dcnt", "_desc"):
+            arr = getattr(self, name)
+            arr[:n] = arr[keep]                          # keep is increasing: fancy indexing copies first
+        for r, mp in enumerate(self.points.values()):
+            mp._row = r
+        self._n = n
+        self._holes = False
+        self._touch(0, n)
 
     def _refresh_desc(self, mp: MapPoint) -> None:
         """Descriptor rows of one landmark from its observation list (pnp_utils.py:46-50, :107-120,
@@ -197,9 +342,11 @@ class Map:
 
     # ---------------- Convenience accessors ------------ #
     def get_point_array(self) -> np.ndarray:
+        self._compact()
         return self._pos[:self._n].copy() if self._n else np.empty((0, 3))
 
     def get_color_array(self) -> np.ndarray:
+        self._compact()
         return self._col[:self._n].copy() if self._n else np.empty((0, 3), np.float32)
 
     def point_ids(self) -> List[int]:
@@ -211,6 +358,7 @@ class Map:
     # ---------------- SoA views (host) ------------------ #
     def soa(self):
         """(ids [Q], positions [Q,3], descriptor counts [Q], descriptors [Q,6,128]) in dict order - views."""
+        self._compact()
         n = self._n
         return self._ids[:n], self._pos[:n], self._dcnt[:n], self._desc[:n]
 
@@ -221,6 +369,7 @@ class Map:
         if len(self.points) < 2:
             return
         from scipy.spatial import cKDTree
+        self._compact()
         ids = list(self.points.keys())
         pts = self._pos[:self._n]
         pairs = sorted(cKDTree(pts).query_pairs(radius))
@@ -231,19 +380,9 @@ class Map:
                 continue
             self.points[ida].position = (self.points[ida].position + self.points[idb].position) * 0.5
             removed.add(idb)
-        if not removed:
-            return
         for idx in removed:
-            self.points.pop(idx, None)
-        keep = np.array([mp._row for mp in self.points.values()], np.int64)
-        n = len(keep)
-        for name in ("_ids", "_pos", "_col", "_dcnt", "_desc"):
-            arr = getattr(self, name)
-            arr[:n] = arr[keep]
-        for r, mp in enumerate(self.points.values()):
-            mp._row = r
-        self._n = n
-        self._touch(0, n)
+            self.points.pop(idx, None)                   # detaches the landmark, leaves a hole
+        self._compact()
 
     # ---------------- device mirror --------------------- #
     def device_arrays(self, ctx):
@@ -251,6 +390,7 @@ class Map:
         map on `ctx`'s GPU, brought up to date: positions and counts are uploaded whole (BA rewrites
         positions in place without telling anyone; 28 bytes per landmark), descriptors only for the
         rows touched since the last call."""
+        self._compact()
         n = self._n
         cap = len(self._ids)
         row_bytes = MAX_OBS_CHECK * DESC_DIM * 4

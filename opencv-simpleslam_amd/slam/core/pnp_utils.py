@@ -133,20 +133,19 @@ def reproject_and_match_2d3d(world_map, K, Tcw_pred, kps_cur, des_cur, img_w, im
                        [int(i) for i in ids[hit]])
 
 
-_SCRATCH = {}
-
-
 def _dev_scratch(ctx, Q, N):
-    """Per-context device buffers of the current-frame inputs / outputs of the association (grown on demand)."""
-    key = id(ctx)
-    cur = _SCRATCH.get(key)
+    """Device buffers of the current-frame inputs / outputs of the association, grown on demand.  They
+    live ON the context object (`ctx.scratch`, released by `Context.close`): a module-level table keyed
+    by `id(ctx)` would hand the pointers of a collected context to a new one that reuses the id."""
+    cur = ctx.scratch.get("reproject")
     if cur is None or cur["Q"] < Q or cur["N"] < N:
         if cur is not None:
             ctx.sync()
-            for k in ("kp", "des", "out", "info"):
-                ctx.free(cur[k])
+            for p_ in cur["_ptrs"]:
+                ctx.free(p_)
         Qc, Nc = max(Q, 2 * (cur["Q"] if cur else 0), 1024), max(N, (cur["N"] if cur else 0), 1024)
         cur = {"Q": Qc, "N": Nc, "kp": ctx.malloc(Nc * 8), "des": ctx.malloc(Nc * DESC_DIM * 4),
                "out": ctx.malloc(Qc * 4), "info": ctx.malloc(16)}
-        _SCRATCH[key] = cur
+        cur["_ptrs"] = (cur["kp"], cur["des"], cur["out"], cur["info"])
+        ctx.scratch["reproject"] = cur
     return cur
