@@ -22,19 +22,18 @@ using half2v = _Float16 __attribute__((ext_vector_type(2)));
 constexpr float SPLIT_SCALE = 2048.0f;          // 2^11
 constexpr float SPLIT_INV = 1.0f / 2048.0f;
 
-// Set (never cleared by device code) when a FINITE value outside the fp16 range reaches a split:
-// |a| >= 65520 rounds to +-inf in the high plane and the product silently becomes inf / NaN.  The
-// split saturates instead and raises this flag; the host entry points report it as an error
-// (the exact-fp32 path, precision 0, has no such limit).  Non-finite inputs are not flagged: they
-// stay NaN / inf as in any fp32 evaluation.
-static __device__ int g_split_range_overflow;
-
-__device__ __forceinline__ void split_f32(float a, _Float16& hi, _Float16& lo) {
+// RANGE.  A FINITE value with |a| >= 65520 does not fit the fp16 planes (it rounds to +-inf in the high
+// plane and the product silently becomes inf / NaN).  Every split reports such a value through the
+// `range_flag` word its caller passes - per matcher instance AND per pair (LGCtrl::range_overflow,
+// lightglue_kernels.hip): the pair's result is then marked invalid (match count -1) and the host
+// entries turn it into an error; the exact-fp32 path (precision 0) has no such limit.  Non-finite
+// inputs are not flagged: they stay NaN / inf as in any fp32 evaluation.
+__device__ __forceinline__ void split_f32(float a, _Float16& hi, _Float16& lo, int* range_flag) {
     // an fp16 subnormal is not a safe MFMA operand (flushed on input): below 2^-14 the whole
     // value moves into the scaled low plane, which keeps 11 bits down to |a| = 2^-25
     const float aa = fabsf(a);
     if (aa >= 65520.0f && aa < INFINITY) {
-        g_split_range_overflow = 1;
+        *range_flag = 1;
         hi = (_Float16)copysignf(65504.0f, a);
         lo = (_Float16)fminf(fmaxf((a - (float)hi) * SPLIT_SCALE, -65504.0f), 65504.0f);
         return;
@@ -48,32 +47,30 @@ __device__ __forceinline__ void split_f32(float a, _Float16& hi, _Float16& lo) {
 // Same planes as split_f32 for every in-range value (hi = rne(a) or 0 below 2^-14, lo = the exact
 // residual x 2^11 rounded once; NaN / inf stay non-finite in both planes).  A finite |a| >= 65520 is
 // NOT saturated here: it leaves as inf (and poisons what consumes it) but is reported through `amax` -
-// the caller keeps the running maximum of |a| and raises g_split_range_overflow once per thread
-// (split_range_check), which the host entries turn into an error.
+// the caller keeps the running maximum of |a| and raises the range flag once per thread
+// (split_range_check).
 // ~5 instructions per value: v_cmp + v_cndmask, 1/2 v_cvt_pk_f16_f32, v_mul, v_fma_mix, 1/2 v_max3.
-__device__ __forceinline__ void split8_fast(const float (&v)[8], uint4& hi, uint4& lo, float& amax) {
+// two values -> packed (hi, lo) half2 words
+__device__ __forceinline__ void split2_fast(float a0, float a1, unsigned& h2, unsigned& l2, float& amax) {
     typedef float float2s __attribute__((ext_vector_type(2)));
-    unsigned h[4], l[4];
     const float neg_scale = -SPLIT_SCALE;
+    amax = fmaxf(amax, fmaxf(fabsf(a0), fabsf(a1)));
+    const float2s z = {fabsf(a0) < 6.103515625e-5f ? 0.0f : a0, fabsf(a1) < 6.103515625e-5f ? 0.0f : a1};
+    h2 = __builtin_bit_cast(unsigned, __builtin_convertvector(z, half2v));
+    const float t0 = a0 * SPLIT_SCALE, t1 = a1 * SPLIT_SCALE;
+    // l2.lo = fp16(h2.lo * -2^11 + t0), l2.hi = fp16(h2.hi * -2^11 + t1): one rounding each
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l2) : "v"(h2), "v"(neg_scale), "v"(t0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l2) : "v"(h2), "v"(neg_scale), "v"(t1));
+}
+__device__ __forceinline__ void split8_fast(const float (&v)[8], uint4& hi, uint4& lo, float& amax) {
+    unsigned h[4], l[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float a0 = v[2 * e], a1 = v[2 * e + 1];
-        amax = fmaxf(amax, fmaxf(fabsf(a0), fabsf(a1)));
-        const float c0 = a0, c1 = a1;
-        const float2s z = {fabsf(c0) < 6.103515625e-5f ? 0.0f : c0, fabsf(c1) < 6.103515625e-5f ? 0.0f : c1};
-        const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_convertvector(z, half2v));
-        const float t0 = c0 * SPLIT_SCALE, t1 = c1 * SPLIT_SCALE;
-        unsigned l2;
-        // l2.lo = fp16(h2.lo * -2^11 + t0), l2.hi = fp16(h2.hi * -2^11 + t1): one rounding each
-        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l2) : "v"(h2), "v"(neg_scale), "v"(t0));
-        asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l2) : "v"(h2), "v"(neg_scale), "v"(t1));
-        h[e] = h2; l[e] = l2;
-    }
+    for (int e = 0; e < 4; ++e) split2_fast(v[2 * e], v[2 * e + 1], h[e], l[e], amax);
     hi = make_uint4(h[0], h[1], h[2], h[3]);
     lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
-__device__ __forceinline__ void split_range_check(float amax) {
-    if (amax >= 65520.0f && amax < INFINITY) g_split_range_overflow = 1;
+__device__ __forceinline__ void split_range_check(float amax, int* range_flag) {
+    if (amax >= 65520.0f && amax < INFINITY) *range_flag = 1;
 }
 
 __device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {

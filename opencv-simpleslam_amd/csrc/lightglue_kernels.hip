@@ -64,14 +64,20 @@ struct LGCtrl {
     int stop;        // 0 running, 1 stopped early, 2 empty set
     int stop_layer;  // index i of the layer whose log_assignment is used
     int unconf;      // #tokens with confidence < threshold (both images)
-    int n_matches;   // K
-    int pad[6];
+    int n_matches;   // K (-1: the split-precision range flag below was raised, the result is invalid)
+    int range_overflow;  // a finite |value| >= 65520 reached an fp16 split while this pair was processed (gemm_f16x3.hpp)
+    int pad[5];
 };
 constexpr int MAX_PAIRS = 16;    // batch capacity bound (kernel-argument tables are sized for it)
 
 __device__ __forceinline__ LGCtrl& ctrl_of(LGCtrl* c, int img) { return c[img >> 1]; }
 __device__ __forceinline__ const LGCtrl& ctrl_of(const LGCtrl* c, int img) { return c[img >> 1]; }
 __device__ __forceinline__ int n_of(const LGCtrl* c, int img) { return c[img >> 1].n[img & 1]; }
+// the range flag of the pair an image belongs to (the one word of the control block that kernels which
+// otherwise only read it may write)
+__device__ __forceinline__ int* range_flag_of(const LGCtrl* c, int img) {
+    return &const_cast<LGCtrl*>(c)[img >> 1].range_overflow;
+}
 
 // Per-image input sources of one call (host-built table passed by value): where the keypoints /
 // descriptors of image i live, the host-side bound on their count and, optionally, the device
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(1024) void lg_prepare_kernel(
         bbox[img * 4 + 0] = sx / 2.0f; bbox[img * 4 + 1] = sy / 2.0f; bbox[img * 4 + 2] = fmaxf(sx, sy) / 2.0f;
         c.n[side] = n; c.n_prev[side] = n; c.n_orig[side] = n;
         if (side == 0) { c.stop = (n == 0 || n_other == 0) ? 2 : 0; c.stop_layer = NL - 1;
-                         c.unconf = 0; c.n_matches = 0; }
+                         c.unconf = 0; c.n_matches = 0; c.range_overflow = 0; }
     }
 }
 
@@ -882,7 +888,7 @@ __global__ __launch_bounds__(1024) void lg_emit_kernel(
     const float* __restrict__ best0, const int* __restrict__ arg0, const float* __restrict__ pval,
     const int* __restrict__ parg, const int* __restrict__ ind, float filter_thr, float min_conf, int32_t* __restrict__ ij_out,
     float* __restrict__ score_out, int32_t* __restrict__ info_out, LGCtrl* __restrict__ ctrl, int Kc,
-    long out_stride) {
+    long out_stride, int* __restrict__ range_sticky) {
     __shared__ int wsum[16];
     const int pair = blockIdx.x;
     ctrl += pair; best0 += (size_t)pair * Kc; arg0 += (size_t)pair * Kc;
@@ -926,6 +932,10 @@ __global__ __launch_bounds__(1024) void lg_emit_kernel(
         }
     }
     if (t == 0) {
+        // a value left the fp16 range of the split-precision path while this pair was processed: its
+        // matches are not fp32-grade - the count says so (-1) wherever the result travels, and the
+        // instance remembers it (sslam_lightglue_range_overflow)
+        if (ctrl->range_overflow) { total = -1; *range_sticky = 1; }
         ctrl->n_matches = total;
         info_out[0] = total;
         info_out[1] = ctrl->stop_layer + 1;     // upstream "stop" = i + 1
@@ -943,12 +953,12 @@ struct SplitOut { _Float16* hi; _Float16* lo; };
 
 // weight matrix W[N][K] (row-major fp32) -> split planes in k-panel layout [K/64][N][64]
 __global__ void lg_split_weight_kernel(const float* __restrict__ src, _Float16* __restrict__ hi,
-                                       _Float16* __restrict__ lo, int N, int K) {
+                                       _Float16* __restrict__ lo, int N, int K, int* __restrict__ range_flag) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)N * K) return;
     const int n = (int)(i / K), k = (int)(i % K);
     const size_t o = panel_index(n, k, N);
-    split_f32(src[i], hi[o], lo[o]);
+    split_f32(src[i], hi[o], lo[o], range_flag);
 }
 
 // token states x[2][Kc][256] -> split planes in k-panel layout over the 2*Kc rows
@@ -974,7 +984,7 @@ __global__ __launch_bounds__(256) void lg_split_rows_kernel(const float* __restr
         const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
         half8 hh, ll;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { _Float16 x, y; split_f32(v[e], x, y); hh[e] = x; ll[e] = y; }
+        for (int e = 0; e < 8; ++e) { _Float16 x, y; split_f32(v[e], x, y, range_flag_of(ctrl, img)); hh[e] = x; ll[e] = y; }
         const size_t o = panel_index(img * Kc + row, col, NIc * Kc);
         *reinterpret_cast<half8*>(hi + o) = hh;
         *reinterpret_cast<half8*>(lo + o) = ll;
@@ -1119,7 +1129,7 @@ __device__ __forceinline__ void linear_h_epilogue(const LinearArgsH& p, const Ro
                 const float y = v[i] * rstd * gm[i] + bt[i];
                 const float gl = 0.5f * y * (1.0f + erf_as(y * 0.70710678118654752440f));
                 _Float16 hh, ll;
-                split_f32(gl, hh, ll);
+                split_f32(gl, hh, ll, range_flag_of(p.ctrl, rd.img));
                 if (i < 4) { h0[i] = hh; l0[i] = ll; } else { h1[i - 4] = hh; l1[i - 4] = ll; }
             }
             const int prow = (int)ibase + row;
@@ -1136,13 +1146,13 @@ __device__ __forceinline__ void linear_h_epilogue(const LinearArgsH& p, const Ro
 #define LG_EPI_FAST_SPLIT 1    // A/B switch (scripts/ab_lib.sh): 0 = the branchy scalar split_f32 per value
 #endif
     float amax = 0.0f;
-    auto split8 = [&amax](const float (&v)[8], uint4& hi, uint4& lo) {
+    auto split8 = [&](const float (&v)[8], uint4& hi, uint4& lo) {
 #if LG_EPI_FAST_SPLIT
         sslam::split8_fast(v, hi, lo, amax);
 #else
         half8 hh, ll;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { _Float16 a, b2; split_f32(v[e], a, b2); hh[e] = a; ll[e] = b2; }
+        for (int e = 0; e < 8; ++e) { _Float16 a, b2; split_f32(v[e], a, b2, range_flag_of(p.ctrl, rd.img)); hh[e] = a; ll[e] = b2; }
         hi = *reinterpret_cast<uint4*>(&hh);
         lo = *reinterpret_cast<uint4*>(&ll);
 #endif
@@ -1216,7 +1226,7 @@ __device__ __forceinline__ void linear_h_epilogue(const LinearArgsH& p, const Ro
         // of V^T (64 key positions of one d), and the next column's lines follow contiguously, so a
         // wave stores two 512-byte segments per plane instead of 64 separate 16-byte pieces.
         constexpr int RG = BM / 8;
-        if (!has_v) { sslam::split_range_check(amax); return; }
+        if (!has_v) { sslam::split_range_check(amax, range_flag_of(p.ctrl, rd.img)); return; }
         for (int u = t; u < BN * RG; u += NT) {
             const int rg = u % RG, cl = u / RG;
             const int col = col0 + cl;
@@ -1240,7 +1250,7 @@ __device__ __forceinline__ void linear_h_epilogue(const LinearArgsH& p, const Ro
             *reinterpret_cast<uint4*>(p.vt.lo + o) = lo;
         }
     }
-    sslam::split_range_check(amax);
+    sslam::split_range_check(amax, range_flag_of(p.ctrl, rd.img));
 }
 
 template <int BM, int BN, int TM, int TN, int EPI>
@@ -1329,7 +1339,7 @@ __global__ __launch_bounds__(256) void lg_ln_gelu_h_kernel(const float* __restri
         const float y = v[i] * rstd * gm[i] + bt[i];
         const float g = 0.5f * y * (1.0f + erf_as(y * 0.70710678118654752440f));
         _Float16 hh, ll;
-        split_f32(g, hh, ll);
+        split_f32(g, hh, ll, range_flag_of(ctrl, img));
         if (i < 4) { h0[i] = hh; l0[i] = ll; } else { h1[i - 4] = hh; l1[i - 4] = ll; }
     }
     const size_t p0 = panel_index(img * Kc + row, lane * 4, NIc * Kc), p1 = panel_index(img * Kc + row, 256 + lane * 4, NIc * Kc);
@@ -1743,7 +1753,7 @@ __global__ __launch_bounds__(256, ATTN_WAVES_PER_SIMD) void lg_attention_p_kerne
                         const float v = half ? (o1b[4 * g4 + e] + o2b[4 * g4 + e] * SPLIT_INV)
                                              : (o1a[4 * g4 + e] + o2a[4 * g4 + e] * SPLIT_INV);
                         _Float16 a, b;
-                        split_f32(v * inv, a, b);
+                        split_f32(v * inv, a, b, range_flag_of(p.ctrl, img));
                         hh[e] = a; ll[e] = b;
                     }
                     const size_t o = panel_index(prow, head * DH + 32 * half + 8 * g4 + 4 * h, p.NIc * p.Kc);
@@ -2005,7 +2015,7 @@ __global__ __launch_bounds__(512) void lg_attention_pp_kernel(AttnArgsH p) {
                     const float v = half ? (o1b[4 * g4 + e] + o2b[4 * g4 + e] * SPLIT_INV)
                                          : (o1a[4 * g4 + e] + o2a[4 * g4 + e] * SPLIT_INV);
                     _Float16 a, b;
-                    split_f32(v * inv, a, b);
+                    split_f32(v * inv, a, b, range_flag_of(p.ctrl, img));
                     hh[e] = a; ll[e] = b;
                 }
                 const size_t o = panel_index(prow, head * DH + 32 * half + 8 * g4 + 4 * h, p.NIc * p.Kc);
@@ -2045,7 +2055,7 @@ __global__ __launch_bounds__(256) void lg_attn_merge_h_kernel(const float* __res
     const float v[4] = {acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv};
     half4 hh, ll;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { _Float16 a, b; split_f32(v[e], a, b); hh[e] = a; ll[e] = b; }
+    for (int e = 0; e < 4; ++e) { _Float16 a, b; split_f32(v[e], a, b, range_flag_of(ctrl, img)); hh[e] = a; ll[e] = b; }
     const size_t o = panel_index(img * Kc + row, head * DH + c4 * 4, NIc * Kc);
     *reinterpret_cast<half4*>(msg.hi + o) = hh;
     *reinterpret_cast<half4*>(msg.lo + o) = ll;
@@ -2080,6 +2090,7 @@ struct sslam_lightglue {
     const float* tc_b[NL - 1];
     // workspace
     LGCtrl* ctrl;
+    int* range_sticky;               // device word: some pair of some call raised its range flag since the last read
     float *x, *enc_cos, *enc_sin, *q, *k, *v, *msg, *hid, *tx, *tc, *ts;
     float *o_part, *m_part, *l_part, *conf, *mat, *md, *sim, *rmax, *rlog, *cmax, *clog, *best0;
     float *cpmax, *cpsum, *cpval, *bbox;
@@ -2136,15 +2147,15 @@ int lg_bind_weights(sslam_lightglue* g, size_t n_floats) {
     return 0;
 }
 
-// read and clear the device-side range flag of the split-precision path (gemm_f16x3.hpp)
-int lg_take_range_flag(hipStream_t s, int* flag_out) {
-    int flag = 0, zero = 0;
-    SSLAM_HIP_CHECK(hipMemcpyFromSymbolAsync(&flag, HIP_SYMBOL(sslam::g_split_range_overflow), sizeof(int), 0,
-                                             hipMemcpyDeviceToHost, s));
+// read and clear THIS instance's sticky range flag of the split-precision path (set by lg_emit_kernel when a
+// pair's LGCtrl::range_overflow was raised; instances never share it)
+int lg_take_range_flag(sslam_lightglue* g, int* flag_out) {
+    hipStream_t s = g->ctx->stream;
+    int flag = 0;
+    SSLAM_HIP_CHECK(hipMemcpyAsync(&flag, g->range_sticky, sizeof(int), hipMemcpyDeviceToHost, s));
     SSLAM_HIP_CHECK(hipStreamSynchronize(s));
     if (flag) {
-        SSLAM_HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(sslam::g_split_range_overflow), &zero, sizeof(int), 0,
-                                               hipMemcpyHostToDevice, s));
+        SSLAM_HIP_CHECK(hipMemsetAsync(g->range_sticky, 0, sizeof(int), s));
         SSLAM_HIP_CHECK(hipStreamSynchronize(s));
     }
     *flag_out = flag;
@@ -2348,7 +2359,6 @@ int lg_enqueue(sslam_lightglue* g, int pairs, const StageSrc& src, float min_con
                float* score_out, int32_t* info_out, long out_stride) {
     hipStream_t s = g->ctx->stream;
     const int Kc = g->Kc, NI = 2 * pairs;
-    g->last_pairs = pairs;
     hipLaunchKernelGGL(lg_prepare_kernel, dim3(NI), dim3(1024), 0, s, src, Kc, g->in_xy, g->in_desc, g->bbox,
                        g->ind, g->prune, g->ctrl);
     hipLaunchKernelGGL(lg_posenc_kernel, dim3(sslam::cdiv(NI * Kc * ENC, 256)), dim3(256), 0, s, g->in_xy,
@@ -2438,7 +2448,7 @@ int lg_enqueue(sslam_lightglue* g, int pairs, const StageSrc& src, float min_con
     hipLaunchKernelGGL(lg_col_argmax_kernel, dim3(sslam::cdiv(Kc, 64), CSLAB, pairs), dim3(256), 0, s, g->sim,
                        g->rmax, g->rlog, g->cmax, g->clog, g->conf, g->cpval, g->cparg, Kc, g->ctrl);
     hipLaunchKernelGGL(lg_emit_kernel, dim3(pairs), dim3(1024), 0, s, g->best0, g->arg0, g->cpval, g->cparg, g->ind,
-                       g->filter_thr, min_conf, ij_out, score_out, info_out, g->ctrl, Kc, out_stride);
+                       g->filter_thr, min_conf, ij_out, score_out, info_out, g->ctrl, Kc, out_stride, g->range_sticky);
     SSLAM_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -2464,6 +2474,7 @@ void lg_configure_kernels() {
 // bracketing events are host-side records)
 int lg_enqueue_cached(sslam_lightglue* g, int pairs, const StageSrc& src, float min_conf, int32_t* ij_out,
                       float* score_out, int32_t* info_out, long out_stride) {
+    g->last_pairs = pairs;                 // host-side bookkeeping lives OUTSIDE the captured sequence (a replay skips the lambda)
     if (!g->use_graphs || g->profile)
         return lg_enqueue(g, pairs, src, min_conf, ij_out, score_out, info_out, out_stride);
     std::vector<uint64_t> key{(uint64_t)pairs, (uint64_t)ij_out, (uint64_t)score_out, (uint64_t)info_out,
@@ -2501,6 +2512,7 @@ int sslam_lightglue_create_batched(sslam_ctx* ctx, const float* weights, size_t 
     auto carve = [&](sslam::Arena& A) {
         g->blob = A.take<float>(n_floats);
         g->ctrl = A.take<LGCtrl>(NB);
+        g->range_sticky = A.take<int>(4);
         g->x = A.take<float>(NI * K * D); g->msg = A.take<float>(NI * K * D);
         g->tx = A.take<float>(NI * K * D); g->md = A.take<float>(NI * K * D);
         g->hid = A.take<float>(NI * K * 2 * D);
@@ -2542,14 +2554,20 @@ int sslam_lightglue_create_batched(sslam_ctx* ctx, const float* weights, size_t 
         auto splitw = [&](const float* w, int N, int K) {
             const size_t off = (size_t)(w - g->blob), n = (size_t)N * K;
             hipLaunchKernelGGL(lg_split_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                               w, g->w_hi + off, g->w_lo + off, N, K);
+                               w, g->w_hi + off, g->w_lo + off, N, K, g->range_sticky);
         };
         for (int i = 0; i < NL; ++i) {
             const LGLayerW& l = g->L[i];
             splitw(l.wqkv, 3 * D, D); splitw(l.w1, 2 * D, 2 * D); splitw(l.w2, D, 2 * D);
             splitw(l.cqkv, 2 * D, D); splitw(l.cw1, 2 * D, 2 * D); splitw(l.cw2, D, 2 * D);
         }
-        SSLAM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        int wflag = 0;
+        if (int rc = lg_take_range_flag(g, &wflag)) { g->arena.release(); delete g; return rc; }
+        if (wflag) {
+            g->arena.release(); delete g;
+            SSLAM_REQUIRE(false, "sslam_lightglue_create: a weight with |value| >= 65520 does not fit the fp16 planes of the "
+                                 "split-precision path");
+        }
     }
     *out = g;
     return 0;
@@ -2643,15 +2661,16 @@ int sslam_lightglue_match_host(sslam_lightglue* g, const float* xy0, const float
     StageSrc src{};
     src.xy[0] = g->up_xy; src.desc[0] = g->up_desc; src.bound[0] = M;
     src.xy[1] = g->up_xy + 2 * K; src.desc[1] = g->up_desc + K * DIN; src.bound[1] = N;
+    g->last_pairs = 1;
     if (int rc = lg_enqueue(g, 1, src, min_conf, g->out_ij, g->out_score, g->out_info, (long)K)) return rc;
     int32_t info[4];
     SSLAM_HIP_CHECK(hipMemcpyAsync(info, g->out_info, sizeof(info), hipMemcpyDeviceToHost, s));
     SSLAM_HIP_CHECK(hipStreamSynchronize(s));
-    if (g->precision == 1) {
+    if (info[0] == -1) {                       // lg_emit_kernel: this pair's range flag was raised
         int flag = 0;
-        if (int rc = lg_take_range_flag(s, &flag)) return rc;
-        SSLAM_REQUIRE(flag == 0, "sslam_lightglue_match_host: an activation left the fp16 range of the split-precision "
-                                 "path (|value| >= 65520); rescale the descriptors or use sslam_lightglue_set_precision(lg, 0)");
+        (void)lg_take_range_flag(g, &flag);    // reported here: clear the instance's sticky word
+        SSLAM_REQUIRE(false, "sslam_lightglue_match_host: an activation left the fp16 range of the split-precision "
+                             "path (|value| >= 65520); rescale the descriptors or use sslam_lightglue_set_precision(lg, 0)");
     }
     const int Kn = info[0];
     SSLAM_REQUIRE(Kn >= 0 && Kn <= (M < N ? M : N), "sslam_lightglue_match_host: corrupt match count %d", Kn);
@@ -2773,7 +2792,7 @@ int sslam_lightglue_use_graphs(sslam_lightglue* g, int enable) {
  * not fp32-grade).  The _host entry points check it themselves; _dev / batch callers poll here. */
 int sslam_lightglue_range_overflow(sslam_lightglue* g, int* flag_out) {
     SSLAM_REQUIRE(g && flag_out, "sslam_lightglue_range_overflow: NULL argument");
-    return lg_take_range_flag(g->ctx->stream, flag_out);
+    return lg_take_range_flag(g, flag_out);
 }
 
 int sslam_lightglue_capacity(sslam_lightglue* g, int* kc_out) {

@@ -112,6 +112,10 @@ def collate(local_records, plan: ShardPlan, group=None):
     return out
 
 
+class RangeOverflowError(RuntimeError):
+    pass
+
+
 class FrameStreamPipeline:
     """Device-resident extract(t) + match(t-1 -> t) over this rank's frame chunks.
 
@@ -292,19 +296,37 @@ class FrameStreamPipeline:
         for c in {id(x.ctx): x.ctx for x in self.dets + self.mats}.values():
             c.sync()
 
-    def results(self):
-        """Host copy of the last round's matches: list of (ij [K,2], scores [K]) per local frame."""
-        self.sync()
-        B, K = self.plan.frames_per_rank, self.K
-        info = np.empty((B, 4), np.int32); ij = np.empty((B, K, 2), np.int32); sc = np.empty((B, K), np.float32)
-        self.ctx.d2h(info, self.info); self.ctx.d2h(ij, self.ij); self.ctx.d2h(sc, self.msc)
-        return [(ij[s, :info[s, 0]].copy(), sc[s, :info[s, 0]].copy()) for s in range(B)]
-
-    def infos(self):
+    def _checked_infos(self):
+        """[B, 4] int32 {matches, layers, n0, n1} of the last round.  A match count of -1 is the matcher's
+        verdict that a finite activation left the fp16 range of the split-precision path while that pair
+        was processed (csrc/gemm_f16x3.hpp: its matches are not fp32-grade): never handed on silently."""
         self.sync()
         info = np.empty((self.plan.frames_per_rank, 4), np.int32)
         self.ctx.d2h(info, self.info)
+        bad = np.flatnonzero(info[:, 0] < 0)
+        if len(bad):
+            for m in self.mats:
+                m.range_overflow()                           # reported here: clear the instances' sticky words
+            raise RangeOverflowError(
+                f"LightGlue split-precision range overflow in pair(s) {bad.tolist()} of the last round (|activation| >= "
+                f"65520 does not fit the fp16 planes): rescale the descriptors or run the matchers with set_precision('f32')")
         return info
+
+    def results(self):
+        """Host copy of the last round's matches: list of (ij [K,2], scores [K]) per local frame."""
+        info = self._checked_infos()
+        B, K = self.plan.frames_per_rank, self.K
+        ij = np.empty((B, K, 2), np.int32); sc = np.empty((B, K), np.float32)
+        self.ctx.d2h(ij, self.ij); self.ctx.d2h(sc, self.msc)
+        return [(ij[s, :info[s, 0]].copy(), sc[s, :info[s, 0]].copy()) for s in range(B)]
+
+    def infos(self):
+        return self._checked_infos()
+
+    def range_overflow(self) -> bool:
+        """True if any matcher of the pipeline raised its range flag since the last poll (every round, not
+        only the last one whose `info` is still on the device); synchronises the matcher streams, clears."""
+        return any([m.range_overflow() for m in self.mats])
 
     def features(self):
         """Host copy of the last round's features: list of (xy [n,2], desc [n,128]) per local frame."""

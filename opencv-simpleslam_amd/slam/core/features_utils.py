@@ -21,6 +21,7 @@ LightGlue path: without the HIP library / an MI355X it raises.
 """
 from __future__ import annotations
 
+import logging
 import os
 from typing import List
 
@@ -31,6 +32,8 @@ from ... import _native, weights as _weights
 from ...aliked import AlikedHIP
 from ...lightglue import LightGlueHIP
 
+_log = logging.getLogger("opencv_simpleslam_amd")
+
 # Optional upstream checkpoints (no network here): set these to .pth paths
 ENV_ALIKED = "SSLAM_ALIKED_WEIGHTS"          # aliked-n16.pth
 ENV_LIGHTGLUE = "SSLAM_LIGHTGLUE_WEIGHTS"    # aliked_lightglue.pth
@@ -38,12 +41,24 @@ MAX_IMAGE_H = int(os.environ.get("SSLAM_MAX_IMAGE_H", 2160))
 MAX_IMAGE_W = int(os.environ.get("SSLAM_MAX_IMAGE_W", 4096))
 
 
-def _state_dict(env_name, random_fn):
+ENV_ALLOW_RANDOM = "SSLAM_ALLOW_RANDOM_WEIGHTS"
+
+
+def _state_dict(env_name, random_fn, what):
+    """Checkpoint named by `env_name`, else - ONLY when SSLAM_ALLOW_RANDOM_WEIGHTS=1 - seeded random
+    weights of the same architecture, with a WARNING.  The reference never runs untrained: it loads
+    `aliked-n16` / `aliked_lightglue` through torch.hub (features_utils.py:25-26) or fails; dropped into
+    main_revamped.py a silent random fallback would produce garbage tracks without a word."""
     path = os.environ.get(env_name)
     if path:
         return _weights.load_state_dict(path)
-    # The reference downloads the checkpoints through torch.hub; offline we fall back to
-    # seeded random-init weights of the same architecture (synthetic benchmarking only).
+    if os.environ.get(ENV_ALLOW_RANDOM, "") != "1":
+        raise RuntimeError(
+            f"init_feature_pipeline: no {what} checkpoint - set {env_name} to the upstream .pth file (there is no "
+            f"network here to download it as the reference does, features_utils.py:25-26), or set "
+            f"{ENV_ALLOW_RANDOM}=1 to run seeded RANDOM weights (synthetic benchmarking / parity tests only)")
+    _log.warning("%s: %s unset - running seeded RANDOM-INIT weights (%s=1): matches are meaningless on real imagery",
+                 what, env_name, ENV_ALLOW_RANDOM)
     return random_fn(0)
 
 
@@ -52,9 +67,9 @@ def init_feature_pipeline(args):
     if args.use_lightglue:
         max_kpts = int(getattr(args, "max_features", 4000))
         ctx = _native.default_context(int(os.environ.get("LOCAL_RANK", 0)) % max(1, _native.device_count()))
-        detector = AlikedHIP(_state_dict(ENV_ALIKED, _weights.random_aliked_state_dict),
+        detector = AlikedHIP(_state_dict(ENV_ALIKED, _weights.random_aliked_state_dict, "ALIKED (aliked-n16)"),
                              max_num_keypoints=max_kpts, max_h=MAX_IMAGE_H, max_w=MAX_IMAGE_W, ctx=ctx)
-        matcher = LightGlueHIP(_state_dict(ENV_LIGHTGLUE, _weights.random_lightglue_state_dict),
+        matcher = LightGlueHIP(_state_dict(ENV_LIGHTGLUE, _weights.random_lightglue_state_dict, "LightGlue (aliked_lightglue)"),
                                max_kpts=max_kpts, ctx=ctx)
         return detector, matcher
     if not HAVE_CV2:

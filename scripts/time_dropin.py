@@ -1,6 +1,7 @@
 """Per-call latency of the drop-in API exactly as slam/monocular/main_revamped.py drives it
 (host arrays / cv2-style objects in and out, one frame at a time, one stream)."""
-import importlib, sys, time
+import importlib, os, sys, time
+os.environ.setdefault("SSLAM_ALLOW_RANDOM_WEIGHTS", "1")     # no checkpoints in the image: timing on random-init weights
 from pathlib import Path
 from types import SimpleNamespace
 import numpy as np

@@ -39,6 +39,8 @@ def pipeline(fu, gpu_ctx):
     mp = pytest.MonkeyPatch()
     sd = _sd_l()                                                      # built BEFORE the function is patched
     mp.setattr(fu._weights, "random_lightglue_state_dict", lambda seed=0: sd)
+    mp.setenv(fu.ENV_ALLOW_RANDOM, "1")
+    mp.delenv(fu.ENV_ALIKED, raising=False); mp.delenv(fu.ENV_LIGHTGLUE, raising=False)
     args = SimpleNamespace(use_lightglue=True, min_conf=0.05)            # no max_features: the default applies
     det, mat = fu.init_feature_pipeline(args)
     mp.undo()

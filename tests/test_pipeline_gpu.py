@@ -143,3 +143,42 @@ def test_two_rank_pipeline_equals_sequential_api():
                          cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     assert out.stdout.count("pairs identical to the sequential API") == 2
+
+
+def test_pipeline_reports_a_split_precision_range_overflow(native):
+    """the headline path must not hand on matches computed past the fp16 range of the
+    split-precision planes.  Descriptors scaled by 1e5 through the PIPELINE: `results()` / `infos()` raise,
+    the per-instance flags are raised (and cleared by the report), a second matcher instance that never saw
+    the data stays clean, and the next (sane) round is served normally."""
+    W = load_pkg("weights"); fs = load_pkg("frame_shard")
+    AL = load_pkg("aliked").AlikedHIP; LG = load_pkg("lightglue").LightGlueHIP
+    K, H, Wd, B, P = 256, 160, 256, 3, 2
+    sd_a = W.random_aliked_state_dict(0)
+    sd_l = W.random_lightglue_state_dict(1, match_gain=4.0, match_bias=3.0)
+    sd_big = {k: v.clone() for k, v in sd_l.items()}
+    sd_big["input_proj.weight"] = sd_big["input_proj.weight"] * 1e5           # every token state x 1e5
+    dets = [AL(sd_a, max_num_keypoints=K, max_h=H, max_w=Wd, ctx=native.Context(0))]
+    imgs = np.stack([frames.structured_frame(i, h=H, w=Wd) for i in range(B)])
+    for sd, expect in ((sd_big, True), (sd_l, False)):
+        mats = [LG(sd, max_kpts=K, ctx=native.Context(0), max_pairs=P) for _ in range(2)]
+        pipe = fs.FrameStreamPipeline(dets, mats, fs.ShardPlan(1, 0, B), K, 0.0, batch_pairs=P)
+        chunk = pipe.ctx.upload(imgs)
+        pipe.round(chunk, H, Wd, 3)
+        pipe.round(chunk, H, Wd, 3)
+        if expect:
+            with pytest.raises(fs.RangeOverflowError, match="fp16"):
+                pipe.results()
+            assert pipe.range_overflow() is False                    # the report cleared the sticky words
+            pipe.round(chunk, H, Wd, 3)
+            pipe.sync()
+            assert pipe.range_overflow() is True                     # polled without reading results
+            with pytest.raises(fs.RangeOverflowError):
+                pipe.infos()
+        else:
+            res = pipe.results()
+            assert len(res) == B and all(len(ij) > 0 for ij, _ in res[1:])
+            assert pipe.range_overflow() is False
+        pipe.ctx.free(chunk)
+        for m in mats:
+            m.close()
+    dets[0].close()
