@@ -29,6 +29,7 @@
 #include "gemm_f32.hpp"
 #include "gemm_f16x3.hpp"
 #include "gemm_f16x3_big.hpp"
+#include "ffn_fused.hpp"
 
 namespace {
 
@@ -1308,6 +1309,39 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void lg_linear_big_kernel(LinearAr
     linear_h_epilogue<BM, BN, TM, TN, WN, NW * 64, EPI>(p, rd, col0, ibase, c1, c2, lg_ring);
 }
 
+// ---- the whole FFN of a block as one kernel (ffn_fused.hpp): batched token sets.  One workgroup = 64 tokens.
+struct FfnKArgs { sslam::FfnFusedArgs f; const LGCtrl* ctrl; int Kc; };
+
+__global__ __launch_bounds__(512, 2) void lg_ffn_fused_kernel(FfnKArgs p) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lg_ring[];
+    const int nb = p.Kc / sslam::FFN_TOK;                      // Kc is a multiple of 128
+    const int img = blockIdx.x / nb, row0 = (blockIdx.x % nb) * sslam::FFN_TOK;
+    const LGCtrl& pc = ctrl_of(p.ctrl, img);
+    if (pc.stop) return;
+    const int n = pc.n[img & 1];
+    if (row0 >= n) return;
+    const int ibase = img * p.Kc;
+    sslam::ffn_fused_tile(p.f, ibase + row0, ibase + p.Kc, min(sslam::FFN_TOK, n - row0), range_flag_of(p.ctrl, img), lg_ring);
+}
+
+// W1 [512][512] / W2 [256][512] (row-major fp32) -> split planes in the fragment order the fused FFN streams
+__global__ void lg_pack_ffn_kernel(const float* __restrict__ w1, const float* __restrict__ w2, _Float16* __restrict__ w1f,
+                                   _Float16* __restrict__ w2f, int* __restrict__ range_flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 512 * 512) {
+        _Float16 a, b;
+        split_f32(w1[i], a, b, range_flag);
+        w1f[sslam::ffn_w1_frag_index(0, i >> 9, i & 511)] = a;
+        w1f[sslam::ffn_w1_frag_index(1, i >> 9, i & 511)] = b;
+    }
+    if (i < 256 * 512) {
+        _Float16 a, b;
+        split_f32(w2[i], a, b, range_flag);
+        w2f[sslam::ffn_w2_frag_index(0, i >> 9, i & 511)] = a;
+        w2f[sslam::ffn_w2_frag_index(1, i >> 9, i & 511)] = b;
+    }
+}
+
 // LayerNorm(512) + GELU: fp32 hidden in, split planes out (one wave / row)
 __global__ __launch_bounds__(256) void lg_ln_gelu_h_kernel(const float* __restrict__ hid, SplitOut outs,
                                                            const float* __restrict__ gamma,
@@ -2105,6 +2139,7 @@ struct sslam_lightglue {
     int force_ks = 0;                // test hook: key split of the attention launches (0 = by batch size)
     int big_gemm = -1;               // test hook: -1 by batch size, 0 / 1 force the ring / big-tile linears
     _Float16 *w_hi, *w_lo;           // whole weight blob, split
+    _Float16 *ffn_w1f[NL][2], *ffn_w2f[NL][2];   // fused-FFN fragment-order weights, [layer][self / cross]
     _Float16 *xs_hi, *xs_lo, *msgs_hi, *msgs_lo, *hids_hi, *hids_lo;
     _Float16 *qs_hi, *qs_lo, *ks_hi, *ks_lo, *vts_hi, *vts_lo;
     size_t n_blob = 0;
@@ -2295,7 +2330,7 @@ void launch_attention_h(sslam_lightglue* g, hipStream_t s, int NI, SplitPtr Q, S
 }
 
 // one transformer layer (self + cross block) on the split-precision path
-void lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, bool self_only) {
+void lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, int layer, bool self_only) {
     const SplitPtr xs{g->xs_hi, g->xs_lo}, msgs{g->msgs_hi, g->msgs_lo};
     const SplitPtr hids{g->hids_hi, g->hids_lo}, none{nullptr, nullptr};
     const SplitPtr qs{g->qs_hi, g->qs_lo}, ks{g->ks_hi, g->ks_lo}, vts{g->vts_hi, g->vts_lo};
@@ -2307,9 +2342,20 @@ void lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, bo
     // loop) measures 2 % under the 128 x 256 / 8-wave one on the whole forward (9.14 vs 9.36 ms for
     // 8 pairs) although its main loop alone is no faster (scripts/ubench/gemm_big_bench.hip)
     // (3 = the 128 x 128 form with the FFN's LayerNorm + GELU fused into a 64 x 512 whole-row GEMM)
-    const int big = g->big_gemm >= 0 ? g->big_gemm : ((long)NI * g->Kc >= 16384 && g->Kc % 128 == 0 ? 3 : 0);
-    auto ffn = [&](const float* w1, const float* b1, const float* lnw, const float* lnb, const float* w2,
+    // (4 = 128 x 128 projections + the whole FFN as ONE kernel, ffn_fused.hpp: the batched default)
+    const int big = g->big_gemm >= 0 ? g->big_gemm : ((long)NI * g->Kc >= 16384 && g->Kc % 128 == 0 ? 4 : 0);
+    auto ffn = [&](int cross, const float* w1, const float* b1, const float* lnw, const float* lnb, const float* w2,
                    const float* b2) {
+        if (big == 4) {
+            FfnKArgs k{};
+            k.f.xs = xs; k.f.msgs = msgs; k.f.plane_rows = g->NIc * g->Kc;
+            k.f.w1f = g->ffn_w1f[layer][cross]; k.f.b1 = b1; k.f.ln_w = lnw; k.f.ln_b = lnb;
+            k.f.w2f = g->ffn_w2f[layer][cross]; k.f.b2 = b2;
+            k.f.x = g->x; k.f.xo_hi = g->xs_hi; k.f.xo_lo = g->xs_lo; k.f.stamps = nullptr;
+            k.ctrl = g->ctrl; k.Kc = g->Kc;
+            hipLaunchKernelGGL(lg_ffn_fused_kernel, dim3(NI * (g->Kc / sslam::FFN_TOK)), dim3(512), sslam::FFN_LDS_BYTES, s, k);
+            return;
+        }
         LinearArgsH a = linh(g, xs, msgs, D, D, 2 * D, w1, b1, 2 * D);      // [x | attention context]
         a.out = g->hid; a.ldo = 2 * D;
         if (big == 3) {
@@ -2338,7 +2384,7 @@ void lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, bo
         else launch_linear_h<64, 192, 1, 3, EPH_QKV>(s, NI, a);  // 768 / 192 = 4 column tiles
     }
     launch_attention_h(g, s, NI, qs, ks, vts, 0);
-    ffn(l.w1, l.b1, l.lnw, l.lnb, l.w2, l.b2);
+    ffn(0, l.w1, l.b1, l.lnw, l.lnb, l.w2, l.b2);
     if (self_only) return;
     {   // cross block: the shared qk projection is both query and key -> sqrt(scale) on it
         LinearArgsH a = linh(g, xs, none, D, D, D, l.cqkv, l.cbqkv, 2 * D);
@@ -2349,7 +2395,7 @@ void lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, bo
         else launch_linear_h<64, 128, 1, 2, EPH_CROSS>(s, NI, a);
     }
     launch_attention_h(g, s, NI, qs, qs, vts, 1);
-    ffn(l.cw1, l.cb1, l.clnw, l.clnb, l.cw2, l.cb2);
+    ffn(1, l.cw1, l.cb1, l.clnw, l.clnb, l.cw2, l.cb2);
 }
 
 // Enqueue one batch of `pairs` pairs on the context stream.  `src` names the inputs of image
@@ -2378,7 +2424,7 @@ int lg_enqueue(sslam_lightglue* g, int pairs, const StageSrc& src, float min_con
         const LGLayerW& l = g->L[i];
         const bool self_only = g->dbg_self_only && i == g->dbg_layers - 1;
         if (g->precision == 1) {
-            lg_layer_h(g, s, NI, l, self_only);
+            lg_layer_h(g, s, NI, l, i, self_only);
         } else {
             // ---- self block
             {
@@ -2468,6 +2514,7 @@ void lg_configure_kernels() {
     launch_linear_big<128, 128, 2, 2, EPH_F32>(s, 0, cfg); launch_linear_big<128, 128, 2, 2, EPH_RESID>(s, 0, cfg);
     launch_linear_big<128, 128, 2, 2, EPH_QKV>(s, 0, cfg); launch_linear_big<128, 128, 2, 2, EPH_CROSS>(s, 0, cfg);
     launch_linear_big<64, 512, 1, 8, EPH_LNGELU>(s, 0, cfg);
+    (void)hipFuncSetAttribute((const void*)lg_ffn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, sslam::FFN_LDS_BYTES);
 }
 
 // lg_enqueue through the graph cache (device entry points only; never while profiling: the
@@ -2534,6 +2581,11 @@ int sslam_lightglue_create_batched(sslam_ctx* ctx, const float* weights, size_t 
         g->up_xy = A.take<float>(2 * K * 2); g->up_desc = A.take<float>(2 * K * DIN);
         g->out_ij = A.take<int32_t>(2 * K); g->out_score = A.take<float>(K); g->out_info = A.take<int32_t>(8);
         g->w_hi = A.take<_Float16>(n_floats); g->w_lo = A.take<_Float16>(n_floats);
+        for (int i = 0; i < NL; ++i)
+            for (int c = 0; c < 2; ++c) {
+                g->ffn_w1f[i][c] = A.take<_Float16>((size_t)2 * 4 * D * D);
+                g->ffn_w2f[i][c] = A.take<_Float16>((size_t)2 * 2 * D * D);
+            }
         g->xs_hi = A.take<_Float16>(NI * K * D); g->xs_lo = A.take<_Float16>(NI * K * D);
         g->msgs_hi = A.take<_Float16>(NI * K * D); g->msgs_lo = A.take<_Float16>(NI * K * D);
         g->hids_hi = A.take<_Float16>(NI * K * 2 * D); g->hids_lo = A.take<_Float16>(NI * K * 2 * D);
@@ -2560,6 +2612,10 @@ int sslam_lightglue_create_batched(sslam_ctx* ctx, const float* weights, size_t 
             const LGLayerW& l = g->L[i];
             splitw(l.wqkv, 3 * D, D); splitw(l.w1, 2 * D, 2 * D); splitw(l.w2, D, 2 * D);
             splitw(l.cqkv, 2 * D, D); splitw(l.cw1, 2 * D, 2 * D); splitw(l.cw2, D, 2 * D);
+            hipLaunchKernelGGL(lg_pack_ffn_kernel, dim3(4 * D * D / 256), dim3(256), 0, ctx->stream, l.w1, l.w2,
+                               g->ffn_w1f[i][0], g->ffn_w2f[i][0], g->range_sticky);
+            hipLaunchKernelGGL(lg_pack_ffn_kernel, dim3(4 * D * D / 256), dim3(256), 0, ctx->stream, l.cw1, l.cw2,
+                               g->ffn_w1f[i][1], g->ffn_w2f[i][1], g->range_sticky);
         }
         int wflag = 0;
         if (int rc = lg_take_range_flag(g, &wflag)) { g->arena.release(); delete g; return rc; }
@@ -2770,7 +2826,7 @@ int sslam_lightglue_debug_key_split(sslam_lightglue* g, int ks) {
 /* Test hook: -1 = linears chosen by batch size, 0 = always the 64-row ring kernel, 1 = always the
  * 128 x 256 big-tile kernel. */
 int sslam_lightglue_debug_big_gemm(sslam_lightglue* g, int mode) {
-    SSLAM_REQUIRE(g != nullptr && mode >= -1 && mode <= 3, "sslam_lightglue_debug_big_gemm: bad argument");
+    SSLAM_REQUIRE(g != nullptr && mode >= -1 && mode <= 4, "sslam_lightglue_debug_big_gemm: bad argument");
     g->settings_changed();
     g->big_gemm = mode;
     return 0;

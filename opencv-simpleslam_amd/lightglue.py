@@ -125,7 +125,8 @@ class LightGlueHIP:
 
     def debug_big_gemm(self, mode: int):
         """Test hook: -1 linears by batch size, 0 always the ring kernel, 1 the 128 x 256 big-tile kernel,
-        2 the 128 x 128 one, 3 the 128 x 128 one with LayerNorm + GELU fused into the first FFN GEMM."""
+        2 the 128 x 128 one, 3 the 128 x 128 one with LayerNorm + GELU fused into the first FFN GEMM, 4 the 128 x 128
+        projections + the whole FFN as one kernel (the default of a batched call)."""
         _native.check(_native.lib().sslam_lightglue_debug_big_gemm(self.handle, int(mode)))
 
     def debug_read(self, which: int, shape, dtype=np.float32):

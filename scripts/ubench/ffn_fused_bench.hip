@@ -47,15 +47,20 @@ int main(int argc, char** argv) {
             split_host(x[(size_t)r * 256 + c], xh[pidx(r, c, M)], xl[pidx(r, c, M)]);
             split_host(msg[(size_t)r * 256 + c], mh[pidx(r, c, M)], ml[pidx(r, c, M)]);
         }
-    std::vector<_Float16> w1h(512 * 512), w1l(512 * 512), w2f(2 * 256 * 512);
+    std::vector<_Float16> w1f(2 * 512 * 512), w2f(2 * 256 * 512);
     for (int j = 0; j < 512; ++j)
-        for (int k = 0; k < 512; ++k) split_host(W1[j * 512 + k], w1h[pidx(j, k, 512)], w1l[pidx(j, k, 512)]);
+        for (int k = 0; k < 512; ++k) {
+            _Float16 a, b;
+            split_host(W1[j * 512 + k], a, b);
+            w1f[ffn_w1_frag_index(0, j, k)] = a;
+            w1f[ffn_w1_frag_index(1, j, k)] = b;
+        }
     for (int n = 0; n < 256; ++n)
         for (int j = 0; j < 512; ++j) {
             _Float16 a, b;
             split_host(W2[n * 512 + j], a, b);
-            w2f[ffn_w2_fused_index(0, n, j)] = a;
-            w2f[ffn_w2_fused_index(1, n, j)] = b;
+            w2f[ffn_w2_frag_index(0, n, j)] = a;
+            w2f[ffn_w2_frag_index(1, n, j)] = b;
         }
     auto up = [&](const void* h, size_t bytes) { void* d = nullptr; hipMalloc(&d, bytes); hipMemcpy(d, h, bytes, hipMemcpyHostToDevice); return d; };
     FfnFusedArgs a{};
@@ -63,7 +68,7 @@ int main(int argc, char** argv) {
     a.xs = SplitPtr{d_xh, d_xl};
     a.msgs = SplitPtr{(_Float16*)up(mh.data(), mh.size() * 2), (_Float16*)up(ml.data(), ml.size() * 2)};
     a.plane_rows = M;
-    a.w1 = SplitPtr{(_Float16*)up(w1h.data(), w1h.size() * 2), (_Float16*)up(w1l.data(), w1l.size() * 2)};
+    a.w1f = (_Float16*)up(w1f.data(), w1f.size() * 2);
     a.b1 = (float*)up(b1.data(), 2048); a.ln_w = (float*)up(lw.data(), 2048); a.ln_b = (float*)up(lb.data(), 2048);
     a.w2f = (_Float16*)up(w2f.data(), w2f.size() * 2);
     a.b2 = (float*)up(b2.data(), 1024);
@@ -136,9 +141,8 @@ int main(int argc, char** argv) {
     {   // phase shares from the in-kernel stamps of the last launch (median over workgroups, shader cycles)
         std::vector<unsigned long long> st((size_t)grid * 8);
         CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
-        const char* names[7] = {"prologue (consts, 2 tiles issued, tile 0 landed)", "phase 1 k-loop (16 k-tiles)", "LayerNorm + GELU + split",
-                                "phase-2 prologue (barrier, step 0 landed)", "phase 2, first quarter k-loop (4 steps)", "K-split reduction of a quarter",
-                                "rest (quarter epilogue + 3 more quarters)"};
+        const char* names[7] = {"prologue (W1 prefetch, operand tile by DMA, barrier)", "phase 1 k-loop (32 steps)", "LayerNorm + GELU + split + hidden to LDS",
+                                "phase 2 k-loop (32 steps)", "epilogue: residual loads, y staged through LDS", "epilogue: row units, stores", "-"};
         for (int i = 0; i < 7; ++i) {
             std::vector<double> d;
             for (int b = 0; b < grid; ++b) d.push_back((double)(st[b * 8 + i + 1] - st[b * 8 + i]));

@@ -102,6 +102,14 @@ def test_big_tile_linears_give_the_ring_kernel_results_bit_for_bit(gpu_ctx):
         big2 = dev.run(batch, 0.0)
         batch.debug_big_gemm(3)                       # + LayerNorm / GELU inside the first FFN GEMM (64 x 512 whole-row tiles)
         big3 = dev.run(batch, 0.0)
+        batch.debug_big_gemm(4)                       # the whole FFN as one kernel (ffn_fused.hpp): the batched default
+        fused = dev.run(batch, 0.0)
+        for (a_ij, a_sc, a_info), (f_ij, f_sc, f_info) in zip(big, fused):
+            # same products, but the LayerNorm statistics are summed in another order (registers of a lane, then
+            # lanes, then waves): indices and control flow identical, scores to fp32 rounding
+            np.testing.assert_array_equal(a_ij, f_ij)
+            np.testing.assert_array_equal(a_info, f_info)
+            np.testing.assert_allclose(a_sc, f_sc, rtol=0, atol=2e-4)      # (vs the oracle the bar is 1e-3)
         for a, b, c in zip(big, big2, big3):
             np.testing.assert_array_equal(a[0], b[0]); np.testing.assert_array_equal(a[1], b[1])
             np.testing.assert_array_equal(a[0], c[0]); np.testing.assert_array_equal(a[1], c[1])
