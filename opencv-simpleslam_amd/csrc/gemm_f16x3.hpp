@@ -207,7 +207,7 @@ __device__ __forceinline__ void gemm_mainloop_h(const GemmAH& ga, SplitPtr W, in
 #endif
 constexpr int PANEL_K = SSLAM_PANEL_K;
 static_assert(PANEL_K == 32 || PANEL_K == 64, "k-panel width");
-__device__ __forceinline__ size_t panel_index(int row, int col, int rows_total) {
+__host__ __device__ __forceinline__ size_t panel_index(int row, int col, int rows_total) {
     return ((size_t)(col / PANEL_K) * rows_total + row) * PANEL_K + (col % PANEL_K);
 }
 // offset (halves) of 16-byte chunk `c8` (0..7) of `row` inside the 64-deep k-tile `kt64`

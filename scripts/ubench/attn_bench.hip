@@ -41,6 +41,7 @@ int main(int argc, char** argv) {
     const int ppm = getenv("ATTN_PP") ? atoi(getenv("ATTN_PP")) : 0;
     const bool pp = ppm == 1 && KS == 1;     // 8-wave ping-pong form
     const bool w1 = ppm == 2 && KS == 1;     // one wave per SIMD, hand-placed gaps
+    const bool hs = ppm == 3 && KS == 1;     // half-step form (fragment reads half a sub-step ahead)
     if (getenv("ATTN_CMP") && KS == 1) {
         // compare the hi / lo context planes of the variant against the 4-wave kernel on the same operands
         std::vector<_Float16> ref_hi(plane), ref_lo(plane), got_hi(plane), got_lo(plane);
@@ -50,17 +51,18 @@ int main(int argc, char** argv) {
         hipMemcpy(ref_hi.data(), buf[6], plane * 2, hipMemcpyDeviceToHost); hipMemcpy(ref_lo.data(), buf[7], plane * 2, hipMemcpyDeviceToHost);
         hipMemset(buf[6], 0, plane * 2); hipMemset(buf[7], 0, plane * 2);
         if (w1) hipLaunchKernelGGL(lg_attention_w1_kernel, dim3(sslam::cdiv(Kc, AQ2), NI * NH), dim3(256), 0, 0, a);
+        else if (hs) hipLaunchKernelGGL(lg_attention_hs_kernel, dim3(sslam::cdiv(Kc, AQ), NI * NH), dim3(256), 0, 0, a);
         else hipLaunchKernelGGL(lg_attention_pp_kernel, dim3(sslam::cdiv(Kc, AQ2), NI * NH), dim3(512), 0, 0, a);
         hipDeviceSynchronize();
         printf("variant launch: %s\n", hipGetErrorString(hipGetLastError()));
         hipMemcpy(got_hi.data(), buf[6], plane * 2, hipMemcpyDeviceToHost); hipMemcpy(got_lo.data(), buf[7], plane * 2, hipMemcpyDeviceToHost);
-        // panel layout: plane[k / 64][row][k % 64] over NI * Kc rows, k = head * 64 + d
+        // panel layout: plane[k / PANEL_K][row][k % PANEL_K] over NI * Kc rows, k = head * 64 + d
         size_t bad = 0; double worst = 0; int shown = 0;
         const size_t rows = (size_t)NI * Kc;
         for (size_t pnl = 0; pnl < 4; ++pnl)
             for (size_t row = 0; row < rows; ++row)
                 for (int d = 0; d < 64; ++d) {
-                    const size_t o = (pnl * rows + row) * 64 + d;
+                    const size_t o = sslam::panel_index((int)row, (int)(pnl * 64 + d), (int)rows);
                     const double r = (double)ref_hi[o] + (double)ref_lo[o] / 2048.0, g = (double)got_hi[o] + (double)got_lo[o] / 2048.0;
                     const double e = fabs(r - g);
                     if (!(e <= 1e-6 + 1e-5 * fabs(r))) {
@@ -74,6 +76,7 @@ int main(int argc, char** argv) {
     }
     auto launch = [&] {
         if (w1) hipLaunchKernelGGL(lg_attention_w1_kernel, dim3(sslam::cdiv(Kc, AQ2), NI * NH), dim3(256), 0, 0, a);
+        else if (hs) hipLaunchKernelGGL(lg_attention_hs_kernel, dim3(sslam::cdiv(Kc, AQ), NI * NH), dim3(256), 0, 0, a);
         else if (pp) hipLaunchKernelGGL(lg_attention_pp_kernel, dim3(sslam::cdiv(Kc, AQ2), NI * NH), dim3(512), 0, 0, a);
         else hipLaunchKernelGGL(lg_attention_p_kernel, grid, dim3(256), 0, 0, a);
     };
@@ -91,7 +94,7 @@ int main(int argc, char** argv) {
     std::sort(t.begin(), t.end());
     const double fl = 8.0 * N * (double)N * 256 * B;
     printf("%s N=%d pairs=%d KS=%d abl=%d sched=%d: median %.1f us/launch (min %.1f) = %.2f us per pair, %.0f TF alg, executed %.1f%% of the f16 peak; err=%s\n",
-           w1 ? "[w1]" : pp ? "[pp]" : "[p4]", N, B, KS, ATTN_ABL,
+           w1 ? "[w1]" : hs ? "[hs]" : pp ? "[pp]" : "[p4]", N, B, KS, ATTN_ABL,
 #ifdef ATTN_SCHED
            ATTN_SCHED,
 #else

@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void lg_attention_w1_kernel(AttnArgsH p) {
                     const float v = half ? (o1b[4 * g4 + e] + o2b[4 * g4 + e] * SPLIT_INV)
                                          : (o1a[4 * g4 + e] + o2a[4 * g4 + e] * SPLIT_INV);
                     _Float16 a, b2;
-                    split_f32(v * inv, a, b2);
+                    split_f32(v * inv, a, b2, range_flag_of(p.ctrl, img));
                     hh[e] = a; ll[e] = b2;
                 }
                 const size_t o = panel_index(prow, head * DH + 32 * half + 8 * g4 + 4 * h, p.NIc * p.Kc);
