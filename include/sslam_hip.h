@@ -229,7 +229,8 @@ int sslam_lightglue_match_host(sslam_lightglue* lg, const float* xy0, const floa
 /* Device-pointer variant; enqueue only.  M, N bound the rows of the input arrays; m_dev /
  * n_dev (device int32[1], may be NULL) carry the actual keypoint counts when they are only
  * known on the device (written by sslam_aliked_extract_dev), so an extract -> match chain
- * needs no host round trip.  info_out[4] (device) = {K, stop_layer, n0, n1 after pruning}. */
+ * needs no host round trip.  info_out[4] (device) = {K, stop_layer, n0, n1 after pruning}; K = -1: range
+ * overflow of the split-precision path (see sslam_lightglue_range_overflow). */
 int sslam_lightglue_match_dev(sslam_lightglue* lg, const float* xy0, const float* desc0, int M,
                               const float* xy1, const float* desc1, int N, const int32_t* m_dev,
                               const int32_t* n_dev, float min_conf, int32_t* ij_out, float* score_out,
@@ -251,10 +252,12 @@ int sslam_lightglue_match_batch_dev(sslam_lightglue* lg, int n_pairs, const floa
  * per distinct argument tuple; ~190 launches become one hipGraphLaunch).  Same results. */
 int sslam_lightglue_use_graphs(sslam_lightglue* lg, int enable);
 /* The split-precision path carries fp32 values as fp16 plane pairs: a FINITE activation with
- * |value| >= 65520 does not fit (the exact-fp32 path, precision 0, has no such limit).  Such a value
- * is flagged on the device (and saturated or turned non-finite, never silently wrapped); sslam_lightglue_match_host fails with a message when the
- * flag is set, callers of the _dev / _batch_dev entries poll it here (synchronises the stream,
- * returns and clears the flag). */
+ * |value| >= 65520 does not fit (the exact-fp32 path, precision 0, has no such limit).  Such a value is flagged
+ * on the device PER PAIR (and saturated or turned non-finite, never silently wrapped): that pair's match count
+ * info_out[0] becomes -1, so the verdict travels with the result (sslam_fmat_ransac_dev clamps it to 0 matches);
+ * sslam_lightglue_match_host fails with a message.  The instance also keeps a sticky word of its own (never
+ * shared with other instances): callers of the _dev / _batch_dev entries that do not read info_out poll it
+ * here (synchronises the stream, returns and clears it). */
 int sslam_lightglue_range_overflow(sslam_lightglue* lg, int* flag_out);
 /* Measurement hook (bench.py): bracket each attention launch - the dominant kernel - with HIP
  * events on the context stream; _read synchronises and returns their summed duration and count. */

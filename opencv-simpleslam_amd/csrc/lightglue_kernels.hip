@@ -3,10 +3,13 @@
 // Replaces `matcher({...})` at slam/core/features_utils.py:157-162 (the
 // cvg/LightGlue forward) plus the confidence filter at :164-169.
 //
-// Numeric type: fp32 end to end.  Every contraction (linear layers, QK^T, PV,
-// the final similarity) runs on the exact-fp32 matrix core instruction
-// v_mfma_f32_32x32x2_f32, so results differ from a torch-CPU fp32 run only by
-// summation order; the roofline is the fp32 MFMA peak (157.3 TFLOP/s).
+// Numeric type: fp32 RESULTS, two selectable arithmetic paths (sslam_lightglue_set_precision):
+//   0  every contraction on the exact-fp32 matrix-core instruction v_mfma_f32_32x32x2_f32 (differs from a
+//      torch-CPU fp32 run only by summation order; 157.3 TFLOP/s peak);
+//   1  (default) split precision: an fp32 operand is two fp16 planes a = hi + lo 2^-11, a product is three
+//      v_mfma_f32_32x32x16_f16 into fp32 accumulators (gemm_f16x3.hpp); the roofline is the dense f16 MFMA
+//      peak (2.5 PFLOP/s), of which an algorithmic product can reach at most a third.  The final
+//      assignment (final_proj, similarity, dual softmax, arg-max) stays on the exact-fp32 path in both modes.
 //
 // BATCH.  One enqueue processes up to NB pairs at once (`sslam_lightglue_match_batch_dev`): pair p
 // owns images 2p (query side) and 2p+1; every token buffer is image-major over NI = 2 NB images and
@@ -18,7 +21,7 @@
 //   enc    [NI][Kc][32]    cos / sin of the Fourier positional projection
 //   q,k,v  [NI][4][Kc][64] head-major, rotary already applied to q,k
 //   msg    [NI][Kc][256]   attention context / message
-//   hid    [NI][Kc][512]   FFN hidden
+//   hid    [NI][Kc][512]   FFN hidden (single-pair path only: the batched FFN keeps it on chip, ffn_fused.hpp)
 //   sim    [NB][Kc][Kc]    final similarity
 // Control flow that the reference decides on the host per layer (early stop,
 // point pruning) lives in a device-side control block `LGCtrl` PER PAIR; every kernel
@@ -993,7 +996,7 @@ __global__ __launch_bounds__(256) void lg_split_rows_kernel(const float* __restr
 }
 constexpr int SPLIT_BLOCKS_PER_IMAGE = 64;
 
-enum { EPH_QKV = 0, EPH_CROSS = 1, EPH_SPLIT = 2, EPH_F32 = 3, EPH_RESID = 4, EPH_LNGELU = 5 };
+enum { EPH_QKV = 0, EPH_CROSS = 1, EPH_SPLIT = 2, EPH_F32 = 3, EPH_RESID = 4 };
 
 struct LinearArgsH {
     SplitPtr A0, A1; int lda; int K0; int K;
@@ -1003,7 +1006,6 @@ struct LinearArgsH {
     SplitOut q, k, vt;                 // QKV / CROSS destinations
     float q_scale, k_scale;
     const float* enc_cos; const float* enc_sin;
-    const float* ln_w; const float* ln_b;  // LNGELU: LayerNorm(512) affine of the fused FFN epilogue
     const LGCtrl* ctrl; int Kc; int NIc;   // NIc: image capacity of the instance (plane rows = NIc * Kc)
 };
 
@@ -1099,49 +1101,6 @@ __device__ __forceinline__ void linear_h_epilogue(const LinearArgsH& p, const Ro
             }
         }
     __syncthreads();
-
-    if constexpr (EPI == EPH_LNGELU) {
-        // The tile holds WHOLE rows of the FFN hidden (BN = 512): LayerNorm + GELU + split right here,
-        // one wave per row, the arithmetic of lg_ln_gelu_h_kernel in its order (bit-identical planes);
-        // the fp32 hidden never goes to HBM (67 MB written + 67 MB read back per 8-pair launch before).
-        static_assert(EPI != EPH_LNGELU || BN == 512, "LayerNorm needs the whole 512-wide row in one tile");
-        const int nw = NT / 64;
-        const float4 ga = *reinterpret_cast<const float4*>(p.ln_w + lane * 4), gb = *reinterpret_cast<const float4*>(p.ln_w + 256 + lane * 4);
-        const float4 ba = *reinterpret_cast<const float4*>(p.ln_b + lane * 4), bb = *reinterpret_cast<const float4*>(p.ln_b + 256 + lane * 4);
-        const float gm[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
-        const float bt[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
-        for (int rl = wave; rl < BM; rl += nw) {
-            const int row = rd.row0 + rl;
-            if (row >= rd.n) break;                    // wave-uniform
-            const float4 a = *reinterpret_cast<const float4*>(&epi[rl * ELD + lane * 4]);
-            const float4 b = *reinterpret_cast<const float4*>(&epi[rl * ELD + 256 + lane * 4]);
-            float sum = (a.x + a.y) + (a.z + a.w) + (b.x + b.y) + (b.z + b.w);
-            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-            const float mean = sum / 512.0f;
-            float v[8] = {a.x - mean, a.y - mean, a.z - mean, a.w - mean, b.x - mean, b.y - mean, b.z - mean, b.w - mean};
-            float q = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) q += v[i] * v[i];
-            for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-            const float rstd = 1.0f / sqrtf(q / 512.0f + 1e-5f);
-            half4 h0, l0, h1, l1;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float y = v[i] * rstd * gm[i] + bt[i];
-                const float gl = 0.5f * y * (1.0f + erf_as(y * 0.70710678118654752440f));
-                _Float16 hh, ll;
-                split_f32(gl, hh, ll, range_flag_of(p.ctrl, rd.img));
-                if (i < 4) { h0[i] = hh; l0[i] = ll; } else { h1[i - 4] = hh; l1[i - 4] = ll; }
-            }
-            const int prow = (int)ibase + row;
-            const size_t p0 = panel_index(prow, lane * 4, p.NIc * p.Kc), p1 = panel_index(prow, 256 + lane * 4, p.NIc * p.Kc);
-            *reinterpret_cast<half4*>(p.outs.hi + p0) = h0;
-            *reinterpret_cast<half4*>(p.outs.lo + p0) = l0;
-            *reinterpret_cast<half4*>(p.outs.hi + p1) = h1;
-            *reinterpret_cast<half4*>(p.outs.lo + p1) = l1;
-        }
-        return;
-    }
 
 #ifndef LG_EPI_FAST_SPLIT
 #define LG_EPI_FAST_SPLIT 1    // A/B switch (scripts/ab_lib.sh): 0 = the branchy scalar split_f32 per value
@@ -1278,16 +1237,9 @@ __global__ __launch_bounds__(512) void lg_linear_h_kernel(LinearArgsH p) {
     linear_h_epilogue<BM, BN, TM, TN, 2, 256, EPI>(p, rd, col0, ibase, c1, c2, lg_ring);
 }
 
-// Big-tile form for batched token sets (gemm_f16x3_big.hpp): WM x WN waves, each loads and multiplies.
-// 8 waves: 128 x 256 tile, 3-stage ring, DMA spread between MFMAs, one workgroup per CU.
-// 4 waves: 128 x 128 tile, 2-stage ring, TWO workgroups per CU (one's epilogue runs under the other's
-// main loop).
-// main-loop form / ring depth by tile: 8 waves on a 128-row tile run the DMA-spread form on 3 stages,
-// 4 waves the lock-step form on 2; the 64 x 512 whole-row tile (fused LayerNorm) has a short A tile
-// (lock-step form) and 74 KB stages (2 of them)
-template <int BM, int WM, int WN> constexpr int big_variant() { return (WM * WN == 8 && BM >= 128) ? 3 : 0; }
-template <int BM, int WM, int WN> constexpr int big_stages() { return (WM * WN == 8 && BM >= 128) ? 3 : 2; }
-
+// Big-tile form for batched token sets (gemm_f16x3_big.hpp): 128 x 128 tile, 4 waves (2 x 2), 2-stage ring,
+// TWO workgroups per CU (one's epilogue runs under the other's main loop).  Used by the two projections of a
+// block (QKV, shared-qk cross); the FFN is one kernel of its own (ffn_fused.hpp).
 template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(WM * WN * 64, 2) void lg_linear_big_kernel(LinearArgsH p) {
     extern __shared__ __attribute__((aligned(16))) _Float16 lg_ring[];
@@ -1304,8 +1256,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void lg_linear_big_kernel(LinearAr
     GemmAH ga{{p.A0.hi, p.A0.lo}, {p.A1.hi ? p.A1.hi : p.A0.hi, p.A1.lo ? p.A1.lo : p.A0.lo}, p.lda, p.K0};
     f32x16 c1[TM][TN], c2[TM][TN];
     constexpr int NW = WM * WN;
-    sslam::gemm_mainloop_big<BM, BN, WM, WN, big_variant<BM, WM, WN>(), big_stages<BM, WM, WN>()>(
-        ga, p.W, p.NIc * p.Kc, p.K, (int)ibase + rd.row0, (int)ibase + p.Kc, col0, p.N, lg_ring, c1, c2);
+    sslam::gemm_mainloop_big<BM, BN, WM, WN>(ga, p.W, p.NIc * p.Kc, p.K, (int)ibase + rd.row0, (int)ibase + p.Kc, col0,
+                                             p.N, lg_ring, c1, c2);
     linear_h_epilogue<BM, BN, TM, TN, WN, NW * 64, EPI>(p, rd, col0, ibase, c1, c2, lg_ring);
 }
 
@@ -1422,39 +1374,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 // high plane then leaves the normal range only below 2^-28 of the row maximum, so the split needs
 // no subnormal guard (MFMA flushes fp16 subnormal operands).
 constexpr float P_BIAS = 14.0f;
-// scheduling recipe for one sub-step's basic block: 24 x { 1 MFMA, ATTN_VALU_PER_MFMA VALU }
-#ifndef ATTN_VALU_PER_MFMA
-#define ATTN_VALU_PER_MFMA 8
-#endif
-#if ATTN_VALU_PER_MFMA > 0
-// ATTN_SCHED (experiments, scripts/ubench/attn_bench.hip): 0 = {1 MFMA, V VALU} x 24 (fragment reads
-// left to the scheduler), 1 = the 16 fragment reads of a sub-step asked for one MFMA ahead of their consumer
-#ifndef ATTN_SCHED
-#define ATTN_SCHED 0
-#endif
-#if ATTN_SCHED == 1
-#define ATTN_INTERLEAVE()                                                     \
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                        \
-    _Pragma("unroll") for (int ig_ = 0; ig_ < 24; ++ig_) {                    \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    \
-        if (ig_ < 14) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      \
-        __builtin_amdgcn_sched_group_barrier(0x002, ATTN_VALU_PER_MFMA, 0);   \
-    }
-#else
+// scheduling recipe for one sub-step's basic block: 24 x { 1 MFMA, 8 VALU } (5 / 0 VALU per MFMA and a
+// fragment-read-ahead recipe measured within 1 %: profiles/r02_attention_experiments.md)
 #define ATTN_INTERLEAVE()                                                     \
     _Pragma("unroll") for (int ig_ = 0; ig_ < 24; ++ig_) {                    \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    \
-        __builtin_amdgcn_sched_group_barrier(0x002, ATTN_VALU_PER_MFMA, 0);   \
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                    \
     }
-#endif
-#else
-#define ATTN_INTERLEAVE()
-#endif
 typedef float float2v __attribute__((ext_vector_type(2)));
 
-#ifndef ATTN_PLO_TRUE
-#define ATTN_PLO_TRUE 1
-#endif
 
 // Deferred rescale (flash-attention "lazy max"): the running maximum - and with it the 64
 // accumulator registers of O - is only updated when some query of the wave sees a logit more than
@@ -1506,7 +1434,6 @@ __device__ __forceinline__ void attn_softmax_step(const f32x16& s1, const f32x16
     // that large only come from absurdly scaled inputs, but the answer must still be a softmax: the
     // bias is dropped there (P <= 2^1.5; the common factor cancels in o / l either way).
     const float mb = fabsf(m_run) < 4.0e6f ? m_run - P_BIAS : m_run;
-#if ATTN_PLO_TRUE
     // The low plane of P is kept UNSCALED: pl = fp16(p - ph), one mixed-precision fma per element
     // (v_fma_mixlo/hi_f16) instead of convert-back, subtract, scale, convert.  An fp16 subnormal
     // operand is flushed by the MFMA, so the low part is lost where p - ph < 2^-14, i.e. for
@@ -1533,66 +1460,12 @@ __device__ __forceinline__ void attn_softmax_step(const f32x16& s1, const f32x16
     ph[0] = __builtin_bit_cast(half8, hu[0]); ph[1] = __builtin_bit_cast(half8, hu[1]);
     pl[0] = __builtin_bit_cast(half8, lu[0]); pl[1] = __builtin_bit_cast(half8, lu[1]);
     l_run = l_run * alpha + (psum0 + psum1);
-#else
-    const float2v mb2 = {mb, mb};
-    float2v psum = {0.0f, 0.0f};
-    const float2v sc2 = {sslam::SPLIT_SCALE, sslam::SPLIT_SCALE};
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const float2v d = sv[r] - mb2;
-        float2v pv;
-        pv[0] = __builtin_amdgcn_exp2f(d[0]);
-        pv[1] = __builtin_amdgcn_exp2f(d[1]);
-        psum += pv;
-        const sslam::half2v hh = __builtin_convertvector(pv, sslam::half2v);
-        const float2v back = __builtin_convertvector(hh, float2v);
-        const float2v res = (pv - back) * sc2;
-        const sslam::half2v ll = __builtin_convertvector(res, sslam::half2v);
-        ph[r >> 2][2 * (r & 3)] = hh[0]; ph[r >> 2][2 * (r & 3) + 1] = hh[1];
-        pl[r >> 2][2 * (r & 3)] = ll[0]; pl[r >> 2][2 * (r & 3) + 1] = ll[1];
-    }
-    l_run = l_run * alpha + (psum[0] + psum[1]);
-#endif
 }
 
-#ifndef ATTN_ABL
-#define ATTN_ABL 0          // experiments: 1 no MFMA, 2 no softmax, 4 no LDS fragment reads, 8 no tile DMA in the loop
-#endif
-#if ATTN_ABL & 1
-__device__ __forceinline__ f32x16 mf_fake(half8 a, half8 b, f32x16 c) { c[0] += (float)a[0] * (float)b[0]; return c; }
-#define MF mf_fake
-#else
-#define MF mfma16
-#endif
-#if ATTN_ABL & 2
-template <bool MASK>
-__device__ __forceinline__ void softmax_fake(const f32x16& s1, const f32x16& s2, int, int, int, float& m_run, float& l_run,
-                                             half8 (&ph)[2], half8 (&pl)[2], float& alpha, bool& rescale, bool) {
-    for (int i = 0; i < 2; ++i) for (int e = 0; e < 8; ++e) { ph[i][e] = (_Float16)s1[8 * i + e]; pl[i][e] = (_Float16)s2[8 * i + e]; }
-    m_run = 0.0f; l_run += 1.0f; alpha = 1.0f; rescale = false;
-}
-#define SOFTMAX_STEP softmax_fake
-#else
-#define SOFTMAX_STEP attn_softmax_step
-#endif
-// The O rescale is a (wave-uniform, rarely taken) branch at the END of a sub-step's block.  Without a
-// use in front of it, LLVM's machine-sink moves the half of the softmax whose results (P, l) are only
-// consumed by the NEXT sub-step across that branch into the successor block - where it runs with no
-// MFMA beside it - and leaves this block's 24 MFMAs with almost no VALU to interleave.  An empty asm
-// that reads P and l pins the whole softmax in front of the branch, inside the block the
-// sched_group_barrier recipe shapes.
-#ifndef ATTN_PIN
-#define ATTN_PIN 0          // measured: 243 us per 8-pair launch pinned vs 236 unpinned (the partner wave, not the placement, sets the time)
-#endif
-#if ATTN_PIN
-#define ATTN_PIN_USE(ph_, pl_, l_) asm volatile("" :: "v"(ph_[0]), "v"(ph_[1]), "v"(pl_[0]), "v"(pl_[1]), "v"(l_))
-#else
-#define ATTN_PIN_USE(ph_, pl_, l_)
-#endif
-#ifndef ATTN_WAVES_PER_SIMD
-#define ATTN_WAVES_PER_SIMD 2
-#endif
-__global__ __launch_bounds__(256, ATTN_WAVES_PER_SIMD) void lg_attention_p_kernel(AttnArgsH p) {
+// (r02 measured this kernel with ablation builds - no MFMA / no softmax / no fragment reads / no tile DMA -, a
+// pinned-softmax variant, a scaled low plane of P and an 8-wave ping-pong form: all recorded in
+// profiles/r02_attention_experiments.md; the switches and the ping-pong kernel now live in scripts/ubench/.)
+__global__ __launch_bounds__(256, 2) void lg_attention_p_kernel(AttnArgsH p) {
     __shared__ AttnSmemH sm;
     const int nqb = gridDim.x, nslab = gridDim.y * gridDim.z;
     int slab, qb;
@@ -1601,11 +1474,7 @@ __global__ __launch_bounds__(256, ATTN_WAVES_PER_SIMD) void lg_attention_p_kerne
         if ((nslab & 7) == 0) { const int xcd = b & 7, idx = b >> 3; slab = xcd + 8 * (idx / nqb); qb = idx % nqb; }
         else { slab = blockIdx.z * gridDim.y + blockIdx.y; qb = blockIdx.x; }
     }
-#ifdef ATTN_BATCH_EMU      // ubench only: gridDim.y = 8 * batch, every batch entry aliases the same operands
-    const int z = slab / gridDim.y, ih = (slab % gridDim.y) & 7;
-#else
     const int z = slab / gridDim.y, ih = slab % gridDim.y;
-#endif
     const int img = ih >> 2, head = ih & 3;
     if (ctrl_of(p.ctrl, img).stop) return;
     const int kimg = p.cross ? (img ^ 1) : img;
@@ -1615,11 +1484,7 @@ __global__ __launch_bounds__(256, ATTN_WAVES_PER_SIMD) void lg_attention_p_kerne
     const int t = threadIdx.x, lane = t & 63, h = lane >> 5, lr = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int ntiles = (nk + AK - 1) / AK;
-#if ATTN_ABL & 32
-    const int t0 = (int)((long)z * ntiles / p.KS), t1 = min(t0 + 1, (int)((long)(z + 1) * ntiles / p.KS));
-#else
     const int t0 = (int)((long)z * ntiles / p.KS), t1 = (int)((long)(z + 1) * ntiles / p.KS);
-#endif
 
     const size_t qoff = ((size_t)img * NH + head) * p.Kc * DH;
     const size_t koff = ((size_t)kimg * NH + head) * p.Kc * DH;
@@ -1675,15 +1540,11 @@ __global__ __launch_bounds__(256, ATTN_WAVES_PER_SIMD) void lg_attention_p_kerne
     auto qk = [&](int buf, int sub, f32x16& s1, f32x16& s2) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-#if ATTN_ABL & 4
-            const half8 kh = qh[(s + 1) & 3], kl = ql[(s + 2) & 3];
-#else
             const half8 kh = *reinterpret_cast<const half8*>(&sm.k_hi[buf][koffs[sub][s]]);
             const half8 kl = *reinterpret_cast<const half8*>(&sm.k_lo[buf][koffs[sub][s]]);
-#endif
-            s1 = MF(kh, qh[s], s == 0 ? zero16 : s1);
-            s2 = MF(kh, ql[s], s == 0 ? zero16 : s2);
-            s2 = MF(kl, qh[s], s2);
+            s1 = mfma16(kh, qh[s], s == 0 ? zero16 : s1);
+            s2 = mfma16(kh, ql[s], s == 0 ? zero16 : s2);
+            s2 = mfma16(kl, qh[s], s2);
         }
     };
     auto pv = [&](int buf, int sub, const half8 (&ph)[2], const half8 (&pl)[2]) {
@@ -1691,34 +1552,18 @@ __global__ __launch_bounds__(256, ATTN_WAVES_PER_SIMD) void lg_attention_p_kerne
         for (int s2i = 0; s2i < 2; ++s2i) {
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-#if ATTN_ABL & 4
-                const half8 vh = qh[s2i + db], vl = ql[s2i + db];
-#else
                 const int vo = voffs[sub][s2i][db];
                 const half8 vh = *reinterpret_cast<const half8*>(&sm.vt_hi[buf][vo]);
                 const half8 vl = *reinterpret_cast<const half8*>(&sm.vt_lo[buf][vo]);
-#endif
-#if ATTN_PLO_TRUE
                 if (db == 0) {          // pl at true scale: with the hi.hi products; V^T lo is the scaled plane
-                    o1a = MF(vh, ph[s2i], o1a);
-                    o1a = MF(vh, pl[s2i], o1a);
-                    o2a = MF(vl, ph[s2i], o2a);
+                    o1a = mfma16(vh, ph[s2i], o1a);
+                    o1a = mfma16(vh, pl[s2i], o1a);
+                    o2a = mfma16(vl, ph[s2i], o2a);
                 } else {
-                    o1b = MF(vh, ph[s2i], o1b);
-                    o1b = MF(vh, pl[s2i], o1b);
-                    o2b = MF(vl, ph[s2i], o2b);
+                    o1b = mfma16(vh, ph[s2i], o1b);
+                    o1b = mfma16(vh, pl[s2i], o1b);
+                    o2b = mfma16(vl, ph[s2i], o2b);
                 }
-#else
-                if (db == 0) {
-                    o1a = MF(vh, ph[s2i], o1a);
-                    o2a = MF(vh, pl[s2i], o2a);
-                    o2a = MF(vl, ph[s2i], o2a);
-                } else {
-                    o1b = MF(vh, ph[s2i], o1b);
-                    o2b = MF(vh, pl[s2i], o2b);
-                    o2b = MF(vl, ph[s2i], o2b);
-                }
-#endif
             }
         }
     };
@@ -1745,21 +1590,17 @@ __global__ __launch_bounds__(256, ATTN_WAVES_PER_SIMD) void lg_attention_p_kerne
             // even: softmax(S(tile,0)) | S(tile,1) = K.Q^T | O += V^T(tile-1,1) P
             pv(tile > t0 ? b ^ 1 : b, 1, ph, pl);
             qk(b, 1, n1, n2);
-            SOFTMAX_STEP<MASK>(s1, s2, tile * AK, nk, lane, m_run, l_run, nh, nl, alpha, rescale, qvalid);
+            attn_softmax_step<MASK>(s1, s2, tile * AK, nk, lane, m_run, l_run, nh, nl, alpha, rescale, qvalid);
             ATTN_INTERLEAVE();
-            ATTN_PIN_USE(nh, nl, l_run);
             if (rescale) { o1a *= alpha; o2a *= alpha; o1b *= alpha; o2b *= alpha; }
             __syncthreads();     // K(tile+1), V^T(tile) landed; K(tile) and V^T(tile-1) are free
-#if !(ATTN_ABL & 8)
             if (is_v) { if (tile + 1 < t1) issue_tile(tile + 1, b ^ 1); }
             else      { if (tile + 2 < t1) issue_tile(tile + 2, b); }
-#endif
             // odd: softmax(S(tile,1)) | S(tile+1,0) | O += V^T(tile,0) P
             pv(b, 0, nh, nl);
             qk(last ? b : b ^ 1, 0, s1, s2);
-            SOFTMAX_STEP<MASK>(n1, n2, tile * AK + 32, nk, lane, m_run, l_run, ph, pl, alpha, rescale, qvalid);
+            attn_softmax_step<MASK>(n1, n2, tile * AK + 32, nk, lane, m_run, l_run, ph, pl, alpha, rescale, qvalid);
             ATTN_INTERLEAVE();
-            ATTN_PIN_USE(ph, pl, l_run);
             if (rescale) { o1a *= alpha; o2a *= alpha; o1b *= alpha; o2b *= alpha; }
         };
         const bool ragged = (nk & (AK - 1)) != 0;            // only the last tile of the image can be
@@ -1910,11 +1751,7 @@ __global__ __launch_bounds__(256, 2) void lg_attention_hs_kernel(AttnArgsH p) {
         if ((nslab & 7) == 0) { const int xcd = b & 7, idx = b >> 3; slab = xcd + 8 * (idx / nqb); qb = idx % nqb; }
         else { slab = blockIdx.y; qb = blockIdx.x; }
     }
-#ifdef ATTN_BATCH_EMU
-    const int ih = slab & 7;
-#else
     const int ih = slab;
-#endif
     const int img = ih >> 2, head = ih & 3;
     if (ctrl_of(p.ctrl, img).stop) return;
     const int kimg = p.cross ? (img ^ 1) : img;
@@ -2103,250 +1940,6 @@ __global__ __launch_bounds__(256, 2) void lg_attention_hs_kernel(AttnArgsH p) {
     }
 }
 
-// ---- attention, split precision, PING-PONG form (batched launches, no key split) -------------
-// Why: in lg_attention_p_kernel the two waves that share a SIMD (one from each of two co-resident
-// workgroups) run the same code in phase, so their MFMA bursts collide on the one matrix pipe and
-// their softmax bursts on the one vector issue port: the launch costs MFMA time PLUS softmax time
-// (ablation at 8 pairs: 117 us of MFMA alone + 105 us of everything else = 228 us, nothing
-// overlapped).  Here a workgroup has EIGHT waves, two per SIMD, and the pair is kept in
-// anti-phase by construction: every 32-key sub-step of a wave is an M segment (24 MFMA on
-// fragments already in registers, raised priority, no LDS or VALU work) followed by a V segment
-// (softmax + P split of that sub-step, the LDS fragment reads of the next M segment, this wave's
-// share of the tile DMA), with a workgroup barrier between segments; waves 4-7 (group B) run one
-// segment behind waves 0-3 (group A), so while one wave of a SIMD multiplies its partner does
-// vector work in the issue slots the MFMAs leave free.
-//   global segment g:   A: M(j) at g = 2j, V(j) at 2j+1      B: M(j) at 2j+1, V(j) at 2j+2
-// K / V^T tiles (64 keys) sit in two LDS buffers each, filled by LDS-DMA (wave w: rows 8w..8w+7 of
-// the hi and the lo plane).  K(t) is read (prefetch of the fragments of sub-steps 2t, 2t+1) in
-// segments 4t-1 .. 4t+2, V^T(t) in 4t+1 .. 4t+4; K(t+2) is issued in V(2t+1) and V^T(t+1) in V(2t)
-// - after the last reader of the buffer they replace - and each is awaited (counted vmcnt: the
-// younger group stays in flight) at the end of the global segment before its first reader.
-constexpr int AQ2 = 256;         // queries per 8-wave workgroup
-
-__global__ __launch_bounds__(512) void lg_attention_pp_kernel(AttnArgsH p) {
-    __shared__ AttnSmemH sm;
-    const int nqb = gridDim.x, nslab = gridDim.y;
-    int slab, qb;
-    {
-        const int b = blockIdx.y * gridDim.x + blockIdx.x;
-        if ((nslab & 7) == 0) { const int xcd = b & 7, idx = b >> 3; slab = xcd + 8 * (idx / nqb); qb = idx % nqb; }
-        else { slab = blockIdx.y; qb = blockIdx.x; }
-    }
-#ifdef ATTN_BATCH_EMU
-    const int ih = slab & 7;
-#else
-    const int ih = slab;
-#endif
-    const int img = ih >> 2, head = ih & 3;
-    if (ctrl_of(p.ctrl, img).stop) return;
-    const int kimg = p.cross ? (img ^ 1) : img;
-    const int nq = n_of(p.ctrl, img), nk = n_of(p.ctrl, kimg);
-    const int q0 = qb * AQ2;
-    if (q0 >= nq) return;
-    const int t = threadIdx.x, lane = t & 63, h = lane >> 5, lr = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int grp = wave >> 2;                       // 0: group A, 1: group B (one segment behind)
-    const int T = (nk + AK - 1) / AK;                // key tiles (>= 1: an empty image sets stop)
-
-    const size_t qoff = ((size_t)img * NH + head) * p.Kc * DH;
-    const size_t koff = ((size_t)kimg * NH + head) * p.Kc * DH;
-    const int qi = min(q0 + wave * 32 + lr, p.Kc - 1);
-    const bool qvalid = q0 + wave * 32 + lr < nq;
-    half8 qh[4], ql[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        qh[s] = *reinterpret_cast<const half8*>(p.Q.hi + qoff + (size_t)qi * DH + 16 * s + 8 * h);
-        ql[s] = *reinterpret_cast<const half8*>(p.Q.lo + qoff + (size_t)qi * DH + 16 * s + 8 * h);
-    }
-
-    // this wave's share of a tile: rows 8 wave .. 8 wave + 7 of the hi and the lo plane
-    const int drow = wave * 8 + (lane >> 3);
-    const int dchunk = ((lane & 7) ^ ((drow >> 1) & 7)) * 8;
-    auto issue_k = [&](int tile, int buf) {
-        const size_t so = koff + (size_t)min(tile * AK + drow, p.Kc - 1) * DH + dchunk;
-        glds16(p.K.hi + so, sm.k_hi[buf] + wave * 8 * DH);
-        glds16(p.K.lo + so, sm.k_lo[buf] + wave * 8 * DH);
-    };
-    auto issue_v = [&](int tile, int buf) {
-        const size_t so = koff + ((size_t)tile * DH + drow) * AK + dchunk;
-        glds16(p.VT.hi + so, sm.vt_hi[buf] + wave * 8 * AK);
-        glds16(p.VT.lo + so, sm.vt_lo[buf] + wave * 8 * AK);
-    };
-
-    int koffs[2][4], voffs[2][2][2];                 // fragment offsets (halves), as in lg_attention_p_kernel
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-        const int krow = sub * 32 + lr, kswz = (krow >> 1) & 7;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) koffs[sub][s] = krow * DH + (((2 * s + h) ^ kswz) * 8);
-#pragma unroll
-        for (int s2i = 0; s2i < 2; ++s2i)
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                const int d = db * 32 + lr, vswz = (d >> 1) & 7, c0 = 4 * sub + 2 * s2i + h;
-                voffs[sub][s2i][db] = d * AK + ((c0 ^ vswz) * 8);
-            }
-    }
-
-    f32x16 o1a, o2a, o1b, o2b, s1, s2;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o1a[r] = 0.0f; o2a[r] = 0.0f; o1b[r] = 0.0f; o2b[r] = 0.0f; }
-    float m_run = -INFINITY, l_run = 0.0f;
-    half8 ph[2], pl[2];                              // P of the last V segment
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { ph[i][e] = (_Float16)0.0f; pl[i][e] = (_Float16)0.0f; }
-    half8 kfh[4], kfl[4], vfh[2][2], vfl[2][2];      // fragments of the next M segment
-    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-
-    auto fetch_k = [&](int buf, auto sub_c) {
-        constexpr int SUB = decltype(sub_c)::value;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            kfh[s] = *reinterpret_cast<const half8*>(&sm.k_hi[buf][koffs[SUB][s]]);
-            kfl[s] = *reinterpret_cast<const half8*>(&sm.k_lo[buf][koffs[SUB][s]]);
-        }
-    };
-    auto fetch_v = [&](int buf, auto sub_c) {
-        constexpr int SUB = decltype(sub_c)::value;
-#pragma unroll
-        for (int s2i = 0; s2i < 2; ++s2i)
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                vfh[s2i][db] = *reinterpret_cast<const half8*>(&sm.vt_hi[buf][voffs[SUB][s2i][db]]);
-                vfl[s2i][db] = *reinterpret_cast<const half8*>(&sm.vt_lo[buf][voffs[SUB][s2i][db]]);
-            }
-    };
-    // M segment: S = K Q^T of this sub-step, O += V^T P of the previous one - registers only
-    auto mseg = [&](bool with_qk) {
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-        // a single wave feeds the matrix pipe here: consecutive MFMAs never share an accumulator
-        // (s2 every third instruction, the others every sixth)
-        static_assert(ATTN_PLO_TRUE, "the ping-pong form keeps the low plane of P unscaled");
-        if (with_qk) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int sa = 2 * i, sb = 2 * i + 1;
-                s2 = MF(kfh[sa], ql[sa], i == 0 ? zero16 : s2);
-                s1 = MF(kfh[sa], qh[sa], i == 0 ? zero16 : s1);
-                o1a = MF(vfh[i][0], ph[i], o1a);
-                s2 = MF(kfl[sa], qh[sa], s2);
-                o1b = MF(vfh[i][1], ph[i], o1b);
-                o2a = MF(vfl[i][0], ph[i], o2a);
-                s2 = MF(kfh[sb], ql[sb], s2);
-                s1 = MF(kfh[sb], qh[sb], s1);
-                o1a = MF(vfh[i][0], pl[i], o1a);
-                s2 = MF(kfl[sb], qh[sb], s2);
-                o1b = MF(vfh[i][1], pl[i], o1b);
-                o2b = MF(vfl[i][1], ph[i], o2b);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                o1a = MF(vfh[i][0], ph[i], o1a);
-                o1b = MF(vfh[i][1], ph[i], o1b);
-                o2a = MF(vfl[i][0], ph[i], o2a);
-                o2b = MF(vfl[i][1], ph[i], o2b);
-                o1a = MF(vfh[i][0], pl[i], o1a);
-                o1b = MF(vfh[i][1], pl[i], o1b);
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    // segment boundary: optional counted wait for this wave's older DMA pieces, LDS reads drained
-    // (their buffer may be refilled by the partner group right after the barrier), barrier
-    auto boundary = [&](int dma_wait /* -1 none, 0 all, 2 all but the youngest group */) {
-        if (dma_wait == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-        else if (dma_wait == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto vseg_softmax = [&](auto mask_c, int kbase) {
-        constexpr bool MASK = decltype(mask_c)::value;
-        float alpha; bool rescale;
-        SOFTMAX_STEP<MASK>(s1, s2, kbase, nk, lane, m_run, l_run, ph, pl, alpha, rescale, qvalid);
-        ATTN_PIN_USE(ph, pl, l_run);
-        if (rescale) { o1a *= alpha; o2a *= alpha; o1b *= alpha; o2b *= alpha; }
-    };
-
-    // ---- prologue: tile 0 of K and V^T, then K(1) in flight; fragments of M(0)
-    issue_k(0, 0);
-    issue_v(0, 0);
-    boundary(0);
-    if (T > 1) issue_k(1, 1);
-    fetch_k(0, std::integral_constant<int, 0>{});
-    fetch_v(0, std::integral_constant<int, 0>{});        // P(-1) = 0 meets finite data
-    if (grp == 1) boundary(-1);                           // group B idles through global segment 0
-
-    auto tile_body = [&](auto mask_c, int tile) {
-        const bool more1 = tile + 1 < T, more2 = tile + 2 < T;
-        const int b = tile & 1;
-        // M(2t)
-        mseg(true);
-        boundary(grp == 0 ? (more1 ? 2 : 0) : -1);              // A: V^T(t) landed
-        // V(2t): V^T(t+1) on its way, fragments of M(2t+1), softmax of sub-step 2t
-#if !(ATTN_ABL & 8)
-        if (more1) issue_v(tile + 1, b ^ 1);
-#endif
-#if !(ATTN_ABL & 4)
-        fetch_k(b, std::integral_constant<int, 1>{});
-        fetch_v(b, std::integral_constant<int, 0>{});
-#endif
-        vseg_softmax(mask_c, tile * AK);
-        boundary(grp == 1 && more1 ? 2 : -1);                    // B: K(t+1) landed
-        // M(2t+1)
-        mseg(true);
-        boundary(grp == 0 && more1 ? 2 : -1);                    // A: K(t+1) landed
-        // V(2t+1): K(t+2) on its way, fragments of M(2t+2), softmax of sub-step 2t+1
-#if !(ATTN_ABL & 8)
-        if (more2) issue_k(tile + 2, b);
-#endif
-#if !(ATTN_ABL & 4)
-        if (more1) fetch_k(b ^ 1, std::integral_constant<int, 0>{});
-        fetch_v(b, std::integral_constant<int, 1>{});
-#endif
-        vseg_softmax(mask_c, tile * AK + 32);
-        boundary(grp == 1 && more1 ? (more2 ? 2 : 0) : -1);      // B: V^T(t+1) landed
-    };
-    const bool ragged = (nk & (AK - 1)) != 0;
-    const int tfull = ragged ? T - 1 : T;
-    for (int tile = 0; tile < tfull; ++tile) tile_body(std::false_type{}, tile);
-    if (tfull < T) tile_body(std::true_type{}, T - 1);
-    mseg(false);                                          // the last sub-step's P.V
-    if (grp == 0) boundary(-1);                           // group A idles through the last global segment
-
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const int qrow = q0 + wave * 32 + lr;
-    if (qrow < nq) {
-        // normalise, split and write the context planes (k-panel layout: 4 consecutive d = 8 bytes per plane)
-        const float inv = 1.0f / l_tot;
-        const int prow = img * p.Kc + qrow;
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                half4 hh, ll;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = half ? (o1b[4 * g4 + e] + o2b[4 * g4 + e] * SPLIT_INV)
-                                         : (o1a[4 * g4 + e] + o2a[4 * g4 + e] * SPLIT_INV);
-                    _Float16 a, b;
-                    split_f32(v * inv, a, b, range_flag_of(p.ctrl, img));
-                    hh[e] = a; ll[e] = b;
-                }
-                const size_t o = panel_index(prow, head * DH + 32 * half + 8 * g4 + 4 * h, p.NIc * p.Kc);
-                *reinterpret_cast<half4*>(p.msg.hi + o) = hh;
-                *reinterpret_cast<half4*>(p.msg.lo + o) = ll;
-            }
-        }
-    }
-}
-
 // merge key-split partials -> split planes of msg[img][row][head*64 + d]
 __global__ __launch_bounds__(256) void lg_attn_merge_h_kernel(const float* __restrict__ o_part,
                                                               const float* __restrict__ m_part,
@@ -2424,7 +2017,7 @@ struct sslam_lightglue {
     int dbg_layers = NL;             // test hook: run only the first dbg_layers layers
     int dbg_self_only = 0;           // test hook: stop after the self block of the last executed layer
     int force_ks = 0;                // test hook: key split of the attention launches (0 = by batch size)
-    int big_gemm = -1;               // test hook: -1 by batch size, 0 / 1 force the ring / big-tile linears
+    int big_gemm = -1;               // test hook: -1 by batch size, 0 / 1 force the single-pair (ring) / batched form of the linears
     _Float16 *w_hi, *w_lo;           // whole weight blob, split
     _Float16 *ffn_w1f[NL][2], *ffn_w2f[NL][2];   // fused-FFN fragment-order weights, [layer][self / cross]
     _Float16 *xs_hi, *xs_lo, *msgs_hi, *msgs_lo, *hids_hi, *hids_lo;
@@ -2557,11 +2150,11 @@ SplitPtr wsp(const sslam_lightglue* g, const float* w) {
     return SplitPtr{g->w_hi + off, g->w_lo + off};
 }
 
-// big-tile launch (batched token sets): 128 x 256 tiles, 8 waves
+// big-tile launch (batched token sets): 128 x 128 tiles, 4 waves
 template <int BM, int BN, int WM, int WN, int EPI>
 void launch_linear_big(hipStream_t s, int NI, const LinearArgsH& a) {
     constexpr int NW = WM * WN;
-    constexpr size_t stage = (size_t)big_stages<BM, WM, WN>() * sslam::big_stage_halves<BM, BN>() * sizeof(_Float16);
+    constexpr size_t stage = (size_t)sslam::BIG_STAGES * sslam::big_stage_halves<BM, BN>() * sizeof(_Float16);
     constexpr size_t epi = (size_t)BM * (BN + 4) * sizeof(float);
     constexpr size_t lds = stage > epi ? stage : epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
@@ -2623,17 +2216,12 @@ void lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, in
     const SplitPtr qs{g->qs_hi, g->qs_lo}, ks{g->ks_hi, g->ks_lo}, vts{g->vts_hi, g->vts_lo};
     const unsigned tokblocks = sslam::cdiv(NI * g->Kc, 4);
     const float sm_scale = 0.125f * 1.4426950408889634f;        // 1/sqrt(64) * log2(e)
-    // enough token rows for 128-row tiles to fill the chip: the big-tile GEMM (1.5 - 2x the flop per
-    // operand byte taken in by a CU); a single pair keeps the 64-row ring kernel.  Of the two big
-    // forms the 128 x 128 / 4-wave one (two workgroups per CU: one's epilogue under the other's main
-    // loop) measures 2 % under the 128 x 256 / 8-wave one on the whole forward (9.14 vs 9.36 ms for
-    // 8 pairs) although its main loop alone is no faster (scripts/ubench/gemm_big_bench.hip)
-    // (3 = the 128 x 128 form with the FFN's LayerNorm + GELU fused into a 64 x 512 whole-row GEMM)
-    // (4 = 128 x 128 projections + the whole FFN as ONE kernel, ffn_fused.hpp: the batched default)
-    const int big = g->big_gemm >= 0 ? g->big_gemm : ((long)NI * g->Kc >= 16384 && g->Kc % 128 == 0 ? 4 : 0);
+    // enough token rows for 128-row tiles to fill the chip (a batch of pairs): 128 x 128 projections and the
+    // whole FFN as ONE kernel (ffn_fused.hpp); a single pair keeps the 64-row ring kernels (r01 form)
+    const bool big = g->big_gemm >= 0 ? g->big_gemm != 0 : ((long)NI * g->Kc >= 16384 && g->Kc % 128 == 0);
     auto ffn = [&](int cross, const float* w1, const float* b1, const float* lnw, const float* lnb, const float* w2,
                    const float* b2) {
-        if (big == 4) {
+        if (big) {
             FfnKArgs k{};
             k.f.xs = xs; k.f.msgs = msgs; k.f.plane_rows = g->NIc * g->Kc;
             k.f.w1f = g->ffn_w1f[layer][cross]; k.f.b1 = b1; k.f.ln_w = lnw; k.f.ln_b = lnb;
@@ -2645,29 +2233,18 @@ void lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, in
         }
         LinearArgsH a = linh(g, xs, msgs, D, D, 2 * D, w1, b1, 2 * D);      // [x | attention context]
         a.out = g->hid; a.ldo = 2 * D;
-        if (big == 3) {
-            // whole 512-wide rows per workgroup: LayerNorm + GELU + split in the GEMM's epilogue
-            a.outs = SplitOut{g->hids_hi, g->hids_lo}; a.ln_w = lnw; a.ln_b = lnb;
-            launch_linear_big<64, 512, 1, 8, EPH_LNGELU>(s, NI, a);
-        } else {
-        if (big == 2) launch_linear_big<128, 128, 2, 2, EPH_F32>(s, NI, a);
-        else if (big) launch_linear_big<128, 256, 2, 4, EPH_F32>(s, NI, a);
-        else launch_linear_h<64, 128, 1, 2, EPH_F32>(s, NI, a);
+        launch_linear_h<64, 128, 1, 2, EPH_F32>(s, NI, a);
         hipLaunchKernelGGL(lg_ln_gelu_h_kernel, dim3(tokblocks), dim3(256), 0, s, g->hid,
                            SplitOut{g->hids_hi, g->hids_lo}, lnw, lnb, g->ctrl, g->Kc, NI, g->NIc);
-        }
         LinearArgsH c = linh(g, hids, none, 2 * D, 2 * D, 2 * D, w2, b2, D);
         c.out = g->x; c.ldo = D; c.outs = SplitOut{g->xs_hi, g->xs_lo};
-        if (big >= 2) launch_linear_big<128, 128, 2, 2, EPH_RESID>(s, NI, c);
-        else if (big) launch_linear_big<128, 256, 2, 4, EPH_RESID>(s, NI, c);
-        else launch_linear_h<64, 64, 1, 1, EPH_RESID>(s, NI, c);
+        launch_linear_h<64, 64, 1, 1, EPH_RESID>(s, NI, c);
     };
     {   // self block
         LinearArgsH a = linh(g, xs, none, D, D, D, l.wqkv, l.bqkv, 3 * D);
         a.q = SplitOut{g->qs_hi, g->qs_lo}; a.k = SplitOut{g->ks_hi, g->ks_lo}; a.vt = SplitOut{g->vts_hi, g->vts_lo};
         a.q_scale = sm_scale; a.k_scale = 1.0f;
-        if (big >= 2) launch_linear_big<128, 128, 2, 2, EPH_QKV>(s, NI, a);
-        else if (big) launch_linear_big<128, 256, 2, 4, EPH_QKV>(s, NI, a);
+        if (big) launch_linear_big<128, 128, 2, 2, EPH_QKV>(s, NI, a);
         else launch_linear_h<64, 192, 1, 3, EPH_QKV>(s, NI, a);  // 768 / 192 = 4 column tiles
     }
     launch_attention_h(g, s, NI, qs, ks, vts, 0);
@@ -2677,8 +2254,7 @@ void lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, in
         LinearArgsH a = linh(g, xs, none, D, D, D, l.cqkv, l.cbqkv, 2 * D);
         a.q = SplitOut{g->qs_hi, g->qs_lo}; a.vt = SplitOut{g->vts_hi, g->vts_lo};
         a.q_scale = sqrtf(sm_scale);
-        if (big >= 2) launch_linear_big<128, 128, 2, 2, EPH_CROSS>(s, NI, a);
-        else if (big) launch_linear_big<128, 256, 2, 4, EPH_CROSS>(s, NI, a);
+        if (big) launch_linear_big<128, 128, 2, 2, EPH_CROSS>(s, NI, a);
         else launch_linear_h<64, 128, 1, 2, EPH_CROSS>(s, NI, a);
     }
     launch_attention_h(g, s, NI, qs, qs, vts, 1);
@@ -2794,13 +2370,9 @@ void lg_configure_kernels() {
     done = true;
     const LinearArgsH cfg{};            // ctrl == nullptr: the launchers only configure
     hipStream_t s = nullptr;
-    launch_linear_h<64, 128, 1, 2, EPH_F32>(s, 0, cfg);   launch_linear_big<128, 256, 2, 4, EPH_F32>(s, 0, cfg);
-    launch_linear_h<64, 64, 1, 1, EPH_RESID>(s, 0, cfg);  launch_linear_big<128, 256, 2, 4, EPH_RESID>(s, 0, cfg);
-    launch_linear_h<64, 192, 1, 3, EPH_QKV>(s, 0, cfg);   launch_linear_big<128, 256, 2, 4, EPH_QKV>(s, 0, cfg);
-    launch_linear_h<64, 128, 1, 2, EPH_CROSS>(s, 0, cfg); launch_linear_big<128, 256, 2, 4, EPH_CROSS>(s, 0, cfg);
-    launch_linear_big<128, 128, 2, 2, EPH_F32>(s, 0, cfg); launch_linear_big<128, 128, 2, 2, EPH_RESID>(s, 0, cfg);
+    launch_linear_h<64, 128, 1, 2, EPH_F32>(s, 0, cfg);   launch_linear_h<64, 64, 1, 1, EPH_RESID>(s, 0, cfg);
+    launch_linear_h<64, 192, 1, 3, EPH_QKV>(s, 0, cfg);   launch_linear_h<64, 128, 1, 2, EPH_CROSS>(s, 0, cfg);
     launch_linear_big<128, 128, 2, 2, EPH_QKV>(s, 0, cfg); launch_linear_big<128, 128, 2, 2, EPH_CROSS>(s, 0, cfg);
-    launch_linear_big<64, 512, 1, 8, EPH_LNGELU>(s, 0, cfg);
     (void)hipFuncSetAttribute((const void*)lg_ffn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, sslam::FFN_LDS_BYTES);
 }
 
@@ -3104,16 +2676,16 @@ int sslam_lightglue_debug_layers(sslam_lightglue* g, int layers, int self_only) 
 /* Test hook: force the key split of the attention launches (0 = chosen by batch size). */
 int sslam_lightglue_debug_key_split(sslam_lightglue* g, int ks) {
     SSLAM_REQUIRE(g != nullptr && (ks == -1 || ks == 0 || ks == 1 || ks == 2 || ks == 4),
-                  "sslam_lightglue_debug_key_split: ks must be -1 (ping-pong experiment), 0, 1, 2 or 4");
+                  "sslam_lightglue_debug_key_split: ks must be -1 (no split, r02 4-wave kernel), 0, 1, 2 or 4");
     g->settings_changed();
     g->force_ks = ks;
     return 0;
 }
 
-/* Test hook: -1 = linears chosen by batch size, 0 = always the 64-row ring kernel, 1 = always the
- * 128 x 256 big-tile kernel. */
+/* Test hook: -1 = linears chosen by batch size, 0 = always the 64-row ring kernels (single-pair form), 1 = always
+ * the batched form (128 x 128 projections + the fused FFN kernel). */
 int sslam_lightglue_debug_big_gemm(sslam_lightglue* g, int mode) {
-    SSLAM_REQUIRE(g != nullptr && mode >= -1 && mode <= 4, "sslam_lightglue_debug_big_gemm: bad argument");
+    SSLAM_REQUIRE(g != nullptr && mode >= -1 && mode <= 1, "sslam_lightglue_debug_big_gemm: bad argument");
     g->settings_changed();
     g->big_gemm = mode;
     return 0;

@@ -120,13 +120,13 @@ class LightGlueHIP:
         return bool(f.value)
 
     def debug_key_split(self, ks: int):
-        """Test hook: force the key split of the attention launches (0 = by batch size)."""
+        """Test hook: force the key split of the attention launches (0 = by batch size; -1 = no split on the r02
+        4-wave kernel instead of the half-step kernel, for A/B and bit-identity checks)."""
         _native.check(_native.lib().sslam_lightglue_debug_key_split(self.handle, int(ks)))
 
     def debug_big_gemm(self, mode: int):
-        """Test hook: -1 linears by batch size, 0 always the ring kernel, 1 the 128 x 256 big-tile kernel,
-        2 the 128 x 128 one, 3 the 128 x 128 one with LayerNorm + GELU fused into the first FFN GEMM, 4 the 128 x 128
-        projections + the whole FFN as one kernel (the default of a batched call)."""
+        """Test hook: -1 linears by batch size, 0 always the 64-row ring kernels (single-pair form), 1 always the
+        batched form (128 x 128 projections + the whole FFN as one kernel)."""
         _native.check(_native.lib().sslam_lightglue_debug_big_gemm(self.handle, int(mode)))
 
     def debug_read(self, which: int, shape, dtype=np.float32):

@@ -1,5 +1,5 @@
 # A/B of the linear-kernel modes of the batched forward on ONE box: ab_mode.sh "<mode A>" "<mode B>" [pairs=8]
-# (SSLAM_BIG_GEMM: 1 = 128x256, 2 = 128x128, 3 = 128x128 + LayerNorm fused into the first FFN GEMM)
+# (SSLAM_BIG_GEMM: 0 = ring kernels, 1 = batched form)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 B=${3:-8}

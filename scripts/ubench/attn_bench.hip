@@ -1,9 +1,10 @@
 // Stand-alone timing of the LightGlue attention kernel (same TU as the product kernels, synthetic
 // operands, no downstream kernels): used for A/B of schedule variants and for ablations that would
 // poison a full match.  Variants are separate builds (-D flags) run back to back on the same device.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I opencv-simpleslam_amd/csrc [-DATTN_ABL=..] [-DATTN_SCHED=..] \
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I opencv-simpleslam_amd/csrc \
 //         scripts/ubench/attn_bench.hip -o /tmp/attn_bench && /tmp/attn_bench [N=2048] [pairs=8] [KS=1] [rounds=5]
 #include "../../opencv-simpleslam_amd/csrc/lightglue_kernels.hip"
+#include "attn_pp_experiment.hpp"
 #include "attn_w1_experiment.hpp"
 #include <cstdio>
 #include <vector>
@@ -93,13 +94,8 @@ int main(int argc, char** argv) {
     }
     std::sort(t.begin(), t.end());
     const double fl = 8.0 * N * (double)N * 256 * B;
-    printf("%s N=%d pairs=%d KS=%d abl=%d sched=%d: median %.1f us/launch (min %.1f) = %.2f us per pair, %.0f TF alg, executed %.1f%% of the f16 peak; err=%s\n",
-           w1 ? "[w1]" : hs ? "[hs]" : pp ? "[pp]" : "[p4]", N, B, KS, ATTN_ABL,
-#ifdef ATTN_SCHED
-           ATTN_SCHED,
-#else
-           -1,
-#endif
+    printf("%s N=%d pairs=%d KS=%d: median %.1f us/launch (min %.1f) = %.2f us per pair, %.0f TF alg, executed %.1f%% of the f16 peak; err=%s\n",
+           w1 ? "[w1]" : hs ? "[hs]" : pp ? "[pp]" : "[p4]", N, B, KS,
            t[t.size() / 2], t[0], t[t.size() / 2] / B, fl / (t[t.size() / 2] * 1e-6) / 1e12, 3 * fl / (t[t.size() / 2] * 1e-6) / 2.5e15 * 100,
            hipGetErrorString(hipGetLastError()));
     return 0;

@@ -7,7 +7,7 @@
 #include <cmath>
 #include <vector>
 #include <type_traits>
-#include "gemm_f16x3_big.hpp"
+#include "gemm_f16x3_big_r02.hpp"   // r02 forms (128 x 256 / 8 waves, pipelined main loops, ablations); the product header keeps one
 using namespace sslam;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
