@@ -63,6 +63,10 @@ int sslam_event_create(sslam_ctx* ctx, void** event_out);
 int sslam_event_destroy(void* event);
 int sslam_event_record(sslam_ctx* ctx, void* event);      /* on ctx's stream */
 int sslam_ctx_wait_event(sslam_ctx* ctx, void* event);    /* ctx's stream waits, host does not */
+/* Timing events (the ordering events above are created without timestamps) and the time between two recorded
+ * ones (waits for the second): per-round durations of a running pipeline without synchronising inside it. */
+int sslam_timing_event_create(sslam_ctx* ctx, void** event_out);
+int sslam_event_elapsed_ms(void* start_event, void* stop_event, float* ms_out);
 
 /* ------------------------------------------------------------------ local BA
  * Batched reprojection residual + Jacobian.  Replaces the per-observation

@@ -48,6 +48,8 @@ def _signatures():
         "sslam_event_destroy": (i32, [vp]),
         "sslam_event_record": (i32, [vp, vp]),
         "sslam_ctx_wait_event": (i32, [vp, vp]),
+        "sslam_timing_event_create": (i32, [vp, c_void_pp]),
+        "sslam_event_elapsed_ms": (i32, [vp, vp, c_float_p]),
         "sslam_ba_residual_jacobian_host": (i32, [vp, i32] + [vp] * 3 + [i32, vp, vp, i32, vp, vp] + [vp] * 4),
         "sslam_ba_residual_jacobian_dev": (i32, [vp, i32] + [vp] * 3 + [i32, vp, vp, i32, vp, vp] + [vp] * 4),
         "sslam_ba_solve_host": (i32, [vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, C.c_double, i32, vp]),
@@ -203,6 +205,17 @@ class Context:
         e = C.c_void_p()
         check(lib().sslam_event_create(self.handle, C.byref(e)), "sslam_event_create")
         return int(e.value)
+
+    def timing_event(self) -> int:
+        e = C.c_void_p()
+        check(lib().sslam_timing_event_create(self.handle, C.byref(e)), "sslam_timing_event_create")
+        return int(e.value)
+
+    @staticmethod
+    def elapsed_ms(start_event: int, stop_event: int) -> float:
+        ms = C.c_float()
+        check(lib().sslam_event_elapsed_ms(C.c_void_p(start_event), C.c_void_p(stop_event), C.byref(ms)), "sslam_event_elapsed_ms")
+        return float(ms.value)
 
     def record(self, event: int):
         """Record `event` on this context's stream."""

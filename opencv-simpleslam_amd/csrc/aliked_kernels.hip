@@ -1301,18 +1301,25 @@ ResizePlan resize_plan(int H, int W, int resize) {
     return p;
 }
 
-int al_enqueue(sslam_aliked* g, const uint8_t* img_dev, int H, int W, int C, int n_limit, float* xy_out,
-               float* desc_out, float* score_out, int32_t* n_out) {
-    hipStream_t s = g->ctx->stream;
+// network-size bookkeeping of one image (resize to 1024 on the long side, centred pad to a multiple of 32)
+Dims al_dims(int H, int W, int C) {
     const ResizePlan rp = resize_plan(H, W, 1024);
     Dims d{};
     d.H = H; d.W = W; d.C = C; d.h = rp.h; d.w = rp.w;
     const int pad_h = (((d.h / 32) + 1) * 32 - d.h) % 32, pad_w = (((d.w / 32) + 1) * 32 - d.w) % 32;
     d.Hp = d.h + pad_h; d.Wp = d.w + pad_w; d.pl = pad_w / 2; d.pt = pad_h / 2;
+    return d;
+}
+
+// (host-side state such as g->last is set by the ENTRY POINTS, not here: a graph replay skips this function)
+int al_enqueue(sslam_aliked* g, const uint8_t* img_dev, int H, int W, int C, int n_limit, float* xy_out,
+               float* desc_out, float* score_out, int32_t* n_out) {
+    hipStream_t s = g->ctx->stream;
+    const ResizePlan rp = resize_plan(H, W, 1024);
+    const Dims d = al_dims(H, W, C);
     SSLAM_REQUIRE(d.Hp <= g->Hp_cap && d.Wp <= g->Wp_cap && d.h >= 8 && d.w >= 8,
                   "sslam_aliked: network size %dx%d outside the instance capacity %dx%d", d.Hp, d.Wp,
                   g->Hp_cap, g->Wp_cap);
-    g->last = d;
     const int Hp = d.Hp, Wp = d.Wp;
     SSLAM_HIP_CHECK(hipMemsetAsync(g->ctrl, 0, sizeof(ALCtrl), s));
     SSLAM_HIP_CHECK(hipMemsetAsync(g->hist, 0, HBINS * sizeof(unsigned), s));
@@ -1524,6 +1531,7 @@ int sslam_aliked_extract_dev(sslam_aliked* g, const uint8_t* img, int H, int W, 
                              float* desc_out, float* score_out, int32_t* n_out) {
     SSLAM_REQUIRE(g && img && xy_out && desc_out && n_out, "sslam_aliked_extract_dev: NULL argument");
     if (int rc = al_check_image(g, H, W, C, max_kpts)) return rc;
+    g->last = al_dims(H, W, C);
     if (!g->use_graphs) return al_enqueue(g, img, H, W, C, max_kpts, xy_out, desc_out, score_out, n_out);
     const std::vector<uint64_t> key{(uint64_t)img, (uint64_t)H, (uint64_t)W, (uint64_t)C, (uint64_t)max_kpts,
                                     (uint64_t)xy_out, (uint64_t)desc_out, (uint64_t)score_out, (uint64_t)n_out};
@@ -1548,6 +1556,7 @@ int sslam_aliked_extract_host(sslam_aliked* g, const uint8_t* img, int H, int W,
     SSLAM_HIP_CHECK(hipSetDevice(g->ctx->device));
     hipStream_t s = g->ctx->stream;
     SSLAM_HIP_CHECK(hipMemcpyAsync(g->in_u8, img, (size_t)H * W * C, hipMemcpyHostToDevice, s));
+    g->last = al_dims(H, W, C);
     if (int rc = al_enqueue(g, g->in_u8, H, W, C, max_kpts, g->out_xy, g->out_desc, g->out_score, g->out_n)) return rc;
     int32_t n = 0;
     SSLAM_HIP_CHECK(hipMemcpyAsync(&n, g->out_n, 4, hipMemcpyDeviceToHost, s));

@@ -131,6 +131,25 @@ int sslam_event_create(sslam_ctx* ctx, void** event_out) {
     return 0;
 }
 
+/* A TIMING event (hipEventDefault) and the elapsed time between two of them: the bench stamps the end of every
+ * round of the running pipeline on a collector stream and reads the intervals afterwards - per-round durations
+ * without a host synchronisation inside the timed region. */
+int sslam_timing_event_create(sslam_ctx* ctx, void** event_out) {
+    SSLAM_REQUIRE(ctx != nullptr && event_out != nullptr, "sslam_timing_event_create: NULL argument");
+    SSLAM_HIP_CHECK(hipSetDevice(ctx->device));
+    hipEvent_t e;
+    SSLAM_HIP_CHECK(hipEventCreate(&e));
+    *event_out = (void*)e;
+    return 0;
+}
+
+int sslam_event_elapsed_ms(void* start_event, void* stop_event, float* ms_out) {
+    SSLAM_REQUIRE(start_event && stop_event && ms_out, "sslam_event_elapsed_ms: NULL argument");
+    SSLAM_HIP_CHECK(hipEventSynchronize((hipEvent_t)stop_event));
+    SSLAM_HIP_CHECK(hipEventElapsedTime(ms_out, (hipEvent_t)start_event, (hipEvent_t)stop_event));
+    return 0;
+}
+
 int sslam_event_destroy(void* event) {
     if (event) SSLAM_HIP_CHECK(hipEventDestroy((hipEvent_t)event));
     return 0;

@@ -2218,7 +2218,7 @@ void lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, in
     const float sm_scale = 0.125f * 1.4426950408889634f;        // 1/sqrt(64) * log2(e)
     // enough token rows for 128-row tiles to fill the chip (a batch of pairs): 128 x 128 projections and the
     // whole FFN as ONE kernel (ffn_fused.hpp); a single pair keeps the 64-row ring kernels (r01 form)
-    const bool big = g->big_gemm >= 0 ? g->big_gemm != 0 : ((long)NI * g->Kc >= 16384 && g->Kc % 128 == 0);
+    const bool big = g->big_gemm >= 0 ? g->big_gemm != 0 : ((long)NI * g->Kc >= 4096 && g->Kc % 128 == 0);
     auto ffn = [&](int cross, const float* w1, const float* b1, const float* lnw, const float* lnb, const float* w2,
                    const float* b2) {
         if (big) {

@@ -96,19 +96,30 @@ def unpack_record(rec, max_kpts):
     return n, rec[:2 * K].reshape(K, 2)[:n], rec[2 * K:K * ROW].reshape(K, DESC_DIM)[:n]
 
 
-def collate(local_records, plan: ShardPlan, group=None):
-    """All-gather the per-frame records of one round.
+def collate(local_records, plan: ShardPlan, group=None, out=None, part=None):
+    """All-gather the per-frame records of one round (or of a part of it).
 
     local_records: [B, REC] float32 tensor of this rank's frames (frame order).
     Returns [world*B, REC] in GLOBAL frame order of the round.  With world == 1 this is the
-    input (no collective)."""
+    input (no collective).
+    out:  optional preallocated [world*B, REC] tensor to gather into (the caller keeps it alive: no
+          allocation and no copy per round);
+    part: optional (lo, hi) - gather only local frames lo..hi-1 of every rank, into rows
+          r*B + lo .. r*B + hi - 1 of `out`, so a round can be collated in pieces as its extracts finish."""
     if plan.world == 1:
         return local_records
     import torch
     import torch.distributed as dist
-    out = torch.empty((plan.world * local_records.shape[0],) + tuple(local_records.shape[1:]),
-                      dtype=local_records.dtype, device=local_records.device)
-    dist.all_gather_into_tensor(out, local_records.contiguous(), group=group)   # rank-major = frame order
+    B = local_records.shape[0]
+    if out is None:
+        out = torch.empty((plan.world * B,) + tuple(local_records.shape[1:]),
+                          dtype=local_records.dtype, device=local_records.device)
+    if part is None or (part[0] == 0 and part[1] == B):
+        dist.all_gather_into_tensor(out, local_records.contiguous(), group=group)   # rank-major = frame order
+    else:
+        lo, hi = part
+        views = [out[r * B + lo:r * B + hi] for r in range(plan.world)]             # each contiguous
+        dist.all_gather(views, local_records[lo:hi].contiguous(), group=group)
     return out
 
 
@@ -152,11 +163,19 @@ class FrameStreamPipeline:
             # the exchange goes through torch.distributed: its tensors own the record slab
             import torch
             self.torch = torch
-            self._slab_t = torch.zeros((self.NSLOT, self.REC), dtype=torch.float32,
-                                       device=torch.device("cuda", self.ctx.device))
+            dev = torch.device("cuda", self.ctx.device)
+            self._slab_t = torch.zeros((self.NSLOT, self.REC), dtype=torch.float32, device=dev)
             self.slab = int(self._slab_t.data_ptr())
-            self._cstream = torch.cuda.ExternalStream(self.ctx.stream, device=self.ctx.device)
-            self._prev_last = torch.zeros(self.REC, dtype=torch.float32, device=self._slab_t.device)
+            # the collation has a stream of its own (a context of this package, seen by torch as an external
+            # stream): on an extractor's stream the first half-round gather would hold back that extractor's
+            # second half
+            from . import _native
+            self.cctx = _native.Context(self.ctx.device)
+            self._cstream = torch.cuda.ExternalStream(self.cctx.stream, device=self.ctx.device)
+            # gathered rounds, one buffer per round parity: the previous round's last record (the halo of
+            # this round's first pair on rank 0) is read where it was gathered - no clone, no allocation
+            self._gathered = [torch.zeros((plan.world * B, self.REC), dtype=torch.float32, device=dev) for _ in range(2)]
+            self.halves = [(0, (B + 1) // 2), ((B + 1) // 2, B)] if B > 1 else [(0, B)]
             torch.cuda.synchronize()
         else:
             self.slab = self.ctx.malloc(dev_bytes)
@@ -238,19 +257,26 @@ class FrameStreamPipeline:
         have_halo = self.have_halo
         prev_slot = (1 - p) * B + B - 1                  # last frame of the previous round (one GPU)
         if not single:
-            # ---- multi-GPU: collate as soon as the EXTRACTS are done; the matches of this round run
-            # on their own streams underneath the all-gather.  The collation rides on the first
-            # extractor's stream (self.ctx), seen by torch as an external stream.
+            # ---- multi-GPU: collate each HALF of the round as soon as its extracts are done (the first
+            # all-gather runs under the second half's extracts, the second under the matches), on the
+            # collation stream; the matches run on their own streams underneath.
             torch = self.torch
-            for s in range(B):
-                self.ctx.wait(self.ev_ext[p][s])
+            G = self._gathered[p]
+            if rnd >= 2:
+                # G was last written two rounds ago; its readers since: that round's halo copy (same stream) and
+                # the NEXT round's halo copy on rank 0 (same stream too) - stream order covers both
+                pass
             with torch.cuda.stream(self._cstream):
-                self.shared_map = collate(self._slab_t[s_base:s_base + B], plan, self.group)
+                for (lo, hi) in self.halves:
+                    for s in range(lo, hi):
+                        self.cctx.wait(self.ev_ext[p][s])
+                    collate(self._slab_t[s_base:s_base + B], plan, self.group, out=G, part=(lo, hi))
+                self.shared_map = G
                 prev = plan.rank * B - 1                     # index inside the gathered round
                 if prev >= 0:
-                    src = self.shared_map[prev]
+                    src = G[prev]
                 elif have_halo:
-                    src = self._prev_last
+                    src = self._gathered[1 - p][plan.world * B - 1]      # last record of the previous round
                 else:
                     src = None
                 if src is not None:
@@ -258,9 +284,8 @@ class FrameStreamPipeline:
                     have_halo = True
                 else:
                     have_halo = False
-                self._prev_last = self.shared_map[plan.world * B - 1].clone()
-            self.ctx.record(self.ev_halo[p])                 # halo of THIS round is in place
-            self.ctx.record(self.ev_collated[p])
+            self.cctx.record(self.ev_halo[p])                # halo of THIS round is in place
+            self.cctx.record(self.ev_collated[p])
             prev_slot = halo_slot
         # ---- batched matches: pair s = (s-1, s); pair 0 = (previous frame, 0)
         out_base = p * B
@@ -295,6 +320,8 @@ class FrameStreamPipeline:
     def sync(self):
         for c in {id(x.ctx): x.ctx for x in self.dets + self.mats}.values():
             c.sync()
+        if self.torch is not None:
+            self.cctx.sync()
 
     def _checked_infos(self):
         """[B, 4] int32 {matches, layers, n0, n1} of the last round.  A match count of -1 is the matcher's

@@ -27,7 +27,10 @@ from typing import List
 
 import numpy as np
 
-from .types import DMatch, KeyPoint, HAVE_CV2, keypoints_from_xy, matches_from_ij, xy_from_keypoints
+import ctypes as _C
+import weakref
+
+from .types import DMatch, KeyPoint, KeyPointList, HAVE_CV2, keypoints_from_xy, matches_from_ij, xy_from_keypoints
 from ... import _native, weights as _weights
 from ...aliked import AlikedHIP
 from ...lightglue import LightGlueHIP
@@ -71,6 +74,8 @@ def init_feature_pipeline(args):
                              max_num_keypoints=max_kpts, max_h=MAX_IMAGE_H, max_w=MAX_IMAGE_W, ctx=ctx)
         matcher = LightGlueHIP(_state_dict(ENV_LIGHTGLUE, _weights.random_lightglue_state_dict, "LightGlue (aliked_lightglue)"),
                                max_kpts=max_kpts, ctx=ctx)
+        # extractor and matcher share one stream: the matcher may read the extractor's device records directly
+        matcher._feature_ring = _ring_of(detector)
         return detector, matcher
     if not HAVE_CV2:
         raise ImportError("the OpenCV detector/matcher branch needs cv2; this backend accelerates "
@@ -106,11 +111,97 @@ def _convert_lg_matches_to_opencv(ij: np.ndarray) -> List[DMatch]:
     return matches_from_ij(np.asarray(ij))
 
 
+class _DeviceFeatureRing:
+    """Device-resident features of the last few frames `feature_extractor` served (a ring of SLOTS records of
+    {xy [K,2], desc [K,128], count}), so that `feature_matcher` on (t-1, t) reads both operands where the
+    extractor left them: no keypoint rebuild, no 2 x 1 MB descriptor upload, no staging copy.
+
+    Ownership: the arrays handed to the caller are the caller's - the descriptor array is
+    returned READ-ONLY (the reference never writes into it; an in-place edit would silently desynchronise the
+    device copy, so numpy refuses it), the keypoint list is a `KeyPointList` that knows when it was edited.  A
+    hit needs the SAME descriptor array object (identity, checked through a weak reference so a recycled `id`
+    cannot alias) and keypoints equal to the remembered ones; anything else takes the host path.  A slot is
+    recycled after SLOTS further extractions (a keyframe's features held longer simply miss)."""
+    SLOTS = 4
+
+    def __init__(self, detector):
+        self.det = detector
+        self.ctx = detector.ctx
+        K = self.K = int(detector.max_num_keypoints)
+        m = self.ctx.malloc
+        self.slots = [dict(xy=m(K * 8), desc=m(K * 128 * 4), score=m(K * 4), cnt=m(16), key=None) for _ in range(self.SLOTS)]
+        self.by_id = {}                  # id(descriptor array) -> entry
+        self.turn = 0
+        self.img_dev, self.img_cap = 0, 0
+        self.tmp_xy = [m(K * 8), m(K * 8)]               # keypoints of an edited list (uploaded per call)
+        self.out_ij, self.out_sc, self.out_info = m(K * 8), m(K * 4), m(16)
+        detector.use_graphs(True)        # the slots are a fixed set of buffers: the launch sequence replays as a graph
+
+    def extract(self, img):
+        det, ctx = self.det, self.ctx
+        img = np.ascontiguousarray(img)
+        if img.dtype != np.uint8:
+            raise TypeError("feature extraction expects a uint8 image (cv2.imread output)")
+        if img.ndim == 2:
+            H, Wd, Cn = img.shape[0], img.shape[1], 1
+        elif img.ndim == 3:
+            H, Wd, Cn = img.shape
+        else:
+            raise ValueError(f"unsupported image shape {img.shape}")
+        if img.nbytes > self.img_cap:
+            if self.img_dev:
+                ctx.sync(); ctx.free(self.img_dev)
+            self.img_cap = max(img.nbytes, 1241 * 376 * 3)
+            self.img_dev = ctx.malloc(self.img_cap)
+        sl = self.slots[self.turn % self.SLOTS]
+        self.turn += 1
+        if sl["key"] is not None:
+            self.by_id.pop(sl["key"], None)
+            sl["key"] = None
+        ctx.h2d(self.img_dev, img)
+        det.extract_dev(self.img_dev, H, Wd, Cn, sl["xy"], sl["desc"], sl["score"], sl["cnt"], max_kpts=self.K)
+        cnt = np.empty(4, np.int32)
+        ctx.d2h(cnt[:1], sl["cnt"])
+        n = int(cnt[0])
+        xy = np.empty((n, 2), np.float32); desc = np.empty((n, 128), np.float32)
+        if n:
+            ctx.d2h(xy, sl["xy"]); ctx.d2h(desc, sl["desc"])
+        desc.setflags(write=False)
+        kps = KeyPointList(keypoints_from_xy(xy), xy)
+        entry = dict(slot=sl, n=n, desc_ref=weakref.ref(desc), xy=xy)
+        sl["key"] = id(desc)
+        self.by_id[id(desc)] = entry
+        return kps, desc
+
+    def lookup(self, des, kps, which):
+        """(device xy, device desc, n, device count) for a frame this ring still holds, else None."""
+        e = self.by_id.get(id(des))
+        if e is None or e["desc_ref"]() is not des or len(kps) != e["n"]:
+            return None
+        xy = kps.pristine_xy() if isinstance(kps, KeyPointList) else None
+        if xy is not None and xy is e["xy"]:
+            return e["slot"]["xy"], e["slot"]["desc"], e["n"], e["slot"]["cnt"]
+        # another list / an edited one: rebuild the keypoints like the reference does (features_utils.py:65-77);
+        # the descriptors on the device are still the ones of `des`
+        xy = xy_from_keypoints(kps)
+        if np.array_equal(xy, e["xy"]):
+            return e["slot"]["xy"], e["slot"]["desc"], e["n"], e["slot"]["cnt"]
+        self.ctx.h2d(self.tmp_xy[which], xy)
+        return self.tmp_xy[which], e["slot"]["desc"], e["n"], e["slot"]["cnt"]
+
+
+def _ring_of(detector):
+    ring = getattr(detector, "_feature_ring", None)
+    if ring is None:
+        ring = detector._feature_ring = _DeviceFeatureRing(detector)
+    return ring
+
+
 def feature_extractor(args, img: np.ndarray, detector):
     """One image -> (list[KeyPoint], descriptors [N,128] float32 unit rows)."""
     if args.use_lightglue:
-        xy, desc = detector.extract(img)        # includes the reference's second L2 normalisation (:100)
-        return _convert_lg_kps_to_opencv(xy), desc
+        # includes the reference's second L2 normalisation (:100); the features also stay on the GPU for the matcher
+        return _ring_of(detector).extract(img)
     kp0, des0 = detector.detectAndCompute(img, None)
     if des0 is None:
         return [], []
@@ -123,6 +214,24 @@ def _as_numpy_f32(x):
     return np.ascontiguousarray(x, dtype=np.float32)
 
 
+def _match_resident(ring, matcher, a, b, thr):
+    """Both frames are still on the GPU: enqueue the match on their records, read back {count, pairs}."""
+    ctx = ring.ctx
+    matcher.match_dev(a[0], a[1], a[2], b[0], b[1], b[2], ring.out_ij, ring.out_sc, ring.out_info, min_conf=thr,
+                      m_dev=a[3], n_dev=b[3])
+    info = np.empty(4, np.int32)
+    ctx.d2h(info, ring.out_info)
+    k = int(info[0])
+    if k < 0:
+        matcher.range_overflow()                # reported here: clear the instance's sticky word
+        raise _native.NativeError("feature_matcher: an activation left the fp16 range of the split-precision path "
+                                  "(|value| >= 65520); rescale the descriptors or use matcher.set_precision('f32')")
+    ij = np.empty((k, 2), np.int32)
+    if k:
+        ctx.d2h(ij, ring.out_ij)
+    return ij
+
+
 def feature_matcher(args, kp0, kp1, des0, des1, matcher):
     """Two frames -> list[DMatch] (LightGlue: ascending queryIdx, score > args.min_conf)."""
     if (des0 is None or des1 is None or kp0 is None or kp1 is None
@@ -130,6 +239,12 @@ def feature_matcher(args, kp0, kp1, des0, des1, matcher):
         return []
     if args.use_lightglue:
         thr = float(getattr(args, "min_conf", 0.7))
+        ring = getattr(matcher, "_feature_ring", None)
+        if ring is not None and isinstance(des0, np.ndarray) and isinstance(des1, np.ndarray):
+            a = ring.lookup(des0, kp0, 0)
+            b = ring.lookup(des1, kp1, 1) if a is not None else None
+            if a is not None and b is not None:
+                return _convert_lg_matches_to_opencv(_match_resident(ring, matcher, a, b, thr))
         ij, _scores, _stop = matcher.match(_convert_opencv_to_lg_kps(kp0), _as_numpy_f32(des0),
                                            _convert_opencv_to_lg_kps(kp1), _as_numpy_f32(des1), min_conf=thr)
         return _convert_lg_matches_to_opencv(ij)

@@ -96,3 +96,46 @@ def xy_from_keypoints(kps):
 def matches_from_ij(ij):
     """[K,2] int array -> list of DMatch(queryIdx, trainIdx, 0, 0.0) (features_utils.py:80-83)."""
     return [DMatch(i, j, 0, 0.0) for i, j in ij.tolist()]
+
+
+class KeyPointList(list):
+    """The list `feature_extractor` returns: an ordinary list of KeyPoint that also remembers the float32 [N,2]
+    array it was built from and whether it has been edited since (every list mutator sets `_dirty`), so that
+    `feature_matcher` can use the copy of the keypoints that is still on the GPU instead of rebuilding and
+    re-uploading them.  A copy (`list(kps)`), a slice or an edited list is an ordinary / dirty list and takes
+    the rebuilding path.  (An in-place edit of an ELEMENT - `kps[i].pt = ...` - cannot be seen by the list;
+    the matcher spot-checks eight elements against the remembered array and falls back when they differ.)"""
+    __slots__ = ("_xy", "_dirty")
+
+    def __init__(self, items=(), xy=None):
+        super().__init__(items)
+        self._xy = xy
+        self._dirty = xy is None
+
+    def _touch(self):
+        self._dirty = True
+
+    def __setitem__(self, i, v): self._touch(); super().__setitem__(i, v)
+    def __delitem__(self, i): self._touch(); super().__delitem__(i)
+    def __iadd__(self, o): self._touch(); return super().__iadd__(o)
+    def __imul__(self, o): self._touch(); return super().__imul__(o)
+    def append(self, v): self._touch(); super().append(v)
+    def extend(self, v): self._touch(); super().extend(v)
+    def insert(self, i, v): self._touch(); super().insert(i, v)
+    def pop(self, *a): self._touch(); return super().pop(*a)
+    def remove(self, v): self._touch(); super().remove(v)
+    def reverse(self): self._touch(); super().reverse()
+    def sort(self, **kw): self._touch(); super().sort(**kw)
+    def clear(self): self._touch(); super().clear()
+
+    def pristine_xy(self):
+        """The array this list was built from if it is provably still what the list holds, else None."""
+        if self._dirty or self._xy is None or len(self) != len(self._xy):
+            return None
+        n = len(self)
+        for i in range(0, n, max(1, n // 8)):              # spot check against in-place element edits
+            x, y = self[i].pt
+            if x != float(self._xy[i, 0]) or y != float(self._xy[i, 1]):
+                self._dirty = True
+                return None
+        return self._xy

@@ -1,0 +1,26 @@
+"""Which random-init weight offsets give a non-trivial early-stop / pruning histogram on the bench streams."""
+import importlib, sys
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import bench
+pkg = importlib.import_module("opencv-simpleslam_amd"); nat = pkg._native
+W = importlib.import_module("opencv-simpleslam_amd.weights")
+AL = importlib.import_module("opencv-simpleslam_amd.aliked").AlikedHIP
+LG = importlib.import_module("opencv-simpleslam_amd.lightglue").LightGlueHIP
+fs = importlib.import_module("opencv-simpleslam_amd.frame_shard")
+B, P, K = 16, 8, 2048
+dets = [AL(W.random_aliked_state_dict(0), max_num_keypoints=K, max_h=376, max_w=1241, ctx=nat.Context(0))]
+frames = np.stack([bench.structured_frame(f) for f in range(B)])
+for cb, mb in [(1.0, -4.6), (1.3, -4.6), (1.5, -4.6), (1.6, -4.6), (1.7, -4.6), (1.8, -4.6), (1.9, -4.6), (1.7, 3.0)]:
+    sd = W.random_lightglue_state_dict(4, match_gain=4.0, match_bias=mb, conf_bias=cb)
+    mats = [LG(sd, max_kpts=K, ctx=nat.Context(0), max_pairs=P)]
+    pipe = fs.FrameStreamPipeline(dets, mats, fs.ShardPlan(1, 0, B), K, 0.7, batch_pairs=P)
+    chunk = pipe.ctx.upload(frames)
+    pipe.round(chunk, 376, 1241, 3); pipe.round(chunk, 376, 1241, 3)
+    info = pipe.infos()
+    lay, cnt = np.unique(info[info[:, 2] > 0, 1], return_counts=True)
+    print(f"conf_bias {cb} match_bias {mb}: layers {dict(zip(lay.tolist(), cnt.tolist()))}  kept kpts {info[:, 2].min()}..{info[:, 2].max()} / {info[:, 3].min()}..{info[:, 3].max()}  matches {info[:, 0].min()}..{info[:, 0].max()}", flush=True)
+    pipe.ctx.free(chunk)
+    for m in mats: m.close()

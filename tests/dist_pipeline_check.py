@@ -1,7 +1,13 @@
-"""Launched by tests/test_pipeline_gpu.py under torch.distributed.run with 2 ranks (gloo, both on
-GPU 0): every rank runs the frame-sharded pipeline for two rounds and checks its own frames against
-the sequential host API - keypoints, and the match indices of EVERY pair including the ones that
-straddle a rank / round boundary (which need the gathered features of the neighbour)."""
+"""Launched by tests/test_pipeline_gpu.py under torch.distributed.run: every rank runs the frame-sharded
+pipeline for THREE rounds enqueued back to back with no host synchronisation in between (so two rounds
+are in flight: record-set double buffering, the per-half all-gathers on the collation stream, the halo
+record of the previous round, extracts of round r+1 under the matches of round r all get exercised), and
+checks its own frames against the sequential host API - keypoints, the match indices of EVERY pair including
+the ones that straddle a rank / round boundary (which need the gathered features of the neighbour) - and the
+collated shared map of every round.
+
+    SSLAM_DIST_BACKEND = gloo (default; ranks may share GPU 0) | nccl (= RCCL: one GPU per rank)
+"""
 import importlib
 import os
 import sys
@@ -16,53 +22,83 @@ sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import frames                                                      # noqa: E402
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-torch.cuda.set_device(0)
-dist.init_process_group("gloo", rank=rank, world_size=world)
+backend = os.environ.get("SSLAM_DIST_BACKEND", "gloo")
+dev = int(os.environ.get("LOCAL_RANK", rank)) % torch.cuda.device_count() if backend == "nccl" else 0
+torch.cuda.set_device(dev)
+if backend == "nccl":
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+else:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
 pkg = importlib.import_module("opencv-simpleslam_amd")
 nat = pkg._native
 W = importlib.import_module("opencv-simpleslam_amd.weights")
 fs = importlib.import_module("opencv-simpleslam_amd.frame_shard")
 AL = importlib.import_module("opencv-simpleslam_amd.aliked").AlikedHIP
 LG = importlib.import_module("opencv-simpleslam_amd.lightglue").LightGlueHIP
-K, B, H, Wd, ROUNDS = 384, 3, 160, 256, 2
+K, B, H, Wd, ROUNDS = 384, 3, 160, 256, 3
 sd_a = W.random_aliked_state_dict(0)
 sd_l = W.random_lightglue_state_dict(1, match_gain=4.0, match_bias=3.0)
 n_frames = ROUNDS * world * B
 imgs = [frames.structured_frame(i, h=H, w=Wd) for i in range(n_frames)]
-ctx0 = nat.default_context(0)
+ctx0 = nat.default_context(dev)
 det0 = AL(sd_a, max_num_keypoints=K, max_h=H, max_w=Wd, ctx=ctx0)
 mat0 = LG(sd_l, max_kpts=K, ctx=ctx0, filter_threshold=0.0)     # every mutual arg-max: non-vacuous
 feats = [det0.extract(im, K) for im in imgs]
 ref = [None] + [mat0.match(feats[i - 1][0], feats[i - 1][1], feats[i][0], feats[i][1], min_conf=0.0)
                 for i in range(1, n_frames)]
 plan = fs.ShardPlan(world, rank, B)
-checked = 0
-dets = [AL(sd_a, max_num_keypoints=K, max_h=H, max_w=Wd, ctx=nat.Context(0)) for _ in range(2)]
-mats = [LG(sd_l, max_kpts=K, ctx=nat.Context(0), max_pairs=2, filter_threshold=0.0) for _ in range(2)]
+dets = [AL(sd_a, max_num_keypoints=K, max_h=H, max_w=Wd, ctx=nat.Context(dev)) for _ in range(2)]
+mats = [LG(sd_l, max_kpts=K, ctx=nat.Context(dev), max_pairs=2, filter_threshold=0.0) for _ in range(2)]
 pipe = fs.FrameStreamPipeline(dets, mats, plan, K, 0.0, batch_pairs=2)
+ctx = pipe.ctx
+col = nat.Context(dev)                      # collector stream: snapshots a round's outputs without a host sync
+chunks = [ctx.upload(np.stack([imgs[f] for f in plan.frames(r)])) for r in range(ROUNDS)]
+hist = []
 for rnd in range(ROUNDS):
+    pipe.round(chunks[rnd], H, Wd, 3)
+    pset = pipe.last_set
+    for ev in pipe.ev_batch[pset][:pipe.n_batches[pset]] + pipe.ev_ext[pset] + [pipe.ev_collated[pset]]:
+        col.wait(ev)
+    h = dict(rec=col.malloc(B * pipe.REC * 4), ij=col.malloc(B * K * 8), info=col.malloc(B * 16),
+             smap=col.malloc(world * B * pipe.REC * 4))
+    col.d2d_async(h["rec"], pipe.rec_ptr(pset * B), B * pipe.REC * 4)
+    col.d2d_async(h["ij"], pipe.ij, B * K * 8)
+    col.d2d_async(h["info"], pipe.info, B * 16)
+    col.d2d_async(h["smap"], int(pipe.shared_map.data_ptr()), world * B * pipe.REC * 4)
+    ev = col.event(); col.record(ev)        # the pipeline's next-but-one round must not overwrite before the copies ran
+    for d in pipe.dets:
+        d.ctx.wait(ev)
+    pipe.cctx.wait(ev)
+    hist.append(h)
+pipe.sync(); col.sync()
+checked = 0
+for rnd, h in enumerate(hist):
     mine = list(plan.frames(rnd))
-    chunk = pipe.ctx.upload(np.stack([imgs[f] for f in mine]))
-    pipe.round(chunk, H, Wd, 3)
-    res = pipe.results()
-    got = pipe.features()
+    rec = np.empty((B, pipe.REC), np.float32); ij = np.empty((B, K, 2), np.int32); info = np.empty((B, 4), np.int32)
+    smap = np.empty((world * B, pipe.REC), np.float32)
+    ctx.d2h(rec, h["rec"]); ctx.d2h(ij, h["ij"]); ctx.d2h(info, h["info"]); ctx.d2h(smap, h["smap"])
     for s, f in enumerate(mine):
-        assert len(got[s][0]) == len(feats[f][0]), (rank, f)
-        np.testing.assert_array_equal(got[s][0], feats[f][0])
+        n, xy, desc = fs.unpack_record(rec[s], K)
+        assert n == len(feats[f][0]), (rank, f)
+        np.testing.assert_array_equal(xy, feats[f][0])
         if f == 0:
             continue
-        np.testing.assert_array_equal(res[s][0], ref[f][0], err_msg=f"rank {rank} frame {f}")
+        assert info[s, 0] >= 0, (rank, f)
+        np.testing.assert_array_equal(ij[s, :info[s, 0]], ref[f][0], err_msg=f"rank {rank} round {rnd} frame {f}")
         checked += 1
     # the collated map holds every rank's features of this round, in global frame order
-    torch.cuda.synchronize()
-    sm_all = pipe.shared_map.cpu().numpy()
     for j in range(world * B):
         f = rnd * world * B + j
-        n, xy, desc = fs.unpack_record(sm_all[j], K)
-        assert n == len(feats[f][0])
+        n, xy, desc = fs.unpack_record(smap[j], K)
+        assert n == len(feats[f][0]), (rank, rnd, j)
         np.testing.assert_array_equal(xy, feats[f][0])
         np.testing.assert_array_equal(desc, feats[f][1])
+for h in hist:
+    for p_ in h.values():
+        col.free(p_)
+for c_ in chunks:
+    ctx.free(c_)
 assert sum(len(r[0]) for r in ref[1:]) > 5, "vacuous: the sequential reference found no matches"
 dist.barrier()
-print(f"rank {rank}: {checked} pairs identical to the sequential API", flush=True)
+print(f"rank {rank} ({backend}, device {dev}): {checked} pairs identical to the sequential API over {ROUNDS} un-synchronised rounds", flush=True)
 dist.destroy_process_group()

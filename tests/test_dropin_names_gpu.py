@@ -112,3 +112,50 @@ def test_grayscale_and_float_images(fu, pipeline):
     assert len(kp) > 0 and des.shape[1] == 128
     with pytest.raises(TypeError):
         fu.feature_extractor(args, g.astype(np.float32), det)
+
+
+def test_matcher_reads_the_extractor_device_records_when_it_can(fu, pipeline, monkeypatch):
+    """r03: `feature_matcher` on the arrays `feature_extractor` returned reads both frames where the extractor
+    left them on the GPU (no keypoint rebuild, no descriptor upload); a copied / edited keypoint list, descriptors
+    that are not the returned array, or a frame that fell out of the ring take the host path - with the same
+    matches either way (reference contract: features_utils.py:109-171, ownership SURVEY 8(b))."""
+    args, det, mat = pipeline
+    T = load_pkg("slam.core.types")
+    frames_ = [frames.structured_frame(i) for i in range(7)]
+    kp0, des0 = fu.feature_extractor(args, frames_[0], det)
+    kp1, des1 = fu.feature_extractor(args, frames_[1], det)
+    assert isinstance(kp0, T.KeyPointList) and not des0.flags.writeable
+    with pytest.raises(ValueError):
+        des0[0, 0] = 1.0                                  # read-only: the device copy cannot go stale silently
+    host_calls = []
+    real_match = mat.match
+    monkeypatch.setattr(mat, "match", lambda *a, **k: (host_calls.append(1), real_match(*a, **k))[1])
+    pairs = lambda ms: [(m.queryIdx, m.trainIdx) for m in ms]
+    m_res = fu.feature_matcher(args, kp0, kp1, des0, des1, mat)
+    assert host_calls == [] and len(m_res) > 0            # resident path
+    m_host = fu.feature_matcher(args, list(kp0), list(kp1), des0.copy(), des1.copy(), mat)
+    assert len(host_calls) == 1 and pairs(m_host) == pairs(m_res)      # same matches through the host path
+    # copied lists with the SAME keypoints still hit (the keypoints are rebuilt and compared)
+    fu.feature_matcher(args, list(kp0), list(kp1), des0, des1, mat)
+    assert len(host_calls) == 1
+    # an edited list: its keypoints are uploaded, the descriptors stay resident; result = host path on the same inputs
+    kp0e = T.KeyPointList(kp0, kp0._xy)
+    i = len(kp0e) // 3
+    kp0e[i] = T.KeyPoint(kp0[i].pt[0] + 150.0, kp0[i].pt[1] + 3.0, 1)
+    m_e = fu.feature_matcher(args, kp0e, kp1, des0, des1, mat)
+    assert len(host_calls) == 1
+    m_eh = fu.feature_matcher(args, list(kp0e), kp1, des0.copy(), des1, mat)
+    assert len(host_calls) == 2 and pairs(m_e) == pairs(m_eh)
+    # an element edited in place is caught by the spot check or by the rebuild: never a stale result
+    orig = kp1[0].pt
+    kp1[0].pt = (orig[0] + 80.0, orig[1])                # (the list itself is untouched and still "pristine")
+    m_p = fu.feature_matcher(args, kp0, kp1, des0, des1, mat)
+    m_ph = fu.feature_matcher(args, list(kp0), list(kp1), des0.copy(), des1.copy(), mat)
+    assert pairs(m_p) == pairs(m_ph)
+    kp1[0].pt = orig
+    # frames older than the ring (4 slots) fall back to the host path
+    for im in frames_[2:7]:
+        kpn, desn = fu.feature_extractor(args, im, det)
+    n_before = len(host_calls)
+    fu.feature_matcher(args, kp0, kpn, des0, desn, mat)
+    assert len(host_calls) == n_before + 1

@@ -64,6 +64,14 @@ def _worker(rank, world, port, out_dir):
         records = torch.from_numpy(np.stack([_frame_record(fs, f, K) for f in plan.frames(rnd)]))
         full = fs.collate(records, plan)
         torch.save(full, Path(out_dir) / f"r{rank}_round{rnd}.pt")
+        # the pipeline's form: gathered in two parts (as the extracts of each half finish) into a buffer the
+        # caller owns - same shared map, no allocation
+        out = torch.full_like(full, -1.0)
+        for part in ((0, 2), (2, 3)):
+            got = fs.collate(records, plan, out=out, part=part)
+            assert got is out
+        assert torch.equal(out, full), f"rank {rank} round {rnd}: part-wise gather differs"
+        assert fs.collate(records, plan, out=out) is out and torch.equal(out, full)
     dist.barrier()
     dist.destroy_process_group()
 

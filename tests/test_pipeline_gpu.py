@@ -102,7 +102,7 @@ def test_bench_contract_single_rank():
     d = _run_bench({}, [sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                 "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "structured_input",
-                "exact_f32", "ba", "reproject"):
+                "exact_f32", "ba", "reproject", "step_ms", "timed_region_s", "early_stop", "dropin"):
         assert key in d
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["unit"] == "frames/s"
     r = d["roofline"]
@@ -110,6 +110,10 @@ def test_bench_contract_single_rank():
     assert 0 < r["in_pipeline_frac"] <= r["frac"] * 1.2
     assert 0 < d["exact_f32"]["value"] < d["value"] * 1.05
     assert d["ba"]["device_lm_ms"] > 0 and 0 < d["ba"]["residual_kernel"]["frac"] < 1 and d["reproject"]["wall_ms"] > 0
+    assert 0 < d["step_ms"]["p10"] <= d["step_ms"]["p50"] <= d["step_ms"]["p90"] <= d["step_ms"]["max"]
+    assert d["dropin"]["value"] > 0 and d["dropin"]["feature_matcher_ms"] > 0, d["dropin"]
+    es = d["early_stop"]
+    assert es["value"] > 0 and es["lightglue_layers_histogram"] and set(es["lightglue_layers_histogram"]) != {"9"}, es
 
 
 def test_bench_self_launches_its_ranks():
@@ -134,20 +138,36 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     assert d["config"]["frames_per_step_per_gpu"] == 6
 
 
-def test_two_rank_pipeline_equals_sequential_api():
-    """N > 1 data path: tests/dist_pipeline_check.py under torch.distributed.run, 2 gloo ranks on one GPU."""
+def _run_dist_check(backend, nproc, port):
     import os, subprocess, sys
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29613", "tests/dist_pipeline_check.py"],
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", SSLAM_DIST_BACKEND=backend,
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), "tests/dist_pipeline_check.py"],
                          cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
-    assert out.stdout.count("pairs identical to the sequential API") == 2
+    assert out.stdout.count("pairs identical to the sequential API") == nproc
+
+
+def test_two_rank_pipeline_equals_sequential_api():
+    """N > 1 data path: tests/dist_pipeline_check.py under torch.distributed.run, 2 gloo ranks on one GPU, three
+    rounds in flight without a host synchronisation."""
+    _run_dist_check("gloo", 2, 29613)
+
+
+def test_two_rank_pipeline_over_rccl(native):
+    """The same check with backend `nccl` (= RCCL over xGMI), one GPU per rank: runs wherever >= 2 devices are
+    visible (the driver's 8-GPU node), skipped on a 1-GPU box - so the first multi-GPU lease produces evidence
+    for the collation path instead of being its first execution."""
+    n = native.device_count()
+    if n < 2:
+        pytest.skip(f"{n} GPU visible: the RCCL path needs two")
+    _run_dist_check("nccl", 2, 29615)
 
 
 def test_pipeline_reports_a_split_precision_range_overflow(native):
     """the headline path must not hand on matches computed past the fp16 range of the
-    split-precision planes.  Descriptors scaled by 1e5 through the PIPELINE: `results()` / `infos()` raise,
+    split-precision planes.  Token states scaled by 1e7 through the PIPELINE: `results()` / `infos()` raise,
     the per-instance flags are raised (and cleared by the report), a second matcher instance that never saw
     the data stays clean, and the next (sane) round is served normally."""
     W = load_pkg("weights"); fs = load_pkg("frame_shard")
@@ -155,12 +175,12 @@ def test_pipeline_reports_a_split_precision_range_overflow(native):
     K, H, Wd, B, P = 256, 160, 256, 3, 2
     sd_a = W.random_aliked_state_dict(0)
     sd_l = W.random_lightglue_state_dict(1, match_gain=4.0, match_bias=3.0)
-    sd_big = {k: v.clone() for k, v in sd_l.items()}
-    sd_big["input_proj.weight"] = sd_big["input_proj.weight"] * 1e5           # every token state x 1e5
+    sd_big = dict(sd_l)
+    sd_big["input_proj.weight"] = sd_big["input_proj.weight"] * 1e7           # every token state x 1e7: far past 65520
     dets = [AL(sd_a, max_num_keypoints=K, max_h=H, max_w=Wd, ctx=native.Context(0))]
     imgs = np.stack([frames.structured_frame(i, h=H, w=Wd) for i in range(B)])
     for sd, expect in ((sd_big, True), (sd_l, False)):
-        mats = [LG(sd, max_kpts=K, ctx=native.Context(0), max_pairs=P) for _ in range(2)]
+        mats = [LG(sd, max_kpts=K, ctx=native.Context(0), max_pairs=P, filter_threshold=0.0) for _ in range(2)]
         pipe = fs.FrameStreamPipeline(dets, mats, fs.ShardPlan(1, 0, B), K, 0.0, batch_pairs=P)
         chunk = pipe.ctx.upload(imgs)
         pipe.round(chunk, H, Wd, 3)
