@@ -230,6 +230,13 @@ int sslam_lightglue_match_host(sslam_lightglue* lg, const float* xy0, const floa
                                const float* xy1, const float* desc1, int N, float min_conf,
                                int32_t* ij_out, float* score_out, int32_t* k_out,
                                int32_t* stop_layer_out);
+/* The same with the 'image_size' of each feature set (size0 / size1: host float[2] = (W, H), or NULL): LightGlue then
+ * normalises the keypoints by the image size instead of their bounding box - what happens when the features
+ * come straight from `extractor.extract`, i.e. the reference's legacy pair entry `_lightglue_detect_and_match`
+ * (slam/core/features_utils.py:233-247; cvg/LightGlue `normalize_keypoints(kpts, size)`). */
+int sslam_lightglue_match_host_sized(sslam_lightglue* lg, const float* xy0, const float* desc0, int M, const float* size0,
+                                     const float* xy1, const float* desc1, int N, const float* size1, float min_conf,
+                                     int32_t* ij_out, float* score_out, int32_t* k_out, int32_t* stop_layer_out);
 /* Device-pointer variant; enqueue only.  M, N bound the rows of the input arrays; m_dev /
  * n_dev (device int32[1], may be NULL) carry the actual keypoint counts when they are only
  * known on the device (written by sslam_aliked_extract_dev), so an extract -> match chain

@@ -91,6 +91,7 @@ struct StageSrc {
     const float* desc[2 * MAX_PAIRS];
     const int32_t* cnt[2 * MAX_PAIRS];
     int bound[2 * MAX_PAIRS];
+    float size_w[2 * MAX_PAIRS], size_h[2 * MAX_PAIRS];   // 'image_size' of the features (W, H); 0 = none: bounding box
 };
 
 // ------------------------------------------------------------------------ //
@@ -134,8 +135,10 @@ __global__ __launch_bounds__(1024) void lg_prepare_kernel(
         mnx = fminf(mnx, red[0][i]); mxx = fmaxf(mxx, red[1][i]);
         mny = fminf(mny, red[2][i]); mxy = fmaxf(mxy, red[3][i]);
     }
-    // size = 1 + max - min ; shift = size / 2 ; scale = max(size) / 2
-    const float sx = 1.0f + mxx - mnx, sy = 1.0f + mxy - mny;
+    // size = 1 + max - min (or the image's (W, H) when the features carry 'image_size': the legacy pair entry,
+    // features_utils.py:233-247) ; shift = size / 2 ; scale = max(size) / 2
+    const bool sized = src.size_w[img] > 0.0f && src.size_h[img] > 0.0f;
+    const float sx = sized ? src.size_w[img] : 1.0f + mxx - mnx, sy = sized ? src.size_h[img] : 1.0f + mxy - mny;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         ind[img * Kc + i] = i;
         prune[img * Kc + i] = 1;
@@ -2389,6 +2392,8 @@ int lg_enqueue_cached(sslam_lightglue* g, int pairs, const StageSrc& src, float 
     for (int i = 0; i < 2 * pairs; ++i) {
         key.push_back((uint64_t)src.xy[i]); key.push_back((uint64_t)src.desc[i]);
         key.push_back((uint64_t)src.cnt[i]); key.push_back((uint64_t)src.bound[i]);
+        uint64_t sz = 0; memcpy(&sz, &src.size_w[i], 4); memcpy((char*)&sz + 4, &src.size_h[i], 4);
+        key.push_back(sz);
     }
     return sslam::run_cached(g->graphs, g->ctx->stream, key, [&] {
         return lg_enqueue(g, pairs, src, min_conf, ij_out, score_out, info_out, out_stride);
@@ -2559,7 +2564,16 @@ int sslam_lightglue_match_host(sslam_lightglue* g, const float* xy0, const float
                                const float* xy1, const float* desc1, int N, float min_conf,
                                int32_t* ij_out, float* score_out, int32_t* k_out,
                                int32_t* stop_layer_out) {
+    return sslam_lightglue_match_host_sized(g, xy0, desc0, M, nullptr, xy1, desc1, N, nullptr, min_conf, ij_out, score_out,
+                                            k_out, stop_layer_out);
+}
+
+int sslam_lightglue_match_host_sized(sslam_lightglue* g, const float* xy0, const float* desc0, int M, const float* size0,
+                                     const float* xy1, const float* desc1, int N, const float* size1, float min_conf,
+                                     int32_t* ij_out, float* score_out, int32_t* k_out, int32_t* stop_layer_out) {
     SSLAM_REQUIRE(g && ij_out && score_out && k_out, "sslam_lightglue_match_host: NULL argument");
+    SSLAM_REQUIRE((!size0 || (size0[0] > 0 && size0[1] > 0)) && (!size1 || (size1[0] > 0 && size1[1] > 0)),
+                  "sslam_lightglue_match_host_sized: image_size must be positive (W, H)");
     SSLAM_REQUIRE(M >= 0 && N >= 0 && M <= g->Kc && N <= g->Kc,
                   "sslam_lightglue_match_host: M=%d N=%d exceed max_kpts capacity %d", M, N, g->Kc);
     *k_out = 0;
@@ -2576,6 +2590,8 @@ int sslam_lightglue_match_host(sslam_lightglue* g, const float* xy0, const float
     StageSrc src{};
     src.xy[0] = g->up_xy; src.desc[0] = g->up_desc; src.bound[0] = M;
     src.xy[1] = g->up_xy + 2 * K; src.desc[1] = g->up_desc + K * DIN; src.bound[1] = N;
+    if (size0) { src.size_w[0] = size0[0]; src.size_h[0] = size0[1]; }
+    if (size1) { src.size_w[1] = size1[0]; src.size_h[1] = size1[1]; }
     g->last_pairs = 1;
     if (int rc = lg_enqueue(g, 1, src, min_conf, g->out_ij, g->out_score, g->out_info, (long)K)) return rc;
     int32_t info[4];

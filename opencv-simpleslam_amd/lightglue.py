@@ -56,8 +56,10 @@ class LightGlueHIP:
         except Exception:
             pass
 
-    def match(self, xy0, desc0, xy1, desc1, min_conf: float = 0.7):
-        """Host arrays in, host arrays out: (matches [K,2] int32, scores [K], stop_layer)."""
+    def match(self, xy0, desc0, xy1, desc1, min_conf: float = 0.7, size0=None, size1=None):
+        """Host arrays in, host arrays out: (matches [K,2] int32, scores [K], stop_layer).  size0 / size1: optional
+        (W, H) of the images - the 'image_size' entry of upstream feature dicts: keypoints are then normalised by
+        it instead of by their bounding box (the reference's legacy pair entry, features_utils.py:233-247)."""
         xy0 = np.ascontiguousarray(xy0, np.float32).reshape(-1, 2)
         xy1 = np.ascontiguousarray(xy1, np.float32).reshape(-1, 2)
         M, N = len(xy0), len(xy1)
@@ -72,8 +74,10 @@ class LightGlueHIP:
         sc = np.empty((kmax,), np.float32)
         k, stop = C.c_int(0), C.c_int(0)
         P = _native.ptr
-        _native.check(_native.lib().sslam_lightglue_match_host(
-            self.handle, P(xy0), P(desc0), M, P(xy1), P(desc1), N, float(min_conf), P(ij), P(sc),
+        s0 = None if size0 is None else np.ascontiguousarray(size0, np.float32).reshape(2)
+        s1 = None if size1 is None else np.ascontiguousarray(size1, np.float32).reshape(2)
+        _native.check(_native.lib().sslam_lightglue_match_host_sized(
+            self.handle, P(xy0), P(desc0), M, P(s0), P(xy1), P(desc1), N, P(s1), float(min_conf), P(ij), P(sc),
             C.byref(k), C.byref(stop)), "sslam_lightglue_match_host")
         return ij[:k.value].copy(), sc[:k.value].copy(), int(stop.value)
 

@@ -8,6 +8,7 @@ same names, arguments, return types and error behaviour
     feature_extractor(args, img, detector)           features_utils.py:85
     feature_matcher(args, kp0, kp1, des0, des1, m)   features_utils.py:109
     filter_matches_ransac(kp1, kp2, matches, thresh) features_utils.py:185
+    detect_and_match(img1, img2, det, m, args)       features_utils.py:250   (legacy pair entry)
 
 `args` is the CLI namespace of slam/monocular/main_revamped.py (fields read:
 use_lightglue, max_features, min_conf).  Keypoints are `cv2.KeyPoint` when
@@ -250,6 +251,37 @@ def feature_matcher(args, kp0, kp1, des0, des1, matcher):
         return _convert_lg_matches_to_opencv(ij)
     matches = matcher.match(des0, des1)
     return sorted(matches, key=lambda m: m.distance)
+
+
+def _lightglue_detect_and_match(img1, img2, extractor, matcher):
+    """Legacy pair entry (reference features_utils.py:233-247; no longer on its main path, still what its own
+    tests/test_lightglue_vs_manual.py drives): extract both images, match the feature dicts as they come out of
+    `extractor.extract` - they carry 'image_size', so LightGlue normalises the keypoints by the IMAGE size, not by
+    their bounding box - and return every match LightGlue keeps (filter_threshold only, no min_conf cut)."""
+    ring = _ring_of(extractor)
+    kp0, des0 = ring.extract(img1)
+    kp1, des1 = ring.extract(img2)
+    if len(kp0) == 0 or len(kp1) == 0:
+        return kp0, kp1, des0, des1, []
+    h0, w0 = np.asarray(img1).shape[:2]
+    h1, w1 = np.asarray(img2).shape[:2]
+    ij, _scores, _stop = matcher.match(kp0._xy, des0, kp1._xy, des1, min_conf=0.0, size0=(w0, h0), size1=(w1, h1))
+    return kp0, kp1, des0, des1, _convert_lg_matches_to_opencv(ij)
+
+
+def _opencv_detect_and_match(img1, img2, detector, matcher):
+    kp1, des1 = detector.detectAndCompute(img1, None)
+    kp2, des2 = detector.detectAndCompute(img2, None)
+    if des1 is None or des2 is None:
+        return [], [], [], [], []        # gracefully handle empty images
+    return kp1, kp2, des1, des2, sorted(matcher.match(des1, des2), key=lambda m: m.distance)
+
+
+def detect_and_match(img1, img2, detector, matcher, args):
+    """Front-end entry of the reference (features_utils.py:250-256): OpenCV or LightGlue depending on the CLI flag."""
+    if args.use_lightglue:
+        return _lightglue_detect_and_match(img1, img2, detector, matcher)
+    return _opencv_detect_and_match(img1, img2, detector, matcher)
 
 
 def filter_matches_ransac(kp1, kp2, matches, thresh=1.0):

@@ -45,9 +45,14 @@ DEFAULT_CONF = dict(
 )
 
 
-def normalize_keypoints(kpts: torch.Tensor) -> torch.Tensor:
-    """`normalize_keypoints(kpts, size=None)`: size = 1 + max - min."""
-    size = 1 + kpts.max(-2).values - kpts.min(-2).values
+def normalize_keypoints(kpts: torch.Tensor, size=None) -> torch.Tensor:
+    """`normalize_keypoints(kpts, size)`: size = 1 + max - min when None (the split API of the reference,
+    features_utils.py:157-162, passes no 'image_size'); the (W, H) of the image when the features carry it - the
+    legacy pair entry features_utils.py:233-247 hands `extractor.extract` dicts, which do."""
+    if size is None:
+        size = 1 + kpts.max(-2).values - kpts.min(-2).values
+    else:
+        size = torch.as_tensor(size, dtype=kpts.dtype).reshape(1, 2)
     shift = size / 2
     scale = size.max(-1).values / 2
     return (kpts - shift[..., None, :]) / scale[..., None, None]
@@ -172,7 +177,7 @@ def filter_matches(scores, th):
 
 
 @torch.no_grad()
-def lightglue_forward(sd, kpts0, desc0, kpts1, desc1, conf=None, return_debug=False):
+def lightglue_forward(sd, kpts0, desc0, kpts1, desc1, conf=None, return_debug=False, size0=None, size1=None):
     """kpts [M,2]/[N,2] pixel coords, desc [M,128]/[N,128]; returns dict with
     matches [K,2] int64, scores [K], stop (1-based layer count), prune0/prune1."""
     c = dict(DEFAULT_CONF)
@@ -186,8 +191,8 @@ def lightglue_forward(sd, kpts0, desc0, kpts1, desc1, conf=None, return_debug=Fa
     L, H = c["n_layers"], c["num_heads"]
     dbg = {}
 
-    k0 = normalize_keypoints(kpts0).clone()
-    k1 = normalize_keypoints(kpts1).clone()
+    k0 = normalize_keypoints(kpts0, size0).clone()
+    k1 = normalize_keypoints(kpts1, size1).clone()
     x0 = F.linear(x0, sd["input_proj.weight"], sd["input_proj.bias"])
     x1 = F.linear(x1, sd["input_proj.weight"], sd["input_proj.bias"])
     enc0, enc1 = posenc(sd, k0), posenc(sd, k1)

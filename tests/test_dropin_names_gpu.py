@@ -159,3 +159,30 @@ def test_matcher_reads_the_extractor_device_records_when_it_can(fu, pipeline, mo
     n_before = len(host_calls)
     fu.feature_matcher(args, kp0, kpn, des0, desn, mat)
     assert len(host_calls) == n_before + 1
+
+
+def test_legacy_pair_entry_normalises_by_the_image_size(fu, pipeline):
+    """`detect_and_match` / `_lightglue_detect_and_match` (reference features_utils.py:233-256), the form the
+    reference's own tests/test_lightglue_vs_manual.py drives, on that test's disc pair: same keypoints and
+    descriptors as the split API (its assertions a, b), and the matches of the oracle run WITH 'image_size'
+    (upstream normalize_keypoints(kpts, size): the feature dicts of `extractor.extract` carry it) and without
+    the min_conf cut."""
+    args, det, mat = pipeline
+    img1, img2 = frames.disc_pair()
+    kp1, kp2, d1, d2, m = fu.detect_and_match(img1, img2, det, mat, args)
+    kp1s, d1s = fu.feature_extractor(args, img1, det)
+    kp2s, d2s = fu.feature_extractor(args, img2, det)
+    assert [k.pt for k in kp1] == [k.pt for k in kp1s] and [k.pt for k in kp2] == [k.pt for k in kp2s]
+    np.testing.assert_array_equal(d1, d1s); np.testing.assert_array_equal(d2, d2s)
+    if len(kp1) == 0 or len(kp2) == 0:
+        pytest.skip("no keypoints on the disc pair with these weights")
+    xy1 = np.array([k.pt for k in kp1], np.float32); xy2 = np.array([k.pt for k in kp2], np.float32)
+    h1, w1 = img1.shape[:2]; h2, w2 = img2.shape[:2]
+    ref = lightglue_ref.lightglue_forward(_sd_l(), xy1, d1, xy2, d2, size0=(w1, h1), size1=(w2, h2))
+    np.testing.assert_array_equal(np.array([(x.queryIdx, x.trainIdx) for x in m], np.int64).reshape(-1, 2), ref["matches"].numpy())
+    # the bounding-box normalisation of the split API is a different function of the same keypoints
+    nob = lightglue_ref.lightglue_forward(_sd_l(), xy1, d1, xy2, d2)
+    kn_b = lightglue_ref.normalize_keypoints(__import__("torch").as_tensor(xy1)[None])
+    kn_s = lightglue_ref.normalize_keypoints(__import__("torch").as_tensor(xy1)[None], (w1, h1))
+    assert not np.allclose(kn_b.numpy(), kn_s.numpy())
+    assert ref["matches"].shape[1] == 2 and nob["matches"].shape[1] == 2
