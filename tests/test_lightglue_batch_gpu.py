@@ -56,6 +56,8 @@ def test_batch_equals_single_pair_calls_and_oracle(gpu_ctx):
     pairs = [lg_inputs.make_pair(m, n, seed=m + n) for m, n in sizes]
     batch = LG(sd, max_kpts=640, max_pairs=6, ctx=gpu_ctx)
     single = LG(sd, max_kpts=640, ctx=gpu_ctx)
+    single.debug_big_gemm(1)               # the batch's form of the linears (by size a 640-keypoint pair would take the
+    batch.debug_big_gemm(1)                # ring kernels, whose LayerNorm sums in another order): same arithmetic both sides
     dev = DevBatch(gpu_ctx, pairs, 640)
     got = dev.run(batch, 0.7)
     for ks in (0, 1):                      # the single-pair default (key split + merge), then the batch's own
