@@ -41,6 +41,45 @@ def _digest(*parts) -> str:
     return h.hexdigest()
 
 
+LLVM_BIN = Path("/opt/rocm/lib/llvm/bin")
+
+
+def _build_asm_kernels(obj_dir: Path, force: bool, verbose: bool):
+    """Hand-written gfx950 assembly kernels: csrc/gen_<name>.py prints the assembly text (the generator IS the
+    source: register map, schedule, hazards are written there), it is assembled and linked into a code object
+    (clang -x assembler, ld.lld -shared) and the code object is embedded into the host library as the byte array
+    `sslam_<name>_hsaco` (an .incbin stub), which the library loads with hipModuleLoadData at instance creation."""
+    clang, lld = LLVM_BIN / "clang", LLVM_BIN / "ld.lld"
+    out = []
+    for gen in sorted(CSRC.glob("gen_*.py")):
+        name = gen.stem[4:]
+        obj = obj_dir / f"{name}_hsaco.o"
+        keyf = obj_dir / f"{name}_hsaco.key"
+        key = _digest(clang, lld, ARCH, gen.read_bytes())
+        if force or not obj.exists() or not keyf.exists() or keyf.read_text().strip() != key:
+            keyf.unlink(missing_ok=True)
+            env = {k: v for k, v in os.environ.items() if not k.startswith("ATTN_ASM_")}     # no experiment switches
+            text = subprocess.run([sys.executable, str(gen)], capture_output=True, text=True, env=env)
+            if text.returncode != 0:
+                raise RuntimeError(f"{gen.name} failed:\n{text.stderr}")
+            asm, dev_o, hsaco, stub = (obj_dir / f"{name}{e}" for e in (".s", ".dev.o", ".hsaco", "_stub.s"))
+            asm.write_text(text.stdout)
+            stub.write_text(f'    .section .rodata\n    .globl sslam_{name}_hsaco\n    .p2align 12\nsslam_{name}_hsaco:\n'
+                            f'    .incbin "{hsaco}"\n    .globl sslam_{name}_hsaco_end\nsslam_{name}_hsaco_end:\n'
+                            f'    .section .note.GNU-stack,"",@progbits\n')
+            for cmd in ([str(clang), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", f"-mcpu={ARCH}", "-c", str(asm), "-o", str(dev_o)],
+                        [str(lld), "-shared", str(dev_o), "-o", str(hsaco)],
+                        [str(clang), "-c", "-fPIC", str(stub), "-o", str(obj)]):
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                res = subprocess.run(cmd, capture_output=True, text=True)
+                if res.returncode != 0:
+                    raise RuntimeError(f"assembling {name} failed:\n{res.stdout}\n{res.stderr}")
+            keyf.write_text(key + "\n")
+        out.append((obj, key))
+    return out
+
+
 def build_native(force: bool = False, verbose: bool = False) -> Path:
     """Incremental build keyed on CONTENT, not mtimes: an object is reused only if its key file
     holds the hash of (compiler, flags, extra flags, the source, every header).  So an experiment
@@ -77,6 +116,7 @@ def build_native(force: bool = False, verbose: bool = False) -> Path:
 
     with ThreadPoolExecutor(max_workers=min(4, len(sources))) as ex:
         built = list(ex.map(compile_one, sources))
+    built += _build_asm_kernels(obj_dir, force, verbose)
     objs = [o for o, _ in built]
 
     lib_keyf = LIB_DIR / "libsslam_hip.key"

@@ -27,6 +27,7 @@
 // point pruning) lives in a device-side control block `LGCtrl` PER PAIR; every kernel
 // reads its row counts from it, so a batch is a fixed launch sequence with no
 // host round trip (graph-capturable).
+#include <mutex>
 #include <type_traits>
 #include "common.hpp"
 #include "gemm_f32.hpp"
@@ -2020,6 +2021,7 @@ struct sslam_lightglue {
     int dbg_layers = NL;             // test hook: run only the first dbg_layers layers
     int dbg_self_only = 0;           // test hook: stop after the self block of the last executed layer
     int force_ks = 0;                // test hook: key split of the attention launches (0 = by batch size)
+    hipError_t launch_error = hipSuccess;   // first failure of a module-API launch (checked with hipGetLastError at the end of an enqueue)
     int big_gemm = -1;               // test hook: -1 by batch size, 0 / 1 force the single-pair (ring) / batched form of the linears
     _Float16 *w_hi, *w_lo;           // whole weight blob, split
     _Float16 *ffn_w1f[NL][2], *ffn_w2f[NL][2];   // fused-FFN fragment-order weights, [layer][self / cross]
@@ -2091,7 +2093,7 @@ float conf_threshold(int layer) {   // np.clip(0.8 + 0.1 * exp(-4 i / n_layers),
 int attn_key_split(const sslam_lightglue* g, int NI) {
     int ks = 1;
     if (g->force_ks > 0) ks = g->force_ks;
-    else if (g->force_ks == -1) ks = 1;        // (test hook: the 4-wave r02 kernel without key split)
+    else if (g->force_ks < 0) ks = 1;          // (test hooks, no key split: -1 the 4-wave r02 kernel, -2 the half-step kernel, -3 the assembly kernel)
     else {
         const int units = NI * NH * (g->Kc / AQ);
         while (ks < 4 && units * ks < 512 && g->Kc / AK >= 2 * ks * 4) ks *= 2;
@@ -2191,17 +2193,54 @@ LinearArgsH linh(const sslam_lightglue* g, SplitPtr A0, SplitPtr A1, int lda, in
     return a;
 }
 
+// ---- the hand-scheduled form of lg_attention_hs_kernel: gfx950 assembly printed by csrc/gen_lg_attention_asm.py,
+// assembled and embedded by build.py (`sslam_lg_attention_asm_hsaco`), loaded once per device at instance creation
+// (never inside a stream capture) and launched through the module API - which a capture records like any launch.
+extern "C" const unsigned char sslam_lg_attention_asm_hsaco[];
+struct AttnAsmArgs {                // the kernel's argument segment (gen_lg_attention_asm.py: s_load offsets 0x0 .. 0x5c)
+    const _Float16 *q_hi, *q_lo, *k_hi, *k_lo, *vt_hi, *vt_lo;
+    _Float16 *msg_hi, *msg_lo;
+    const LGCtrl* ctrl;
+    int cross, Kc, NIc, nqb, nslab;
+    unsigned magic;                 // floor(2^32 / nqb) + 1: idx / nqb = mulhi(idx, magic) for idx * nqb < 2^32 (nqb > 1)
+    int pad[2];
+};
+static_assert(sizeof(AttnAsmArgs) == 104, "kernel argument segment of lg_attention_asm_kernel");
+constexpr int ASM_MAX_DEVICES = 64;
+hipFunction_t g_attn_asm_fn[ASM_MAX_DEVICES] = {};
+std::mutex g_attn_asm_mutex;
+
+int lg_load_attention_asm(int device) {
+    SSLAM_REQUIRE(device >= 0 && device < ASM_MAX_DEVICES, "device %d out of range", device);
+    std::lock_guard<std::mutex> lock(g_attn_asm_mutex);
+    if (g_attn_asm_fn[device]) return 0;
+    hipModule_t mod;
+    SSLAM_HIP_CHECK(hipModuleLoadData(&mod, sslam_lg_attention_asm_hsaco));
+    SSLAM_HIP_CHECK(hipModuleGetFunction(&g_attn_asm_fn[device], mod, "lg_attention_asm_kernel"));
+    return 0;
+}
+
 void launch_attention_h(sslam_lightglue* g, hipStream_t s, int NI, SplitPtr Q, SplitPtr K, SplitPtr VT, int cross) {
     const int KS = attn_key_split(g, NI);
     AttnArgsH a{Q, K, VT, cross, g->o_part, g->m_part, g->l_part, SplitOut{g->msgs_hi, g->msgs_lo}, KS, g->Kc,
                 g->NIc, g->ctrl};
     attn_event(g, s, true);
-    if (KS == 1 && g->force_ks != -1) {
-        // no key split (batched launches): the half-step form - same arithmetic, bit-identical context planes,
-        // fragment reads half a sub-step ahead of their MFMAs.  (debug_key_split(lg, -1) keeps the r02 kernel
-        // without key split for A/B and for the bit-identity test.)
+    if (KS == 1 && (g->force_ks == 0 || g->force_ks == -3)) {
+        // no key split (batched launches; debug_key_split(lg, -3) at any size): the hand-scheduled assembly kernel - the arithmetic, LDS images and
+        // results of lg_attention_hs_kernel bit for bit, 8 - 10 % faster (profiles/r03_attention_experiments.md)
+        AttnAsmArgs k{Q.hi, Q.lo, K.hi, K.lo, VT.hi, VT.lo, g->msgs_hi, g->msgs_lo, g->ctrl, cross, g->Kc, g->NIc,
+                      sslam::cdiv(g->Kc, AQ), NI * NH, 0u, {0, 0}};
+        k.magic = k.nqb > 1 ? (unsigned)((1ull << 32) / (unsigned)k.nqb + 1) : 0u;
+        size_t sz = sizeof(k);
+        void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+        const hipError_t e = hipModuleLaunchKernel(g_attn_asm_fn[g->ctx->device], (unsigned)k.nqb, (unsigned)k.nslab, 1,
+                                                   256, 1, 1, 0, s, nullptr, cfg);
+        if (e != hipSuccess && g->launch_error == hipSuccess) g->launch_error = e;
+    } else if (KS == 1 && g->force_ks == -2) {
+        // (debug_key_split(lg, -2): the compiler-scheduled half-step kernel, for A/B and the bit-identity test)
         hipLaunchKernelGGL(lg_attention_hs_kernel, dim3(sslam::cdiv(g->Kc, AQ), NI * NH), dim3(256), 0, s, a);
     } else {
+        // key split, or debug_key_split(lg, -1): the r02 4-wave kernel
         dim3 grid(sslam::cdiv(g->Kc, AQ), NI * NH, KS);
         hipLaunchKernelGGL(lg_attention_p_kernel, grid, dim3(256), 0, s, a);
     }
@@ -2362,6 +2401,11 @@ int lg_enqueue(sslam_lightglue* g, int pairs, const StageSrc& src, float min_con
     hipLaunchKernelGGL(lg_emit_kernel, dim3(pairs), dim3(1024), 0, s, g->best0, g->arg0, g->cpval, g->cparg, g->ind,
                        g->filter_thr, min_conf, ij_out, score_out, info_out, g->ctrl, Kc, out_stride, g->range_sticky);
     SSLAM_HIP_CHECK(hipGetLastError());
+    if (g->launch_error != hipSuccess) {                 // a module-API launch (the assembly attention kernel) failed
+        const hipError_t e = g->launch_error;
+        g->launch_error = hipSuccess;
+        SSLAM_HIP_CHECK(e);
+    }
     return 0;
 }
 
@@ -2413,6 +2457,7 @@ int sslam_lightglue_create_batched(sslam_ctx* ctx, const float* weights, size_t 
                   max_pairs, MAX_PAIRS);
     SSLAM_HIP_CHECK(hipSetDevice(ctx->device));
     lg_configure_kernels();
+    if (int rc = lg_load_attention_asm(ctx->device)) return rc;
     sslam_lightglue* g = new sslam_lightglue();
     g->ctx = ctx;
     const int Kc = (max_kpts + 127) / 128 * 128;     // whole attention / GEMM row blocks
@@ -2691,8 +2736,9 @@ int sslam_lightglue_debug_layers(sslam_lightglue* g, int layers, int self_only) 
 
 /* Test hook: force the key split of the attention launches (0 = chosen by batch size). */
 int sslam_lightglue_debug_key_split(sslam_lightglue* g, int ks) {
-    SSLAM_REQUIRE(g != nullptr && (ks == -1 || ks == 0 || ks == 1 || ks == 2 || ks == 4),
-                  "sslam_lightglue_debug_key_split: ks must be -1 (no split, r02 4-wave kernel), 0, 1, 2 or 4");
+    SSLAM_REQUIRE(g != nullptr && (ks == -3 || ks == -2 || ks == -1 || ks == 0 || ks == 1 || ks == 2 || ks == 4),
+                  "sslam_lightglue_debug_key_split: ks must be -3 (no split, assembly kernel), -2 (no split, compiler-scheduled "
+                  "half-step kernel), -1 (no split, r02 4-wave kernel), 0, 1, 2 or 4");
     g->settings_changed();
     g->force_ks = ks;
     return 0;

@@ -1,0 +1,9 @@
+# more timing ablations of the hand-scheduled attention kernel (which property of the VALU stream costs), random and all-zero operands
+cd $GRAFT_REPO_ROOT
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I opencv-simpleslam_amd/csrc scripts/ubench/attn_bench.hip -o /tmp/attn_b 2>/dev/null
+for abl in "" fakevalu notrans nopk novalu,nods,nodma nomfma; do
+  ATTN_ASM_ABL=$abl python3 opencv-simpleslam_amd/csrc/gen_lg_attention_asm.py > /tmp/a.s
+  /opt/rocm/lib/llvm/bin/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c /tmp/a.s -o /tmp/a.o && /opt/rocm/lib/llvm/bin/ld.lld -shared /tmp/a.o -o /tmp/a.hsaco || continue
+  echo -n "[$abl] random: "; ATTN_HSACO=/tmp/a.hsaco ATTN_PP=4 timeout -k 5 120 /tmp/attn_b 2048 8 1 5
+  echo -n "[$abl] zeros:  "; ATTN_ZERO=1 ATTN_HSACO=/tmp/a.hsaco ATTN_PP=4 timeout -k 5 120 /tmp/attn_b 2048 8 1 5
+done

@@ -1,0 +1,11 @@
+# MFMA-only stream of the hand-scheduled attention kernel: does the distance between dependent MFMAs matter?
+cd $GRAFT_REPO_ROOT
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I opencv-simpleslam_amd/csrc scripts/ubench/attn_bench.hip -o /tmp/attn_b 2>/dev/null
+for abl in novalu,nods,nodma novalu,nods,nodma,qk3acc novalu,nods,nodma,qkchain novalu,qk3acc novalu; do
+  ATTN_ASM_ABL=$abl python3 opencv-simpleslam_amd/csrc/gen_lg_attention_asm.py > /tmp/a.s
+  /opt/rocm/lib/llvm/bin/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c /tmp/a.s -o /tmp/a.o && /opt/rocm/lib/llvm/bin/ld.lld -shared /tmp/a.o -o /tmp/a.hsaco || continue
+  echo -n "[$abl] random: "; ATTN_HSACO=/tmp/a.hsaco ATTN_PP=4 timeout -k 5 120 /tmp/attn_b 2048 8 1 5
+  echo -n "[$abl] zeros:  "; ATTN_ZERO=1 ATTN_HSACO=/tmp/a.hsaco ATTN_PP=4 timeout -k 5 120 /tmp/attn_b 2048 8 1 5
+done
+echo -n "[hs] zeros: "; ATTN_ZERO=1 ATTN_PP=3 timeout -k 5 120 /tmp/attn_b 2048 8 1 5
+echo -n "[hs] random: "; ATTN_PP=3 timeout -k 5 120 /tmp/attn_b 2048 8 1 5

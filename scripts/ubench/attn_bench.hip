@@ -7,9 +7,32 @@
 #include "attn_pp_experiment.hpp"
 #include "attn_w1_experiment.hpp"
 #include <cstdio>
+#include <cstring>
 #include <vector>
 #include <algorithm>
 namespace sslam { void set_error(const char*, ...) {} }
+
+// the hand-scheduled kernel (opencv-simpleslam_amd/csrc/gen_lg_attention_asm.py): loaded from the code object named by ATTN_HSACO
+struct AsmArgs {
+    const void *q_hi, *q_lo, *k_hi, *k_lo, *vt_hi, *vt_lo; void *msg_hi, *msg_lo; const void* ctrl;
+    int cross, Kc, NIc, nqb, nslab; unsigned magic; int pad0, pad1;
+};
+static hipFunction_t asm_fn;
+static bool asm_load() {
+    const char* path = getenv("ATTN_HSACO");
+    if (!path) return false;
+    hipModule_t m;
+    if (hipModuleLoad(&m, path) != hipSuccess) { printf("cannot load %s\n", path); return false; }
+    return hipModuleGetFunction(&asm_fn, m, "lg_attention_asm_kernel") == hipSuccess;
+}
+static void asm_launch(const AttnArgsH& a, int NI) {
+    AsmArgs k{a.Q.hi, a.Q.lo, a.K.hi, a.K.lo, a.VT.hi, a.VT.lo, a.msg.hi, a.msg.lo, a.ctrl, a.cross, a.Kc, a.NIc,
+              sslam::cdiv(a.Kc, AQ), NI * NH, 0, 0, 0};
+    k.magic = k.nqb > 1 ? (unsigned)((1ull << 32) / (unsigned)k.nqb + 1) : 0;
+    size_t sz = sizeof(k);
+    void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+    hipModuleLaunchKernel(asm_fn, k.nqb, k.nslab, 1, 256, 1, 1, 0, 0, nullptr, cfg);
+}
 
 __global__ void fill_half(_Float16* p, size_t n, unsigned seed, float scale) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -43,6 +66,13 @@ int main(int argc, char** argv) {
     const bool pp = ppm == 1 && KS == 1;     // 8-wave ping-pong form
     const bool w1 = ppm == 2 && KS == 1;     // one wave per SIMD, hand-placed gaps
     const bool hs = ppm == 3 && KS == 1;     // half-step form (fragment reads half a sub-step ahead)
+    const bool as = ppm == 4 && KS == 1;     // hand-scheduled assembly form of the half-step kernel
+    if (as && !asm_load()) { printf("ATTN_PP=4 needs ATTN_HSACO=<code object>\n"); return 1; }
+    if (getenv("ATTN_CROSS")) a.cross = atoi(getenv("ATTN_CROSS"));
+    if (getenv("ATTN_N1")) {                 // different counts for the two images of a pair
+        for (auto& c : h) c.n[1] = atoi(getenv("ATTN_N1"));
+        hipMemcpy(ctrl, h.data(), sizeof(LGCtrl) * B, hipMemcpyHostToDevice);
+    }
     if (getenv("ATTN_CMP") && KS == 1) {
         // compare the hi / lo context planes of the variant against the 4-wave kernel on the same operands
         std::vector<_Float16> ref_hi(plane), ref_lo(plane), got_hi(plane), got_lo(plane);
@@ -53,12 +83,16 @@ int main(int argc, char** argv) {
         hipMemset(buf[6], 0, plane * 2); hipMemset(buf[7], 0, plane * 2);
         if (w1) hipLaunchKernelGGL(lg_attention_w1_kernel, dim3(sslam::cdiv(Kc, AQ2), NI * NH), dim3(256), 0, 0, a);
         else if (hs) hipLaunchKernelGGL(lg_attention_hs_kernel, dim3(sslam::cdiv(Kc, AQ), NI * NH), dim3(256), 0, 0, a);
+        else if (as) asm_launch(a, NI);
         else hipLaunchKernelGGL(lg_attention_pp_kernel, dim3(sslam::cdiv(Kc, AQ2), NI * NH), dim3(512), 0, 0, a);
         hipDeviceSynchronize();
         printf("variant launch: %s\n", hipGetErrorString(hipGetLastError()));
         hipMemcpy(got_hi.data(), buf[6], plane * 2, hipMemcpyDeviceToHost); hipMemcpy(got_lo.data(), buf[7], plane * 2, hipMemcpyDeviceToHost);
         // panel layout: plane[k / PANEL_K][row][k % PANEL_K] over NI * Kc rows, k = head * 64 + d
-        size_t bad = 0; double worst = 0; int shown = 0;
+        size_t bad = 0, bits = 0; double worst = 0; int shown = 0;
+        for (size_t i = 0; i < plane; ++i)
+            bits += memcmp(&ref_hi[i], &got_hi[i], 2) != 0 || memcmp(&ref_lo[i], &got_lo[i], 2) != 0;
+        printf("bitwise: %zu of %zu (hi, lo) words differ\n", bits, plane);
         const size_t rows = (size_t)NI * Kc;
         for (size_t pnl = 0; pnl < 4; ++pnl)
             for (size_t row = 0; row < rows; ++row)
@@ -78,6 +112,7 @@ int main(int argc, char** argv) {
     auto launch = [&] {
         if (w1) hipLaunchKernelGGL(lg_attention_w1_kernel, dim3(sslam::cdiv(Kc, AQ2), NI * NH), dim3(256), 0, 0, a);
         else if (hs) hipLaunchKernelGGL(lg_attention_hs_kernel, dim3(sslam::cdiv(Kc, AQ), NI * NH), dim3(256), 0, 0, a);
+        else if (as) asm_launch(a, NI);
         else if (pp) hipLaunchKernelGGL(lg_attention_pp_kernel, dim3(sslam::cdiv(Kc, AQ2), NI * NH), dim3(512), 0, 0, a);
         else hipLaunchKernelGGL(lg_attention_p_kernel, grid, dim3(256), 0, 0, a);
     };
@@ -95,7 +130,7 @@ int main(int argc, char** argv) {
     std::sort(t.begin(), t.end());
     const double fl = 8.0 * N * (double)N * 256 * B;
     printf("%s N=%d pairs=%d KS=%d: median %.1f us/launch (min %.1f) = %.2f us per pair, %.0f TF alg, executed %.1f%% of the f16 peak; err=%s\n",
-           w1 ? "[w1]" : hs ? "[hs]" : pp ? "[pp]" : "[p4]", N, B, KS,
+           w1 ? "[w1]" : hs ? "[hs]" : as ? "[asm]" : pp ? "[pp]" : "[p4]", N, B, KS,
            t[t.size() / 2], t[0], t[t.size() / 2] / B, fl / (t[t.size() / 2] * 1e-6) / 1e12, 3 * fl / (t[t.size() / 2] * 1e-6) / 2.5e15 * 100,
            hipGetErrorString(hipGetLastError()));
     return 0;

@@ -73,12 +73,15 @@ def test_batch_equals_single_pair_calls_and_oracle(gpu_ctx):
             np.testing.assert_array_equal(ij, o_ij)
             np.testing.assert_allclose(sc, o_sc, atol=1e-3, rtol=1e-3)
             assert info[1] == o_stop
-    # the r02 attention kernel without key split (debug_key_split(-1)) multiplies the same products in the same
-    # order as the half-step kernel a batch runs by default: bit-identical
-    batch.debug_key_split(-1)
-    for (ij, sc, info), (p_ij, p_sc, p_info) in zip(got, dev.run(batch, 0.7)):
-        np.testing.assert_array_equal(ij, p_ij)
-        np.testing.assert_array_equal(sc, p_sc)
+    # the three attention kernels without key split - the r02 4-wave kernel (-1), the compiler-scheduled half-step
+    # kernel (-2) and the hand-scheduled assembly kernel batched launches run by default (-3) - multiply the same
+    # products in the same order: bit-identical results, ragged key counts, the 1-keypoint image and all
+    for mode in (-1, -2, -3):
+        batch.debug_key_split(mode)
+        for (ij, sc, info), (p_ij, p_sc, p_info) in zip(got, dev.run(batch, 0.7)):
+            np.testing.assert_array_equal(ij, p_ij)
+            np.testing.assert_array_equal(sc, p_sc)
+            np.testing.assert_array_equal(info, p_info)
     # default key-split policy of a batch differs from the single-pair one: indices still identical
     batch.debug_key_split(0); single.debug_key_split(0)
     assert sum(len(g[0]) for g in got) > 300
