@@ -178,6 +178,10 @@ int sslam_reproject_match_dev(sslam_ctx* ctx, int n_points, const double* pts3d,
  * max_h/max_w bound the input image, max_kpts the keypoints per call. */
 int sslam_aliked_create(sslam_ctx* ctx, const float* weights, size_t n_floats, int max_h, int max_w,
                         int max_kpts, sslam_aliked** out);
+/* An instance whose _extract_batch_dev entry takes up to max_frames (<= 16) frames per call: one workspace block
+ * per frame (about 0.75 GB each at the full 1056 x 1056 network capacity). */
+int sslam_aliked_create_batched(sslam_ctx* ctx, const float* weights, size_t n_floats, int max_h, int max_w,
+                                int max_kpts, int max_frames, sslam_aliked** out);
 int sslam_aliked_destroy(sslam_aliked* al);
 /* img: uint8 HWC, C = 3 (BGR as cv2.imread gives), 1 (gray) or 4 (BGRA).
  * xy_out[2*max_kpts] (x, y) in input-image pixels, desc_out[128*max_kpts]
@@ -189,6 +193,15 @@ int sslam_aliked_extract_host(sslam_aliked* al, const uint8_t* img, int H, int W
 /* Device-pointer variant (all pointers device, n_out[1] device int32); enqueue only. */
 int sslam_aliked_extract_dev(sslam_aliked* al, const uint8_t* img, int H, int W, int C, int max_kpts,
                              float* xy_out, float* desc_out, float* score_out, int32_t* n_out);
+/* n_frames frames of ONE size through ONE launch sequence (the reference extracts frame by frame,
+ * features_utils.py:92-100; a frame stream hands over several at once): imgs / xy_out / desc_out / score_out / n_out
+ * are host arrays of n_frames device pointers (score_out, or any of its entries, may be NULL).  Every kernel carries
+ * the frame in a grid dimension, so the ~50 launches of a frame become ~50 per BATCH and the small stages (1/8 and
+ * 1/32 resolution maps, selection, descriptor head) fill the chip; a frame's arithmetic does not depend on the batch:
+ * results are those of n_frames sslam_aliked_extract_dev calls, bit for bit.  Enqueue only. */
+int sslam_aliked_extract_batch_dev(sslam_aliked* al, int n_frames, const uint8_t* const* imgs, int H, int W, int C,
+                                   int max_kpts, float* const* xy_out, float* const* desc_out,
+                                   float* const* score_out, int32_t* const* n_out);
 /* Replay the launch sequence of sslam_aliked_extract_dev as a cached hipGraph (one graph per distinct
  * argument tuple; for callers that cycle through a fixed set of buffers).  Same results, ~10 us of
  * host time per call instead of ~45 launches. */

@@ -60,6 +60,8 @@ def _signatures():
         "sslam_reproject_match_dev": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, C.c_double, C.c_double,
                                             vp, vp, vp]),
         "sslam_aliked_create": (i32, [vp, vp, sz, i32, i32, i32, c_void_pp]),
+        "sslam_aliked_create_batched": (i32, [vp, vp, sz, i32, i32, i32, i32, c_void_pp]),
+        "sslam_aliked_extract_batch_dev": (i32, [vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
         "sslam_aliked_destroy": (i32, [vp]),
         "sslam_aliked_extract_host": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, c_int_p]),
         "sslam_aliked_extract_dev": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),

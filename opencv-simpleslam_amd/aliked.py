@@ -15,15 +15,18 @@ from . import _native, weights as W
 
 class AlikedHIP:
     def __init__(self, state_dict=None, max_num_keypoints: int = 4000, max_h: int = 1200, max_w: int = 2048,
-                 ctx=None):
+                 ctx=None, max_frames: int = 1):
+        """max_frames > 1: the instance also takes batches of that many frames (`extract_batch_dev`); one workspace
+        block per frame."""
         self.ctx = ctx or _native.default_context()
         self.state_dict = state_dict if state_dict is not None else W.random_aliked_state_dict(0)
         blob = W.pack_aliked(self.state_dict)
         h = C.c_void_p()
-        _native.check(_native.lib().sslam_aliked_create(
+        _native.check(_native.lib().sslam_aliked_create_batched(
             self.ctx.handle, _native.ptr(blob), blob.size, int(max_h), int(max_w), int(max_num_keypoints),
-            C.byref(h)), "sslam_aliked_create")
+            int(max_frames), C.byref(h)), "sslam_aliked_create")
         self.handle = h
+        self.max_frames = int(max_frames)
         self.max_num_keypoints = int(max_num_keypoints)
         self.max_h, self.max_w = int(max_h), int(max_w)
 
@@ -69,6 +72,17 @@ class AlikedHIP:
         _native.check(_native.lib().sslam_aliked_extract_dev(
             self.handle, P(img_dev), int(H), int(Wd), int(Cn), int(max_kpts or self.max_num_keypoints),
             P(xy_out), P(desc_out), P(score_out), P(n_out)), "sslam_aliked_extract_dev")
+
+    def extract_batch_dev(self, imgs_dev, H, Wd, Cn, xy_out, desc_out, score_out, n_out, max_kpts=None):
+        """F frames of one size through one launch sequence: every argument but the sizes is a sequence of F device
+        pointers (score_out may be None).  Same results as F `extract_dev` calls, bit for bit."""
+        F = len(imgs_dev)
+        arr = lambda seq: (C.c_void_p * F)(*[int(_native.ptr(p).value or 0) if p is not None else 0 for p in seq])
+        a_img, a_xy, a_desc, a_n = arr(imgs_dev), arr(xy_out), arr(desc_out), arr(n_out)
+        a_sc = arr(score_out) if score_out is not None else None
+        _native.check(_native.lib().sslam_aliked_extract_batch_dev(
+            self.handle, F, a_img, int(H), int(Wd), int(Cn), int(max_kpts or self.max_num_keypoints),
+            a_xy, a_desc, a_sc, a_n), "sslam_aliked_extract_batch_dev")
 
     def use_graphs(self, enable: bool = True):
         """Replay `extract_dev` as a cached hipGraph per distinct argument tuple (same results)."""

@@ -50,12 +50,26 @@ struct Dims {
     int pl, pt;           // left / top padding
 };
 
+// Batched extraction (sslam_aliked_extract_batch_dev): F frames of one size go through ONE launch sequence.  Every
+// per-frame buffer of frame f sits `fs` bytes behind frame 0's (one workspace block per frame, carved identically),
+// so a kernel takes frame 0's pointers plus that stride and finds its frame in a grid dimension; weights and the
+// blur taps are shared.  The arithmetic of a frame does not depend on F: a batch gives the single-frame results bit
+// for bit.
+constexpr int MAX_FRAMES = 16;
+template <typename T> __device__ __forceinline__ T* fsh(T* p, int f, size_t fs) {
+    return p ? reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + (size_t)f * fs) : p;
+}
+struct FrameIn { const uint8_t* img[MAX_FRAMES]; };
+struct FrameOut { float* xy[MAX_FRAMES]; float* desc[MAX_FRAMES]; float* score[MAX_FRAMES]; int32_t* n[MAX_FRAMES]; };
+
 // ------------------------------------------------------------------------ //
 //  0. pre-processing: u8 HWC (BGR | gray | BGRA) -> RGB/255 -> [blur] -> resize -> pad
 // ------------------------------------------------------------------------ //
-__global__ void al_to_float_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, Dims d,
-                                   const float* __restrict__ gx, int kx, int blur) {
+__global__ void al_to_float_kernel(FrameIn srcs, float* __restrict__ dst, Dims d,
+                                   const float* __restrict__ gx, int kx, int blur, size_t fs) {
     // dst [3][H][W] = horizontally blurred RGB/255 (reflect border), or plain RGB/255
+    const uint8_t* __restrict__ src = srcs.img[blockIdx.z];
+    dst = fsh(dst, blockIdx.z, fs);
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= d.W) return;
     for (int c = 0; c < 3; ++c) {
@@ -77,8 +91,9 @@ __global__ void al_to_float_kernel(const uint8_t* __restrict__ src, float* __res
 }
 
 __global__ void al_resize_pad_kernel(const float* __restrict__ src, float* __restrict__ img, Dims d,
-                                     const float* __restrict__ gy, int ky, int blur) {
+                                     const float* __restrict__ gy, int ky, int blur, size_t fs) {
     // img [3][Hp][Wp]: replicate-padded bilinear (align_corners=False) resize of (vertically blurred) src
+    src = fsh(src, blockIdx.z, fs); img = fsh(img, blockIdx.z, fs);
     const int xp = blockIdx.x * blockDim.x + threadIdx.x, yp = blockIdx.y;
     if (xp >= d.Wp) return;
     const int y = min(max(yp - d.pt, 0), d.h - 1), x = min(max(xp - d.pl, 0), d.w - 1);
@@ -139,8 +154,9 @@ __global__ __launch_bounds__(256) void al_conv3x3_mfma_kernel(
     const float* __restrict__ in, int inH, int inW, float* __restrict__ out, int H, int W,
     const float* __restrict__ w /*[ci][tap][COUT]*/, const float* __restrict__ alpha, const float* __restrict__ beta,
     const float* __restrict__ wd /*[ci][COUT]*/, const float* __restrict__ bd, float* __restrict__ idn,
-    const float* __restrict__ resid) {
+    const float* __restrict__ resid, size_t fs) {
     static_assert(COUT == 16 || COUT == 32, "two matrix-core shapes");
+    in = fsh(in, blockIdx.z, fs); out = fsh(out, blockIdx.z, fs); idn = fsh(idn, blockIdx.z, fs); resid = fsh(resid, blockIdx.z, fs);
     static_assert(!(DOWN && COUT == 16), "the 1x1 branch is only built for the 32-row shape");
     constexpr bool M16 = COUT == 16;
     constexpr int KG = M16 ? 4 : 2;                                  // channels per MFMA
@@ -332,7 +348,8 @@ __global__ __launch_bounds__(256) void al_conv3x3_mfma_kernel(
 //     deformable conv (torchvision deform_conv2d semantics) + BN + residual + SELU
 // ------------------------------------------------------------------------ //
 __global__ void al_avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int H, int W,
-                                  int P) {   // out [C][H/P][W/P]
+                                  int P, size_t fs) {   // out [C][H/P][W/P]
+    in = fsh(in, blockIdx.y, fs); out = fsh(out, blockIdx.y, fs);
     const int oh = H / P, ow = W / P;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= C * oh * ow) return;
@@ -352,9 +369,10 @@ template <int CIN>
 __global__ __launch_bounds__(256) void al_offset_conv_kernel(const float* __restrict__ in, float* __restrict__ off,
                                                              int H, int W,
                                                              const float* __restrict__ wt /*[18][CIN*9]*/,
-                                                             const float* __restrict__ b, float max_off) {
+                                                             const float* __restrict__ b, float max_off, size_t fs) {
     const int lane = threadIdx.x & 63, pix = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pix >= H * W) return;
+    in = fsh(in, blockIdx.y, fs); off = fsh(off, blockIdx.y, fs);
     const int y = pix / W, x = pix % W;
     float part[18];
 #pragma unroll
@@ -403,7 +421,8 @@ __global__ __launch_bounds__(256) void al_offset_conv_kernel(const float* __rest
 // the slabs in order (deterministic) and applies BN affine + residual + SELU.
 __global__ __launch_bounds__(256) void al_dcn_col_kernel(const float* __restrict__ in, const float* __restrict__ off,
                                                          float* __restrict__ col, int CIN, int H, int W,
-                                                         const float* __restrict__ res_in, int RC) {
+                                                         const float* __restrict__ res_in, int RC, size_t fs) {
+    in = fsh(in, blockIdx.y, fs); off = fsh(off, blockIdx.y, fs); col = fsh(col, blockIdx.y, fs); res_in = fsh(res_in, blockIdx.y, fs);
     // thread = (channel quad, tap slot, pixel), pixel fastest: the 16 gathers of a lane and of its
     // neighbours fall into the same few rows of one channel plane (16 reads vs 1 write per thread)
     const int K = CIN * 9, KT = K + RC, HW = H * W, slots = RC ? 10 : 9, CQ = CIN / 4;
@@ -443,9 +462,11 @@ __global__ __launch_bounds__(256) void al_dcn_col_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void al_dcn_gemm_kernel(const float* __restrict__ wt /*[COUT][K]*/, int K,
                                                           const float* __restrict__ col /*[HW][K + RC]*/, int ldc,
                                                           int HW, int COUT, float* __restrict__ part /*[KS+1][COUT][HW]*/,
-                                                          const float* __restrict__ wdt /*[COUT][RC]*/, int RC) {
+                                                          const float* __restrict__ wdt /*[COUT][RC]*/, int RC, int KS,
+                                                          size_t fs) {
     __shared__ GemmSmem<64, 64> sm;
-    const int pix0 = blockIdx.x * 64, co0 = blockIdx.y * 64, z = blockIdx.z, KS = gridDim.z;
+    const int pix0 = blockIdx.x * 64, co0 = blockIdx.y * 64, z = blockIdx.z % KS, fr = blockIdx.z / KS;   // grid z = frame * KS + slice
+    col = fsh(col, fr, fs); part = fsh(part, fr, fs);
     const int kper = K / KS, koff = z * kper;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
     const int pix = pix0 + wn * 32 + (lane & 31);
@@ -471,9 +492,10 @@ __global__ __launch_bounds__(256) void al_dcn_gemm_kernel(const float* __restric
 __global__ __launch_bounds__(256) void al_dcn_epilogue_kernel(const float* __restrict__ part, int KS, int HW, int COUT,
                                                               float* __restrict__ out, const float* __restrict__ alpha,
                                                               const float* __restrict__ beta, int resid,
-                                                              const float* __restrict__ bd) {
+                                                              const float* __restrict__ bd, size_t fs) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= COUT * HW) return;
+    part = fsh(part, blockIdx.y, fs); out = fsh(out, blockIdx.y, fs);
     const int co = i / HW;
     float acc = part[i];
     for (int z = 1; z < KS; ++z) acc += part[(size_t)z * COUT * HW + i];
@@ -500,9 +522,10 @@ __global__ void al_dcn_wt_kernel(const float* __restrict__ src, float* __restric
 // weights [ci][32] as wave-uniform scalar loads)
 __global__ __launch_bounds__(256) void al_gate_kernel(const float* __restrict__ in, float* __restrict__ out, int CIN,
                                                       int HW, const float* __restrict__ w /*[ci][32]*/,
-                                                      float* __restrict__ out_cl /*[HW][32]*/) {
+                                                      float* __restrict__ out_cl /*[HW][32]*/, size_t fs) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= HW) return;
+    in = fsh(in, blockIdx.y, fs); out = fsh(out, blockIdx.y, fs); out_cl = fsh(out_cl, blockIdx.y, fs);
     float acc[32];
 #pragma unroll
     for (int o = 0; o < 32; ++o) acc[o] = 0.0f;
@@ -523,9 +546,10 @@ __global__ __launch_bounds__(256) void al_gate_kernel(const float* __restrict__ 
 
 // small-map variant (1/8, 1/32 resolution): one thread per (co, pixel), more parallelism
 __global__ void al_gate_small_kernel(const float* __restrict__ in, float* __restrict__ out, int CIN, int HW,
-                                     const float* __restrict__ w /*[ci][32]*/, float* __restrict__ out_cl) {
+                                     const float* __restrict__ w /*[ci][32]*/, float* __restrict__ out_cl, size_t fs) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 32 * HW) return;
+    in = fsh(in, blockIdx.y, fs); out = fsh(out, blockIdx.y, fs); out_cl = fsh(out_cl, blockIdx.y, fs);
     const int co = i / HW, p = i % HW;
     float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll 8                 // 16 loads in flight per thread: the loop is pure load latency otherwise
@@ -556,6 +580,12 @@ struct Pyr {
     const float *g2cl, *g3cl, *g4cl;
 };
 
+__device__ __forceinline__ Pyr pyr_at(Pyr P, int f, size_t fs) {      // the pyramid of frame f (weights w1 shared)
+    P.x1 = fsh(P.x1, f, fs); P.g2 = fsh(P.g2, f, fs); P.g3 = fsh(P.g3, f, fs); P.g4 = fsh(P.g4, f, fs);
+    P.g1cl = fsh(P.g1cl, f, fs); P.g2cl = fsh(P.g2cl, f, fs); P.g3cl = fsh(P.g3cl, f, fs); P.g4cl = fsh(P.g4cl, f, fs);
+    return P;
+}
+
 struct UpTap { int o00, o01, o10, o11; float w00, w01, w10, w11; };
 
 __device__ __forceinline__ UpTap up_tap(int y, int x, int Hp, int Wp, int S, float sy, float sx) {
@@ -577,8 +607,10 @@ __device__ __forceinline__ float up_eval(const float* __restrict__ p, const UpTa
     return t.w10 * (t.w00 * p[t.o00] + t.w01 * p[t.o01]) + t.w11 * (t.w00 * p[t.o10] + t.w01 * p[t.o11]);
 }
 
-__global__ __launch_bounds__(256) void al_aggregate_kernel(Pyr P, const float* __restrict__ ws0 /*[128][8]*/,
-                                                           float* __restrict__ s8, float* __restrict__ rnorm) {
+__global__ __launch_bounds__(256) void al_aggregate_kernel(Pyr P0, const float* __restrict__ ws0 /*[128][8]*/,
+                                                           float* __restrict__ s8, float* __restrict__ rnorm, size_t fs) {
+    const Pyr P = pyr_at(P0, blockIdx.z, fs);
+    s8 = fsh(s8, blockIdx.z, fs); rnorm = fsh(rnorm, blockIdx.z, fs);
     // the block's 256 pixels x 32 channels of g1 are one contiguous 32 KiB run of the channel-last
     // map: stage them in LDS ([pixel][33], conflict-free) and write them out as coalesced float4
     __shared__ float g1s[256 * 33];
@@ -674,7 +706,8 @@ __global__ __launch_bounds__(256) void al_score_tail_kernel(const float* __restr
                                                             const float* __restrict__ w4 /*[4][9][4]*/,
                                                             const float* __restrict__ w6 /*[4][9][1]*/,
                                                             float* __restrict__ score, int h, int w, int pl,
-                                                            int pt) {
+                                                            int pt, size_t fs) {
+    s8 = fsh(s8, blockIdx.z, fs); score = fsh(score, blockIdx.z, fs);
     __shared__ float t0[8][ST_H + 6][ST_W + 6];
     __shared__ float t1[4][ST_H + 4][ST_W + 4];
     __shared__ float t2[4][ST_H + 2][ST_W + 2];
@@ -770,7 +803,8 @@ __device__ __forceinline__ float pool5_col(const float* __restrict__ tmp, int i)
 }
 
 __global__ __launch_bounds__(256) void al_nms_kernel(const float* __restrict__ score, int h, int w,
-                                                     float* __restrict__ nms, float* __restrict__ block_sum) {
+                                                     float* __restrict__ nms, float* __restrict__ block_sum, size_t fs) {
+    score = fsh(score, blockIdx.z, fs); nms = fsh(nms, blockIdx.z, fs); block_sum = fsh(block_sum, blockIdx.z, fs);
     // s: scores (-inf outside the map); m: max_mask (0/1); q: suppressed scores; tmp: row-pooled scratch.
     // Values at the LDS-tile rim are wrong (missing neighbours) but the 10-pixel halo keeps them out
     // of the dependency cone of the central NT_H x NT_W outputs.
@@ -846,9 +880,11 @@ __global__ __launch_bounds__(256) void al_collect_kernel(const float* __restrict
                                                          int fallback, const float* __restrict__ block_sum,
                                                          int n_blocks, unsigned long long* __restrict__ cand,
                                                          int cap, ALCtrl* __restrict__ ctrl,
-                                                         unsigned* __restrict__ hist) {
+                                                         unsigned* __restrict__ hist, size_t fs) {
     __shared__ int wcnt[4];
     __shared__ int s_base;
+    nms = fsh(nms, blockIdx.y, fs); block_sum = fsh(block_sum, blockIdx.y, fs); cand = fsh(cand, blockIdx.y, fs);
+    ctrl = fsh(ctrl, blockIdx.y, fs); hist = fsh(hist, blockIdx.y, fs);
     if (fallback) {
         if (!ctrl->need_fallback) return;           // the normal threshold found keypoints
         float s = 0.0f;                             // mean of the raw score map, fixed summation order
@@ -887,7 +923,16 @@ __global__ __launch_bounds__(256) void al_collect_kernel(const float* __restrict
     }
 }
 // decided between the two collect launches so every thread of the fallback launch sees one answer
-__global__ void al_fallback_flag_kernel(ALCtrl* __restrict__ ctrl) { ctrl->need_fallback = ctrl->n_cand == 0; }
+__global__ void al_fallback_flag_kernel(ALCtrl* __restrict__ ctrl, size_t fs) {
+    ctrl = fsh(ctrl, blockIdx.x, fs);
+    ctrl->need_fallback = ctrl->n_cand == 0;
+}
+// per-frame control block and score histogram back to zero (one block per frame)
+__global__ void al_reset_kernel(ALCtrl* __restrict__ ctrl, unsigned* __restrict__ hist, size_t fs) {
+    ctrl = fsh(ctrl, blockIdx.x, fs); hist = fsh(hist, blockIdx.x, fs);
+    if (threadIdx.x < sizeof(ALCtrl) / 4) reinterpret_cast<int*>(ctrl)[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < HBINS; i += blockDim.x) hist[i] = 0u;
+}
 
 // kornia get_gaussian_kernel1d in fp32: gk[0..kx) horizontal taps, gk[32..32+ky) vertical taps
 __global__ void al_taps_kernel(float* __restrict__ gk, int kx, float sx, int ky, float sy) {
@@ -931,7 +976,10 @@ constexpr int EDGE_CAP = 2048;     // candidates allowed in the cut bin before f
 
 __global__ __launch_bounds__(1024) void al_select_kernel(const unsigned long long* __restrict__ cand, int cap,
                                                          int n_limit, int* __restrict__ kp_index,
-                                                         ALCtrl* __restrict__ ctrl, const unsigned* __restrict__ hist_g) {
+                                                         ALCtrl* __restrict__ ctrl, const unsigned* __restrict__ hist_g,
+                                                         size_t fs) {
+    cand = fsh(cand, blockIdx.x, fs); kp_index = fsh(kp_index, blockIdx.x, fs); ctrl = fsh(ctrl, blockIdx.x, fs);
+    hist_g = fsh(hist_g, blockIdx.x, fs);                                       // one block per frame
     extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];   // SEL_CAP + EDGE_CAP
     unsigned long long* edge = keys + SEL_CAP;
     __shared__ unsigned hist[256];
@@ -1034,7 +1082,9 @@ __global__ __launch_bounds__(1024) void al_select_kernel(const unsigned long lon
 // soft-argmax refinement + score sampling (DKD.forward sub_pixel=True)
 __global__ void al_refine_kernel(const float* __restrict__ score, int h, int w, const int* __restrict__ kp_index,
                                  float* __restrict__ kp_norm, float* __restrict__ kp_score,
-                                 const ALCtrl* __restrict__ ctrl) {
+                                 const ALCtrl* __restrict__ ctrl, size_t fs) {
+    score = fsh(score, blockIdx.y, fs); kp_index = fsh(kp_index, blockIdx.y, fs); kp_norm = fsh(kp_norm, blockIdx.y, fs);
+    kp_score = fsh(kp_score, blockIdx.y, fs); ctrl = fsh(ctrl, blockIdx.y, fs);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ctrl->n_kp) return;
     const int idx = kp_index[i], x = idx % w, y = idx / w;
@@ -1071,9 +1121,12 @@ __global__ void al_refine_kernel(const float* __restrict__ score, int h, int w, 
 // ------------------------------------------------------------------------ //
 // 3x3 patch of the normalised feature map around each keypoint -> patch[n][c*9 + tap]
 // (get_patches corner rule); one wave per (keypoint, tap)
-__global__ __launch_bounds__(256) void al_patch_kernel(Pyr P, const float* __restrict__ rnorm, int pl, int pt,
+__global__ __launch_bounds__(256) void al_patch_kernel(Pyr P0, const float* __restrict__ rnorm, int pl, int pt,
                                                        int h, int w, const float* __restrict__ kp_norm,
-                                                       float* __restrict__ patch, const ALCtrl* __restrict__ ctrl) {
+                                                       float* __restrict__ patch, const ALCtrl* __restrict__ ctrl, size_t fs) {
+    const Pyr P = pyr_at(P0, blockIdx.y, fs);
+    rnorm = fsh(rnorm, blockIdx.y, fs); kp_norm = fsh(kp_norm, blockIdx.y, fs); patch = fsh(patch, blockIdx.y, fs);
+    ctrl = fsh(ctrl, blockIdx.y, fs);
     const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n = gw / 9, tap = gw % 9;
     if (n >= ctrl->n_kp) return;
@@ -1098,7 +1151,8 @@ __global__ void al_offsets_kernel(const float* __restrict__ h32 /*[KSPLIT][cap][
                                   int cap, const float* __restrict__ b1,
                                   const float* __restrict__ w2 /*[32][32] (o,i)*/, const float* __restrict__ b2,
                                   const float* __restrict__ kp_norm, int h, int w, float max_off,
-                                  float* __restrict__ pos /*[n][16][2]*/, const ALCtrl* __restrict__ ctrl) {
+                                  float* __restrict__ pos /*[n][16][2]*/, const ALCtrl* __restrict__ ctrl, size_t fs) {
+    h32 = fsh(h32, blockIdx.y, fs); kp_norm = fsh(kp_norm, blockIdx.y, fs); pos = fsh(pos, blockIdx.y, fs); ctrl = fsh(ctrl, blockIdx.y, fs);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = i / 32, o = i % 32;
     if (n >= ctrl->n_kp) return;
@@ -1117,9 +1171,11 @@ __global__ void al_offsets_kernel(const float* __restrict__ h32 /*[KSPLIT][cap][
 
 // bilinear sample (grid_sample align_corners=True, zeros padding) of the normalised feature map at
 // the 16 positions of each keypoint -> sampled[n*16 + p][128]; one wave per (keypoint, position)
-__global__ __launch_bounds__(256) void al_sample_kernel(Pyr P, const float* __restrict__ rnorm, int pl, int pt,
+__global__ __launch_bounds__(256) void al_sample_kernel(Pyr P0, const float* __restrict__ rnorm, int pl, int pt,
                                                         int h, int w, const float* __restrict__ pos,
-                                                        float* __restrict__ sampled, const ALCtrl* __restrict__ ctrl) {
+                                                        float* __restrict__ sampled, const ALCtrl* __restrict__ ctrl, size_t fs) {
+    const Pyr P = pyr_at(P0, blockIdx.y, fs);
+    rnorm = fsh(rnorm, blockIdx.y, fs); pos = fsh(pos, blockIdx.y, fs); sampled = fsh(sampled, blockIdx.y, fs); ctrl = fsh(ctrl, blockIdx.y, fs);
     const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (gw >= ctrl->n_kp * 16) return;
     // pos -> normalised -> back to pixels exactly as grid_sample does
@@ -1152,15 +1208,17 @@ template <int BM, int BN, int TM, int TN>
 __global__ __launch_bounds__(256) void al_gemm_kernel(const float* __restrict__ A, int K, const float* __restrict__ Wt,
                                                       const float* __restrict__ bias, int N, float* __restrict__ C,
                                                       int rows_per_kp, int row_cap, int do_selu,
-                                                      const ALCtrl* __restrict__ ctrl) {
+                                                      const ALCtrl* __restrict__ ctrl, int KS, size_t fs) {
     __shared__ GemmSmem<BM, BN> sm;
+    const int zs = blockIdx.z % KS, fr = blockIdx.z / KS;              // grid z = frame * KS + k slice
+    A = fsh(A, fr, fs); C = fsh(C, fr, fs); ctrl = fsh(ctrl, fr, fs);
     const int M = ctrl->n_kp * rows_per_kp;
     const int row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
     if (row0 >= M) return;
     // split-K over blockIdx.z: these GEMMs have few row blocks (M <= 2048) and a long K; slice z
     // writes its partial product to C + z * row_cap * N, the consumer adds the slices in order
-    const int kper = K / gridDim.z, koff = blockIdx.z * kper;
-    C += (size_t)blockIdx.z * row_cap * N;
+    const int kper = K / KS, koff = zs * kper;
+    C += (size_t)zs * row_cap * N;
     GemmA ga{A + koff, K, A + koff, K, kper};   // (A1 unused; a null A1 trips an InstCombine crash in ROCm 7.2)
     f32x16 acc[TM][TN];
     gemm_mainloop<BM, BN, TM, TN>(ga, Wt + koff, K, kper, row0, row_cap, col0, N, sm, acc);
@@ -1186,9 +1244,12 @@ __global__ __launch_bounds__(256) void al_gemm_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void al_finalize_kernel(const float* __restrict__ raw /*[KSPLIT][cap][128]*/, int cap,
                                                           const float* __restrict__ kp_norm,
                                                           const float* __restrict__ kp_score, int h, int w, float scale_x,
-                                                          float scale_y, float* __restrict__ xy_out,
-                                                          float* __restrict__ desc_out, float* __restrict__ score_out,
-                                                          int32_t* __restrict__ n_out, const ALCtrl* __restrict__ ctrl) {
+                                                          float scale_y, FrameOut outs, const ALCtrl* __restrict__ ctrl,
+                                                          size_t fs) {
+    raw = fsh(raw, blockIdx.y, fs); kp_norm = fsh(kp_norm, blockIdx.y, fs); kp_score = fsh(kp_score, blockIdx.y, fs);
+    ctrl = fsh(ctrl, blockIdx.y, fs);
+    float* __restrict__ xy_out = outs.xy[blockIdx.y]; float* __restrict__ desc_out = outs.desc[blockIdx.y];
+    float* __restrict__ score_out = outs.score[blockIdx.y]; int32_t* __restrict__ n_out = outs.n[blockIdx.y];
     const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (blockIdx.x == 0 && threadIdx.x == 0) n_out[0] = ctrl->n_kp;
     if (n >= ctrl->n_kp) return;
@@ -1227,6 +1288,8 @@ struct ALDcnW { const float *ow, *ob, *w, *a, *b; };
 struct sslam_aliked {
     sslam_ctx* ctx = nullptr;
     int max_h = 0, max_w = 0, max_kpts = 0;
+    int max_frames = 1;               // frames per batched launch sequence (workspace blocks)
+    size_t fs = 0;                    // bytes between the workspace blocks of consecutive frames
     int Hp_cap = 0, Wp_cap = 0;
     sslam::Arena arena;
     float* blob = nullptr;
@@ -1312,78 +1375,82 @@ Dims al_dims(int H, int W, int C) {
 }
 
 // (host-side state such as g->last is set by the ENTRY POINTS, not here: a graph replay skips this function)
-int al_enqueue(sslam_aliked* g, const uint8_t* img_dev, int H, int W, int C, int n_limit, float* xy_out,
-               float* desc_out, float* score_out, int32_t* n_out) {
+// One launch sequence for F frames of one size: every grid carries the frame in its last used dimension and every
+// per-frame pointer is frame 0's plus f * g->fs (see fsh above).  F = 1 is the single-frame entry.
+int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C, int n_limit, const FrameOut& outs) {
     hipStream_t s = g->ctx->stream;
     const ResizePlan rp = resize_plan(H, W, 1024);
     const Dims d = al_dims(H, W, C);
     SSLAM_REQUIRE(d.Hp <= g->Hp_cap && d.Wp <= g->Wp_cap && d.h >= 8 && d.w >= 8,
                   "sslam_aliked: network size %dx%d outside the instance capacity %dx%d", d.Hp, d.Wp,
                   g->Hp_cap, g->Wp_cap);
+    SSLAM_REQUIRE(F >= 1 && F <= g->max_frames, "sslam_aliked: %d frames, instance capacity %d", F, g->max_frames);
     const int Hp = d.Hp, Wp = d.Wp;
-    SSLAM_HIP_CHECK(hipMemsetAsync(g->ctrl, 0, sizeof(ALCtrl), s));
-    SSLAM_HIP_CHECK(hipMemsetAsync(g->hist, 0, HBINS * sizeof(unsigned), s));
+    const unsigned uF = (unsigned)F;
+    const size_t fs = g->fs;
+    hipLaunchKernelGGL(al_reset_kernel, dim3(uF), dim3(256), 0, s, g->ctrl, g->hist, fs);
     SSLAM_REQUIRE(rp.kx <= 31 && rp.ky <= 31, "sslam_aliked: blur kernel too large (%d,%d)", rp.kx, rp.ky);
     hipLaunchKernelGGL(al_taps_kernel, dim3(1), dim3(64), 0, s, g->gk, rp.kx, rp.sx, rp.ky, rp.sy);
 
-    hipLaunchKernelGGL(al_to_float_kernel, dim3(sslam::cdiv(W, 256), H), dim3(256), 0, s, img_dev, g->fsrc, d,
-                       g->gk, rp.kx, rp.blur);
-    hipLaunchKernelGGL(al_resize_pad_kernel, dim3(sslam::cdiv(Wp, 256), Hp), dim3(256), 0, s, g->fsrc, g->img, d,
-                       g->gk + 32, rp.ky, rp.blur);
+    hipLaunchKernelGGL(al_to_float_kernel, dim3(sslam::cdiv(W, 256), H, uF), dim3(256), 0, s, srcs, g->fsrc, d,
+                       g->gk, rp.kx, rp.blur, fs);
+    hipLaunchKernelGGL(al_resize_pad_kernel, dim3(sslam::cdiv(Wp, 256), Hp, uF), dim3(256), 0, s, g->fsrc, g->img, d,
+                       g->gk + 32, rp.ky, rp.blur, fs);
     // block1
-    dim3 g1(sslam::cdiv(Wp, CT_W), sslam::cdiv(Hp, 16));
+    dim3 g1(sslam::cdiv(Wp, CT_W), sslam::cdiv(Hp, 16), uF);
     hipLaunchKernelGGL((al_conv3x3_mfma_kernel<3, 16, 1, false, false, 4>), g1, dim3(256), 0, s, g->img, Hp, Wp, g->x1a, Hp,
-                       Wp, g->b1c1.w, g->b1c1.a, g->b1c1.b, nullptr, nullptr, nullptr, nullptr);
+                       Wp, g->b1c1.w, g->b1c1.a, g->b1c1.b, nullptr, nullptr, nullptr, nullptr, fs);
     hipLaunchKernelGGL((al_conv3x3_mfma_kernel<16, 16, 1, false, false, 4>), g1, dim3(256), 0, s, g->x1a, Hp, Wp, g->x1, Hp,
-                       Wp, g->b1c2.w, g->b1c2.a, g->b1c2.b, nullptr, nullptr, nullptr, nullptr);
+                       Wp, g->b1c2.w, g->b1c2.a, g->b1c2.b, nullptr, nullptr, nullptr, nullptr, fs);
     // block2 at 1/2: conv1 pools on load and also emits the downsample branch
     const int H2 = Hp / 2, W2 = Wp / 2;
-    dim3 g2(sslam::cdiv(W2, CT_W), sslam::cdiv(H2, 8));
+    dim3 g2(sslam::cdiv(W2, CT_W), sslam::cdiv(H2, 8), uF);
     hipLaunchKernelGGL((al_conv3x3_mfma_kernel<16, 32, 2, true, false, 2>), g2, dim3(256), 0, s, g->x1, Hp, Wp, g->t2, H2, W2,
-                       g->b2c1.w, g->b2c1.a, g->b2c1.b, g->b2dw, g->b2db, g->idn2, nullptr);
+                       g->b2c1.w, g->b2c1.a, g->b2c1.b, g->b2dw, g->b2db, g->idn2, nullptr, fs);
     hipLaunchKernelGGL((al_conv3x3_mfma_kernel<32, 32, 1, false, true, 2>), g2, dim3(256), 0, s, g->t2, H2, W2, g->x2, H2, W2,
-                       g->b2c2.w, g->b2c2.a, g->b2c2.b, nullptr, nullptr, nullptr, g->idn2);
+                       g->b2c2.w, g->b2c2.a, g->b2c2.b, nullptr, nullptr, nullptr, g->idn2, fs);
     // deformable conv = im2col of the bilinear samples + matrix-core GEMM (offsets in g->off)
     auto dcn = [&](const float* in, int cin, float* outp, int cout, int Hh, int Ww, const float* wt, const float* al_,
                    const float* be_, const float* res, int rc, const float* wdt, const float* bdp) {
         const int K = cin * 9, KT = K + rc, HWl = Hh * Ww, slots = rc ? 10 : 9;
-        hipLaunchKernelGGL(al_dcn_col_kernel, dim3(sslam::cdiv(HWl * slots * (cin / 4), 256)), dim3(256), 0, s, in, g->off,
-                           g->dcol, cin, Hh, Ww, res, rc);
-        // split K so that the grid fills the chip: the largest divisor of the k-tile count that
-        // keeps the grid within ~1 workgroup per CU
+        hipLaunchKernelGGL(al_dcn_col_kernel, dim3(sslam::cdiv(HWl * slots * (cin / 4), 256), uF), dim3(256), 0, s, in, g->off,
+                           g->dcol, cin, Hh, Ww, res, rc, fs);
+        // split K so that ONE frame's grid fills the chip: the largest divisor of the k-tile count that keeps it
+        // within ~1 workgroup per CU.  (Not re-derived for a batch: the slice count fixes the summation order, and
+        // a frame's result must not depend on how many frames travel with it.)
         const int base = sslam::cdiv(HWl, 64) * (cout / 64), tiles = K / 32;
         int ks = 1;
         for (int d_ = 1; d_ <= tiles && d_ <= DCN_KS_MAX; ++d_)
             if (tiles % d_ == 0 && base * d_ <= 288) ks = d_;
-        hipLaunchKernelGGL(al_dcn_gemm_kernel, dim3(sslam::cdiv(HWl, 64), cout / 64, ks), dim3(256), 0, s, wt, K, g->dcol, KT,
-                           HWl, cout, g->dpart, wdt, rc);
-        hipLaunchKernelGGL(al_dcn_epilogue_kernel, dim3(sslam::cdiv(cout * HWl, 256)), dim3(256), 0, s, g->dpart, ks, HWl, cout,
-                           outp, al_, be_, res ? 1 : 0, bdp);
+        hipLaunchKernelGGL(al_dcn_gemm_kernel, dim3(sslam::cdiv(HWl, 64), cout / 64, ks * uF), dim3(256), 0, s, wt, K, g->dcol, KT,
+                           HWl, cout, g->dpart, wdt, rc, ks, fs);
+        hipLaunchKernelGGL(al_dcn_epilogue_kernel, dim3(sslam::cdiv(cout * HWl, 256), uF), dim3(256), 0, s, g->dpart, ks, HWl, cout,
+                           outp, al_, be_, res ? 1 : 0, bdp, fs);
     };
     // block3 at 1/8 (deformable)
     const int H3 = Hp / 8, W3 = Wp / 8, HW3 = H3 * W3;
-    hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(32 * HW3, 256)), dim3(256), 0, s, g->x2, g->p3, 32, H2, W2, 4);
+    hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(32 * HW3, 256), uF), dim3(256), 0, s, g->x2, g->p3, 32, H2, W2, 4, fs);
     const float mo3 = (float)(H3 > W3 ? H3 : W3) / 4.0f;
-    hipLaunchKernelGGL(al_offset_conv_kernel<32>, dim3(sslam::cdiv(HW3, 4)), dim3(256), 0, s, g->p3, g->off, H3,
-                       W3, g->b3c1ot, g->b3c1.ob, mo3);
+    hipLaunchKernelGGL(al_offset_conv_kernel<32>, dim3(sslam::cdiv(HW3, 4), uF), dim3(256), 0, s, g->p3, g->off, H3,
+                       W3, g->b3c1ot, g->b3c1.ob, mo3, fs);
     dcn(g->p3, 32, g->t3, 64, H3, W3, g->b3c1t, g->b3c1.a, g->b3c1.b, nullptr, 0, nullptr, nullptr);
-    hipLaunchKernelGGL(al_offset_conv_kernel<64>, dim3(sslam::cdiv(HW3, 4)), dim3(256), 0, s, g->t3, g->off, H3,
-                       W3, g->b3c2ot, g->b3c2.ob, mo3);
+    hipLaunchKernelGGL(al_offset_conv_kernel<64>, dim3(sslam::cdiv(HW3, 4), uF), dim3(256), 0, s, g->t3, g->off, H3,
+                       W3, g->b3c2ot, g->b3c2.ob, mo3, fs);
     dcn(g->t3, 64, g->x3, 64, H3, W3, g->b3c2t, g->b3c2.a, g->b3c2.b, g->p3, 32, g->b3dwt, g->b3db);
     // block4 at 1/32
     const int H4 = Hp / 32, W4 = Wp / 32, HW4 = H4 * W4;
-    hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(64 * HW4, 256)), dim3(256), 0, s, g->x3, g->p4, 64, H3, W3, 4);
+    hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(64 * HW4, 256), uF), dim3(256), 0, s, g->x3, g->p4, 64, H3, W3, 4, fs);
     const float mo4 = (float)(H4 > W4 ? H4 : W4) / 4.0f;
-    hipLaunchKernelGGL(al_offset_conv_kernel<64>, dim3(sslam::cdiv(HW4, 4)), dim3(256), 0, s, g->p4, g->off, H4,
-                       W4, g->b4c1ot, g->b4c1.ob, mo4);
+    hipLaunchKernelGGL(al_offset_conv_kernel<64>, dim3(sslam::cdiv(HW4, 4), uF), dim3(256), 0, s, g->p4, g->off, H4,
+                       W4, g->b4c1ot, g->b4c1.ob, mo4, fs);
     dcn(g->p4, 64, g->t4, 128, H4, W4, g->b4c1t, g->b4c1.a, g->b4c1.b, nullptr, 0, nullptr, nullptr);
-    hipLaunchKernelGGL(al_offset_conv_kernel<128>, dim3(sslam::cdiv(HW4, 4)), dim3(256), 0, s, g->t4, g->off, H4,
-                       W4, g->b4c2ot, g->b4c2.ob, mo4);
+    hipLaunchKernelGGL(al_offset_conv_kernel<128>, dim3(sslam::cdiv(HW4, 4), uF), dim3(256), 0, s, g->t4, g->off, H4,
+                       W4, g->b4c2ot, g->b4c2.ob, mo4, fs);
     dcn(g->t4, 128, g->x4, 128, H4, W4, g->b4c2t, g->b4c2.a, g->b4c2.b, g->p4, 64, g->b4dwt, g->b4db);
     // gates
-    hipLaunchKernelGGL(al_gate_kernel, dim3(sslam::cdiv(H2 * W2, 256)), dim3(256), 0, s, g->x2, g->g2, 32, H2 * W2, g->gw2, g->g2cl);
-    hipLaunchKernelGGL(al_gate_small_kernel, dim3(sslam::cdiv(32 * HW3, 256)), dim3(256), 0, s, g->x3, g->g3, 64, HW3, g->gw3, g->g3cl);
-    hipLaunchKernelGGL(al_gate_small_kernel, dim3(sslam::cdiv(32 * HW4, 256)), dim3(256), 0, s, g->x4, g->g4, 128, HW4, g->gw4, g->g4cl);
+    hipLaunchKernelGGL(al_gate_kernel, dim3(sslam::cdiv(H2 * W2, 256), uF), dim3(256), 0, s, g->x2, g->g2, 32, H2 * W2, g->gw2, g->g2cl, fs);
+    hipLaunchKernelGGL(al_gate_small_kernel, dim3(sslam::cdiv(32 * HW3, 256), uF), dim3(256), 0, s, g->x3, g->g3, 64, HW3, g->gw3, g->g3cl, fs);
+    hipLaunchKernelGGL(al_gate_small_kernel, dim3(sslam::cdiv(32 * HW4, 256), uF), dim3(256), 0, s, g->x4, g->g4, 128, HW4, g->gw4, g->g4cl, fs);
     // aggregation + score head
     Pyr P{g->x1, g->g2, g->g3, g->g4, g->gw1, Hp, Wp, g->g1cl};
     {
@@ -1392,63 +1459,81 @@ int al_enqueue(sslam_aliked* g, const uint8_t* img_dev, int H, int W, int C, int
         P.sy32 = step(Hp, 32); P.sx32 = step(Wp, 32);
         P.g2cl = g->g2cl; P.g3cl = g->g3cl; P.g4cl = g->g4cl;
     }
-    hipLaunchKernelGGL(al_aggregate_kernel, dim3(sslam::cdiv(Wp, 256), Hp), dim3(256), 0, s, P, g->sh0, g->s8, g->rnorm);
-    hipLaunchKernelGGL(al_score_tail_kernel, dim3(sslam::cdiv(Wp, ST_W), sslam::cdiv(Hp, ST_H)), dim3(256), 0, s, g->s8,
-                       Hp, Wp, g->sh2, g->sh4, g->sh6, g->score, d.h, d.w, d.pl, d.pt);
+    hipLaunchKernelGGL(al_aggregate_kernel, dim3(sslam::cdiv(Wp, 256), Hp, uF), dim3(256), 0, s, P, g->sh0, g->s8, g->rnorm, fs);
+    hipLaunchKernelGGL(al_score_tail_kernel, dim3(sslam::cdiv(Wp, ST_W), sslam::cdiv(Hp, ST_H), uF), dim3(256), 0, s, g->s8,
+                       Hp, Wp, g->sh2, g->sh4, g->sh6, g->score, d.h, d.w, d.pl, d.pt, fs);
     // DKD
     const int nbx = sslam::cdiv(d.w, NT_W), nby = sslam::cdiv(d.h, NT_H), npx = d.h * d.w;
-    hipLaunchKernelGGL(al_nms_kernel, dim3(nbx, nby), dim3(256), 0, s, g->score, d.h, d.w, g->nms, g->bsum);
-    hipLaunchKernelGGL(al_collect_kernel, dim3(sslam::cdiv(npx, 256 * COLLECT_PPT)), dim3(256), 0, s, g->nms, npx, 0.2f, 0, g->bsum,
-                       nbx * nby, g->cand, g->cand_cap, g->ctrl, g->hist);
-    hipLaunchKernelGGL(al_fallback_flag_kernel, dim3(1), dim3(1), 0, s, g->ctrl);
-    hipLaunchKernelGGL(al_collect_kernel, dim3(sslam::cdiv(npx, 256 * COLLECT_PPT)), dim3(256), 0, s, g->nms, npx, 0.0f, 1, g->bsum,
-                       nbx * nby, g->cand, g->cand_cap, g->ctrl, g->hist);
-    hipLaunchKernelGGL(al_select_kernel, dim3(1), dim3(1024), (SEL_CAP + EDGE_CAP) * 8, s, g->cand, g->cand_cap, n_limit,
-                       g->kp_index, g->ctrl, g->hist);
+    hipLaunchKernelGGL(al_nms_kernel, dim3(nbx, nby, uF), dim3(256), 0, s, g->score, d.h, d.w, g->nms, g->bsum, fs);
+    hipLaunchKernelGGL(al_collect_kernel, dim3(sslam::cdiv(npx, 256 * COLLECT_PPT), uF), dim3(256), 0, s, g->nms, npx, 0.2f, 0, g->bsum,
+                       nbx * nby, g->cand, g->cand_cap, g->ctrl, g->hist, fs);
+    hipLaunchKernelGGL(al_fallback_flag_kernel, dim3(uF), dim3(1), 0, s, g->ctrl, fs);
+    hipLaunchKernelGGL(al_collect_kernel, dim3(sslam::cdiv(npx, 256 * COLLECT_PPT), uF), dim3(256), 0, s, g->nms, npx, 0.0f, 1, g->bsum,
+                       nbx * nby, g->cand, g->cand_cap, g->ctrl, g->hist, fs);
+    hipLaunchKernelGGL(al_select_kernel, dim3(uF), dim3(1024), (SEL_CAP + EDGE_CAP) * 8, s, g->cand, g->cand_cap, n_limit,
+                       g->kp_index, g->ctrl, g->hist, fs);
     const int NK = g->max_kpts;
-    hipLaunchKernelGGL(al_refine_kernel, dim3(sslam::cdiv(NK, 256)), dim3(256), 0, s, g->score, d.h, d.w, g->kp_index,
-                       g->kp_norm, g->kp_score, g->ctrl);
+    hipLaunchKernelGGL(al_refine_kernel, dim3(sslam::cdiv(NK, 256), uF), dim3(256), 0, s, g->score, d.h, d.w, g->kp_index,
+                       g->kp_norm, g->kp_score, g->ctrl, fs);
     // SDDH
-    hipLaunchKernelGGL(al_patch_kernel, dim3(sslam::cdiv(NK * 9, 4)), dim3(256), 0, s, P, g->rnorm, d.pl, d.pt, d.h, d.w,
-                       g->kp_norm, g->patch, g->ctrl);
-    hipLaunchKernelGGL((al_gemm_kernel<64, 64, 1, 1>), dim3(1, sslam::cdiv(NK, 64), SDDH_KSPLIT), dim3(256), 0, s, g->patch,
-                       1152, g->d_ow, nullptr, 32, g->h32, 1, NK, 0, g->ctrl);
+    hipLaunchKernelGGL(al_patch_kernel, dim3(sslam::cdiv(NK * 9, 4), uF), dim3(256), 0, s, P, g->rnorm, d.pl, d.pt, d.h, d.w,
+                       g->kp_norm, g->patch, g->ctrl, fs);
+    hipLaunchKernelGGL((al_gemm_kernel<64, 64, 1, 1>), dim3(1, sslam::cdiv(NK, 64), SDDH_KSPLIT * uF), dim3(256), 0, s, g->patch,
+                       1152, g->d_ow, nullptr, 32, g->h32, 1, NK, 0, g->ctrl, SDDH_KSPLIT, fs);
     const float mo = (float)(d.h > d.w ? d.h : d.w) / 4.0f;
-    hipLaunchKernelGGL(al_offsets_kernel, dim3(sslam::cdiv(NK * 32, 256)), dim3(256), 0, s, g->h32, NK, g->d_ob, g->d_w2, g->d_b2,
-                       g->kp_norm, d.h, d.w, mo, g->pos, g->ctrl);
-    hipLaunchKernelGGL(al_sample_kernel, dim3(sslam::cdiv(NK * 16, 4)), dim3(256), 0, s, P, g->rnorm, d.pl, d.pt, d.h,
-                       d.w, g->pos, g->sampled, g->ctrl);
-    hipLaunchKernelGGL((al_gemm_kernel<64, 128, 1, 2>), dim3(1, sslam::cdiv(NK * 16, 64)), dim3(256), 0, s, g->sampled,
-                       128, g->d_sf, nullptr, 128, g->feats, 16, NK * 16, 1, g->ctrl);
-    hipLaunchKernelGGL((al_gemm_kernel<64, 64, 1, 1>), dim3(2, sslam::cdiv(NK, 64), SDDH_KSPLIT), dim3(256), 0, s, g->feats,
-                       2048, g->d_agg, nullptr, 128, g->raw, 1, NK, 0, g->ctrl);
+    hipLaunchKernelGGL(al_offsets_kernel, dim3(sslam::cdiv(NK * 32, 256), uF), dim3(256), 0, s, g->h32, NK, g->d_ob, g->d_w2, g->d_b2,
+                       g->kp_norm, d.h, d.w, mo, g->pos, g->ctrl, fs);
+    hipLaunchKernelGGL(al_sample_kernel, dim3(sslam::cdiv(NK * 16, 4), uF), dim3(256), 0, s, P, g->rnorm, d.pl, d.pt, d.h,
+                       d.w, g->pos, g->sampled, g->ctrl, fs);
+    hipLaunchKernelGGL((al_gemm_kernel<64, 128, 1, 2>), dim3(1, sslam::cdiv(NK * 16, 64), uF), dim3(256), 0, s, g->sampled,
+                       128, g->d_sf, nullptr, 128, g->feats, 16, NK * 16, 1, g->ctrl, 1, fs);
+    hipLaunchKernelGGL((al_gemm_kernel<64, 64, 1, 1>), dim3(2, sslam::cdiv(NK, 64), SDDH_KSPLIT * uF), dim3(256), 0, s, g->feats,
+                       2048, g->d_agg, nullptr, 128, g->raw, 1, NK, 0, g->ctrl, SDDH_KSPLIT, fs);
     const float scale_x = (float)d.w / (float)W, scale_y = (float)d.h / (float)H;
-    hipLaunchKernelGGL(al_finalize_kernel, dim3(sslam::cdiv(NK, 4)), dim3(256), 0, s, g->raw, NK, g->kp_norm, g->kp_score,
-                       d.h, d.w, scale_x, scale_y, xy_out, desc_out, score_out, n_out, g->ctrl);
+    hipLaunchKernelGGL(al_finalize_kernel, dim3(sslam::cdiv(NK, 4), uF), dim3(256), 0, s, g->raw, NK, g->kp_norm, g->kp_score,
+                       d.h, d.w, scale_x, scale_y, outs, g->ctrl, fs);
     SSLAM_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+// single-frame form
+int al_enqueue(sslam_aliked* g, const uint8_t* img_dev, int H, int W, int C, int n_limit, float* xy_out,
+               float* desc_out, float* score_out, int32_t* n_out) {
+    FrameIn in{}; FrameOut out{};
+    in.img[0] = img_dev; out.xy[0] = xy_out; out.desc[0] = desc_out; out.score[0] = score_out; out.n[0] = n_out;
+    return al_enqueue(g, 1, in, H, W, C, n_limit, out);
 }
 
 }  // namespace
 
 extern "C" {
 
-int sslam_aliked_create(sslam_ctx* ctx, const float* weights, size_t n_floats, int max_h, int max_w,
-                        int max_kpts, sslam_aliked** out) {
+int sslam_aliked_create_batched(sslam_ctx* ctx, const float* weights, size_t n_floats, int max_h, int max_w,
+                                int max_kpts, int max_frames, sslam_aliked** out) {
     SSLAM_REQUIRE(ctx && weights && out, "sslam_aliked_create: NULL argument");
+    SSLAM_REQUIRE(max_frames >= 1 && max_frames <= MAX_FRAMES, "sslam_aliked_create: max_frames %d not in [1, %d]",
+                  max_frames, MAX_FRAMES);
     SSLAM_REQUIRE(max_h >= 16 && max_w >= 16 && max_h <= 8192 && max_w <= 8192,
                   "sslam_aliked_create: image size %dx%d unsupported", max_w, max_h);
     SSLAM_REQUIRE(max_kpts >= 1 && max_kpts <= SEL_CAP, "sslam_aliked_create: max_kpts %d not in [1, %d]", max_kpts,
                   SEL_CAP);
     SSLAM_HIP_CHECK(hipSetDevice(ctx->device));
     sslam_aliked* g = new sslam_aliked();
-    g->ctx = ctx; g->max_h = max_h; g->max_w = max_w; g->max_kpts = max_kpts;
+    g->ctx = ctx; g->max_h = max_h; g->max_w = max_w; g->max_kpts = max_kpts; g->max_frames = max_frames;
     // the network never runs larger than 1024 on the long side (+ padding to /32)
     g->Hp_cap = 1024 + 32; g->Wp_cap = 1024 + 32;
     const size_t HWp = (size_t)g->Hp_cap * g->Wp_cap, HWi = (size_t)max_h * max_w, NK = (size_t)max_kpts;
     g->cand_cap = (int)(1024 * 1024);
-    auto carve = [&](sslam::Arena& A) {
+    // shared by all frames: weights, their re-ordered copies, the blur taps
+    auto carve_shared = [&](sslam::Arena& A) {
         g->blob = A.take<float>(n_floats);
+        g->b3c1t = A.take<float>(288 * 64); g->b3c2t = A.take<float>(576 * 64); g->b4c1t = A.take<float>(576 * 128);
+        g->b4c2t = A.take<float>(1152 * 128); g->b3dwt = A.take<float>(32 * 64); g->b4dwt = A.take<float>(64 * 128);
+        g->b3c1ot = A.take<float>(288 * 18); g->b3c2ot = A.take<float>(576 * 18); g->b4c1ot = A.take<float>(576 * 18); g->b4c2ot = A.take<float>(1152 * 18);
+        g->gk = A.take<float>(64);
+    };
+    // one workspace block per frame of a batch (frame f's copy of a buffer = frame 0's + f * g->fs bytes)
+    auto carve_frame = [&](sslam::Arena& A) {
         g->ctrl = A.take<ALCtrl>(1);
         g->in_u8 = A.take<uint8_t>(HWi * 4);
         g->fsrc = A.take<float>(3 * HWi); g->img = A.take<float>(3 * HWp);
@@ -1457,9 +1542,6 @@ int sslam_aliked_create(sslam_ctx* ctx, const float* weights, size_t n_floats, i
         g->p3 = A.take<float>(32 * HWp / 64); g->off = A.take<float>(18 * HWp / 64);
         g->t3 = A.take<float>(64 * HWp / 64); g->x3 = A.take<float>(64 * HWp / 64);
         g->p4 = A.take<float>(64 * HWp / 1024); g->t4 = A.take<float>(128 * HWp / 1024); g->x4 = A.take<float>(128 * HWp / 1024);
-        g->b3c1t = A.take<float>(288 * 64); g->b3c2t = A.take<float>(576 * 64); g->b4c1t = A.take<float>(576 * 128);
-        g->b4c2t = A.take<float>(1152 * 128); g->b3dwt = A.take<float>(32 * 64); g->b4dwt = A.take<float>(64 * 128);
-        g->b3c1ot = A.take<float>(288 * 18); g->b3c2ot = A.take<float>(576 * 18); g->b4c1ot = A.take<float>(576 * 18); g->b4c2ot = A.take<float>(1152 * 18);
         {   // im2col rows: 1/8 level (64*9 + 32) floats per pixel, 1/32 level (128*9 + 64)
             const size_t a = (HWp / 64) * (size_t)(576 + 32), b = (HWp / 1024) * (size_t)(1152 + 64);
             g->dcol = A.take<float>((a > b ? a : b) + 64);
@@ -1469,7 +1551,7 @@ int sslam_aliked_create(sslam_ctx* ctx, const float* weights, size_t n_floats, i
         g->g2 = A.take<float>(32 * HWp / 4); g->g3 = A.take<float>(32 * HWp / 64); g->g4 = A.take<float>(32 * HWp / 1024);
         g->g2cl = A.take<float>(32 * HWp / 4); g->g3cl = A.take<float>(32 * HWp / 64); g->g4cl = A.take<float>(32 * HWp / 1024);
         g->s8 = A.take<float>(8 * HWp); g->rnorm = A.take<float>(HWp); g->g1cl = A.take<float>(32 * HWp);
-        g->score = A.take<float>(HWp); g->nms = A.take<float>(HWp); g->bsum = A.take<float>(4096); g->gk = A.take<float>(64);
+        g->score = A.take<float>(HWp); g->nms = A.take<float>(HWp); g->bsum = A.take<float>(4096);
         g->cand = A.take<unsigned long long>(g->cand_cap); g->hist = A.take<unsigned>(HBINS);
         g->kp_index = A.take<int>(SEL_CAP);
         g->kp_norm = A.take<float>(2 * NK + 64); g->kp_score = A.take<float>(NK + 64);
@@ -1481,9 +1563,15 @@ int sslam_aliked_create(sslam_ctx* ctx, const float* weights, size_t n_floats, i
     };
     sslam::Arena probe;
     probe.measure();
-    carve(probe);
-    if (g->arena.init(probe.off + 256)) { delete g; return 1; }
-    carve(g->arena);
+    carve_shared(probe);
+    const size_t shared_bytes = (probe.off + 4095) / 4096 * 4096;
+    probe.off = 0;
+    carve_frame(probe);
+    g->fs = (probe.off + 4095) / 4096 * 4096;
+    if (g->arena.init(shared_bytes + g->fs * (size_t)max_frames + 4096)) { delete g; return 1; }
+    carve_shared(g->arena);
+    g->arena.off = shared_bytes;               // frame 0's block starts on a page boundary; blocks 1.. follow at g->fs
+    carve_frame(g->arena);
     SSLAM_REQUIRE(g->out_n != nullptr, "sslam_aliked_create: workspace arena exhausted");
     SSLAM_HIP_CHECK(hipMemcpy(g->blob, weights, n_floats * 4, hipMemcpyHostToDevice));
     if (int rc = al_bind_weights(g, n_floats)) { g->arena.release(); delete g; return rc; }
@@ -1507,6 +1595,11 @@ int sslam_aliked_create(sslam_ctx* ctx, const float* weights, size_t n_floats, i
                                         (SEL_CAP + EDGE_CAP) * 8));
     *out = g;
     return 0;
+}
+
+int sslam_aliked_create(sslam_ctx* ctx, const float* weights, size_t n_floats, int max_h, int max_w,
+                        int max_kpts, sslam_aliked** out) {
+    return sslam_aliked_create_batched(ctx, weights, n_floats, max_h, max_w, max_kpts, 1, out);
 }
 
 int sslam_aliked_destroy(sslam_aliked* g) {
@@ -1537,6 +1630,27 @@ int sslam_aliked_extract_dev(sslam_aliked* g, const uint8_t* img, int H, int W, 
                                     (uint64_t)xy_out, (uint64_t)desc_out, (uint64_t)score_out, (uint64_t)n_out};
     return sslam::run_cached(g->graphs, g->ctx->stream, key,
                              [&] { return al_enqueue(g, img, H, W, C, max_kpts, xy_out, desc_out, score_out, n_out); });
+}
+
+int sslam_aliked_extract_batch_dev(sslam_aliked* g, int n_frames, const uint8_t* const* imgs, int H, int W, int C,
+                                   int max_kpts, float* const* xy_out, float* const* desc_out,
+                                   float* const* score_out, int32_t* const* n_out) {
+    SSLAM_REQUIRE(g && imgs && xy_out && desc_out && n_out, "sslam_aliked_extract_batch_dev: NULL argument");
+    SSLAM_REQUIRE(n_frames >= 1 && n_frames <= g->max_frames, "sslam_aliked_extract_batch_dev: %d frames, instance capacity %d",
+                  n_frames, g->max_frames);
+    if (int rc = al_check_image(g, H, W, C, max_kpts)) return rc;
+    FrameIn in{}; FrameOut out{};
+    std::vector<uint64_t> key{(uint64_t)n_frames, (uint64_t)H, (uint64_t)W, (uint64_t)C, (uint64_t)max_kpts};
+    for (int f = 0; f < n_frames; ++f) {
+        SSLAM_REQUIRE(imgs[f] && xy_out[f] && desc_out[f] && n_out[f], "sslam_aliked_extract_batch_dev: NULL pointer for frame %d", f);
+        in.img[f] = imgs[f]; out.xy[f] = xy_out[f]; out.desc[f] = desc_out[f];
+        out.score[f] = score_out ? score_out[f] : nullptr; out.n[f] = n_out[f];
+        key.push_back((uint64_t)imgs[f]); key.push_back((uint64_t)xy_out[f]); key.push_back((uint64_t)desc_out[f]);
+        key.push_back((uint64_t)out.score[f]); key.push_back((uint64_t)n_out[f]);
+    }
+    g->last = al_dims(H, W, C);
+    if (!g->use_graphs) return al_enqueue(g, n_frames, in, H, W, C, max_kpts, out);
+    return sslam::run_cached(g->graphs, g->ctx->stream, key, [&] { return al_enqueue(g, n_frames, in, H, W, C, max_kpts, out); });
 }
 
 /* Replay the launch sequence of sslam_aliked_extract_dev as a cached hipGraph (one graph per

@@ -33,6 +33,10 @@ ABL = set(filter(None, os.environ.get("ATTN_ASM_ABL", "").split(",")))
 # packed fp32 (v_pk_fma_f32 / v_pk_add_f32) for the pairwise element-wise steps: measured SLOWER by 55 us per 8-pair launch
 # than two plain instructions each (they do not issue under a running MFMA), kept as a switch for the record
 PK = os.environ.get("ATTN_ASM_PK", "0") == "1"
+# schedule knobs (experiments; the defaults are the measured best)
+NEXP_ODD = int(os.environ.get("ATTN_ASM_NEXP_ODD", "4"))     # exp2 pairs (of 8) taken in the ODD half, the rest in EVEN
+DEFER = int(os.environ.get("ATTN_ASM_DEFER", "0"))           # 1: row sums of the EVEN half's pairs + the l update run in slots 0-2 of the next ODD half
+WEIGHTED = int(os.environ.get("ATTN_ASM_WEIGHTED", "0"))     # 1: spread the VALU stream by issue cost (transcendental 2, else 1) instead of by count
 
 out = []
 def e(s=""):
@@ -204,9 +208,19 @@ def softmax_split(pair):
             f"v_fma_mixhi_f16 {v(lreg)}, {v(hreg)}, -1.0, {v(r1)} op_sel:[1,0,0] op_sel_hi:[1,0,0]"]
 
 def softmax_lsum():
-    return [f"v_add_f32_e32 {v(V_PS0)}, {v(V_PS0)}, {v(V_PS1)}",
-            f"v_fmac_f32_e32 {v(V_PS0)}, {v(V_L)}, {v(V_ALPHA)}",      # ps0 = l_run * alpha + (psum0 + psum1)
-            f"v_mov_b32_e32 {v(V_L)}, {v(V_PS0)}"]
+    c = [f"v_add_f32_e32 {v(V_PS0)}, {v(V_PS0)}, {v(V_PS1)}",
+         f"v_fmac_f32_e32 {v(V_PS0)}, {v(V_L)}, {v(V_ALPHA)}",      # ps0 = l_run * alpha + (psum0 + psum1)
+         f"v_mov_b32_e32 {v(V_L)}, {v(V_PS0)}"]
+    if DEFER:                                                        # (the rescale subroutine ran before this: reset here)
+        c.append(f"v_mov_b32_e32 {v(V_ALPHA)}, 1.0")
+    return c
+
+def deferred_block():
+    """row sums of the pairs whose exp2 ran in the previous EVEN half, then the l update (sub-step j - 1)"""
+    c = []
+    for p in range(NEXP_ODD, 8):
+        c += softmax_sum(p)
+    return c + softmax_lsum()
 
 def interleave(*streams):
     """round-robin merge keeping each stream's order (hides the latency of exp / cvt behind the neighbour)."""
@@ -230,11 +244,22 @@ def dma_issue(ldsbase_sgpr):
     return c
 
 # ---------------------------------------------------------------- half-step scheduler
-def emit_half(mfmas, ds, valu, dma=None, valu_start=0, comment=""):
+def _cost(x):
+    if not WEIGHTED:
+        return 1.0
+    if x.startswith("v_exp_f32"):
+        return 2.0
+    if x.startswith("s_") and not x.startswith("s_nop"):
+        return 0.25
+    return 1.0
+
+def emit_half(mfmas, ds, valu, dma=None, valu_start=0, comment="", head=None):
     """12 (or 0) MFMAs; one ds_read behind each of the first MFMAs, the VALU stream spread over the slots from
-    `valu_start` on, one DMA piece (m0 + offset set-up + load) per slot from slot 1 on."""
+    `valu_start` on (`head`: a second stream for the slots before it), one DMA piece (m0 + offset set-up + load) per
+    slot from slot 1 on."""
     e(f"    ; ---- {comment}")
-    if "novalu" in ABL: valu = []
+    head = list(head or [])
+    if "novalu" in ABL: valu, head = [], []
     if "fakevalu" in ABL:       # the same number of VALU instructions, all independent full-rate fmas
         valu = [f"v_fma_f32 {v(SV + i % 16)}, {v(SV + i % 16)}, {v(V_ROW)}, {v(V_NINF)}" for i, x in enumerate(valu) if x.startswith("v_")]
     if "notrans" in ABL:        # transcendentals replaced by moves
@@ -246,14 +271,19 @@ def emit_half(mfmas, ds, valu, dma=None, valu_start=0, comment=""):
     if "nomfma" in ABL: mfmas = ["s_nop 0"] * len(mfmas)
     if not mfmas:
         for x in ds: e("    " + x)
-        for x in valu: e("    " + x)
+        for x in head + valu: e("    " + x)
         return
     nslot = len(mfmas)
     per = [[] for _ in range(nslot)]
-    ns = nslot - valu_start
-    nv = max(len(valu), 1)
-    for i, x in enumerate(valu):
-        per[valu_start + min(ns - 1, i * ns // nv)].append(x)
+    def spread(items, lo, hi):
+        tot = sum(_cost(x) for x in items) or 1.0
+        acc = 0.0
+        for x in items:
+            per[lo + min(hi - lo - 1, int(acc / tot * (hi - lo)))].append(x)
+            acc += _cost(x)
+    if head:
+        spread(head, 0, valu_start)
+    spread(valu, valu_start if head or valu_start else 0, nslot)
     dsl = list(ds)
     dml = list(dma or [])
     for sl in range(nslot):
@@ -291,11 +321,15 @@ def body(b, last, mask, tag):
         else:
             kr = [] if last else k_reads(0, b ^ 1)
         ex, sm = [], []
-        for p in range(4):
+        for p in range(NEXP_ODD):
             ex += softmax_exp(p)
             sm += softmax_sum(p)
-        valu = ["s_nop 3"] + softmax_part1(mask, st) + ex + sm
-        emit_half(mfma_pv(), kr, valu, valu_start=3, comment=f"ODD  buf {b} sub {sub}: PV(j-1) | K frags(j+1) | softmax part 1")
+        if DEFER:
+            emit_half(mfma_pv(), kr, softmax_part1(mask, st) + ex + sm, valu_start=3, head=deferred_block(),
+                      comment=f"ODD  buf {b} sub {sub}: PV(j-1) | K frags(j+1) | sums(j-1), softmax part 1")
+        else:
+            emit_half(mfma_pv(), kr, ["s_nop 3"] + softmax_part1(mask, st) + ex + sm, valu_start=3,
+                      comment=f"ODD  buf {b} sub {sub}: PV(j-1) | K frags(j+1) | softmax part 1")
         dma = None
         if sub == 0:
             # ---------------- tile barrier: own DMA pieces landed; K(tile) and V^T(tile-1) completely read
@@ -310,15 +344,15 @@ def body(b, last, mask, tag):
         # ---------------- EVEN half
         do_qk = not (last and sub == 1)
         ex, sm, first, rest = [], [], [], []
-        for p in range(4, 8):
+        for p in range(NEXP_ODD, 8):
             ex += softmax_exp(p)
             sm += softmax_sum(p)
-        for p in range(4):
+        for p in range(NEXP_ODD):
             first += softmax_split(p)
-        for p in range(4, 8):
+        for p in range(NEXP_ODD, 8):
             rest += softmax_split(p)
-        # exp2 of the second half of the elements under the split of the first half's, then sums and the rest
-        valu = interleave(ex, first) + sm + rest + softmax_lsum()
+        # exp2 of the remaining elements under the split of the ODD half's, then (sums and) the rest
+        valu = interleave(ex, first) + ([] if DEFER else sm) + rest + ([] if DEFER else softmax_lsum())
         e("    s_waitcnt lgkmcnt(0)")
         emit_half(mfma_qk() if do_qk else [], v_reads(sub, b), valu, dma=dma, valu_start=0,
                   comment=f"EVEN buf {b} sub {sub}: QK(j+1) | V frags(j) | softmax part 2")
@@ -486,7 +520,7 @@ for grp in dma_issue("s58"):
 # state (under the DMA)
 for r in range(64):
     e(f"    v_mov_b32_e32 {v(r)}, 0")
-for r in range(PH, PH + 16):
+for r in list(range(PH, PH + 16)) + ([V_PS0, V_PS1] + list(range(SV, SV + 16)) if DEFER else []):
     e(f"    v_mov_b32_e32 {v(r)}, 0")
 e(f"    v_mov_b32_e32 {v(V_M)}, 0xff800000")
 e(f"    v_mov_b32_e32 {v(V_THR)}, 0xff800000")
@@ -537,6 +571,9 @@ e(".Lfin:")
 e("    s_waitcnt lgkmcnt(0)")
 for x in mfma_pv():
     e("    " + x)
+if DEFER:
+    for x in deferred_block():
+        e("    " + x)
 # l_tot = l(lo half) + l(hi half)
 e(f"    v_mov_b32_e32 {v(V_T0)}, {v(V_L)}")
 e("    s_nop 1")
@@ -620,7 +657,8 @@ e("    s_endpgm")
 e(".Lrescale_sub:")
 for r in range(0, 64, 2):
     e(f"    v_pk_mul_f32 {v(r, 2)}, {v(r, 2)}, {v(V_ALPHA, 2)} op_sel_hi:[1,0]")
-e(f"    v_mov_b32_e32 {v(V_ALPHA)}, 1.0")                       # the next sub-steps keep the reference
+if not DEFER:
+    e(f"    v_mov_b32_e32 {v(V_ALPHA)}, 1.0")                   # the next sub-steps keep the reference
 e(f"    s_setpc_b64 {S_RET}")
 # ---------------------------------------------------------------- new reference (rare): m_run, alpha, threshold, exponent bias
 e(".Lnewref_sub:")

@@ -164,3 +164,52 @@ def test_extraction_is_bit_reproducible_and_stateless(W, AL):
         for x, y in zip(a, b):
             np.testing.assert_array_equal(x, y)
     al.close()
+
+
+def test_batched_entry_gives_the_single_frame_results_bit_for_bit(W, AL, gpu_ctx):
+    """sslam_aliked_extract_batch_dev: F frames of one size through ONE launch sequence (frame in a grid
+    dimension, one workspace block per frame).  A frame's arithmetic does not depend on the batch, so keypoints,
+    descriptors, scores and counts must equal those of the single-frame entry exactly - in the top-k branch (every
+    frame fills max_kpts) and in the threshold / raster branch (a different count per frame), at F = 1, 3 and 5,
+    plain and twice through a cached graph, and again after a batch of another size went through the instance."""
+    H, Wd = 200, 333
+    imgs = [frames.structured_frame(i, h=H, w=Wd) if i % 2 else frames.noise_frame(i, h=H, w=Wd) for i in range(5)]
+    dev = [gpu_ctx.upload(im) for im in imgs]
+    for sd, K, varied in ((W.random_aliked_state_dict(0), 1024, False), (W.random_aliked_state_dict(2, score_gain=-0.1), 4096, True)):
+        single = AL(sd, max_num_keypoints=K, max_h=H, max_w=Wd, ctx=gpu_ctx)
+        want = [single.extract(im, K, return_scores=True) for im in imgs]
+        counts = {len(w[0]) for w in want}
+        assert (len(counts) > 1 and max(counts) < K) if varied else counts == {K}, counts
+        al = AL(sd, max_num_keypoints=K, max_h=H, max_w=Wd, ctx=gpu_ctx, max_frames=5)
+        xy = [gpu_ctx.malloc(K * 8) for _ in imgs]; de = [gpu_ctx.malloc(K * 512) for _ in imgs]
+        sc = [gpu_ctx.malloc(K * 4) for _ in imgs]; nn = [gpu_ctx.malloc(16) for _ in imgs]
+
+        def check(order):
+            gpu_ctx.sync()
+            for slot, i in enumerate(order):
+                n = np.empty(1, np.int32); gpu_ctx.d2h(n, nn[slot])
+                k = int(n[0])
+                assert k == len(want[i][0]), (i, k, len(want[i][0]))
+                a = np.empty((K, 2), np.float32); d = np.empty((K, 128), np.float32); s = np.empty(K, np.float32)
+                gpu_ctx.d2h(a, xy[slot]); gpu_ctx.d2h(d, de[slot]); gpu_ctx.d2h(s, sc[slot])
+                np.testing.assert_array_equal(a[:k], want[i][0])
+                np.testing.assert_array_equal(d[:k], want[i][1])
+                np.testing.assert_array_equal(s[:k], want[i][2])
+
+        for use_graph in (False, True):
+            al.use_graphs(use_graph)
+            for order in ([0, 1, 2, 3, 4], [3], [4, 0, 2], [0, 1, 2, 3, 4]):
+                F = len(order)
+                for rep in range(2):
+                    al.extract_batch_dev([dev[i] for i in order], H, Wd, 3, xy[:F], de[:F], sc[:F], nn[:F], K)
+                check(order)
+        # the single-frame device entry of a batched instance is the F = 1 batch
+        al.extract_dev(dev[1], H, Wd, 3, xy[0], de[0], sc[0], nn[0], K)
+        check([1])
+        with pytest.raises(RuntimeError):
+            al.extract_batch_dev([dev[0]] * 6, H, Wd, 3, xy + xy[:1], de + de[:1], sc + sc[:1], nn + nn[:1], K)
+        for p in xy + de + sc + nn:
+            gpu_ctx.free(p)
+        al.close(); single.close()
+    for p in dev:
+        gpu_ctx.free(p)
