@@ -420,7 +420,9 @@ def main():
     ctx_e = [nat.Context(device_index) for _ in range(N_EXT)]
     ctx_m = [nat.Context(device_index) for _ in range(N_MAT)]
     sd_a, sd_l = W.random_aliked_state_dict(0), W.random_lightglue_state_dict(0)
-    dets = [AlikedHIP(sd_a, max_num_keypoints=MAX_KPTS, max_h=H_IMG, max_w=W_IMG, ctx=c) for c in ctx_e]
+    # extractors take EXT_FRAMES frames per call (one launch sequence per chunk, sslam_aliked_extract_batch_dev)
+    EXT_FRAMES = int(os.environ.get("SSLAM_BENCH_EF", 8))
+    dets = [AlikedHIP(sd_a, max_num_keypoints=MAX_KPTS, max_h=H_IMG, max_w=W_IMG, ctx=c, max_frames=EXT_FRAMES) for c in ctx_e]
     mats = [LightGlueHIP(sd_l, max_kpts=MAX_KPTS, ctx=c, max_pairs=BATCH_PAIRS) for c in ctx_m]
     if os.environ.get("SSLAM_BIG_GEMM"):                 # A/B hook (scripts/): linear-kernel form of the batched forward
         for mat in mats:
@@ -572,13 +574,13 @@ def main():
                        # depth is data dependent (early stop) - layers executed over the pairs of the last round
                        "lightglue_layers_histogram": {str(int(k)): int(v) for k, v in
                                                       zip(*np.unique(info[info[:, 2] > 0, 1], return_counts=True))},
-                       "pairs_per_lightglue_launch": BATCH_PAIRS,
+                       "pairs_per_lightglue_launch": BATCH_PAIRS, "frames_per_aliked_launch": pipe.EF,
                        "parallelism": f"frame-shard x{world}; per GPU {N_EXT} extractor + {N_MAT} matcher streams, "
-                                      f"LightGlue in batches of {BATCH_PAIRS} pairs"},
+                                      f"ALIKED in batches of {pipe.EF} frames, LightGlue in batches of {BATCH_PAIRS} pairs"},
             # achieved = ALGORITHMIC flops (8 n0 n1 256 per pair, x pairs per launch) / HIP-event launch
             # duration on an otherwise idle GPU; the kernel issues 3 v_mfma_f32_32x32x16_f16 per
             # algorithmic product (executed = 3x)
-            "roofline": {"bound": "mfma", "kernel": "lg_attention_hs_kernel (v_mfma_f32_32x32x16_f16 x3 per product)",
+            "roofline": {"bound": "mfma", "kernel": "lg_attention_asm_kernel (hand-scheduled gfx950 assembly; v_mfma_f32_32x32x16_f16 x3 per product)",
                          "achieved": round(ach, 2) if ach else None, "peak": F16_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(ach / F16_MFMA_PEAK_TFLOPS, 4) if ach else None,
                          # HBM-side bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,

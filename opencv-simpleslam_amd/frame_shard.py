@@ -132,7 +132,8 @@ class FrameStreamPipeline:
 
     `detectors` / `matchers` are lists of AlikedHIP / LightGlueHIP instances, each created on its
     own `_native.Context` (= its own HIP stream).  Frame s of a round is extracted on extractor
-    s % NE; pairs are matched in batches of `batch_pairs` on matcher (batch index) % NM (each
+    s % NE - or, when the extractors were created with max_frames = EF > 1, chunk c of EF consecutive frames
+    goes through one batched launch sequence on extractor c % NE; pairs are matched in batches of `batch_pairs` on matcher (batch index) % NM (each
     matcher needs max_pairs >= batch_pairs)."""
 
     def __init__(self, detectors, matchers, plan: ShardPlan, max_kpts: int, min_conf: float = 0.7,
@@ -148,6 +149,7 @@ class FrameStreamPipeline:
         if self.K % 2:
             raise ValueError("max_kpts must be even (16-byte aligned descriptor rows inside a record)")
         self.min_conf = float(min_conf)
+        self.EF = min(min(getattr(d, "max_frames", 1) for d in self.dets), plan.frames_per_rank)   # frames per extractor call
         self.P = int(batch_pairs or min(m.max_pairs for m in self.mats))
         if any(m.max_pairs < self.P for m in self.mats):
             raise ValueError(f"batch_pairs={self.P} exceeds a matcher's max_pairs")
@@ -249,11 +251,25 @@ class FrameStreamPipeline:
                     d.ctx.wait(self.ev_collated[p])
             if rnd >= 1 and self.n_batches[1 - p]:
                 d.ctx.wait(self.ev_batch[1 - p][0])
-        for s in range(B):
-            d = self.dets[s % NE]
-            d.extract_dev(base + s * fbytes, H, W, C, self.xy_ptr(s_base + s), self.desc_ptr(s_base + s),
-                          self.score + (s_base + s) * K * 4, self.count_ptr(s_base + s), max_kpts=K)
-            d.ctx.record(self.ev_ext[p][s])
+        EF = self.EF
+        if EF == 1:
+            for s in range(B):
+                d = self.dets[s % NE]
+                d.extract_dev(base + s * fbytes, H, W, C, self.xy_ptr(s_base + s), self.desc_ptr(s_base + s),
+                              self.score + (s_base + s) * K * 4, self.count_ptr(s_base + s), max_kpts=K)
+                d.ctx.record(self.ev_ext[p][s])
+        else:
+            # batched extractors: chunk c = frames [c EF, (c + 1) EF) goes through ONE launch sequence on extractor
+            # c % NE (sslam_aliked_extract_batch_dev); every frame of the chunk gets its event behind it
+            for c, lo in enumerate(range(0, B, EF)):
+                fr = range(lo, min(B, lo + EF))
+                d = self.dets[c % NE]
+                d.extract_batch_dev([base + s * fbytes for s in fr], H, W, C, [self.xy_ptr(s_base + s) for s in fr],
+                                    [self.desc_ptr(s_base + s) for s in fr],
+                                    [self.score + (s_base + s) * K * 4 for s in fr],
+                                    [self.count_ptr(s_base + s) for s in fr], max_kpts=K)
+                for s in fr:
+                    d.ctx.record(self.ev_ext[p][s])
         have_halo = self.have_halo
         prev_slot = (1 - p) * B + B - 1                  # last frame of the previous round (one GPU)
         if not single:

@@ -24,13 +24,15 @@ def _sequential_reference(native, imgs, K, H, Wd, sd_a, sd_l, min_conf):
     return feats, ref
 
 
-@pytest.mark.parametrize("B,P,NE,NM,sync_each_round", [(4, 2, 2, 3, True), (5, 3, 2, 2, False), (4, 4, 1, 1, False)])
-def test_pipeline_equals_sequential_api(native, B, P, NE, NM, sync_each_round):
+@pytest.mark.parametrize("B,P,NE,NM,sync_each_round,EF", [(4, 2, 2, 3, True, 1), (5, 3, 2, 2, False, 1), (4, 4, 1, 1, False, 1),
+                                                         (5, 3, 2, 2, False, 2), (6, 4, 2, 2, False, 4), (4, 2, 1, 2, True, 4)])
+def test_pipeline_equals_sequential_api(native, B, P, NE, NM, sync_each_round, EF):
     """Extracts on NE streams, batched matches (P pairs per enqueue) on NM streams, on the C-ABI
     alone (no torch).  With sync_each_round=False three rounds are enqueued back to back with NO
     host synchronisation in between (per-round results are copied on-stream into a history buffer),
     so every cross-round ordering edge - slot reuse, the alternating halo record, matcher events -
-    is exercised the way bench.py drives the pipeline."""
+    is exercised the way bench.py drives the pipeline.  EF > 1: the extractors take chunks of EF frames per call
+    (the batched ALIKED entry, ragged last chunk included)."""
     W = load_pkg("weights"); fs = load_pkg("frame_shard")
     AL = load_pkg("aliked").AlikedHIP; LG = load_pkg("lightglue").LightGlueHIP
     K, H, Wd, ROUNDS = 512, 200, 320, 3
@@ -39,9 +41,10 @@ def test_pipeline_equals_sequential_api(native, B, P, NE, NM, sync_each_round):
     imgs = [frames.structured_frame(i, h=H, w=Wd) for i in range(ROUNDS * B)]
     feats, ref = _sequential_reference(native, imgs, K, H, Wd, sd_a, sd_l, 0.0)
 
-    dets = [AL(sd_a, max_num_keypoints=K, max_h=H, max_w=Wd, ctx=native.Context(0)) for _ in range(NE)]
+    dets = [AL(sd_a, max_num_keypoints=K, max_h=H, max_w=Wd, ctx=native.Context(0), max_frames=EF) for _ in range(NE)]
     mats = [LG(sd_l, max_kpts=K, ctx=native.Context(0), max_pairs=P, filter_threshold=0.0) for _ in range(NM)]
     pipe = fs.FrameStreamPipeline(dets, mats, fs.ShardPlan(1, 0, B), K, 0.0, batch_pairs=P)
+    assert pipe.EF == min(EF, B)
     ctx = pipe.ctx
     chunks = [ctx.upload(np.stack(imgs[r * B:(r + 1) * B])) for r in range(ROUNDS)]
     hist = []                                   # per round: device copies of (records, ij, info)
