@@ -37,6 +37,10 @@ PK = os.environ.get("ATTN_ASM_PK", "0") == "1"
 NEXP_ODD = int(os.environ.get("ATTN_ASM_NEXP_ODD", "4"))     # exp2 pairs (of 8) taken in the ODD half, the rest in EVEN
 DEFER = int(os.environ.get("ATTN_ASM_DEFER", "0"))           # 1: row sums of the EVEN half's pairs + the l update run in slots 0-2 of the next ODD half
 WEIGHTED = int(os.environ.get("ATTN_ASM_WEIGHTED", "0"))     # 1: spread the VALU stream by issue cost (transcendental 2, else 1) instead of by count
+# diagnostic build (never the product): s_memtime stamps around the three kinds of waits of the loop; every wave writes
+# {lifetime, tile-barrier wait, fragment wait at ODD, fragment wait at EVEN, stamp-pair overhead, tiles} (cycles) to the
+# buffer whose address sits at kernel-argument offset 96
+STAMP = os.environ.get("ATTN_ASM_STAMP", "0") == "1"
 
 out = []
 def e(s=""):
@@ -88,7 +92,17 @@ S_RAGGED, S_NKREM = "s64", "s65"
 S_INV2 = "s[68:69]"               # {2^-11, 2^-11}
 S_C4E6, S_TLAST, S_CMIN = "s70", "s71", "s72"   # 4.0e6f ; T - 1 ; 2^-14
 S_NSCALE, S_C65520, S_CINF = "s73", "s74", "s75"
-N_SGPR = 80
+N_SGPR = 96 if STAMP else 80
+S_DBG, S_ACC_BAR, S_ACC_ODD, S_ACC_EVEN, S_T0, S_TA, S_TB, S_ACC_CAL = "s[80:81]", 82, 84, 86, "s[88:89]", 90, 92, 94
+
+def stamped(wait_lines, acc):
+    """the wait, bracketed by two s_memtime reads whose difference is added to the 64-bit SGPR counter `acc`"""
+    if not STAMP:
+        return list(wait_lines)
+    return ([f"s_memtime s[{S_TA}:{S_TA + 1}]"] + list(wait_lines) +
+            [f"s_memtime s[{S_TB}:{S_TB + 1}]", "s_waitcnt lgkmcnt(0)",
+             f"s_sub_u32 s{S_TB}, s{S_TB}, s{S_TA}", f"s_subb_u32 s{S_TB + 1}, s{S_TB + 1}, s{S_TA + 1}",
+             f"s_add_u32 s{acc}, s{acc}, s{S_TB}", f"s_addc_u32 s{acc + 1}, s{acc + 1}, s{S_TB + 1}"])
 
 MFMA = "v_mfma_f32_32x32x16_f16"
 
@@ -310,7 +324,7 @@ def body(b, last, mask, tag):
     for sub in range(2):
         st = f"{tag}_s{sub}"
         # ---------------- ODD half
-        e("    s_waitcnt lgkmcnt(0)")
+        for x in stamped(["s_waitcnt lgkmcnt(0)"], S_ACC_ODD): e("    " + x)
         if mask:
             e(f"    s_lshl_b32 {S_TMP2}, {S_TILE}, 6")
             e(f"    s_sub_i32 {S_NKREM}, {S_NK}, {S_TMP2}")
@@ -333,8 +347,7 @@ def body(b, last, mask, tag):
         dma = None
         if sub == 0:
             # ---------------- tile barrier: own DMA pieces landed; K(tile) and V^T(tile-1) completely read
-            e("    s_waitcnt vmcnt(0) lgkmcnt(0)")
-            e("    s_barrier")
+            for x in stamped(["s_waitcnt vmcnt(0) lgkmcnt(0)", "s_barrier"], S_ACC_BAR): e("    " + x)
             if not last:
                 # K waves: tile + 2 (clamped) -> buf b ; V^T waves: tile + 1 -> buf b ^ 1 (S_LDSx: the right base per wave)
                 e(f"    s_add_u32 {S_TMP2}, {S_TILE}, {S_DDELTA}")
@@ -353,7 +366,7 @@ def body(b, last, mask, tag):
             rest += softmax_split(p)
         # exp2 of the remaining elements under the split of the ODD half's, then (sums and) the rest
         valu = interleave(ex, first) + ([] if DEFER else sm) + rest + ([] if DEFER else softmax_lsum())
-        e("    s_waitcnt lgkmcnt(0)")
+        for x in stamped(["s_waitcnt lgkmcnt(0)"], S_ACC_EVEN): e("    " + x)
         emit_half(mfma_qk() if do_qk else [], v_reads(sub, b), valu, dma=dma, valu_start=0,
                   comment=f"EVEN buf {b} sub {sub}: QK(j+1) | V frags(j) | softmax part 2")
         rescale_call(st)
@@ -373,6 +386,12 @@ e("    s_load_dwordx16 s[4:19], s[0:1], 0x0")          # 8 pointers
 e("    s_load_dwordx2 s[20:21], s[0:1], 0x40")         # ctrl
 e("    s_load_dwordx4 s[24:27], s[0:1], 0x48")         # cross, Kc, NIc, nqb
 e("    s_load_dwordx2 s[28:29], s[0:1], 0x58")         # nslab, magic = floor(2^32 / nqb) + 1 (nqb > 1)
+if STAMP:
+    e(f"    s_load_dwordx2 {S_DBG}, s[0:1], 0x60")
+    e(f"    s_memtime {S_T0}")
+    for r in (S_ACC_BAR, S_ACC_ODD, S_ACC_EVEN, S_ACC_CAL):
+        e(f"    s_mov_b32 s{r}, 0")
+        e(f"    s_mov_b32 s{r + 1}, 0")
 T = V_TMP
 e(f"    v_mov_b32_e32 {v(T)}, v0")                      # workitem id before v0 becomes an accumulator
 e("    s_waitcnt lgkmcnt(0)")
@@ -546,6 +565,9 @@ for x in mfma_qk():
     e("    " + x)
 
 # ---------------------------------------------------------------- main loop
+if STAMP:
+    for x in stamped(["s_waitcnt lgkmcnt(0)"], S_ACC_CAL):       # what an empty stamp pair costs
+        e("    " + x)
 e(".Lloop:")
 e(f"    s_cmp_ge_u32 {S_TILE}, {S_TLAST}")
 e("    s_cbranch_scc1 .Llast_b0")
@@ -568,6 +590,29 @@ for b in range(2):
 
 # ---------------------------------------------------------------- the last P.V, normalise, split, store
 e(".Lfin:")
+if STAMP:
+    T_ = V_TMP
+    e(f"    s_memtime s[{S_TB}:{S_TB + 1}]")
+    e("    s_waitcnt lgkmcnt(0)")
+    e(f"    s_sub_u32 s{S_TB}, s{S_TB}, s88")
+    e(f"    s_mul_i32 {S_TMP}, s3, {S_NQB}")
+    e(f"    s_add_u32 {S_TMP}, {S_TMP}, s2")
+    e(f"    s_lshl_b32 {S_TMP}, {S_TMP}, 2")
+    e(f"    s_add_u32 {S_TMP}, {S_TMP}, {S_WAVE}")
+    e(f"    s_lshl_b32 {S_TMP}, {S_TMP}, 5")                     # 32 bytes per wave
+    e(f"    v_mov_b32_e32 {v(T_ + 10)}, {S_TMP}")
+    for i, r in enumerate((S_TB, S_ACC_BAR, S_ACC_ODD, S_ACC_EVEN)):
+        e(f"    v_mov_b32_e32 {v(T_ + 1 + i)}, s{r}")
+    e(f"    v_mov_b32_e32 {v(T_ + 5)}, s{S_ACC_CAL}")
+    e(f"    v_mov_b32_e32 {v(T_ + 6)}, {S_T}")
+    e(f"    v_mov_b32_e32 {v(T_ + 7)}, 0")
+    e(f"    v_mov_b32_e32 {v(T_ + 8)}, 0")
+    e("    s_mov_b64 s[90:91], exec")
+    e("    s_mov_b64 exec, 1")
+    e("    s_nop 1")
+    e(f"    global_store_dwordx4 {v(T_ + 10)}, {v(T_ + 1, 4)}, {S_DBG}")
+    e(f"    global_store_dwordx4 {v(T_ + 10)}, {v(T_ + 5, 4)}, {S_DBG} offset:16")
+    e("    s_mov_b64 exec, s[90:91]")
 e("    s_waitcnt lgkmcnt(0)")
 for x in mfma_pv():
     e("    " + x)

@@ -16,9 +16,10 @@ extern "C" const unsigned char sslam_lg_attention_asm_hsaco[1] = {0};      // (t
 // the hand-scheduled kernel (opencv-simpleslam_amd/csrc/gen_lg_attention_asm.py): loaded from the code object named by ATTN_HSACO
 struct AsmArgs {
     const void *q_hi, *q_lo, *k_hi, *k_lo, *vt_hi, *vt_lo; void *msg_hi, *msg_lo; const void* ctrl;
-    int cross, Kc, NIc, nqb, nslab; unsigned magic; int pad0, pad1;
+    int cross, Kc, NIc, nqb, nslab; unsigned magic; unsigned* dbg;      // dbg: the stamp buffer of a diagnostic build
 };
 static hipFunction_t asm_fn;
+static unsigned* g_dbg = nullptr;
 static bool asm_load() {
     const char* path = getenv("ATTN_HSACO");
     if (!path) return false;
@@ -28,7 +29,7 @@ static bool asm_load() {
 }
 static void asm_launch(const AttnArgsH& a, int NI) {
     AsmArgs k{a.Q.hi, a.Q.lo, a.K.hi, a.K.lo, a.VT.hi, a.VT.lo, a.msg.hi, a.msg.lo, a.ctrl, a.cross, a.Kc, a.NIc,
-              sslam::cdiv(a.Kc, AQ), NI * NH, 0, 0, 0};
+              sslam::cdiv(a.Kc, AQ), NI * NH, 0, g_dbg};
     k.magic = k.nqb > 1 ? (unsigned)((1ull << 32) / (unsigned)k.nqb + 1) : 0;
     size_t sz = sizeof(k);
     void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
@@ -108,6 +109,24 @@ int main(int argc, char** argv) {
                     if (e == e) worst = fmax(worst, e);
                 }
         printf("compare: %zu of %zu values differ, worst |diff| %.3g\n", bad, plane, worst);
+        return 0;
+    }
+    if (as && getenv("ATTN_STAMP")) {
+        // diagnostic code object (ATTN_ASM_STAMP=1): per-wave cycle counters {lifetime, barrier wait, ODD wait, EVEN wait, pair cost, tiles}
+        const int nw = sslam::cdiv(Kc, AQ) * NI * NH * 4;
+        hipMalloc(&g_dbg, (size_t)nw * 32); hipMemset(g_dbg, 0, (size_t)nw * 32);
+        for (int i = 0; i < 3; ++i) asm_launch(a, NI);
+        hipDeviceSynchronize();
+        std::vector<unsigned> hdbg((size_t)nw * 8);
+        hipMemcpy(hdbg.data(), g_dbg, hdbg.size() * 4, hipMemcpyDeviceToHost);
+        double s[6] = {0, 0, 0, 0, 0, 0}; int live = 0;
+        for (int w = 0; w < nw; ++w) if (hdbg[8 * w]) { ++live; for (int k = 0; k < 6; ++k) s[k] += hdbg[8 * w + k]; }
+        for (double& x : s) x /= live;
+        const double stamps = 4 * s[5];          // stamp pairs per kind: barrier 1 per tile, ODD 2, EVEN 2
+        printf("stamps over %d waves: lifetime %.0f cycles, %.0f tiles; per tile: barrier wait %.0f, fragment wait ODD %.0f EVEN %.0f (two each), "
+               "empty stamp pair %.0f -> net per tile: barrier %.0f, ODD %.0f, EVEN %.0f of %.0f cycles\n", live, s[0], s[5], s[1] / s[5], s[2] / s[5],
+               s[3] / s[5], s[4], s[1] / s[5] - s[4], s[2] / s[5] - 2 * s[4], s[3] / s[5] - 2 * s[4], s[0] / s[5]);
+        (void)stamps;
         return 0;
     }
     auto launch = [&] {
