@@ -185,8 +185,8 @@ def lightglue_forward(sd, kpts0, desc0, kpts1, desc1, conf=None, return_debug=Fa
     sd = {k: torch.as_tensor(v, dtype=torch.float32) for k, v in sd.items()}
     kpts0 = torch.as_tensor(kpts0, dtype=torch.float32)[None]
     kpts1 = torch.as_tensor(kpts1, dtype=torch.float32)[None]
-    x0 = torch.as_tensor(desc0, dtype=torch.float32)[None].contiguous()
-    x1 = torch.as_tensor(desc1, dtype=torch.float32)[None].contiguous()
+    x0 = torch.tensor(np.asarray(desc0), dtype=torch.float32)[None].contiguous()      # (a copy: the drop-in hands out read-only descriptor arrays)
+    x1 = torch.tensor(np.asarray(desc1), dtype=torch.float32)[None].contiguous()
     m, n = kpts0.shape[1], kpts1.shape[1]
     L, H = c["n_layers"], c["num_heads"]
     dbg = {}
