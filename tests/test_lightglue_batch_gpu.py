@@ -175,3 +175,32 @@ def test_batch_argument_errors(gpu_ctx, native):
     with pytest.raises(native.NativeError, match="max_pairs"):
         LG(W.random_lightglue_state_dict(0), max_kpts=128, max_pairs=17, ctx=gpu_ctx)
     dev.free(); lg.close()
+
+
+@pytest.mark.parametrize("max_kpts,sizes", [(128, [(128, 97), (64, 128), (5, 31)]), (256, [(256, 130), (129, 256)]),
+                                            (384, [(384, 384), (300, 77), (1, 384), (260, 259)])])
+def test_assembly_attention_at_small_capacities(gpu_ctx, max_kpts, sizes):
+    """The hand-scheduled attention kernel (csrc/gen_lg_attention_asm.py) at the capacities the other tests do not
+    reach: one, two and three query blocks per (image, head) (the single-block case skips the magic-number division
+    of the XCD remap), one-tile and ragged key counts, 1 / 5 keypoints (workgroups beyond n exit, whole waves without
+    a valid query), forced on at any batch size (debug_key_split(-3)).  Bit-identical to the r02 4-wave kernel
+    (-1), index-identical to the oracle."""
+    W, LG = load_pkg("weights"), load_pkg("lightglue").LightGlueHIP
+    sd = W.random_lightglue_state_dict(3, match_gain=4.0, match_bias=3.0)
+    pairs = [lg_inputs.make_pair(m, n, seed=7 * m + n) for m, n in sizes]
+    batch = LG(sd, max_kpts=max_kpts, max_pairs=len(pairs), ctx=gpu_ctx)
+    dev = DevBatch(gpu_ctx, pairs, max_kpts)
+    batch.debug_key_split(-1)
+    ref = dev.run(batch, 0.5)
+    batch.debug_key_split(-3)
+    got = dev.run(batch, 0.5)
+    for pr, (ij, sc, info), (r_ij, r_sc, r_info) in zip(pairs, got, ref):
+        np.testing.assert_array_equal(ij, r_ij)
+        np.testing.assert_array_equal(sc, r_sc)
+        np.testing.assert_array_equal(info, r_info)
+        o_ij, o_sc, o_stop = _oracle(sd, pr, 0.5)
+        np.testing.assert_array_equal(ij, o_ij)
+        np.testing.assert_allclose(sc, o_sc, atol=1e-3, rtol=1e-3)
+    assert sum(len(g[0]) for g in got) > 20
+    assert not batch.range_overflow()
+    dev.free(); batch.close()
