@@ -415,7 +415,8 @@ def main():
     # extractor / matcher instances, one HIP stream (context) each.  The matcher runs BATCHES of
     # pairs, every launch over the whole batch: two matcher streams overlap the under-filled tail
     # of one batch with the head of the next; the extractors' short kernels fill in beside them.
-    N_EXT = int(os.environ.get("SSLAM_BENCH_NE", 2))
+    # r03: with the batched ALIKED entry ONE extractor stream is best (2 / 3 streams: 948 / 870 frames/s against 970)
+    N_EXT = int(os.environ.get("SSLAM_BENCH_NE", 1))
     N_MAT = int(os.environ.get("SSLAM_BENCH_NM", 2))
     ctx_e = [nat.Context(device_index) for _ in range(N_EXT)]
     ctx_m = [nat.Context(device_index) for _ in range(N_MAT)]
