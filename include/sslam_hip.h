@@ -294,6 +294,9 @@ int sslam_lightglue_profile_read(sslam_lightglue* lg, float* total_ms_out, int32
  * batch size (the three no-split kernels give bit-identical context planes). */
 int sslam_lightglue_debug_layers(sslam_lightglue* lg, int layers, int self_only);
 int sslam_lightglue_debug_key_split(sslam_lightglue* lg, int ks);
+/* Linear-kernel form: -1 by token count (default), 0 = 64-row ring kernels, 1 = batched form (128 x 128 projections +
+ * the fused FFN kernel, its tile size by token count), 2 / 3 = batched form with 64- / 32-token FFN tiles forced
+ * (a token's FFN arithmetic is the same in both: bit-identical). */
 int sslam_lightglue_debug_big_gemm(sslam_lightglue* lg, int mode);
 int sslam_lightglue_debug_read(sslam_lightglue* lg, int which, void* dst, size_t bytes);
 

@@ -119,11 +119,16 @@ __device__ __forceinline__ float ffn_erf(float x) {        // Abramowitz & Stegu
     return copysignf(fmaf(-p * t, e, 1.0f), x);
 }
 
-// One 64-token tile.  grow0: plane row of token 0; grow_cap: one past the last plane row that may be read
-// (rows are clamped to it); n_valid: tokens of the tile that exist (stores are masked to them).
-// 512 threads; `smem` = FFN_LDS_BYTES of dynamic LDS, 16-byte aligned.
+// One tile of 32 TT tokens (TT = 2: the 64-token tile described above; TT = 1: 32 tokens, for token sets too small
+// to give every CU a 64-token tile - one pair, pruned sets: half the MFMA / LayerNorm / GELU work per workgroup and
+// twice the workgroups.  The LDS images keep their 64-token strides, the second token tile simply does not exist; a
+// token's arithmetic is the same in both forms, bit for bit).  grow0: plane row of token 0; grow_cap: one past the
+// last plane row that may be read (rows are clamped to it); n_valid: tokens of the tile that exist (stores are masked
+// to them).  512 threads; `smem` = FFN_LDS_BYTES of dynamic LDS, 16-byte aligned.
+template <int TT = 2>
 __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0, int grow_cap, int n_valid,
                                                int* range_flag, _Float16* smem) {
+    static_assert(TT == 1 || TT == 2, "one or two 32-token tiles per workgroup");
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int h = lane >> 5, lr = lane & 31;
@@ -173,11 +178,13 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
         const unsigned a_bytes = (unsigned)p.plane_rows * FFN_D * 2;
         const auto r_ax = ffn_rsrc(lo ? p.xs.lo : p.xs.hi, a_bytes), r_am = ffn_rsrc(lo ? p.msgs.lo : p.msgs.hi, a_bytes);
         const int pstride = p.plane_rows * (PANEL_K * 2);           // bytes per k-panel of a plane
+        if (TT == 2 || (wave & 3) < 2) {               // (TT = 1: rows 32 .. 63 of the image are never read)
 #pragma unroll
-        for (int kp = 0; kp < 16; ++kp) {
-            _Float16* dst = smem + ((kp * 2 + (lo ? 1 : 0)) * 64 + (wave & 3) * 16) * 32;
-            if (kp < 8) ffn_dma16(r_ax, aoff, kp * pstride, dst);
-            else ffn_dma16(r_am, aoff, (kp - 8) * pstride, dst);
+            for (int kp = 0; kp < 16; ++kp) {
+                _Float16* dst = smem + ((kp * 2 + (lo ? 1 : 0)) * 64 + (wave & 3) * 16) * 32;
+                if (kp < 8) ffn_dma16(r_ax, aoff, kp * pstride, dst);
+                else ffn_dma16(r_am, aoff, (kp - 8) * pstride, dst);
+            }
         }
     }
     // the x half of the operand tile (k-panels 0-7: this wave's first 8 pieces) and the W1 prefetch have landed;
@@ -187,29 +194,29 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
     FFN_STAMP_AT(1);
 
     // ------------------------------------------------------------------ phase 1: h^T = W1 . a^T
-    f32x16 c1[2][2], c2[2][2];                     // [j tile][token tile]
+    f32x16 c1[2][TT], c2[2][TT];                   // [j tile][token tile]
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { c1[i][j][r] = 0.0f; c2[i][j][r] = 0.0f; }
     const int fsw = (lr >> 2) & 3;
     // B fragments of step ks: token tile tt, planes hi / lo; image [k-panel][plane][tok][32 halves], chunk swizzled
-    auto read_a = [&](int ks, half8 (&ah)[2], half8 (&al)[2]) {
+    auto read_a = [&](int ks, half8 (&ah)[TT], half8 (&al)[TT]) {
         const int kp = ks >> 1, s = ks & 1;
         const _Float16* base = smem + (kp * 2 * 64 + lr) * 32 + (((2 * s + h) ^ fsw) * 8);
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
+        for (int tt = 0; tt < TT; ++tt) {
             ah[tt] = *reinterpret_cast<const half8*>(base + tt * 32 * 32);
             al[tt] = *reinterpret_cast<const half8*>(base + 64 * 32 + tt * 32 * 32);
         }
     };
-    auto mma1 = [&](const half8 (&w)[4], const half8 (&ah)[2], const half8 (&al)[2]) {
+    auto mma1 = [&](const half8 (&w)[4], const half8 (&ah)[TT], const half8 (&al)[TT]) {
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
+            for (int tt = 0; tt < TT; ++tt) {
 #if FFN_ABL & 1
                 c1[jt][tt][0] += (float)w[jt][0] + (float)ah[tt][1];
                 c2[jt][tt][0] += (float)w[2 + jt][0] + (float)al[tt][1];
@@ -221,7 +228,7 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
             }
     };
     {
-        half8 ah0[2], al0[2], ah1[2], al1[2];
+        half8 ah0[TT], al0[TT], ah1[TT], al1[TT];
         read_a(0, ah0, al0);
         static_assert(32 % FFN_D1 == 0 && FFN_D1 % 2 == 0, "the ring of W1 fragment sets divides the 32 steps, even depth");
         for (int ks0 = 0; ks0 < 32; ks0 += FFN_D1) {
@@ -257,9 +264,9 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
 
     // ------------------------------------------------------------------ LayerNorm + GELU + split, in registers
     // v[jt][tt][r] = h[j = 64 w + 32 jt + (r & 3) + 8 (r >> 2) + 4 h][tok = 32 tt + lr]
-    float v[2][2][16];
+    float v[2][TT][16];
     {
-        float s[2] = {0.0f, 0.0f};
+        float s[TT] = {};
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
@@ -267,7 +274,7 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
                 const float4 b = *reinterpret_cast<const float4*>(cst + 64 * wave + 32 * jt + 8 * g + 4 * h);
                 const float bb[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
+                for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int r = 4 * g + e;
@@ -276,36 +283,36 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
                     }
             }
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
+        for (int tt = 0; tt < TT; ++tt) {
             s[tt] += __shfl_xor(s[tt], 32);
             if (h == 0) red[wave * FFN_TOK + 32 * tt + lr] = s[tt];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();              // (also: every wave is done with the operand tile)
-        float mean[2], rstd[2];
+        float mean[TT], rstd[TT];
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
+        for (int tt = 0; tt < TT; ++tt) {
             const float* q = red + 32 * tt + lr;
             mean[tt] = (((q[0] + q[FFN_TOK]) + (q[2 * FFN_TOK] + q[3 * FFN_TOK])) +
                         ((q[4 * FFN_TOK] + q[5 * FFN_TOK]) + (q[6 * FFN_TOK] + q[7 * FFN_TOK]))) / 512.0f;
         }
-        float qs[2] = {0.0f, 0.0f};
+        float qs[TT] = {};
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
+            for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { v[jt][tt][r] -= mean[tt]; qs[tt] += v[jt][tt][r] * v[jt][tt][r]; }
         float* red2 = red + 8 * FFN_TOK;
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
+        for (int tt = 0; tt < TT; ++tt) {
             qs[tt] += __shfl_xor(qs[tt], 32);
             if (h == 0) red2[wave * FFN_TOK + 32 * tt + lr] = qs[tt];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
+        for (int tt = 0; tt < TT; ++tt) {
             const float* q = red2 + 32 * tt + lr;
             const float var = (((q[0] + q[FFN_TOK]) + (q[2 * FFN_TOK] + q[3 * FFN_TOK])) +
                                ((q[4 * FFN_TOK] + q[5 * FFN_TOK]) + (q[6 * FFN_TOK] + q[7 * FFN_TOK]))) / 512.0f;
@@ -314,7 +321,7 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
+            for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[jt][tt][r] *= rstd[tt];
     }
@@ -332,7 +339,7 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
             const float btt[8] = {bt0.x, bt0.y, bt0.z, bt0.w, bt1.x, bt1.y, bt1.z, bt1.w};
             const int ks = 2 * (2 * wave + jt) + s;
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
+            for (int tt = 0; tt < TT; ++tt) {
                 float ge[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -355,22 +362,22 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
     FFN_STAMP_AT(3);
 
     // ------------------------------------------------------------------ phase 2: y^T = W2 . g^T, wave w = columns [32 w, +32)
-    f32x16 d1[2], d2[2];                           // [token tile]
+    f32x16 d1[TT], d2[TT];                         // [token tile]
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { d1[i][r] = 0.0f; d2[i][r] = 0.0f; }
-    auto read_g = [&](int ks, half8 (&gh)[2], half8 (&gl)[2]) {
+    auto read_g = [&](int ks, half8 (&gh)[TT], half8 (&gl)[TT]) {
         const _Float16* base = smem + (ks * 2 * 64 + lane) * 8;
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
+        for (int tt = 0; tt < TT; ++tt) {
             gh[tt] = *reinterpret_cast<const half8*>(base + tt * 64 * 8);
             gl[tt] = *reinterpret_cast<const half8*>(base + 32 * 2 * 64 * 8 + tt * 64 * 8);
         }
     };
-    auto mma2 = [&](const half8 (&w)[2], const half8 (&gh)[2], const half8 (&gl)[2]) {
+    auto mma2 = [&](const half8 (&w)[2], const half8 (&gh)[TT], const half8 (&gl)[TT]) {
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
+        for (int tt = 0; tt < TT; ++tt) {
 #if FFN_ABL & 1
             d1[tt][0] += (float)w[0][0] + (float)gh[tt][1];
             d2[tt][0] += (float)w[1][0] + (float)gl[tt][1];
@@ -382,7 +389,7 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
         }
     };
     {
-        half8 gh0[2], gl0[2], gh1[2], gl1[2];
+        half8 gh0[TT], gl0[TT], gh1[TT], gl1[TT];
         read_g(0, gh0, gl0);
         static_assert(32 % FFN_D2 == 0 && FFN_D2 % 2 == 0, "the ring of W2 fragment sets divides the 32 steps, even depth");
         for (int ks0 = 0; ks0 < 32; ks0 += FFN_D2) {
@@ -405,7 +412,7 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
 
     // ------------------------------------------------------------------ epilogue
     // residual of this thread's units first (its latency hides under the staging)
-    constexpr int UNITS = FFN_TOK * (FFN_D / 8) / 512;       // 4 units of 8 columns per thread
+    constexpr int UNITS = 32 * TT * (FFN_D / 8) / 512;       // 4 (2) units of 8 columns per thread
     float4 xa[UNITS], xb[UNITS];
 #pragma unroll
     for (int it = 0; it < UNITS; ++it) {
@@ -417,7 +424,7 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
     __builtin_amdgcn_s_barrier();                  // every wave is done reading the hidden fragments
     float* const ybuf = reinterpret_cast<float*>(smem_b);
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
+    for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float4 o;

@@ -1265,19 +1265,22 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void lg_linear_big_kernel(LinearAr
     linear_h_epilogue<BM, BN, TM, TN, WN, NW * 64, EPI>(p, rd, col0, ibase, c1, c2, lg_ring);
 }
 
-// ---- the whole FFN of a block as one kernel (ffn_fused.hpp): batched token sets.  One workgroup = 64 tokens.
+// ---- the whole FFN of a block as one kernel (ffn_fused.hpp): batched token sets.  One workgroup = 32 TT tokens:
+// 64 when the token set gives every CU a tile, 32 below that (one pair: 64 -> 128 workgroups of half the work).
 struct FfnKArgs { sslam::FfnFusedArgs f; const LGCtrl* ctrl; int Kc; };
 
+template <int TT>
 __global__ __launch_bounds__(512, 2) void lg_ffn_fused_kernel(FfnKArgs p) {
     extern __shared__ __attribute__((aligned(16))) _Float16 lg_ring[];
-    const int nb = p.Kc / sslam::FFN_TOK;                      // Kc is a multiple of 128
-    const int img = blockIdx.x / nb, row0 = (blockIdx.x % nb) * sslam::FFN_TOK;
+    constexpr int TOK = 32 * TT;
+    const int nb = p.Kc / TOK;                                 // Kc is a multiple of 128
+    const int img = blockIdx.x / nb, row0 = (blockIdx.x % nb) * TOK;
     const LGCtrl& pc = ctrl_of(p.ctrl, img);
     if (pc.stop) return;
     const int n = pc.n[img & 1];
     if (row0 >= n) return;
     const int ibase = img * p.Kc;
-    sslam::ffn_fused_tile(p.f, ibase + row0, ibase + p.Kc, min(sslam::FFN_TOK, n - row0), range_flag_of(p.ctrl, img), lg_ring);
+    sslam::ffn_fused_tile<TT>(p.f, ibase + row0, ibase + p.Kc, min(TOK, n - row0), range_flag_of(p.ctrl, img), lg_ring);
 }
 
 // W1 [512][512] / W2 [256][512] (row-major fp32) -> split planes in the fragment order the fused FFN streams
@@ -2022,7 +2025,8 @@ struct sslam_lightglue {
     int dbg_self_only = 0;           // test hook: stop after the self block of the last executed layer
     int force_ks = 0;                // test hook: key split of the attention launches (0 = by batch size)
     hipError_t launch_error = hipSuccess;   // first failure of a module-API launch (checked with hipGetLastError at the end of an enqueue)
-    int big_gemm = -1;               // test hook: -1 by batch size, 0 / 1 force the single-pair (ring) / batched form of the linears
+    int big_gemm = -1;               // test hook: -1 by batch size, 0 / 1 force the single-pair (ring) / batched form of the linears;
+                                     // 2 / 3: batched form with 64- / 32-token FFN tiles whatever the size
     _Float16 *w_hi, *w_lo;           // whole weight blob, split
     _Float16 *ffn_w1f[NL][2], *ffn_w2f[NL][2];   // fused-FFN fragment-order weights, [layer][self / cross]
     _Float16 *xs_hi, *xs_lo, *msgs_hi, *msgs_lo, *hids_hi, *hids_lo;
@@ -2270,7 +2274,11 @@ void lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, in
             k.f.w2f = g->ffn_w2f[layer][cross]; k.f.b2 = b2;
             k.f.x = g->x; k.f.xo_hi = g->xs_hi; k.f.xo_lo = g->xs_lo; k.f.stamps = nullptr;
             k.ctrl = g->ctrl; k.Kc = g->Kc;
-            hipLaunchKernelGGL(lg_ffn_fused_kernel, dim3(NI * (g->Kc / sslam::FFN_TOK)), dim3(512), sslam::FFN_LDS_BYTES, s, k);
+            const bool small_tiles = g->big_gemm == 3 || (g->big_gemm != 2 && NI * (g->Kc / 64) <= 128);
+            if (small_tiles)                       // too few 64-token tiles for the chip: 32-token tiles (same results)
+                hipLaunchKernelGGL(lg_ffn_fused_kernel<1>, dim3(NI * (g->Kc / 32)), dim3(512), sslam::FFN_LDS_BYTES, s, k);
+            else
+                hipLaunchKernelGGL(lg_ffn_fused_kernel<2>, dim3(NI * (g->Kc / 64)), dim3(512), sslam::FFN_LDS_BYTES, s, k);
             return;
         }
         LinearArgsH a = linh(g, xs, msgs, D, D, 2 * D, w1, b1, 2 * D);      // [x | attention context]
@@ -2420,7 +2428,8 @@ void lg_configure_kernels() {
     launch_linear_h<64, 128, 1, 2, EPH_F32>(s, 0, cfg);   launch_linear_h<64, 64, 1, 1, EPH_RESID>(s, 0, cfg);
     launch_linear_h<64, 192, 1, 3, EPH_QKV>(s, 0, cfg);   launch_linear_h<64, 128, 1, 2, EPH_CROSS>(s, 0, cfg);
     launch_linear_big<128, 128, 2, 2, EPH_QKV>(s, 0, cfg); launch_linear_big<128, 128, 2, 2, EPH_CROSS>(s, 0, cfg);
-    (void)hipFuncSetAttribute((const void*)lg_ffn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, sslam::FFN_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)lg_ffn_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, sslam::FFN_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)lg_ffn_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, sslam::FFN_LDS_BYTES);
 }
 
 // lg_enqueue through the graph cache (device entry points only; never while profiling: the
@@ -2747,7 +2756,7 @@ int sslam_lightglue_debug_key_split(sslam_lightglue* g, int ks) {
 /* Test hook: -1 = linears chosen by batch size, 0 = always the 64-row ring kernels (single-pair form), 1 = always
  * the batched form (128 x 128 projections + the fused FFN kernel). */
 int sslam_lightglue_debug_big_gemm(sslam_lightglue* g, int mode) {
-    SSLAM_REQUIRE(g != nullptr && mode >= -1 && mode <= 1, "sslam_lightglue_debug_big_gemm: bad argument");
+    SSLAM_REQUIRE(g != nullptr && mode >= -1 && mode <= 3, "sslam_lightglue_debug_big_gemm: bad argument");
     g->settings_changed();
     g->big_gemm = mode;
     return 0;

@@ -11,6 +11,8 @@ import frames
 fu = importlib.import_module("opencv-simpleslam_amd.slam.core.features_utils")
 args = SimpleNamespace(use_lightglue=True, max_features=2048, min_conf=0.7, detector="aliked", matcher="lightglue")
 det, mat = fu.init_feature_pipeline(args)
+if os.environ.get("SSLAM_DROPIN_MATCHER_GRAPHS"):          # A/B: replay the matcher's launch sequence as a graph (4 slot pairs cycle)
+    mat.use_graphs(bool(int(os.environ["SSLAM_DROPIN_MATCHER_GRAPHS"])))
 imgs = [frames.structured_frame(i) for i in range(12)]
 kp_prev, des_prev = fu.feature_extractor(args, imgs[0], det)
 te, tm, tr = [], [], []

@@ -202,5 +202,15 @@ def test_assembly_attention_at_small_capacities(gpu_ctx, max_kpts, sizes):
         np.testing.assert_array_equal(ij, o_ij)
         np.testing.assert_allclose(sc, o_sc, atol=1e-3, rtol=1e-3)
     assert sum(len(g[0]) for g in got) > 20
+    # the fused FFN in 64-token and in 32-token tiles (the form small token sets take): a token's arithmetic is the
+    # same in both - bit-identical results
+    for mode in (2, 3):
+        batch.debug_big_gemm(mode)
+        for (ij, sc, info), (t_ij, t_sc, t_info) in zip(got if mode == 3 else dev.run(batch, 0.5), dev.run(batch, 0.5)):
+            np.testing.assert_array_equal(ij, t_ij)
+            np.testing.assert_array_equal(sc, t_sc)
+            np.testing.assert_array_equal(info, t_info)
+        if mode == 2:
+            got = dev.run(batch, 0.5)
     assert not batch.range_overflow()
     dev.free(); batch.close()
