@@ -47,7 +47,7 @@ feats = [det0.extract(im, K) for im in imgs]
 ref = [None] + [mat0.match(feats[i - 1][0], feats[i - 1][1], feats[i][0], feats[i][1], min_conf=0.0)
                 for i in range(1, n_frames)]
 plan = fs.ShardPlan(world, rank, B)
-dets = [AL(sd_a, max_num_keypoints=K, max_h=H, max_w=Wd, ctx=nat.Context(dev)) for _ in range(2)]
+dets = [AL(sd_a, max_num_keypoints=K, max_h=H, max_w=Wd, ctx=nat.Context(dev), max_frames=2) for _ in range(2)]   # chunks of 2 frames per extractor call (ragged last chunk)
 mats = [LG(sd_l, max_kpts=K, ctx=nat.Context(dev), max_pairs=2, filter_threshold=0.0) for _ in range(2)]
 pipe = fs.FrameStreamPipeline(dets, mats, plan, K, 0.0, batch_pairs=2)
 ctx = pipe.ctx
