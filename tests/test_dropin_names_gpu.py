@@ -87,7 +87,7 @@ def test_extractor_and_matcher_conventions(fu, pipeline):
 
     # torch-tensor descriptors are accepted like numpy ones (features_utils.py:136-154)
     torch = pytest.importorskip("torch")
-    m_t = fu.feature_matcher(args, kp0, kp1, torch.from_numpy(des0), torch.from_numpy(des1), mat)
+    m_t = fu.feature_matcher(args, kp0, kp1, torch.tensor(des0), torch.tensor(des1), mat)      # (copies: the arrays are read-only)
     assert [(x.queryIdx, x.trainIdx) for x in m_t] == [(x.queryIdx, x.trainIdx) for x in m]
 
     # the keypoint list is the caller's: an in-place edit of an INTERIOR keypoint must be seen
