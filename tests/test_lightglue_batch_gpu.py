@@ -145,19 +145,30 @@ def test_batch_with_an_empty_image_early_stop_and_pruning_per_pair(gpu_ctx):
 
 
 def test_batch_at_c2_size_no_key_split(gpu_ctx):
-    """4 pairs of 2048 x 2048 keypoints (BASELINE C2 size): the attention launches run un-split
-    (one workgroup sees every key of its queries, context written straight to the split planes)."""
+    """The bench configuration itself: 8 pairs of 2048 x 2048 keypoints (BASELINE C2 size) per enqueue, replayed as a
+    cached hipGraph - the attention launches run un-split on the assembly kernel (one workgroup sees every key of its
+    queries, context written straight to the split planes), the FFN in 64-token tiles.  Plain enqueue and graph
+    replay must agree bit for bit; four of the eight pairs (one of them ragged) are held to the oracle."""
     W, LG = load_pkg("weights"), load_pkg("lightglue").LightGlueHIP
     sd = W.random_lightglue_state_dict(2, match_gain=4.0, match_bias=3.0)
-    pairs = [lg_inputs.make_pair(2048, seed=11 + i) for i in range(3)] + [lg_inputs.make_pair(2048, 1900, seed=20)]
-    batch = LG(sd, max_kpts=2048, max_pairs=4, ctx=gpu_ctx)
+    pairs = [lg_inputs.make_pair(2048, seed=11 + i) for i in range(7)] + [lg_inputs.make_pair(2048, 1900, seed=20)]
+    batch = LG(sd, max_kpts=2048, max_pairs=8, ctx=gpu_ctx)
     dev = DevBatch(gpu_ctx, pairs, 2048)
-    got = dev.run(batch, 0.7)
-    for pr, (ij, sc, info) in zip(pairs[:2] + pairs[3:], got[:2] + got[3:]):        # oracle at 2048 is slow: 3 of 4
-        o_ij, o_sc, o_stop = _oracle(sd, pr, 0.7)
+    plain = dev.run(batch, 0.7)
+    batch.use_graphs(True)
+    dev.run(batch, 0.7)                                   # capture
+    got = dev.run(batch, 0.7)                             # replay
+    for (ij, sc, info), (p_ij, p_sc, p_info) in zip(got, plain):
+        np.testing.assert_array_equal(ij, p_ij)
+        np.testing.assert_array_equal(sc, p_sc)
+        np.testing.assert_array_equal(info, p_info)
+    for k in (0, 3, 6, 7):                                # the oracle at 2048 is slow: 4 of 8
+        ij, sc, info = got[k]
+        o_ij, o_sc, o_stop = _oracle(sd, pairs[k], 0.7)
         np.testing.assert_array_equal(ij, o_ij)
         np.testing.assert_allclose(sc, o_sc, atol=1e-3, rtol=1e-3)
         assert info[1] == o_stop == 9 and len(ij) > 100
+    assert not batch.range_overflow()
     dev.free(); batch.close()
 
 
