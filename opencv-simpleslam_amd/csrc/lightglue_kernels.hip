@@ -110,6 +110,16 @@ __global__ __launch_bounds__(1024) void lg_prepare_kernel(
     if (src.cnt[img]) n = min(max(src.cnt[img][0], 0), n);
     if (src.cnt[img ^ 1]) n_other = min(max(src.cnt[img ^ 1][0], 0), n_other);
     __shared__ float red[4][32];
+    {   // descriptors into the staging rows the input projection reads (16-byte pieces): 1 MB per image at 2048
+        // keypoints - one workgroup moved it at a single CU's share of the memory system (28 of the kernel's 45 us), so the
+        // copy is striped over gridDim.y workgroups; workgroup y = 0 does the rest of the preparation
+        const float4* sd = reinterpret_cast<const float4*>(src.desc[img]);
+        float4* dd = reinterpret_cast<float4*>(in_desc + (size_t)img * Kc * DIN);
+        const int total = n * (DIN / 4), per = (total + (int)gridDim.y - 1) / (int)gridDim.y;
+        const int lo = (int)blockIdx.y * per, hi = min(total, lo + per);
+        for (int i = lo + (int)threadIdx.x; i < hi; i += blockDim.x) dd[i] = sd[i];
+    }
+    if (blockIdx.y != 0) return;
     float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
     float* dxy = in_xy + (size_t)img * Kc * 2;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -117,11 +127,6 @@ __global__ __launch_bounds__(1024) void lg_prepare_kernel(
         dxy[2 * i] = x; dxy[2 * i + 1] = y;
         mnx = fminf(mnx, x); mxx = fmaxf(mxx, x);
         mny = fminf(mny, y); mxy = fmaxf(mxy, y);
-    }
-    {   // descriptors into the staging rows the input projection reads (16-byte pieces)
-        const float4* sd = reinterpret_cast<const float4*>(src.desc[img]);
-        float4* dd = reinterpret_cast<float4*>(in_desc + (size_t)img * Kc * DIN);
-        for (int i = threadIdx.x; i < n * (DIN / 4); i += blockDim.x) dd[i] = sd[i];
     }
     for (int o = 32; o > 0; o >>= 1) {
         mnx = fminf(mnx, __shfl_xor(mnx, o)); mxx = fmaxf(mxx, __shfl_xor(mxx, o));
@@ -2318,7 +2323,7 @@ int lg_enqueue(sslam_lightglue* g, int pairs, const StageSrc& src, float min_con
                float* score_out, int32_t* info_out, long out_stride) {
     hipStream_t s = g->ctx->stream;
     const int Kc = g->Kc, NI = 2 * pairs;
-    hipLaunchKernelGGL(lg_prepare_kernel, dim3(NI), dim3(1024), 0, s, src, Kc, g->in_xy, g->in_desc, g->bbox,
+    hipLaunchKernelGGL(lg_prepare_kernel, dim3(NI, 8), dim3(1024), 0, s, src, Kc, g->in_xy, g->in_desc, g->bbox,
                        g->ind, g->prune, g->ctrl);
     hipLaunchKernelGGL(lg_posenc_kernel, dim3(sslam::cdiv(NI * Kc * ENC, 256)), dim3(256), 0, s, g->in_xy,
                        g->bbox, g->w_r, g->enc_cos, g->enc_sin, Kc, NI, g->ctrl);
