@@ -1397,17 +1397,20 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
     hipLaunchKernelGGL(al_resize_pad_kernel, dim3(sslam::cdiv(Wp, 256), Hp, uF), dim3(256), 0, s, g->fsrc, g->img, d,
                        g->gk + 32, rp.ky, rp.blur, fs);
     // block1
-    dim3 g1(sslam::cdiv(Wp, CT_W), sslam::cdiv(Hp, 16), uF);
-    hipLaunchKernelGGL((al_conv3x3_mfma_kernel<3, 16, 1, false, false, 4>), g1, dim3(256), 0, s, g->img, Hp, Wp, g->x1a, Hp,
+    // (tile height = 4 rows x RPW per workgroup, chosen per layer on the batched profile, r03: smaller tiles =
+    //  more workgroups per CU whose load / MFMA / store phases overlap: 16 -> 16 with RPW 1: 36 -> 27 us per frame,
+    //  3 -> 16 with 2: 10.9 -> 9.7, 16 -> 32 with 1: 18.3 -> 16.9; 32 -> 32 stays at 2 (1: 32.7 vs 30.9))
+    dim3 g1a(sslam::cdiv(Wp, CT_W), sslam::cdiv(Hp, 8), uF), g1b(sslam::cdiv(Wp, CT_W), sslam::cdiv(Hp, 4), uF);
+    hipLaunchKernelGGL((al_conv3x3_mfma_kernel<3, 16, 1, false, false, 2>), g1a, dim3(256), 0, s, g->img, Hp, Wp, g->x1a, Hp,
                        Wp, g->b1c1.w, g->b1c1.a, g->b1c1.b, nullptr, nullptr, nullptr, nullptr, fs);
-    hipLaunchKernelGGL((al_conv3x3_mfma_kernel<16, 16, 1, false, false, 4>), g1, dim3(256), 0, s, g->x1a, Hp, Wp, g->x1, Hp,
+    hipLaunchKernelGGL((al_conv3x3_mfma_kernel<16, 16, 1, false, false, 1>), g1b, dim3(256), 0, s, g->x1a, Hp, Wp, g->x1, Hp,
                        Wp, g->b1c2.w, g->b1c2.a, g->b1c2.b, nullptr, nullptr, nullptr, nullptr, fs);
     // block2 at 1/2: conv1 pools on load and also emits the downsample branch
     const int H2 = Hp / 2, W2 = Wp / 2;
-    dim3 g2(sslam::cdiv(W2, CT_W), sslam::cdiv(H2, 8), uF);
-    hipLaunchKernelGGL((al_conv3x3_mfma_kernel<16, 32, 2, true, false, 2>), g2, dim3(256), 0, s, g->x1, Hp, Wp, g->t2, H2, W2,
+    dim3 g2a(sslam::cdiv(W2, CT_W), sslam::cdiv(H2, 4), uF), g2b(sslam::cdiv(W2, CT_W), sslam::cdiv(H2, 8), uF);
+    hipLaunchKernelGGL((al_conv3x3_mfma_kernel<16, 32, 2, true, false, 1>), g2a, dim3(256), 0, s, g->x1, Hp, Wp, g->t2, H2, W2,
                        g->b2c1.w, g->b2c1.a, g->b2c1.b, g->b2dw, g->b2db, g->idn2, nullptr, fs);
-    hipLaunchKernelGGL((al_conv3x3_mfma_kernel<32, 32, 1, false, true, 2>), g2, dim3(256), 0, s, g->t2, H2, W2, g->x2, H2, W2,
+    hipLaunchKernelGGL((al_conv3x3_mfma_kernel<32, 32, 1, false, true, 2>), g2b, dim3(256), 0, s, g->t2, H2, W2, g->x2, H2, W2,
                        g->b2c2.w, g->b2c2.a, g->b2c2.b, nullptr, nullptr, nullptr, g->idn2, fs);
     // deformable conv = im2col of the bilinear samples + matrix-core GEMM (offsets in g->off)
     auto dcn = [&](const float* in, int cin, float* outp, int cout, int Hh, int Ww, const float* wt, const float* al_,
