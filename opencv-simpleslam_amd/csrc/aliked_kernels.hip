@@ -365,47 +365,67 @@ __global__ void al_avgpool_kernel(const float* __restrict__ in, float* __restric
 // are read from the [18][CIN*9] copy made at create time, so each of the 18 loads of an iteration
 // is 256 contiguous bytes across the wave (with the packed [k][18] layout every one of them
 // walked the same 36 cache lines again: 648 line look-ups per iteration instead of 36).
-template <int CIN>
+template <int CIN, int OC_PP>      // OC_PP: pixels per wave (4 for batches of frames, 1 when one frame has to fill the chip)
 __global__ __launch_bounds__(256) void al_offset_conv_kernel(const float* __restrict__ in, float* __restrict__ off,
                                                              int H, int W,
                                                              const float* __restrict__ wt /*[18][CIN*9]*/,
                                                              const float* __restrict__ b, float max_off, size_t fs) {
-    const int lane = threadIdx.x & 63, pix = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pix >= H * W) return;
+    // r03: a wave takes OC_PP consecutive pixels, so the 18 weight loads of an iteration serve four pixels (one
+    // wave per pixel re-read the whole [18][CIN*9] weight block for every pixel: 1.7 GB of L1 / L2 traffic per launch
+    // at F = 8).  A pixel's sums run over the same lanes and k's in the same order as before: bit-identical.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pix0 = (blockIdx.x * 4 + wave) * OC_PP;
+    if (pix0 >= H * W) return;
     in = fsh(in, blockIdx.y, fs); off = fsh(off, blockIdx.y, fs);
-    const int y = pix / W, x = pix % W;
-    float part[18];
+    float part[OC_PP][18];
 #pragma unroll
-    for (int o = 0; o < 18; ++o) part[o] = 0.0f;
-    // fully unrolled (CIN is a template parameter): all (CIN*9/64) x 19 loads are in flight at once;
+    for (int p = 0; p < OC_PP; ++p)
+#pragma unroll
+        for (int o = 0; o < 18; ++o) part[p][o] = 0.0f;
+    // fully unrolled (CIN is a template parameter): all loads of an iteration are in flight at once;
     // as a rolled loop every iteration waited out a full memory latency
 #pragma unroll
     for (int it = 0; it < (CIN * 9 + 63) / 64; ++it) {
         const int k = lane + 64 * it;
         if (CIN * 9 % 64 != 0 && k >= CIN * 9) break;
         const int ci = k / 9, tap = k % 9;
-        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-        const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? in[((size_t)ci * H + yy) * W + xx] : 0.0f;
+        float v[OC_PP];
 #pragma unroll
-        for (int o = 0; o < 18; ++o) part[o] = fmaf(v, wt[o * (CIN * 9) + k], part[o]);
+        for (int p = 0; p < OC_PP; ++p) {
+            const int pix = min(pix0 + p, H * W - 1);
+            const int y = pix / W, x = pix % W;
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            v[p] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? in[((size_t)ci * H + yy) * W + xx] : 0.0f;
+        }
+#pragma unroll
+        for (int o = 0; o < 18; ++o) {
+            const float wv = wt[o * (CIN * 9) + k];
+#pragma unroll
+            for (int p = 0; p < OC_PP; ++p) part[p][o] = fmaf(v[p], wv, part[p][o]);
+        }
     }
     // 18 sums over the 64 lanes: through LDS, lane (o, third) adds a third of row o, two shuffles
     // finish it (18 butterfly reductions = 108 cross-lane steps dominated the kernel)
     __shared__ float red[4][18][65];
-    const int wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int o = 0; o < 18; ++o) red[wave][o][lane] = part[o];
-    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's own slab
-    __builtin_amdgcn_wave_barrier();
     const int o = lane / 3, th = lane % 3;
-    float v = 0.0f;
-    if (lane < 54) {
-        const float* r = red[wave][o];
-        const int j0 = th * 22, j1 = th == 2 ? 64 : j0 + 22;
-        for (int j = j0; j < j1; ++j) v += r[j];
+#pragma unroll
+    for (int p = 0; p < OC_PP; ++p) {
+        if (p) __builtin_amdgcn_wave_barrier();      // the previous pixel's reads of the slab are done (one wave: program order)
+#pragma unroll
+        for (int q = 0; q < 18; ++q) red[wave][q][lane] = part[p][q];
+        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's own slab
+        __builtin_amdgcn_wave_barrier();
+        float v = 0.0f;
+        if (lane < 54) {
+            const float* r = red[wave][o];
+            const int j0 = th * 22, j1 = th == 2 ? 64 : j0 + 22;
+            for (int j = j0; j < j1; ++j) v += r[j];
+        }
+        v += __shfl_down(v, 1) + __shfl_down(v, 2);
+        const int pix = pix0 + p;
+        if (lane < 54 && th == 0 && pix < H * W) off[(size_t)o * H * W + pix] = fminf(fmaxf(v + b[o], -max_off), max_off);
+        __builtin_amdgcn_s_waitcnt(0xc07f);          // the reads above, before the next pixel overwrites the slab
     }
-    v += __shfl_down(v, 1) + __shfl_down(v, 2);
-    if (lane < 54 && th == 0) off[(size_t)o * H * W + pix] = fminf(fmaxf(v + b[o], -max_off), max_off);
 }
 
 // ---- deformable conv as im2col + matrix-core GEMM --------------------------------------------
@@ -1434,20 +1454,28 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
     const int H3 = Hp / 8, W3 = Wp / 8, HW3 = H3 * W3;
     hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(32 * HW3, 256), uF), dim3(256), 0, s, g->x2, g->p3, 32, H2, W2, 4, fs);
     const float mo3 = (float)(H3 > W3 ? H3 : W3) / 4.0f;
-    hipLaunchKernelGGL(al_offset_conv_kernel<32>, dim3(sslam::cdiv(HW3, 4), uF), dim3(256), 0, s, g->p3, g->off, H3,
+    if (F >= 4) hipLaunchKernelGGL((al_offset_conv_kernel<32, 4>), dim3(sslam::cdiv(HW3, 16), uF), dim3(256), 0, s, g->p3, g->off, H3,
+                       W3, g->b3c1ot, g->b3c1.ob, mo3, fs);
+    else hipLaunchKernelGGL((al_offset_conv_kernel<32, 1>), dim3(sslam::cdiv(HW3, 4), uF), dim3(256), 0, s, g->p3, g->off, H3,
                        W3, g->b3c1ot, g->b3c1.ob, mo3, fs);
     dcn(g->p3, 32, g->t3, 64, H3, W3, g->b3c1t, g->b3c1.a, g->b3c1.b, nullptr, 0, nullptr, nullptr);
-    hipLaunchKernelGGL(al_offset_conv_kernel<64>, dim3(sslam::cdiv(HW3, 4), uF), dim3(256), 0, s, g->t3, g->off, H3,
+    if (F >= 4) hipLaunchKernelGGL((al_offset_conv_kernel<64, 4>), dim3(sslam::cdiv(HW3, 16), uF), dim3(256), 0, s, g->t3, g->off, H3,
+                       W3, g->b3c2ot, g->b3c2.ob, mo3, fs);
+    else hipLaunchKernelGGL((al_offset_conv_kernel<64, 1>), dim3(sslam::cdiv(HW3, 4), uF), dim3(256), 0, s, g->t3, g->off, H3,
                        W3, g->b3c2ot, g->b3c2.ob, mo3, fs);
     dcn(g->t3, 64, g->x3, 64, H3, W3, g->b3c2t, g->b3c2.a, g->b3c2.b, g->p3, 32, g->b3dwt, g->b3db);
     // block4 at 1/32
     const int H4 = Hp / 32, W4 = Wp / 32, HW4 = H4 * W4;
     hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(64 * HW4, 256), uF), dim3(256), 0, s, g->x3, g->p4, 64, H3, W3, 4, fs);
     const float mo4 = (float)(H4 > W4 ? H4 : W4) / 4.0f;
-    hipLaunchKernelGGL(al_offset_conv_kernel<64>, dim3(sslam::cdiv(HW4, 4), uF), dim3(256), 0, s, g->p4, g->off, H4,
+    if (F >= 4) hipLaunchKernelGGL((al_offset_conv_kernel<64, 4>), dim3(sslam::cdiv(HW4, 16), uF), dim3(256), 0, s, g->p4, g->off, H4,
+                       W4, g->b4c1ot, g->b4c1.ob, mo4, fs);
+    else hipLaunchKernelGGL((al_offset_conv_kernel<64, 1>), dim3(sslam::cdiv(HW4, 4), uF), dim3(256), 0, s, g->p4, g->off, H4,
                        W4, g->b4c1ot, g->b4c1.ob, mo4, fs);
     dcn(g->p4, 64, g->t4, 128, H4, W4, g->b4c1t, g->b4c1.a, g->b4c1.b, nullptr, 0, nullptr, nullptr);
-    hipLaunchKernelGGL(al_offset_conv_kernel<128>, dim3(sslam::cdiv(HW4, 4), uF), dim3(256), 0, s, g->t4, g->off, H4,
+    if (F >= 4) hipLaunchKernelGGL((al_offset_conv_kernel<128, 4>), dim3(sslam::cdiv(HW4, 16), uF), dim3(256), 0, s, g->t4, g->off, H4,
+                       W4, g->b4c2ot, g->b4c2.ob, mo4, fs);
+    else hipLaunchKernelGGL((al_offset_conv_kernel<128, 1>), dim3(sslam::cdiv(HW4, 4), uF), dim3(256), 0, s, g->t4, g->off, H4,
                        W4, g->b4c2ot, g->b4c2.ob, mo4, fs);
     dcn(g->t4, 128, g->x4, 128, H4, W4, g->b4c2t, g->b4c2.a, g->b4c2.b, g->p4, 64, g->b4dwt, g->b4db);
     // gates
