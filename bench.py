@@ -417,7 +417,7 @@ def main():
     # of one batch with the head of the next; the extractors' short kernels fill in beside them.
     # r03: with the batched ALIKED entry ONE extractor stream is best (2 / 3 streams: 948 / 870 frames/s against 970)
     N_EXT = int(os.environ.get("SSLAM_BENCH_NE", 1))
-    N_MAT = int(os.environ.get("SSLAM_BENCH_NM", 2))
+    N_MAT = int(os.environ.get("SSLAM_BENCH_NM", 3))     # r03, beside ONE extractor stream: 2 / 3 / 4 matcher streams 967 / 979 / 954 frames/s
     ctx_e = [nat.Context(device_index) for _ in range(N_EXT)]
     ctx_m = [nat.Context(device_index) for _ in range(N_MAT)]
     sd_a, sd_l = W.random_aliked_state_dict(0), W.random_lightglue_state_dict(0)
