@@ -627,6 +627,11 @@ __device__ __forceinline__ float up_eval(const float* __restrict__ p, const UpTa
     return t.w10 * (t.w00 * p[t.o00] + t.w01 * p[t.o01]) + t.w11 * (t.w00 * p[t.o10] + t.w01 * p[t.o11]);
 }
 
+// (r03: the kernel is latency-bound - waves parked 65 % of their cycles, SQ counters - so the level loops carry four
+//  channels = 16 gathers in flight per iteration: 49 -> 40 us per frame; eight: the weights start to spill to v_readlane)
+#ifndef AL_AGG_UNROLL
+#define AL_AGG_UNROLL 4
+#endif
 __global__ __launch_bounds__(256) void al_aggregate_kernel(Pyr P0, const float* __restrict__ ws0 /*[128][8]*/,
                                                            float* __restrict__ s8, float* __restrict__ rnorm, size_t fs) {
     const Pyr P = pyr_at(P0, blockIdx.z, fs);
@@ -660,21 +665,21 @@ __global__ __launch_bounds__(256) void al_aggregate_kernel(Pyr P0, const float* 
     const UpTap t2 = up_tap(y, x, P.Hp, P.Wp, 2, P.sy2, P.sx2), t3 = up_tap(y, x, P.Hp, P.Wp, 8, P.sy8, P.sx8),
                 t4 = up_tap(y, x, P.Hp, P.Wp, 32, P.sy32, P.sx32);
     const size_t hw2 = HW / 4, hw3 = HW / 64, hw4 = HW / 1024;
-#pragma unroll 2
+#pragma unroll AL_AGG_UNROLL
     for (int c = 0; c < 32; ++c) {
         const float a = up_eval(P.g2 + c * hw2, t2);
         n2 = fmaf(a, a, n2);
 #pragma unroll
         for (int o = 0; o < 8; ++o) s[o] = fmaf(a, ws0[(32 + c) * 8 + o], s[o]);
     }
-#pragma unroll 2
+#pragma unroll AL_AGG_UNROLL
     for (int c = 0; c < 32; ++c) {
         const float a = up_eval(P.g3 + c * hw3, t3);
         n2 = fmaf(a, a, n2);
 #pragma unroll
         for (int o = 0; o < 8; ++o) s[o] = fmaf(a, ws0[(64 + c) * 8 + o], s[o]);
     }
-#pragma unroll 2
+#pragma unroll AL_AGG_UNROLL
     for (int c = 0; c < 32; ++c) {
         const float a = up_eval(P.g4 + c * hw4, t4);
         n2 = fmaf(a, a, n2);
