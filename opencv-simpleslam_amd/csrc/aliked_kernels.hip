@@ -149,6 +149,9 @@ constexpr int CT_W = 32;                // output tile width of the dense 3x3 co
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef AL_CONV_UNROLL
+#define AL_CONV_UNROLL 8
+#endif
 template <int CIN, int COUT, int POOL, bool DOWN, bool RESID, int RPW>
 __global__ __launch_bounds__(256) void al_conv3x3_mfma_kernel(
     const float* __restrict__ in, int inH, int inW, float* __restrict__ out, int H, int W,
@@ -178,7 +181,9 @@ __global__ __launch_bounds__(256) void al_conv3x3_mfma_kernel(
 #endif
     {
         constexpr int ROWS = CINP * TH;
-        // interior: 8 x 16 bytes per tile row
+        // interior: 8 x 16 bytes per tile row (unrolled: the loads of several trips in flight, then their LDS stores -
+        // rolled, every trip waited out its own load: the convs' waves were parked on memory half of their cycles)
+#pragma unroll AL_CONV_UNROLL
         for (int idx = t; idx < ROWS * 8; idx += 256) {
             const int row = idx >> 3, v4 = idx & 7;
             const int c = row / TH, rr = row % TH;
@@ -211,6 +216,7 @@ __global__ __launch_bounds__(256) void al_conv3x3_mfma_kernel(
             else { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
         }
         // halo columns x0 - 1 and x0 + 32
+#pragma unroll AL_CONV_UNROLL
         for (int idx = t; idx < ROWS * 2; idx += 256) {
             const int row = idx >> 1, side = idx & 1;
             const int c = row / TH, rr = row % TH;
@@ -227,6 +233,7 @@ __global__ __launch_bounds__(256) void al_conv3x3_mfma_kernel(
             tile[c * CHS + rr * CT_TW + (side ? IC + CT_W : IC - 1)] = v;
         }
     }
+#pragma unroll AL_CONV_UNROLL
     for (int i = t; i < K * WLD; i += 256) {          // global [ci][tap][co] -> LDS [tap][ci][co], zero padded
         const int co = i % WLD, k = i / WLD, tap = k / CINP, ci = k % CINP;
         wl[i] = ci < CIN ? w[(ci * 9 + tap) * COUT + co] : 0.0f;
