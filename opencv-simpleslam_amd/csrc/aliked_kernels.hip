@@ -72,6 +72,7 @@ __global__ void al_to_float_kernel(FrameIn srcs, float* __restrict__ dst, Dims d
     dst = fsh(dst, blockIdx.z, fs);
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= d.W) return;
+#pragma unroll
     for (int c = 0; c < 3; ++c) {
         const int sc = d.C == 1 ? 0 : 2 - c;                      // BGR -> RGB
         float v;
@@ -104,6 +105,7 @@ __global__ void al_resize_pad_kernel(const float* __restrict__ src, float* __res
     const int y0 = (int)fy, x0 = (int)fx;
     const int y1 = y0 + (y0 < d.H - 1), x1 = x0 + (x0 < d.W - 1);
     const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
+#pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float* p = src + (size_t)c * d.H * d.W;
         float v00, v01, v10, v11;
@@ -362,8 +364,18 @@ __global__ void al_avgpool_kernel(const float* __restrict__ in, float* __restric
     if (i >= C * oh * ow) return;
     const int c = i / (oh * ow), y = (i / ow) % oh, x = i % ow;
     float s = 0.0f;
-    for (int a = 0; a < P; ++a)
-        for (int b = 0; b < P; ++b) s += in[((size_t)c * H + y * P + a) * W + x * P + b];
+    if (P == 4) {                      // (both call sites: all 16 loads in flight; same summation order)
+        float v[16];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) v[4 * a + b] = in[((size_t)c * H + y * 4 + a) * W + x * 4 + b];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += v[k];
+    } else {
+        for (int a = 0; a < P; ++a)
+            for (int b = 0; b < P; ++b) s += in[((size_t)c * H + y * P + a) * W + x * P + b];
+    }
     out[i] = s / (float)(P * P);
 }
 
@@ -525,6 +537,7 @@ __global__ __launch_bounds__(256) void al_dcn_epilogue_kernel(const float* __res
     part = fsh(part, blockIdx.y, fs); out = fsh(out, blockIdx.y, fs);
     const int co = i / HW;
     float acc = part[i];
+#pragma unroll 6
     for (int z = 1; z < KS; ++z) acc += part[(size_t)z * COUT * HW + i];
     float v = fmaf(acc, alpha[co], beta[co]);
     if (resid) v += part[(size_t)KS * COUT * HW + i] + bd[co];
@@ -1189,8 +1202,10 @@ __global__ void al_offsets_kernel(const float* __restrict__ h32 /*[KSPLIT][cap][
     const int n = i / 32, o = i % 32;
     if (n >= ctrl->n_kp) return;
     float acc = 0.0f;
+#pragma unroll 8
     for (int k = 0; k < 32; ++k) {
         float hv = b1[k];
+#pragma unroll
         for (int z = 0; z < SDDH_KSPLIT; ++z) hv += h32[((size_t)z * cap + n) * 32 + k];
         acc = fmaf(selu(hv), w2[o * 32 + k], acc);
     }
