@@ -368,7 +368,7 @@ def _self_launch(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=120)         # x 24 frames: a timed region of ~3 s
+    ap.add_argument("--steps", type=int, default=140)         # x 24 frames: a timed region of ~3 s
     ap.add_argument("--warmup", type=int, default=8)          # a multiple of the 4-round input pool x 2 record sets: every graph key is captured
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the exact-f32 / BA / reproject legs")
