@@ -838,6 +838,7 @@ __global__ __launch_bounds__(256) void lg_row_argmax_kernel(
     if (row >= n0) return;
     const float rm = rmax[row], rl = rlog[row], a = z[row];          // z: log sigmoid(matchability), per token
     float bv = -INFINITY; int bj = 0x7fffffff;
+#pragma unroll 8                                 // 32 loads in flight (rolled, the wave sat in s_waitcnt 82 % of its cycles)
     for (int j = lane; j < n1; j += 64) {
         const float v = score_ij(sim[(size_t)row * Kc + j], rm, rl, cmax[j], clog[j], a, z[Kc + j]);
         if (v > bv) { bv = v; bj = j; }          // ascending j per lane: first maximum kept
@@ -869,6 +870,7 @@ __global__ __launch_bounds__(256) void lg_col_argmax_kernel(
     float bv = -INFINITY; int bi = 0x7fffffff;
     if (col < n1) {
         const float cm = cmax[col], cl = clog[col], b = z[Kc + col];
+#pragma unroll 8
         for (int i = r0 + part; i < r1; i += 4) {
             const float v = score_ij(sim[(size_t)i * Kc + col], rmax[i], rlog[i], cm, cl, z[i], b);
             if (v > bv) { bv = v; bi = i; }
