@@ -1165,15 +1165,17 @@ __global__ void al_refine_kernel(const float* __restrict__ score, int h, int w, 
 //  7. SDDH descriptor head
 // ------------------------------------------------------------------------ //
 // 3x3 patch of the normalised feature map around each keypoint -> patch[n][c*9 + tap]
-// (get_patches corner rule); one wave per (keypoint, tap)
+// (get_patches corner rule); one wave per (keypoint, patch row)
 __global__ __launch_bounds__(256) void al_patch_kernel(Pyr P0, const float* __restrict__ rnorm, int pl, int pt,
                                                        int h, int w, const float* __restrict__ kp_norm,
                                                        float* __restrict__ patch, const ALCtrl* __restrict__ ctrl, size_t fs) {
     const Pyr P = pyr_at(P0, blockIdx.y, fs);
     rnorm = fsh(rnorm, blockIdx.y, fs); kp_norm = fsh(kp_norm, blockIdx.y, fs); patch = fsh(patch, blockIdx.y, fs);
     ctrl = fsh(ctrl, blockIdx.y, fs);
+    // one wave per (keypoint, patch row): its three taps' 42 gathers are in flight together (one wave per tap was pure
+    // latency: three quarters of the wave cycles parked in s_waitcnt)
     const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int n = gw / 9, tap = gw % 9;
+    const int n = gw / 3, trow = gw % 3;
     if (n >= ctrl->n_kp) return;
     const float kx = (kp_norm[2 * n] / 2.0f + 0.5f) * (float)(w - 1);
     const float ky = (kp_norm[2 * n + 1] / 2.0f + 0.5f) * (float)(h - 1);
@@ -1181,12 +1183,17 @@ __global__ __launch_bounds__(256) void al_patch_kernel(Pyr P0, const float* __re
     int cx = (int)((float)(int)kx - 1.5f + 1.0f), cy = (int)((float)(int)ky - 1.5f + 1.0f);
     cx = min(max(cx, 0), w - 1 - 3);
     cy = min(max(cy, 0), h - 1 - 3);
-    const float2 f = feat_pair(P, rnorm, pl, pt, cy + tap / 3, cx + tap % 3, lane);
+    float2 f[3];
+#pragma unroll
+    for (int tc = 0; tc < 3; ++tc) f[tc] = feat_pair(P, rnorm, pl, pt, cy + trow, cx + tc, lane);
     const int c = lane & 31;
     const int ca = lane < 32 ? c : 32 + c, cb = lane < 32 ? 64 + c : 96 + c;
     float* dst = patch + (size_t)n * 1152;
-    dst[ca * 9 + tap] = f.x;
-    dst[cb * 9 + tap] = f.y;
+#pragma unroll
+    for (int tc = 0; tc < 3; ++tc) {
+        dst[ca * 9 + 3 * trow + tc] = f[tc].x;
+        dst[cb * 9 + 3 * trow + tc] = f[tc].y;
+    }
 }
 
 // offsets = clamp(conv1x1(selu(h32)) + b) ; sample positions in un-padded pixel coordinates
@@ -1534,7 +1541,7 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
     hipLaunchKernelGGL(al_refine_kernel, dim3(sslam::cdiv(NK, 256), uF), dim3(256), 0, s, g->score, d.h, d.w, g->kp_index,
                        g->kp_norm, g->kp_score, g->ctrl, fs);
     // SDDH
-    hipLaunchKernelGGL(al_patch_kernel, dim3(sslam::cdiv(NK * 9, 4), uF), dim3(256), 0, s, P, g->rnorm, d.pl, d.pt, d.h, d.w,
+    hipLaunchKernelGGL(al_patch_kernel, dim3(sslam::cdiv(NK * 3, 4), uF), dim3(256), 0, s, P, g->rnorm, d.pl, d.pt, d.h, d.w,
                        g->kp_norm, g->patch, g->ctrl, fs);
     hipLaunchKernelGGL((al_gemm_kernel<64, 64, 1, 1>), dim3(1, sslam::cdiv(NK, 64), SDDH_KSPLIT * uF), dim3(256), 0, s, g->patch,
                        1152, g->d_ow, nullptr, 32, g->h32, 1, NK, 0, g->ctrl, SDDH_KSPLIT, fs);
