@@ -33,6 +33,7 @@
 // Barriers per tile: 6 (v1 with LDS rings for the weights: 47).  The kernel is bound by the L2 -> CU path
 // (1.5 MB of weights + 128 KB of activations per 64 tokens at ~36-46 B/clk/CU), not by the matrix pipe.
 #pragma once
+#include <utility>
 #include "gemm_f16x3.hpp"
 
 namespace sslam {
@@ -119,6 +120,45 @@ __device__ __forceinline__ float ffn_erf(float x) {        // Abramowitz & Stegu
     return copysignf(fmaf(-p * t, e, 1.0f), x);
 }
 
+// ---- operand-tile streaming -----------------------------------------------------------------------------------
+// r03b: the operand tile arrives in CHUNKS of two k-panels (= four 16-deep steps of phase 1), FFN_LEADC chunks ahead
+// of the MFMAs that read them, instead of all 128 KB up front.  Vector-memory operations of a wave return in order, so
+// with everything issued in the prologue the first W1 refill a wave had to wait for (step 4) also waited for its last
+// operand piece: the whole tile's fetch (13 k of a tile's 77 k cycles, an HBM burst every workgroup issues at the same
+// moment) sat in front of the MFMAs.  Now a wave waits for exactly its own pieces of the next chunk with a counted
+// s_waitcnt - ffn_ops_after_chunk() replays the wave's issue order at compile time - and one barrier per chunk makes
+// the other waves' pieces visible.
+#ifndef FFN_LEADC_N
+#define FFN_LEADC_N 2
+#endif
+constexpr int FFN_LEADC = FFN_LEADC_N;
+// vector-memory operations a wave issues after the last piece of chunk c and before the point where chunk c must be
+// in place (before the loop for chunk 0, else the start of step 4 c - 1: the fragment read runs one step ahead).
+// Program order: prologue = chunks 0 .. LEADC - 1 (two pieces each); step s = [wait point] MFMAs, W1 refill (4 loads,
+// while s + FFN_D1 < 32), then chunk s / 4 + LEADC when s % 4 == 0.
+constexpr int ffn_ops_after_chunk(int c) {
+    int n = 0; bool seen = false;
+    for (int k = 0; k < FFN_LEADC; ++k) { if (seen) n += 2; if (k == c) seen = true; }
+    if (c == 0) return n;
+    for (int s = 0; s < 32; ++s) {
+        if (s == 4 * c - 1) return n;
+        if (s + FFN_D1 < 32 && seen) n += 4;
+        if (s % 4 == 0 && s / 4 + FFN_LEADC < 8) { if (seen) n += 2; if (s / 4 + FFN_LEADC == c) seen = true; }
+    }
+    return n;
+}
+template <int N> __device__ __forceinline__ void ffn_wait_vm() {
+#if defined(FFN_STAMP) || (FFN_ABL & 2)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // diagnostic builds issue other vector-memory operations
+#else
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+#endif
+}
+template <class F, int... I> __device__ __forceinline__ void ffn_static_for(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+
 // One tile of 32 TT tokens (TT = 2: the 64-token tile described above; TT = 1: 32 tokens, for token sets too small
 // to give every CU a 64-token tile - one pair, pruned sets: half the MFMA / LayerNorm / GELU work per workgroup and
 // twice the workgroups.  The LDS images keep their 64-token strides, the second token tile simply does not exist; a
@@ -170,26 +210,28 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
     half8 wq[FFN_D1][4];
 #pragma unroll
     for (int d = 0; d < FFN_D1; ++d) load_w1(d, wq[d]);
-    {
-        const int prow = lane >> 2, pc = lane & 3;
-        const int psw = (pc ^ ((prow >> 2) & 3)) * 8;
-        const int aoff = (min(grow0 + (wave & 3) * 16 + prow, grow_cap - 1) * PANEL_K + psw) * 2;      // bytes
-        const bool lo = wave >= 4;
-        const unsigned a_bytes = (unsigned)p.plane_rows * FFN_D * 2;
-        const auto r_ax = ffn_rsrc(lo ? p.xs.lo : p.xs.hi, a_bytes), r_am = ffn_rsrc(lo ? p.msgs.lo : p.msgs.hi, a_bytes);
-        const int pstride = p.plane_rows * (PANEL_K * 2);           // bytes per k-panel of a plane
-        if (TT == 2 || (wave & 3) < 2) {               // (TT = 1: rows 32 .. 63 of the image are never read)
+    const int prow = lane >> 2, pc = lane & 3;
+    const int psw = (pc ^ ((prow >> 2) & 3)) * 8;
+    const int aoff = (min(grow0 + (wave & 3) * 16 + prow, grow_cap - 1) * PANEL_K + psw) * 2;      // bytes
+    const bool lo = wave >= 4;
+    const unsigned a_bytes = (unsigned)p.plane_rows * FFN_D * 2;
+    const auto r_ax = ffn_rsrc(lo ? p.xs.lo : p.xs.hi, a_bytes), r_am = ffn_rsrc(lo ? p.msgs.lo : p.msgs.hi, a_bytes);
+    const int pstride = p.plane_rows * (PANEL_K * 2);               // bytes per k-panel of a plane
+    const bool dma_wave = TT == 2 || (wave & 3) < 2;                // (TT = 1: rows 32 .. 63 of the image are never read)
+    // chunk c = k-panels 2 c, 2 c + 1 (panels 0 - 7: x, 8 - 15: message): this wave's two pieces of 16 rows x 64 B each
+    auto issue_chunk = [&](int c) {
+        if (!dma_wave) return;
 #pragma unroll
-            for (int kp = 0; kp < 16; ++kp) {
-                _Float16* dst = smem + ((kp * 2 + (lo ? 1 : 0)) * 64 + (wave & 3) * 16) * 32;
-                if (kp < 8) ffn_dma16(r_ax, aoff, kp * pstride, dst);
-                else ffn_dma16(r_am, aoff, (kp - 8) * pstride, dst);
-            }
+        for (int j = 0; j < 2; ++j) {
+            const int kp = 2 * c + j;
+            _Float16* dst = smem + ((kp * 2 + (lo ? 1 : 0)) * 64 + (wave & 3) * 16) * 32;
+            if (kp < 8) ffn_dma16(r_ax, aoff, kp * pstride, dst);
+            else ffn_dma16(r_am, aoff, (kp - 8) * pstride, dst);
         }
-    }
-    // the x half of the operand tile (k-panels 0-7: this wave's first 8 pieces) and the W1 prefetch have landed;
-    // the message half (8 younger pieces) stays in flight under the first 16 steps
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    };
+#pragma unroll
+    for (int c = 0; c < FFN_LEADC; ++c) issue_chunk(c);
+    ffn_wait_vm<ffn_ops_after_chunk(0)>();             // own pieces of chunk 0 (and the W1 prefetch, older) have landed
     __builtin_amdgcn_s_barrier();
     FFN_STAMP_AT(1);
 
@@ -231,29 +273,26 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
         half8 ah0[TT], al0[TT], ah1[TT], al1[TT];
         read_a(0, ah0, al0);
         static_assert(32 % FFN_D1 == 0 && FFN_D1 % 2 == 0, "the ring of W1 fragment sets divides the 32 steps, even depth");
-        for (int ks0 = 0; ks0 < 32; ks0 += FFN_D1) {
-            if (ks0 == 16 - FFN_D1) {
-                // the next group's last step prefetches the first message fragments: the message half must be in place
-                // (every wave's pieces: wait for the own ones, then the barrier).  Drains this wave's W1 ring once.
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ffn_static_for([&](auto ks_c) {
+            constexpr int ks = decltype(ks_c)::value, u = ks % FFN_D1;
+            if constexpr (ks % 4 == 3 && (ks + 1) / 4 < 8) {
+                // the next step's fragments come from chunk (ks + 1) / 4: own pieces landed, then everybody's
+                ffn_wait_vm<ffn_ops_after_chunk((ks + 1) / 4)>();
                 __builtin_amdgcn_s_barrier();
             }
-#pragma unroll
-            for (int u = 0; u < FFN_D1; ++u) {
-                const int ks = ks0 + u;
-                if (u & 1) {
-                    if (ks + 1 < 32) read_a(ks + 1, ah0, al0);
-                    mma1(wq[u], ah1, al1);
-                } else {
-                    read_a(ks + 1, ah1, al1);
-                    mma1(wq[u], ah0, al0);
-                }
-                if (ks + FFN_D1 < 32) load_w1(ks + FFN_D1, wq[u]);
-                // keep the refill HERE, FFN_D1 steps ahead of its use: left alone the scheduler sinks it to just
-                // in front of the consuming MFMAs (fewer live registers, one exposed L2 round trip per step)
-                __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ks & 1) {
+                if constexpr (ks + 1 < 32) read_a(ks + 1, ah0, al0);
+                mma1(wq[u], ah1, al1);
+            } else {
+                read_a(ks + 1, ah1, al1);
+                mma1(wq[u], ah0, al0);
             }
-        }
+            if constexpr (ks + FFN_D1 < 32) load_w1(ks + FFN_D1, wq[u]);
+            if constexpr (ks % 4 == 0 && ks / 4 + FFN_LEADC < 8) issue_chunk(ks / 4 + FFN_LEADC);
+            // keep the refill HERE, FFN_D1 steps ahead of its use: left alone the scheduler sinks it to just
+            // in front of the consuming MFMAs (fewer live registers, one exposed L2 round trip per step)
+            __builtin_amdgcn_sched_barrier(0);
+        }, std::make_integer_sequence<int, 32>{});
     }
     FFN_STAMP_AT(2);
 
