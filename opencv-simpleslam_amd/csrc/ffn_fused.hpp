@@ -79,8 +79,9 @@ struct FfnFusedArgs {
 };
 
 #ifdef FFN_STAMP
-#define FFN_STAMP_AT(i_) do { if (threadIdx.x == 0) { unsigned long long t_; \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); p.stamps[blockIdx.x * 8 + (i_)] = t_; } } while (0)
+// stamps are kept in registers and stored once at the end of the tile: a store in the middle of the k-loops would be one
+// more vector-memory operation in the wave's in-order queue and throw the counted waits off
+#define FFN_STAMP_AT(i_) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ffn_st_[(i_)] = t_; } while (0)
 #else
 #define FFN_STAMP_AT(i_)
 #endif
@@ -134,11 +135,16 @@ __device__ __forceinline__ float ffn_erf(float x) {        // Abramowitz & Stegu
 constexpr int FFN_LEADC = FFN_LEADC_N;
 // vector-memory operations a wave issues after the last piece of chunk c and before the point where chunk c must be
 // in place (before the loop for chunk 0, else the start of step 4 c - 1: the fragment read runs one step ahead).
-// Program order: prologue = chunks 0 .. LEADC - 1 (two pieces each); step s = [wait point] MFMAs, W1 refill (4 loads,
-// while s + FFN_D1 < 32), then chunk s / 4 + LEADC when s % 4 == 0.
+// Program order: prologue = W1 set 0 (4 loads), chunk 0 (two pieces), W1 sets 1 .. FFN_D1 - 1, chunks 1 .. LEADC - 1 -
+// what step 0 needs first in the queue; step s = [wait point] MFMAs, W1 refill (4 loads, while s + FFN_D1 < 32), then
+// chunk s / 4 + LEADC when s % 4 == 0.
 constexpr int ffn_ops_after_chunk(int c) {
     int n = 0; bool seen = false;
-    for (int k = 0; k < FFN_LEADC; ++k) { if (seen) n += 2; if (k == c) seen = true; }
+    for (int k = 0; k < FFN_LEADC; ++k) {
+        if (seen) n += 2;
+        if (k == c) seen = true;
+        if (k == 0 && seen) n += 4 * (FFN_D1 - 1);
+    }
     if (c == 0) return n;
     for (int s = 0; s < 32; ++s) {
         if (s == 4 * c - 1) return n;
@@ -148,8 +154,8 @@ constexpr int ffn_ops_after_chunk(int c) {
     return n;
 }
 template <int N> __device__ __forceinline__ void ffn_wait_vm() {
-#if defined(FFN_STAMP) || (FFN_ABL & 2)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // diagnostic builds issue other vector-memory operations
+#if FFN_ABL & 2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (ablation builds skip vector-memory operations the count assumes)
 #else
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
@@ -176,6 +182,9 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
     float* const red = reinterpret_cast<float*>(smem_b + FFN_RED_OFF);
     const int lane16 = lane * 16;
     float* const cst = reinterpret_cast<float*>(smem_b + FFN_CONST_OFF);
+#ifdef FFN_STAMP
+    unsigned long long ffn_st_[8] = {};
+#endif
     FFN_STAMP_AT(0);
     {   // constants of the two epilogues into LDS (a global load at their point of use is an exposed L2 round trip
         // in front of arithmetic that all eight waves wait for)
@@ -208,8 +217,7 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
     // the first W1 fragment sets (plain loads, to registers), then the operand tile by LDS-DMA: wave w
     // brings rows 16 (w & 3) .. + 15 of plane (w >> 2) of every k-panel (16 pieces of 16 rows x 64 B)
     half8 wq[FFN_D1][4];
-#pragma unroll
-    for (int d = 0; d < FFN_D1; ++d) load_w1(d, wq[d]);
+    load_w1(0, wq[0]);
     const int prow = lane >> 2, pc = lane & 3;
     const int psw = (pc ^ ((prow >> 2) & 3)) * 8;
     const int aoff = (min(grow0 + (wave & 3) * 16 + prow, grow_cap - 1) * PANEL_K + psw) * 2;      // bytes
@@ -229,9 +237,14 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
             else ffn_dma16(r_am, aoff, (kp - 8) * pstride, dst);
         }
     };
+    issue_chunk(0);
+    __builtin_amdgcn_sched_barrier(0);                 // (the queue order is the point: set 0, chunk 0, then the rest)
 #pragma unroll
-    for (int c = 0; c < FFN_LEADC; ++c) issue_chunk(c);
-    ffn_wait_vm<ffn_ops_after_chunk(0)>();             // own pieces of chunk 0 (and the W1 prefetch, older) have landed
+    for (int d = 1; d < FFN_D1; ++d) load_w1(d, wq[d]);
+#pragma unroll
+    for (int c = 1; c < FFN_LEADC; ++c) issue_chunk(c);
+    __builtin_amdgcn_sched_barrier(0);
+    ffn_wait_vm<ffn_ops_after_chunk(0)>();             // own pieces of chunk 0 (and W1 set 0, older) have landed
     __builtin_amdgcn_s_barrier();
     FFN_STAMP_AT(1);
 
@@ -500,6 +513,10 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
     split_range_check(amax, range_flag);
     FFN_STAMP_AT(6);
     FFN_STAMP_AT(7);
+#ifdef FFN_STAMP
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 8; ++i) p.stamps[blockIdx.x * 8 + i] = ffn_st_[i];
+#endif
 }
 
 }  // namespace sslam
