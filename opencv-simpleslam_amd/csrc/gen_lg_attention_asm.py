@@ -36,6 +36,7 @@ PK = os.environ.get("ATTN_ASM_PK", "0") == "1"
 # schedule knobs (experiments; the defaults are the measured best)
 NEXP_ODD = int(os.environ.get("ATTN_ASM_NEXP_ODD", "4"))     # exp2 pairs (of 8) taken in the ODD half, the rest in EVEN
 DEFER = int(os.environ.get("ATTN_ASM_DEFER", "0"))           # 1: row sums of the EVEN half's pairs + the l update run in slots 0-2 of the next ODD half
+DMA_FIRST = int(os.environ.get("ATTN_ASM_DMA_FIRST", "1"))   # first MFMA slot that carries a DMA piece (experiments: 4 = behind the fragment reads)
 WEIGHTED = int(os.environ.get("ATTN_ASM_WEIGHTED", "0"))     # 1: spread the VALU stream by issue cost (transcendental 2, else 1) instead of by count
 # diagnostic build (never the product): s_memtime stamps around the three kinds of waits of the loop; every wave writes
 # {lifetime, tile-barrier wait, fragment wait at ODD, fragment wait at EVEN, stamp-pair overhead, tiles} (cycles) to the
@@ -304,9 +305,10 @@ def emit_half(mfmas, ds, valu, dma=None, valu_start=0, comment="", head=None):
         e("    " + mfmas[sl])
         if dsl:
             e("    " + dsl.pop(0))
-        if dml and sl >= 1:
-            for x in dml.pop(0):
-                e("    " + x)
+        if dml and sl >= DMA_FIRST:
+            for _ in range(2 if len(dml) > nslot - sl else 1):      # (a late first slot: two pieces per slot where needed)
+                for x in dml.pop(0):
+                    e("    " + x)
         for x in per[sl]:
             e("    " + x)
     assert not dsl and not dml
