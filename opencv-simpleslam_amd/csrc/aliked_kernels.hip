@@ -744,7 +744,10 @@ __device__ __forceinline__ float2 feat_pair(const Pyr& P, const float* __restric
 //  4. score head tail: 3x3 (8->4) SELU, 3x3 (4->4) SELU, 3x3 (4->1), sigmoid.
 //     One kernel, intermediate layers kept in LDS; zero padding at the padded-map border.
 // ------------------------------------------------------------------------ //
-constexpr int ST_W = 32, ST_H = 8;
+#ifndef AL_ST_H
+#define AL_ST_H 8
+#endif
+constexpr int ST_W = 32, ST_H = AL_ST_H;
 
 __global__ __launch_bounds__(256) void al_score_tail_kernel(const float* __restrict__ s8, int Hp, int Wp,
                                                             const float* __restrict__ w2 /*[8][9][4]*/,
@@ -815,7 +818,13 @@ __global__ __launch_bounds__(256) void al_score_tail_kernel(const float* __restr
 // ------------------------------------------------------------------------ //
 //  5. DKD: simple_nms (5x5, two recovery rounds) + border + threshold -> candidates
 // ------------------------------------------------------------------------ //
-constexpr int NT_W = 64, NT_H = 16, NHALO = 10;     // dependency radius 2 + 4 + 4
+#ifndef AL_NT_W
+#define AL_NT_W 32      // 32 x 16 tiles: 30 KB of LDS, five workgroups per CU (64 x 16: 48 KB, three; 11.5 -> 9.6 us per frame)
+#endif
+#ifndef AL_NT_H
+#define AL_NT_H 16
+#endif
+constexpr int NT_W = AL_NT_W, NT_H = AL_NT_H, NHALO = 10;     // dependency radius 2 + 4 + 4
 constexpr int NE_W = NT_W + 2 * NHALO, NE_H = NT_H + 2 * NHALO;
 constexpr int NE = NE_H * NE_W;
 constexpr int NPASS = (NE + 255) / 256;
