@@ -174,7 +174,11 @@ __global__ __launch_bounds__(256) void al_conv3x3_mfma_kernel(
     constexpr int K = 9 * CINP;
     constexpr int WLD = COUT;                                        // weight row stride in LDS
     __shared__ __attribute__((aligned(16))) float tile[CINP * CHS];
-    __shared__ float wl[(K + (DOWN ? CINP : 0)) * WLD];              // [k = tap*CINP + ci][co] (+ 1x1 rows)
+#ifndef AL_W_GLOBAL
+#define AL_W_GLOBAL 1      // 32-row shape: the A operand (weights) straight from global memory / L1 instead of an LDS copy
+#endif
+    constexpr bool WG = AL_W_GLOBAL && !M16;
+    __shared__ float wl[WG ? 1 : (K + (DOWN ? CINP : 0)) * WLD];     // [k = tap*CINP + ci][co] (+ 1x1 rows)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CTH;
 #if CONV_ABL & 2
@@ -235,16 +239,18 @@ __global__ __launch_bounds__(256) void al_conv3x3_mfma_kernel(
             tile[c * CHS + rr * CT_TW + (side ? IC + CT_W : IC - 1)] = v;
         }
     }
+    if constexpr (!WG) {
 #pragma unroll AL_CONV_UNROLL
-    for (int i = t; i < K * WLD; i += 256) {          // global [ci][tap][co] -> LDS [tap][ci][co], zero padded
-        const int co = i % WLD, k = i / WLD, tap = k / CINP, ci = k % CINP;
-        wl[i] = ci < CIN ? w[(ci * 9 + tap) * COUT + co] : 0.0f;
-    }
-    if (DOWN)
-        for (int i = t; i < CINP * WLD; i += 256) {
-            const int co = i % WLD, ci = i / WLD;
-            wl[K * WLD + i] = ci < CIN ? wd[ci * COUT + co] : 0.0f;
+        for (int i = t; i < K * WLD; i += 256) {          // global [ci][tap][co] -> LDS [tap][ci][co], zero padded
+            const int co = i % WLD, k = i / WLD, tap = k / CINP, ci = k % CINP;
+            wl[i] = ci < CIN ? w[(ci * 9 + tap) * COUT + co] : 0.0f;
         }
+        if (DOWN)
+            for (int i = t; i < CINP * WLD; i += 256) {
+                const int co = i % WLD, ci = i / WLD;
+                wl[K * WLD + i] = ci < CIN ? wd[ci * COUT + co] : 0.0f;
+            }
+    }
     __syncthreads();
 
     if constexpr (M16) {
@@ -313,7 +319,9 @@ __global__ __launch_bounds__(256) void al_conv3x3_mfma_kernel(
             for (int c2 = 0; c2 < CINP / 2; ++c2) {
                 const int koff = (tap * CINP + 2 * c2) * WLD;                        // A: rows k0, k0+1
                 const int boff = (2 * c2) * CHS + (tap / 3) * CT_TW + (tap % 3);      // B: channels 2c2, 2c2+1
-                const float a = abase[koff];
+                // (32 consecutive output channels of one (ci, tap) per lane half: two coalesced 128-byte runs of the
+                //  [ci][tap][co] weights as they are - no per-workgroup LDS copy, 37 KB of LDS less, three workgroups per CU)
+                const float a = WG ? w[((2 * c2 + h) * 9 + tap) * COUT + px] : abase[koff];
 #pragma unroll
                 for (int q = 0; q < RPW; ++q) acc[q] = sslam::mfma32(a, bbase[boff + q * CT_TW], acc[q]);
             }
@@ -324,7 +332,7 @@ __global__ __launch_bounds__(256) void al_conv3x3_mfma_kernel(
         if (DOWN) {
 #pragma unroll
             for (int c2 = 0; c2 < CINP / 2; ++c2) {
-                const float a = abase[(K + 2 * c2) * WLD];
+                const float a = WG ? wd[(2 * c2 + h) * COUT + px] : abase[(K + 2 * c2) * WLD];
                 const int boff = (2 * c2) * CHS + CT_TW + 1;                          // centre tap
 #pragma unroll
                 for (int q = 0; q < RPW; ++q) dn[q] = sslam::mfma32(a, bbase[boff + q * CT_TW], dn[q]);
