@@ -59,6 +59,14 @@ int sslam_memcpy_d2h(sslam_ctx* ctx, void* dst_host, const void* src_dev, size_t
  * the single-GPU product path runs without any other GPU runtime. */
 int sslam_memcpy_d2d_async(sslam_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
 int sslam_memset_async(sslam_ctx* ctx, void* dst_dev, int value, size_t bytes);
+/* Page-locked host memory and enqueue-only host <-> device copies on the context's stream (the host buffer
+ * must stay valid, and for a real overlap be page-locked, until the stream has passed the copy): the
+ * drop-in `feature_extractor` / `feature_matcher` (slam/core/features_utils.py:85-171) stage the image and
+ * read the result records back through these instead of the torch `.cuda()` / `.cpu()` calls at :222, :97. */
+int sslam_host_alloc(sslam_ctx* ctx, size_t bytes, void** hptr_out);
+int sslam_host_free(sslam_ctx* ctx, void* hptr);
+int sslam_memcpy_h2d_async(sslam_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int sslam_memcpy_d2h_async(sslam_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 int sslam_event_create(sslam_ctx* ctx, void** event_out);
 int sslam_event_destroy(void* event);
 int sslam_event_record(sslam_ctx* ctx, void* event);      /* on ctx's stream */

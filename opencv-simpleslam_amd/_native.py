@@ -43,6 +43,10 @@ def _signatures():
         "sslam_memcpy_h2d": (i32, [vp, vp, vp, sz]),
         "sslam_memcpy_d2h": (i32, [vp, vp, vp, sz]),
         "sslam_memcpy_d2d_async": (i32, [vp, vp, vp, sz]),
+        "sslam_host_alloc": (i32, [vp, sz, c_void_pp]),
+        "sslam_host_free": (i32, [vp, vp]),
+        "sslam_memcpy_h2d_async": (i32, [vp, vp, vp, sz]),
+        "sslam_memcpy_d2h_async": (i32, [vp, vp, vp, sz]),
         "sslam_memset_async": (i32, [vp, vp, i32, sz]),
         "sslam_event_create": (i32, [vp, c_void_pp]),
         "sslam_event_destroy": (i32, [vp]),
@@ -151,6 +155,7 @@ class Context:
         self.handle = h
         self.device = int(device)
         self.scratch = {}                 # named device buffers owned by this context (freed in close)
+        self._pinned = []                 # page-locked host blocks (address, ctypes view) from host_alloc
 
     def close(self):
         if getattr(self, "handle", None):
@@ -158,6 +163,9 @@ class Context:
                 for ptr_ in buf.get("_ptrs", ()):
                     lib().sslam_free(self.handle, C.c_void_p(ptr_))
             self.scratch = {}
+            for addr, _buf in getattr(self, "_pinned", ()):
+                lib().sslam_host_free(self.handle, C.c_void_p(addr))
+            self._pinned = []
             lib().sslam_ctx_destroy(self.handle)
             self.handle = None
 
@@ -197,6 +205,23 @@ class Context:
 
     def d2h(self, arr: np.ndarray, dptr: int):
         check(lib().sslam_memcpy_d2h(self.handle, ptr(arr), C.c_void_p(dptr), arr.nbytes), "d2h")
+
+    def host_alloc(self, nbytes: int) -> np.ndarray:
+        """Page-locked host memory as a uint8 array (freed with the context; views keep it alive)."""
+        p = C.c_void_p()
+        check(lib().sslam_host_alloc(self.handle, int(nbytes), C.byref(p)), "sslam_host_alloc")
+        buf = (C.c_uint8 * int(nbytes)).from_address(p.value)
+        arr = np.frombuffer(buf, np.uint8)
+        self._pinned.append((p.value, buf))
+        return arr
+
+    def h2d_async(self, dptr: int, arr: np.ndarray):
+        """Enqueue only; `arr` (contiguous, page-locked for a real overlap) must stay untouched until the stream passed it."""
+        check(lib().sslam_memcpy_h2d_async(self.handle, C.c_void_p(dptr), ptr(arr), arr.nbytes), "h2d_async")
+
+    def d2h_async(self, arr: np.ndarray, dptr: int, nbytes: int | None = None):
+        check(lib().sslam_memcpy_d2h_async(self.handle, ptr(arr), C.c_void_p(dptr),
+                                           arr.nbytes if nbytes is None else int(nbytes)), "d2h_async")
 
     def d2d_async(self, dst: int, src: int, nbytes: int):
         check(lib().sslam_memcpy_d2d_async(self.handle, C.c_void_p(dst), C.c_void_p(src), int(nbytes)), "d2d")

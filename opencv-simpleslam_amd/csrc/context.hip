@@ -173,6 +173,35 @@ int sslam_memcpy_d2d_async(sslam_ctx* ctx, void* dst_dev, const void* src_dev, s
     return 0;
 }
 
+/* ---- page-locked host memory + enqueue-only host <-> device copies: the drop-in path stages the image and reads a
+ * frame's {count, keypoints, descriptors} record back through these (a copy from / to pageable memory costs 30 - 80 us
+ * of runtime staging per call and synchronises; measured in scripts/time_dropin_parts.py) */
+int sslam_host_alloc(sslam_ctx* ctx, size_t bytes, void** hptr_out) {
+    SSLAM_REQUIRE(ctx != nullptr && hptr_out != nullptr, "sslam_host_alloc: NULL argument");
+    *hptr_out = nullptr;
+    SSLAM_HIP_CHECK(hipSetDevice(ctx->device));
+    SSLAM_HIP_CHECK(hipHostMalloc(hptr_out, bytes ? bytes : 1, hipHostMallocDefault));
+    return 0;
+}
+
+int sslam_host_free(sslam_ctx* ctx, void* hptr) {
+    SSLAM_REQUIRE(ctx != nullptr, "sslam_host_free: ctx is NULL");
+    if (hptr) SSLAM_HIP_CHECK(hipHostFree(hptr));
+    return 0;
+}
+
+int sslam_memcpy_h2d_async(sslam_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+    SSLAM_REQUIRE(ctx != nullptr && (bytes == 0 || (dst_dev && src_host)), "sslam_memcpy_h2d_async: NULL argument");
+    if (bytes) SSLAM_HIP_CHECK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+
+int sslam_memcpy_d2h_async(sslam_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+    SSLAM_REQUIRE(ctx != nullptr && (bytes == 0 || (dst_host && src_dev)), "sslam_memcpy_d2h_async: NULL argument");
+    if (bytes) SSLAM_HIP_CHECK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return 0;
+}
+
 int sslam_memset_async(sslam_ctx* ctx, void* dst_dev, int value, size_t bytes) {
     SSLAM_REQUIRE(ctx != nullptr && (bytes == 0 || dst_dev), "sslam_memset_async: NULL argument");
     if (bytes) SSLAM_HIP_CHECK(hipMemsetAsync(dst_dev, value, bytes, ctx->stream));

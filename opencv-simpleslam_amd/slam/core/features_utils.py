@@ -31,7 +31,8 @@ import numpy as np
 import ctypes as _C
 import weakref
 
-from .types import DMatch, KeyPoint, KeyPointList, HAVE_CV2, keypoints_from_xy, matches_from_ij, xy_from_keypoints
+from .types import (DMatch, KeyPoint, KeyPointList, HAVE_CV2, keypoint_shells, keypoints_from_xy, matches_from_ij,
+                    xy_from_keypoints)
 from ... import _native, weights as _weights
 from ...aliked import AlikedHIP
 from ...lightglue import LightGlueHIP
@@ -130,17 +131,34 @@ class _DeviceFeatureRing:
         self.ctx = detector.ctx
         K = self.K = int(detector.max_num_keypoints)
         m = self.ctx.malloc
-        self.slots = [dict(xy=m(K * 8), desc=m(K * 128 * 4), score=m(K * 4), cnt=m(16), key=None) for _ in range(self.SLOTS)]
+        # one device block per slot, [count 16 B | xy K x 2 | desc K x 128 | score K]: {count, xy, desc} come back
+        # in ONE copy into a page-locked mirror (three pageable copies + the count's own round trip were 140 us)
+        self.o_xy, self.o_desc, self.o_score = 16, 16 + K * 8, 16 + K * 8 + K * 512
+        self.rec_bytes = self.o_score + K * 4
+        self.slots = []
+        for _ in range(self.SLOTS):
+            base = m(self.rec_bytes)
+            self.slots.append(dict(base=base, cnt=base, xy=base + self.o_xy, desc=base + self.o_desc,
+                                   score=base + self.o_score, key=None))
+        self.pin_rec = self.ctx.host_alloc(self.o_score)
+        self.pin_cnt = self.pin_rec[:16].view(np.int32)
+        self.pin_xy = self.pin_rec[self.o_xy:self.o_desc].view(np.float32).reshape(K, 2)
+        self.pin_desc = self.pin_rec[self.o_desc:self.o_score].view(np.float32).reshape(K, 128)
         self.by_id = {}                  # id(descriptor array) -> entry
         self.turn = 0
-        self.img_dev, self.img_cap = 0, 0
+        self.img_dev, self.img_cap, self.pin_img = 0, 0, None
         self.tmp_xy = [m(K * 8), m(K * 8)]               # keypoints of an edited list (uploaded per call)
-        self.out_ij, self.out_sc, self.out_info = m(K * 8), m(K * 4), m(16)
+        out = m(16 + K * 8 + K * 4)                      # match results, [info 16 B | pairs K x 2 | scores K]
+        self.out_info, self.out_ij, self.out_sc = out, out + 16, out + 16 + K * 8
+        self.pin_match = self.ctx.host_alloc(16 + K * 8)
+        self.pin_info = self.pin_match[:16].view(np.int32)
+        self.pin_ij = self.pin_match[16:].view(np.int32).reshape(K, 2)
         detector.use_graphs(True)        # the slots are a fixed set of buffers: the launch sequence replays as a graph
 
     def extract(self, img):
         det, ctx = self.det, self.ctx
-        img = np.ascontiguousarray(img)
+        if not isinstance(img, np.ndarray):
+            img = np.asarray(img)
         if img.dtype != np.uint8:
             raise TypeError("feature extraction expects a uint8 image (cv2.imread output)")
         if img.ndim == 2:
@@ -154,21 +172,32 @@ class _DeviceFeatureRing:
                 ctx.sync(); ctx.free(self.img_dev)
             self.img_cap = max(img.nbytes, 1241 * 376 * 3)
             self.img_dev = ctx.malloc(self.img_cap)
+            self.pin_img = ctx.host_alloc(self.img_cap)
         sl = self.slots[self.turn % self.SLOTS]
         self.turn += 1
         if sl["key"] is not None:
             self.by_id.pop(sl["key"], None)
             sl["key"] = None
-        ctx.h2d(self.img_dev, img)
-        det.extract_dev(self.img_dev, H, Wd, Cn, sl["xy"], sl["desc"], sl["score"], sl["cnt"], max_kpts=self.K)
-        cnt = np.empty(4, np.int32)
-        ctx.d2h(cnt[:1], sl["cnt"])
-        n = int(cnt[0])
-        xy = np.empty((n, 2), np.float32); desc = np.empty((n, 128), np.float32)
-        if n:
-            ctx.d2h(xy, sl["xy"]); ctx.d2h(desc, sl["desc"])
+        K = self.K
+        stage = self.pin_img[:img.nbytes]
+        np.copyto(stage.reshape(img.shape), img)         # (also makes a strided view contiguous)
+        ctx.h2d_async(self.img_dev, stage)
+        det.extract_dev(self.img_dev, H, Wd, Cn, sl["xy"], sl["desc"], sl["score"], sl["cnt"], max_kpts=K)
+        ctx.d2h_async(self.pin_rec, sl["base"])
+        # the GPU needs ~0.5 ms from here: build the frame's KeyPoint objects meanwhile (their coordinates resolve
+        # against the array below on first use)
+        shells, src = keypoint_shells(K) if keypoint_shells is not None else (None, None)
+        ctx.sync()
+        n = int(self.pin_cnt[0])
+        xy = self.pin_xy[:n].copy(); desc = self.pin_desc[:n].copy()
         desc.setflags(write=False)
-        kps = KeyPointList(keypoints_from_xy(xy), xy)
+        if shells is not None:
+            src.xy = xy
+            if n < K:
+                del shells[n:]
+            kps = KeyPointList(shells, xy)
+        else:
+            kps = KeyPointList(keypoints_from_xy(xy), xy)
         entry = dict(slot=sl, n=n, desc_ref=weakref.ref(desc), xy=xy)
         sl["key"] = id(desc)
         self.by_id[id(desc)] = entry
@@ -220,17 +249,14 @@ def _match_resident(ring, matcher, a, b, thr):
     ctx = ring.ctx
     matcher.match_dev(a[0], a[1], a[2], b[0], b[1], b[2], ring.out_ij, ring.out_sc, ring.out_info, min_conf=thr,
                       m_dev=a[3], n_dev=b[3])
-    info = np.empty(4, np.int32)
-    ctx.d2h(info, ring.out_info)
-    k = int(info[0])
+    ctx.d2h_async(ring.pin_match, ring.out_info)           # {count, pairs} in one copy into page-locked memory
+    ctx.sync()
+    k = int(ring.pin_info[0])
     if k < 0:
         matcher.range_overflow()                # reported here: clear the instance's sticky word
         raise _native.NativeError("feature_matcher: an activation left the fp16 range of the split-precision path "
                                   "(|value| >= 65520); rescale the descriptors or use matcher.set_precision('f32')")
-    ij = np.empty((k, 2), np.int32)
-    if k:
-        ctx.d2h(ij, ring.out_ij)
-    return ij
+    return ring.pin_ij[:k].copy()
 
 
 def feature_matcher(args, kp0, kp1, des0, des1, matcher):

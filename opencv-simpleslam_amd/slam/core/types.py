@@ -12,6 +12,7 @@ try:                                       # pragma: no cover - cv2 absent in th
     KeyPoint = _cv2.KeyPoint
     DMatch = _cv2.DMatch
     HAVE_CV2 = True
+    keypoint_shells = None                 # cv2.KeyPoint stores its coordinates at construction
 except Exception:                          # noqa: BLE001
     HAVE_CV2 = False
 
@@ -25,11 +26,13 @@ except Exception:                          # noqa: BLE001
 
     class KeyPoint(_KeyPointDefaults):
         """Duck type of cv2.KeyPoint(x, y, size).  Only `pt` is stored per instance unless another
-        field is set: the reference reads nothing else downstream, and a frame builds thousands."""
-        __slots__ = ("pt", "__dict__")
+        field is set: the reference reads nothing else downstream, and a frame builds thousands.
+        A keypoint made by `keypoint_shells` reads its `pt` from the frame's coordinate array on first use
+        (then keeps it), so the objects can be built while the GPU is still extracting."""
+        __slots__ = ("_pt", "_src", "_i", "__dict__")
 
         def __init__(self, x=0.0, y=0.0, size=1.0, angle=-1.0, response=0.0, octave=0, class_id=-1):
-            self.pt = (float(x), float(y))
+            self._pt = (float(x), float(y))
             if size != 1.0:
                 self.size = float(size)
             if angle != -1.0:
@@ -41,8 +44,51 @@ except Exception:                          # noqa: BLE001
             if class_id != -1:
                 self.class_id = int(class_id)
 
+        @property
+        def pt(self):
+            try:
+                return self._pt
+            except AttributeError:
+                p = self._pt = self._src.point(self._i)
+                return p
+
+        @pt.setter
+        def pt(self, v):
+            x, y = v
+            self._pt = (float(x), float(y))
+
         def __repr__(self):
             return f"KeyPoint(pt={self.pt})"
+
+    class _PointSource:
+        """The [N,2] coordinates a frame's keypoint shells resolve their `pt` against (set once the
+        extraction has finished; converted to python floats in one C pass on the first read)."""
+        __slots__ = ("xy", "pts")
+
+        def __init__(self):
+            self.xy = None
+            self.pts = None
+
+        def point(self, i):
+            pts = self.pts
+            if pts is None:
+                pts = self.pts = self.xy.tolist()
+            x, y = pts[i]
+            return (x, y)
+
+    def keypoint_shells(n):
+        """n KeyPoint objects without coordinates yet + the source to hand the [>= n, 2] array to
+        (`src.xy = xy`) before anyone reads a `pt`."""
+        src = _PointSource()
+        new = KeyPoint.__new__
+        out = []
+        add = out.append
+        for i in range(n):
+            k = new(KeyPoint)
+            k._src = src
+            k._i = i
+            add(k)
+        return out, src
 
     class DMatch:
         """Duck type of cv2.DMatch(queryIdx, trainIdx, imgIdx, distance)."""
@@ -68,7 +114,7 @@ def keypoints_from_xy(xy):
     new = KeyPoint.__new__
     for x, y in pts:
         k = new(KeyPoint)
-        k.pt = (x, y)
+        k._pt = (x, y)
         out.append(k)
     return out
 

@@ -1,0 +1,43 @@
+"""Where a drop-in `feature_extractor` / `feature_matcher` call spends its wall time (the ring's steps timed one by one;
+the real call overlaps the keypoint objects with the GPU work, here every step is fenced)."""
+import importlib, os, sys, time
+os.environ.setdefault("SSLAM_ALLOW_RANDOM_WEIGHTS", "1")
+from pathlib import Path
+from types import SimpleNamespace
+import numpy as np
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+import frames
+fu = importlib.import_module("opencv-simpleslam_amd.slam.core.features_utils")
+ty = importlib.import_module("opencv-simpleslam_amd.slam.core.types")
+args = SimpleNamespace(use_lightglue=True, max_features=2048, min_conf=0.7, detector="aliked", matcher="lightglue")
+det, mat = fu.init_feature_pipeline(args)
+ring = fu._ring_of(det); ctx = ring.ctx
+imgs = [frames.structured_frame(i) for i in range(12)]
+for im in imgs[:3]:
+    fu.feature_extractor(args, im, det)
+T = {}
+def tick(name, t0):
+    t1 = time.perf_counter(); T.setdefault(name, []).append(t1 - t0); return t1
+K = ring.K
+prev = None
+for im in imgs[3:]:
+    sl = ring.slots[ring.turn % ring.SLOTS]; ring.turn += 1
+    ctx.sync()
+    t = time.perf_counter()
+    stage = ring.pin_img[:im.nbytes]; np.copyto(stage.reshape(im.shape), im); t = tick("image -> page-locked stage", t)
+    ctx.h2d_async(ring.img_dev, stage); ctx.sync(); t = tick("h2d image + sync", t)
+    det.extract_dev(ring.img_dev, 376, 1241, 3, sl["xy"], sl["desc"], sl["score"], sl["cnt"], max_kpts=K); t = tick("extract_dev enqueue", t)
+    ctx.sync(); t = tick("sync (GPU work)", t)
+    ctx.d2h_async(ring.pin_rec, sl["base"]); ctx.sync(); t = tick("d2h record + sync", t)
+    shells, src = ty.keypoint_shells(K); t = tick("keypoint shells (hidden behind the GPU)", t)
+    n = int(ring.pin_cnt[0]); xy = ring.pin_xy[:n].copy(); desc = ring.pin_desc[:n].copy(); t = tick("copies out of the mirror", t)
+    src.xy = xy; kps = ty.KeyPointList(shells, xy); t = tick("keypoint list", t)
+    if prev is not None:
+        mat.match_dev(prev[0], prev[1], n, sl["xy"], sl["desc"], n, ring.out_ij, ring.out_sc, ring.out_info, min_conf=0.7,
+                      m_dev=prev[2], n_dev=sl["cnt"]); t = tick("match_dev enqueue", t)
+        ctx.sync(); t = tick("match sync (GPU work)", t)
+        ctx.d2h_async(ring.pin_match, ring.out_info); ctx.sync(); t = tick("d2h match record + sync", t)
+    prev = (sl["xy"], sl["desc"], sl["cnt"])
+for k, v in T.items():
+    print(f"{k:42s} {np.median(v)*1e6:8.1f} us")
