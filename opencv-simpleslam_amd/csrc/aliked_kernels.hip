@@ -1015,7 +1015,9 @@ __global__ void al_taps_kernel(float* __restrict__ gk, int kx, float sx, int ky,
 }
 
 // ------------------------------------------------------------------------ //
-//  6. selection: top-n_limit by (score desc, index asc) or all in raster order; one block.
+//  6. selection: top-n_limit by (score desc, index asc) or all in raster order.  One block per frame picks the
+//     SET of keys (histogram cut + ordered edge bin); their ORDER is a rank count spread over the chip in
+//     al_refine_kernel (r03: a 66-pass bitonic sort of the 2048 keys in this one block was 30 of its 45 us).
 // ------------------------------------------------------------------------ //
 constexpr int SEL_CAP = 8192;      // max keypoints (sort capacity)
 
@@ -1037,10 +1039,10 @@ __device__ void bitonic_sort_desc(unsigned long long* a, int n_pow2) {
 constexpr int EDGE_CAP = 2048;     // candidates allowed in the cut bin before falling back to radix select
 
 __global__ __launch_bounds__(1024) void al_select_kernel(const unsigned long long* __restrict__ cand, int cap,
-                                                         int n_limit, int* __restrict__ kp_index,
+                                                         int n_limit, unsigned long long* __restrict__ sel_keys,
                                                          ALCtrl* __restrict__ ctrl, const unsigned* __restrict__ hist_g,
                                                          size_t fs) {
-    cand = fsh(cand, blockIdx.x, fs); kp_index = fsh(kp_index, blockIdx.x, fs); ctrl = fsh(ctrl, blockIdx.x, fs);
+    cand = fsh(cand, blockIdx.x, fs); sel_keys = fsh(sel_keys, blockIdx.x, fs); ctrl = fsh(ctrl, blockIdx.x, fs);
     hist_g = fsh(hist_g, blockIdx.x, fs);                                       // one block per frame
     extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];   // SEL_CAP + EDGE_CAP
     unsigned long long* edge = keys + SEL_CAP;
@@ -1133,23 +1135,35 @@ __global__ __launch_bounds__(1024) void al_select_kernel(const unsigned long lon
         }
         n_sel = n_limit;
     }
-    int p2 = 2;
-    while (p2 < n_sel) p2 <<= 1;
-    bitonic_sort_desc(keys, p2);
-    for (int i = t; i < n_sel; i += blockDim.x)
-        kp_index[i] = (int)(0xffffffffu - (unsigned)(keys[i] & 0xffffffffull));
+    for (int i = t; i < n_sel; i += blockDim.x) sel_keys[i] = keys[i];         // the set; al_refine_kernel ranks it
     if (t == 0) ctrl->n_kp = n_sel;
 }
 
-// soft-argmax refinement + score sampling (DKD.forward sub_pixel=True)
-__global__ void al_refine_kernel(const float* __restrict__ score, int h, int w, const int* __restrict__ kp_index,
-                                 float* __restrict__ kp_norm, float* __restrict__ kp_score,
-                                 const ALCtrl* __restrict__ ctrl, size_t fs) {
+// output position of every selected key = the number of selected keys above it (keys are distinct: score bits over
+// ~index, so descending key order is score descending, index ascending - torch.topk's order / raster order), counted by
+// 8 lanes per key over 1/8 of the set each; then soft-argmax refinement + score sampling (DKD.forward sub_pixel=True)
+// by the first lane of each group, written at that position
+constexpr int REFINE_KPB = 32;       // keys per 256-thread block
+__global__ __launch_bounds__(256) void al_refine_kernel(const float* __restrict__ score, int h, int w,
+                                                        const unsigned long long* __restrict__ sel_keys,
+                                                        int* __restrict__ kp_index, float* __restrict__ kp_norm,
+                                                        float* __restrict__ kp_score, const ALCtrl* __restrict__ ctrl, size_t fs) {
     score = fsh(score, blockIdx.y, fs); kp_index = fsh(kp_index, blockIdx.y, fs); kp_norm = fsh(kp_norm, blockIdx.y, fs);
-    kp_score = fsh(kp_score, blockIdx.y, fs); ctrl = fsh(ctrl, blockIdx.y, fs);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ctrl->n_kp) return;
-    const int idx = kp_index[i], x = idx % w, y = idx / w;
+    kp_score = fsh(kp_score, blockIdx.y, fs); ctrl = fsh(ctrl, blockIdx.y, fs); sel_keys = fsh(sel_keys, blockIdx.y, fs);
+    const int n = ctrl->n_kp;
+    const int p = blockIdx.x * REFINE_KPB + (threadIdx.x >> 3), c = threadIdx.x & 7;
+    if (blockIdx.x * REFINE_KPB >= n) return;
+    const unsigned long long key = sel_keys[p < n ? p : 0];
+    int above = 0;
+#pragma unroll 4
+    for (int j = c; j < n; j += 8) above += sel_keys[j] > key;
+    above += __shfl_xor(above, 1);
+    above += __shfl_xor(above, 2);
+    above += __shfl_xor(above, 4);
+    if (p >= n || c != 0) return;
+    const int i = above;
+    const int idx = (int)(0xffffffffu - (unsigned)(key & 0xffffffffull)), x = idx % w, y = idx / w;
+    kp_index[i] = idx;
     float patch[25], mx = -INFINITY;
 #pragma unroll
     for (int k = 0; k < 25; ++k) {
@@ -1383,6 +1397,7 @@ struct sslam_aliked {
     unsigned* hist;
     int cand_cap;
     int* kp_index;
+    unsigned long long* sel_keys;      // the selected keys, unordered (al_select -> al_refine)
     float *kp_norm, *kp_score, *patch, *h32, *pos, *sampled, *feats, *raw;
     float *out_xy, *out_desc, *out_score;
     int32_t* out_n;
@@ -1553,10 +1568,10 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
     hipLaunchKernelGGL(al_collect_kernel, dim3(sslam::cdiv(npx, 256 * COLLECT_PPT), uF), dim3(256), 0, s, g->nms, npx, 0.0f, 1, g->bsum,
                        nbx * nby, g->cand, g->cand_cap, g->ctrl, g->hist, fs);
     hipLaunchKernelGGL(al_select_kernel, dim3(uF), dim3(1024), (SEL_CAP + EDGE_CAP) * 8, s, g->cand, g->cand_cap, n_limit,
-                       g->kp_index, g->ctrl, g->hist, fs);
+                       g->sel_keys, g->ctrl, g->hist, fs);
     const int NK = g->max_kpts;
-    hipLaunchKernelGGL(al_refine_kernel, dim3(sslam::cdiv(NK, 256), uF), dim3(256), 0, s, g->score, d.h, d.w, g->kp_index,
-                       g->kp_norm, g->kp_score, g->ctrl, fs);
+    hipLaunchKernelGGL(al_refine_kernel, dim3(sslam::cdiv(NK, REFINE_KPB), uF), dim3(256), 0, s, g->score, d.h, d.w, g->sel_keys,
+                       g->kp_index, g->kp_norm, g->kp_score, g->ctrl, fs);
     // SDDH
     hipLaunchKernelGGL(al_patch_kernel, dim3(sslam::cdiv(NK * 3, 4), uF), dim3(256), 0, s, P, g->rnorm, d.pl, d.pt, d.h, d.w,
                        g->kp_norm, g->patch, g->ctrl, fs);
@@ -1635,7 +1650,7 @@ int sslam_aliked_create_batched(sslam_ctx* ctx, const float* weights, size_t n_f
         g->s8 = A.take<float>(8 * HWp); g->rnorm = A.take<float>(HWp); g->g1cl = A.take<float>(32 * HWp);
         g->score = A.take<float>(HWp); g->nms = A.take<float>(HWp); g->bsum = A.take<float>(4096);
         g->cand = A.take<unsigned long long>(g->cand_cap); g->hist = A.take<unsigned>(HBINS);
-        g->kp_index = A.take<int>(SEL_CAP);
+        g->kp_index = A.take<int>(SEL_CAP); g->sel_keys = A.take<unsigned long long>(SEL_CAP);
         g->kp_norm = A.take<float>(2 * NK + 64); g->kp_score = A.take<float>(NK + 64);
         g->patch = A.take<float>((NK + 64) * 1152); g->h32 = A.take<float>(SDDH_KSPLIT * (NK + 64) * 32); g->pos = A.take<float>(NK * 32 + 64);
         g->sampled = A.take<float>((NK * 16 + 64) * 128); g->feats = A.take<float>((NK * 16 + 64) * 128);
@@ -1675,6 +1690,7 @@ int sslam_aliked_create_batched(sslam_ctx* ctx, const float* weights, size_t n_f
     }
     SSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)al_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (SEL_CAP + EDGE_CAP) * 8));
+    sslam::ctx_retain(ctx);
     *out = g;
     return 0;
 }
@@ -1689,7 +1705,9 @@ int sslam_aliked_destroy(sslam_aliked* g) {
     (void)hipStreamSynchronize(g->ctx->stream);
     g->graphs.clear();
     g->arena.release();
+    sslam_ctx* ctx = g->ctx;
     delete g;
+    sslam::ctx_release(ctx);
     return 0;
 }
 

@@ -136,4 +136,13 @@ struct sslam_ctx {
     // scratch for the *_host BA entry point (grown on demand, outside any graph)
     void* ba_scratch = nullptr;
     size_t ba_scratch_bytes = 0;
+    // instances (ALIKED / LightGlue) created on this context; sslam_ctx_destroy with instances alive only marks
+    // the context closed and the last instance's destroy frees it (a garbage collector may finalise a context
+    // before its instances; their destroy still needs the stream)
+    int instances = 0;
+    bool closed = false;
 };
+namespace sslam {
+void ctx_retain(sslam_ctx* ctx);
+void ctx_release(sslam_ctx* ctx);      // frees a closed context when its last instance goes
+}

@@ -59,8 +59,28 @@ int sslam_ctx_create(int device, void* stream, sslam_ctx** out) {
     return 0;
 }
 
+static void ctx_free(sslam_ctx* ctx);
+extern "C++" {
+namespace sslam {
+void ctx_retain(sslam_ctx* ctx) { ++ctx->instances; }
+void ctx_release(sslam_ctx* ctx) {
+    if (--ctx->instances == 0 && ctx->closed) ctx_free(ctx);
+}
+}  // namespace sslam
+}
+
 int sslam_ctx_destroy(sslam_ctx* ctx) {
     if (!ctx) return 0;
+    if (ctx->instances > 0) {           // instances alive: the last one's destroy frees the context
+        ctx->closed = true;
+        (void)hipStreamSynchronize(ctx->stream);
+        return 0;
+    }
+    ctx_free(ctx);
+    return 0;
+}
+
+static void ctx_free(sslam_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ba_scratch) (void)hipFree(ctx->ba_scratch);
@@ -68,7 +88,6 @@ int sslam_ctx_destroy(sslam_ctx* ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
-    return 0;
 }
 
 int sslam_ctx_sync(sslam_ctx* ctx) {

@@ -90,10 +90,12 @@ S_RESC = "s54"                    # rescale flag of the current sub-step
 S_TMP, S_TMP2, S_TMP3 = "s55", "s56", "s57"
 S_RET, S_SUB, S_SUB2 = "s[60:61]", "s[62:63]", "s[76:77]"
 S_RAGGED, S_NKREM = "s64", "s65"
+S_NIH, S_LKS, S_Z = "s22", "s23", "s30"      # key split: (image, head) slabs per key range, log2(ranges), this workgroup's range
 S_INV2 = "s[68:69]"               # {2^-11, 2^-11}
 S_C4E6, S_TLAST, S_CMIN = "s70", "s71", "s72"   # 4.0e6f ; T - 1 ; 2^-14
 S_NSCALE, S_C65520, S_CINF = "s73", "s74", "s75"
 N_SGPR = 96 if STAMP else 80
+KARG = 136 if STAMP else 128      # kernel-argument bytes: 9 pointers, 8 ints, the 3 partial buffers (, the stamp buffer)
 S_DBG, S_ACC_BAR, S_ACC_ODD, S_ACC_EVEN, S_T0, S_TA, S_TB, S_ACC_CAL = "s[80:81]", 82, 84, 86, "s[88:89]", 90, 92, 94
 
 def stamped(wait_lines, acc):
@@ -388,8 +390,9 @@ e("    s_load_dwordx16 s[4:19], s[0:1], 0x0")          # 8 pointers
 e("    s_load_dwordx2 s[20:21], s[0:1], 0x40")         # ctrl
 e("    s_load_dwordx4 s[24:27], s[0:1], 0x48")         # cross, Kc, NIc, nqb
 e("    s_load_dwordx2 s[28:29], s[0:1], 0x58")         # nslab, magic = floor(2^32 / nqb) + 1 (nqb > 1)
+e("    s_load_dwordx2 s[22:23], s[0:1], 0x60")         # nih = images * heads, log2(key ranges) (0: the kernel normalises and writes the context itself)
 if STAMP:
-    e(f"    s_load_dwordx2 {S_DBG}, s[0:1], 0x60")
+    e(f"    s_load_dwordx2 {S_DBG}, s[0:1], 0x80")
     e(f"    s_memtime {S_T0}")
     for r in (S_ACC_BAR, S_ACC_ODD, S_ACC_EVEN, S_ACC_CAL):
         e(f"    s_mov_b32 s{r}, 0")
@@ -417,6 +420,14 @@ e(".Lnoremap:")
 e("    s_mov_b32 s58, s3")
 e("    s_mov_b32 s59, s2")
 e(".Lremapped:")
+# slab = z * nih + (img * 4 + head): z = the key range of this workgroup (<= 3)
+e(f"    s_mov_b32 {S_Z}, 0")
+for _ in range(3):
+    e(f"    s_cmp_ge_u32 s58, {S_NIH}")
+    e("    s_cbranch_scc0 .Lzdone")
+    e(f"    s_sub_u32 s58, s58, {S_NIH}")
+    e(f"    s_add_u32 {S_Z}, {S_Z}, 1")
+e(".Lzdone:")
 e(f"    s_lshr_b32 {S_IMG}, s58, 2")
 e(f"    s_and_b32 {S_HEAD}, s58, 3")
 e(f"    s_lshl_b32 {S_Q0}, s59, 7")
@@ -445,8 +456,6 @@ e(f"    s_cmp_ge_u32 {S_Q0}, {S_NQ}")
 e("    s_cbranch_scc1 .Lend")
 e(f"    s_add_u32 {S_T}, {S_NK}, 63")
 e(f"    s_lshr_b32 {S_T}, {S_T}, 6")                     # key tiles (>= 1)
-e(f"    s_sub_u32 {S_TLAST}, {S_T}, 1")
-e(f"    s_and_b32 {S_RAGGED}, {S_NK}, 63")               # != 0: the last tile is masked
 e("    s_mov_b32 s68, 0x3a000000")
 e("    s_mov_b32 s69, 0x3a000000")
 e(f"    s_mov_b32 {S_C4E6}, 0x4a742400")
@@ -467,6 +476,17 @@ e(f"    s_lshl_b32 {S_TMP}, {S_WAVE}, 5")
 e(f"    s_add_u32 {S_TMP}, {S_TMP}, {S_Q0}")             # first query of this wave
 e(f"    v_add_u32_e32 {v(T + 4)}, {S_TMP}, {v(T + 3)}")  # qrow
 e(f"    v_cmp_gt_u32_e64 {S_QV}, {S_NQ}, {v(T + 4)}")
+# key tiles [t0, t1) of this workgroup's range: t0 = z T >> lks, t1 = (z + 1) T >> lks (the p kernel's z * ntiles / KS, KS a power of two)
+e(f"    s_mul_i32 {S_TMP}, {S_Z}, {S_T}")
+e(f"    s_lshr_b32 {S_TILE}, {S_TMP}, {S_LKS}")          # t0: the loop counts absolute tiles
+e(f"    s_add_u32 {S_TMP}, {S_TMP}, {S_T}")
+e(f"    s_lshr_b32 {S_TMP}, {S_TMP}, {S_LKS}")           # t1
+e(f"    s_cmp_ge_u32 {S_TILE}, {S_TMP}")
+e("    s_cbranch_scc1 .Lempty")                         # fewer tiles than ranges: o = 0, m = -inf, l = 0
+e(f"    s_sub_u32 {S_TLAST}, {S_TMP}, 1")
+e(f"    s_and_b32 {S_RAGGED}, {S_NK}, 63")               # != 0: the last tile OF THE IMAGE is masked
+e(f"    s_cmp_eq_u32 {S_TMP}, {S_T}")
+e(f"    s_cselect_b32 {S_RAGGED}, {S_RAGGED}, 0")
 # fragment addresses: addr[q] = lr * 128 + ((2 q + h) ^ ((lr >> 1) & 7)) * 16
 e(f"    v_lshrrev_b32_e32 {v(T + 5)}, 1, {v(T + 3)}")
 e(f"    v_and_b32_e32 {v(T + 5)}, 7, {v(T + 5)}")        # swz
@@ -532,8 +552,8 @@ e("    s_add_u32 s76, s62, .Lnewref_sub-.Lpc_here")
 e("    s_addc_u32 s77, s63, 0")
 e("    s_add_u32 s62, s62, .Lrescale_sub-.Lpc_here")
 e("    s_addc_u32 s63, s63, 0")
-# ---- tile 0 of every plane, then K(1)
-e(f"    s_mov_b32 {S_DOFF}, 0")
+# ---- tile t0 of every plane, then K(t0 + 1)
+e(f"    s_lshl_b32 {S_DOFF}, {S_TILE}, 13")
 e(f"    s_mov_b32 s58, {S_TMP}")                            # plane base, buffer 0
 for grp in dma_issue("s58"):
     for ins in grp:
@@ -548,12 +568,12 @@ e(f"    v_mov_b32_e32 {v(V_THR)}, 0xff800000")
 e(f"    v_mov_b32_e32 {v(V_ALPHA)}, 1.0")
 e(f"    v_mov_b32_e32 {v(V_MB)}, 0")
 e(f"    v_mov_b32_e32 {v(V_L)}, 0")
-e(f"    s_mov_b32 {S_TILE}, 0")
 e("    s_waitcnt vmcnt(0)")
 e("    s_barrier")
 e(f"    s_cmp_lt_u32 {S_WAVE}, 2")
 e("    s_cbranch_scc0 .Lnok1")
-e(f"    s_min_u32 {S_TMP2}, {S_TLAST}, 1")
+e(f"    s_add_u32 {S_TMP2}, {S_TILE}, 1")
+e(f"    s_min_u32 {S_TMP2}, {S_TMP2}, {S_TLAST}")
 e(f"    s_lshl_b32 {S_DOFF}, {S_TMP2}, 13")
 e(f"    s_add_u32 s58, {S_TMP}, 8192")                      # K(1) -> buffer 1
 for grp in dma_issue("s58"):
@@ -626,6 +646,8 @@ e(f"    v_mov_b32_e32 {v(V_T0)}, {v(V_L)}")
 e("    s_nop 1")
 e(f"    v_permlane32_swap_b32_e32 {v(V_L)}, {v(V_T0)}")
 e(f"    v_add_f32_e32 {v(V_L)}, {v(V_L)}, {v(V_T0)}")
+e(f"    s_cmp_lg_u32 {S_LKS}, 0")
+e("    s_cbranch_scc1 .Lpart")                          # a key range: the partial (o, m, l) goes to the merge kernel
 # inv = 1 / l_tot (IEEE division, as the compiler expands 1.0f / x)
 L, D0, D1, D2, D3, D4 = V_L, V_TMAX, V_PS0, V_PS1, V_T1, V_MB
 e(f"    v_div_scale_f32 {v(D0)}, {S_M0}, {v(L)}, {v(L)}, 1.0")
@@ -700,6 +722,49 @@ e(f"    v_mov_b32_e32 {v(T + 8)}, 1")
 e(f"    global_store_dword {v(T + 7)}, {v(T + 8)}, s[20:21] offset:40")
 e(".Lend:")
 e("    s_endpgm")
+# ---------------------------------------------------------------- key split: o (unnormalised), m, l of this range -> partial buffers
+e(".Lempty:")
+for r in list(range(16)) + list(range(32, 48)):
+    e(f"    v_mov_b32_e32 {v(r)}, 0")
+e(f"    v_mov_b32_e32 {v(V_M)}, 0xff800000")
+e(f"    v_mov_b32_e32 {v(V_L)}, 0")
+e("    s_branch .Lpart_store")
+e(".Lpart:")
+e("    s_nop 7")                                              # the last P.V results
+for half in range(2):
+    for r in range(0, 16, 2):
+        o1, o2 = 32 * half + r, 32 * half + 16 + r
+        e(f"    v_pk_fma_f32 {v(o1, 2)}, {v(o2, 2)}, {S_INV2}, {v(o1, 2)}")
+e(".Lpart_store:")
+e("    s_load_dwordx4 s[4:7], s[0:1], 0x68")                  # o_part, m_part   (the Q pointers are dead)
+e("    s_load_dwordx2 s[8:9], s[0:1], 0x78")                  # l_part
+# pbase = ((z * NIc + img) * 4 + head) * Kc + q0 + 32 wave + lr ; o at pbase * 64 floats (+ 8 g4 + 4 h, +32 for half b)
+e(f"    s_mul_i32 {S_TMP}, {S_Z}, {S_NIC}")
+e(f"    s_add_u32 {S_TMP}, {S_TMP}, {S_IMG}")
+e(f"    s_lshl_b32 {S_TMP}, {S_TMP}, 2")
+e(f"    s_add_u32 {S_TMP}, {S_TMP}, {S_HEAD}")
+e(f"    s_mul_i32 {S_TMP}, {S_TMP}, {S_KC}")
+e(f"    s_lshl_b32 {S_TMP3}, {S_WAVE}, 5")
+e(f"    s_add_u32 {S_TMP3}, {S_TMP3}, {S_Q0}")
+e(f"    s_add_u32 {S_TMP}, {S_TMP}, {S_TMP3}")
+e(f"    v_and_b32_e32 {v(T)}, 31, {v(T)}")                      # lr (T still holds the lane)
+e(f"    v_add_u32_e32 {v(T)}, {S_TMP}, {v(T)}")                 # pbase
+e(f"    v_lshrrev_b32_e32 {v(T + 1)}, 2, {v(V_ROW)}")           # h
+e(f"    v_lshlrev_b32_e32 {v(T + 2)}, 8, {v(T)}")               # * 64 floats (the partial buffers are far below 4 GiB)
+e(f"    v_lshl_add_u32 {v(T + 2)}, {v(T + 1)}, 4, {v(T + 2)}")  # + 4 h floats
+e(f"    v_lshlrev_b32_e32 {v(T + 3)}, 2, {v(T)}")               # m / l: one float per (range, image, head, query)
+e(f"    s_and_b64 exec, exec, {S_QV}")                           # only real queries are stored
+e("    s_cbranch_execz .Lend")
+e("    s_waitcnt lgkmcnt(0)")
+for g4 in range(4):
+    e(f"    global_store_dwordx4 {v(T + 2)}, {v(4 * g4, 4)}, s[4:5] offset:{32 * g4}")
+    e(f"    global_store_dwordx4 {v(T + 2)}, {v(32 + 4 * g4, 4)}, s[4:5] offset:{128 + 32 * g4}")
+e(f"    v_cmp_eq_u32_e32 vcc, 0, {v(T + 1)}")
+e("    s_and_b64 exec, exec, vcc")
+e("    s_cbranch_execz .Lend")
+e(f"    global_store_dword {v(T + 3)}, {v(V_M)}, s[6:7]")
+e(f"    global_store_dword {v(T + 3)}, {v(V_L)}, s[8:9]")
+e("    s_endpgm")
 # ---------------------------------------------------------------- O *= alpha (rare)
 e(".Lrescale_sub:")
 for r in range(0, 64, 2):
@@ -726,7 +791,7 @@ e("    .p2align 6")
 e(f"    .amdhsa_kernel {KERNEL}")
 e("        .amdhsa_group_segment_fixed_size 65536")
 e("        .amdhsa_private_segment_fixed_size 0")
-e("        .amdhsa_kernarg_size 104")
+e(f"        .amdhsa_kernarg_size {KARG}")
 e("        .amdhsa_user_sgpr_count 2")
 e("        .amdhsa_user_sgpr_kernarg_segment_ptr 1")
 e("        .amdhsa_system_sgpr_workgroup_id_x 1")
@@ -750,7 +815,7 @@ e("amdhsa.version: [ 1, 2 ]")
 e("amdhsa.kernels:")
 e(f"  - .name: {KERNEL}")
 e(f"    .symbol: {KERNEL}.kd")
-e("    .kernarg_segment_size: 104")
+e(f"    .kernarg_segment_size: {KARG}")
 e("    .group_segment_fixed_size: 65536")
 e("    .private_segment_fixed_size: 0")
 e("    .kernarg_segment_align: 8")
@@ -767,6 +832,10 @@ for i in range(9):
 for i in range(8):
     e(f"      - {{.size: 4, .offset: {off}, .value_kind: by_value}}")
     off += 4
+for i in range(4 if STAMP else 3):
+    e(f"      - {{.size: 8, .offset: {off}, .value_kind: global_buffer, .address_space: global}}")
+    off += 8
+assert off == KARG
 e("...")
 e("    .end_amdgpu_metadata")
 

@@ -649,14 +649,18 @@ __global__ __launch_bounds__(1024) void lg_decide_kernel(
     }
 }
 
-// gather surviving rows: x, enc -> tmp (then copied back by lg_copyback_kernel)
+// gather surviving rows: x, enc -> tmp (back == 0), then tmp -> x, enc (back == 1).  On the split-precision path the
+// copy back also refreshes the (hi, lo) planes of the rows it moves (xs_hi != nullptr: what a separate
+// lg_split_rows_kernel(only_moved) launch did - the same rows, the same split, one launch less per layer)
 __global__ __launch_bounds__(256) void lg_gather_kernel(const float* __restrict__ x,
                                                         const float* __restrict__ ec,
                                                         const float* __restrict__ es,
                                                         const int* __restrict__ gmap,
                                                         float* __restrict__ tx, float* __restrict__ tc,
                                                         float* __restrict__ ts,
-                                                        const LGCtrl* __restrict__ ctrl, int Kc, int NI, int back) {
+                                                        const LGCtrl* __restrict__ ctrl, int Kc, int NI, int back,
+                                                        _Float16* __restrict__ xs_hi, _Float16* __restrict__ xs_lo,
+                                                        int NIc) {
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int img = gw / Kc, row = gw % Kc;
@@ -669,7 +673,17 @@ __global__ __launch_bounds__(256) void lg_gather_kernel(const float* __restrict_
     const float* sx = back ? tx : x; float* dx = back ? const_cast<float*>(x) : tx;
     const float* sc = back ? tc : ec; float* dc = back ? const_cast<float*>(ec) : tc;
     const float* ss = back ? ts : es; float* ds = back ? const_cast<float*>(es) : ts;
-    *reinterpret_cast<float4*>(dx + dst * D + lane * 4) = *reinterpret_cast<const float4*>(sx + src * D + lane * 4);
+    const float4 val = *reinterpret_cast<const float4*>(sx + src * D + lane * 4);
+    *reinterpret_cast<float4*>(dx + dst * D + lane * 4) = val;
+    if (back && xs_hi) {
+        const float v4[4] = {val.x, val.y, val.z, val.w};
+        half4 hh, ll;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { _Float16 a, b; split_f32(v4[e], a, b, range_flag_of(ctrl, img)); hh[e] = a; ll[e] = b; }
+        const size_t o = panel_index(img * Kc + row, lane * 4, NIc * Kc);
+        *reinterpret_cast<half4*>(xs_hi + o) = hh;
+        *reinterpret_cast<half4*>(xs_lo + o) = ll;
+    }
     if (lane < 32) dc[dst * ENC + lane] = sc[src * ENC + lane];
     else ds[dst * ENC + lane - 32] = ss[src * ENC + lane - 32];
 }
@@ -2103,11 +2117,14 @@ float conf_threshold(int layer) {   // np.clip(0.8 + 0.1 * exp(-4 i / n_layers),
 // workgroups without it, otherwise split the keys (partials + merge launch)
 int attn_key_split(const sslam_lightglue* g, int NI) {
     int ks = 1;
-    if (g->force_ks > 0) ks = g->force_ks;
-    else if (g->force_ks < 0) ks = 1;          // (test hooks, no key split: -1 the 4-wave r02 kernel, -2 the half-step kernel, -3 the assembly kernel)
-    else {
+    if (g->force_ks > 100) ks = g->force_ks - 100;     // (test hook: forced split, assembly kernel)
+    else if (g->force_ks > 0) ks = g->force_ks;        // (test hook: forced split, the 4-wave r02 kernel)
+    else if (g->force_ks < 0 && g->force_ks != -4) ks = 1;   // (test hooks, no key split: -1 the 4-wave r02 kernel, -2 the half-step kernel, -3 the assembly kernel)
+    else {                                             // 0, and -4 = the same policy on the 4-wave r02 kernel
+        // one workgroup per CU is the measured optimum of the assembly kernel (2048-keypoint pair, 128 units: no split 1.68 ms
+        // per forward, 2 ranges 1.59, 4 ranges 1.65; the 4-wave kernel 1.69 at 2 or 4)
         const int units = NI * NH * (g->Kc / AQ);
-        while (ks < 4 && units * ks < 512 && g->Kc / AK >= 2 * ks * 4) ks *= 2;
+        while (ks < 4 && units * ks < 256 && g->Kc / AK >= 2 * ks * 4) ks *= 2;
     }
     return ks > g->KSmax ? g->KSmax : ks;
 }
@@ -2212,11 +2229,12 @@ struct AttnAsmArgs {                // the kernel's argument segment (gen_lg_att
     const _Float16 *q_hi, *q_lo, *k_hi, *k_lo, *vt_hi, *vt_lo;
     _Float16 *msg_hi, *msg_lo;
     const LGCtrl* ctrl;
-    int cross, Kc, NIc, nqb, nslab;
+    int cross, Kc, NIc, nqb, nslab; // nslab = key ranges x images x heads = gridDim.y
     unsigned magic;                 // floor(2^32 / nqb) + 1: idx / nqb = mulhi(idx, magic) for idx * nqb < 2^32 (nqb > 1)
-    int pad[2];
+    int nih, lks;                   // images x heads ; log2(key ranges): 0 = the kernel normalises and writes the context planes
+    float *o_part, *m_part, *l_part;   // lks > 0: the unnormalised (o, m, l) of a key range, lg_attention_p_kernel's layout
 };
-static_assert(sizeof(AttnAsmArgs) == 104, "kernel argument segment of lg_attention_asm_kernel");
+static_assert(sizeof(AttnAsmArgs) == 128, "kernel argument segment of lg_attention_asm_kernel");
 constexpr int ASM_MAX_DEVICES = 64;
 hipFunction_t g_attn_asm_fn[ASM_MAX_DEVICES] = {};
 std::mutex g_attn_asm_mutex;
@@ -2236,11 +2254,13 @@ void launch_attention_h(sslam_lightglue* g, hipStream_t s, int NI, SplitPtr Q, S
     AttnArgsH a{Q, K, VT, cross, g->o_part, g->m_part, g->l_part, SplitOut{g->msgs_hi, g->msgs_lo}, KS, g->Kc,
                 g->NIc, g->ctrl};
     attn_event(g, s, true);
-    if (KS == 1 && (g->force_ks == 0 || g->force_ks == -3)) {
-        // no key split (batched launches; debug_key_split(lg, -3) at any size): the hand-scheduled assembly kernel - the arithmetic, LDS images and
-        // results of lg_attention_hs_kernel bit for bit, 8 - 10 % faster (profiles/r03_attention_experiments.md)
+    if (g->force_ks == 0 || g->force_ks == -3 || g->force_ks > 100) {
+        // the hand-scheduled assembly kernel - the arithmetic, LDS images and results of lg_attention_hs_kernel (no key split: batched
+        // launches, debug_key_split(lg, -3)) and of lg_attention_p_kernel's key ranges (single pairs) bit for bit, 8 - 10 % faster
+        // (profiles/r03_attention_experiments.md)
+        const int lks = KS == 4 ? 2 : KS == 2 ? 1 : 0;
         AttnAsmArgs k{Q.hi, Q.lo, K.hi, K.lo, VT.hi, VT.lo, g->msgs_hi, g->msgs_lo, g->ctrl, cross, g->Kc, g->NIc,
-                      sslam::cdiv(g->Kc, AQ), NI * NH, 0u, {0, 0}};
+                      sslam::cdiv(g->Kc, AQ), NI * NH * KS, 0u, NI * NH, lks, g->o_part, g->m_part, g->l_part};
         k.magic = k.nqb > 1 ? (unsigned)((1ull << 32) / (unsigned)k.nqb + 1) : 0u;
         size_t sz = sizeof(k);
         void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
@@ -2379,13 +2399,12 @@ int lg_enqueue(sslam_lightglue* g, int pairs, const StageSrc& src, float min_con
                            g->width_conf, g->prune_min, do_stop, g->conf, g->mat, g->ind, g->gmap,
                            g->prune, g->ctrl, Kc);
         if (do_prune) {
+            const bool sp = g->precision == 1;        // token rows moved: the copy back refreshes their split planes
             hipLaunchKernelGGL(lg_gather_kernel, dim3(tokblocks), dim3(256), 0, s, g->x, g->enc_cos,
-                               g->enc_sin, g->gmap, g->tx, g->tc, g->ts, g->ctrl, Kc, NI, 0);
+                               g->enc_sin, g->gmap, g->tx, g->tc, g->ts, g->ctrl, Kc, NI, 0, nullptr, nullptr, g->NIc);
             hipLaunchKernelGGL(lg_gather_kernel, dim3(tokblocks), dim3(256), 0, s, g->x, g->enc_cos,
-                               g->enc_sin, g->gmap, g->tx, g->tc, g->ts, g->ctrl, Kc, NI, 1);
-            if (g->precision == 1)      // token rows moved: refresh their split planes
-                hipLaunchKernelGGL(lg_split_rows_kernel, splitblocks, dim3(256), 0, s, g->x, g->xs_hi,
-                                   g->xs_lo, D, Kc, NI, g->NIc, g->ctrl, 1);
+                               g->enc_sin, g->gmap, g->tx, g->tc, g->ts, g->ctrl, Kc, NI, 1, sp ? g->xs_hi : nullptr,
+                               sp ? g->xs_lo : nullptr, g->NIc);
         }
     }
     // ---- assignment with log_assignment[stop_layer]
@@ -2550,6 +2569,7 @@ int sslam_lightglue_create_batched(sslam_ctx* ctx, const float* weights, size_t 
                                  "split-precision path");
         }
     }
+    sslam::ctx_retain(ctx);
     *out = g;
     return 0;
 }
@@ -2565,7 +2585,9 @@ int sslam_lightglue_destroy(sslam_lightglue* g) {
     g->graphs.clear();
     for (hipEvent_t e : g->ev) (void)hipEventDestroy(e);
     g->arena.release();
+    sslam_ctx* ctx = g->ctx;
     delete g;
+    sslam::ctx_release(ctx);
     return 0;
 }
 
@@ -2752,9 +2774,10 @@ int sslam_lightglue_debug_layers(sslam_lightglue* g, int layers, int self_only) 
 
 /* Test hook: force the key split of the attention launches (0 = chosen by batch size). */
 int sslam_lightglue_debug_key_split(sslam_lightglue* g, int ks) {
-    SSLAM_REQUIRE(g != nullptr && (ks == -3 || ks == -2 || ks == -1 || ks == 0 || ks == 1 || ks == 2 || ks == 4),
-                  "sslam_lightglue_debug_key_split: ks must be -3 (no split, assembly kernel), -2 (no split, compiler-scheduled "
-                  "half-step kernel), -1 (no split, r02 4-wave kernel), 0, 1, 2 or 4");
+    SSLAM_REQUIRE(g != nullptr && ((ks >= -4 && ks <= 2) || ks == 4 || ks == 101 || ks == 102 || ks == 104),
+                  "sslam_lightglue_debug_key_split: ks must be -4 (split by size, r02 4-wave kernel), -3 (no split, assembly kernel), "
+                  "-2 (no split, compiler-scheduled half-step kernel), -1 (no split, r02 4-wave kernel), 0, 1, 2 or 4 (forced split, "
+                  "r02 4-wave kernel), 101, 102 or 104 (forced split, assembly kernel)");
     g->settings_changed();
     g->force_ks = ks;
     return 0;

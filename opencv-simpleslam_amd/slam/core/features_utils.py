@@ -146,7 +146,7 @@ class _DeviceFeatureRing:
         self.pin_desc = self.pin_rec[self.o_desc:self.o_score].view(np.float32).reshape(K, 128)
         self.by_id = {}                  # id(descriptor array) -> entry
         self.turn = 0
-        self.img_dev, self.img_cap, self.pin_img = 0, 0, None
+        self.img_dev, self.img_cap = 0, 0
         self.tmp_xy = [m(K * 8), m(K * 8)]               # keypoints of an edited list (uploaded per call)
         out = m(16 + K * 8 + K * 4)                      # match results, [info 16 B | pairs K x 2 | scores K]
         self.out_info, self.out_ij, self.out_sc = out, out + 16, out + 16 + K * 8
@@ -172,16 +172,15 @@ class _DeviceFeatureRing:
                 ctx.sync(); ctx.free(self.img_dev)
             self.img_cap = max(img.nbytes, 1241 * 376 * 3)
             self.img_dev = ctx.malloc(self.img_cap)
-            self.pin_img = ctx.host_alloc(self.img_cap)
         sl = self.slots[self.turn % self.SLOTS]
         self.turn += 1
         if sl["key"] is not None:
             self.by_id.pop(sl["key"], None)
             sl["key"] = None
         K = self.K
-        stage = self.pin_img[:img.nbytes]
-        np.copyto(stage.reshape(img.shape), img)         # (also makes a strided view contiguous)
-        ctx.h2d_async(self.img_dev, stage)
+        # (the image goes up straight from the caller's pageable array: the runtime's own staged copy, 69 us for
+        #  1.4 MB, beats a host copy into a page-locked stage + DMA, 57 + 41 us)
+        ctx.h2d_async(self.img_dev, np.ascontiguousarray(img))   # (pageable source: the call returns once the runtime staged it)
         det.extract_dev(self.img_dev, H, Wd, Cn, sl["xy"], sl["desc"], sl["score"], sl["cnt"], max_kpts=K)
         ctx.d2h_async(self.pin_rec, sl["base"])
         # the GPU needs ~0.5 ms from here: build the frame's KeyPoint objects meanwhile (their coordinates resolve

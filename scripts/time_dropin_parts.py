@@ -25,8 +25,7 @@ for im in imgs[3:]:
     sl = ring.slots[ring.turn % ring.SLOTS]; ring.turn += 1
     ctx.sync()
     t = time.perf_counter()
-    stage = ring.pin_img[:im.nbytes]; np.copyto(stage.reshape(im.shape), im); t = tick("image -> page-locked stage", t)
-    ctx.h2d_async(ring.img_dev, stage); ctx.sync(); t = tick("h2d image + sync", t)
+    ctx.h2d(ring.img_dev, im); t = tick("h2d image (pageable, synchronous)", t)
     det.extract_dev(ring.img_dev, 376, 1241, 3, sl["xy"], sl["desc"], sl["score"], sl["cnt"], max_kpts=K); t = tick("extract_dev enqueue", t)
     ctx.sync(); t = tick("sync (GPU work)", t)
     ctx.d2h_async(ring.pin_rec, sl["base"]); ctx.sync(); t = tick("d2h record + sync", t)

@@ -16,7 +16,8 @@ extern "C" const unsigned char sslam_lg_attention_asm_hsaco[1] = {0};      // (t
 // the hand-scheduled kernel (opencv-simpleslam_amd/csrc/gen_lg_attention_asm.py): loaded from the code object named by ATTN_HSACO
 struct AsmArgs {
     const void *q_hi, *q_lo, *k_hi, *k_lo, *vt_hi, *vt_lo; void *msg_hi, *msg_lo; const void* ctrl;
-    int cross, Kc, NIc, nqb, nslab; unsigned magic; unsigned* dbg;      // dbg: the stamp buffer of a diagnostic build
+    int cross, Kc, NIc, nqb, nslab; unsigned magic; int nih, lks;      // lks = 0: no key ranges here
+    float *o_part, *m_part, *l_part; unsigned* dbg;                    // dbg: the stamp buffer of a diagnostic build (offset 128)
 };
 static hipFunction_t asm_fn;
 static unsigned* g_dbg = nullptr;
@@ -29,7 +30,7 @@ static bool asm_load() {
 }
 static void asm_launch(const AttnArgsH& a, int NI) {
     AsmArgs k{a.Q.hi, a.Q.lo, a.K.hi, a.K.lo, a.VT.hi, a.VT.lo, a.msg.hi, a.msg.lo, a.ctrl, a.cross, a.Kc, a.NIc,
-              sslam::cdiv(a.Kc, AQ), NI * NH, 0, g_dbg};
+              sslam::cdiv(a.Kc, AQ), NI * NH, 0, NI * NH, 0, nullptr, nullptr, nullptr, g_dbg};
     k.magic = k.nqb > 1 ? (unsigned)((1ull << 32) / (unsigned)k.nqb + 1) : 0;
     size_t sz = sizeof(k);
     void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};

@@ -225,3 +225,52 @@ def test_assembly_attention_at_small_capacities(gpu_ctx, max_kpts, sizes):
             got = dev.run(batch, 0.5)
     assert not batch.range_overflow()
     dev.free(); batch.close()
+
+
+@pytest.mark.parametrize("seed,kw", [(3, dict(match_gain=4.0, match_bias=3.0)),
+                                     (4, dict(match_gain=4.0, match_bias=-4.6, conf_bias=2.3))])
+def test_assembly_attention_key_ranges_give_the_4_wave_kernel_partials(gpu_ctx, seed, kw):
+    """Key ranges on the assembly kernel (what a single pair runs: 2 or 4 ranges of the keys + the merge launch): the
+    same (o, m, l) partials as lg_attention_p_kernel with the same split, so everything downstream is bit-identical -
+    full and ragged key counts, a range that holds the image's ragged last tile, fewer key tiles than ranges (empty
+    ranges: o = 0, m = -inf, l = 0), a 1-keypoint image, and (second weight set) pruning and an early stop that shrink
+    the key counts from layer to layer.  The default policy must also give the oracle's indices."""
+    W, LG = load_pkg("weights"), load_pkg("lightglue").LightGlueHIP
+    sd = W.random_lightglue_state_dict(seed, **kw)
+    sizes = [(1024, 1024), (700, 900), (130, 64), (1000, 1), (257, 511)]
+    pairs = [lg_inputs.make_pair(m, n, seed=5 * m + n) for m, n in sizes]
+    batch = LG(sd, max_kpts=1024, max_pairs=len(pairs), ctx=gpu_ctx)
+    dev = DevBatch(gpu_ctx, pairs, 1024)
+    for ks in (2, 4):
+        batch.debug_key_split(ks)
+        ref = dev.run(batch, 0.5)
+        batch.debug_key_split(100 + ks)
+        got = dev.run(batch, 0.5)
+        for (ij, sc, info), (r_ij, r_sc, r_info) in zip(got, ref):
+            np.testing.assert_array_equal(ij, r_ij)
+            np.testing.assert_array_equal(sc, r_sc)
+            np.testing.assert_array_equal(info, r_info)
+    if seed == 3:
+        assert sum(len(g[0]) for g in got) > 20
+    else:
+        assert any(info[1] < 9 for _, _, info in got)          # (this weight set stops early and prunes)
+    # one pair per call: the default policy (key ranges on the assembly kernel) against the same policy on the 4-wave
+    # kernel, and against the oracle
+    single = LG(sd, max_kpts=1024, ctx=gpu_ctx)
+    for pr in pairs:
+        single.debug_key_split(-4)
+        r_ij, r_sc, r_stop = single.match(*pr, min_conf=0.5)
+        single.debug_key_split(0)
+        ij, sc, stop = single.match(*pr, min_conf=0.5)
+        np.testing.assert_array_equal(ij, r_ij)
+        np.testing.assert_array_equal(sc, r_sc)
+        assert stop == r_stop
+        o_ij, o_sc, o_stop = _oracle(sd, pr, 0.5)
+        np.testing.assert_array_equal(ij, o_ij)
+        # (an image pruned down to no keypoints at all - the 1-keypoint image under this weight set - ends the pair on
+        # the device at that layer with no matches; upstream keeps stepping the other image until its confidence test
+        # fires and reports that later layer with the same empty result: the layer number is compared elsewhere)
+        if len(pr[2]) > 1:
+            assert stop == o_stop
+    assert not batch.range_overflow() and not single.range_overflow()
+    dev.free(); batch.close(); single.close()
