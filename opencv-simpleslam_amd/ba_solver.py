@@ -15,11 +15,13 @@ Two drivers share that algorithm:
 
 * `solve_device` - `sslam_ba_solve_host` (csrc/ba_lm.hip): the whole loop on the GPU, control
   state in a device control block, one enqueue per solve.
-  Takes up to MAX_DEVICE_POSES optimised poses (local BA: window_size 6 / 10).
-* `solve_host` - the numpy loop below around the HIP residual/Jacobian kernel; used for
-  global BA (hundreds of optimised poses: the dense Schur layout of the device path does
-  not fit) and as the independent restatement the device path is tested against.  Its Schur
-  complement is accumulated sparsely, per pair of observations of one landmark.
+  Takes up to MAX_DEVICE_POSES optimised poses: local BA (window_size 6 / 10, reduced system
+  factored in LDS) and global BA of a map of that many keyframes (factored in device memory)
+  as long as its dense Schur operands ([poses][points][18] twice) stay under
+  MAX_DEVICE_SCHUR_BYTES.
+* `solve_host` - the numpy loop below around the HIP residual/Jacobian kernel; used beyond
+  those bounds and as the independent restatement the device path is tested against.  Its
+  Schur complement is accumulated sparsely, per pair of observations of one landmark.
 
 `solve` picks by problem size (override: SSLAM_BA_SOLVER=host|device).
 """
@@ -106,7 +108,8 @@ def _huber(s, delta):
     return rho, w
 
 
-MAX_DEVICE_POSES = 12
+MAX_DEVICE_POSES = 256                 # csrc/ba_lm.hip MAX_PO_BIG
+MAX_DEVICE_SCHUR_BYTES = 32 << 30      # dense [Po][Q][18] f64 x 2 (the library refuses more)
 _PAIR_CHUNK = 1 << 18        # (a, b) observation pairs per accumulation chunk of the host Schur loop
 _TERMINATION = {0: "max iterations", 1: "gradient tolerance", 2: "parameter tolerance",
                 3: "function tolerance", 4: "trust region collapsed"}
@@ -144,7 +147,8 @@ def solve(prob: BAProblem, max_iters: int, huber_delta: float = 2.0, ctx=None,
     import os
     mode = os.environ.get("SSLAM_BA_SOLVER", "auto")
     n_opt = int(np.count_nonzero(~np.asarray(prob.pose_const, bool)))
-    if mode == "device" or (mode == "auto" and n_opt <= MAX_DEVICE_POSES and int(max_iters) > 0):
+    fits = n_opt <= MAX_DEVICE_POSES and n_opt * len(prob.X) * 288 <= MAX_DEVICE_SCHUR_BYTES
+    if mode == "device" or (mode == "auto" and fits and int(max_iters) > 0):
         return solve_device(prob, max_iters, huber_delta, ctx, points_const)
     return solve_host(prob, max_iters, huber_delta, ctx, points_const)
 

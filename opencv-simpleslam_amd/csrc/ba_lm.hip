@@ -3,7 +3,9 @@
 // Stands where `pyceres.solve(opts, problem, summary)` stands in the reference
 // (slam/core/ba_utils.py:288-293) for the sliding-window problem `_core_ba` builds
 // (:220-286): <= 12 optimised poses (window_size 6 / 10), all earlier keyframes constant,
-// <= max_points landmarks, Huber(2.0) on every reprojection block, Eigen-quaternion manifold.
+// <= max_points landmarks, Huber(2.0) on every reprojection block, Eigen-quaternion manifold -
+// and, r03, for `global_bundle_adjustment`'s problem (:170-218) up to 256 optimised poses (the
+// reduced system is then factored in device memory, lm_solve_big_kernel).
 // It is the same algorithm as the host loop in ba_solver.py (Ceres' trust-region policy with
 // its default constants, Schur complement onto the poses); here the whole loop - linearise,
 // reduce, factor, step, evaluate, accept/reject, terminate - runs as a FIXED launch sequence
@@ -23,8 +25,11 @@ namespace {
 
 constexpr int LM_T = 256;          // threads per block, element-wise kernels
 constexpr int LM_RT = 128;         // threads per block, slab reductions
-constexpr int MAX_PO = 12;         // optimised poses the device path takes
+constexpr int MAX_PO = 12;         // optimised poses whose reduced system is factored in LDS (local BA: window 6 / 10)
 constexpr int MAX_M = 6 * MAX_PO;
+constexpr int MAX_PO_BIG = 256;    // optimised poses the device path takes at all (global BA): the reduced system is then
+constexpr int MAX_M_BIG = 6 * MAX_PO_BIG;   // factored in place in device memory by one 1024-thread workgroup
+constexpr int LM_BT = 1024;
 
 struct LMCtrl {
     int cur;            // which (q, t, X) buffer holds the accepted iterate
@@ -51,6 +56,7 @@ struct LMArgs {
     double *Wd, *Y;                                      // [Po][Q][18]
     double *U, *gP;                                      // [Po][36], [Po][6]
     double *S, *rhs, *dP;                                // [m][m], [m], [Po][6]
+    double* Lbig;                                        // [m][m] factor of the reduced system when m > MAX_M
     double* dX;                                          // [Q][3]
     double *pc, *pm, *pstep, *px, *pgmax;                // block partials
     int* pbad;
@@ -349,6 +355,73 @@ __global__ __launch_bounds__(LM_T) void lm_solve_kernel(LMArgs a) {
     }
 }
 
+// ---- 5b. the same for more than MAX_PO optimised poses (global BA, ba_utils.py:170-218): the factor lives in device
+// memory (L2-resident: 242 KB at 29 poses, 18.9 MB at 256), one workgroup of 1024 threads runs the right-looking
+// Cholesky column by column and the two triangular solves column-oriented (every y[k] takes its subtractions in the
+// same order as the serial loop of the LDS kernel would apply them in the forward pass)
+__global__ __launch_bounds__(LM_BT) void lm_solve_big_kernel(LMArgs a) {
+    __shared__ double sh[LM_BT];
+    __shared__ double y[MAX_M_BIG];
+    __shared__ int fail;
+    LMCtrl* c = a.ctrl;
+    if (c->done) return;
+    const int t = threadIdx.x, m = 6 * a.Po;
+    double gm = 0.0;
+    for (int k = t; k < a.nb_pt; k += LM_BT) gm = fmax(gm, a.pgmax[k]);
+    for (int k = t; k < m; k += LM_BT) gm = fmax(gm, fabs(a.gP[k]));
+    gm = block_max(gm, sh);
+    if (t == 0) { c->iterations += 1; c->chol_fail = 0; fail = 0; }
+    __syncthreads();
+    if (gm < 1e-10) {
+        if (t == 0) c->done = 1;
+        return;
+    }
+    double* L = a.Lbig;
+    for (size_t e = t; e < (size_t)m * m; e += LM_BT) L[e] = a.S[e];
+    __syncthreads();
+    for (int k = 0; k < m; ++k) {
+        if (t == 0) {
+            const double d = L[(size_t)k * m + k];
+            if (!(d > 0.0) || !isfinite(d)) fail = 1;
+            L[(size_t)k * m + k] = sqrt(d);
+        }
+        __syncthreads();
+        if (fail) break;
+        const double dk = L[(size_t)k * m + k];
+        for (int i = k + 1 + t; i < m; i += LM_BT) L[(size_t)i * m + k] /= dk;
+        __syncthreads();
+        // trailing update of the lower triangle: a wave per row i, lanes over the columns jj <= i
+        const int lane = t & 63, wave = t >> 6;
+        for (int i = k + 1 + wave; i < m; i += LM_BT / 64) {
+            const double lik = L[(size_t)i * m + k];
+            for (int jj = k + 1 + lane; jj <= i; jj += 64) L[(size_t)i * m + jj] -= lik * L[(size_t)jj * m + k];
+        }
+        __syncthreads();
+    }
+    if (fail) {
+        if (t == 0) c->chol_fail = 1;
+        for (int k = t; k < m; k += LM_BT) a.dP[k] = 0.0;
+        return;
+    }
+    for (int i = t; i < m; i += LM_BT) y[i] = a.rhs[i];
+    __syncthreads();
+    for (int i = 0; i < m; ++i) {                     // L y = rhs
+        if (t == 0) y[i] /= L[(size_t)i * m + i];
+        __syncthreads();
+        const double yi = y[i];
+        for (int k = i + 1 + t; k < m; k += LM_BT) y[k] -= L[(size_t)k * m + i] * yi;
+        __syncthreads();
+    }
+    for (int i = m - 1; i >= 0; --i) {                // L^T x = y
+        if (t == 0) y[i] /= L[(size_t)i * m + i];
+        __syncthreads();
+        const double yi = y[i];
+        for (int k = t; k < i; k += LM_BT) y[k] -= L[(size_t)i * m + k] * yi;
+        __syncthreads();
+    }
+    for (int k = t; k < m; k += LM_BT) a.dP[k] = y[k];
+}
+
 // ---- 6. back-substitute landmarks, build the candidate (thread / point) ----------------------
 __global__ __launch_bounds__(LM_T) void lm_update_points_kernel(LMArgs a) {
     __shared__ double sh[LM_T];
@@ -514,8 +587,13 @@ extern "C" int sslam_ba_solve_host(sslam_ctx* ctx, int n_obs, const int32_t* pos
     for (int p = 0; p < n_poses; ++p)
         if (!pose_const[p]) { pose_slot[p] = (int)slot_pose.size(); slot_pose.push_back(p); }
     const int Po = (int)slot_pose.size();
-    SSLAM_REQUIRE(Po <= MAX_PO, "sslam_ba_solve_host: %d optimised poses, the device solver takes <= %d "
-                  "(use the host Schur loop for global BA)", Po, MAX_PO);
+    SSLAM_REQUIRE(Po <= MAX_PO_BIG, "sslam_ba_solve_host: %d optimised poses, the device solver takes <= %d "
+                  "(use the host Schur loop beyond)", Po, MAX_PO_BIG);
+    // the Schur operands are dense [Po][Q][18] (a local window sees most of its points from most of its poses);
+    // a global problem too large for that form is the host loop's
+    SSLAM_REQUIRE((double)Po * (double)n_points * 288.0 <= 32.0 * 1024 * 1024 * 1024,
+                  "sslam_ba_solve_host: %d optimised poses x %d points need %.1f GB of dense Schur operands "
+                  "(limit 32 GB; use the host Schur loop)", Po, n_points, (double)Po * n_points * 288.0 / 1073741824.0);
     // CSR of observations by point and by optimised-pose slot (stable: observation order kept)
     std::vector<int32_t> obs_slot(n_obs), pt_ptr(n_points + 1, 0), pt_obs(n_obs), ps_ptr(Po + 1, 0), ps_obs;
     for (int i = 0; i < n_obs; ++i) {
@@ -551,6 +629,8 @@ extern "C" int sslam_ba_solve_host(sslam_ctx* ctx, int n_obs, const int32_t* pos
     const size_t o_Wd = carve((size_t)Po * Q * 144), o_Y = carve((size_t)Po * Q * 144);
     const size_t o_U = carve((size_t)Po * 288), o_gP = carve((size_t)Po * 48);
     const size_t o_S = carve(m * m * 8), o_rhs = carve(m * 8), o_dP = carve(m * 8), o_dX = carve(Q * 24);
+    const bool big = Po > MAX_PO;
+    const size_t o_Lb = carve(big ? m * m * 8 : 0);
     const size_t o_pc = carve((size_t)nb_obs * 8), o_pm = carve((size_t)nb_obs * 8), o_pb = carve((size_t)nb_obs * 4);
     const size_t o_ps = carve((size_t)nb_pt * 8), o_px = carve((size_t)nb_pt * 8), o_pg = carve((size_t)nb_pt * 8);
     const size_t o_ctrl = carve(sizeof(LMCtrl));
@@ -589,6 +669,7 @@ extern "C" int sslam_ba_solve_host(sslam_ctx* ctx, int n_obs, const int32_t* pos
     a.rw = (double*)(b + o_rw); a.JXw = (double*)(b + o_JX); a.Jpw = (double*)(b + o_Jp);
     a.V = (double*)(b + o_V); a.gX = (double*)(b + o_gX); a.Vinv = (double*)(b + o_Vi);
     a.Wd = (double*)(b + o_Wd); a.Y = (double*)(b + o_Y); a.U = (double*)(b + o_U); a.gP = (double*)(b + o_gP);
+    a.Lbig = (double*)(b + o_Lb);
     a.S = (double*)(b + o_S); a.rhs = (double*)(b + o_rhs); a.dP = (double*)(b + o_dP); a.dX = (double*)(b + o_dX);
     a.pc = (double*)(b + o_pc); a.pm = (double*)(b + o_pm); a.pbad = (int*)(b + o_pb);
     a.pstep = (double*)(b + o_ps); a.px = (double*)(b + o_px); a.pgmax = (double*)(b + o_pg);
@@ -603,7 +684,8 @@ extern "C" int sslam_ba_solve_host(sslam_ctx* ctx, int n_obs, const int32_t* pos
             hipLaunchKernelGGL(lm_pose_kernel, dim3(Po), dim3(LM_RT), 0, s, a);
             hipLaunchKernelGGL(lm_schur_kernel, dim3(Po, Po + 1), dim3(LM_RT), 0, s, a);
         }
-        hipLaunchKernelGGL(lm_solve_kernel, dim3(1), dim3(LM_T), 0, s, a);
+        if (big) hipLaunchKernelGGL(lm_solve_big_kernel, dim3(1), dim3(LM_BT), 0, s, a);
+        else hipLaunchKernelGGL(lm_solve_kernel, dim3(1), dim3(LM_T), 0, s, a);
         hipLaunchKernelGGL(lm_update_points_kernel, dim3(nb_pt), dim3(LM_T), 0, s, a);
         hipLaunchKernelGGL(lm_update_poses_kernel, dim3(1), dim3(64), 0, s, a);
         hipLaunchKernelGGL(lm_eval_kernel<true>, dim3(nb_obs), dim3(LM_T), 0, s, a);

@@ -31,8 +31,8 @@ import numpy as np
 import ctypes as _C
 import weakref
 
-from .types import (DMatch, KeyPoint, KeyPointList, HAVE_CV2, keypoint_shells, keypoints_from_xy, matches_from_ij,
-                    xy_from_keypoints)
+from .types import (DMatch, KeyPoint, KeyPointList, HAVE_CV2, keypoint_shells, keypoints_from_xy, match_shells,
+                    matches_from_ij, xy_from_keypoints)
 from ... import _native, weights as _weights
 from ...aliked import AlikedHIP
 from ...lightglue import LightGlueHIP
@@ -244,18 +244,25 @@ def _as_numpy_f32(x):
 
 
 def _match_resident(ring, matcher, a, b, thr):
-    """Both frames are still on the GPU: enqueue the match on their records, read back {count, pairs}."""
+    """Both frames are still on the GPU: enqueue the match on their records, read back {count, pairs} -> list[DMatch]."""
     ctx = ring.ctx
     matcher.match_dev(a[0], a[1], a[2], b[0], b[1], b[2], ring.out_ij, ring.out_sc, ring.out_info, min_conf=thr,
                       m_dev=a[3], n_dev=b[3])
     ctx.d2h_async(ring.pin_match, ring.out_info)           # {count, pairs} in one copy into page-locked memory
+    # the GPU needs > 1 ms from here: build the DMatch objects meanwhile (indices resolve against the array below)
+    shells, src = match_shells(min(a[2], b[2])) if match_shells is not None else (None, None)
     ctx.sync()
     k = int(ring.pin_info[0])
     if k < 0:
         matcher.range_overflow()                # reported here: clear the instance's sticky word
         raise _native.NativeError("feature_matcher: an activation left the fp16 range of the split-precision path "
                                   "(|value| >= 65520); rescale the descriptors or use matcher.set_precision('f32')")
-    return ring.pin_ij[:k].copy()
+    ij = ring.pin_ij[:k].copy()
+    if shells is None:
+        return _convert_lg_matches_to_opencv(ij)
+    src.ij = ij
+    del shells[k:]
+    return shells
 
 
 def feature_matcher(args, kp0, kp1, des0, des1, matcher):
@@ -270,7 +277,7 @@ def feature_matcher(args, kp0, kp1, des0, des1, matcher):
             a = ring.lookup(des0, kp0, 0)
             b = ring.lookup(des1, kp1, 1) if a is not None else None
             if a is not None and b is not None:
-                return _convert_lg_matches_to_opencv(_match_resident(ring, matcher, a, b, thr))
+                return _match_resident(ring, matcher, a, b, thr)
         ij, _scores, _stop = matcher.match(_convert_opencv_to_lg_kps(kp0), _as_numpy_f32(des0),
                                            _convert_opencv_to_lg_kps(kp1), _as_numpy_f32(des1), min_conf=thr)
         return _convert_lg_matches_to_opencv(ij)

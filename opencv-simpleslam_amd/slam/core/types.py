@@ -12,7 +12,8 @@ try:                                       # pragma: no cover - cv2 absent in th
     KeyPoint = _cv2.KeyPoint
     DMatch = _cv2.DMatch
     HAVE_CV2 = True
-    keypoint_shells = None                 # cv2.KeyPoint stores its coordinates at construction
+    keypoint_shells = None                 # cv2.KeyPoint / cv2.DMatch store their fields at construction
+    match_shells = None
 except Exception:                          # noqa: BLE001
     HAVE_CV2 = False
 
@@ -62,16 +63,23 @@ except Exception:                          # noqa: BLE001
 
     class _PointSource:
         """The [N,2] coordinates a frame's keypoint shells resolve their `pt` against (set once the
-        extraction has finished; converted to python floats in one C pass on the first read)."""
-        __slots__ = ("xy", "pts")
+        extraction has finished).  The first few reads convert their own element (the matcher's spot check
+        of 8 keypoints must not pay for the frame); from the 17th on, the whole array goes to python
+        floats in one C pass."""
+        __slots__ = ("xy", "pts", "reads")
 
         def __init__(self):
             self.xy = None
             self.pts = None
+            self.reads = 0
 
         def point(self, i):
             pts = self.pts
             if pts is None:
+                self.reads += 1
+                if self.reads <= 16:
+                    x, y = self.xy[i]
+                    return (float(x), float(y))
                 pts = self.pts = self.xy.tolist()
             x, y = pts[i]
             return (x, y)
@@ -91,17 +99,80 @@ except Exception:                          # noqa: BLE001
         return out, src
 
     class DMatch:
-        """Duck type of cv2.DMatch(queryIdx, trainIdx, imgIdx, distance)."""
-        __slots__ = ("queryIdx", "trainIdx", "imgIdx", "distance")
+        """Duck type of cv2.DMatch(queryIdx, trainIdx, imgIdx, distance).  A match made by `match_shells` reads
+        its two indices from the call's [K,2] pair array on first use (then keeps them), so the objects can be
+        built while the GPU is still matching."""
+        __slots__ = ("_q", "_t", "imgIdx", "distance", "_src", "_i")
 
         def __init__(self, queryIdx=-1, trainIdx=-1, imgIdx=0, distance=0.0):
-            self.queryIdx = int(queryIdx)
-            self.trainIdx = int(trainIdx)
+            self._q = int(queryIdx)
+            self._t = int(trainIdx)
             self.imgIdx = int(imgIdx)
             self.distance = float(distance)
 
+        def _resolve(self):
+            q, t = self._src.pair(self._i)
+            self._q, self._t = q, t
+
+        @property
+        def queryIdx(self):
+            try:
+                return self._q
+            except AttributeError:
+                self._resolve()
+                return self._q
+
+        @queryIdx.setter
+        def queryIdx(self, v):
+            if not hasattr(self, "_t"):
+                self._resolve()
+            self._q = int(v)
+
+        @property
+        def trainIdx(self):
+            try:
+                return self._t
+            except AttributeError:
+                self._resolve()
+                return self._t
+
+        @trainIdx.setter
+        def trainIdx(self, v):
+            if not hasattr(self, "_q"):
+                self._resolve()
+            self._t = int(v)
+
         def __repr__(self):
             return f"DMatch({self.queryIdx}->{self.trainIdx})"
+
+    class _PairSource:
+        __slots__ = ("ij", "pairs")
+
+        def __init__(self):
+            self.ij = None
+            self.pairs = None
+
+        def pair(self, i):
+            pairs = self.pairs
+            if pairs is None:
+                pairs = self.pairs = self.ij.tolist()
+            return pairs[i]
+
+    def match_shells(n):
+        """n DMatch(-, -, 0, 0.0) objects without indices yet + the source to hand the [>= n, 2] int array to
+        (`src.ij = ij`) before anyone reads an index."""
+        src = _PairSource()
+        new = DMatch.__new__
+        out = []
+        add = out.append
+        for i in range(n):
+            m = new(DMatch)
+            m._src = src
+            m._i = i
+            m.imgIdx = 0
+            m.distance = 0.0
+            add(m)
+        return out, src
 
 
 def keypoints_from_xy(xy):

@@ -18,3 +18,16 @@ for name, fn in (("device", S.solve_device), ("host", S.solve_host)):
         t0 = time.perf_counter(); s = fn(p, 12, 2.0); ts.append(time.perf_counter() - t0)
     print(f"{name:6s}: {np.median(ts)*1e3:9.2f} ms per solve  iters={s.iterations} steps={s.successful_steps} "
           f"cost {s.initial_cost:.1f} -> {s.final_cost:.1f} ({s.termination})")
+
+# global-BA shape (ba_utils.py:170-218): every keyframe but the first free
+wmap, kfs, K = ba_scenes.scaled_scene(n_kf=30, n_points=5000)
+prob, _, _ = bau.snapshot_problem(wmap, K, kfs, list(range(30)), [0], 30000)
+print(f"global shape: {len(prob.obs_pose)} observations, {len(prob.X)} points, {int((~prob.pose_const).sum())} opt + {int(prob.pose_const.sum())} fixed poses")
+for name, fn in (("device", S.solve_device), ("host", S.solve_host)):
+    fn(copy.deepcopy(prob), 12, 2.0)
+    ts = []
+    for _ in range(3 if name == "device" else 1):
+        p = copy.deepcopy(prob)
+        t0 = time.perf_counter(); s = fn(p, 12, 2.0); ts.append(time.perf_counter() - t0)
+    print(f"{name:6s}: {np.median(ts)*1e3:9.2f} ms per solve  iters={s.iterations} steps={s.successful_steps} "
+          f"cost {s.initial_cost:.1f} -> {s.final_cost:.1f} ({s.termination})")

@@ -92,26 +92,35 @@ def test_device_lm_matches_oracle_at_c3_size_and_is_deterministic():
     np.testing.assert_array_equal(dev.X, dev2.X)
 
 
-def test_host_schur_loop_with_more_than_12_free_poses_matches_oracle():
-    """Global-BA shape: 29 free poses (> MAX_DEVICE_POSES, so `solve` takes the host loop), one
-    gauge keyframe.  The loop accumulates the Schur complement per pair of observations of a
-    landmark; the oracle never forms a Schur complement."""
+def test_global_ba_shape_on_the_device_and_in_the_host_loop_match_the_oracle(monkeypatch):
+    """Global-BA shape: 29 free poses, one gauge keyframe - more than the 12 whose reduced system fits LDS, so the
+    device LM factors it in device memory (lm_solve_big_kernel); the host loop (SSLAM_BA_SOLVER=host) accumulates
+    the Schur complement per pair of observations of a landmark; the oracle never forms a Schur complement.  All
+    three must walk the same trust-region trajectory."""
     S = load_pkg("ba_solver")
     bau = load_pkg("slam.core.ba_utils")
     wmap, kfs, K = ba_scenes.scaled_scene(n_kf=30, n_points=1500)
     prob, _, _ = bau.snapshot_problem(wmap, K, kfs, list(range(30)), [0], 30000)
-    assert int(np.count_nonzero(~prob.pose_const)) == 29 > S.MAX_DEVICE_POSES
-    got = _clone(prob)
-    summ = S.solve(got, 10, 2.0)
+    assert 12 < int(np.count_nonzero(~prob.pose_const)) == 29 <= S.MAX_DEVICE_POSES
     q, t, X, info = _oracle(prob, 10)
-    assert (summ.iterations, summ.successful_steps, summ.termination) == (
-        info["iterations"], info["successful_steps"], info["termination"])
-    np.testing.assert_allclose(summ.final_cost, info["final_cost"], rtol=1e-8)
-    assert summ.final_cost < 0.2 * summ.initial_cost
-    np.testing.assert_allclose(got.q, q, rtol=1e-7, atol=1e-8)
-    np.testing.assert_allclose(got.t, t, rtol=1e-7, atol=1e-7)
-    # a landmark seen twice under a small baseline is weakly determined along its ray
-    np.testing.assert_allclose(got.X, X, rtol=1e-4, atol=1e-3)
+    for mode in ("auto", "host"):
+        monkeypatch.setenv("SSLAM_BA_SOLVER", mode)
+        got = _clone(prob)
+        summ = S.solve(got, 10, 2.0)
+        assert (summ.iterations, summ.successful_steps, summ.termination) == (
+            info["iterations"], info["successful_steps"], info["termination"]), mode
+        np.testing.assert_allclose(summ.final_cost, info["final_cost"], rtol=1e-8)
+        assert summ.final_cost < 0.2 * summ.initial_cost
+        np.testing.assert_allclose(got.q, q, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(got.t, t, rtol=1e-7, atol=1e-7)
+        # a landmark seen twice under a small baseline is weakly determined along its ray
+        np.testing.assert_allclose(got.X, X, rtol=1e-4, atol=1e-3)
+    # the device path is bit-reproducible here too
+    monkeypatch.setenv("SSLAM_BA_SOLVER", "device")
+    a, b = _clone(prob), _clone(prob)
+    S.solve(a, 10, 2.0); S.solve(b, 10, 2.0)
+    np.testing.assert_array_equal(a.q, b.q)
+    np.testing.assert_array_equal(a.X, b.X)
 
 
 def test_global_bundle_adjustment_through_the_driver_name():
@@ -161,7 +170,7 @@ def test_device_lm_rejects_oversized_window_and_bad_index(native):
     prob = _snapshot(n_frames=10, window=8)
     big = _clone(prob)
     big.pose_const = np.zeros(len(big.q), bool)
-    reps = 2
+    reps = 30                                                # 300 free poses > MAX_DEVICE_POSES
     big.q = np.tile(big.q, (reps, 1)); big.t = np.tile(big.t, (reps, 1)); big.pose_const = np.zeros(len(big.q), bool)
     with pytest.raises(native.NativeError, match="optimised poses"):
         S.solve_device(big, 5, 2.0)
