@@ -1496,8 +1496,12 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
     dim3 g2a(sslam::cdiv(W2, CT_W), sslam::cdiv(H2, 4), uF), g2b(sslam::cdiv(W2, CT_W), sslam::cdiv(H2, 8), uF);
     hipLaunchKernelGGL((al_conv3x3_mfma_kernel<16, 32, 2, true, false, 1>), g2a, dim3(256), 0, s, g->x1, Hp, Wp, g->t2, H2, W2,
                        g->b2c1.w, g->b2c1.a, g->b2c1.b, g->b2dw, g->b2db, g->idn2, nullptr, fs);
-    hipLaunchKernelGGL((al_conv3x3_mfma_kernel<32, 32, 1, false, true, 2>), g2b, dim3(256), 0, s, g->t2, H2, W2, g->x2, H2, W2,
-                       g->b2c2.w, g->b2c2.a, g->b2c2.b, nullptr, nullptr, nullptr, g->idn2, fs);
+    if (F >= 2)
+        hipLaunchKernelGGL((al_conv3x3_mfma_kernel<32, 32, 1, false, true, 2>), g2b, dim3(256), 0, s, g->t2, H2, W2, g->x2, H2, W2,
+                           g->b2c2.w, g->b2c2.a, g->b2c2.b, nullptr, nullptr, nullptr, g->idn2, fs);
+    else        // one frame: 320 workgroups of 8 rows leave the chip half empty - 4-row tiles (same arithmetic per output)
+        hipLaunchKernelGGL((al_conv3x3_mfma_kernel<32, 32, 1, false, true, 1>), g2a, dim3(256), 0, s, g->t2, H2, W2, g->x2, H2, W2,
+                           g->b2c2.w, g->b2c2.a, g->b2c2.b, nullptr, nullptr, nullptr, g->idn2, fs);
     // deformable conv = im2col of the bilinear samples + matrix-core GEMM (offsets in g->off)
     auto dcn = [&](const float* in, int cin, float* outp, int cout, int Hh, int Ww, const float* wt, const float* al_,
                    const float* be_, const float* res, int rc, const float* wdt, const float* bdp) {

@@ -573,19 +573,24 @@ __global__ __launch_bounds__(256) void lg_token_heads_kernel(
     }
 }
 
-// single block: early-stop test, then order-preserving compaction maps
+// single block: early-stop test, then order-preserving compaction maps.  The two images of the pair are compacted side
+// by side, 512 threads each (r03: one after the other before - two dependent load / scan / store chains per launch on the
+// single-pair path's critical path); a thread parks the old indices of its chunk in LDS with the keep flag in bit 15
+// (indices < 8192 = sslam_lightglue_create's bound on max_kpts).
+constexpr int DECIDE_MAX_KC = 8192;
 __global__ __launch_bounds__(1024) void lg_decide_kernel(
     int layer, float conf_thr, float depth_conf, float width_conf, int prune_min, int do_stop,
     const float* __restrict__ conf, const float* __restrict__ mat, int* __restrict__ ind,
     int* __restrict__ gmap, int* __restrict__ prune, LGCtrl* __restrict__ ctrl, int Kc) {
-    __shared__ int wsum[16];
+    __shared__ unsigned short s_ind[2][DECIDE_MAX_KC];
+    __shared__ int wsum[2][8];
     __shared__ int s_stop;
     const int pair = blockIdx.x;
     ctrl += pair;                                    // this pair's control block and 2 Kc-row slices
     conf += (size_t)pair * 2 * Kc; mat += (size_t)pair * 2 * Kc; ind += (size_t)pair * 2 * Kc;
     gmap += (size_t)pair * 2 * Kc; prune += (size_t)pair * 2 * Kc;
     if (ctrl->stop) return;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x;
     if (t == 0) {
         int stop = 0;
         if (do_stop) {
@@ -600,52 +605,50 @@ __global__ __launch_bounds__(1024) void lg_decide_kernel(
     }
     __syncthreads();
     if (s_stop || width_conf <= 0.0f) return;
-    const int per = (Kc + 1023) / 1024;
-    for (int img = 0; img < 2; ++img) {
-        const int n = ctrl->n[img];
-        if (!(n > prune_min)) continue;
-        // thread owns the contiguous chunk [t*per, t*per+per)
-        int keep[8], oldind[8], cnt = 0;
+    const int img = t >> 9, th = t & 511, lane = th & 63, wave = th >> 6;
+    const int n = ctrl->n[img];
+    const bool act = n > prune_min;                  // (uniform over the image's eight waves)
+    const int per = (Kc + 511) / 512;
+    // thread owns the contiguous chunk [th*per, th*per+per) of its image
+    int cnt = 0;
+    if (act)
         for (int j = 0; j < per; ++j) {
-            const int i = t * per + j;
-            int k = 0;
+            const int i = th * per + j;
             if (i < n) {
                 const float sc = sigmoidf_(mat[img * Kc + i]);
-                k = sc > (1.0f - width_conf);
+                int k = sc > (1.0f - width_conf);
                 if (do_stop) k |= conf[img * Kc + i] <= conf_thr;
-                oldind[j] = ind[img * Kc + i];
-            }
-            keep[j] = k;
-            cnt += k;
-        }
-        int incl = cnt;
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o);
-            if (lane >= o) incl += v;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        int base = 0, total = 0;
-        for (int w = 0; w < 16; ++w) {
-            if (w < wave) base += wsum[w];
-            total += wsum[w];
-        }
-        int pos = base + incl - cnt;
-        __syncthreads();       // all reads of ind[] done before any write
-        for (int j = 0; j < per; ++j) {
-            const int i = t * per + j;
-            if (i < n && keep[j]) {
-                ind[img * Kc + pos] = oldind[j];
-                gmap[img * Kc + pos] = i;
-                prune[img * Kc + oldind[j]] += 1;
-                ++pos;
+                s_ind[img][i] = (unsigned short)(ind[img * Kc + i] | (k << 15));
+                cnt += k;
             }
         }
-        if (t == 0) {
-            ctrl->n[img] = total;
-            if (total == 0) { ctrl->stop = 2; ctrl->stop_layer = layer; }
+    int incl = cnt;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[img][wave] = incl;
+    __syncthreads();       // (also: all reads of ind[] done before any write)
+    if (!act) return;
+    int base = 0, total = 0;
+    for (int w = 0; w < 8; ++w) {
+        if (w < wave) base += wsum[img][w];
+        total += wsum[img][w];
+    }
+    int pos = base + incl - cnt;
+    for (int j = 0; j < per; ++j) {
+        const int i = th * per + j;
+        if (i < n && (s_ind[img][i] & 0x8000)) {
+            const int old = s_ind[img][i] & 0x7fff;
+            ind[img * Kc + pos] = old;
+            gmap[img * Kc + pos] = i;
+            prune[img * Kc + old] += 1;
+            ++pos;
         }
-        __syncthreads();
+    }
+    if (th == 0) {
+        ctrl->n[img] = total;
+        if (total == 0) { ctrl->stop = 2; ctrl->stop_layer = layer; }
     }
 }
 
