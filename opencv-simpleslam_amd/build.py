@@ -123,7 +123,9 @@ def build_native(force: bool = False, verbose: bool = False) -> Path:
     lib_key = _digest(*[k for _, k in built])
     if force or not LIB_PATH.exists() or not lib_keyf.exists() or lib_keyf.read_text().strip() != lib_key:
         lib_keyf.unlink(missing_ok=True)
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB_PATH),
+        # -z defs: an undefined symbol is a link error here, not a dlopen failure on the GPU box (hipcc's host pass can
+        # drop the definition of a kernel template specialization without a diagnostic)
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-Wl,-z,defs", "-o", str(LIB_PATH),
                *map(str, objs)]
         if verbose:
             print(" ".join(cmd), flush=True)
