@@ -2,8 +2,8 @@
 // with).  Result: bit-identical to the 128 x 128 LDS-ring projection kernels and NOT faster - as one 8-wave workgroup per
 // CU QKV 68.8 / cross 44.4 us per 8-pair launch against 60.2 / 41.6; as the 4-wave form below, two workgroups per CU:
 // 59.3 / 40.5.  The k-loops alone take 34.7 / 24.3 us; the rest is the 100 MB (QKV) / 67 MB (cross) of split planes the
-// epilogue writes, which every workgroup of a dispatch round does at the same moment: the projections are bound by
-// their output traffic arriving in phase, not by how the operands reach the matrix pipe.
+// epilogue writes: the projections are bound by their output side, not by how the operands reach the matrix pipe
+// (delaying half of the first dispatch round to de-phase the bursts only added the delay).
 //
 // proj_stream.hpp - main loop of the two projections of a LightGlue transformer block (QKV, shared-qk cross; K = 256) in
 // the form of the fused FFN's phase 1 (ffn_fused.hpp): the 64-token operand tile (x planes, 64 x 256 hi + lo = 64 KB)
