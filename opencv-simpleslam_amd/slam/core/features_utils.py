@@ -74,10 +74,13 @@ def init_feature_pipeline(args):
         ctx = _native.default_context(int(os.environ.get("LOCAL_RANK", 0)) % max(1, _native.device_count()))
         detector = AlikedHIP(_state_dict(ENV_ALIKED, _weights.random_aliked_state_dict, "ALIKED (aliked-n16)"),
                              max_num_keypoints=max_kpts, max_h=MAX_IMAGE_H, max_w=MAX_IMAGE_W, ctx=ctx)
+        # the matcher runs on a stream of its own (same device): it reads the extractor's device records directly, ordered
+        # behind the extraction by an event, so a match can run while a frame's results are still on their way to the host
+        mctx = _native.Context(ctx.device)
         matcher = LightGlueHIP(_state_dict(ENV_LIGHTGLUE, _weights.random_lightglue_state_dict, "LightGlue (aliked_lightglue)"),
-                               max_kpts=max_kpts, ctx=ctx)
-        # extractor and matcher share one stream: the matcher may read the extractor's device records directly
+                               max_kpts=max_kpts, ctx=mctx)
         matcher._feature_ring = _ring_of(detector)
+        matcher._feature_ring.attach_matcher(matcher)
         return detector, matcher
     if not HAVE_CV2:
         raise ImportError("the OpenCV detector/matcher branch needs cv2; this backend accelerates "
@@ -123,7 +126,15 @@ class _DeviceFeatureRing:
     device copy, so numpy refuses it), the keypoint list is a `KeyPointList` that knows when it was edited.  A
     hit needs the SAME descriptor array object (identity, checked through a weak reference so a recycled `id`
     cannot alias) and keypoints equal to the remembered ones; anything else takes the host path.  A slot is
-    recycled after SLOTS further extractions (a keyframe's features held longer simply miss)."""
+    recycled after SLOTS further extractions (a keyframe's features held longer simply miss).
+
+    Look-ahead (r03): the reference's frame loop calls `feature_matcher(prev, cur)` right after every
+    `feature_extractor(cur)` (main_revamped.py:325-330).  Once the ring has seen that pattern it enqueues exactly that
+    match - previous record, this record, the last threshold - on the matcher's stream from INSIDE `extract`, ordered
+    behind the extraction by an event: the GPU goes from the extraction straight into the match while the host still
+    copies the features out and builds its objects, and the `feature_matcher` call that follows only collects the
+    result.  A call with other arguments waits for the look-ahead to finish and runs normally; an extraction that
+    finds the previous look-ahead unused switches it off until the pattern is seen again (one wasted match)."""
     SLOTS = 4
 
     def __init__(self, detector):
@@ -154,6 +165,15 @@ class _DeviceFeatureRing:
         self.pin_info = self.pin_match[:16].view(np.int32)
         self.pin_ij = self.pin_match[16:].view(np.int32).reshape(K, 2)
         detector.use_graphs(True)        # the slots are a fixed set of buffers: the launch sequence replays as a graph
+        self.matcher, self.mctx = None, None
+        self.ev_extracted = self.ctx.event()
+        self.last_entry = None           # the most recently extracted frame
+        self.ahead_on = False            # the prev -> cur pattern has been seen
+        self.ahead = None                # outstanding look-ahead: dict(a=entry, b=entry, thr=float)
+        self.last_thr = None
+
+    def attach_matcher(self, matcher):
+        self.matcher, self.mctx = matcher, matcher.ctx
 
     def extract(self, img):
         det, ctx = self.det, self.ctx
@@ -175,14 +195,32 @@ class _DeviceFeatureRing:
         sl = self.slots[self.turn % self.SLOTS]
         self.turn += 1
         if sl["key"] is not None:
-            self.by_id.pop(sl["key"], None)
+            # (only if the entry under that id is still THIS slot's: the id of a descriptor array the caller has dropped is
+            #  handed out again by the allocator, possibly to a newer frame's array)
+            e = self.by_id.get(sl["key"])
+            if e is not None and e["slot"] is sl:
+                del self.by_id[sl["key"]]
             sl["key"] = None
         K = self.K
         # (the image goes up straight from the caller's pageable array: the runtime's own staged copy, 69 us for
         #  1.4 MB, beats a host copy into a page-locked stage + DMA, 57 + 41 us)
         ctx.h2d_async(self.img_dev, np.ascontiguousarray(img))   # (pageable source: the call returns once the runtime staged it)
+        prev = self.last_entry
+        if self.ahead is not None:       # the last look-ahead was never collected: the caller is not in the prev -> cur loop
+            self.mctx.sync()             # (it may still read a record this ring is about to recycle)
+            self.ahead, self.ahead_on = None, False
         det.extract_dev(self.img_dev, H, Wd, Cn, sl["xy"], sl["desc"], sl["score"], sl["cnt"], max_kpts=K)
+        ctx.record(self.ev_extracted)
         ctx.d2h_async(self.pin_rec, sl["base"])
+        look = (self.ahead_on and self.matcher is not None and prev is not None and prev["slot"] is not sl
+                and prev["n"] > 0 and self.last_thr is not None)
+        if look:
+            # (this frame's count is only known on the device yet: K bounds it, the matcher clamps to the record's count)
+            self.mctx.wait(self.ev_extracted)
+            ps = prev["slot"]
+            self.matcher.match_dev(ps["xy"], ps["desc"], prev["n"], sl["xy"], sl["desc"], K, self.out_ij, self.out_sc,
+                                   self.out_info, min_conf=self.last_thr, m_dev=ps["cnt"], n_dev=sl["cnt"])
+            self.mctx.d2h_async(self.pin_match, self.out_info)
         # the GPU needs ~0.5 ms from here: build the frame's KeyPoint objects meanwhile (their coordinates resolve
         # against the array below on first use)
         shells, src = keypoint_shells(K) if keypoint_shells is not None else (None, None)
@@ -197,9 +235,14 @@ class _DeviceFeatureRing:
             kps = KeyPointList(shells, xy)
         else:
             kps = KeyPointList(keypoints_from_xy(xy), xy)
-        entry = dict(slot=sl, n=n, desc_ref=weakref.ref(desc), xy=xy)
+        entry = dict(slot=sl, n=n, desc_ref=weakref.ref(desc), xy=xy, prev=prev)
         sl["key"] = id(desc)
         self.by_id[id(desc)] = entry
+        self.last_entry = entry
+        if look:
+            self.ahead = dict(a=prev, b=entry, thr=self.last_thr)
+        if prev is not None:
+            prev["prev"] = None          # (no chains of dead frames)
         return kps, desc
 
     def lookup(self, des, kps, which):
@@ -209,14 +252,14 @@ class _DeviceFeatureRing:
             return None
         xy = kps.pristine_xy() if isinstance(kps, KeyPointList) else None
         if xy is not None and xy is e["xy"]:
-            return e["slot"]["xy"], e["slot"]["desc"], e["n"], e["slot"]["cnt"]
+            return e["slot"]["xy"], e["slot"]["desc"], e["n"], e["slot"]["cnt"], e
         # another list / an edited one: rebuild the keypoints like the reference does (features_utils.py:65-77);
         # the descriptors on the device are still the ones of `des`
         xy = xy_from_keypoints(kps)
         if np.array_equal(xy, e["xy"]):
-            return e["slot"]["xy"], e["slot"]["desc"], e["n"], e["slot"]["cnt"]
+            return e["slot"]["xy"], e["slot"]["desc"], e["n"], e["slot"]["cnt"], e
         self.ctx.h2d(self.tmp_xy[which], xy)
-        return self.tmp_xy[which], e["slot"]["desc"], e["n"], e["slot"]["cnt"]
+        return self.tmp_xy[which], e["slot"]["desc"], e["n"], e["slot"]["cnt"], None      # (edited keypoints: no look-ahead)
 
 
 def _ring_of(detector):
@@ -244,14 +287,23 @@ def _as_numpy_f32(x):
 
 
 def _match_resident(ring, matcher, a, b, thr):
-    """Both frames are still on the GPU: enqueue the match on their records, read back {count, pairs} -> list[DMatch]."""
-    ctx = ring.ctx
-    matcher.match_dev(a[0], a[1], a[2], b[0], b[1], b[2], ring.out_ij, ring.out_sc, ring.out_info, min_conf=thr,
-                      m_dev=a[3], n_dev=b[3])
-    ctx.d2h_async(ring.pin_match, ring.out_info)           # {count, pairs} in one copy into page-locked memory
+    """Both frames are still on the GPU: enqueue the match on their records (or collect the look-ahead that already runs
+    on exactly them), read back {count, pairs} -> list[DMatch]."""
+    mctx = matcher.ctx
+    ahead, ring.ahead = ring.ahead, None
+    hit = (ahead is not None and ahead["a"] is a[4] and ahead["b"] is b[4] and ahead["thr"] == thr)
+    if not hit:
+        if ahead is not None:
+            mctx.sync()                          # (its outputs share the buffers below)
+        matcher.match_dev(a[0], a[1], a[2], b[0], b[1], b[2], ring.out_ij, ring.out_sc, ring.out_info, min_conf=thr,
+                          m_dev=a[3], n_dev=b[3])
+        mctx.d2h_async(ring.pin_match, ring.out_info)      # {count, pairs} in one copy into page-locked memory
+    # the prev -> cur pattern of the reference's frame loop: from now on `extract` enqueues this match itself
+    ring.last_thr = thr
+    ring.ahead_on = b[4] is not None and b[4] is ring.last_entry and a[4] is not None and b[4].get("prev") is a[4]
     # the GPU needs > 1 ms from here: build the DMatch objects meanwhile (indices resolve against the array below)
     shells, src = match_shells(min(a[2], b[2])) if match_shells is not None else (None, None)
-    ctx.sync()
+    mctx.sync()
     k = int(ring.pin_info[0])
     if k < 0:
         matcher.range_overflow()                # reported here: clear the instance's sticky word

@@ -33,10 +33,12 @@ for im in imgs[3:]:
     n = int(ring.pin_cnt[0]); xy = ring.pin_xy[:n].copy(); desc = ring.pin_desc[:n].copy(); t = tick("copies out of the mirror", t)
     src.xy = xy; kps = ty.KeyPointList(shells, xy); t = tick("keypoint list", t)
     if prev is not None:
+        mctx = mat.ctx                                    # (the matcher has a stream of its own)
+        mctx.timer_start()
         mat.match_dev(prev[0], prev[1], n, sl["xy"], sl["desc"], n, ring.out_ij, ring.out_sc, ring.out_info, min_conf=0.7,
                       m_dev=prev[2], n_dev=sl["cnt"]); t = tick("match_dev enqueue", t)
-        ctx.sync(); t = tick("match sync (GPU work)", t)
-        ctx.d2h_async(ring.pin_match, ring.out_info); ctx.sync(); t = tick("d2h match record + sync", t)
+        T.setdefault("match, device time between events (GPU idle before it)", []).append(mctx.timer_stop() * 1e-3); t = tick("match sync (GPU work)", t)
+        mctx.d2h_async(ring.pin_match, ring.out_info); mctx.sync(); t = tick("d2h match record + sync", t)
     prev = (sl["xy"], sl["desc"], sl["cnt"])
 for k, v in T.items():
     print(f"{k:42s} {np.median(v)*1e6:8.1f} us")

@@ -186,3 +186,67 @@ def test_legacy_pair_entry_normalises_by_the_image_size(fu, pipeline):
     kn_s = lightglue_ref.normalize_keypoints(__import__("torch").as_tensor(xy1)[None], (w1, h1))
     assert not np.allclose(kn_b.numpy(), kn_s.numpy())
     assert ref["matches"].shape[1] == 2 and nob["matches"].shape[1] == 2
+
+
+def test_look_ahead_match_of_the_frame_loop_gives_the_same_matches(fu, pipeline):
+    """r03: in the reference's frame loop every `feature_extractor(cur)` is followed by `feature_matcher(prev, cur)`
+    (main_revamped.py:325-330).  Once the ring has seen that pattern, `feature_extractor` itself enqueues that match
+    behind the extraction and the matcher call only collects it.  Same matches as the plain path (a fresh pipeline's
+    first pair, the host path); a call with other arguments (keyframe -> cur, another threshold) is answered
+    correctly while a look-ahead is outstanding; extractions that never collect it switch it off."""
+    args, det, mat = pipeline
+    ring = fu._ring_of(det)
+    pairs = lambda ms: [(m.queryIdx, m.trainIdx) for m in ms]
+    host = lambda k0, k1, d0, d1, a=args: pairs(fu.feature_matcher(a, list(k0), list(k1), d0.copy(), d1.copy(), mat))
+    fr = [frames.structured_frame(20 + i) for i in range(8)]
+    kp = [None] * 8; des = [None] * 8
+    kp[0], des[0] = fu.feature_extractor(args, fr[0], det)
+    kp[1], des[1] = fu.feature_extractor(args, fr[1], det)
+    m01 = pairs(fu.feature_matcher(args, kp[0], kp[1], des[0], des[1], mat))       # plain resident path; sets the pattern
+    assert ring.ahead_on and ring.ahead is None and len(m01) > 0
+    got = []
+    for i in (2, 3, 4):                                                           # look-ahead enqueued by the extractor
+        kp[i], des[i] = fu.feature_extractor(args, fr[i], det)
+        assert ring.ahead is not None
+        got.append(pairs(fu.feature_matcher(args, kp[i - 1], kp[i], des[i - 1], des[i], mat)))
+        assert ring.ahead is None and ring.ahead_on
+    for i, g in zip((2, 3, 4), got):
+        assert g == host(kp[i - 1], kp[i], des[i - 1], des[i]) and len(g) > 0
+    # other arguments while a look-ahead (4 -> 5) is outstanding: keyframe 3 -> 5, then 4 -> 5 at another threshold
+    kp[5], des[5] = fu.feature_extractor(args, fr[5], det)
+    assert ring.ahead is not None
+    m35 = pairs(fu.feature_matcher(args, kp[3], kp[5], des[3], des[5], mat))
+    assert ring.ahead is None and not ring.ahead_on                               # not the frame loop's pattern
+    assert m35 == host(kp[3], kp[5], des[3], des[5])
+    loose = SimpleNamespace(use_lightglue=True, min_conf=0.2)
+    m45 = pairs(fu.feature_matcher(loose, kp[4], kp[5], des[4], des[5], mat))
+    assert ring.ahead_on and m45 == host(kp[4], kp[5], des[4], des[5], loose)
+    kp[6], des[6] = fu.feature_extractor(args, fr[6], det)                         # look-ahead at 0.2 ...
+    assert ring.ahead is not None and ring.ahead["thr"] == 0.2
+    m56 = pairs(fu.feature_matcher(args, kp[5], kp[6], des[5], des[6], mat))       # ... but the call asks for 0.7
+    assert m56 == host(kp[5], kp[6], des[5], des[6])
+    # extractions that never collect their look-ahead switch it off
+    kp[7], des[7] = fu.feature_extractor(args, fr[7], det)
+    assert ring.ahead is not None
+    fu.feature_extractor(args, fr[0], det)
+    assert ring.ahead is None and not ring.ahead_on
+
+
+def test_ring_survives_recycled_array_ids(fu, pipeline):
+    """A long run of the frame loop, holding only the previous and the current frame as the reference's loop does
+    (main_revamped.py:708): the allocator hands the ids of dropped descriptor arrays to new ones, and the ring, which
+    keys its records by id, must neither alias a dead frame nor lose a live one - every prev -> cur match stays on the
+    device-resident path."""
+    args, det, mat = pipeline
+    calls = []
+    real = mat.match
+    mat.match = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        kp_prev, des_prev = fu.feature_extractor(args, frames.structured_frame(40), det)
+        for i in range(1, 25):
+            kp, des = fu.feature_extractor(args, frames.structured_frame(40 + i % 6), det)
+            fu.feature_matcher(args, kp_prev, kp, des_prev, des, mat)
+            kp_prev, des_prev = kp, des
+    finally:
+        del mat.match
+    assert calls == []
