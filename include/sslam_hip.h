@@ -305,7 +305,8 @@ int sslam_lightglue_debug_layers(sslam_lightglue* lg, int layers, int self_only)
 int sslam_lightglue_debug_key_split(sslam_lightglue* lg, int ks);
 /* Linear-kernel form: -1 by token count (default), 0 = 64-row ring kernels, 1 = batched form (128 x 128 projections +
  * the fused FFN kernel, its tile size by token count), 2 / 3 = batched form with 64- / 32-token FFN tiles forced
- * (a token's FFN arithmetic is the same in both: bit-identical). */
+ * (a token's FFN arithmetic is the same in both: bit-identical), 5 = batched form with the token heads (early stop /
+ * pruning inputs) as a launch of their own instead of in the cross block's fused FFN. */
 int sslam_lightglue_debug_big_gemm(sslam_lightglue* lg, int mode);
 int sslam_lightglue_debug_read(sslam_lightglue* lg, int which, void* dst, size_t bytes);
 

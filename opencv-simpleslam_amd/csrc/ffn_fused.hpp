@@ -76,6 +76,11 @@ struct FfnFusedArgs {
     float* x;                   // fp32 token state [plane_rows][256]: residual in, new state out
     _Float16* xo_hi; _Float16* xo_lo;   // split planes of the new state (k-panel layout; may alias xs)
     unsigned long long* stamps;         // diagnostic builds only (FFN_STAMP): [workgroup][8] s_memtime values; else unused
+    // token heads on the new state (LightGlue's token-confidence and matchability Linear(256, 1), evaluated after a
+    // layer's cross block; lightglue.py check_if_stop / get_pruning_mask): hm != nullptr turns them on.
+    //   mat[row] = hm . x + hm_b ; hc != nullptr: conf[row] = sigmoid(hc . x + hc_b), *unconf += #(conf < conf_thr)
+    const float* hm; const float* hm_b; const float* hc; const float* hc_b;
+    float conf_thr; float* conf; float* mat; int* unconf;
 };
 
 #ifdef FFN_STAMP
@@ -466,6 +471,15 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
     // residual of this thread's units first (its latency hides under the staging)
     constexpr int UNITS = 32 * TT * (FFN_D / 8) / 512;       // 4 (2) units of 8 columns per thread
     float4 xa[UNITS], xb[UNITS];
+    // (token heads: this thread's 8 columns of the two weight rows; a unit's 32 threads are one half wave = one token)
+    const bool heads = p.hm != nullptr, with_conf = heads && p.hc != nullptr;
+    float hmw[8] = {}, hcw[8] = {};
+    if (heads) {
+        const int col = (t & 31) * 8;              // (scalar loads: the head vectors sit at any 4-byte offset of the weight blob)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { hmw[e] = p.hm[col + e]; if (with_conf) hcw[e] = p.hc[col + e]; }
+    }
+    int n_unconf = 0;
 #pragma unroll
     for (int it = 0; it < UNITS; ++it) {
         const int u = t + 512 * it, tok = u >> 5, col = (u & 31) * 8;
@@ -474,6 +488,7 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                  // every wave is done reading the hidden fragments
+    if (t == 0) *reinterpret_cast<int*>(red) = 0;  // (the workgroup's count of unconfident tokens; the LayerNorm sums are long read)
     float* const ybuf = reinterpret_cast<float*>(smem_b);
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt)
@@ -506,11 +521,42 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
         const size_t po = panel_index(grow0 + tok, col, p.plane_rows);
         *reinterpret_cast<uint4*>(p.xo_hi + po) = hi;
         *reinterpret_cast<uint4*>(p.xo_lo + po) = lo;
+        if (heads) {
+            // 8 columns in the lane, then the 32 lanes of the token's half wave (xor tree: every lane ends with the sum)
+            float sm = ((o[0] * hmw[0] + o[1] * hmw[1]) + (o[2] * hmw[2] + o[3] * hmw[3])) +
+                       ((o[4] * hmw[4] + o[5] * hmw[5]) + (o[6] * hmw[6] + o[7] * hmw[7]));
+            float sc = ((o[0] * hcw[0] + o[1] * hcw[1]) + (o[2] * hcw[2] + o[3] * hcw[3])) +
+                       ((o[4] * hcw[4] + o[5] * hcw[5]) + (o[6] * hcw[6] + o[7] * hcw[7]));
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) {
+                sm += __shfl_xor(sm, m);
+                if (with_conf) sc += __shfl_xor(sc, m);
+            }
+            if ((t & 31) == 0) {
+                p.mat[grow0 + tok] = sm + p.hm_b[0];
+                if (with_conf) {
+                    const float c = 1.0f / (1.0f + expf(-(sc + p.hc_b[0])));
+                    p.conf[grow0 + tok] = c;
+                    n_unconf += c < p.conf_thr;
+                }
+            }
+        }
 #else
         if (o[0] == 123.456f) *xr = o[1];
 #endif
     }
     split_range_check(amax, range_flag);
+    if (with_conf && p.unconf) {
+        // one atomic per workgroup (same-address atomics retire one per ~11 ns): lanes 0 / 32 of every wave hold counts
+        const unsigned long long any = __ballot(n_unconf != 0);
+        if (any) {
+            int wsum = n_unconf + __shfl_xor(n_unconf, 32);          // (lanes other than 0 / 32 hold 0)
+            if (lane == 0) atomicAdd(reinterpret_cast<int*>(red), wsum);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t == 0) { const int tot = *reinterpret_cast<volatile int*>(red); if (tot) atomicAdd(p.unconf, tot); }
+    }
     FFN_STAMP_AT(6);
     FFN_STAMP_AT(7);
 #ifdef FFN_STAMP

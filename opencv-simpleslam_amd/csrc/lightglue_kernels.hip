@@ -1304,7 +1304,9 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_fused_kernel(FfnKArgs p) {
     const int n = pc.n[img & 1];
     if (row0 >= n) return;
     const int ibase = img * p.Kc;
-    sslam::ffn_fused_tile<TT>(p.f, ibase + row0, ibase + p.Kc, min(TOK, n - row0), range_flag_of(p.ctrl, img), lg_ring);
+    sslam::FfnFusedArgs f = p.f;
+    f.unconf = &const_cast<LGCtrl*>(p.ctrl)[img >> 1].unconf;          // (used with the token heads only)
+    sslam::ffn_fused_tile<TT>(f, ibase + row0, ibase + p.Kc, min(TOK, n - row0), range_flag_of(p.ctrl, img), lg_ring);
 }
 
 // W1 [512][512] / W2 [256][512] (row-major fp32) -> split planes in the fragment order the fused FFN streams
@@ -2286,7 +2288,9 @@ void launch_attention_h(sslam_lightglue* g, hipStream_t s, int NI, SplitPtr Q, S
 }
 
 // one transformer layer (self + cross block) on the split-precision path
-void lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, int layer, bool self_only) {
+// `heads`: the layer's cross-block FFN also evaluates the token heads on the new state (batched form only; returns whether
+// it did - otherwise lg_token_heads_kernel has to run)
+bool lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, int layer, bool self_only, bool heads) {
     const SplitPtr xs{g->xs_hi, g->xs_lo}, msgs{g->msgs_hi, g->msgs_lo};
     const SplitPtr hids{g->hids_hi, g->hids_lo}, none{nullptr, nullptr};
     const SplitPtr qs{g->qs_hi, g->qs_lo}, ks{g->ks_hi, g->ks_lo}, vts{g->vts_hi, g->vts_lo};
@@ -2303,6 +2307,12 @@ void lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, in
             k.f.w1f = g->ffn_w1f[layer][cross]; k.f.b1 = b1; k.f.ln_w = lnw; k.f.ln_b = lnb;
             k.f.w2f = g->ffn_w2f[layer][cross]; k.f.b2 = b2;
             k.f.x = g->x; k.f.xo_hi = g->xs_hi; k.f.xo_lo = g->xs_lo; k.f.stamps = nullptr;
+            if (cross && heads) {
+                const bool do_stop = g->depth_conf > 0.0f;
+                k.f.hm = g->mt_w + (size_t)layer * g->mt_stride; k.f.hm_b = g->mt_b + (size_t)layer * g->mt_stride;
+                k.f.hc = do_stop ? g->tc_w[layer] : nullptr; k.f.hc_b = do_stop ? g->tc_b[layer] : nullptr;
+                k.f.conf_thr = conf_threshold(layer); k.f.conf = g->conf; k.f.mat = g->mat;
+            }
             k.ctrl = g->ctrl; k.Kc = g->Kc;
             const bool small_tiles = g->big_gemm == 3 || (g->big_gemm != 2 && NI * (g->Kc / 64) <= 128);
             if (small_tiles)                       // too few 64-token tiles for the chip: 32-token tiles (same results)
@@ -2329,7 +2339,7 @@ void lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, in
     }
     launch_attention_h(g, s, NI, qs, ks, vts, 0);
     ffn(0, l.w1, l.b1, l.lnw, l.lnb, l.w2, l.b2);
-    if (self_only) return;
+    if (self_only) return false;
     {   // cross block: the shared qk projection is both query and key -> sqrt(scale) on it
         LinearArgsH a = linh(g, xs, none, D, D, D, l.cqkv, l.cbqkv, 2 * D);
         a.q = SplitOut{g->qs_hi, g->qs_lo}; a.vt = SplitOut{g->vts_hi, g->vts_lo};
@@ -2339,6 +2349,7 @@ void lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, in
     }
     launch_attention_h(g, s, NI, qs, qs, vts, 1);
     ffn(1, l.cw1, l.cb1, l.clnw, l.clnb, l.cw2, l.cb2);
+    return big && heads;
 }
 
 // Enqueue one batch of `pairs` pairs on the context stream.  `src` names the inputs of image
@@ -2366,8 +2377,11 @@ int lg_enqueue(sslam_lightglue* g, int pairs, const StageSrc& src, float min_con
     for (int i = 0; i < g->dbg_layers; ++i) {
         const LGLayerW& l = g->L[i];
         const bool self_only = g->dbg_self_only && i == g->dbg_layers - 1;
+        // the token heads of this layer (early stop + pruning) ride in the cross block's fused FFN when there is one
+        const bool want_heads = !(i == NL - 1 || i == g->dbg_layers - 1) && (g->depth_conf > 0.0f || g->width_conf > 0.0f);
+        bool heads_done = false;
         if (g->precision == 1) {
-            lg_layer_h(g, s, NI, l, i, self_only);
+            heads_done = lg_layer_h(g, s, NI, l, i, self_only, want_heads && g->big_gemm != 5);
         } else {
             // ---- self block
             {
@@ -2394,10 +2408,11 @@ int lg_enqueue(sslam_lightglue* g, int pairs, const StageSrc& src, float min_con
         const int do_prune = g->width_conf > 0.0f;
         if (!do_stop && !do_prune) continue;
         const float thr = conf_threshold(i);
-        hipLaunchKernelGGL(lg_token_heads_kernel, headgrid, dim3(256), 0, s, g->x,
-                           do_stop ? g->tc_w[i] : nullptr, do_stop ? g->tc_b[i] : nullptr,
-                           g->mt_w + (size_t)i * g->mt_stride, g->mt_b + (size_t)i * g->mt_stride, 0L, 0,
-                           thr, g->conf, g->mat, g->ctrl, Kc, do_stop);
+        if (!heads_done)
+            hipLaunchKernelGGL(lg_token_heads_kernel, headgrid, dim3(256), 0, s, g->x,
+                               do_stop ? g->tc_w[i] : nullptr, do_stop ? g->tc_b[i] : nullptr,
+                               g->mt_w + (size_t)i * g->mt_stride, g->mt_b + (size_t)i * g->mt_stride, 0L, 0,
+                               thr, g->conf, g->mat, g->ctrl, Kc, do_stop);
         hipLaunchKernelGGL(lg_decide_kernel, dim3(pairs), dim3(1024), 0, s, i, thr, g->depth_conf,
                            g->width_conf, g->prune_min, do_stop, g->conf, g->mat, g->ind, g->gmap,
                            g->prune, g->ctrl, Kc);
@@ -2789,7 +2804,7 @@ int sslam_lightglue_debug_key_split(sslam_lightglue* g, int ks) {
 /* Test hook: -1 = linears chosen by batch size, 0 = always the 64-row ring kernels (single-pair form), 1 = always
  * the batched form (128 x 128 projections + the fused FFN kernel). */
 int sslam_lightglue_debug_big_gemm(sslam_lightglue* g, int mode) {
-    SSLAM_REQUIRE(g != nullptr && mode >= -1 && mode <= 3, "sslam_lightglue_debug_big_gemm: bad argument");
+    SSLAM_REQUIRE(g != nullptr && mode >= -1 && mode <= 5 && mode != 4, "sslam_lightglue_debug_big_gemm: bad argument");
     g->settings_changed();
     g->big_gemm = mode;
     return 0;

@@ -134,7 +134,8 @@ class LightGlueHIP:
     def debug_big_gemm(self, mode: int):
         """Test hook: -1 linears by batch size, 0 always the 64-row ring kernels (single-pair form), 1 always the
         batched form (128 x 128 projections + the whole FFN as one kernel, its tile by token count), 2 / 3 the batched
-        form with 64- / 32-token FFN tiles forced (bit-identical results)."""
+        form with 64- / 32-token FFN tiles forced (bit-identical results), 5 the batched form with the token heads as a
+        launch of their own (by default the cross block's fused FFN evaluates them on the state it writes)."""
         _native.check(_native.lib().sslam_lightglue_debug_big_gemm(self.handle, int(mode)))
 
     def debug_read(self, which: int, shape, dtype=np.float32):

@@ -274,3 +274,34 @@ def test_assembly_attention_key_ranges_give_the_4_wave_kernel_partials(gpu_ctx, 
             assert stop == o_stop
     assert not batch.range_overflow() and not single.range_overflow()
     dev.free(); batch.close(); single.close()
+
+
+@pytest.mark.parametrize("seed,kw", [(1, dict(match_gain=4.0, match_bias=3.0)),
+                                     (4, dict(match_gain=4.0, match_bias=-4.6, conf_bias=2.3)),
+                                     (7, dict(match_gain=4.0, match_bias=-1.0, conf_bias=1.2))])
+def test_token_heads_in_the_fused_ffn_decide_like_the_separate_kernel(gpu_ctx, seed, kw):
+    """The token-confidence / matchability heads evaluated in the cross block's fused FFN (default for batched token
+    sets) against the lane-per-token kernel (debug_big_gemm(5)): the dot products sum in another order, so the control
+    flow they feed - stop layer, the keypoints kept by every pruning step - and the matches must be identical and the
+    scores equal to fp32 rounding; weight sets that never stop, stop at once, and stop / prune midway; ragged sizes."""
+    W, LG = load_pkg("weights"), load_pkg("lightglue").LightGlueHIP
+    sd = W.random_lightglue_state_dict(seed, **kw)
+    sizes = [(1024, 1024), (700, 900), (130, 64), (1000, 1), (257, 511)]
+    pairs = [lg_inputs.make_pair(m, n, seed=11 * m + n) for m, n in sizes]
+    batch = LG(sd, max_kpts=1024, max_pairs=len(pairs), ctx=gpu_ctx)
+    dev = DevBatch(gpu_ctx, pairs, 1024)
+    batch.debug_big_gemm(5)
+    ref = dev.run(batch, 0.3)
+    batch.debug_big_gemm(-1)
+    got = dev.run(batch, 0.3)
+    for (ij, sc, info), (r_ij, r_sc, r_info) in zip(got, ref):
+        np.testing.assert_array_equal(info, r_info)
+        np.testing.assert_array_equal(ij, r_ij)
+        np.testing.assert_allclose(sc, r_sc, rtol=2e-5, atol=2e-6)
+    single = LG(sd, max_kpts=1024, ctx=gpu_ctx)                  # one pair per call: 32-token FFN tiles
+    for pr, (ij, sc, info) in zip(pairs, got):
+        s_ij, s_sc, s_stop = single.match(*pr, min_conf=0.3)
+        np.testing.assert_array_equal(ij, s_ij)
+        assert info[1] == s_stop
+    assert not batch.range_overflow()
+    dev.free(); batch.close(); single.close()
