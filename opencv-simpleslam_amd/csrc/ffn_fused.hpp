@@ -43,7 +43,7 @@ constexpr int FFN_D = 256, FFN_H = 512;        // model width, hidden width
 constexpr int FFN_OPER_BYTES = 131072;         // operand tile [16 k-panels][2 planes][64 tok][32] = hidden fragments [2][32][2][64][8]
 constexpr int FFN_RED_OFF = FFN_OPER_BYTES;    // bytes: LayerNorm partial sums [2 passes][8 waves][64 tok] fp32
 constexpr int FFN_CONST_OFF = FFN_RED_OFF + 2 * 8 * FFN_TOK * 4;      // bytes: b1 | ln_w | ln_b (512 each) | b2 (256), fp32
-constexpr int FFN_LDS_BYTES = FFN_CONST_OFF + (3 * FFN_H + FFN_D) * 4;  // 142 336
+constexpr int FFN_LDS_BYTES = FFN_CONST_OFF + (3 * FFN_H + 3 * FFN_D) * 4;  // 144 384 (+ the two token-head weight rows, 256 each)
 constexpr int FFN_Y_LD = 260;                  // fp32 row stride of the staged output tile [64][256]
 static_assert(FFN_TOK * FFN_Y_LD * 4 <= FFN_OPER_BYTES, "the output tile is staged where the hidden fragments were");
 
@@ -113,6 +113,23 @@ __device__ __forceinline__ void ffn_dma16(R rsrc, int voff_bytes, int soff_bytes
 template <typename R>
 __device__ __forceinline__ half8 ffn_ldfrag(R rsrc, int voff_bytes, int soff_bytes) {
     return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_bytes, soff_bytes, 0));
+}
+
+// sum over each 32-lane half of the wave, valid in lanes 31 and 63 (row_shr 1 / 2 / 3, row_shr 4 and 8 on the upper
+// banks, then lane 15 of rows 0 / 2 added into rows 1 / 3; lanes without a source add 0)
+__device__ __forceinline__ float ffn_half_wave_sum(float x) {
+    auto dpp = [](float v, auto ctrl, auto row_mask, auto bank_mask) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value,
+                                                                     decltype(row_mask)::value, decltype(bank_mask)::value, false));
+    };
+    using std::integral_constant;
+    float v = x + dpp(x, integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{});
+    v += dpp(x, integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{});
+    v += dpp(x, integral_constant<int, 0x113>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{});
+    v += dpp(v, integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xe>{});
+    v += dpp(v, integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xc>{});
+    v += dpp(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{}, integral_constant<int, 0xf>{});
+    return v;
 }
 
 __device__ __forceinline__ float ffn_erf(float x) {        // Abramowitz & Stegun 7.1.26 (see lightglue_kernels.hip erf_as)
@@ -197,6 +214,11 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
         const float b2v = p.b2[t & (FFN_D - 1)];
         cst[t] = b1v; cst[FFN_H + t] = lwv; cst[2 * FFN_H + t] = lbv;
         if (t < FFN_D) cst[3 * FFN_H + t] = b2v;
+        if (p.hm != nullptr) {                     // token heads: the two weight rows, read back 8 columns per lane in the epilogue
+            const bool second = t >= FFN_D;
+            const float* src = second ? p.hc : p.hm;
+            cst[3 * FFN_H + FFN_D + t] = src != nullptr ? src[t & (FFN_D - 1)] : 0.0f;
+        }
     }
 
     const auto r_w1 = ffn_rsrc(p.w1f, 2 * FFN_H * FFN_H * 2), r_w2 = ffn_rsrc(p.w2f, 2 * FFN_D * FFN_H * 2);
@@ -475,9 +497,9 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
     const bool heads = p.hm != nullptr, with_conf = heads && p.hc != nullptr;
     float hmw[8] = {}, hcw[8] = {};
     if (heads) {
-        const int col = (t & 31) * 8;              // (scalar loads: the head vectors sit at any 4-byte offset of the weight blob)
+        const float* hw = cst + 3 * FFN_H + FFN_D + (t & 31) * 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { hmw[e] = p.hm[col + e]; if (with_conf) hcw[e] = p.hc[col + e]; }
+        for (int e = 0; e < 8; ++e) { hmw[e] = hw[e]; hcw[e] = hw[FFN_D + e]; }
     }
     int n_unconf = 0;
 #pragma unroll
@@ -522,17 +544,16 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
         *reinterpret_cast<uint4*>(p.xo_hi + po) = hi;
         *reinterpret_cast<uint4*>(p.xo_lo + po) = lo;
         if (heads) {
-            // 8 columns in the lane, then the 32 lanes of the token's half wave (xor tree: every lane ends with the sum)
+            // 8 columns in the lane ...
             float sm = ((o[0] * hmw[0] + o[1] * hmw[1]) + (o[2] * hmw[2] + o[3] * hmw[3])) +
                        ((o[4] * hmw[4] + o[5] * hmw[5]) + (o[6] * hmw[6] + o[7] * hmw[7]));
             float sc = ((o[0] * hcw[0] + o[1] * hcw[1]) + (o[2] * hcw[2] + o[3] * hcw[3])) +
                        ((o[4] * hcw[4] + o[5] * hcw[5]) + (o[6] * hcw[6] + o[7] * hcw[7]));
-#pragma unroll
-            for (int m = 1; m < 32; m <<= 1) {
-                sm += __shfl_xor(sm, m);
-                if (with_conf) sc += __shfl_xor(sc, m);
-            }
-            if ((t & 31) == 0) {
+            // the 32 lanes of the token's half wave: DPP row reductions (vector ALU; five dependent LDS permutes per value
+            // and unit measured 7.6 us per launch of 8 pairs), the total lands in the half's last lane
+            sm = ffn_half_wave_sum(sm);
+            if (with_conf) sc = ffn_half_wave_sum(sc);
+            if ((t & 31) == 31) {
                 p.mat[grow0 + tok] = sm + p.hm_b[0];
                 if (with_conf) {
                     const float c = 1.0f / (1.0f + expf(-(sc + p.hc_b[0])));
@@ -547,11 +568,11 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
     }
     split_range_check(amax, range_flag);
     if (with_conf && p.unconf) {
-        // one atomic per workgroup (same-address atomics retire one per ~11 ns): lanes 0 / 32 of every wave hold counts
+        // one atomic per workgroup (same-address atomics retire one per ~11 ns): lanes 31 / 63 of every wave hold counts
         const unsigned long long any = __ballot(n_unconf != 0);
         if (any) {
-            int wsum = n_unconf + __shfl_xor(n_unconf, 32);          // (lanes other than 0 / 32 hold 0)
-            if (lane == 0) atomicAdd(reinterpret_cast<int*>(red), wsum);
+            int wsum = n_unconf + __shfl_xor(n_unconf, 32);          // (lanes other than 31 / 63 hold 0)
+            if (lane == 31) atomicAdd(reinterpret_cast<int*>(red), wsum);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
