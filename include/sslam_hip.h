@@ -299,8 +299,7 @@ int sslam_lightglue_profile_read(sslam_lightglue* lg, float* total_ms_out, int32
  * debug_key_split: 0 = by batch size (no split for batched launches, 2 or 4 key ranges + a merge for one pair; the
  * hand-scheduled assembly attention kernel either way), -4 = the same policy on the r02 4-wave kernel, 1 / 2 / 4 = that
  * many key ranges (4-wave kernel), 101 / 102 / 104 = that many (assembly kernel), -1 = no split, r02 4-wave kernel,
- * -2 = no split, compiler-scheduled half-step kernel, -3 = no split, the assembly kernel at any batch size (for one
- * split the kernels give bit-identical results). */
+ * -3 = no split, the assembly kernel at any batch size (for one split the two kernels give bit-identical results). */
 int sslam_lightglue_debug_layers(sslam_lightglue* lg, int layers, int self_only);
 int sslam_lightglue_debug_key_split(sslam_lightglue* lg, int ks);
 /* Linear-kernel form: -1 by token count (default), 0 = 64-row ring kernels, 1 = batched form (128 x 128 projections +

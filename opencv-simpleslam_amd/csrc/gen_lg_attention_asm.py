@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Generator of the hand-scheduled LightGlue attention kernel for gfx950 (csrc/lg_attention_asm.s).
 
-Same arithmetic, LDS images, DMA schedule and results (bit for bit) as lg_attention_hs_kernel in
-csrc/lightglue_kernels.hip - flash-style split-precision attention, 4 waves x 32 queries, S^T = K Q^T so a
+Same arithmetic, LDS images, DMA schedule and results (bit for bit) as lg_attention_p_kernel in
+csrc/lightglue_kernels.hip (and as the compiler-scheduled half-step form of it, scripts/ubench/attn_hs_reference.hpp,
+whose schedule this one writes out by hand) - flash-style split-precision attention, 4 waves x 32 queries, S^T = K Q^T so a
 lane owns a query column, P fed to P.V straight from registers - but written as ONE instruction stream per
 wave in which every 32-cycle MFMA slot carries its share of the softmax arithmetic, the LDS fragment reads
 of the next half and the tile DMA.  hipcc cannot produce this stream: with the ~250 registers the kernel
@@ -377,7 +378,7 @@ def body(b, last, mask, tag):
 
 # ================================================================= the kernel text
 e("// lg_attention_asm.s - GENERATED by opencv-simpleslam_amd/csrc/gen_lg_attention_asm.py (do not edit): hand-scheduled split-precision attention")
-e("// for gfx950.  See the generator for the design; csrc/lightglue_kernels.hip lg_attention_hs_kernel for the arithmetic.")
+e("// for gfx950.  See the generator for the design; csrc/lightglue_kernels.hip lg_attention_p_kernel for the arithmetic.")
 e("    .text")
 e("    .amdgcn_target \"amdgcn-amd-amdhsa--gfx950\"")
 e("    .amdhsa_code_object_version 5")

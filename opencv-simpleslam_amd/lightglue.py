@@ -127,8 +127,7 @@ class LightGlueHIP:
         """Test hook: the key split of the attention launches.  0 = by batch size (none for batched launches, 2 or 4 key
         ranges + a merge for one pair) on the hand-scheduled assembly kernel; -4 = the same policy on the r02 4-wave
         kernel; 1 / 2 / 4 = that many ranges (4-wave kernel); 101 / 102 / 104 = that many (assembly kernel); no split at
-        any size: -1 the 4-wave kernel, -2 the compiler-scheduled half-step kernel, -3 the assembly kernel - for A/B and
-        bit-identity checks."""
+        any size: -1 the 4-wave kernel, -3 the assembly kernel - for A/B and bit-identity checks."""
         _native.check(_native.lib().sslam_lightglue_debug_key_split(self.handle, int(ks)))
 
     def debug_big_gemm(self, mode: int):

@@ -4,6 +4,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I opencv-simpleslam_amd/csrc \
 //         scripts/ubench/attn_bench.hip -o /tmp/attn_bench && /tmp/attn_bench [N=2048] [pairs=8] [KS=1] [rounds=5]
 #include "../../opencv-simpleslam_amd/csrc/lightglue_kernels.hip"
+#include "attn_hs_reference.hpp"
 #include "attn_pp_experiment.hpp"
 #include "attn_w1_experiment.hpp"
 #include <cstdio>

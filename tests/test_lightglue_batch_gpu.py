@@ -73,10 +73,10 @@ def test_batch_equals_single_pair_calls_and_oracle(gpu_ctx):
             np.testing.assert_array_equal(ij, o_ij)
             np.testing.assert_allclose(sc, o_sc, atol=1e-3, rtol=1e-3)
             assert info[1] == o_stop
-    # the three attention kernels without key split - the r02 4-wave kernel (-1), the compiler-scheduled half-step
-    # kernel (-2) and the hand-scheduled assembly kernel batched launches run by default (-3) - multiply the same
-    # products in the same order: bit-identical results, ragged key counts, the 1-keypoint image and all
-    for mode in (-1, -2, -3):
+    # the two attention kernels without key split - the r02 4-wave kernel (-1) and the hand-scheduled assembly kernel
+    # batched launches run by default (-3) - multiply the same products in the same order: bit-identical results,
+    # ragged key counts, the 1-keypoint image and all
+    for mode in (-1, -3):
         batch.debug_key_split(mode)
         for (ij, sc, info), (p_ij, p_sc, p_info) in zip(got, dev.run(batch, 0.7)):
             np.testing.assert_array_equal(ij, p_ij)
