@@ -138,6 +138,16 @@ def test_tall_and_tiny_images(W, AL):
     al.close()
 
 
+def test_common_camera_sizes(W, AL):
+    """1280 x 720 (resize 0.8, 3-tap blur, 1024 x 576 network: padding on neither side) and KITTI's other image width
+    1226 x 370 (odd resize factor, bottom / right padding of a few rows)."""
+    sd = W.random_aliked_state_dict(5)
+    al = AL(sd, max_num_keypoints=2048, max_h=720, max_w=1280)
+    _check(al, sd, frames.noise_frame(7, h=720, w=1280), 2048)
+    _check(al, sd, frames.structured_frame(9, h=370, w=1226), 1500)
+    al.close()
+
+
 def test_bad_arguments(W, AL, native):
     al = AL(W.random_aliked_state_dict(0), max_num_keypoints=256, max_h=128, max_w=128)
     with pytest.raises(native.NativeError, match="capacity"):
