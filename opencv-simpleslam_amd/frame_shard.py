@@ -96,7 +96,7 @@ def unpack_record(rec, max_kpts):
     return n, rec[:2 * K].reshape(K, 2)[:n], rec[2 * K:K * ROW].reshape(K, DESC_DIM)[:n]
 
 
-def collate(local_records, plan: ShardPlan, group=None, out=None, part=None):
+def collate(local_records, plan: ShardPlan, group=None, out=None, part=None, always=False):
     """All-gather the per-frame records of one round (or of a part of it).
 
     local_records: [B, REC] float32 tensor of this rank's frames (frame order).
@@ -105,8 +105,9 @@ def collate(local_records, plan: ShardPlan, group=None, out=None, part=None):
     out:  optional preallocated [world*B, REC] tensor to gather into (the caller keeps it alive: no
           allocation and no copy per round);
     part: optional (lo, hi) - gather only local frames lo..hi-1 of every rank, into rows
-          r*B + lo .. r*B + hi - 1 of `out`, so a round can be collated in pieces as its extracts finish."""
-    if plan.world == 1:
+          r*B + lo .. r*B + hi - 1 of `out`, so a round can be collated in pieces as its extracts finish.
+    always: run the collective with one rank too (tests: the RCCL path on a single GPU)."""
+    if plan.world == 1 and not always:
         return local_records
     import torch
     import torch.distributed as dist
@@ -137,10 +138,13 @@ class FrameStreamPipeline:
     matcher needs max_pairs >= batch_pairs)."""
 
     def __init__(self, detectors, matchers, plan: ShardPlan, max_kpts: int, min_conf: float = 0.7,
-                 batch_pairs: int | None = None, group=None, use_graphs: bool = True):
+                 batch_pairs: int | None = None, group=None, use_graphs: bool = True, collate_always: bool = False):
         self.dets = list(detectors) if isinstance(detectors, (list, tuple)) else [detectors]
         self.mats = list(matchers) if isinstance(matchers, (list, tuple)) else [matchers]
         self.plan, self.group = plan, group
+        # collate_always: take the multi-GPU path (torch-owned slab, collation stream, per-half all-gathers, halo record)
+        # with ONE rank too - how the tests run the RCCL branch on a single GPU
+        self.distributed = plan.world > 1 or bool(collate_always)
         # every round cycles through the same record slots: each extractor / matcher call sequence is
         # replayed as a cached hipGraph (one hipGraphLaunch instead of 45 / 190 launches per call)
         for x in self.dets + self.mats:
@@ -161,7 +165,7 @@ class FrameStreamPipeline:
         self.NSLOT = 2 * B + 2
         dev_bytes = self.NSLOT * self.REC * 4
         self.torch = None
-        if plan.world > 1:
+        if self.distributed:
             # the exchange goes through torch.distributed: its tensors own the record slab
             import torch
             self.torch = torch
@@ -242,7 +246,7 @@ class FrameStreamPipeline:
         p = rnd & 1
         s_base = p * B                                   # first slot of this round's set
         halo_slot = 2 * B + p
-        single = plan.world == 1
+        single = not self.distributed
         for d in self.dets:
             if rnd >= 2:
                 for j in range(self.n_batches[p]):
@@ -286,7 +290,7 @@ class FrameStreamPipeline:
                 for (lo, hi) in self.halves:
                     for s in range(lo, hi):
                         self.cctx.wait(self.ev_ext[p][s])
-                    collate(self._slab_t[s_base:s_base + B], plan, self.group, out=G, part=(lo, hi))
+                    collate(self._slab_t[s_base:s_base + B], plan, self.group, out=G, part=(lo, hi), always=True)
                 self.shared_map = G
                 prev = plan.rank * B - 1                     # index inside the gathered round
                 if prev >= 0:

@@ -49,7 +49,7 @@ ref = [None] + [mat0.match(feats[i - 1][0], feats[i - 1][1], feats[i][0], feats[
 plan = fs.ShardPlan(world, rank, B)
 dets = [AL(sd_a, max_num_keypoints=K, max_h=H, max_w=Wd, ctx=nat.Context(dev), max_frames=2) for _ in range(2)]   # chunks of 2 frames per extractor call (ragged last chunk)
 mats = [LG(sd_l, max_kpts=K, ctx=nat.Context(dev), max_pairs=2, filter_threshold=0.0) for _ in range(2)]
-pipe = fs.FrameStreamPipeline(dets, mats, plan, K, 0.0, batch_pairs=2)
+pipe = fs.FrameStreamPipeline(dets, mats, plan, K, 0.0, batch_pairs=2, collate_always=True)    # (one rank: still the collective path)
 ctx = pipe.ctx
 col = nat.Context(dev)                      # collector stream: snapshots a round's outputs without a host sync
 chunks = [ctx.upload(np.stack([imgs[f] for f in plan.frames(r)])) for r in range(ROUNDS)]

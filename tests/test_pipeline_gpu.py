@@ -168,6 +168,13 @@ def test_two_rank_pipeline_over_rccl(native):
     _run_dist_check("nccl", 2, 29615)
 
 
+def test_one_rank_pipeline_over_rccl():
+    """The RCCL branch on the one GPU of a test box: the same check with backend `nccl` and world size 1 - process-group
+    creation on the device, the per-half all-gathers on the collation stream (RCCL kernels, one rank), the torch
+    ExternalStream plumbing around them - so that code has executed before the first multi-GPU lease."""
+    _run_dist_check("nccl", 1, 29617)
+
+
 def test_pipeline_reports_a_split_precision_range_overflow(native):
     """the headline path must not hand on matches computed past the fp16 range of the
     split-precision planes.  Token states scaled by 1e7 through the PIPELINE: `results()` / `infos()` raise,
