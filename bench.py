@@ -383,7 +383,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     dist = torch = None
-    if world > 1:
+    # SSLAM_BENCH_FORCE_DIST=1 (tests): take the N > 1 branches - process group, collective barrier, max-reduce of the
+    # time, the pipeline's collation path - with ONE rank, so the RCCL code has run on a single-GPU box
+    distributed = world > 1 or os.environ.get("SSLAM_BENCH_FORCE_DIST") == "1"
+    if distributed:
         # one process per GPU; SSLAM_DIST_BACKEND=gloo + fewer GPUs than ranks is a test-only mode that
         # exercises the N > 1 code path on a single-GPU box (ranks share device local_rank % n_gpus).
         # torch brings its own HIP runtime: it must initialise BEFORE libsslam_hip.so touches the
@@ -396,6 +399,7 @@ def main():
         device_index = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(device_index)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29621")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
         else:
@@ -409,7 +413,7 @@ def main():
     fs = importlib.import_module("opencv-simpleslam_amd.frame_shard")
     if nat.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    if world == 1:
+    if not distributed:
         device_index = 0
 
     # extractor / matcher instances, one HIP stream (context) each.  The matcher runs BATCHES of
@@ -429,7 +433,8 @@ def main():
         for mat in mats:
             mat.debug_big_gemm(int(os.environ["SSLAM_BIG_GEMM"]))
     plan = fs.ShardPlan(world, rank, FRAMES_PER_RANK)
-    pipe = fs.FrameStreamPipeline(dets, mats, plan, MAX_KPTS, MIN_CONF, batch_pairs=BATCH_PAIRS)
+    pipe = fs.FrameStreamPipeline(dets, mats, plan, MAX_KPTS, MIN_CONF, batch_pairs=BATCH_PAIRS,
+                                  collate_always=distributed)
     c0 = ctx_e[0]
 
     # synthetic stream, resident in HBM: a pool of rounds that the timed loop cycles through
@@ -438,7 +443,7 @@ def main():
 
     def barrier():
         pipe.sync()
-        if world > 1:
+        if distributed:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -542,7 +547,7 @@ def main():
             mat.set_precision("f16x3")
 
     times = np.array([dt, s_dt, x_dt or 0.0, e_dt or 0.0])
-    if world > 1:
+    if distributed:
         t = torch.tensor(times, dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         times = t.cpu().numpy()
@@ -634,7 +639,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

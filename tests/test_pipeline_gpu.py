@@ -141,6 +141,17 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     assert d["config"]["frames_per_step_per_gpu"] == 6
 
 
+def test_bench_rccl_branches_with_one_rank():
+    """bench.py's N > 1 branches over RCCL on one GPU (SSLAM_BENCH_FORCE_DIST=1): `nccl` process group on the device,
+    collective barrier around the timed region, max-reduce of the times, the pipeline's collation path - same JSON
+    contract, a positive rate."""
+    import sys
+    d = _run_bench({"SSLAM_BENCH_FORCE_DIST": "1", "SSLAM_DIST_BACKEND": "nccl", "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": "29623"},
+                   [sys.executable, "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-extras"])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["frames_per_step_per_gpu"] == 6
+
+
 def _run_dist_check(backend, nproc, port):
     import os, subprocess, sys
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", SSLAM_DIST_BACKEND=backend,
