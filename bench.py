@@ -386,7 +386,29 @@ def main():
     # SSLAM_BENCH_FORCE_DIST=1 (tests): take the N > 1 branches - process group, collective barrier, max-reduce of the
     # time, the pipeline's collation path - with ONE rank, so the RCCL code has run on a single-GPU box
     distributed = world > 1 or os.environ.get("SSLAM_BENCH_FORCE_DIST") == "1"
-    if distributed:
+    backend = os.environ.get("SSLAM_DIST_BACKEND", "nccl")
+    comm = None
+    if distributed and backend == "rccl":
+        # RCCL driven directly (opencv-simpleslam_amd/rccl.py): the library - and with it the SYSTEM HIP runtime - first,
+        # torch only for the CPU-side rendezvous (gloo); its GPU side is never initialised in this process
+        pkg_ = importlib.import_module("opencv-simpleslam_amd")
+        if pkg_._native.device_count() < 1:
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+        device_index = local_rank % pkg_._native.device_count()
+        pkg_._native.default_context(device_index)
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29621")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        rccl = importlib.import_module("opencv-simpleslam_amd.rccl")
+
+        def _exchange(payload):
+            box = [payload]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        comm = rccl.RcclComm.create(rank, world, _exchange)
+    elif distributed:
         # one process per GPU; SSLAM_DIST_BACKEND=gloo + fewer GPUs than ranks is a test-only mode that
         # exercises the N > 1 code path on a single-GPU box (ranks share device local_rank % n_gpus).
         # torch brings its own HIP runtime: it must initialise BEFORE libsslam_hip.so touches the
@@ -395,7 +417,6 @@ def main():
         import torch.distributed as dist
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-        backend = os.environ.get("SSLAM_DIST_BACKEND", "nccl")
         device_index = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(device_index)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -434,7 +455,7 @@ def main():
             mat.debug_big_gemm(int(os.environ["SSLAM_BIG_GEMM"]))
     plan = fs.ShardPlan(world, rank, FRAMES_PER_RANK)
     pipe = fs.FrameStreamPipeline(dets, mats, plan, MAX_KPTS, MIN_CONF, batch_pairs=BATCH_PAIRS,
-                                  collate_always=distributed)
+                                  collate_always=distributed, comm=comm)
     c0 = ctx_e[0]
 
     # synthetic stream, resident in HBM: a pool of rounds that the timed loop cycles through
@@ -443,7 +464,9 @@ def main():
 
     def barrier():
         pipe.sync()
-        if distributed:
+        if comm is not None:
+            dist.barrier()                                       # (gloo, host side; the device is idle after pipe.sync())
+        elif distributed:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -548,7 +571,7 @@ def main():
 
     times = np.array([dt, s_dt, x_dt or 0.0, e_dt or 0.0])
     if distributed:
-        t = torch.tensor(times, dtype=torch.float64, device="cuda")
+        t = torch.tensor(times, dtype=torch.float64, device="cpu" if comm is not None else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         times = t.cpu().numpy()
     dt_max, s_dt_max, x_dt_max, e_dt_max = (float(v) for v in times)
@@ -582,7 +605,9 @@ def main():
                                                       zip(*np.unique(info[info[:, 2] > 0, 1], return_counts=True))},
                        "pairs_per_lightglue_launch": BATCH_PAIRS, "frames_per_aliked_launch": pipe.EF,
                        "parallelism": f"frame-shard x{world}; per GPU {N_EXT} extractor + {N_MAT} matcher streams, "
-                                      f"ALIKED in batches of {pipe.EF} frames, LightGlue in batches of {BATCH_PAIRS} pairs"},
+                                      f"ALIKED in batches of {pipe.EF} frames, LightGlue in batches of {BATCH_PAIRS} pairs"
+                                      + (f"; collation: {'RCCL directly' if comm is not None else backend + ' through torch.distributed'}"
+                                         if distributed else "")},
             # achieved = ALGORITHMIC flops (8 n0 n1 256 per pair, x pairs per launch) / HIP-event launch
             # duration on an otherwise idle GPU; the kernel issues 3 v_mfma_f32_32x32x16_f16 per
             # algorithmic product (executed = 3x)

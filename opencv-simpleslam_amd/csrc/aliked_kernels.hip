@@ -1465,6 +1465,7 @@ Dims al_dims(int H, int W, int C) {
 // per-frame pointer is frame 0's plus f * g->fs (see fsh above).  F = 1 is the single-frame entry.
 int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C, int n_limit, const FrameOut& outs) {
     hipStream_t s = g->ctx->stream;
+    (void)hipGetLastError();     // (a stale error of another library on this thread - e.g. RCCL's probes - is not ours)
     const ResizePlan rp = resize_plan(H, W, 1024);
     const Dims d = al_dims(H, W, C);
     SSLAM_REQUIRE(d.Hp <= g->Hp_cap && d.Wp <= g->Wp_cap && d.h >= 8 && d.w >= 8,

@@ -100,6 +100,7 @@ int launch_ba(sslam_ctx* ctx, int n_obs, const int32_t* pose_idx, const int32_t*
               const double* uv, const double* q, const double* t, const double* X,
               const double* intr, double* r, double* Jq, double* Jt, double* JX) {
     if (n_obs == 0) return 0;
+    (void)hipGetLastError();     // (a stale error of another library on this thread is not ours)
     const int blocks = sslam::cdiv(n_obs, BA_THREADS);
     hipLaunchKernelGGL(ba_residual_jacobian_kernel, dim3(blocks), dim3(BA_THREADS), 0, ctx->stream,
                        n_obs, pose_idx, point_idx, uv, q, t, X, intr, r, Jq, Jt, JX);

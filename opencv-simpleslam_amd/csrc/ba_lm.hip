@@ -675,6 +675,7 @@ extern "C" int sslam_ba_solve_host(sslam_ctx* ctx, int n_obs, const int32_t* pos
     a.pstep = (double*)(b + o_ps); a.px = (double*)(b + o_px); a.pgmax = (double*)(b + o_pg);
     a.ctrl = (LMCtrl*)(b + o_ctrl);
 
+    (void)hipGetLastError();     // (a stale error of another library on this thread is not ours)
     hipLaunchKernelGGL(lm_eval_kernel<false>, dim3(nb_obs), dim3(LM_T), 0, s, a);
     hipLaunchKernelGGL(lm_init_kernel, dim3(1), dim3(LM_T), 0, s, a);
     for (int it = 0; it < max_iters; ++it) {

@@ -2072,6 +2072,7 @@ bool lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, in
 int lg_enqueue(sslam_lightglue* g, int pairs, const StageSrc& src, float min_conf, int32_t* ij_out,
                float* score_out, int32_t* info_out, long out_stride) {
     hipStream_t s = g->ctx->stream;
+    (void)hipGetLastError();     // (a stale error of another library on this thread - e.g. RCCL's probes - is not ours)
     const int Kc = g->Kc, NI = 2 * pairs;
     hipLaunchKernelGGL(lg_prepare_kernel, dim3(NI, 8), dim3(1024), 0, s, src, Kc, g->in_xy, g->in_desc, g->bbox,
                        g->ind, g->prune, g->ctrl);

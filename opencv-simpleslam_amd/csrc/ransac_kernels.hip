@@ -451,6 +451,7 @@ void rs_enqueue(hipStream_t s, RSArgs a, int max_iters) {
     // the sample loop in chunks: a chunk whose first sample lies beyond the (shrinking) budget is a
     // handful of early-exit launches, so a typical call costs two or three chunks, not max_iters
     constexpr int CHUNK = 128;
+    (void)hipGetLastError();     // (a stale error of another library on this thread is not ours)
     for (int h0 = 0; h0 < max_iters; h0 += CHUNK) {
         a.h0 = h0; a.h1 = std::min(h0 + CHUNK, max_iters);
         hipLaunchKernelGGL(rs_subsets_kernel, dim3(1), dim3(64), 0, s, a);

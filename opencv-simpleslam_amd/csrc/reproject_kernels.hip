@@ -159,6 +159,7 @@ int rp_enqueue(sslam_ctx* ctx, const RPScratch& sc, int n_points, const double* 
                int img_w, int img_h, double radius_px, double max_dist, int32_t* out_d, float* uv_d, int32_t* info_d) {
     hipStream_t s = ctx->stream;
     char* b = sc.base;
+    (void)hipGetLastError();     // (a stale error of another library on this thread is not ours)
     SSLAM_HIP_CHECK(hipMemcpyAsync(b + sc.K, K9, 72, hipMemcpyHostToDevice, s));
     SSLAM_HIP_CHECK(hipMemcpyAsync(b + sc.T, Tcw16, 128, hipMemcpyHostToDevice, s));
     SSLAM_HIP_CHECK(hipMemsetAsync(info_d, 0, 16, s));

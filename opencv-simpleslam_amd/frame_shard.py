@@ -138,13 +138,17 @@ class FrameStreamPipeline:
     matcher needs max_pairs >= batch_pairs)."""
 
     def __init__(self, detectors, matchers, plan: ShardPlan, max_kpts: int, min_conf: float = 0.7,
-                 batch_pairs: int | None = None, group=None, use_graphs: bool = True, collate_always: bool = False):
+                 batch_pairs: int | None = None, group=None, use_graphs: bool = True, collate_always: bool = False,
+                 comm=None):
         self.dets = list(detectors) if isinstance(detectors, (list, tuple)) else [detectors]
         self.mats = list(matchers) if isinstance(matchers, (list, tuple)) else [matchers]
         self.plan, self.group = plan, group
         # collate_always: take the multi-GPU path (torch-owned slab, collation stream, per-half all-gathers, halo record)
         # with ONE rank too - how the tests run the RCCL branch on a single GPU
+        # comm: an `rccl.RcclComm` - the collation runs on RCCL directly, over memory of the C-ABI (no torch in the data
+        # path); without it the exchange goes through torch.distributed (`group`; gloo in the CPU / shared-GPU tests)
         self.distributed = plan.world > 1 or bool(collate_always)
+        self.comm = comm if self.distributed else None
         # every round cycles through the same record slots: each extractor / matcher call sequence is
         # replayed as a cached hipGraph (one hipGraphLaunch instead of 45 / 190 launches per call)
         for x in self.dets + self.mats:
@@ -165,7 +169,19 @@ class FrameStreamPipeline:
         self.NSLOT = 2 * B + 2
         dev_bytes = self.NSLOT * self.REC * 4
         self.torch = None
-        if self.distributed:
+        self.cctx = None
+        if self.distributed and self.comm is not None:
+            from . import _native
+            self.slab = self.ctx.malloc(dev_bytes)
+            self.ctx.memset_async(self.slab, 0, dev_bytes)
+            self.cctx = _native.Context(self.ctx.device)         # the collation has a stream of its own (see below)
+            gbytes = plan.world * B * self.REC * 4
+            self._gathered_ptr = [self.ctx.malloc(gbytes), self.ctx.malloc(gbytes)]
+            for g_ in self._gathered_ptr:
+                self.ctx.memset_async(g_, 0, gbytes)
+            self.halves = [(0, (B + 1) // 2), ((B + 1) // 2, B)] if B > 1 else [(0, B)]
+            self.ctx.sync()
+        elif self.distributed:
             # the exchange goes through torch.distributed: its tensors own the record slab
             import torch
             self.torch = torch
@@ -201,7 +217,8 @@ class FrameStreamPipeline:
         self.have_halo = False
         self.rounds = 0
         self.batches = 0                                         # global batch counter (matcher round-robin)
-        self.shared_map = None          # last collated round [world*B, REC] (torch tensor; N > 1 only)
+        self.shared_map = None          # last collated round [world*B, REC] (torch tensor; torch.distributed path only)
+        self.shared_map_ptr = 0         # ... its device address (both paths)
 
     # ---- record addressing (slot = index into the slab; set p holds slots p*B .. p*B + B-1)
     def rec_ptr(self, slot: int) -> int:
@@ -276,7 +293,30 @@ class FrameStreamPipeline:
                     d.ctx.record(self.ev_ext[p][s])
         have_halo = self.have_halo
         prev_slot = (1 - p) * B + B - 1                  # last frame of the previous round (one GPU)
-        if not single:
+        if not single and self.comm is not None:
+            # ---- multi-GPU, RCCL directly: the same choreography as below on raw device memory
+            G = self._gathered_ptr[p]
+            rb = self.REC * 4
+            prev = plan.rank * B - 1
+            if prev < 0:
+                # rank 0: the halo is the LAST record of the previous round's collation - in place already, so the copy
+                # (and the halo event the first batch waits for) goes in front of this round's gathers
+                if have_halo:
+                    self.cctx.d2d_async(self.rec_ptr(halo_slot), self._gathered_ptr[1 - p] + (plan.world * B - 1) * rb, rb)
+                self.cctx.record(self.ev_halo[p])
+            for (lo, hi) in self.halves:
+                for s in range(lo, hi):
+                    self.cctx.wait(self.ev_ext[p][s])
+                self.comm.all_gather_rows(self.cctx.stream, self.rec_ptr(s_base), G, B, lo, hi, rb)
+            self.shared_map_ptr = G
+            if prev >= 0:
+                # other ranks: the last frame of the neighbour, gathered in this round's second half
+                self.cctx.d2d_async(self.rec_ptr(halo_slot), G + prev * rb, rb)
+                have_halo = True
+                self.cctx.record(self.ev_halo[p])
+            self.cctx.record(self.ev_collated[p])
+            prev_slot = halo_slot
+        elif not single:
             # ---- multi-GPU: collate each HALF of the round as soon as its extracts are done (the first
             # all-gather runs under the second half's extracts, the second under the matches), on the
             # collation stream; the matches run on their own streams underneath.
@@ -286,33 +326,43 @@ class FrameStreamPipeline:
                 # G was last written two rounds ago; its readers since: that round's halo copy (same stream) and
                 # the NEXT round's halo copy on rank 0 (same stream too) - stream order covers both
                 pass
+            prev = plan.rank * B - 1                         # index inside the gathered round
             with torch.cuda.stream(self._cstream):
+                if prev < 0:
+                    # rank 0: the halo is the LAST record of the previous round's collation - in place already, so the
+                    # copy (and the halo event the first batch waits for) goes in front of this round's gathers
+                    if have_halo:
+                        self._slab_t[halo_slot].copy_(self._gathered[1 - p][plan.world * B - 1])
+                    self.cctx.record(self.ev_halo[p])
                 for (lo, hi) in self.halves:
                     for s in range(lo, hi):
                         self.cctx.wait(self.ev_ext[p][s])
                     collate(self._slab_t[s_base:s_base + B], plan, self.group, out=G, part=(lo, hi), always=True)
                 self.shared_map = G
-                prev = plan.rank * B - 1                     # index inside the gathered round
+                self.shared_map_ptr = int(G.data_ptr())
                 if prev >= 0:
-                    src = G[prev]
-                elif have_halo:
-                    src = self._gathered[1 - p][plan.world * B - 1]      # last record of the previous round
-                else:
-                    src = None
-                if src is not None:
-                    self._slab_t[halo_slot].copy_(src)
+                    # other ranks: the last frame of the neighbour, gathered in this round's second half
+                    self._slab_t[halo_slot].copy_(G[prev])
                     have_halo = True
-                else:
-                    have_halo = False
-            self.cctx.record(self.ev_halo[p])                # halo of THIS round is in place
+                    self.cctx.record(self.ev_halo[p])
             self.cctx.record(self.ev_collated[p])
             prev_slot = halo_slot
         # ---- batched matches: pair s = (s-1, s); pair 0 = (previous frame, 0)
         out_base = p * B
         s0 = 0 if have_halo else 1
-        j = 0
+        spans = []
         while s0 < B:
             s1 = min(B, (s0 // P + 1) * P)
+            spans.append((s0, s1))
+            s0 = s1
+        if not single and plan.rank > 0 and len(spans) > 1 and spans[0][0] == 0:
+            # multi-GPU: the batch with the halo pair (previous frame = a neighbour's record, in place only after this
+            # round's all-gathers) goes LAST; the others need local extracts only and start under the collation
+            # (r03: enqueued first, it held every matcher stream back until the whole round was extracted and gathered -
+            # 957 -> see DESIGN section 7)
+            spans = spans[1:] + spans[:1]
+        j = 0
+        for s0, s1 in spans:
             m = self.mats[self.batches % NM]
             pairs = []
             for s in range(s0, s1):
@@ -332,7 +382,6 @@ class FrameStreamPipeline:
             m.ctx.record(self.ev_batch[p][j])
             self.batches += 1
             j += 1
-            s0 = s1
         self.n_batches[p] = j
         self.have_halo = True
         self.rounds += 1
@@ -340,7 +389,7 @@ class FrameStreamPipeline:
     def sync(self):
         for c in {id(x.ctx): x.ctx for x in self.dets + self.mats}.values():
             c.sync()
-        if self.torch is not None:
+        if self.cctx is not None:
             self.cctx.sync()
 
     def _checked_infos(self):

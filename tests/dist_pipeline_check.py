@@ -6,7 +6,9 @@ checks its own frames against the sequential host API - keypoints, the match ind
 the ones that straddle a rank / round boundary (which need the gathered features of the neighbour) - and the
 collated shared map of every round.
 
-    SSLAM_DIST_BACKEND = gloo (default; ranks may share GPU 0) | nccl (= RCCL: one GPU per rank)
+    SSLAM_DIST_BACKEND = gloo (default; ranks may share GPU 0) | nccl (= RCCL through torch: one GPU per rank)
+                       | rccl (RCCL driven directly, opencv-simpleslam_amd/rccl.py: records in C-ABI memory, torch only
+                         carries the communicator id over gloo and never touches the GPU)
 """
 import importlib
 import os
@@ -23,12 +25,28 @@ import frames                                                      # noqa: E402
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 backend = os.environ.get("SSLAM_DIST_BACKEND", "gloo")
-dev = int(os.environ.get("LOCAL_RANK", rank)) % torch.cuda.device_count() if backend == "nccl" else 0
-torch.cuda.set_device(dev)
-if backend == "nccl":
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
-else:
+comm = None
+if backend == "rccl":
+    # the system HIP runtime first (the library), then torch for the CPU-side rendezvous only
+    pkg = importlib.import_module("opencv-simpleslam_amd")
+    nat = pkg._native
+    dev = int(os.environ.get("LOCAL_RANK", rank)) % nat.device_count()
+    ctx_first = nat.default_context(dev)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    rccl = importlib.import_module("opencv-simpleslam_amd.rccl")
+
+    def _exchange(payload):
+        box = [payload]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+    comm = rccl.RcclComm.create(rank, world, _exchange)
+else:
+    dev = int(os.environ.get("LOCAL_RANK", rank)) % torch.cuda.device_count() if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 pkg = importlib.import_module("opencv-simpleslam_amd")
 nat = pkg._native
 W = importlib.import_module("opencv-simpleslam_amd.weights")
@@ -49,7 +67,7 @@ ref = [None] + [mat0.match(feats[i - 1][0], feats[i - 1][1], feats[i][0], feats[
 plan = fs.ShardPlan(world, rank, B)
 dets = [AL(sd_a, max_num_keypoints=K, max_h=H, max_w=Wd, ctx=nat.Context(dev), max_frames=2) for _ in range(2)]   # chunks of 2 frames per extractor call (ragged last chunk)
 mats = [LG(sd_l, max_kpts=K, ctx=nat.Context(dev), max_pairs=2, filter_threshold=0.0) for _ in range(2)]
-pipe = fs.FrameStreamPipeline(dets, mats, plan, K, 0.0, batch_pairs=2, collate_always=True)    # (one rank: still the collective path)
+pipe = fs.FrameStreamPipeline(dets, mats, plan, K, 0.0, batch_pairs=2, collate_always=True, comm=comm)    # (one rank: still the collective path)
 ctx = pipe.ctx
 col = nat.Context(dev)                      # collector stream: snapshots a round's outputs without a host sync
 chunks = [ctx.upload(np.stack([imgs[f] for f in plan.frames(r)])) for r in range(ROUNDS)]
@@ -64,7 +82,7 @@ for rnd in range(ROUNDS):
     col.d2d_async(h["rec"], pipe.rec_ptr(pset * B), B * pipe.REC * 4)
     col.d2d_async(h["ij"], pipe.ij, B * K * 8)
     col.d2d_async(h["info"], pipe.info, B * 16)
-    col.d2d_async(h["smap"], int(pipe.shared_map.data_ptr()), world * B * pipe.REC * 4)
+    col.d2d_async(h["smap"], pipe.shared_map_ptr, world * B * pipe.REC * 4)
     ev = col.event(); col.record(ev)        # the pipeline's next-but-one round must not overwrite before the copies ran
     for d in pipe.dets:
         d.ctx.wait(ev)
@@ -101,4 +119,6 @@ for c_ in chunks:
 assert sum(len(r[0]) for r in ref[1:]) > 5, "vacuous: the sequential reference found no matches"
 dist.barrier()
 print(f"rank {rank} ({backend}, device {dev}): {checked} pairs identical to the sequential API over {ROUNDS} un-synchronised rounds", flush=True)
+if comm is not None:
+    comm.close()
 dist.destroy_process_group()

@@ -186,6 +186,13 @@ def test_one_rank_pipeline_over_rccl():
     _run_dist_check("nccl", 1, 29617)
 
 
+def test_one_rank_pipeline_over_rccl_directly():
+    """The collation on RCCL driven directly (opencv-simpleslam_amd/rccl.py, backend `rccl`): communicator from an id
+    exchanged over gloo, per-half gathers as broadcast groups on the collation stream, records and the gathered map in
+    C-ABI memory, torch never touching the GPU (the ranks keep the system HIP runtime) - with one rank on the test box."""
+    _run_dist_check("rccl", 1, 29625)
+
+
 def test_pipeline_reports_a_split_precision_range_overflow(native):
     """the headline path must not hand on matches computed past the fp16 range of the
     split-precision planes.  Token states scaled by 1e7 through the PIPELINE: `results()` / `infos()` raise,
