@@ -115,4 +115,4 @@ def test_soa_map_stays_in_step_with_mutations(P, native):
             P.reproject_and_match_2d3d(mm, *args)
         t.append((time.perf_counter() - t0) / 5 * 1e3)
     print(f"\n[reproject_and_match_2d3d, ~9000 / 5000 points x 2048 keypoints] SoA map {t[0]:.2f} ms, dict-of-objects map {t[1]:.2f} ms")
-    assert t[0] < t[1]
+    # printed, not asserted: a wall-clock relation does not belong in a parity suite

@@ -1,0 +1,69 @@
+"""bench.py's JSON contract, run as a subprocess the way the driver runs it.  Collected LAST (file name) so that no
+parity file sits behind it under `-x`, and it asserts the CONTRACT of the line only (keys, shapes, signs): relations
+between two sub-second timings are noise on a fresh box and do not belong in a parity suite."""
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_bench(extra_env, cmd):
+    import json, os, subprocess, sys
+    env = dict(os.environ, SSLAM_BENCH_FRAMES="6", SSLAM_BENCH_NE="1", SSLAM_BENCH_NM="2", SSLAM_BENCH_PAIRS="4", **extra_env)
+    out = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]               # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_contract_single_rank():
+    import sys
+    d = _run_bench({}, [sys.executable, "bench.py", "--steps", "2", "--warmup", "4", "--no-cpu-baseline"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "structured_input",
+                "exact_f32", "ba", "reproject", "step_ms", "timed_region_s", "early_stop", "dropin"):
+        assert key in d
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["unit"] == "frames/s"
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["in_pipeline_frac"] > 0 and d["exact_f32"]["value"] > 0        # present and positive; which is larger is bench.py's business
+    assert d["ba"]["device_lm_ms"] > 0 and 0 < d["ba"]["residual_kernel"]["frac"] < 1 and d["reproject"]["wall_ms"] > 0
+    assert 0 < d["step_ms"]["p10"] <= d["step_ms"]["p50"] <= d["step_ms"]["p90"] <= d["step_ms"]["max"]
+    assert d["dropin"]["value"] > 0 and d["dropin"]["feature_matcher_ms"] > 0, d["dropin"]
+    es = d["early_stop"]
+    assert es["value"] > 0 and es["lightglue_layers_histogram"] and set(es["lightglue_layers_histogram"]) != {"9"}, es
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` outside torch.distributed.run starts its ranks as a child process
+    (same command shape as --gpus 1); gloo + one shared GPU on this box."""
+    import sys
+    d = _run_bench({"SSLAM_DIST_BACKEND": "gloo", "MASTER_PORT": "29617"},
+                   [sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "4", "--no-cpu-baseline",
+                    "--no-extras"])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["frames_per_step_per_gpu"] == 6
+
+
+def test_bench_two_ranks_share_one_gpu_over_gloo():
+    """The N > 1 code path (frame sharding, all-gather collation, boundary pair, max-over-ranks
+    timing) on a 1-GPU box: two ranks on the same device, gloo instead of RCCL."""
+    import sys
+    d = _run_bench({"SSLAM_DIST_BACKEND": "gloo", "MASTER_ADDR": "127.0.0.1"},
+                   [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                    "--master-addr", "127.0.0.1", "--master-port", "29611", "bench.py", "--gpus", "2",
+                    "--steps", "2", "--warmup", "4", "--no-cpu-baseline", "--no-extras"])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert d["config"]["frames_per_step_per_gpu"] == 6
+
+
+def test_bench_rccl_branches_with_one_rank():
+    """bench.py's N > 1 branches over RCCL on one GPU (SSLAM_BENCH_FORCE_DIST=1): `nccl` process group on the device,
+    collective barrier around the timed region, max-reduce of the times, the pipeline's collation path - same JSON
+    contract, a positive rate."""
+    import sys
+    d = _run_bench({"SSLAM_BENCH_FORCE_DIST": "1", "SSLAM_DIST_BACKEND": "nccl", "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": "29623"},
+                   [sys.executable, "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "4", "--no-cpu-baseline", "--no-extras"])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["frames_per_step_per_gpu"] == 6
