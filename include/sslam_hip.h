@@ -307,6 +307,11 @@ int sslam_lightglue_debug_key_split(sslam_lightglue* lg, int ks);
  * (a token's FFN arithmetic is the same in both: bit-identical), 5 = batched form with the token heads (early stop /
  * pruning inputs) as a launch of their own instead of in the cross block's fused FFN. */
 int sslam_lightglue_debug_big_gemm(sslam_lightglue* lg, int mode);
+/* Precision-study hook (profiles/r04_split_study.md; the product never sets it): drop cross terms of the three-term
+ * split products and measure what that does to the matches.  mask: 0x01 / 0x02 K / Q as one fp16 plane in the logits,
+ * 0x04 / 0x08 P / V as one plane in the context, 0x10 / 0x20 activation low plane dropped in the projections / the FFN,
+ * 0x40 / 0x80 weight low plane dropped there.  0 = the product arithmetic. */
+int sslam_lightglue_debug_split_form(sslam_lightglue* lg, int mask);
 int sslam_lightglue_debug_read(sslam_lightglue* lg, int which, void* dst, size_t bytes);
 
 #ifdef __cplusplus

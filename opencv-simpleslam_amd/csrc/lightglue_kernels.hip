@@ -1386,6 +1386,7 @@ struct AttnArgsH {
     float* o_part; float* m_part; float* l_part;      // key-split partials (KS > 1)
     SplitOut msg;                                     // KS == 1: the normalised context goes straight to the split planes
     int KS; int Kc; int NIc; const LGCtrl* ctrl;
+    int p_single;                                     // precision study only (sslam_lightglue_debug_split_form bit 0x04): P as ONE fp16 plane
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
@@ -1430,7 +1431,7 @@ constexpr float RESCALE_THR = 1.5f;
 template <bool MASK>
 __device__ __forceinline__ void attn_softmax_step(const f32x16& s1, const f32x16& s2, int kbase, int nk, int lane,
                                                   float& m_run, float& l_run, half8 (&ph)[2], half8 (&pl)[2],
-                                                  float& alpha, bool& rescale, bool qvalid) {
+                                                  float& alpha, bool& rescale, bool qvalid, bool p_single) {
     float2v sv[8];
     const float2v inv2 = {SPLIT_INV, SPLIT_INV};
 #pragma unroll
@@ -1480,13 +1481,21 @@ __device__ __forceinline__ void attn_softmax_step(const f32x16& s1, const f32x16
     for (int r = 0; r < 8; ++r) {
         const float p0 = __builtin_amdgcn_exp2f(sv[r][0] - mb);
         const float p1 = __builtin_amdgcn_exp2f(sv[r][1] - mb);
-        psum0 += p0; psum1 += p1;
         const float2v pv2 = {p0, p1};
-        const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_convertvector(pv2, sslam::half2v));
+        const sslam::half2v hv2 = __builtin_convertvector(pv2, sslam::half2v);
+        const unsigned h2 = __builtin_bit_cast(unsigned, hv2);
         unsigned l2;
-        // l2.lo = fp16(h2.lo * -1 + p0) ; l2.hi = fp16(h2.hi * -1 + p1)   (sources: fp16 half, f32, f32)
-        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l2) : "v"(h2), "v"(p0));
-        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l2) : "v"(h2), "v"(p1));
+        if (p_single) {
+            // precision study (never the product): P is its fp16 rounding alone and the row sum is taken over the ROUNDED
+            // weights, so o / l stays an exact softmax of slightly perturbed logits
+            psum0 += (float)hv2[0]; psum1 += (float)hv2[1];
+            l2 = 0u;
+        } else {
+            psum0 += p0; psum1 += p1;
+            // l2.lo = fp16(h2.lo * -1 + p0) ; l2.hi = fp16(h2.hi * -1 + p1)   (sources: fp16 half, f32, f32)
+            asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l2) : "v"(h2), "v"(p0));
+            asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l2) : "v"(h2), "v"(p1));
+        }
         hu[r >> 2][r & 3] = h2;
         lu[r >> 2][r & 3] = l2;
     }
@@ -1518,6 +1527,7 @@ __global__ __launch_bounds__(256, 2) void lg_attention_p_kernel(AttnArgsH p) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int ntiles = (nk + AK - 1) / AK;
     const int t0 = (int)((long)z * ntiles / p.KS), t1 = (int)((long)(z + 1) * ntiles / p.KS);
+    const bool p_single = p.p_single != 0;
 
     const size_t qoff = ((size_t)img * NH + head) * p.Kc * DH;
     const size_t koff = ((size_t)kimg * NH + head) * p.Kc * DH;
@@ -1623,7 +1633,7 @@ __global__ __launch_bounds__(256, 2) void lg_attention_p_kernel(AttnArgsH p) {
             // even: softmax(S(tile,0)) | S(tile,1) = K.Q^T | O += V^T(tile-1,1) P
             pv(tile > t0 ? b ^ 1 : b, 1, ph, pl);
             qk(b, 1, n1, n2);
-            attn_softmax_step<MASK>(s1, s2, tile * AK, nk, lane, m_run, l_run, nh, nl, alpha, rescale, qvalid);
+            attn_softmax_step<MASK>(s1, s2, tile * AK, nk, lane, m_run, l_run, nh, nl, alpha, rescale, qvalid, p_single);
             ATTN_INTERLEAVE();
             if (rescale) { o1a *= alpha; o2a *= alpha; o1b *= alpha; o2b *= alpha; }
             __syncthreads();     // K(tile+1), V^T(tile) landed; K(tile) and V^T(tile-1) are free
@@ -1632,7 +1642,7 @@ __global__ __launch_bounds__(256, 2) void lg_attention_p_kernel(AttnArgsH p) {
             // odd: softmax(S(tile,1)) | S(tile+1,0) | O += V^T(tile,0) P
             pv(b, 0, nh, nl);
             qk(last ? b : b ^ 1, 0, s1, s2);
-            attn_softmax_step<MASK>(n1, n2, tile * AK + 32, nk, lane, m_run, l_run, ph, pl, alpha, rescale, qvalid);
+            attn_softmax_step<MASK>(n1, n2, tile * AK + 32, nk, lane, m_run, l_run, ph, pl, alpha, rescale, qvalid, p_single);
             ATTN_INTERLEAVE();
             if (rescale) { o1a *= alpha; o2a *= alpha; o1b *= alpha; o2b *= alpha; }
         };
@@ -1768,6 +1778,8 @@ struct sslam_lightglue {
     int dbg_self_only = 0;           // test hook: stop after the self block of the last executed layer
     int force_ks = 0;                // test hook: key split of the attention launches (0 = by batch size)
     hipError_t launch_error = hipSuccess;   // first failure of a module-API launch (checked with hipGetLastError at the end of an enqueue)
+    int study = 0;                   // precision study (sslam_lightglue_debug_split_form): which cross terms of the split products are dropped
+    _Float16* zero_plane = nullptr;  // study only: an all-zero fp16 plane standing in for a dropped low plane
     int big_gemm = -1;               // test hook: -1 by batch size, 0 / 1 force the single-pair (ring) / batched form of the linears;
                                      // 2 / 3: batched form with 64- / 32-token FFN tiles whatever the size
     _Float16 *w_hi, *w_lo;           // whole weight blob, split
@@ -1973,10 +1985,15 @@ int lg_load_attention_asm(int device) {
 
 void launch_attention_h(sslam_lightglue* g, hipStream_t s, int NI, SplitPtr Q, SplitPtr K, SplitPtr VT, int cross) {
     const int KS = attn_key_split(g, NI);
+    if (g->study) {       // precision study: a dropped cross term = its low-plane operand replaced by zeros (bit-identical to not issuing the MFMA)
+        if (g->study & 0x01) K.lo = g->zero_plane;          // S = kh.qh + kh.ql          (K as one fp16 plane)
+        if (g->study & 0x02) Q.lo = g->zero_plane;          // S = kh.qh + kl.qh          (Q as one fp16 plane)
+        if (g->study & 0x08) VT.lo = g->zero_plane;         // O = vh.ph + vh.pl          (V as one fp16 plane)
+    }
     AttnArgsH a{Q, K, VT, cross, g->o_part, g->m_part, g->l_part, SplitOut{g->msgs_hi, g->msgs_lo}, KS, g->Kc,
-                g->NIc, g->ctrl};
+                g->NIc, g->ctrl, (g->study & 0x04) ? 1 : 0};     // 0x04: O = vh.ph + vl.ph (P as one fp16 plane; 4-wave kernel only)
     attn_event(g, s, true);
-    if (g->force_ks == 0 || g->force_ks == -3 || g->force_ks > 100) {
+    if (!(g->study & 0x04) && (g->force_ks == 0 || g->force_ks == -3 || g->force_ks > 100)) {
         // the hand-scheduled assembly kernel - the arithmetic, LDS images and results of lg_attention_p_kernel (no key split: batched
         // launches, debug_key_split(lg, -3)) and of lg_attention_p_kernel's key ranges (single pairs) bit for bit, 8 - 10 % faster
         // (profiles/r03_attention_experiments.md)
@@ -2008,6 +2025,11 @@ bool lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, in
     const SplitPtr xs{g->xs_hi, g->xs_lo}, msgs{g->msgs_hi, g->msgs_lo};
     const SplitPtr hids{g->hids_hi, g->hids_lo}, none{nullptr, nullptr};
     const SplitPtr qs{g->qs_hi, g->qs_lo}, ks{g->ks_hi, g->ks_lo}, vts{g->vts_hi, g->vts_lo};
+    // precision study (sslam_lightglue_debug_split_form): W.x products with one cross term dropped - the READ side of the
+    // activation (0x10 projections, 0x20 FFN) or weight (0x40 projections, 0x80 FFN) low plane is an all-zero plane
+    const int st = g->study;
+    auto act = [&](SplitPtr a, int bit) { if (st & bit) a.lo = g->zero_plane; return a; };
+    auto wgt = [&](LinearArgsH& a, int bit) { if (st & bit) a.W.lo = g->zero_plane; };
     const unsigned tokblocks = sslam::cdiv(NI * g->Kc, 4);
     const float sm_scale = 0.125f * 1.4426950408889634f;        // 1/sqrt(64) * log2(e)
     // enough token rows for 128-row tiles to fill the chip (a batch of pairs): 128 x 128 projections and the
@@ -2017,7 +2039,7 @@ bool lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, in
                    const float* b2) {
         if (big) {
             FfnKArgs k{};
-            k.f.xs = xs; k.f.msgs = msgs; k.f.plane_rows = g->NIc * g->Kc;
+            k.f.xs = act(xs, 0x20); k.f.msgs = act(msgs, 0x20); k.f.plane_rows = g->NIc * g->Kc;   // (study: the hidden planes are internal - FFN-2 keeps 3 terms here)
             k.f.w1f = g->ffn_w1f[layer][cross]; k.f.b1 = b1; k.f.ln_w = lnw; k.f.ln_b = lnb;
             k.f.w2f = g->ffn_w2f[layer][cross]; k.f.b2 = b2;
             k.f.x = g->x; k.f.xo_hi = g->xs_hi; k.f.xo_lo = g->xs_lo; k.f.stamps = nullptr;
@@ -2035,17 +2057,20 @@ bool lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, in
                 hipLaunchKernelGGL(lg_ffn_fused_kernel<2>, dim3(NI * (g->Kc / 64)), dim3(512), sslam::FFN_LDS_BYTES, s, k);
             return;
         }
-        LinearArgsH a = linh(g, xs, msgs, D, D, 2 * D, w1, b1, 2 * D);      // [x | attention context]
+        LinearArgsH a = linh(g, act(xs, 0x20), act(msgs, 0x20), D, D, 2 * D, w1, b1, 2 * D);      // [x | attention context]
+        wgt(a, 0x80);
         a.out = g->hid; a.ldo = 2 * D;
         launch_linear_h<64, 128, 1, 2, EPH_F32>(s, NI, a);
         hipLaunchKernelGGL(lg_ln_gelu_h_kernel, dim3(tokblocks), dim3(256), 0, s, g->hid,
                            SplitOut{g->hids_hi, g->hids_lo}, lnw, lnb, g->ctrl, g->Kc, NI, g->NIc);
-        LinearArgsH c = linh(g, hids, none, 2 * D, 2 * D, 2 * D, w2, b2, D);
+        LinearArgsH c = linh(g, act(hids, 0x20), none, 2 * D, 2 * D, 2 * D, w2, b2, D);
+        wgt(c, 0x80);
         c.out = g->x; c.ldo = D; c.outs = SplitOut{g->xs_hi, g->xs_lo};
         launch_linear_h<64, 64, 1, 1, EPH_RESID>(s, NI, c);
     };
     {   // self block
-        LinearArgsH a = linh(g, xs, none, D, D, D, l.wqkv, l.bqkv, 3 * D);
+        LinearArgsH a = linh(g, act(xs, 0x10), none, D, D, D, l.wqkv, l.bqkv, 3 * D);
+        wgt(a, 0x40);
         a.q = SplitOut{g->qs_hi, g->qs_lo}; a.k = SplitOut{g->ks_hi, g->ks_lo}; a.vt = SplitOut{g->vts_hi, g->vts_lo};
         a.q_scale = sm_scale; a.k_scale = 1.0f;
         if (big) launch_linear_big<128, 128, 2, 2, EPH_QKV>(s, NI, a);
@@ -2055,7 +2080,8 @@ bool lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, in
     ffn(0, l.w1, l.b1, l.lnw, l.lnb, l.w2, l.b2);
     if (self_only) return false;
     {   // cross block: the shared qk projection is both query and key -> sqrt(scale) on it
-        LinearArgsH a = linh(g, xs, none, D, D, D, l.cqkv, l.cbqkv, 2 * D);
+        LinearArgsH a = linh(g, act(xs, 0x10), none, D, D, D, l.cqkv, l.cbqkv, 2 * D);
+        wgt(a, 0x40);
         a.q = SplitOut{g->qs_hi, g->qs_lo}; a.vt = SplitOut{g->vts_hi, g->vts_lo};
         a.q_scale = sqrtf(sm_scale);
         if (big) launch_linear_big<128, 128, 2, 2, EPH_CROSS>(s, NI, a);
@@ -2317,6 +2343,7 @@ int sslam_lightglue_destroy(sslam_lightglue* g) {
     (void)hipStreamSynchronize(g->ctx->stream);
     g->graphs.clear();
     for (hipEvent_t e : g->ev) (void)hipEventDestroy(e);
+    if (g->zero_plane) (void)hipFree(g->zero_plane);
     g->arena.release();
     sslam_ctx* ctx = g->ctx;
     delete g;
@@ -2522,6 +2549,26 @@ int sslam_lightglue_debug_big_gemm(sslam_lightglue* g, int mode) {
     SSLAM_REQUIRE(g != nullptr && mode >= -1 && mode <= 5 && mode != 4, "sslam_lightglue_debug_big_gemm: bad argument");
     g->settings_changed();
     g->big_gemm = mode;
+    return 0;
+}
+
+/* Precision study hook (profiles/r04_split_study.md; never set by the product): drop cross terms of the three-term split
+ * products.  mask bits - attention logits: 0x01 K as one fp16 plane (S = kh.qh + kh.ql), 0x02 Q as one plane; context:
+ * 0x04 P as one plane (row sum over the rounded weights; runs on the 4-wave kernel), 0x08 V as one plane; W.x products:
+ * activation low plane dropped in the projections (0x10) / the FFN (0x20), weight low plane dropped in the projections
+ * (0x40) / the FFN (0x80).  A dropped term is computed against an all-zero plane (same bits as not issuing the MFMA).
+ * With the fused FFN kernel (batched form) the hidden activations stay three-term; debug_big_gemm(lg, 0) covers them. */
+int sslam_lightglue_debug_split_form(sslam_lightglue* g, int mask) {
+    SSLAM_REQUIRE(g != nullptr && mask >= 0 && mask <= 0xff, "sslam_lightglue_debug_split_form: bad argument");
+    g->settings_changed();
+    if (mask && !g->zero_plane) {
+        const size_t act = (size_t)g->NIc * g->Kc * 2 * D, wmax = (size_t)4 * D * D;
+        const size_t n = (act > wmax ? act : wmax) * sizeof(_Float16);
+        SSLAM_HIP_CHECK(hipSetDevice(g->ctx->device));
+        SSLAM_HIP_CHECK(hipMalloc((void**)&g->zero_plane, n));
+        SSLAM_HIP_CHECK(hipMemset(g->zero_plane, 0, n));
+    }
+    g->study = mask;
     return 0;
 }
 

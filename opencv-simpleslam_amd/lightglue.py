@@ -130,6 +130,10 @@ class LightGlueHIP:
         any size: -1 the 4-wave kernel, -3 the assembly kernel - for A/B and bit-identity checks."""
         _native.check(_native.lib().sslam_lightglue_debug_key_split(self.handle, int(ks)))
 
+    def debug_split_form(self, mask: int):
+        """Precision-study hook (profiles/r04_split_study.md): drop cross terms of the split products; 0 = product."""
+        _native.check(_native.lib().sslam_lightglue_debug_split_form(self.handle, int(mask)))
+
     def debug_big_gemm(self, mode: int):
         """Test hook: -1 linears by batch size, 0 always the 64-row ring kernels (single-pair form), 1 always the
         batched form (128 x 128 projections + the whole FFN as one kernel, its tile by token count), 2 / 3 the batched
