@@ -47,6 +47,7 @@ MAX_IMAGE_W = int(os.environ.get("SSLAM_MAX_IMAGE_W", 4096))
 
 
 ENV_ALLOW_RANDOM = "SSLAM_ALLOW_RANDOM_WEIGHTS"
+ENV_RANDOM_LG_ARGS = "SSLAM_RANDOM_LIGHTGLUE_ARGS"   # e.g. "seed=1,match_gain=4.0,match_bias=3.0": arguments of the random fallback
 
 
 def _state_dict(env_name, random_fn, what):
@@ -64,7 +65,13 @@ def _state_dict(env_name, random_fn, what):
             f"{ENV_ALLOW_RANDOM}=1 to run seeded RANDOM weights (synthetic benchmarking / parity tests only)")
     _log.warning("%s: %s unset - running seeded RANDOM-INIT weights (%s=1): matches are meaningless on real imagery",
                  what, env_name, ENV_ALLOW_RANDOM)
-    return random_fn(0)
+    kw = {}
+    if env_name == ENV_LIGHTGLUE and os.environ.get(ENV_RANDOM_LG_ARGS):
+        # synthetic benchmarking only: a random init whose assignment head is sharp enough to produce matches
+        for item in os.environ[ENV_RANDOM_LG_ARGS].split(","):
+            k, v = item.split("=")
+            kw[k.strip()] = int(v) if k.strip() == "seed" else float(v)
+    return random_fn(kw.pop("seed", 0), **kw)
 
 
 def init_feature_pipeline(args):
