@@ -68,6 +68,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3           # same table: v_mfma_f32_32x32x2_f32, the
 HBM_PEAK_GBS = 8000.0
 ALIKED_GFLOP_PER_FRAME = 8.9           # 6.56 dense conv + 2.34 SDDH at 2048 keypoints
 EARLY_STOP_CONF_BIAS = float(os.environ.get("SSLAM_BENCH_CONF_BIAS", 1.7))   # early_stop leg (scripts/probe_early_stop.py)
+EARLY_STOP_MATCH_BIAS = float(os.environ.get("SSLAM_BENCH_MATCH_BIAS", -4.6))
 
 
 def _pmc_traffic():
@@ -364,6 +365,8 @@ def _self_launch(args):
            "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
+    if args.no_extras:
+        cmd.append("--no-extras")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     res = subprocess.run(cmd, env=env, capture_output=True, text=True)
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
@@ -395,7 +398,9 @@ def main():
     # SSLAM_BENCH_FORCE_DIST=1 (tests): take the N > 1 branches - process group, collective barrier, max-reduce of the
     # time, the pipeline's collation path - with ONE rank, so the RCCL code has run on a single-GPU box
     distributed = world > 1 or os.environ.get("SSLAM_BENCH_FORCE_DIST") == "1"
-    backend = os.environ.get("SSLAM_DIST_BACKEND", "nccl")
+    # ONE default for `bench.py --gpus N`: RCCL driven directly (the ranks keep the system HIP runtime; measured 950 vs 947
+    # frames/s against torch's `nccl` with one rank, r03).  SSLAM_DIST_BACKEND=nccl / gloo select torch.distributed.
+    backend = os.environ.get("SSLAM_DIST_BACKEND", "rccl")
     comm = None
     if distributed and backend == "rccl":
         # RCCL driven directly (opencv-simpleslam_amd/rccl.py): the library - and with it the SYSTEM HIP runtime - first,
@@ -471,8 +476,10 @@ def main():
     n_pool = 4
     pool = [c0.upload(np.stack([noise_frame(f) for f in plan.frames(r)])) for r in range(n_pool)]
 
-    def barrier():
+    def barrier(p_=None):
         pipe.sync()
+        if p_ is not None and p_ is not pipe:
+            p_.sync()                                            # (a leg's own matcher streams)
         if comm is not None:
             dist.barrier()                                       # (gloo, host side; the device is idle after pipe.sync())
         elif distributed:
@@ -487,7 +494,7 @@ def main():
         p_ = p_ or pipe
         for i in range(warmup):
             p_.round(frames_pool[i % len(frames_pool)], H_IMG, W_IMG, C_IMG)
-        barrier()
+        barrier(p_)
         if stamp:
             while len(stamps) < steps + 1:
                 stamps.append(col.timing_event())
@@ -502,7 +509,7 @@ def main():
                 for ev in p_.ev_batch[ps][:p_.n_batches[ps]]:
                     col.wait(ev)
                 col.record(stamps[i + 1])
-        barrier()
+        barrier(p_)
         return time.perf_counter() - t0
 
     timed_rounds(pool, 0, args.warmup)                      # warm-up (untimed; also captures the hipGraphs)
@@ -553,12 +560,16 @@ def main():
     s_dt = timed_rounds(spool, s_steps, 2)
     s_info = pipe.infos()
 
+    # the auxiliary legs run at N = 1 only (they build pipelines of their own; at N > 1 every GPU-second of the lease
+    # belongs to the scaling number)
+    extras = not args.no_extras and not distributed
+
     # early stop + point pruning under load: same pipeline, matchers whose token-confidence / matchability heads are
     # biased (random-init weights cannot learn to be confident) so that the device-side depth / width control
     # (lg_token_heads -> lg_decide -> lg_gather) actually stops pairs early and compacts token sets
     e_dt = e_info = None
-    if not args.no_extras:
-        sd_e = W.random_lightglue_state_dict(4, match_gain=4.0, match_bias=-4.6, conf_bias=EARLY_STOP_CONF_BIAS)
+    if extras:
+        sd_e = W.random_lightglue_state_dict(4, match_gain=4.0, match_bias=EARLY_STOP_MATCH_BIAS, conf_bias=EARLY_STOP_CONF_BIAS)
         ctx_x = [nat.Context(device_index) for _ in range(N_MAT)]
         mats_e = [LightGlueHIP(sd_e, max_kpts=MAX_KPTS, ctx=c, max_pairs=BATCH_PAIRS) for c in ctx_x]
         pipe_e = fs.FrameStreamPipeline(dets, mats_e, plan, MAX_KPTS, MIN_CONF, batch_pairs=BATCH_PAIRS)
@@ -570,13 +581,126 @@ def main():
 
     # exact-fp32 leg (precision 0): same pipeline, every contraction on v_mfma_f32_32x32x2_f32
     x_dt = None
-    if not args.no_extras:
+    if extras:
         for mat in mats:
             mat.set_precision("f32")
         x_steps = max(2, args.steps // 8)
         x_dt = timed_rounds(pool, x_steps, 1)
         for mat in mats:
             mat.set_precision("f16x3")
+
+    # PCIe-inclusive leg: the same pipeline with the host in the loop - every round's frames come up from page-locked
+    # host memory and its {info, pairs} go back, on copy streams of their own, double-buffered like the record sets
+    pcie = None
+    if extras:
+        B, K = FRAMES_PER_RANK, MAX_KPTS
+        fbytes = H_IMG * W_IMG * C_IMG
+        up, down = nat.Context(device_index), nat.Context(device_index)
+        host_in = c0.host_alloc(n_pool * B * fbytes).reshape(n_pool, B * fbytes)
+        for r in range(n_pool):
+            host_in[r] = np.stack([noise_frame(f) for f in plan.frames(r)]).reshape(-1)
+        chunks = [c0.malloc(B * fbytes) for _ in range(2)]
+        host_out = [c0.host_alloc(B * 16 + B * K * 8) for _ in range(2)]
+        ev_up, ev_down = [up.event(), up.event()], [down.event(), down.event()]
+
+        def pcie_round(i):
+            q = pipe.rounds & 1                              # record / output set of the round about to be enqueued
+            if i >= 2:
+                for s_ in range(B):
+                    up.wait(pipe.ev_ext[q][s_])              # the extracts that last read this chunk buffer
+            up.h2d_async(chunks[q], host_in[i % n_pool])
+            up.record(ev_up[q])
+            for d_ in pipe.dets:
+                d_.ctx.wait(ev_up[q])
+            if i >= 2:
+                for m_ in pipe.mats:
+                    m_.ctx.wait(ev_down[q])                  # the read-back of the outputs this round overwrites
+            pipe.round(chunks[q], H_IMG, W_IMG, C_IMG)
+            for ev in pipe.ev_batch[q][:pipe.n_batches[q]]:
+                down.wait(ev)
+            down.d2h_async(host_out[q][:B * 16], pipe.info, B * 16)
+            down.d2h_async(host_out[q][B * 16:], pipe.ij, B * K * 8)
+            down.record(ev_down[q])
+
+        p_steps = max(4, args.steps // 4)
+        for i in range(4):
+            pcie_round(i)
+        barrier(); up.sync(); down.sync()
+        t0 = time.perf_counter()
+        for i in range(4, 4 + p_steps):
+            pcie_round(i)
+        barrier(); up.sync(); down.sync()
+        p_dt = time.perf_counter() - t0
+        last = host_out[pipe.last_set][:B * 16].view(np.int32).reshape(B, 4)
+        pcie = {"value": round(p_steps * B / p_dt, 2), "unit": "frames/s", "steps": p_steps,
+                "h2d_bytes_per_round": B * fbytes, "d2h_bytes_per_round": B * 16 + B * K * 8,
+                "matches_read_back_last_round": int(last[:, 0].sum()),
+                "what": "same pipeline, per round: frames uploaded from page-locked host memory (copy stream) and "
+                        "{info, index pairs} read back (second copy stream); never `value`"}
+        for q in chunks:
+            c0.free(q)
+
+    # the other stated sizes, each with the attention kernel's (kpts4000) / the extraction's (c5) own roofline figure
+    sized = {}
+    if extras:
+        def sized_leg(name, Hh, Ww, K, B, P, steps):
+            plan_s = fs.ShardPlan(1, 0, B)
+            det_s = [AlikedHIP(sd_a, max_num_keypoints=K, max_h=Hh, max_w=Ww, ctx=nat.Context(device_index), max_frames=min(8, B))]
+            own = K != MAX_KPTS
+            mats_s = ([LightGlueHIP(sd_l, max_kpts=K, ctx=nat.Context(device_index), max_pairs=P) for _ in range(2)] if own else mats)
+            pipe_s = fs.FrameStreamPipeline(det_s, mats_s, plan_s, K, MIN_CONF, batch_pairs=P)
+            rng = np.random.default_rng(99)
+            pool_s = [c0.upload(rng.integers(0, 256, (B, Hh, Ww, 3), dtype=np.uint8)) for _ in range(2)]
+            def rounds(n):
+                for i in range(n):
+                    pipe_s.round(pool_s[i % 2], Hh, Ww, 3)
+            rounds(4); barrier(pipe_s)
+            t0 = time.perf_counter(); rounds(steps); barrier(pipe_s)
+            dt_s = time.perf_counter() - t0
+            info_s = pipe_s.infos()
+            # extraction alone (one stream, idle GPU): kernel time per frame against the HBM roofline
+            d0 = det_s[0]
+            fr = list(range(min(8, B)))
+            fb = Hh * Ww * 3
+            args_e = ([pool_s[0] + s_ * fb for s_ in fr], Hh, Ww, 3, [pipe_s.xy_ptr(s_) for s_ in fr], [pipe_s.desc_ptr(s_) for s_ in fr],
+                      [pipe_s.score + s_ * K * 4 for s_ in fr], [pipe_s.count_ptr(s_) for s_ in fr])
+            d0.extract_batch_dev(*args_e, max_kpts=K); d0.ctx.sync(); d0.ctx.timer_start()
+            for _ in range(5):
+                d0.extract_batch_dev(*args_e, max_kpts=K)
+            ext_ms = d0.ctx.timer_stop() / 5 / len(fr)
+            scale = (Hh * Ww) / float(H_IMG * W_IMG)
+            rec = {"value": round(steps * B / dt_s, 2), "unit": "frames/s", "steps": steps, "frames_per_step": B,
+                   "image": [Ww, Hh], "max_kpts": K, "kpts_matched": [int(info_s[-1, 2]), int(info_s[-1, 3])],
+                   "lightglue_layers_executed": int(info_s[-1, 1]),
+                   "aliked_ms_per_frame_isolated": round(ext_ms, 4),
+                   "aliked_hbm": {"algorithmic_GB_per_frame": round(0.2 * scale, 3), "achieved_GBs": round(0.2 * scale / ext_ms * 1e3, 1),
+                                  "peak_GBs": HBM_PEAK_GBS, "frac": round(0.2 * scale / ext_ms * 1e3 / HBM_PEAK_GBS, 4)}}
+            if own:
+                n0_, n1_ = int(info_s[-1, 2]), int(info_s[-1, 3])
+                prs = [(pipe_s.xy_ptr(s_ - 1), pipe_s.desc_ptr(s_ - 1), K, pipe_s.xy_ptr(s_), pipe_s.desc_ptr(s_), K,
+                        pipe_s.count_ptr(s_ - 1), pipe_s.count_ptr(s_)) for s_ in range(1, min(P, B - 1) + 1)]
+                m_ = mats_s[0]
+                m_.profile(True)
+                for _ in range(2):
+                    m_.match_batch_dev(prs, pipe_s.ij + K * 8, pipe_s.msc + K * 4, pipe_s.info + 16, K, min_conf=MIN_CONF)
+                m_.ctx.sync(); m_.profile(False)
+                ms_, n_ = m_.profile_read()
+                if n_:
+                    tf = attention_flops(n0_, n1_) * len(prs) / (ms_ / n_ * 1e-3) / 1e12
+                    rec["attention"] = {"pairs_per_launch": len(prs), "avg_launch_us": round(ms_ / n_ * 1e3, 2), "achieved": round(tf, 2),
+                                        "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / F16_MFMA_PEAK_TFLOPS, 4)}
+                for m_ in mats_s:
+                    m_.close()
+            for q in pool_s:
+                c0.free(q)
+            det_s[0].close()
+            return rec
+        for name, cfg in (("c5", (1080, 1920, MAX_KPTS, 8, 8, max(4, args.steps // 12))),
+                          ("kpts4000", (H_IMG, W_IMG, 4000, 8, 4, max(4, args.steps // 12)))):
+            try:
+                sized[name] = sized_leg(name, *cfg)
+            except Exception as e:                       # never lose the headline line to an auxiliary leg
+                sized[name] = {"error": repr(e)}
 
     times = np.array([dt, s_dt, x_dt or 0.0, e_dt or 0.0])
     if distributed:
@@ -599,6 +723,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 3),
             "timed_region_s": round(dt_max, 3),
+            # GPU-side span of the timed region on rank 0: first to last round stamp (device timing events), so the line
+            # corroborates its own busy time when an external utilisation sampler reads nothing
+            "gpu_busy_s": round(float(step_ms.sum()) / 1e3, 3),
             "step_ms": {"p10": round(float(np.percentile(step_ms, 10)), 3), "p50": round(float(np.percentile(step_ms, 50)), 3),
                         "p90": round(float(np.percentile(step_ms, 90)), 3), "max": round(float(step_ms.max()), 3),
                         "what": "per-round durations on rank 0 (timing events on a collector stream, no host sync in the region)"},
@@ -606,7 +733,10 @@ def main():
             "dtype": "f32 (contractions: f16 hi/lo split operands, 3 MFMA per product, f32 accumulate)",
             "data": "synthetic",
             "config": {"workload": "C2/C4: synthetic 1241x376x3 uint8 frame stream, ALIKED-n16 extract + "
-                                   "LightGlue match (t-1,t), 2048 kpts/frame, min_conf 0.7, random-init weights",
+                                   "LightGlue match (t-1,t), 2048 kpts/frame, min_conf 0.7, random-init weights; "
+                                   "inputs resident in HBM before the timed region, features and matches left on the "
+                                   "device (the `pcie` leg times the same pipeline with per-round H2D of the frames and "
+                                   "D2H of {count, pairs})",
                        "frames_per_step_per_gpu": FRAMES_PER_RANK, "max_kpts": MAX_KPTS,
                        "lightglue_layers_executed": stop, "kpts_matched": [n0, n1],
                        # depth is data dependent (early stop) - layers executed over the pairs of the last round
@@ -616,7 +746,10 @@ def main():
                        "parallelism": f"frame-shard x{world}; per GPU {N_EXT} extractor + {N_MAT} matcher streams, "
                                       f"ALIKED in batches of {pipe.EF} frames, LightGlue in batches of {BATCH_PAIRS} pairs"
                                       + (f"; collation: {'RCCL directly' if comm is not None else backend + ' through torch.distributed'}"
-                                         if distributed else "")},
+                                         if distributed else ""),
+                       # N > 1: the size of the communicator the collation ran on, as the communicator reports it
+                       "rccl_ranks": (comm.count() if comm is not None else (dist.get_world_size() if distributed else None)),
+                       "collation_backend": (("rccl (direct)" if comm is not None else dist.get_backend()) if distributed else None)},
             # achieved = ALGORITHMIC flops (8 n0 n1 256 per pair, x pairs per launch) / HIP-event launch
             # duration on an otherwise idle GPU; the kernel issues 3 v_mfma_f32_32x32x16_f16 per
             # algorithmic product (executed = 3x)
@@ -648,10 +781,13 @@ def main():
         if e_info is not None:
             e_steps = max(4, args.steps // 4)
             ok = e_info[:, 2] > 0
+            pruned = bool(ok.any() and int(e_info[ok, 2:4].min()) < MAX_KPTS)
             out["early_stop"] = {
                 "value": round(e_steps * plan.frames_per_round() / e_dt_max, 2), "unit": "frames/s", "steps": e_steps,
                 "what": f"same pipeline, structured stream, random-init weights with token-confidence bias {EARLY_STOP_CONF_BIAS} / "
-                        "matchability bias -4.6: pairs stop early and points are pruned on the device",
+                        f"matchability bias {EARLY_STOP_MATCH_BIAS}: pairs stop early"
+                        + (" and points are pruned on the device" if pruned else " (no point was pruned before the stop on these inputs)"),
+                "points_pruned": pruned,
                 "lightglue_layers_histogram": {str(int(k)): int(v) for k, v in zip(*np.unique(e_info[ok, 1], return_counts=True))},
                 "kpts_after_pruning_min_max": [int(e_info[ok, 2:4].min()), int(e_info[ok, 2:4].max())] if ok.any() else None}
         if x_dt is not None:
@@ -659,12 +795,15 @@ def main():
             out["exact_f32"] = {"value": round(x_steps * plan.frames_per_round() / x_dt_max, 2), "unit": "frames/s",
                                 "steps": x_steps, "peak": F32_MFMA_PEAK_TFLOPS,
                                 "what": "same pipeline, every contraction on v_mfma_f32_32x32x2_f32 (precision 0)"}
-        if not args.no_extras and world == 1:
+        if pcie is not None:
+            out["pcie"] = pcie
+        out.update(sized)
+        if extras:
             try:
                 out["ba"], out["reproject"] = ba_and_reproject_records(c0, with_cpu=not args.no_cpu_baseline)
             except Exception as e:                       # never lose the headline line to an auxiliary leg
                 out["ba"] = {"error": repr(e)}
-        if not args.no_extras and world == 1:
+        if extras:
             try:
                 out["dropin"] = dropin_leg()
             except Exception as e:                       # never lose the headline line to an auxiliary leg

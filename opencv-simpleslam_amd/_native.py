@@ -208,7 +208,8 @@ class Context:
         check(lib().sslam_memcpy_d2h(self.handle, ptr(arr), C.c_void_p(dptr), arr.nbytes), "d2h")
 
     def host_alloc(self, nbytes: int) -> np.ndarray:
-        """Page-locked host memory as a uint8 array (freed with the context; views keep it alive)."""
+        """Page-locked host memory as a uint8 array.  The block belongs to the CONTEXT: `Context.close()` frees it, after
+        which the array and every view of it dangle - keep the context alive as long as they are used."""
         p = C.c_void_p()
         check(lib().sslam_host_alloc(self.handle, int(nbytes), C.byref(p)), "sslam_host_alloc")
         buf = (C.c_uint8 * int(nbytes)).from_address(p.value)

@@ -41,7 +41,16 @@ def _digest(*parts) -> str:
     return h.hexdigest()
 
 
-LLVM_BIN = Path("/opt/rocm/lib/llvm/bin")
+def _llvm_bin() -> Path:
+    """clang / ld.lld of the SAME ROCm install as the hipcc in use (ROCM_PATH, else next to the resolved hipcc)."""
+    roots = [os.environ.get("ROCM_PATH"), str(Path(os.path.realpath(_hipcc())).parent.parent), "/opt/rocm"]
+    for r in filter(None, roots):
+        for sub in ("lib/llvm/bin", "llvm/bin"):
+            d = Path(r) / sub
+            if (d / "clang").exists() and (d / "ld.lld").exists():
+                return d
+    raise RuntimeError("clang / ld.lld of the ROCm install not found (set ROCM_PATH)")
+
 
 
 def _build_asm_kernels(obj_dir: Path, force: bool, verbose: bool):
@@ -49,7 +58,8 @@ def _build_asm_kernels(obj_dir: Path, force: bool, verbose: bool):
     source: register map, schedule, hazards are written there), it is assembled and linked into a code object
     (clang -x assembler, ld.lld -shared) and the code object is embedded into the host library as the byte array
     `sslam_<name>_hsaco` (an .incbin stub), which the library loads with hipModuleLoadData at instance creation."""
-    clang, lld = LLVM_BIN / "clang", LLVM_BIN / "ld.lld"
+    llvm = _llvm_bin()
+    clang, lld = llvm / "clang", llvm / "ld.lld"
     out = []
     for gen in sorted(CSRC.glob("gen_*.py")):
         name = gen.stem[4:]

@@ -1674,7 +1674,10 @@ int sslam_aliked_create_batched(sslam_ctx* ctx, const float* weights, size_t n_f
     carve_shared(g->arena);
     g->arena.off = shared_bytes;               // frame 0's block starts on a page boundary; blocks 1.. follow at g->fs
     carve_frame(g->arena);
-    SSLAM_REQUIRE(g->out_n != nullptr, "sslam_aliked_create: workspace arena exhausted");
+    if (g->out_n == nullptr) {                 // (release before reporting: the batched workspace is GBs)
+        g->arena.release(); delete g;
+        SSLAM_REQUIRE(false, "sslam_aliked_create: workspace arena exhausted");
+    }
     SSLAM_HIP_CHECK(hipMemcpy(g->blob, weights, n_floats * 4, hipMemcpyHostToDevice));
     if (int rc = al_bind_weights(g, n_floats)) { g->arena.release(); delete g; return rc; }
     {   // [ci][tap][co] -> [co][tap*CIN + ci] copies for the GEMM form of the deformable convs

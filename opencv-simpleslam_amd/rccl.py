@@ -42,6 +42,8 @@ def lib():
         L.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
         L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
         L.ncclCommDestroy.argtypes = [C.c_void_p]
+        L.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.ncclCommCount.restype = C.c_int
         L.ncclGroupStart.argtypes = []
         L.ncclGroupEnd.argtypes = []
         L.ncclBroadcast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -83,6 +85,12 @@ class RcclComm:
         on every rank (e.g. a `torch.distributed.broadcast_object_list` over gloo, or a file / socket)."""
         uid = exchange(new_unique_id() if rank == 0 else None)
         return cls(rank, world, uid)
+
+    def count(self) -> int:
+        """Number of ranks, as the communicator itself reports it (ncclCommCount)."""
+        n = C.c_int()
+        _check(lib().ncclCommCount(self.handle, C.byref(n)), "ncclCommCount")
+        return int(n.value)
 
     def all_gather_rows(self, stream: int, src_ptr: int, dst_ptr: int, rows_per_rank: int, lo: int, hi: int, row_bytes: int):
         """Every rank contributes rows lo .. hi-1 of its `rows_per_rank` local rows (src_ptr = row 0 of the local block);

@@ -211,7 +211,8 @@ class _DeviceFeatureRing:
         K = self.K
         # (the image goes up straight from the caller's pageable array: the runtime's own staged copy, 69 us for
         #  1.4 MB, beats a host copy into a page-locked stage + DMA, 57 + 41 us)
-        ctx.h2d_async(self.img_dev, np.ascontiguousarray(img))   # (pageable source: the call returns once the runtime staged it)
+        staged = np.ascontiguousarray(img)   # (a non-contiguous image: this copy must outlive the DMA - it is held until the ctx.sync() below)
+        ctx.h2d_async(self.img_dev, staged)  # (pageable source: the runtime stages it before the call returns; page-locked: the DMA reads it in place)
         prev = self.last_entry
         if self.ahead is not None:       # the last look-ahead was never collected: the caller is not in the prev -> cur loop
             self.mctx.sync()             # (it may still read a record this ring is about to recycle)
@@ -232,6 +233,7 @@ class _DeviceFeatureRing:
         # against the array below on first use)
         shells, src = keypoint_shells(K) if keypoint_shells is not None else (None, None)
         ctx.sync()
+        del staged                           # the upload is done: the caller's image may change from here on
         n = int(self.pin_cnt[0])
         xy = self.pin_xy[:n].copy(); desc = self.pin_desc[:n].copy()
         desc.setflags(write=False)

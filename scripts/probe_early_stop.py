@@ -13,7 +13,9 @@ fs = importlib.import_module("opencv-simpleslam_amd.frame_shard")
 B, P, K = 16, 8, 2048
 dets = [AL(W.random_aliked_state_dict(0), max_num_keypoints=K, max_h=376, max_w=1241, ctx=nat.Context(0))]
 frames = np.stack([bench.structured_frame(f) for f in range(B)])
-for cb, mb in [(1.0, -4.6), (1.3, -4.6), (1.5, -4.6), (1.6, -4.6), (1.7, -4.6), (1.8, -4.6), (1.9, -4.6), (1.7, 3.0)]:
+import itertools
+grid = [(1.7, -4.6)] + list(itertools.product((1.2, 1.4, 1.5, 1.6, 1.65), (-5.5, -7.0, -9.0)))
+for cb, mb in grid:
     sd = W.random_lightglue_state_dict(4, match_gain=4.0, match_bias=mb, conf_bias=cb)
     mats = [LG(sd, max_kpts=K, ctx=nat.Context(0), max_pairs=P)]
     pipe = fs.FrameStreamPipeline(dets, mats, fs.ShardPlan(1, 0, B), K, 0.7, batch_pairs=P)

@@ -23,7 +23,8 @@ def test_bench_contract_single_rank():
     d = _run_bench({}, [sys.executable, "bench.py", "--steps", "2", "--warmup", "4", "--no-cpu-baseline"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                 "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "structured_input",
-                "exact_f32", "ba", "reproject", "step_ms", "timed_region_s", "early_stop", "dropin"):
+                "exact_f32", "ba", "reproject", "step_ms", "timed_region_s", "early_stop", "dropin", "pcie", "c5", "kpts4000",
+                "gpu_busy_s"):
         assert key in d
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["unit"] == "frames/s"
     r = d["roofline"]
@@ -32,6 +33,13 @@ def test_bench_contract_single_rank():
     assert d["ba"]["device_lm_ms"] > 0 and 0 < d["ba"]["residual_kernel"]["frac"] < 1 and d["reproject"]["wall_ms"] > 0
     assert 0 < d["step_ms"]["p10"] <= d["step_ms"]["p50"] <= d["step_ms"]["p90"] <= d["step_ms"]["max"]
     assert d["dropin"]["value"] > 0 and d["dropin"]["feature_matcher_ms"] > 0, d["dropin"]
+    # the drop-in leg does the work of the reference's loop: real matches, so RANSAC / DMatch / read-back are in the number
+    assert d["dropin"]["matches_median"] > 100 and d["dropin"]["filter_matches_ransac_ms"] > 0, d["dropin"]
+    assert "resident in HBM" in d["config"]["workload"] and d["gpu_busy_s"] > 0
+    assert d["pcie"]["value"] > 0 and d["pcie"]["h2d_bytes_per_round"] == 6 * 1241 * 376 * 3, d["pcie"]
+    for leg in ("c5", "kpts4000"):
+        assert d[leg].get("value", 0) > 0 and 0 < d[leg]["aliked_hbm"]["frac"] < 1, d[leg]
+    assert d["kpts4000"]["max_kpts"] == 4000 and 0 < d["kpts4000"]["attention"]["frac"] < 1
     es = d["early_stop"]
     assert es["value"] > 0 and es["lightglue_layers_histogram"] and set(es["lightglue_layers_histogram"]) != {"9"}, es
 
@@ -67,3 +75,13 @@ def test_bench_rccl_branches_with_one_rank():
                     "MASTER_PORT": "29623"},
                    [sys.executable, "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "4", "--no-cpu-baseline", "--no-extras"])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["frames_per_step_per_gpu"] == 6
+
+
+def test_bench_direct_rccl_with_one_rank():
+    """The default backend of `bench.py --gpus N` (RCCL driven directly, no torch in the data path) with one rank on this
+    box: the line reports the communicator's own rank count."""
+    import sys
+    d = _run_bench({"SSLAM_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29627"},
+                   [sys.executable, "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "4", "--no-cpu-baseline", "--no-extras"])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert d["config"]["rccl_ranks"] == 1 and d["config"]["collation_backend"] == "rccl (direct)"
