@@ -166,11 +166,21 @@ class _DeviceFeatureRing:
         self.turn = 0
         self.img_dev, self.img_cap = 0, 0
         self.tmp_xy = [m(K * 8), m(K * 8)]               # keypoints of an edited list (uploaded per call)
-        out = m(16 + K * 8 + K * 4)                      # match results, [info 16 B | pairs K x 2 | scores K]
-        self.out_info, self.out_ij, self.out_sc = out, out + 16, out + 16 + K * 8
-        self.pin_match = self.ctx.host_alloc(16 + K * 8)
+        # match results [info 16 B | pairs K x 2 | RANSAC info 16 B | RANSAC mask K] + scores K: the first four come back
+        # in ONE copy (the filter of filter_matches_ransac runs on the device right behind the match, see below)
+        KM = (K + 15) // 16 * 16
+        out = m(16 + K * 8 + 16 + KM + K * 4)
+        self.out_info, self.out_ij = out, out + 16
+        self.rs_info, self.rs_mask = out + 16 + K * 8, out + 16 + K * 8 + 16
+        self.out_sc = out + 16 + K * 8 + 16 + KM
+        self.match_bytes, self.filtered_bytes = 16 + K * 8, 16 + K * 8 + 16 + KM
+        self.pin_match = self.ctx.host_alloc(self.filtered_bytes)
         self.pin_info = self.pin_match[:16].view(np.int32)
-        self.pin_ij = self.pin_match[16:].view(np.int32).reshape(K, 2)
+        self.pin_ij = self.pin_match[16:16 + K * 8].view(np.int32).reshape(K, 2)
+        self.pin_rs_info = self.pin_match[16 + K * 8:16 + K * 8 + 16].view(np.int32)
+        self.pin_rs_mask = self.pin_match[16 + K * 8 + 16:16 + K * 8 + 16 + K]
+        self.ransac_thr = None           # threshold of the last filter_matches_ransac call on a resident match (None: not seen)
+        self.filtered = None             # the resident match whose filter already ran on the device: dict(matches=list, kp0, kp1, thr)
         detector.use_graphs(True)        # the slots are a fixed set of buffers: the launch sequence replays as a graph
         self.matcher, self.mctx = None, None
         self.ev_extracted = self.ctx.event()
@@ -228,7 +238,7 @@ class _DeviceFeatureRing:
             ps = prev["slot"]
             self.matcher.match_dev(ps["xy"], ps["desc"], prev["n"], sl["xy"], sl["desc"], K, self.out_ij, self.out_sc,
                                    self.out_info, min_conf=self.last_thr, m_dev=ps["cnt"], n_dev=sl["cnt"])
-            self.mctx.d2h_async(self.pin_match, self.out_info)
+            look_filter = self.ransac_thr if self.enqueue_filter_and_readback(ps["xy"], sl["xy"]) else None
         # the GPU needs ~0.5 ms from here: build the frame's KeyPoint objects meanwhile (their coordinates resolve
         # against the array below on first use)
         shells, src = keypoint_shells(K) if keypoint_shells is not None else (None, None)
@@ -249,10 +259,24 @@ class _DeviceFeatureRing:
         self.by_id[id(desc)] = entry
         self.last_entry = entry
         if look:
-            self.ahead = dict(a=prev, b=entry, thr=self.last_thr)
+            self.ahead = dict(a=prev, b=entry, thr=self.last_thr, filter_thr=look_filter)
         if prev is not None:
             prev["prev"] = None          # (no chains of dead frames)
         return kps, desc
+
+    def enqueue_filter_and_readback(self, xy_a, xy_b):
+        """Behind a match on the matcher's stream: the reference's frame loop filters every match with F-matrix RANSAC
+        right away (main_revamped.py:118-126) - once that has been seen, the filter runs on the device on the matcher's
+        own output (sslam_fmat_ransac_dev: no host round trip, no pixel gather on the host) and its mask rides back with
+        {count, pairs} in the same copy."""
+        if self.ransac_thr is not None:
+            from ... import epipolar
+            epipolar.filter_matches_dev(self.mctx, self.K, self.out_info, xy_a, xy_b, self.out_ij, None, self.rs_info,
+                                        thresh=self.ransac_thr, confidence=0.99, mask_out_dev=self.rs_mask)
+            self.mctx.d2h_async(self.pin_match, self.out_info)
+            return True
+        self.mctx.d2h_async(self.pin_match[:self.match_bytes], self.out_info)
+        return False
 
     def lookup(self, des, kps, which):
         """(device xy, device desc, n, device count) for a frame this ring still holds, else None."""
@@ -295,18 +319,25 @@ def _as_numpy_f32(x):
     return np.ascontiguousarray(x, dtype=np.float32)
 
 
+_last_ring = None        # weak reference to the ring of the last resident match (filter_matches_ransac has no matcher argument)
+
+
 def _match_resident(ring, matcher, a, b, thr):
     """Both frames are still on the GPU: enqueue the match on their records (or collect the look-ahead that already runs
     on exactly them), read back {count, pairs} -> list[DMatch]."""
     mctx = matcher.ctx
     ahead, ring.ahead = ring.ahead, None
     hit = (ahead is not None and ahead["a"] is a[4] and ahead["b"] is b[4] and ahead["thr"] == thr)
-    if not hit:
+    ring.filtered = None
+    if hit:
+        with_filter = ahead.get("filter_thr")
+    else:
         if ahead is not None:
             mctx.sync()                          # (its outputs share the buffers below)
         matcher.match_dev(a[0], a[1], a[2], b[0], b[1], b[2], ring.out_ij, ring.out_sc, ring.out_info, min_conf=thr,
                           m_dev=a[3], n_dev=b[3])
-        mctx.d2h_async(ring.pin_match, ring.out_info)      # {count, pairs} in one copy into page-locked memory
+        # {count, pairs} (and the RANSAC mask when the caller is known to filter) in one copy into page-locked memory
+        with_filter = ring.ransac_thr if ring.enqueue_filter_and_readback(a[0], b[0]) else None
     # the prev -> cur pattern of the reference's frame loop: from now on `extract` enqueues this match itself
     ring.last_thr = thr
     ring.ahead_on = b[4] is not None and b[4] is ring.last_entry and a[4] is not None and b[4].get("prev") is a[4]
@@ -320,10 +351,22 @@ def _match_resident(ring, matcher, a, b, thr):
                                   "(|value| >= 65520); rescale the descriptors or use matcher.set_precision('f32')")
     ij = ring.pin_ij[:k].copy()
     if shells is None:
-        return _convert_lg_matches_to_opencv(ij)
-    src.ij = ij
-    del shells[k:]
-    return shells
+        out = _convert_lg_matches_to_opencv(ij)
+    else:
+        src.ij = ij
+        del shells[k:]
+        out = shells
+    global _last_ring
+    _last_ring = weakref.ref(ring)
+    if a[4] is None or b[4] is None:
+        ring.filtered = None                     # (edited keypoint lists: filter_matches_ransac takes the host path)
+    elif with_filter is not None:
+        # filter_matches_ransac(kp0, kp1, <this list>, <that threshold>) only has to apply the mask that is already here
+        ring.filtered = dict(matches=out, n=k, a=a[4], b=b[4], thr=with_filter, kept=int(ring.pin_rs_info[0]),
+                             mask=ring.pin_rs_mask[:k].copy())
+    else:
+        ring.filtered = dict(matches=out, n=k, a=a[4], b=b[4], thr=None)
+    return out
 
 
 def feature_matcher(args, kp0, kp1, des0, des1, matcher):
@@ -383,6 +426,19 @@ def filter_matches_ransac(kp1, kp2, matches, thresh=1.0):
     7-point RANSAC / LMedS restated, no cv2 needed)."""
     if len(matches) < 8:
         return matches
+    ring = _last_ring() if _last_ring is not None else None
+    f = ring.filtered if ring is not None else None
+    if (f is not None and f["matches"] is matches and len(matches) == f["n"]
+            and isinstance(kp1, KeyPointList) and isinstance(kp2, KeyPointList)
+            and kp1.pristine_xy() is f["a"]["xy"] and kp2.pristine_xy() is f["b"]["xy"]):
+        # the list feature_matcher just returned for exactly these frames
+        if f["thr"] is not None and f["thr"] == float(thresh):
+            # the filter already ran on the device behind the match (same matches, same pixels, same threshold):
+            # its mask came back with the matches
+            if f["kept"] == -1:                  # no model: cv2 returns mask None
+                return []
+            return [m for m, ok in zip(matches, f["mask"].tolist()) if ok]
+        ring.ransac_thr = float(thresh)          # from now on the filter rides behind the match
     from ... import epipolar
     pts1 = np.float32([kp1[m.queryIdx].pt for m in matches])
     pts2 = np.float32([kp2[m.trainIdx].pt for m in matches])

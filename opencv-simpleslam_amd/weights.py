@@ -60,12 +60,14 @@ def load_state_dict(path):
 # --------------------------------------------------------------------------- #
 #  LightGlue(features='aliked')
 # --------------------------------------------------------------------------- #
-def random_lightglue_state_dict(seed=0, match_gain=1.0, conf_bias=0.0, match_bias=0.0):
+def random_lightglue_state_dict(seed=0, match_gain=1.0, conf_bias=0.0, match_bias=0.0, conf_gain=1.0):
     """Seeded random init with upstream key names/shapes.
     nn.Linear-style U(-1/sqrt(fan_in), 1/sqrt(fan_in)); LayerNorm (1, 0).
     `match_gain` scales log_assignment.final_proj (sharper assignments),
     `conf_bias` / `match_bias` shift the token-confidence / matchability
-    logits (to drive early stopping and pruning in tests)."""
+    logits (to drive early stopping and pruning in tests); `conf_gain` scales the
+    token-confidence weights (spreads the confidences, so that SOME points are
+    confident - and prunable - layers before 95 % of them are and the pair stops)."""
     rng = np.random.default_rng(seed)
     D = LG_DIM
 
@@ -95,7 +97,7 @@ def random_lightglue_state_dict(seed=0, match_gain=1.0, conf_bias=0.0, match_bia
         sd[p + ".matchability.weight"], sd[p + ".matchability.bias"] = w, b + np.float32(match_bias)
     for i in range(LG_LAYERS - 1):
         w, b = lin(1, D)
-        sd[f"token_confidence.{i}.token.0.weight"] = w
+        sd[f"token_confidence.{i}.token.0.weight"] = w * np.float32(conf_gain)
         sd[f"token_confidence.{i}.token.0.bias"] = b + np.float32(conf_bias)
     return sd
 

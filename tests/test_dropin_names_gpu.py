@@ -232,6 +232,37 @@ def test_look_ahead_match_of_the_frame_loop_gives_the_same_matches(fu, pipeline)
     assert ring.ahead is None and not ring.ahead_on
 
 
+def test_filter_matches_ransac_behind_the_match_equals_the_host_filter(fu, pipeline):
+    """r04: the reference's loop filters every match with F-matrix RANSAC right away (main_revamped.py:118-126).  Once
+    `filter_matches_ransac` has been called on a resident match, the filter is enqueued on the device behind every such
+    match (sslam_fmat_ransac_dev on the matcher's own output) and the call only applies the mask that came back with
+    the matches: same kept matches - the same OBJECTS - as the host filter on the same lists; another threshold or
+    other lists take the host path."""
+    args, det, mat = pipeline
+    ring = fu._ring_of(det)
+    ring.ransac_thr = None
+    pairs = lambda ms: [(m.queryIdx, m.trainIdx) for m in ms]
+    host = lambda k0, k1, ms, thr: pairs(fu.filter_matches_ransac(list(k0), list(k1), list(ms), thr))   # plain lists: host path
+    fr = [frames.structured_frame(40 + i) for i in range(7)]
+    kp0, des0 = fu.feature_extractor(args, fr[0], det)
+    fast = []
+    for i in range(1, 7):
+        kp1, des1 = fu.feature_extractor(args, fr[i], det)
+        m = fu.feature_matcher(args, kp0, kp1, des0, des1, mat)
+        assert len(m) >= 15                                            # the RANSAC branch, not LMedS / pass-through
+        thr = 2.5 if i == 4 else 1.0
+        on_device = ring.filtered is not None and ring.filtered["thr"] == thr
+        fast.append(on_device)
+        f = fu.filter_matches_ransac(kp0, kp1, m, thr)
+        assert pairs(f) == host(kp0, kp1, m, thr), f"frame {i}"
+        ids = {id(x) for x in m}
+        assert all(id(x) in ids for x in f) and 0 < len(f) <= len(m)
+        kp0, des0 = kp1, des1
+    # call 1 teaches the threshold (host), 2 and 3 ride behind the match, 4 asks another threshold (host, and teaches 2.5),
+    # 5 asks 1.0 again while 2.5 was enqueued (host), 6 rides again
+    assert fast == [False, True, True, False, False, True], fast
+
+
 def test_ring_survives_recycled_array_ids(fu, pipeline):
     """A long run of the frame loop, holding only the previous and the current frame as the reference's loop does
     (main_revamped.py:708): the allocator hands the ids of dropped descriptor arrays to new ones, and the ring, which
