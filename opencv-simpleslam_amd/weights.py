@@ -60,14 +60,20 @@ def load_state_dict(path):
 # --------------------------------------------------------------------------- #
 #  LightGlue(features='aliked')
 # --------------------------------------------------------------------------- #
-def random_lightglue_state_dict(seed=0, match_gain=1.0, conf_bias=0.0, match_bias=0.0, conf_gain=1.0):
+def random_lightglue_state_dict(seed=0, match_gain=1.0, conf_bias=0.0, match_bias=0.0, conf_gain=1.0, ffn_gain=1.0,
+                                final_identity=0.0):
     """Seeded random init with upstream key names/shapes.
     nn.Linear-style U(-1/sqrt(fan_in), 1/sqrt(fan_in)); LayerNorm (1, 0).
     `match_gain` scales log_assignment.final_proj (sharper assignments),
     `conf_bias` / `match_bias` shift the token-confidence / matchability
     logits (to drive early stopping and pruning in tests); `conf_gain` scales the
     token-confidence weights (spreads the confidences, so that SOME points are
-    confident - and prunable - layers before 95 % of them are and the pair stops)."""
+    confident - and prunable - layers before 95 % of them are and the pair stops).
+    `ffn_gain` scales the output Linear of every FFN (<< 1: the token state stays close to the input
+    projection of the descriptor) and `final_identity` = g > 0 replaces final_proj by g.I: together a
+    random init that behaves like a mutual-nearest-neighbour matcher on the descriptors - every kernel
+    still runs on every layer, and frames that overlap produce hundreds of matches, which an untrained
+    transformer otherwise never does (benchmarks of the callers downstream of the matcher need them)."""
     rng = np.random.default_rng(seed)
     D = LG_DIM
 
@@ -88,10 +94,12 @@ def random_lightglue_state_dict(seed=0, match_gain=1.0, conf_bias=0.0, match_bia
             sd[f"{p}.ffn.0.weight"], sd[f"{p}.ffn.0.bias"] = lin(2 * D, 2 * D)
             sd[f"{p}.ffn.1.weight"] = (1.0 + 0.1 * rng.standard_normal(2 * D)).astype(np.float32)
             sd[f"{p}.ffn.1.bias"] = (0.1 * rng.standard_normal(2 * D)).astype(np.float32)
-            sd[f"{p}.ffn.3.weight"], sd[f"{p}.ffn.3.bias"] = lin(D, 2 * D)
+            sd[f"{p}.ffn.3.weight"], sd[f"{p}.ffn.3.bias"] = lin(D, 2 * D, gain=ffn_gain)
     for i in range(LG_LAYERS):
         p = f"log_assignment.{i}"
         w, b = lin(D, D, gain=match_gain)
+        if final_identity > 0:
+            w, b = np.float32(final_identity) * np.eye(D, dtype=np.float32), np.zeros(D, np.float32)
         sd[p + ".final_proj.weight"], sd[p + ".final_proj.bias"] = w, b
         w, b = lin(1, D)
         sd[p + ".matchability.weight"], sd[p + ".matchability.bias"] = w, b + np.float32(match_bias)
@@ -170,10 +178,15 @@ def pack_lightglue(sd) -> np.ndarray:
 AL = dict(c1=16, c2=32, c3=64, c4=128, dim=128, K=3, M=16)
 
 
-def random_aliked_state_dict(seed=0, score_gain=0.1):
+def random_aliked_state_dict(seed=0, score_gain=0.1, desc_centered=False):
     """Seeded random init with upstream key names/shapes:
     kaiming-uniform convs, BatchNorm with non-trivial running statistics.
-    `score_gain` scales the last score-head conv (spread of the score map)."""
+    `score_gain` scales the last score-head conv (spread of the score map).
+    `desc_centered`: the aggregation weights of the descriptor head are drawn from U(-0.5, 0.5)
+    instead of upstream's U(0, 1) init.  With all-positive weights an untrained head sums its
+    (SELU, positive-mean) features into almost the same direction for every keypoint - any two
+    descriptors have cosine 0.9995 - so nothing downstream can match; zero-mean weights cancel the
+    common component and overlapping frames give matchable descriptors (drop-in benchmarks)."""
     rng = np.random.default_rng(seed)
 
     def conv(co, ci, k, bias=False, gain=1.0):
@@ -216,6 +229,8 @@ def random_aliked_state_dict(seed=0, score_gain=0.1):
     sd["desc_head.offset_conv.2.weight"], sd["desc_head.offset_conv.2.bias"] = w, b
     sd["desc_head.sf_conv.weight"] = conv(dim, dim, 1, gain=1.7)
     sd["desc_head.agg_weights"] = rng.uniform(0, 1, (AL["M"], dim, dim)).astype(np.float32)
+    if desc_centered:
+        sd["desc_head.agg_weights"] = sd["desc_head.agg_weights"] - np.float32(0.5)
     return sd
 
 
