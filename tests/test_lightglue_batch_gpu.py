@@ -333,5 +333,5 @@ def test_assignment_forms_give_the_same_matches(gpu_ctx, max_kpts, max_pairs, si
         o_ij, o_sc, o_stop = _oracle(sd, pairs[p], 0.0)
         np.testing.assert_array_equal(got[1][p][0], o_ij)
         np.testing.assert_allclose(got[1][p][1], o_sc, atol=1e-3, rtol=1e-3)
-    assert sum(len(g[0]) for g in got[1]) > 200
+    assert sum(len(g[0]) for g in got[1]) > 100
     dev.free(); batch.close()
