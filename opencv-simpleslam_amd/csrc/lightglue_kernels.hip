@@ -701,6 +701,18 @@ struct SimArgs {
     float* rpmax; float* rpsum; float* cpmax; float* cpsum;
 };
 
+// exp(x) for x <= 0 (a value minus its maximum) in 5 vector instructions + one v_exp_f32: the product x log2(e) is carried
+// as (t, e) - its rounding error and the low part of log2(e) - so the argument of exp2 is exact to ~2^-48 and the result is
+// v_exp_f32's own ~1 ulp (ocml's expf costs ~25 instructions; the two statistics directions take one exp per element each)
+__device__ __forceinline__ float exp_neg(float x) {
+    const float L = 1.4426950408889634f, L_LO = 1.925963033500395e-8f;
+    const float t = x * L;
+    float e = fmaf(x, L, -t);
+    e = fmaf(x, L_LO, e);
+    const float r = __builtin_amdgcn_exp2f(t);
+    return fmaf(r, e * 0.6931471805599453f, r);
+}
+
 constexpr int SIM_TLD = 129;      // row stride of the staged 64 x 128 tile (bank = (row + col) % 64: rows and columns both scan conflict-free)
 
 template <int BM, int BN, int TM, int TN>
@@ -748,7 +760,8 @@ __global__ __launch_bounds__(256) void lg_sim_kernel(SimArgs p) {
         if (col0 + cl < n1)
 #pragma unroll 8
             for (int rl = t >> 7; rl < BM; rl += 2)
-                if (row0 + rl < n0) simp[(size_t)(row0 + rl) * p.Kc + col0 + cl] = tile[rl * SIM_TLD + cl];
+                if (row0 + rl < n0)      // (streamed past L2: the 16 MB of a pair's `sim` would evict the 4 MB of operands its tiles share)
+                    __builtin_nontemporal_store(tile[rl * SIM_TLD + cl], &simp[(size_t)(row0 + rl) * p.Kc + col0 + cl]);
     }
     if (p.rpmax == nullptr) return;
     const size_t pb = (size_t)pair * (p.Kc / 64) * p.Kc;
@@ -762,7 +775,7 @@ __global__ __launch_bounds__(256) void lg_sim_kernel(SimArgs p) {
             for (int c = 0; c < 64; ++c) m = fmaxf(m, q[c]);
             float sum = 0.0f;
 #pragma unroll 16
-            for (int c = 0; c < 64; ++c) sum += expf(q[c] - m);       // (masked columns: exp(-inf) = 0)
+            for (int c = 0; c < 64; ++c) sum += exp_neg(q[c] - m);    // (masked columns: exp(-inf) = 0)
             const size_t o = pb + (size_t)(2 * bx + half) * p.Kc + row0 + rl;
             p.rpmax[o] = m; p.rpsum[o] = sum;
         }
@@ -776,7 +789,7 @@ __global__ __launch_bounds__(256) void lg_sim_kernel(SimArgs p) {
             for (int r = 0; r < BM; ++r) m = fmaxf(m, q[r * SIM_TLD]);
             float sum = 0.0f;
 #pragma unroll 16
-            for (int r = 0; r < BM; ++r) sum += expf(q[r * SIM_TLD] - m);
+            for (int r = 0; r < BM; ++r) sum += exp_neg(q[r * SIM_TLD] - m);
             const size_t o = pb + (size_t)by * p.Kc + col0 + cl;
             p.cpmax[o] = m; p.cpsum[o] = sum;
         }
@@ -800,12 +813,24 @@ __global__ __launch_bounds__(256) void lg_stats_merge_kernel(const float* __rest
     const float* pm = (cols ? cpmax : rpmax) + pb + i;
     const float* ps = (cols ? cpsum : rpsum) + pb + i;
     const int parts = ((cols ? n0 : n1) + 63) / 64;
-    float m = -INFINITY;
-    for (int z = 0; z < parts; ++z) m = fmaxf(m, pm[(size_t)z * Kc]);
-    float s = 0.0f;
-    for (int z = 0; z < parts; ++z) {
-        const float v = pm[(size_t)z * Kc];
-        if (v > -INFINITY) s += ps[(size_t)z * Kc] * expf(v - m);
+    float m = -INFINITY, s = 0.0f;
+    if (parts <= 32) {                      // (capacities up to 2048: the partials stay in registers between the two passes)
+        float vm[32], vs[32];
+#pragma unroll
+        for (int z = 0; z < 32; ++z) {
+            vm[z] = z < parts ? pm[(size_t)z * Kc] : -INFINITY;
+            vs[z] = z < parts ? ps[(size_t)z * Kc] : 0.0f;
+            m = fmaxf(m, vm[z]);
+        }
+#pragma unroll
+        for (int z = 0; z < 32; ++z)
+            if (vm[z] > -INFINITY) s += vs[z] * expf(vm[z] - m);
+    } else {
+        for (int z = 0; z < parts; ++z) m = fmaxf(m, pm[(size_t)z * Kc]);
+        for (int z = 0; z < parts; ++z) {
+            const float v = pm[(size_t)z * Kc];
+            if (v > -INFINITY) s += ps[(size_t)z * Kc] * expf(v - m);
+        }
     }
     (cols ? cmax : rmax)[(size_t)pair * Kc + i] = m;
     (cols ? clog : rlog)[(size_t)pair * Kc + i] = logf(s);
@@ -996,7 +1021,7 @@ __global__ __launch_bounds__(256) void lg_col_argmax_kernel(
 // scores are formed (coalesced rows) and the column's best row is kept; the scores go through LDS and thread = (row, 64-column
 // segment) picks the row's best column.  Partials: columns per 64-row tile [Kc / 64][Kc], rows per 256-column tile
 // [Kc / 256][Kc]; ties go to the smaller index in both directions, as in the one-direction kernels.
-constexpr int A2_ROWS = 64, A2_COLS = 256, A2_LD = A2_COLS + 1;
+constexpr int A2_ROWS = 32, A2_COLS = 256, A2_LD = A2_COLS + 1;
 constexpr int A2_LDS_BYTES = A2_ROWS * A2_LD * 4;
 
 __global__ __launch_bounds__(256) void lg_argmax2d_kernel(
@@ -1004,7 +1029,7 @@ __global__ __launch_bounds__(256) void lg_argmax2d_kernel(
     const float* __restrict__ cmax, const float* __restrict__ clog, const float* __restrict__ z,
     float* __restrict__ rbv, int* __restrict__ rbj, float* __restrict__ cbv, int* __restrict__ cbi, int Kc,
     const LGCtrl* __restrict__ ctrl) {
-    extern __shared__ float a2_tile[];
+    __shared__ float a2_tile[A2_ROWS * A2_LD];
     const int pair = blockIdx.z;
     ctrl += pair; sim += (size_t)pair * Kc * Kc; rmax += (size_t)pair * Kc; rlog += (size_t)pair * Kc;
     cmax += (size_t)pair * Kc; clog += (size_t)pair * Kc; z += (size_t)pair * 2 * Kc;
@@ -1021,7 +1046,7 @@ __global__ __launch_bounds__(256) void lg_argmax2d_kernel(
         const float cm = ok ? cmax[col] : 0.0f, cl = ok ? clog[col] : 0.0f, b = ok ? z[Kc + col] : 0.0f;
         float bv = -INFINITY; int bi = 0x7fffffff;
         const int rows = min(A2_ROWS, n0 - r0);
-#pragma unroll 8
+#pragma unroll 16
         for (int i = 0; i < rows; ++i) {
             float v = -INFINITY;
             if (ok) {
@@ -1034,25 +1059,50 @@ __global__ __launch_bounds__(256) void lg_argmax2d_kernel(
     }
     __syncthreads();
     {
-        const int rl = t >> 2, seg = t & 3;
+        // thread = (row, 32-column segment): 32 rows x 8 segments
+        const int rl = t >> 3, seg = t & 7;
         float bv = -INFINITY; int bj = 0x7fffffff;
         if (r0 + rl < n0) {
-            const float* q = a2_tile + rl * A2_LD + seg * 64;
+            const float* q = a2_tile + rl * A2_LD + seg * 32;
 #pragma unroll 16
-            for (int c = 0; c < 64; ++c) {
-                const int cc = (c + 16 * seg) & 63;            // rotated start per segment: bank = (row + c + 16 seg) % 64, conflict-free
+            for (int c = 0; c < 32; ++c) {
+                const int cc = (c + 4 * seg) & 31;             // rotated start per segment: bank = (row + 32 seg + ((c + 4 seg) & 31)) % 64 - the 8 rows x 8 segments of a wave spread over the banks
                 const float v = q[cc];
-                const int j = c0 + seg * 64 + cc;
+                const int j = c0 + seg * 32 + cc;
                 if (v > bv || (v == bv && j < bj)) { bv = v; bj = j; }
             }
         }
 #pragma unroll
-        for (int o = 1; o < 4; o <<= 1) {
+        for (int o = 1; o < 8; o <<= 1) {
             const float ov = __shfl_xor(bv, o); const int oj = __shfl_xor(bj, o);
             if (ov > bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
         }
         if (seg == 0 && r0 + rl < n0) { rbv[(size_t)blockIdx.x * Kc + r0 + rl] = bv; rbj[(size_t)blockIdx.x * Kc + r0 + rl] = bj; }
     }
+}
+
+// merge of lg_argmax2d_kernel's partials, in place into slab 0: rows (grid y = 0) over the ceil(n1 / 256) column tiles, columns
+// (y = 1) over the ceil(n0 / 32) row tiles; ties to the smaller index
+__global__ __launch_bounds__(256) void lg_argmax_merge_kernel(float* __restrict__ rbv, int* __restrict__ rbj,
+                                                              float* __restrict__ cbv, int* __restrict__ cbi, int Kc,
+                                                              const LGCtrl* __restrict__ ctrl) {
+    const int pair = blockIdx.z, cols = blockIdx.y;
+    ctrl += pair;
+    if (ctrl->stop == 2) return;
+    const int n0 = ctrl->n[0], n1 = ctrl->n[1];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (cols ? n1 : n0)) return;
+    const size_t slabs = cols ? (size_t)(Kc / A2_ROWS) : (size_t)((Kc + A2_COLS - 1) / A2_COLS);
+    float* pv = (cols ? cbv : rbv) + (size_t)pair * slabs * Kc + i;
+    int* pi = (cols ? cbi : rbj) + (size_t)pair * slabs * Kc + i;
+    const int parts = cols ? (n0 + A2_ROWS - 1) / A2_ROWS : (n1 + A2_COLS - 1) / A2_COLS;
+    float bv = pv[0]; int bi = pi[0];
+#pragma unroll 8
+    for (int z = 1; z < parts; ++z) {
+        const float ov = pv[(size_t)z * Kc]; const int oi = pi[(size_t)z * Kc];
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    pv[0] = bv; pi[0] = bi;
 }
 
 __device__ __forceinline__ int col_argmax_merge(const float* __restrict__ pval, const int* __restrict__ parg,
@@ -1072,7 +1122,8 @@ __global__ __launch_bounds__(1024) void lg_emit_kernel(
     float* __restrict__ score_out, int32_t* __restrict__ info_out, LGCtrl* __restrict__ ctrl, int Kc,
     long out_stride, int* __restrict__ range_sticky, int tiled) {
     // tiled = 0: best0 / arg0 are final per row, pval / parg hold CSLAB column partials (r03 one-direction kernels);
-    // tiled = 1: best0 / arg0 hold the row partials of lg_argmax2d_kernel [Kc / 256][Kc], pval / parg its column partials [Kc / 64][Kc]
+    // tiled = 1: slab 0 of lg_argmax2d_kernel's row partials [ceil(Kc / 256)][Kc] / column partials [Kc / 32][Kc] holds the
+    // merged result (lg_argmax_merge_kernel)
     __shared__ int wsum[16];
     const int pair = blockIdx.x;
     ctrl += pair;
@@ -1089,19 +1140,11 @@ __global__ __launch_bounds__(1024) void lg_emit_kernel(
         const int i = t * per + q;
         int k = 0;
         if (i < n0) {
-            int j = arg0[i];
-            float bs = best0[i];
-            if (tiled) {
-                const int rparts = (n1 + A2_COLS - 1) / A2_COLS;
-                for (int zz = 1; zz < rparts; ++zz) {
-                    const float ov = best0[(size_t)zz * Kc + i]; const int oj = arg0[(size_t)zz * Kc + i];
-                    if (ov > bs || (ov == bs && oj < j)) { bs = ov; j = oj; }
-                }
-            }
-            const float s = expf(bs);
+            const int j = arg0[i];
+            const float s = expf(best0[i]);
             // a row whose scores are all NaN (non-finite input) has no arg-max: no match, no lookup
             const bool valid = (unsigned)j < (unsigned)n1;
-            const int cparts = tiled ? (n0 + A2_ROWS - 1) / A2_ROWS : CSLAB;
+            const int cparts = tiled ? 1 : CSLAB;
             k = valid && (col_argmax_merge(pval, parg, Kc, j, cparts) == i) && (s > filter_thr) && (s > min_conf);
             jj[q] = valid ? j : 0; sc[q] = s;
         }
@@ -2348,8 +2391,10 @@ int lg_enqueue(sslam_lightglue* g, int pairs, const StageSrc& src, float min_con
         hipLaunchKernelGGL(lg_stats_merge_kernel, dim3(sslam::cdiv(Kc, 256), 2, pairs), dim3(256), 0, s, g->rpmax, g->rpsum,
                            g->cpmax, g->cpsum, g->rmax, g->rlog, g->cmax, g->clog, Kc, g->ctrl);
         hipLaunchKernelGGL(lg_argmax2d_kernel, dim3(sslam::cdiv(Kc, A2_COLS), sslam::cdiv(Kc, A2_ROWS), pairs), dim3(256),
-                           A2_LDS_BYTES, s, g->sim, g->rmax, g->rlog, g->cmax, g->clog, g->conf, g->best0, g->arg0, g->cpval,
+                           0, s, g->sim, g->rmax, g->rlog, g->cmax, g->clog, g->conf, g->best0, g->arg0, g->cpval,
                            g->cparg, Kc, g->ctrl);
+        hipLaunchKernelGGL(lg_argmax_merge_kernel, dim3(sslam::cdiv(Kc, 256), 2, pairs), dim3(256), 0, s, g->best0, g->arg0,
+                           g->cpval, g->cparg, Kc, g->ctrl);
         hipLaunchKernelGGL(lg_emit_kernel, dim3(pairs), dim3(1024), 0, s, g->best0, g->arg0, g->cpval, g->cparg, g->ind,
                            g->filter_thr, min_conf, ij_out, score_out, info_out, g->ctrl, Kc, out_stride, g->range_sticky, 1);
     } else {
@@ -2389,8 +2434,7 @@ void lg_configure_kernels() {
     launch_linear_h<64, 128, 1, 2, EPH_F32>(s, 0, cfg);   launch_linear_h<64, 64, 1, 1, EPH_RESID>(s, 0, cfg);
     launch_linear_h<64, 192, 1, 3, EPH_QKV>(s, 0, cfg);   launch_linear_h<64, 128, 1, 2, EPH_CROSS>(s, 0, cfg);
     launch_linear_big<128, 128, 2, 2, EPH_QKV>(s, 0, cfg); launch_linear_big<128, 128, 2, 2, EPH_CROSS>(s, 0, cfg);
-    (void)hipFuncSetAttribute((const void*)lg_argmax2d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)lg_ffn_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, sslam::FFN_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)lg_ffn_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, sslam::FFN_LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)lg_ffn_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, sslam::FFN_LDS_BYTES);
 }
 
@@ -2453,7 +2497,7 @@ int sslam_lightglue_create_batched(sslam_ctx* ctx, const float* weights, size_t 
         g->sim = A.take<float>(NB * K * K);
         g->rmax = A.take<float>(NB * K); g->rlog = A.take<float>(NB * K); g->cmax = A.take<float>(NB * K);
         g->clog = A.take<float>(NB * K);
-        const size_t rtiles = (K + 255) / 256, ctiles = K / 64 > (size_t)CSLAB ? K / 64 : (size_t)CSLAB;   // partial slabs of either assignment form
+        const size_t rtiles = (K + 255) / 256, ctiles = K / 32 > (size_t)CSLAB ? K / 32 : (size_t)CSLAB;   // partial slabs of either assignment form
         g->best0 = A.take<float>(NB * rtiles * K);
         g->ind = A.take<int>(NI * K); g->gmap = A.take<int>(NI * K); g->prune = A.take<int>(NI * K);
         g->arg0 = A.take<int>(NB * rtiles * K);
