@@ -307,9 +307,6 @@ int sslam_lightglue_debug_key_split(sslam_lightglue* lg, int ks);
  * (a token's FFN arithmetic is the same in both: bit-identical), 5 = batched form with the token heads (early stop /
  * pruning inputs) as a launch of their own instead of in the cross block's fused FFN. */
 int sslam_lightglue_debug_big_gemm(sslam_lightglue* lg, int mode);
-/* Test / A-B hook: 1 (default) = the dual-softmax statistics leave the similarity kernel with its tiles and both arg-max
- * directions come from one pass (`sim` written once, read once); 0 = the r03 one-direction kernels (four reads). */
-int sslam_lightglue_debug_assignment(sslam_lightglue* lg, int form);
 /* Precision-study hook (profiles/r04_split_study.md; the product never sets it): drop cross terms of the three-term
  * split products and measure what that does to the matches.  mask: 0x01 / 0x02 K / Q as one fp16 plane in the logits,
  * 0x04 / 0x08 P / V as one plane in the context, 0x10 / 0x20 activation low plane dropped in the projections / the FFN,

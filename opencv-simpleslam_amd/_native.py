@@ -82,7 +82,6 @@ def _signatures():
         "sslam_lightglue_debug_key_split": (i32, [vp, i32]),
         "sslam_lightglue_debug_big_gemm": (i32, [vp, i32]),
         "sslam_lightglue_debug_split_form": (i32, [vp, i32]),
-        "sslam_lightglue_debug_assignment": (i32, [vp, i32]),
         "sslam_lightglue_set_conf": (i32, [vp, f32, f32, f32, i32]),
         "sslam_lightglue_match_host": (i32, [vp, vp, vp, i32, vp, vp, i32, f32, vp, vp, c_int_p, c_int_p]),
         "sslam_lightglue_match_host_sized": (i32, [vp, vp, vp, i32, vp, vp, vp, i32, vp, f32, vp, vp, c_int_p, c_int_p]),

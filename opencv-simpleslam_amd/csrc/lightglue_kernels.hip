@@ -694,35 +694,14 @@ __global__ __launch_bounds__(256) void lg_gather_kernel(const float* __restrict_
 // ------------------------------------------------------------------------ //
 //  5. assignment: sim GEMM, dual log-softmax statistics, arg-max, mutual check
 // ------------------------------------------------------------------------ //
-struct SimArgs {
-    const float* md; float* sim; int Kc; const LGCtrl* ctrl;
-    // r04: the dual-softmax statistics of the tile leave with it (no pass over `sim` for them): per 64-column half a row
-    // partial (max, sum exp) [Kc / 64][Kc], per 64-row tile a column partial [Kc / 64][Kc]; nullptr = not wanted
-    float* rpmax; float* rpsum; float* cpmax; float* cpsum;
-};
-
-// exp(x) for x <= 0 (a value minus its maximum) in 5 vector instructions + one v_exp_f32: the product x log2(e) is carried
-// as (t, e) - its rounding error and the low part of log2(e) - so the argument of exp2 is exact to ~2^-48 and the result is
-// v_exp_f32's own ~1 ulp (ocml's expf costs ~25 instructions; the two statistics directions take one exp per element each)
-__device__ __forceinline__ float exp_neg(float x) {
-    const float L = 1.4426950408889634f, L_LO = 1.925963033500395e-8f;
-    const float t = x * L;
-    float e = fmaf(x, L, -t);
-    e = fmaf(x, L_LO, e);
-    const float r = __builtin_amdgcn_exp2f(t);
-    return fmaf(r, e * 0.6931471805599453f, r);
-}
-
-constexpr int SIM_TLD = 129;      // row stride of the staged 64 x 128 tile (bank = (row + col) % 64: rows and columns both scan conflict-free)
+struct SimArgs { const float* md; float* sim; int Kc; const LGCtrl* ctrl; };
 
 template <int BM, int BN, int TM, int TN>
 __global__ __launch_bounds__(256) void lg_sim_kernel(SimArgs p) {
-    static_assert(BM == 64 && BN == 128, "the statistics epilogue is written for 64 x 128 tiles");
     __shared__ GemmSmem<BM, BN> sm;
-    static_assert(sizeof(GemmSmem<BM, BN>) >= BM * SIM_TLD * sizeof(float), "the tile is staged where the operand ring was");
-    // XCD-aware order: workgroups go to the 8 XCDs round-robin by their linear id, each XCD has its own L2.  With the
-    // pair in the grid's z every XCD fetched every pair's operands (PMC r03: 151 MB for 33.5 MB); with pairs a multiple
-    // of 8 the pair is taken from the low bits of the id instead, so one pair's 4 MB stay in ONE L2.
+    // XCD-aware order (r04): workgroups go to the 8 XCDs round-robin by their linear id and each XCD has its own L2.  With the
+    // pair in the grid's z every XCD fetched every pair's operands (PMC r03: 151 MB fetched for 33.5 MB of inputs); with the
+    // pair count a multiple of 8 the pair comes from the low bits of the id instead, so one pair's 4 MB stay in ONE L2.
     int pair = blockIdx.z, bx = blockIdx.x, by = blockIdx.y;
     if ((gridDim.z & 7) == 0) {
         const unsigned T = gridDim.x * gridDim.y;
@@ -742,98 +721,18 @@ __global__ __launch_bounds__(256) void lg_sim_kernel(SimArgs p) {
     GemmA ga{md0, D, nullptr, 0, D};
     f32x16 acc[TM][TN];
     gemm_mainloop<BM, BN, TM, TN>(ga, md0 + (size_t)p.Kc * D, D, D, row0, p.Kc, col0, p.Kc, sm, acc);
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
-    // (the main loop's last barrier: every wave is done with the operand ring) stage the tile, masked to the problem
-    float* tile = reinterpret_cast<float*>(&sm);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int cl = wn * 32 * TN + j * 32 + (lane & 31);
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rl = wm * 32 * TM + acc_row(r, lane);
-            tile[rl * SIM_TLD + cl] = (row0 + rl < n0 && col0 + cl < n1) ? acc[0][j][r] : -INFINITY;
-        }
-    }
-    __syncthreads();
-    {   // sim: whole 512-byte row pieces
-        const int cl = t & 127;
-        if (col0 + cl < n1)
-#pragma unroll 8
-            for (int rl = t >> 7; rl < BM; rl += 2)
-                if (row0 + rl < n0)      // (streamed past L2: the 16 MB of a pair's `sim` would evict the 4 MB of operands its tiles share)
-                    __builtin_nontemporal_store(tile[rl * SIM_TLD + cl], &simp[(size_t)(row0 + rl) * p.Kc + col0 + cl]);
-    }
-    if (p.rpmax == nullptr) return;
-    const size_t pb = (size_t)pair * (p.Kc / 64) * p.Kc;
-    if (wave < 2) {
-        // row partials: thread = (row, 64-column half); columns ascending: m, then sum exp(v - m)
-        const int rl = lane, half = wave;
-        const float* q = tile + rl * SIM_TLD + 64 * half;
-        if (row0 + rl < n0 && col0 + 64 * half < n1) {
-            float m = -INFINITY;
-#pragma unroll 16
-            for (int c = 0; c < 64; ++c) m = fmaxf(m, q[c]);
-            float sum = 0.0f;
-#pragma unroll 16
-            for (int c = 0; c < 64; ++c) sum += exp_neg(q[c] - m);    // (masked columns: exp(-inf) = 0)
-            const size_t o = pb + (size_t)(2 * bx + half) * p.Kc + row0 + rl;
-            p.rpmax[o] = m; p.rpsum[o] = sum;
-        }
-    } else {
-        // column partials: thread = column; rows ascending
-        const int cl = t - 128;
-        const float* q = tile + cl;
-        if (col0 + cl < n1) {
-            float m = -INFINITY;
-#pragma unroll 16
-            for (int r = 0; r < BM; ++r) m = fmaxf(m, q[r * SIM_TLD]);
-            float sum = 0.0f;
-#pragma unroll 16
-            for (int r = 0; r < BM; ++r) sum += exp_neg(q[r * SIM_TLD] - m);
-            const size_t o = pb + (size_t)by * p.Kc + col0 + cl;
-            p.cpmax[o] = m; p.cpsum[o] = sum;
-        }
-    }
-}
-
-// merge of the tile partials: rows (grid y = 0) over the ceil(n1 / 64) column halves, columns (y = 1) over the ceil(n0 / 64) row
-// tiles, in tile order: max, then the rescaled sums
-__global__ __launch_bounds__(256) void lg_stats_merge_kernel(const float* __restrict__ rpmax, const float* __restrict__ rpsum,
-                                                             const float* __restrict__ cpmax, const float* __restrict__ cpsum,
-                                                             float* __restrict__ rmax, float* __restrict__ rlog,
-                                                             float* __restrict__ cmax, float* __restrict__ clog,
-                                                             int Kc, const LGCtrl* __restrict__ ctrl) {
-    const int pair = blockIdx.z, cols = blockIdx.y;
-    ctrl += pair;
-    if (ctrl->stop == 2) return;
-    const int n0 = ctrl->n[0], n1 = ctrl->n[1];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (cols ? n1 : n0)) return;
-    const size_t pb = (size_t)pair * (Kc / 64) * Kc;
-    const float* pm = (cols ? cpmax : rpmax) + pb + i;
-    const float* ps = (cols ? cpsum : rpsum) + pb + i;
-    const int parts = ((cols ? n0 : n1) + 63) / 64;
-    float m = -INFINITY, s = 0.0f;
-    if (parts <= 32) {                      // (capacities up to 2048: the partials stay in registers between the two passes)
-        float vm[32], vs[32];
+        for (int j = 0; j < TN; ++j) {
+            const int col = col0 + wn * 32 * TN + j * 32 + (lane & 31);
 #pragma unroll
-        for (int z = 0; z < 32; ++z) {
-            vm[z] = z < parts ? pm[(size_t)z * Kc] : -INFINITY;
-            vs[z] = z < parts ? ps[(size_t)z * Kc] : 0.0f;
-            m = fmaxf(m, vm[z]);
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wm * 32 * TM + i * 32 + acc_row(r, lane);
+                if (row < n0 && col < n1) simp[(size_t)row * p.Kc + col] = acc[i][j][r];
+            }
         }
-#pragma unroll
-        for (int z = 0; z < 32; ++z)
-            if (vm[z] > -INFINITY) s += vs[z] * expf(vm[z] - m);
-    } else {
-        for (int z = 0; z < parts; ++z) m = fmaxf(m, pm[(size_t)z * Kc]);
-        for (int z = 0; z < parts; ++z) {
-            const float v = pm[(size_t)z * Kc];
-            if (v > -INFINITY) s += ps[(size_t)z * Kc] * expf(v - m);
-        }
-    }
-    (cols ? cmax : rmax)[(size_t)pair * Kc + i] = m;
-    (cols ? clog : rlog)[(size_t)pair * Kc + i] = logf(s);
 }
 
 constexpr int STAT_CACHE = 32;    // values of `sim` a thread keeps between the max and the sum pass (rows / column slabs up to 2048)
@@ -1017,98 +916,10 @@ __global__ __launch_bounds__(256) void lg_col_argmax_kernel(
     }
 }
 
-// r04: both arg-max directions from ONE read of `sim`.  A workgroup owns a 64-row x 256-column tile: thread = column while the
-// scores are formed (coalesced rows) and the column's best row is kept; the scores go through LDS and thread = (row, 64-column
-// segment) picks the row's best column.  Partials: columns per 64-row tile [Kc / 64][Kc], rows per 256-column tile
-// [Kc / 256][Kc]; ties go to the smaller index in both directions, as in the one-direction kernels.
-constexpr int A2_ROWS = 32, A2_COLS = 256, A2_LD = A2_COLS + 1;
-constexpr int A2_LDS_BYTES = A2_ROWS * A2_LD * 4;
-
-__global__ __launch_bounds__(256) void lg_argmax2d_kernel(
-    const float* __restrict__ sim, const float* __restrict__ rmax, const float* __restrict__ rlog,
-    const float* __restrict__ cmax, const float* __restrict__ clog, const float* __restrict__ z,
-    float* __restrict__ rbv, int* __restrict__ rbj, float* __restrict__ cbv, int* __restrict__ cbi, int Kc,
-    const LGCtrl* __restrict__ ctrl) {
-    __shared__ float a2_tile[A2_ROWS * A2_LD];
-    const int pair = blockIdx.z;
-    ctrl += pair; sim += (size_t)pair * Kc * Kc; rmax += (size_t)pair * Kc; rlog += (size_t)pair * Kc;
-    cmax += (size_t)pair * Kc; clog += (size_t)pair * Kc; z += (size_t)pair * 2 * Kc;
-    rbv += (size_t)pair * ((Kc + A2_COLS - 1) / A2_COLS) * Kc; rbj += (size_t)pair * ((Kc + A2_COLS - 1) / A2_COLS) * Kc;
-    cbv += (size_t)pair * (Kc / A2_ROWS) * Kc; cbi += (size_t)pair * (Kc / A2_ROWS) * Kc;
-    if (ctrl->stop == 2) return;
-    const int n0 = ctrl->n[0], n1 = ctrl->n[1];
-    const int r0 = blockIdx.y * A2_ROWS, c0 = blockIdx.x * A2_COLS;
-    if (r0 >= n0 || c0 >= n1) return;
-    const int t = threadIdx.x;
-    {
-        const int col = c0 + t;
-        const bool ok = col < n1;
-        const float cm = ok ? cmax[col] : 0.0f, cl = ok ? clog[col] : 0.0f, b = ok ? z[Kc + col] : 0.0f;
-        float bv = -INFINITY; int bi = 0x7fffffff;
-        const int rows = min(A2_ROWS, n0 - r0);
-#pragma unroll 16
-        for (int i = 0; i < rows; ++i) {
-            float v = -INFINITY;
-            if (ok) {
-                v = score_ij(sim[(size_t)(r0 + i) * Kc + col], rmax[r0 + i], rlog[r0 + i], cm, cl, z[r0 + i], b);
-                if (v > bv) { bv = v; bi = r0 + i; }           // ascending rows: the first maximum is kept
-            }
-            a2_tile[i * A2_LD + t] = v;
-        }
-        if (ok) { cbv[(size_t)blockIdx.y * Kc + col] = bv; cbi[(size_t)blockIdx.y * Kc + col] = bi; }
-    }
-    __syncthreads();
-    {
-        // thread = (row, 32-column segment): 32 rows x 8 segments
-        const int rl = t >> 3, seg = t & 7;
-        float bv = -INFINITY; int bj = 0x7fffffff;
-        if (r0 + rl < n0) {
-            const float* q = a2_tile + rl * A2_LD + seg * 32;
-#pragma unroll 16
-            for (int c = 0; c < 32; ++c) {
-                const int cc = (c + 4 * seg) & 31;             // rotated start per segment: bank = (row + 32 seg + ((c + 4 seg) & 31)) % 64 - the 8 rows x 8 segments of a wave spread over the banks
-                const float v = q[cc];
-                const int j = c0 + seg * 32 + cc;
-                if (v > bv || (v == bv && j < bj)) { bv = v; bj = j; }
-            }
-        }
-#pragma unroll
-        for (int o = 1; o < 8; o <<= 1) {
-            const float ov = __shfl_xor(bv, o); const int oj = __shfl_xor(bj, o);
-            if (ov > bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
-        }
-        if (seg == 0 && r0 + rl < n0) { rbv[(size_t)blockIdx.x * Kc + r0 + rl] = bv; rbj[(size_t)blockIdx.x * Kc + r0 + rl] = bj; }
-    }
-}
-
-// merge of lg_argmax2d_kernel's partials, in place into slab 0: rows (grid y = 0) over the ceil(n1 / 256) column tiles, columns
-// (y = 1) over the ceil(n0 / 32) row tiles; ties to the smaller index
-__global__ __launch_bounds__(256) void lg_argmax_merge_kernel(float* __restrict__ rbv, int* __restrict__ rbj,
-                                                              float* __restrict__ cbv, int* __restrict__ cbi, int Kc,
-                                                              const LGCtrl* __restrict__ ctrl) {
-    const int pair = blockIdx.z, cols = blockIdx.y;
-    ctrl += pair;
-    if (ctrl->stop == 2) return;
-    const int n0 = ctrl->n[0], n1 = ctrl->n[1];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (cols ? n1 : n0)) return;
-    const size_t slabs = cols ? (size_t)(Kc / A2_ROWS) : (size_t)((Kc + A2_COLS - 1) / A2_COLS);
-    float* pv = (cols ? cbv : rbv) + (size_t)pair * slabs * Kc + i;
-    int* pi = (cols ? cbi : rbj) + (size_t)pair * slabs * Kc + i;
-    const int parts = cols ? (n0 + A2_ROWS - 1) / A2_ROWS : (n1 + A2_COLS - 1) / A2_COLS;
-    float bv = pv[0]; int bi = pi[0];
-#pragma unroll 8
-    for (int z = 1; z < parts; ++z) {
-        const float ov = pv[(size_t)z * Kc]; const int oi = pi[(size_t)z * Kc];
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
-    pv[0] = bv; pi[0] = bi;
-}
-
 __device__ __forceinline__ int col_argmax_merge(const float* __restrict__ pval, const int* __restrict__ parg,
-                                                int Kc, int col, int parts) {
+                                                int Kc, int col) {
     float bv = -INFINITY; int bi = 0x7fffffff;
-    for (int z = 0; z < parts; ++z) {
+    for (int z = 0; z < CSLAB; ++z) {
         const float ov = pval[(size_t)z * Kc + col]; const int oi = parg[(size_t)z * Kc + col];
         if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
     }
@@ -1120,16 +931,11 @@ __global__ __launch_bounds__(1024) void lg_emit_kernel(
     const float* __restrict__ best0, const int* __restrict__ arg0, const float* __restrict__ pval,
     const int* __restrict__ parg, const int* __restrict__ ind, float filter_thr, float min_conf, int32_t* __restrict__ ij_out,
     float* __restrict__ score_out, int32_t* __restrict__ info_out, LGCtrl* __restrict__ ctrl, int Kc,
-    long out_stride, int* __restrict__ range_sticky, int tiled) {
-    // tiled = 0: best0 / arg0 are final per row, pval / parg hold CSLAB column partials (r03 one-direction kernels);
-    // tiled = 1: slab 0 of lg_argmax2d_kernel's row partials [ceil(Kc / 256)][Kc] / column partials [Kc / 32][Kc] holds the
-    // merged result (lg_argmax_merge_kernel)
+    long out_stride, int* __restrict__ range_sticky) {
     __shared__ int wsum[16];
     const int pair = blockIdx.x;
-    ctrl += pair;
-    const int rstride = tiled ? ((Kc + A2_COLS - 1) / A2_COLS) : 1, cstride = tiled ? (Kc / A2_ROWS) : CSLAB;
-    best0 += (size_t)pair * rstride * Kc; arg0 += (size_t)pair * rstride * Kc;
-    pval += (size_t)pair * cstride * Kc; parg += (size_t)pair * cstride * Kc; ind += (size_t)pair * 2 * Kc;
+    ctrl += pair; best0 += (size_t)pair * Kc; arg0 += (size_t)pair * Kc;
+    pval += (size_t)pair * CSLAB * Kc; parg += (size_t)pair * CSLAB * Kc; ind += (size_t)pair * 2 * Kc;
     ij_out += (size_t)pair * out_stride * 2; score_out += (size_t)pair * out_stride; info_out += pair * 4;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int n0 = ctrl->stop == 2 ? 0 : ctrl->n[0];
@@ -1144,8 +950,7 @@ __global__ __launch_bounds__(1024) void lg_emit_kernel(
             const float s = expf(best0[i]);
             // a row whose scores are all NaN (non-finite input) has no arg-max: no match, no lookup
             const bool valid = (unsigned)j < (unsigned)n1;
-            const int cparts = tiled ? 1 : CSLAB;
-            k = valid && (col_argmax_merge(pval, parg, Kc, j, cparts) == i) && (s > filter_thr) && (s > min_conf);
+            k = valid && (col_argmax_merge(pval, parg, Kc, j) == i) && (s > filter_thr) && (s > min_conf);
             jj[q] = valid ? j : 0; sc[q] = s;
         }
         keep[q] = k; cnt += k;
@@ -1973,9 +1778,7 @@ struct sslam_lightglue {
     int* range_sticky;               // device word: some pair of some call raised its range flag since the last read
     float *x, *enc_cos, *enc_sin, *q, *k, *v, *msg, *hid, *tx, *tc, *ts;
     float *o_part, *m_part, *l_part, *conf, *mat, *md, *sim, *rmax, *rlog, *cmax, *clog, *best0;
-    float *cpmax, *cpsum, *cpval, *bbox, *rpmax, *rpsum;
-    int assign_form = 1;             // 1 (default, r04): statistics in the sim epilogue + one 2-D arg-max pass (sim written once, read once);
-                                     // 0: the r03 one-direction kernels (sim read four times) - kept selectable for A/B and the identity test
+    float *cpmax, *cpsum, *cpval, *bbox;
     int* cparg;
     int *ind, *gmap, *prune, *arg0;
     float *in_xy, *in_desc, *up_xy, *up_desc, *out_score;
@@ -2384,36 +2187,23 @@ int lg_enqueue(sslam_lightglue* g, int pairs, const StageSrc& src, float min_con
     }
     hipLaunchKernelGGL(lg_token_heads_kernel, headgrid, dim3(256), 0, s, g->x, nullptr, nullptr,
                        g->mt_w, g->mt_b, g->mt_stride, 1, 0.0f, g->conf, g->mat, g->ctrl, Kc, 0);
-    if (g->assign_form == 1) {
-        SimArgs a{g->md, g->sim, Kc, g->ctrl, g->rpmax, g->rpsum, g->cpmax, g->cpsum};
+    {
+        SimArgs a{g->md, g->sim, Kc, g->ctrl};
         dim3 grid(sslam::cdiv(Kc, 128), sslam::cdiv(Kc, 64), pairs);
         hipLaunchKernelGGL((lg_sim_kernel<64, 128, 1, 2>), grid, dim3(256), 0, s, a);
-        hipLaunchKernelGGL(lg_stats_merge_kernel, dim3(sslam::cdiv(Kc, 256), 2, pairs), dim3(256), 0, s, g->rpmax, g->rpsum,
-                           g->cpmax, g->cpsum, g->rmax, g->rlog, g->cmax, g->clog, Kc, g->ctrl);
-        hipLaunchKernelGGL(lg_argmax2d_kernel, dim3(sslam::cdiv(Kc, A2_COLS), sslam::cdiv(Kc, A2_ROWS), pairs), dim3(256),
-                           0, s, g->sim, g->rmax, g->rlog, g->cmax, g->clog, g->conf, g->best0, g->arg0, g->cpval,
-                           g->cparg, Kc, g->ctrl);
-        hipLaunchKernelGGL(lg_argmax_merge_kernel, dim3(sslam::cdiv(Kc, 256), 2, pairs), dim3(256), 0, s, g->best0, g->arg0,
-                           g->cpval, g->cparg, Kc, g->ctrl);
-        hipLaunchKernelGGL(lg_emit_kernel, dim3(pairs), dim3(1024), 0, s, g->best0, g->arg0, g->cpval, g->cparg, g->ind,
-                           g->filter_thr, min_conf, ij_out, score_out, info_out, g->ctrl, Kc, out_stride, g->range_sticky, 1);
-    } else {
-        SimArgs a{g->md, g->sim, Kc, g->ctrl, nullptr, nullptr, nullptr, nullptr};
-        dim3 grid(sslam::cdiv(Kc, 128), sslam::cdiv(Kc, 64), pairs);
-        hipLaunchKernelGGL((lg_sim_kernel<64, 128, 1, 2>), grid, dim3(256), 0, s, a);
-        hipLaunchKernelGGL(lg_row_stats_kernel, dim3(sslam::cdiv(Kc, 4), pairs), dim3(256), 0, s, g->sim, g->rmax,
-                           g->rlog, Kc, g->ctrl);
-        hipLaunchKernelGGL(lg_col_stats_kernel, dim3(sslam::cdiv(Kc, 64), CSLAB, pairs), dim3(256), 0, s, g->sim,
-                           g->cpmax, g->cpsum, Kc, g->ctrl);
-        hipLaunchKernelGGL(lg_col_stats_merge_kernel, dim3(sslam::cdiv(Kc, 256), pairs), dim3(256), 0, s, g->cpmax,
-                           g->cpsum, g->cmax, g->clog, Kc, g->ctrl);
-        hipLaunchKernelGGL(lg_row_argmax_kernel, dim3(sslam::cdiv(Kc, 4), pairs), dim3(256), 0, s, g->sim, g->rmax,
-                           g->rlog, g->cmax, g->clog, g->conf, g->best0, g->arg0, Kc, g->ctrl);
-        hipLaunchKernelGGL(lg_col_argmax_kernel, dim3(sslam::cdiv(Kc, 64), CSLAB, pairs), dim3(256), 0, s, g->sim,
-                           g->rmax, g->rlog, g->cmax, g->clog, g->conf, g->cpval, g->cparg, Kc, g->ctrl);
-        hipLaunchKernelGGL(lg_emit_kernel, dim3(pairs), dim3(1024), 0, s, g->best0, g->arg0, g->cpval, g->cparg, g->ind,
-                           g->filter_thr, min_conf, ij_out, score_out, info_out, g->ctrl, Kc, out_stride, g->range_sticky, 0);
     }
+    hipLaunchKernelGGL(lg_row_stats_kernel, dim3(sslam::cdiv(Kc, 4), pairs), dim3(256), 0, s, g->sim, g->rmax,
+                       g->rlog, Kc, g->ctrl);
+    hipLaunchKernelGGL(lg_col_stats_kernel, dim3(sslam::cdiv(Kc, 64), CSLAB, pairs), dim3(256), 0, s, g->sim,
+                       g->cpmax, g->cpsum, Kc, g->ctrl);
+    hipLaunchKernelGGL(lg_col_stats_merge_kernel, dim3(sslam::cdiv(Kc, 256), pairs), dim3(256), 0, s, g->cpmax,
+                       g->cpsum, g->cmax, g->clog, Kc, g->ctrl);
+    hipLaunchKernelGGL(lg_row_argmax_kernel, dim3(sslam::cdiv(Kc, 4), pairs), dim3(256), 0, s, g->sim, g->rmax,
+                       g->rlog, g->cmax, g->clog, g->conf, g->best0, g->arg0, Kc, g->ctrl);
+    hipLaunchKernelGGL(lg_col_argmax_kernel, dim3(sslam::cdiv(Kc, 64), CSLAB, pairs), dim3(256), 0, s, g->sim,
+                       g->rmax, g->rlog, g->cmax, g->clog, g->conf, g->cpval, g->cparg, Kc, g->ctrl);
+    hipLaunchKernelGGL(lg_emit_kernel, dim3(pairs), dim3(1024), 0, s, g->best0, g->arg0, g->cpval, g->cparg, g->ind,
+                       g->filter_thr, min_conf, ij_out, score_out, info_out, g->ctrl, Kc, out_stride, g->range_sticky);
     SSLAM_HIP_CHECK(hipGetLastError());
     if (g->launch_error != hipSuccess) {                 // a module-API launch (the assembly attention kernel) failed
         const hipError_t e = g->launch_error;
@@ -2434,7 +2224,7 @@ void lg_configure_kernels() {
     launch_linear_h<64, 128, 1, 2, EPH_F32>(s, 0, cfg);   launch_linear_h<64, 64, 1, 1, EPH_RESID>(s, 0, cfg);
     launch_linear_h<64, 192, 1, 3, EPH_QKV>(s, 0, cfg);   launch_linear_h<64, 128, 1, 2, EPH_CROSS>(s, 0, cfg);
     launch_linear_big<128, 128, 2, 2, EPH_QKV>(s, 0, cfg); launch_linear_big<128, 128, 2, 2, EPH_CROSS>(s, 0, cfg);
-        (void)hipFuncSetAttribute((const void*)lg_ffn_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, sslam::FFN_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)lg_ffn_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, sslam::FFN_LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)lg_ffn_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, sslam::FFN_LDS_BYTES);
 }
 
@@ -2496,14 +2286,11 @@ int sslam_lightglue_create_batched(sslam_ctx* ctx, const float* weights, size_t 
         g->conf = A.take<float>(NI * K); g->mat = A.take<float>(NI * K); g->bbox = A.take<float>(NI * 4);
         g->sim = A.take<float>(NB * K * K);
         g->rmax = A.take<float>(NB * K); g->rlog = A.take<float>(NB * K); g->cmax = A.take<float>(NB * K);
-        g->clog = A.take<float>(NB * K);
-        const size_t rtiles = (K + 255) / 256, ctiles = K / 32 > (size_t)CSLAB ? K / 32 : (size_t)CSLAB;   // partial slabs of either assignment form
-        g->best0 = A.take<float>(NB * rtiles * K);
+        g->clog = A.take<float>(NB * K); g->best0 = A.take<float>(NB * K);
         g->ind = A.take<int>(NI * K); g->gmap = A.take<int>(NI * K); g->prune = A.take<int>(NI * K);
-        g->arg0 = A.take<int>(NB * rtiles * K);
-        g->cpmax = A.take<float>(NB * ctiles * K); g->cpsum = A.take<float>(NB * ctiles * K);
-        g->cpval = A.take<float>(NB * ctiles * K); g->cparg = A.take<int>(NB * ctiles * K);
-        g->rpmax = A.take<float>(NB * ctiles * K); g->rpsum = A.take<float>(NB * ctiles * K);
+        g->arg0 = A.take<int>(NB * K);
+        g->cpmax = A.take<float>(NB * CSLAB * K); g->cpsum = A.take<float>(NB * CSLAB * K);
+        g->cpval = A.take<float>(NB * CSLAB * K); g->cparg = A.take<int>(NB * CSLAB * K);
         g->in_xy = A.take<float>(NI * K * 2); g->in_desc = A.take<float>(NI * K * DIN);
         g->up_xy = A.take<float>(2 * K * 2); g->up_desc = A.take<float>(2 * K * DIN);
         g->out_ij = A.take<int32_t>(2 * K); g->out_score = A.take<float>(K); g->out_info = A.take<int32_t>(8);
@@ -2773,15 +2560,6 @@ int sslam_lightglue_debug_big_gemm(sslam_lightglue* g, int mode) {
     SSLAM_REQUIRE(g != nullptr && mode >= -1 && mode <= 5 && mode != 4, "sslam_lightglue_debug_big_gemm: bad argument");
     g->settings_changed();
     g->big_gemm = mode;
-    return 0;
-}
-
-/* Test / A-B hook: 1 (default) = assignment with the dual-softmax statistics in the sim epilogue and one 2-D arg-max pass
- * (`sim` written once, read once); 0 = the r03 one-direction kernels (`sim` read four times).  Same matches. */
-int sslam_lightglue_debug_assignment(sslam_lightglue* g, int form) {
-    SSLAM_REQUIRE(g != nullptr && (form == 0 || form == 1), "sslam_lightglue_debug_assignment: bad argument");
-    g->settings_changed();
-    g->assign_form = form;
     return 0;
 }
 

@@ -134,10 +134,6 @@ class LightGlueHIP:
         """Precision-study hook (profiles/r04_split_study.md): drop cross terms of the split products; 0 = product."""
         _native.check(_native.lib().sslam_lightglue_debug_split_form(self.handle, int(mask)))
 
-    def debug_assignment(self, form: int):
-        """A/B hook: 1 = fused statistics + 2-D arg-max (default), 0 = the r03 one-direction kernels.  Same matches."""
-        _native.check(_native.lib().sslam_lightglue_debug_assignment(self.handle, int(form)))
-
     def debug_big_gemm(self, mode: int):
         """Test hook: -1 linears by batch size, 0 always the 64-row ring kernels (single-pair form), 1 always the
         batched form (128 x 128 projections + the whole FFN as one kernel, its tile by token count), 2 / 3 the batched
