@@ -42,6 +42,7 @@ from oracle import lightglue_ref as L                                # noqa: E40
 SEED, N, LAYERS = 5, 64, 9
 KEEP = {'self_0', 'cross_0', 'cross_3', 'self_8', 'cross_8', 'conf_0', 'conf_7'}     # stages stored (fixture size)
 SD_KW = dict(match_gain=4.0, match_bias=3.0)
+ROWS = 16
 
 
 def build_hf_layer(hf, cfg, sd, i):
@@ -92,6 +93,9 @@ def main():
                 out[f"self_{i}"] = hidden[1].numpy()    # descriptors after the self block
             if f"cross_{i}" in KEEP:
                 out[f"cross_{i}"] = x.numpy()           # after the cross block
+            # r04: EVERY half layer of the 9-layer forward, first ROWS tokens of each image (fixture size)
+            out[f"rows_self_{i}"] = hidden[1][:, :ROWS].numpy()
+            out[f"rows_cross_{i}"] = x[:, :ROWS].numpy()
             tc = hf.LightGlueTokenConfidenceLayer(cfg).eval()
             if i < LAYERS - 1 and f"conf_{i}" in KEEP:
                 tc.token.weight.data = t(f"token_confidence.{i}.token.0.weight"); tc.token.bias.data = t(f"token_confidence.{i}.token.0.bias")

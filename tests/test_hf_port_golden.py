@@ -3,7 +3,8 @@ port (a separately written implementation of the same published network), stored
 tests/golden/hf_lightglue.npz by tests/golden/make_hf_lightglue_golden.py.
 
   * CPU: oracle/lightglue_ref.py reproduces every stored stage - positional encoding, the self and
-    cross blocks of layers 0 / 3 / 8, token confidence, the log-assignment matrix, the match filter.
+    cross blocks of layers 0 / 3 / 8 in full and (r04) EVERY half layer of the 9-layer forward on the first 16
+    tokens of each image, token confidence, the log-assignment matrix, the match filter.
   * GPU (-m gpu): the HIP path reproduces the same stages through the C-ABI (token states after
     k layers via the debug hooks; final matches).
 
@@ -46,6 +47,11 @@ def test_oracle_reproduces_every_hf_stage(sd):
             for img in (0, 1):
                 np.testing.assert_allclose(d["layers"][int(i)][f"{kind}{img}"].numpy(), G[key][img], atol=2e-5, rtol=1e-5,
                                            err_msg=key)
+        if key.startswith("rows_"):                    # r04: every half layer of the full forward (first 16 tokens per image)
+            _, kind, i = key.split("_")
+            for img in (0, 1):
+                np.testing.assert_allclose(d["layers"][int(i)][f"{kind}{img}"].numpy()[:G[key].shape[1]], G[key][img], atol=2e-5,
+                                           rtol=1e-5, err_msg=key)
         if key.startswith("conf_"):
             i = int(key.split("_")[1])
             x = torch.stack([d["layers"][i]["cross0"], d["layers"][i]["cross1"]])
@@ -71,14 +77,15 @@ def test_hip_path_reproduces_the_hf_stages(sd, gpu_ctx, precision):
     Kc = lg.capacity
     args = (G["k0"], G["d0"], G["k1"], G["d1"])
     for key in sorted(G.files):
-        if not (key.startswith("self_") or key.startswith("cross_")):
+        if not (key.startswith("self_") or key.startswith("cross_") or key.startswith("rows_")):
             continue
-        kind, i = key.split("_")
+        kind, i = key.split("_")[-2:]
         lg.debug_layers(int(i) + 1, self_only=(kind == "self"))
         lg.match(*args, min_conf=0.0)
         x = lg.debug_read(0, (2, Kc, 256))
+        rows = G[key].shape[1]                            # whole images for the stored stages, 16 tokens for every half layer
         for img in (0, 1):
-            np.testing.assert_allclose(x[img, :n], G[key][img], atol=3e-5, rtol=1e-5, err_msg=f"{key} {precision}")
+            np.testing.assert_allclose(x[img, :rows], G[key][img], atol=3e-5, rtol=1e-5, err_msg=f"{key} {precision}")
     lg.debug_layers(9, False)
     ij, sc, stop = lg.match(*args, min_conf=0.0)
     m0 = G["matches0"]
