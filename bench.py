@@ -711,7 +711,10 @@ def main():
             for _ in range(5):
                 d0.extract_batch_dev(*args_e, max_kpts=K)
             ext_ms = d0.ctx.timer_stop() / 5 / len(fr)
-            scale = (Hh * Ww) / float(H_IMG * W_IMG)
+            # ALIKED runs at the resized size (long side 1024, short side padded to 32): its 0.2 GB / frame at 1024 x 320 scales with
+            # that area (x1.8 at C5), the 3-byte input image with its own
+            net = lambda hh, ww: 1024 * ((int(round(min(hh, ww) * 1024.0 / max(hh, ww))) + 31) // 32 * 32)      # noqa: E731
+            scale = net(Hh, Ww) / float(net(H_IMG, W_IMG))
             rec = {"value": round(steps * B / dt_s, 2), "unit": "frames/s", "steps": steps, "frames_per_step": B,
                    "image": [Ww, Hh], "max_kpts": K, "kpts_matched": [int(info_s[-1, 2]), int(info_s[-1, 3])],
                    "lightglue_layers_executed": int(info_s[-1, 1]),
@@ -738,7 +741,7 @@ def main():
                 c0.free(q)
             det_s[0].close()
             return rec
-        for name, cfg in (("c5", (1080, 1920, MAX_KPTS, 8, 8, max(4, args.steps // 12))),
+        for name, cfg in (("c5", (1080, 1920, MAX_KPTS, 8, min(8, BATCH_PAIRS), max(4, args.steps // 12))),
                           ("kpts4000", (H_IMG, W_IMG, 4000, 8, 4, max(4, args.steps // 12)))):
             try:
                 sized[name] = sized_leg(name, *cfg)
