@@ -626,11 +626,15 @@ struct Pyr {
     // channel-last copies [pixel][32] of the three gated levels for the descriptor head: a bilinear
     // tap of all 32 channels is then ONE 128-byte line instead of 32 lines of 32 planes
     const float *g2cl, *g3cl, *g4cl;
+    // r04: what the aggregate kernel needs of an upsampled level, formed ONCE at the level's own resolution
+    // (al_agg_pre_kernel): [AGG_PRE][pixels] planar per level - see there
+    const float *pre2, *pre3, *pre4;
 };
 
 __device__ __forceinline__ Pyr pyr_at(Pyr P, int f, size_t fs) {      // the pyramid of frame f (weights w1 shared)
     P.x1 = fsh(P.x1, f, fs); P.g2 = fsh(P.g2, f, fs); P.g3 = fsh(P.g3, f, fs); P.g4 = fsh(P.g4, f, fs);
     P.g1cl = fsh(P.g1cl, f, fs); P.g2cl = fsh(P.g2cl, f, fs); P.g3cl = fsh(P.g3cl, f, fs); P.g4cl = fsh(P.g4cl, f, fs);
+    P.pre2 = fsh(P.pre2, f, fs); P.pre3 = fsh(P.pre3, f, fs); P.pre4 = fsh(P.pre4, f, fs);
     return P;
 }
 
@@ -653,6 +657,70 @@ __device__ __forceinline__ float up_eval_cl(const float* __restrict__ p, const U
 }
 __device__ __forceinline__ float up_eval(const float* __restrict__ p, const UpTap& t) {
     return t.w10 * (t.w00 * p[t.o00] + t.w01 * p[t.o01]) + t.w11 * (t.w00 * p[t.o10] + t.w01 * p[t.o11]);
+}
+
+// r04: bilinear upsampling is linear, so what the aggregate kernel needs of an upsampled 32-channel level g at a
+// full-resolution pixel - its contribution to the first score-head layer, sum_c Ws0[c][o] up(g_c), and to ||F||^2,
+// sum_c up(g_c)^2 - are functions of low-resolution maps formed ONCE per level pixel instead of 32 channels x 4 taps per
+// full-resolution pixel (r03: 384 gathers and ~2000 vector instructions per pixel for the three levels; now 126 and ~250):
+//     proj[o][p] = sum_c Ws0[c][o] g_c[p]                                  (8 maps)   -> contribution = up(proj[o])
+//     S[p] = <g[p], g[p]>, H[p] = <g[p], g[p + x]>, V[p] = <g[p], g[p + y]>, D1[p] = <g[p], g[p + x + y]>,
+//     D2[p] = <g[p + x], g[p + y]>                                          (5 maps)
+//     sum_c up(g_c)^2 = sum_{t, t'} w_t w_t' <g[t], g[t']> over the four taps = a quadratic form in S, H, V, D1, D2
+// (neighbours clamped at the border, where their tap weight is exactly zero).  One thread per level pixel, all three levels
+// of a frame in one launch; reads the channel-last copies (one 128-byte line per pixel).
+constexpr int AGG_PRE = 13;
+__global__ __launch_bounds__(256) void al_agg_pre_kernel(const float* __restrict__ g2cl, const float* __restrict__ g3cl,
+                                                         const float* __restrict__ g4cl, const float* __restrict__ ws0 /*[128][8]*/,
+                                                         float* __restrict__ pre2, float* __restrict__ pre3, float* __restrict__ pre4,
+                                                         int Hp, int Wp, size_t fs) {
+    const int f = blockIdx.y;
+    const int n2 = (Hp / 2) * (Wp / 2), n3 = (Hp / 8) * (Wp / 8), n4 = (Hp / 32) * (Wp / 32);
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float* g; float* pre; int S, lvl;
+    if (i < n2) { g = g2cl; pre = pre2; S = 2; lvl = 1; }
+    else if (i < n2 + n3) { i -= n2; g = g3cl; pre = pre3; S = 8; lvl = 2; }
+    else if (i < n2 + n3 + n4) { i -= n2 + n3; g = g4cl; pre = pre4; S = 32; lvl = 3; }
+    else return;
+    g = fsh(g, f, fs); pre = fsh(pre, f, fs);
+    const int ih = Hp / S, iw = Wp / S, n = ih * iw;
+    const int y = i / iw, x = i % iw;
+    const int xr = x + (x < iw - 1), yd = y + (y < ih - 1);
+    const float4* a4 = reinterpret_cast<const float4*>(g + (size_t)(y * iw + x) * 32);
+    const float4* b4 = reinterpret_cast<const float4*>(g + (size_t)(y * iw + xr) * 32);
+    const float4* c4 = reinterpret_cast<const float4*>(g + (size_t)(yd * iw + x) * 32);
+    const float4* d4 = reinterpret_cast<const float4*>(g + (size_t)(yd * iw + xr) * 32);
+    float pr[8] = {}, ss = 0.0f, hh = 0.0f, vv = 0.0f, d1 = 0.0f, d2 = 0.0f;
+    const float* w = ws0 + lvl * 32 * 8;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float4 a = a4[q], b = b4[q], c = c4[q], d = d4[q];
+        const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w}, cv[4] = {c.x, c.y, c.z, c.w}, dv[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ss = fmaf(av[e], av[e], ss); hh = fmaf(av[e], bv[e], hh); vv = fmaf(av[e], cv[e], vv);
+            d1 = fmaf(av[e], dv[e], d1); d2 = fmaf(bv[e], cv[e], d2);
+#pragma unroll
+            for (int o = 0; o < 8; ++o) pr[o] = fmaf(av[e], w[(4 * q + e) * 8 + o], pr[o]);
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) pre[(size_t)o * n + i] = pr[o];
+    pre[(size_t)8 * n + i] = ss; pre[(size_t)9 * n + i] = hh; pre[(size_t)10 * n + i] = vv;
+    pre[(size_t)11 * n + i] = d1; pre[(size_t)12 * n + i] = d2;
+}
+
+// contribution of one upsampled level at a full-resolution pixel: s[o] += up(proj[o]), n2 += the quadratic form
+__device__ __forceinline__ void agg_level(const float* __restrict__ pre, int n, const UpTap& t, float (&s)[8], float& n2) {
+#pragma unroll
+    for (int o = 0; o < 8; ++o) s[o] += up_eval(pre + (size_t)o * n, t);
+    const float w00 = t.w10 * t.w00, w01 = t.w10 * t.w01, w10 = t.w11 * t.w00, w11 = t.w11 * t.w01;     // hy hx, hy lx, ly hx, ly lx
+    const float* S = pre + (size_t)8 * n; const float* H = pre + (size_t)9 * n; const float* V = pre + (size_t)10 * n;
+    const float* D1 = pre + (size_t)11 * n; const float* D2 = pre + (size_t)12 * n;
+    const float sq = (w00 * w00 * S[t.o00] + w01 * w01 * S[t.o01]) + (w10 * w10 * S[t.o10] + w11 * w11 * S[t.o11]);
+    const float cr = ((w00 * w01) * H[t.o00] + (w10 * w11) * H[t.o10]) + ((w00 * w10) * V[t.o00] + (w01 * w11) * V[t.o01]) +
+                     ((w00 * w11) * D1[t.o00] + (w01 * w10) * D2[t.o00]);
+    n2 += fmaf(2.0f, cr, sq);
 }
 
 // (r03: the kernel is latency-bound - waves parked 65 % of their cycles, SQ counters - so the level loops carry four
@@ -692,28 +760,9 @@ __global__ __launch_bounds__(256) void al_aggregate_kernel(Pyr P0, const float* 
     }
     const UpTap t2 = up_tap(y, x, P.Hp, P.Wp, 2, P.sy2, P.sx2), t3 = up_tap(y, x, P.Hp, P.Wp, 8, P.sy8, P.sx8),
                 t4 = up_tap(y, x, P.Hp, P.Wp, 32, P.sy32, P.sx32);
-    const size_t hw2 = HW / 4, hw3 = HW / 64, hw4 = HW / 1024;
-#pragma unroll AL_AGG_UNROLL
-    for (int c = 0; c < 32; ++c) {
-        const float a = up_eval(P.g2 + c * hw2, t2);
-        n2 = fmaf(a, a, n2);
-#pragma unroll
-        for (int o = 0; o < 8; ++o) s[o] = fmaf(a, ws0[(32 + c) * 8 + o], s[o]);
-    }
-#pragma unroll AL_AGG_UNROLL
-    for (int c = 0; c < 32; ++c) {
-        const float a = up_eval(P.g3 + c * hw3, t3);
-        n2 = fmaf(a, a, n2);
-#pragma unroll
-        for (int o = 0; o < 8; ++o) s[o] = fmaf(a, ws0[(64 + c) * 8 + o], s[o]);
-    }
-#pragma unroll AL_AGG_UNROLL
-    for (int c = 0; c < 32; ++c) {
-        const float a = up_eval(P.g4 + c * hw4, t4);
-        n2 = fmaf(a, a, n2);
-#pragma unroll
-        for (int o = 0; o < 8; ++o) s[o] = fmaf(a, ws0[(96 + c) * 8 + o], s[o]);
-    }
+    agg_level(P.pre2, (int)(HW / 4), t2, s, n2);
+    agg_level(P.pre3, (int)(HW / 64), t3, s, n2);
+    agg_level(P.pre4, (int)(HW / 1024), t4, s, n2);
     if (live) {
 #pragma unroll
         for (int o = 0; o < 8; ++o) s8[o * HW + pix] = selu(s[o]);
@@ -1392,7 +1441,7 @@ struct sslam_aliked {
     ALCtrl* ctrl;
     uint8_t* in_u8;
     float *fsrc, *img, *x1a, *x1, *t2, *idn2, *x2, *p3, *off, *t3, *x3, *p4, *t4, *x4, *g2, *g3, *g4;
-    float *s8, *rnorm, *score, *nms, *bsum, *gk, *g1cl, *g2cl, *g3cl, *g4cl;
+    float *s8, *rnorm, *score, *nms, *bsum, *gk, *g1cl, *g2cl, *g3cl, *g4cl, *pre2, *pre3, *pre4;
     unsigned long long* cand;
     unsigned* hist;
     int cand_cap;
@@ -1560,7 +1609,10 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
         P.sy2 = step(Hp, 2); P.sx2 = step(Wp, 2); P.sy8 = step(Hp, 8); P.sx8 = step(Wp, 8);
         P.sy32 = step(Hp, 32); P.sx32 = step(Wp, 32);
         P.g2cl = g->g2cl; P.g3cl = g->g3cl; P.g4cl = g->g4cl;
+        P.pre2 = g->pre2; P.pre3 = g->pre3; P.pre4 = g->pre4;
     }
+    hipLaunchKernelGGL(al_agg_pre_kernel, dim3(sslam::cdiv(H2 * W2 + HW3 + HW4, 256), uF), dim3(256), 0, s, g->g2cl, g->g3cl, g->g4cl,
+                       g->sh0, g->pre2, g->pre3, g->pre4, Hp, Wp, fs);
     hipLaunchKernelGGL(al_aggregate_kernel, dim3(sslam::cdiv(Wp, 256), Hp, uF), dim3(256), 0, s, P, g->sh0, g->s8, g->rnorm, fs);
     hipLaunchKernelGGL(al_score_tail_kernel, dim3(sslam::cdiv(Wp, ST_W), sslam::cdiv(Hp, ST_H), uF), dim3(256), 0, s, g->s8,
                        Hp, Wp, g->sh2, g->sh4, g->sh6, g->score, d.h, d.w, d.pl, d.pt, fs);
@@ -1653,6 +1705,7 @@ int sslam_aliked_create_batched(sslam_ctx* ctx, const float* weights, size_t n_f
         g->g2 = A.take<float>(32 * HWp / 4); g->g3 = A.take<float>(32 * HWp / 64); g->g4 = A.take<float>(32 * HWp / 1024);
         g->g2cl = A.take<float>(32 * HWp / 4); g->g3cl = A.take<float>(32 * HWp / 64); g->g4cl = A.take<float>(32 * HWp / 1024);
         g->s8 = A.take<float>(8 * HWp); g->rnorm = A.take<float>(HWp); g->g1cl = A.take<float>(32 * HWp);
+        g->pre2 = A.take<float>(AGG_PRE * HWp / 4); g->pre3 = A.take<float>(AGG_PRE * HWp / 64); g->pre4 = A.take<float>(AGG_PRE * HWp / 1024);
         g->score = A.take<float>(HWp); g->nms = A.take<float>(HWp); g->bsum = A.take<float>(4096);
         g->cand = A.take<unsigned long long>(g->cand_cap); g->hist = A.take<unsigned>(HBINS);
         g->kp_index = A.take<int>(SEL_CAP); g->sel_keys = A.take<unsigned long long>(SEL_CAP);
