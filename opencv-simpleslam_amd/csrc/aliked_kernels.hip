@@ -29,6 +29,8 @@ using sslam::gemm_mainloop;
 
 constexpr float SELU_SCALE = 1.0507009873554804934193349852946f;
 constexpr float SELU_ALPHA = 1.6732632423543772848170429916717f;
+// (r04: a ~18-instruction expm1 - Taylor near zero, exact-argument exp2 below - instead of ocml's expm1f changed no kernel's
+//  time by more than 4 %: these kernels wait on memory, their vector pipe is not the limit; ocml's stays)
 __device__ __forceinline__ float selu(float x) {
     return SELU_SCALE * (x > 0.0f ? x : SELU_ALPHA * expm1f(x));
 }
@@ -668,9 +670,9 @@ __device__ __forceinline__ float up_eval(const float* __restrict__ p, const UpTa
 //     D2[p] = <g[p + x], g[p + y]>                                          (5 maps)
 //     sum_c up(g_c)^2 = sum_{t, t'} w_t w_t' <g[t], g[t']> over the four taps = a quadratic form in S, H, V, D1, D2
 // (neighbours clamped at the border, where their tap weight is exactly zero).  One thread per level pixel, all three levels
-// of a frame in one launch; reads the channel-last copies (one 128-byte line per pixel).
+// of a frame in one launch; reads the planar levels.
 constexpr int AGG_PRE = 13;
-__global__ __launch_bounds__(256) void al_agg_pre_kernel(const float* __restrict__ g2cl, const float* __restrict__ g3cl,
+__global__ __launch_bounds__(256) void al_agg_pre_kernel(const float* __restrict__ g2cl /* planar [32][pixels] */, const float* __restrict__ g3cl,
                                                          const float* __restrict__ g4cl, const float* __restrict__ ws0 /*[128][8]*/,
                                                          float* __restrict__ pre2, float* __restrict__ pre3, float* __restrict__ pre4,
                                                          int Hp, int Wp, size_t fs) {
@@ -686,23 +688,19 @@ __global__ __launch_bounds__(256) void al_agg_pre_kernel(const float* __restrict
     const int ih = Hp / S, iw = Wp / S, n = ih * iw;
     const int y = i / iw, x = i % iw;
     const int xr = x + (x < iw - 1), yd = y + (y < ih - 1);
-    const float4* a4 = reinterpret_cast<const float4*>(g + (size_t)(y * iw + x) * 32);
-    const float4* b4 = reinterpret_cast<const float4*>(g + (size_t)(y * iw + xr) * 32);
-    const float4* c4 = reinterpret_cast<const float4*>(g + (size_t)(yd * iw + x) * 32);
-    const float4* d4 = reinterpret_cast<const float4*>(g + (size_t)(yd * iw + xr) * 32);
+    const int ia = y * iw + x, ib = y * iw + xr, ic = yd * iw + x, id = yd * iw + xr;
     float pr[8] = {}, ss = 0.0f, hh = 0.0f, vv = 0.0f, d1 = 0.0f, d2 = 0.0f;
     const float* w = ws0 + lvl * 32 * 8;
+    // planar reads: lane = pixel, so one load instruction is 256 contiguous bytes per channel (the channel-last copies
+    // would make every lane fetch its own 128-byte line: 22 us per frame measured, this form ~3)
+#pragma unroll 8
+    for (int c = 0; c < 32; ++c) {
+        const float* gc = g + (size_t)c * n;
+        const float av = gc[ia], bv = gc[ib], cv = gc[ic], dv = gc[id];
+        ss = fmaf(av, av, ss); hh = fmaf(av, bv, hh); vv = fmaf(av, cv, vv);
+        d1 = fmaf(av, dv, d1); d2 = fmaf(bv, cv, d2);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const float4 a = a4[q], b = b4[q], c = c4[q], d = d4[q];
-        const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w}, cv[4] = {c.x, c.y, c.z, c.w}, dv[4] = {d.x, d.y, d.z, d.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            ss = fmaf(av[e], av[e], ss); hh = fmaf(av[e], bv[e], hh); vv = fmaf(av[e], cv[e], vv);
-            d1 = fmaf(av[e], dv[e], d1); d2 = fmaf(bv[e], cv[e], d2);
-#pragma unroll
-            for (int o = 0; o < 8; ++o) pr[o] = fmaf(av[e], w[(4 * q + e) * 8 + o], pr[o]);
-        }
+        for (int o = 0; o < 8; ++o) pr[o] = fmaf(av, w[c * 8 + o], pr[o]);
     }
 #pragma unroll
     for (int o = 0; o < 8; ++o) pre[(size_t)o * n + i] = pr[o];
@@ -1611,7 +1609,7 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
         P.g2cl = g->g2cl; P.g3cl = g->g3cl; P.g4cl = g->g4cl;
         P.pre2 = g->pre2; P.pre3 = g->pre3; P.pre4 = g->pre4;
     }
-    hipLaunchKernelGGL(al_agg_pre_kernel, dim3(sslam::cdiv(H2 * W2 + HW3 + HW4, 256), uF), dim3(256), 0, s, g->g2cl, g->g3cl, g->g4cl,
+    hipLaunchKernelGGL(al_agg_pre_kernel, dim3(sslam::cdiv(H2 * W2 + HW3 + HW4, 256), uF), dim3(256), 0, s, g->g2, g->g3, g->g4,
                        g->sh0, g->pre2, g->pre3, g->pre4, Hp, Wp, fs);
     hipLaunchKernelGGL(al_aggregate_kernel, dim3(sslam::cdiv(Wp, 256), Hp, uF), dim3(256), 0, s, P, g->sh0, g->s8, g->rnorm, fs);
     hipLaunchKernelGGL(al_score_tail_kernel, dim3(sslam::cdiv(Wp, ST_W), sslam::cdiv(Hp, ST_H), uF), dim3(256), 0, s, g->s8,
