@@ -389,54 +389,72 @@ __global__ void al_avgpool_kernel(const float* __restrict__ in, float* __restric
     out[i] = s / (float)(P * P);
 }
 
-// offset conv: 3x3, zero pad, bias, clamp to +-max_off.  r04: a workgroup owns 64 consecutive pixels; lane = pixel, wave q
-// sums input channels [q CIN / 4, (q + 1) CIN / 4) x 9 taps, so an input load is 256 contiguous bytes per (channel, tap) and the
-// 18 weights of a (channel, tap) are wave-uniform (scalar loads from the packed [ci][tap][18] tensor); the four partial sums
-// of a pixel meet in LDS and are added in wave order.  (r03 gave a wave 1 - 4 pixels with the K = CIN * 9 products spread over
-// its lanes: every wave re-read the whole weight block - 420 MB through L2 per launch at F = 8, 43 us for 0.4 GFLOP.)
-template <int CIN>
+// offset conv: 3x3, zero pad, bias, clamp to +-max_off.  One wave per pixel: lanes stride over the
+// CIN*9 (ci, tap) products, each lane keeps 18 partial sums, then 18 wave reductions.  The weights
+// are read from the [18][CIN*9] copy made at create time, so each of the 18 loads of an iteration
+// is 256 contiguous bytes across the wave (with the packed [k][18] layout every one of them
+// walked the same 36 cache lines again: 648 line look-ups per iteration instead of 36).
+template <int CIN, int OC_PP>      // OC_PP: pixels per wave (4 for batches of frames, 1 when one frame has to fill the chip)
 __global__ __launch_bounds__(256) void al_offset_conv_kernel(const float* __restrict__ in, float* __restrict__ off,
                                                              int H, int W,
-                                                             const float* __restrict__ wk /*[CIN][9][18]*/,
+                                                             const float* __restrict__ wt /*[18][CIN*9]*/,
                                                              const float* __restrict__ b, float max_off, size_t fs) {
-    __shared__ float red[4][18][64];
-    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int HW = H * W;
-    const int pix = min((int)blockIdx.x * 64 + lane, HW - 1);
+    // r03: a wave takes OC_PP consecutive pixels, so the 18 weight loads of an iteration serve four pixels (one
+    // wave per pixel re-read the whole [18][CIN*9] weight block for every pixel: 1.7 GB of L1 / L2 traffic per launch
+    // at F = 8).  A pixel's sums run over the same lanes and k's in the same order as before: bit-identical.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pix0 = (blockIdx.x * 4 + wave) * OC_PP;
+    if (pix0 >= H * W) return;
     in = fsh(in, blockIdx.y, fs); off = fsh(off, blockIdx.y, fs);
-    const int y = pix / W, x = pix % W;
-    int o9[9]; bool ok9[9];
+    float part[OC_PP][18];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-        ok9[tap] = yy >= 0 && yy < H && xx >= 0 && xx < W;
-        o9[tap] = ok9[tap] ? yy * W + xx : 0;
-    }
-    float acc[18];
+    for (int p = 0; p < OC_PP; ++p)
 #pragma unroll
-    for (int o = 0; o < 18; ++o) acc[o] = 0.0f;
-    constexpr int CQ = CIN / 4;
-    const int c0 = __builtin_amdgcn_readfirstlane(part) * CQ;
-#pragma unroll 2
-    for (int ci = 0; ci < CQ; ++ci) {
-        const float* plane = in + (size_t)(c0 + ci) * HW;
-        const float* wrow = wk + (size_t)(c0 + ci) * 9 * 18;
-        float v[9];
+        for (int o = 0; o < 18; ++o) part[p][o] = 0.0f;
+    // fully unrolled (CIN is a template parameter): all loads of an iteration are in flight at once;
+    // as a rolled loop every iteration waited out a full memory latency
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) v[tap] = ok9[tap] ? plane[o9[tap]] : 0.0f;      // nine loads in flight
+    for (int it = 0; it < (CIN * 9 + 63) / 64; ++it) {
+        const int k = lane + 64 * it;
+        if (CIN * 9 % 64 != 0 && k >= CIN * 9) break;
+        const int ci = k / 9, tap = k % 9;
+        float v[OC_PP];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-            for (int o = 0; o < 18; ++o) acc[o] = fmaf(v[tap], wrow[tap * 18 + o], acc[o]);
-    }
-#pragma unroll
-    for (int o = 0; o < 18; ++o) red[part][o][lane] = acc[o];
-    __syncthreads();
-    if ((int)blockIdx.x * 64 + lane < HW)
-        for (int o = part; o < 18; o += 4) {
-            const float v = ((red[0][o][lane] + red[1][o][lane]) + red[2][o][lane]) + red[3][o][lane];
-            off[(size_t)o * HW + pix] = fminf(fmaxf(v + b[o], -max_off), max_off);
+        for (int p = 0; p < OC_PP; ++p) {
+            const int pix = min(pix0 + p, H * W - 1);
+            const int y = pix / W, x = pix % W;
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            v[p] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? in[((size_t)ci * H + yy) * W + xx] : 0.0f;
         }
+#pragma unroll
+        for (int o = 0; o < 18; ++o) {
+            const float wv = wt[o * (CIN * 9) + k];
+#pragma unroll
+            for (int p = 0; p < OC_PP; ++p) part[p][o] = fmaf(v[p], wv, part[p][o]);
+        }
+    }
+    // 18 sums over the 64 lanes: through LDS, lane (o, third) adds a third of row o, two shuffles
+    // finish it (18 butterfly reductions = 108 cross-lane steps dominated the kernel)
+    __shared__ float red[4][18][65];
+    const int o = lane / 3, th = lane % 3;
+#pragma unroll
+    for (int p = 0; p < OC_PP; ++p) {
+        if (p) __builtin_amdgcn_wave_barrier();      // the previous pixel's reads of the slab are done (one wave: program order)
+#pragma unroll
+        for (int q = 0; q < 18; ++q) red[wave][q][lane] = part[p][q];
+        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's own slab
+        __builtin_amdgcn_wave_barrier();
+        float v = 0.0f;
+        if (lane < 54) {
+            const float* r = red[wave][o];
+            const int j0 = th * 22, j1 = th == 2 ? 64 : j0 + 22;
+            for (int j = j0; j < j1; ++j) v += r[j];
+        }
+        v += __shfl_down(v, 1) + __shfl_down(v, 2);
+        const int pix = pix0 + p;
+        if (lane < 54 && th == 0 && pix < H * W) off[(size_t)o * H * W + pix] = fminf(fmaxf(v + b[o], -max_off), max_off);
+        __builtin_amdgcn_s_waitcnt(0xc07f);          // the reads above, before the next pixel overwrites the slab
+    }
 }
 
 // ---- deformable conv as im2col + matrix-core GEMM --------------------------------------------
@@ -1412,6 +1430,7 @@ struct sslam_aliked {
     const float *b2dw, *b2db;
     ALDcnW b3c1, b3c2, b4c1, b4c2;
     const float *b3dw, *b3db, *b4dw, *b4db;
+    float *b3c1ot, *b3c2ot, *b4c1ot, *b4c2ot;                              // offset-conv weights as [18][CIN*9]
     float *b3c1t, *b3c2t, *b4c1t, *b4c2t, *b3dwt, *b4dwt, *dcol, *dpart;   // [co][k] copies, im2col buffer, split-K slabs
     const float *gw1, *gw2, *gw3, *gw4;
     const float *sh0, *sh2, *sh4, *sh6;
@@ -1553,21 +1572,29 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
     const int H3 = Hp / 8, W3 = Wp / 8, HW3 = H3 * W3;
     hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(32 * HW3, 256), uF), dim3(256), 0, s, g->x2, g->p3, 32, H2, W2, 4, fs);
     const float mo3 = (float)(H3 > W3 ? H3 : W3) / 4.0f;
-    hipLaunchKernelGGL((al_offset_conv_kernel<32>), dim3(sslam::cdiv(HW3, 64), uF), dim3(256), 0, s, g->p3, g->off, H3,
-                       W3, g->b3c1.ow, g->b3c1.ob, mo3, fs);
+    if (F >= 4) hipLaunchKernelGGL((al_offset_conv_kernel<32, 4>), dim3(sslam::cdiv(HW3, 16), uF), dim3(256), 0, s, g->p3, g->off, H3,
+                       W3, g->b3c1ot, g->b3c1.ob, mo3, fs);
+    else hipLaunchKernelGGL((al_offset_conv_kernel<32, 1>), dim3(sslam::cdiv(HW3, 4), uF), dim3(256), 0, s, g->p3, g->off, H3,
+                       W3, g->b3c1ot, g->b3c1.ob, mo3, fs);
     dcn(g->p3, 32, g->t3, 64, H3, W3, g->b3c1t, g->b3c1.a, g->b3c1.b, nullptr, 0, nullptr, nullptr);
-    hipLaunchKernelGGL((al_offset_conv_kernel<64>), dim3(sslam::cdiv(HW3, 64), uF), dim3(256), 0, s, g->t3, g->off, H3,
-                       W3, g->b3c2.ow, g->b3c2.ob, mo3, fs);
+    if (F >= 4) hipLaunchKernelGGL((al_offset_conv_kernel<64, 4>), dim3(sslam::cdiv(HW3, 16), uF), dim3(256), 0, s, g->t3, g->off, H3,
+                       W3, g->b3c2ot, g->b3c2.ob, mo3, fs);
+    else hipLaunchKernelGGL((al_offset_conv_kernel<64, 1>), dim3(sslam::cdiv(HW3, 4), uF), dim3(256), 0, s, g->t3, g->off, H3,
+                       W3, g->b3c2ot, g->b3c2.ob, mo3, fs);
     dcn(g->t3, 64, g->x3, 64, H3, W3, g->b3c2t, g->b3c2.a, g->b3c2.b, g->p3, 32, g->b3dwt, g->b3db);
     // block4 at 1/32
     const int H4 = Hp / 32, W4 = Wp / 32, HW4 = H4 * W4;
     hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(64 * HW4, 256), uF), dim3(256), 0, s, g->x3, g->p4, 64, H3, W3, 4, fs);
     const float mo4 = (float)(H4 > W4 ? H4 : W4) / 4.0f;
-    hipLaunchKernelGGL((al_offset_conv_kernel<64>), dim3(sslam::cdiv(HW4, 64), uF), dim3(256), 0, s, g->p4, g->off, H4,
-                       W4, g->b4c1.ow, g->b4c1.ob, mo4, fs);
+    if (F >= 4) hipLaunchKernelGGL((al_offset_conv_kernel<64, 4>), dim3(sslam::cdiv(HW4, 16), uF), dim3(256), 0, s, g->p4, g->off, H4,
+                       W4, g->b4c1ot, g->b4c1.ob, mo4, fs);
+    else hipLaunchKernelGGL((al_offset_conv_kernel<64, 1>), dim3(sslam::cdiv(HW4, 4), uF), dim3(256), 0, s, g->p4, g->off, H4,
+                       W4, g->b4c1ot, g->b4c1.ob, mo4, fs);
     dcn(g->p4, 64, g->t4, 128, H4, W4, g->b4c1t, g->b4c1.a, g->b4c1.b, nullptr, 0, nullptr, nullptr);
-    hipLaunchKernelGGL((al_offset_conv_kernel<128>), dim3(sslam::cdiv(HW4, 64), uF), dim3(256), 0, s, g->t4, g->off, H4,
-                       W4, g->b4c2.ow, g->b4c2.ob, mo4, fs);
+    if (F >= 4) hipLaunchKernelGGL((al_offset_conv_kernel<128, 4>), dim3(sslam::cdiv(HW4, 16), uF), dim3(256), 0, s, g->t4, g->off, H4,
+                       W4, g->b4c2ot, g->b4c2.ob, mo4, fs);
+    else hipLaunchKernelGGL((al_offset_conv_kernel<128, 1>), dim3(sslam::cdiv(HW4, 4), uF), dim3(256), 0, s, g->t4, g->off, H4,
+                       W4, g->b4c2ot, g->b4c2.ob, mo4, fs);
     dcn(g->t4, 128, g->x4, 128, H4, W4, g->b4c2t, g->b4c2.a, g->b4c2.b, g->p4, 64, g->b4dwt, g->b4db);
     // gates
     hipLaunchKernelGGL(al_gate_kernel, dim3(sslam::cdiv(H2 * W2, 256), uF), dim3(256), 0, s, g->x2, g->g2, 32, H2 * W2, g->gw2, g->g2cl, fs);
@@ -1654,6 +1681,7 @@ int sslam_aliked_create_batched(sslam_ctx* ctx, const float* weights, size_t n_f
         g->blob = A.take<float>(n_floats);
         g->b3c1t = A.take<float>(288 * 64); g->b3c2t = A.take<float>(576 * 64); g->b4c1t = A.take<float>(576 * 128);
         g->b4c2t = A.take<float>(1152 * 128); g->b3dwt = A.take<float>(32 * 64); g->b4dwt = A.take<float>(64 * 128);
+        g->b3c1ot = A.take<float>(288 * 18); g->b3c2ot = A.take<float>(576 * 18); g->b4c1ot = A.take<float>(576 * 18); g->b4c2ot = A.take<float>(1152 * 18);
         g->gk = A.take<float>(64);
     };
     // one workspace block per frame of a batch (frame f's copy of a buffer = frame 0's + f * g->fs bytes)
@@ -1712,6 +1740,11 @@ int sslam_aliked_create_batched(sslam_ctx* ctx, const float* weights, size_t n_f
         tr(g->b3c1.w, g->b3c1t, 32, 9, 64); tr(g->b3c2.w, g->b3c2t, 64, 9, 64);
         tr(g->b4c1.w, g->b4c1t, 64, 9, 128); tr(g->b4c2.w, g->b4c2t, 128, 9, 128);
         tr(g->b3dw, g->b3dwt, 32, 1, 64); tr(g->b4dw, g->b4dwt, 64, 1, 128);
+        auto tro = [&](const float* src, float* dst, int K) {      // [k][18] -> [18][k]
+            hipLaunchKernelGGL(al_transpose_kernel, dim3(sslam::cdiv(K * 18, 256)), dim3(256), 0, s, src, dst, K, 18);
+        };
+        tro(g->b3c1.ow, g->b3c1ot, 288); tro(g->b3c2.ow, g->b3c2ot, 576); tro(g->b4c1.ow, g->b4c1ot, 576);
+        tro(g->b4c2.ow, g->b4c2ot, 1152);
         SSLAM_HIP_CHECK(hipStreamSynchronize(s));
     }
     SSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)al_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
