@@ -672,6 +672,9 @@ __device__ __forceinline__ float up_eval(const float* __restrict__ p, const UpTa
 // (neighbours clamped at the border, where their tap weight is exactly zero).  One thread per level pixel, all three levels
 // of a frame in one launch; reads the planar levels.
 constexpr int AGG_PRE = 13;
+#ifndef AL_PRE_UNROLL
+#define AL_PRE_UNROLL 16       // channels per round of loads: 64 loads in flight per thread (the kernel is one memory latency per round)
+#endif
 __global__ __launch_bounds__(256) void al_agg_pre_kernel(const float* __restrict__ g2cl /* planar [32][pixels] */, const float* __restrict__ g3cl,
                                                          const float* __restrict__ g4cl, const float* __restrict__ ws0 /*[128][8]*/,
                                                          float* __restrict__ pre2, float* __restrict__ pre3, float* __restrict__ pre4,
@@ -693,7 +696,7 @@ __global__ __launch_bounds__(256) void al_agg_pre_kernel(const float* __restrict
     const float* w = ws0 + lvl * 32 * 8;
     // planar reads: lane = pixel, so one load instruction is 256 contiguous bytes per channel (the channel-last copies
     // would make every lane fetch its own 128-byte line: 22 us per frame measured, this form ~3)
-#pragma unroll 8
+#pragma unroll AL_PRE_UNROLL
     for (int c = 0; c < 32; ++c) {
         const float* gc = g + (size_t)c * n;
         const float av = gc[ia], bv = gc[ib], cv = gc[ic], dv = gc[id];
