@@ -673,7 +673,7 @@ __device__ __forceinline__ float up_eval(const float* __restrict__ p, const UpTa
 // of a frame in one launch; reads the planar levels.
 constexpr int AGG_PRE = 13;
 #ifndef AL_PRE_UNROLL
-#define AL_PRE_UNROLL 16       // channels per round of loads: 64 loads in flight per thread (the kernel is one memory latency per round)
+#define AL_PRE_UNROLL 32       // all 128 loads of a thread in flight at once: 5.4 us per frame (rounds of 8 / 16 channels: 11.3 / 18.5 - a memory latency per round)
 #endif
 __global__ __launch_bounds__(256) void al_agg_pre_kernel(const float* __restrict__ g2cl /* planar [32][pixels] */, const float* __restrict__ g3cl,
                                                          const float* __restrict__ g4cl, const float* __restrict__ ws0 /*[128][8]*/,
@@ -726,8 +726,8 @@ __device__ __forceinline__ void agg_level(const float* __restrict__ pre, int n, 
 
 // (r03: the kernel is latency-bound - waves parked 65 % of their cycles, SQ counters - so the level loops carry four
 //  channels = 16 gathers in flight per iteration: 49 -> 40 us per frame; eight: the weights start to spill to v_readlane)
-#ifndef AL_AGG_UNROLL
-#define AL_AGG_UNROLL 4
+#ifndef AL_AGG1_UNROLL
+#define AL_AGG1_UNROLL 2
 #endif
 __global__ __launch_bounds__(256) void al_aggregate_kernel(Pyr P0, const float* __restrict__ ws0 /*[128][8]*/,
                                                            float* __restrict__ s8, float* __restrict__ rnorm, size_t fs) {
@@ -746,9 +746,9 @@ __global__ __launch_bounds__(256) void al_aggregate_kernel(Pyr P0, const float* 
 #pragma unroll
     for (int o = 0; o < 8; ++o) s[o] = 0.0f;
     float n2 = 0.0f;
-    // channel loops stay rolled (2 channels per iteration): fully unrolled, their ~1500 wave-uniform
+    // channel loops stay rolled (AL_AGG1_UNROLL channels per iteration): fully unrolled, their wave-uniform
     // weights overflow the SGPR file and return through v_readlane
-#pragma unroll 2
+#pragma unroll AL_AGG1_UNROLL
     for (int c = 0; c < 32; ++c) {
         float a = 0.0f;
 #pragma unroll
