@@ -73,7 +73,7 @@ EARLY_STOP_MATCH_BIAS = float(os.environ.get("SSLAM_BENCH_MATCH_BIAS", -4.6))
 
 def _pmc_traffic():
     """Per-launch HBM-side bytes of the attention kernel at the bench size, from profiles/ (None when absent)."""
-    for name in ("r03_attention_traffic.json", "r02final_attention_traffic.json", "r02_attention_traffic.json", "r01_attention_traffic.json"):
+    for name in ("r04_attention_traffic.json", "r03_attention_traffic.json", "r02final_attention_traffic.json", "r02_attention_traffic.json", "r01_attention_traffic.json"):
         try:
             d = json.loads((ROOT / "profiles" / name).read_text())
             return int(d["fetch_bytes_per_launch"]) + int(d["write_bytes_per_launch"]), name
