@@ -448,12 +448,16 @@ __global__ __launch_bounds__(1024) void rs_compact_kernel(RSArgs a) {
 
 // the sample loop + finish + mask (shared by the two entries)
 void rs_enqueue(hipStream_t s, RSArgs a, int max_iters) {
-    // the sample loop in chunks: a chunk whose first sample lies beyond the (shrinking) budget is a
-    // handful of early-exit launches, so a typical call costs two or three chunks, not max_iters
-    constexpr int CHUNK = 128;
+    // the sample loop in chunks: a chunk whose first sample lies beyond the (shrinking) budget is a handful of early-exit
+    // launches.  The sample stream is replayed by ONE lane (cv::RNG is sequential: ~1.4 us per 7-point sample), so the first
+    // chunk is small - with the inlier ratios a matcher's output has, OpenCV's budget drops below 16 after the first good
+    // model and the 128-sample first chunk of r03 spent 180 us drawing samples the loop never looks at (r04: a call on ~600
+    // matches 324 -> ~90 us of GPU time) - and the rest are few and large: the result does not depend on the chunking.
+    const int bounds[] = {0, 16, 128, 512, max_iters};
     (void)hipGetLastError();     // (a stale error of another library on this thread is not ours)
-    for (int h0 = 0; h0 < max_iters; h0 += CHUNK) {
-        a.h0 = h0; a.h1 = std::min(h0 + CHUNK, max_iters);
+    for (int ci = 0; ci < 4; ++ci) {
+        a.h0 = std::min(bounds[ci], max_iters); a.h1 = std::min(bounds[ci + 1], max_iters);
+        if (a.h1 <= a.h0) continue;
         hipLaunchKernelGGL(rs_subsets_kernel, dim3(1), dim3(64), 0, s, a);
         hipLaunchKernelGGL(rs_models_kernel, dim3(sslam::cdiv(a.h1 - a.h0, 64)), dim3(64), 0, s, a);
         hipLaunchKernelGGL(rs_score_kernel, dim3(a.h1 - a.h0, 3), dim3(RS_T), 0, s, a);
