@@ -43,6 +43,11 @@ WEIGHTED = int(os.environ.get("ATTN_ASM_WEIGHTED", "0"))     # 1: spread the VAL
 # {lifetime, tile-barrier wait, fragment wait at ODD, fragment wait at EVEN, stamp-pair overhead, tiles} (cycles) to the
 # buffer whose address sits at kernel-argument offset 96
 STAMP = os.environ.get("ATTN_ASM_STAMP", "0") == "1"
+# r04 timing experiment (never the product; build.py strips ATTN_ASM_* from the environment): P as ONE fp16 plane - the four
+# V^T.hi x P.lo MFMAs of a sub-step and the two fma_mix per element pair that form P.lo are not issued (20 MFMAs per sub-step
+# instead of 24).  The row sums stay fp32 sums of the unrounded weights here, so the results are NOT the study's P-one-plane
+# form (profiles/r04_split_study.md) - only its instruction stream, for the time it would take.
+P1 = os.environ.get("ATTN_ASM_P1", "0") == "1"
 
 out = []
 def e(s=""):
@@ -140,9 +145,10 @@ def mfma_pv():
         m += [f"{MFMA} {v(O1A, 16)}, {vh0}, {ph}, {v(O1A, 16)}",
               f"{MFMA} {v(O1B, 16)}, {vh1}, {ph}, {v(O1B, 16)}",
               f"{MFMA} {v(O2A, 16)}, {vl0}, {ph}, {v(O2A, 16)}",
-              f"{MFMA} {v(O2B, 16)}, {vl1}, {ph}, {v(O2B, 16)}",
-              f"{MFMA} {v(O1A, 16)}, {vh0}, {pl}, {v(O1A, 16)}",
-              f"{MFMA} {v(O1B, 16)}, {vh1}, {pl}, {v(O1B, 16)}"]
+              f"{MFMA} {v(O2B, 16)}, {vl1}, {ph}, {v(O2B, 16)}"]
+        if not P1:
+            m += [f"{MFMA} {v(O1A, 16)}, {vh0}, {pl}, {v(O1A, 16)}",
+                  f"{MFMA} {v(O1B, 16)}, {vh1}, {pl}, {v(O1B, 16)}"]
     return m
 
 def mfma_qk():
@@ -221,6 +227,8 @@ def softmax_split(pair):
     """hi = fp16(p) packed, lo = fp16(p - hi) (one fma_mix each): P fragment registers."""
     r0, r1 = SV + 2 * pair, SV + 2 * pair + 1
     hreg, lreg = PH + pair, PL + pair          # element pair r -> word r of (ph[0], ph[1])
+    if P1:
+        return [f"v_cvt_pk_f16_f32 {v(hreg)}, {v(r0)}, {v(r1)}"]
     return [f"v_cvt_pk_f16_f32 {v(hreg)}, {v(r0)}, {v(r1)}",
             f"v_fma_mixlo_f16 {v(lreg)}, {v(hreg)}, -1.0, {v(r0)} op_sel_hi:[1,0,0]",
             f"v_fma_mixhi_f16 {v(lreg)}, {v(hreg)}, -1.0, {v(r1)} op_sel:[1,0,0] op_sel_hi:[1,0,0]"]
