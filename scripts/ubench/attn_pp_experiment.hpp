@@ -174,7 +174,7 @@ __global__ __launch_bounds__(512) void lg_attention_pp_kernel(AttnArgsH p) {
     auto vseg_softmax = [&](auto mask_c, int kbase) {
         constexpr bool MASK = decltype(mask_c)::value;
         float alpha; bool rescale;
-        SOFTMAX_STEP<MASK>(s1, s2, kbase, nk, lane, m_run, l_run, ph, pl, alpha, rescale, qvalid);
+        SOFTMAX_STEP<MASK>(s1, s2, kbase, nk, lane, m_run, l_run, ph, pl, alpha, rescale, qvalid, false);
         ATTN_PIN_USE(ph, pl, l_run);
         if (rescale) { o1a *= alpha; o2a *= alpha; o1b *= alpha; o2b *= alpha; }
     };
