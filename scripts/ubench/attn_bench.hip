@@ -11,7 +11,7 @@
 #include <cstring>
 #include <vector>
 #include <algorithm>
-namespace sslam { void set_error(const char*, ...) {} }
+namespace sslam { void set_error(const char*, ...) {} void ctx_retain(sslam_ctx*) {} void ctx_release(sslam_ctx*) {} }
 extern "C" const unsigned char sslam_lg_attention_asm_hsaco[1] = {0};      // (the product embeds the code object; here it is loaded from a file)
 
 // the hand-scheduled kernel (opencv-simpleslam_amd/csrc/gen_lg_attention_asm.py): loaded from the code object named by ATTN_HSACO
