@@ -18,6 +18,7 @@
 //   score [h][w]         un-padded score map     nms [h][w]
 #include "common.hpp"
 #include "gemm_f32.hpp"
+#include "gemm_f16x3.hpp"
 
 namespace {
 
@@ -1308,7 +1309,8 @@ __global__ void al_offsets_kernel(const float* __restrict__ h32 /*[KSPLIT][cap][
 // the 16 positions of each keypoint -> sampled[n*16 + p][128]; one wave per (keypoint, position)
 __global__ __launch_bounds__(256) void al_sample_kernel(Pyr P0, const float* __restrict__ rnorm, int pl, int pt,
                                                         int h, int w, const float* __restrict__ pos,
-                                                        float* __restrict__ sampled, const ALCtrl* __restrict__ ctrl, size_t fs) {
+                                                        _Float16* __restrict__ sampled /* hi plane [rows][128]; lo plane `lo_off` halves behind */,
+                                                        size_t lo_off, const ALCtrl* __restrict__ ctrl, size_t fs) {
     const Pyr P = pyr_at(P0, blockIdx.y, fs);
     rnorm = fsh(rnorm, blockIdx.y, fs); pos = fsh(pos, blockIdx.y, fs); sampled = fsh(sampled, blockIdx.y, fs); ctrl = fsh(ctrl, blockIdx.y, fs);
     const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1334,8 +1336,14 @@ __global__ __launch_bounds__(256) void al_sample_kernel(Pyr P0, const float* __r
     for (int q = 0; q < 4; ++q) { ax = fmaf(f[q].x, wgt[q], ax); bx = fmaf(f[q].y, wgt[q], bx); }
     const int c = lane & 31;
     const int ca = lane < 32 ? c : 32 + c, cb = lane < 32 ? 64 + c : 96 + c;
-    sampled[(size_t)gw * 128 + ca] = ax;
-    sampled[(size_t)gw * 128 + cb] = bx;
+    // r04: the sampled features feed the split-precision GEMM (gemm_f16x3.hpp) - written as its (hi, lo) fp16 planes
+    // (same bytes as the fp32 row they replace)
+    unsigned h2, l2; float amax = 0.0f;
+    sslam::split2_fast(ax, bx, h2, l2, amax);
+    const _Float16 hv[2] = {__builtin_bit_cast(sslam::half2v, h2)[0], __builtin_bit_cast(sslam::half2v, h2)[1]};
+    const _Float16 lv[2] = {__builtin_bit_cast(sslam::half2v, l2)[0], __builtin_bit_cast(sslam::half2v, l2)[1]};
+    sampled[(size_t)gw * 128 + ca] = hv[0]; sampled[(size_t)gw * 128 + cb] = hv[1];
+    sampled[lo_off + (size_t)gw * 128 + ca] = lv[0]; sampled[lo_off + (size_t)gw * 128 + cb] = lv[1];
 }
 
 // generic row GEMM for the descriptor head: C[M][N] = act(A[M][K] W[N][K]^T + bias)
@@ -1372,6 +1380,63 @@ __global__ __launch_bounds__(256) void al_gemm_kernel(const float* __restrict__ 
                 if (row < M && col < N) C[(size_t)row * N + col] = v;
             }
         }
+}
+
+// r04: the two large GEMMs of the descriptor head (sf_conv 128 -> 128 over 16 sample rows per keypoint, and the
+// aggregation, K = 2048) on the split-precision matrix path (gemm_f16x3.hpp: operands as fp16 (hi, lo) planes, three
+// v_mfma_f32_32x32x16_f16 per product into two fp32 accumulators, ~2^-22 relative per product) instead of the exact-fp32
+// MFMA (1/16 of the f16 rate): their fp32 main loops ran at 46 % of a 157 TFLOP/s ceiling.  A planes row-major
+// [rows][K] (lo plane `a_lo` halves behind hi), W planes [N][K] split once at create time.  SPLIT_OUT: SELU, then the
+// output goes out as the NEXT GEMM's A planes ([rows][N] == [keypoints][16 N]); else fp32 slabs per k slice.
+template <int BM, int BN, int TM, int TN, bool SPLIT_OUT>
+__global__ __launch_bounds__(256) void al_gemm_h_kernel(const _Float16* __restrict__ A, size_t a_lo, int K,
+                                                        const _Float16* __restrict__ W, size_t w_lo, int N,
+                                                        float* __restrict__ C, _Float16* __restrict__ Ch, size_t c_lo,
+                                                        int rows_per_kp, int row_cap, const ALCtrl* __restrict__ ctrl, int KS,
+                                                        size_t fs) {
+    __shared__ sslam::GemmSmemH<BM, BN> sm;
+    const int zs = blockIdx.z % KS, fr = blockIdx.z / KS;
+    A = fsh(A, fr, fs); C = fsh(C, fr, fs); Ch = fsh(Ch, fr, fs); ctrl = fsh(ctrl, fr, fs);
+    const int M = ctrl->n_kp * rows_per_kp;
+    const int row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
+    if (row0 >= M) return;
+    const int kper = K / KS, koff = zs * kper;
+    sslam::GemmAH ga{{A + koff, A + a_lo + koff}, {A + koff, A + a_lo + koff}, K, kper};
+    f32x16 c1[TM][TN], c2[TM][TN];
+    sslam::gemm_mainloop_h<BM, BN, TM, TN>(ga, sslam::SplitPtr{W + koff, W + w_lo + koff}, K, kper, row0, row_cap, col0, N, sm, c1, c2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+    if constexpr (!SPLIT_OUT) C += (size_t)zs * row_cap * N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = col0 + wn * 32 * TN + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wm * 32 * TM + i * 32 + acc_row(r, lane);
+                float v = c1[i][j][r] + c2[i][j][r] * sslam::SPLIT_INV;
+                if (row >= M || col >= N) continue;
+                if constexpr (SPLIT_OUT) {
+                    v = selu(v);
+                    const float aa = fabsf(v);
+                    const _Float16 hi = aa < 6.103515625e-5f ? (_Float16)0.0f : (_Float16)v;      // (as sslam::split_f32; |v| is O(1) here)
+                    Ch[(size_t)row * N + col] = hi;
+                    Ch[c_lo + (size_t)row * N + col] = (_Float16)((v - (float)hi) * sslam::SPLIT_SCALE);
+                } else {
+                    C[(size_t)row * N + col] = v;
+                }
+            }
+        }
+}
+
+// fp32 [n] -> (hi, lo) planes (weights of the split GEMMs, once at create time)
+__global__ void al_split_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = src[i];
+    const _Float16 hi = fabsf(v) < 6.103515625e-5f ? (_Float16)0.0f : (_Float16)v;
+    dst[i] = hi;
+    dst[n + i] = (_Float16)((v - (float)hi) * sslam::SPLIT_SCALE);
 }
 
 // L2 normalise (F.normalize), the reference's second normalisation (features_utils.py:100),
@@ -1449,6 +1514,7 @@ struct sslam_aliked {
     int* kp_index;
     unsigned long long* sel_keys;      // the selected keys, unordered (al_select -> al_refine)
     float *kp_norm, *kp_score, *patch, *h32, *pos, *sampled, *feats, *raw;
+    _Float16 *d_sf_s, *d_agg_s;          // split (hi | lo) copies of the two large descriptor-head weight matrices
     float *out_xy, *out_desc, *out_score;
     int32_t* out_n;
     Dims last{};
@@ -1638,12 +1704,16 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
     const float mo = (float)(d.h > d.w ? d.h : d.w) / 4.0f;
     hipLaunchKernelGGL(al_offsets_kernel, dim3(sslam::cdiv(NK * 32, 256), uF), dim3(256), 0, s, g->h32, NK, g->d_ob, g->d_w2, g->d_b2,
                        g->kp_norm, d.h, d.w, mo, g->pos, g->ctrl, fs);
+    // (r04: `sampled` and `feats` hold the (hi, lo) fp16 planes of [rows][128] - the same bytes as the fp32 rows they replaced)
+    const size_t plane = (size_t)(NK * 16 + 64) * 128;
+    _Float16* sampled_h = reinterpret_cast<_Float16*>(g->sampled);
+    _Float16* feats_h = reinterpret_cast<_Float16*>(g->feats);
     hipLaunchKernelGGL(al_sample_kernel, dim3(sslam::cdiv(NK * 16, 4), uF), dim3(256), 0, s, P, g->rnorm, d.pl, d.pt, d.h,
-                       d.w, g->pos, g->sampled, g->ctrl, fs);
-    hipLaunchKernelGGL((al_gemm_kernel<64, 128, 1, 2>), dim3(1, sslam::cdiv(NK * 16, 64), uF), dim3(256), 0, s, g->sampled,
-                       128, g->d_sf, nullptr, 128, g->feats, 16, NK * 16, 1, g->ctrl, 1, fs);
-    hipLaunchKernelGGL((al_gemm_kernel<64, 64, 1, 1>), dim3(2, sslam::cdiv(NK, 64), SDDH_KSPLIT * uF), dim3(256), 0, s, g->feats,
-                       2048, g->d_agg, nullptr, 128, g->raw, 1, NK, 0, g->ctrl, SDDH_KSPLIT, fs);
+                       d.w, g->pos, sampled_h, plane, g->ctrl, fs);
+    hipLaunchKernelGGL((al_gemm_h_kernel<64, 128, 1, 2, true>), dim3(1, sslam::cdiv(NK * 16, 64), uF), dim3(256), 0, s, sampled_h, plane,
+                       128, g->d_sf_s, (size_t)128 * 128, 128, nullptr, feats_h, plane, 16, NK * 16, g->ctrl, 1, fs);
+    hipLaunchKernelGGL((al_gemm_h_kernel<64, 64, 1, 1, false>), dim3(2, sslam::cdiv(NK, 64), SDDH_KSPLIT * uF), dim3(256), 0, s, feats_h,
+                       plane, 2048, g->d_agg_s, (size_t)128 * 2048, 128, g->raw, nullptr, 0, 1, NK, g->ctrl, SDDH_KSPLIT, fs);
     const float scale_x = (float)d.w / (float)W, scale_y = (float)d.h / (float)H;
     hipLaunchKernelGGL(al_finalize_kernel, dim3(sslam::cdiv(NK, 4), uF), dim3(256), 0, s, g->raw, NK, g->kp_norm, g->kp_score,
                        d.h, d.w, scale_x, scale_y, outs, g->ctrl, fs);
@@ -1684,6 +1754,7 @@ int sslam_aliked_create_batched(sslam_ctx* ctx, const float* weights, size_t n_f
         g->blob = A.take<float>(n_floats);
         g->b3c1t = A.take<float>(288 * 64); g->b3c2t = A.take<float>(576 * 64); g->b4c1t = A.take<float>(576 * 128);
         g->b4c2t = A.take<float>(1152 * 128); g->b3dwt = A.take<float>(32 * 64); g->b4dwt = A.take<float>(64 * 128);
+        g->d_sf_s = A.take<_Float16>(2 * 128 * 128); g->d_agg_s = A.take<_Float16>((size_t)2 * 128 * 2048);
         g->b3c1ot = A.take<float>(288 * 18); g->b3c2ot = A.take<float>(576 * 18); g->b4c1ot = A.take<float>(576 * 18); g->b4c2ot = A.take<float>(1152 * 18);
         g->gk = A.take<float>(64);
     };
@@ -1743,6 +1814,8 @@ int sslam_aliked_create_batched(sslam_ctx* ctx, const float* weights, size_t n_f
         tr(g->b3c1.w, g->b3c1t, 32, 9, 64); tr(g->b3c2.w, g->b3c2t, 64, 9, 64);
         tr(g->b4c1.w, g->b4c1t, 64, 9, 128); tr(g->b4c2.w, g->b4c2t, 128, 9, 128);
         tr(g->b3dw, g->b3dwt, 32, 1, 64); tr(g->b4dw, g->b4dwt, 64, 1, 128);
+        hipLaunchKernelGGL(al_split_kernel, dim3(sslam::cdiv(128 * 128, 256)), dim3(256), 0, s, g->d_sf, g->d_sf_s, (size_t)128 * 128);
+        hipLaunchKernelGGL(al_split_kernel, dim3(sslam::cdiv(128 * 2048, 256)), dim3(256), 0, s, g->d_agg, g->d_agg_s, (size_t)128 * 2048);
         auto tro = [&](const float* src, float* dst, int K) {      // [k][18] -> [18][k]
             hipLaunchKernelGGL(al_transpose_kernel, dim3(sslam::cdiv(K * 18, 256)), dim3(256), 0, s, src, dst, K, 18);
         };
