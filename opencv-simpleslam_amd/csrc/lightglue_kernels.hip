@@ -34,7 +34,6 @@
 #include "gemm_f16x3.hpp"
 #include "gemm_f16x3_big.hpp"
 #include "ffn_fused.hpp"
-#include "ffn_fused4.hpp"
 
 namespace {
 
@@ -1321,21 +1320,6 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_fused_kernel(FfnKArgs p) {
     sslam::ffn_fused_tile<TT>(f, ibase + row0, ibase + p.Kc, min(TOK, n - row0), range_flag_of(p.ctrl, img), lg_ring);
 }
 
-// r04: the same FFN as 32-token tiles on four waves, 75 KB of LDS: two workgroups per CU (ffn_fused4.hpp)
-__global__ __launch_bounds__(256, 2) void lg_ffn_fused4_kernel(FfnKArgs p) {
-    extern __shared__ __attribute__((aligned(16))) _Float16 lg_ring[];
-    constexpr int TOK = sslam::FFN4_TOK;
-    const int nb = p.Kc / TOK;
-    const int img = blockIdx.x / nb, row0 = (blockIdx.x % nb) * TOK;
-    const LGCtrl& pc = ctrl_of(p.ctrl, img);
-    if (pc.stop) return;
-    const int n = pc.n[img & 1];
-    if (row0 >= n) return;
-    const int ibase = img * p.Kc;
-    sslam::FfnFusedArgs f = p.f;
-    f.unconf = &const_cast<LGCtrl*>(p.ctrl)[img >> 1].unconf;
-    sslam::ffn_fused_tile4(f, ibase + row0, ibase + p.Kc, min(TOK, n - row0), range_flag_of(p.ctrl, img), lg_ring);
-}
 
 // W1 [512][512] / W2 [256][512] (row-major fp32) -> split planes in the fragment order the fused FFN streams
 __global__ void lg_pack_ffn_kernel(const float* __restrict__ w1, const float* __restrict__ w2, _Float16* __restrict__ w1f,
@@ -2079,9 +2063,7 @@ bool lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, in
             }
             k.ctrl = g->ctrl; k.Kc = g->Kc;
             const bool small_tiles = g->big_gemm == 3 || (g->big_gemm != 2 && NI * (g->Kc / 64) <= 128);
-            if (g->big_gemm == 6)                  // (A/B hook: 32-token tiles on four waves, two workgroups per CU)
-                hipLaunchKernelGGL(lg_ffn_fused4_kernel, dim3(NI * (g->Kc / 32)), dim3(256), sslam::FFN4_LDS_BYTES, s, k);
-            else if (small_tiles)                       // too few 64-token tiles for the chip: 32-token tiles (same results)
+            if (small_tiles)                       // too few 64-token tiles for the chip: 32-token tiles (same results)
                 hipLaunchKernelGGL(lg_ffn_fused_kernel<1>, dim3(NI * (g->Kc / 32)), dim3(512), sslam::FFN_LDS_BYTES, s, k);
             else
                 hipLaunchKernelGGL(lg_ffn_fused_kernel<2>, dim3(NI * (g->Kc / 64)), dim3(512), sslam::FFN_LDS_BYTES, s, k);
@@ -2243,7 +2225,6 @@ void lg_configure_kernels() {
     launch_linear_h<64, 128, 1, 2, EPH_F32>(s, 0, cfg);   launch_linear_h<64, 64, 1, 1, EPH_RESID>(s, 0, cfg);
     launch_linear_h<64, 192, 1, 3, EPH_QKV>(s, 0, cfg);   launch_linear_h<64, 128, 1, 2, EPH_CROSS>(s, 0, cfg);
     launch_linear_big<128, 128, 2, 2, EPH_QKV>(s, 0, cfg); launch_linear_big<128, 128, 2, 2, EPH_CROSS>(s, 0, cfg);
-    (void)hipFuncSetAttribute((const void*)lg_ffn_fused4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, sslam::FFN4_LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)lg_ffn_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, sslam::FFN_LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)lg_ffn_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, sslam::FFN_LDS_BYTES);
 }
@@ -2577,7 +2558,7 @@ int sslam_lightglue_debug_key_split(sslam_lightglue* g, int ks) {
 /* Test hook: -1 = linears chosen by batch size, 0 = always the 64-row ring kernels (single-pair form), 1 = always
  * the batched form (128 x 128 projections + the fused FFN kernel). */
 int sslam_lightglue_debug_big_gemm(sslam_lightglue* g, int mode) {
-    SSLAM_REQUIRE(g != nullptr && mode >= -1 && mode <= 6 && mode != 4, "sslam_lightglue_debug_big_gemm: bad argument");
+    SSLAM_REQUIRE(g != nullptr && mode >= -1 && mode <= 5 && mode != 4, "sslam_lightglue_debug_big_gemm: bad argument");
     g->settings_changed();
     g->big_gemm = mode;
     return 0;

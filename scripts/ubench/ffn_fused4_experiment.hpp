@@ -1,4 +1,6 @@
-// ffn_fused4.hpp - the fused FFN (ffn_fused.hpp) as 32-token tiles on FOUR waves with a compact LDS image, so that TWO
+// ffn_fused4_experiment.hpp (r04, NOT part of the product: measured slower, see below; it was wired into
+// csrc/lightglue_kernels.hip as lg_ffn_fused4_kernel / debug_big_gemm(lg, 6) at commit a862be4, scripts/ubench/ffn4_check.py and
+// ab_ffn4.sh ran against that build) - the fused FFN (ffn_fused.hpp) as 32-token tiles on FOUR waves with a compact LDS image, so that TWO
 // workgroups share a CU (r04).
 //
 // The 64-token / 8-wave kernel keeps one workgroup per CU (135 KB of LDS, 230 registers x 2 waves per SIMD): its matrix
@@ -8,7 +10,12 @@
 // of one 8-wave wave on 64 tokens - and needs 75 KB of LDS: two workgroups per CU, one's LayerNorm / GELU under the other's
 // MFMAs.  Price: every weight byte crosses L2 -> CU once per 32 tokens instead of once per 64.
 // Arithmetic, fragment layouts of W1 / W2 and every summation order are those of ffn_fused_tile (the LayerNorm partial sums
-// stay per 64-column slot and are added in the same tree): results are bit-identical, tested.
+// stay per 64-column slot and are added in the same tree): results are bit-identical, tested (matches, scores, token states,
+// early stop and pruning on ragged batches: ffn4_check.py).
+// MEASURED (8 pairs of 2048 x 2048 per launch, kernel trace, one box): 99.2 us against 91 - 93 us for the 64-token / 8-wave kernel;
+// deeper weight rings spill (FFN4_D2 = 8: 113 us, FFN4_D1 = 4: 178 us).  Two co-resident half-size workgroups do overlap their
+// vector and matrix phases, but every workgroup streams all 1.5 MB of W1 + W2 through the CU for 32 tokens: the doubled weight
+// stream costs more than the overlap returns.  VERDICT r03 item 6, option 1: closed by measurement.
 #pragma once
 #include "ffn_fused.hpp"
 
