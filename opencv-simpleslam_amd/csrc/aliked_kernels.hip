@@ -157,7 +157,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef AL_CONV_UNROLL
 #define AL_CONV_UNROLL 8
 #endif
-template <int CIN, int COUT, int POOL, bool DOWN, bool RESID, int RPW>
+template <int CIN, int COUT, int POOL, bool DOWN, bool RESID, int RPW, bool CLOUT = false>
 __global__ __launch_bounds__(256) void al_conv3x3_mfma_kernel(
     const float* __restrict__ in, int inH, int inW, float* __restrict__ out, int H, int W,
     const float* __restrict__ w /*[ci][tap][COUT]*/, const float* __restrict__ alpha, const float* __restrict__ beta,
@@ -347,6 +347,30 @@ __global__ __launch_bounds__(256) void al_conv3x3_mfma_kernel(
         for (int q = 0; q < RPW; ++q) {
             const int y = y0 + RPW * wave + q;
             if (y >= H) continue;
+            if constexpr (CLOUT) {
+                // r04: the only consumer of this map (block2.conv2, al_conv32_h_kernel) runs on the split-precision matrix
+                // path: the output leaves channel-last as fp16 (hi, lo) planes [H][W][32] (the bytes of the planar fp32 map);
+                // a lane holds four consecutive channels per register quad: 8-byte pieces
+                _Float16* oh = reinterpret_cast<_Float16*>(out);
+                const size_t plane = (size_t)H * W * 32;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float vv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g4 + e, co = acc_row(r, lane);
+                        vv[e] = selu(fmaf(acc[q][r], alpha[co], beta[co]));
+                        if (DOWN) idn[((size_t)co * H + y) * W + x] = dn[q][r] + bd[co];
+                    }
+                    unsigned h01, l01, h23, l23; float amax = 0.0f;
+                    sslam::split2_fast(vv[0], vv[1], h01, l01, amax);
+                    sslam::split2_fast(vv[2], vv[3], h23, l23, amax);
+                    const size_t o = ((size_t)y * W + x) * 32 + 8 * g4 + 4 * (lane >> 5);
+                    *reinterpret_cast<uint2*>(oh + o) = make_uint2(h01, h23);
+                    *reinterpret_cast<uint2*>(oh + plane + o) = make_uint2(l01, l23);
+                }
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = acc_row(r, lane);
@@ -359,6 +383,92 @@ __global__ __launch_bounds__(256) void al_conv3x3_mfma_kernel(
                 out[o] = selu(v);
                 if (DOWN) idn[o] = dn[q][r] + bd[co];
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------ //
+//  1b. block2.conv2 (32 -> 32 at 1/2 resolution, + BN + residual + SELU) on the SPLIT-PRECISION matrix path (r04).
+//      The exact-fp32 MFMA form above spent 23 of its 29 us per frame in the matrix loop (144 v_mfma_f32_32x32x2_f32 of 64
+//      cycles per 32 x 32 output tile, the fp32 matrix rate is 1/16 of the f16 rate; CONV_ABL = 1: 6 us without the loop).
+//      Here k = tap * 32 + ci runs in 18 steps of 16 on v_mfma_f32_32x32x16_f16, three per step (hi.hi, hi.lo, lo.hi:
+//      gemm_f16x3.hpp): 54 MFMAs of 32 cycles per tile.  The input arrives channel-last as fp16 (hi, lo) planes from its only
+//      producer (CLOUT above), so a B fragment - 8 consecutive channels of one tap of one pixel - is one ds_read_b128 from a
+//      tile [rows][34 px][32 ch + 8 pad] (80-byte pixel stride: conflict-free); the A fragments (weights) come from a
+//      fragment-ordered global copy [ks][plane][h][co][8] (1 KiB per wave load, L1-resident).  Accumulator layout, epilogue
+//      and output (planar fp32 x2) are those of the 32-row shape above.  Relative error per product ~2^-22.
+// ------------------------------------------------------------------------ //
+constexpr int C32_PS = 40;                          // halves per tile pixel (32 channels + 8 pad)
+__global__ void al_conv32_wfrag_kernel(const float* __restrict__ w /*[ci 32][tap 9][co 32]*/, _Float16* __restrict__ wf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // one element (co, k)
+    if (i >= 32 * 288) return;
+    const int co = i / 288, k = i % 288, tap = k / 32, ci = k % 32;
+    const float v = w[(ci * 9 + tap) * 32 + co];
+    const _Float16 hi = fabsf(v) < 6.103515625e-5f ? (_Float16)0.0f : (_Float16)v;
+    const _Float16 lo = (_Float16)((v - (float)hi) * sslam::SPLIT_SCALE);
+    const int ks = k >> 4, hh = (k >> 3) & 1, e = k & 7;
+    wf[(((ks * 2 + 0) * 2 + hh) * 32 + co) * 8 + e] = hi;
+    wf[(((ks * 2 + 1) * 2 + hh) * 32 + co) * 8 + e] = lo;
+}
+
+template <int RPW>
+__global__ __launch_bounds__(256) void al_conv32_h_kernel(const _Float16* __restrict__ in /* hi plane [H][W][32]; lo `plane` halves behind */,
+                                                          float* __restrict__ out, int H, int W, const _Float16* __restrict__ wf,
+                                                          const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                          const float* __restrict__ resid, size_t fs) {
+    in = fsh(in, blockIdx.z, fs); out = fsh(out, blockIdx.z, fs); resid = fsh(resid, blockIdx.z, fs);
+    constexpr int CTH = 4 * RPW, TH = CTH + 2, TW = CT_W + 2;
+    __shared__ __attribute__((aligned(16))) _Float16 tile[2][TH * TW * C32_PS];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CTH;
+    const size_t plane = (size_t)H * W * 32;
+    // tile fill: 16-byte chunks, (plane, row, pixel, chunk) with the chunk fastest: 64 contiguous bytes per pixel
+    constexpr int CHUNKS = 2 * TH * TW * 4;
+#pragma unroll 4
+    for (int idx = t; idx < CHUNKS; idx += 256) {
+        const int c4 = idx & 3, pxl = (idx >> 2) % TW, rr = ((idx >> 2) / TW) % TH, pl = (idx >> 2) / (TW * TH);
+        const int yy = y0 + rr - 1, xx = x0 + pxl - 1;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+            v = *reinterpret_cast<const uint4*>(in + pl * plane + ((size_t)yy * W + xx) * 32 + 8 * c4);
+        *reinterpret_cast<uint4*>(&tile[pl][(rr * TW + pxl) * C32_PS + 8 * c4]) = v;
+    }
+    __syncthreads();
+    const int h = lane >> 5, px = lane & 31;
+    f32x16 c1[RPW], c2[RPW];
+#pragma unroll
+    for (int q = 0; q < RPW; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { c1[q][r] = 0.0f; c2[q][r] = 0.0f; }
+    const _Float16* bh = &tile[0][((RPW * wave) * TW + px) * C32_PS + 8 * h];
+    const _Float16* bl = &tile[1][((RPW * wave) * TW + px) * C32_PS + 8 * h];
+    const _Float16* af = wf + (h * 32 + px) * 8;               // + ((ks * 2 + plane) * 2) * 32 * 8
+#pragma unroll
+    for (int ks = 0; ks < 18; ++ks) {
+        const int tap = ks >> 1, boff = ((tap / 3) * TW + (tap % 3)) * C32_PS + 16 * (ks & 1);
+        const sslam::half8 ah = *reinterpret_cast<const sslam::half8*>(af + (size_t)(ks * 2 + 0) * 2 * 32 * 8);
+        const sslam::half8 al = *reinterpret_cast<const sslam::half8*>(af + (size_t)(ks * 2 + 1) * 2 * 32 * 8);
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            const sslam::half8 xh = *reinterpret_cast<const sslam::half8*>(bh + boff + q * TW * C32_PS);
+            const sslam::half8 xl = *reinterpret_cast<const sslam::half8*>(bl + boff + q * TW * C32_PS);
+            c1[q] = sslam::mfma16(ah, xh, c1[q]);
+            c2[q] = sslam::mfma16(ah, xl, c2[q]);
+            c2[q] = sslam::mfma16(al, xh, c2[q]);
+        }
+    }
+    const int x = x0 + px;
+    if (x >= W) return;
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+        const int y = y0 + RPW * wave + q;
+        if (y >= H) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = acc_row(r, lane);
+            const size_t o = ((size_t)co * H + y) * W + x;
+            const float acc = c1[q][r] + c2[q][r] * sslam::SPLIT_INV;
+            out[o] = selu(fmaf(acc, alpha[co], beta[co]) + resid[o]);
         }
     }
 }
@@ -1515,6 +1625,7 @@ struct sslam_aliked {
     unsigned long long* sel_keys;      // the selected keys, unordered (al_select -> al_refine)
     float *kp_norm, *kp_score, *patch, *h32, *pos, *sampled, *feats, *raw;
     _Float16 *d_sf_s, *d_agg_s;          // split (hi | lo) copies of the two large descriptor-head weight matrices
+    _Float16* b2c2f;                     // block2.conv2 weights, split, fragment order (al_conv32_wfrag_kernel)
     float *out_xy, *out_desc, *out_score;
     int32_t* out_n;
     Dims last{};
@@ -1611,14 +1722,15 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
     // block2 at 1/2: conv1 pools on load and also emits the downsample branch
     const int H2 = Hp / 2, W2 = Wp / 2;
     dim3 g2a(sslam::cdiv(W2, CT_W), sslam::cdiv(H2, 4), uF), g2b(sslam::cdiv(W2, CT_W), sslam::cdiv(H2, 8), uF);
-    hipLaunchKernelGGL((al_conv3x3_mfma_kernel<16, 32, 2, true, false, 1>), g2a, dim3(256), 0, s, g->x1, Hp, Wp, g->t2, H2, W2,
+    // (r04: t2 leaves block2.conv1 channel-last as fp16 (hi, lo) planes - the bytes of the planar fp32 map - for the
+    //  split-precision form of block2.conv2)
+    hipLaunchKernelGGL((al_conv3x3_mfma_kernel<16, 32, 2, true, false, 1, true>), g2a, dim3(256), 0, s, g->x1, Hp, Wp, g->t2, H2, W2,
                        g->b2c1.w, g->b2c1.a, g->b2c1.b, g->b2dw, g->b2db, g->idn2, nullptr, fs);
+    const _Float16* t2h = reinterpret_cast<const _Float16*>(g->t2);
     if (F >= 2)
-        hipLaunchKernelGGL((al_conv3x3_mfma_kernel<32, 32, 1, false, true, 2>), g2b, dim3(256), 0, s, g->t2, H2, W2, g->x2, H2, W2,
-                           g->b2c2.w, g->b2c2.a, g->b2c2.b, nullptr, nullptr, nullptr, g->idn2, fs);
+        hipLaunchKernelGGL(al_conv32_h_kernel<2>, g2b, dim3(256), 0, s, t2h, g->x2, H2, W2, g->b2c2f, g->b2c2.a, g->b2c2.b, g->idn2, fs);
     else        // one frame: 320 workgroups of 8 rows leave the chip half empty - 4-row tiles (same arithmetic per output)
-        hipLaunchKernelGGL((al_conv3x3_mfma_kernel<32, 32, 1, false, true, 1>), g2a, dim3(256), 0, s, g->t2, H2, W2, g->x2, H2, W2,
-                           g->b2c2.w, g->b2c2.a, g->b2c2.b, nullptr, nullptr, nullptr, g->idn2, fs);
+        hipLaunchKernelGGL(al_conv32_h_kernel<1>, g2a, dim3(256), 0, s, t2h, g->x2, H2, W2, g->b2c2f, g->b2c2.a, g->b2c2.b, g->idn2, fs);
     // deformable conv = im2col of the bilinear samples + matrix-core GEMM (offsets in g->off)
     auto dcn = [&](const float* in, int cin, float* outp, int cout, int Hh, int Ww, const float* wt, const float* al_,
                    const float* be_, const float* res, int rc, const float* wdt, const float* bdp) {
@@ -1755,6 +1867,7 @@ int sslam_aliked_create_batched(sslam_ctx* ctx, const float* weights, size_t n_f
         g->b3c1t = A.take<float>(288 * 64); g->b3c2t = A.take<float>(576 * 64); g->b4c1t = A.take<float>(576 * 128);
         g->b4c2t = A.take<float>(1152 * 128); g->b3dwt = A.take<float>(32 * 64); g->b4dwt = A.take<float>(64 * 128);
         g->d_sf_s = A.take<_Float16>(2 * 128 * 128); g->d_agg_s = A.take<_Float16>((size_t)2 * 128 * 2048);
+        g->b2c2f = A.take<_Float16>(2 * 32 * 288);
         g->b3c1ot = A.take<float>(288 * 18); g->b3c2ot = A.take<float>(576 * 18); g->b4c1ot = A.take<float>(576 * 18); g->b4c2ot = A.take<float>(1152 * 18);
         g->gk = A.take<float>(64);
     };
@@ -1814,6 +1927,7 @@ int sslam_aliked_create_batched(sslam_ctx* ctx, const float* weights, size_t n_f
         tr(g->b3c1.w, g->b3c1t, 32, 9, 64); tr(g->b3c2.w, g->b3c2t, 64, 9, 64);
         tr(g->b4c1.w, g->b4c1t, 64, 9, 128); tr(g->b4c2.w, g->b4c2t, 128, 9, 128);
         tr(g->b3dw, g->b3dwt, 32, 1, 64); tr(g->b4dw, g->b4dwt, 64, 1, 128);
+        hipLaunchKernelGGL(al_conv32_wfrag_kernel, dim3(sslam::cdiv(32 * 288, 256)), dim3(256), 0, s, g->b2c2.w, g->b2c2f);
         hipLaunchKernelGGL(al_split_kernel, dim3(sslam::cdiv(128 * 128, 256)), dim3(256), 0, s, g->d_sf, g->d_sf_s, (size_t)128 * 128);
         hipLaunchKernelGGL(al_split_kernel, dim3(sslam::cdiv(128 * 2048, 256)), dim3(256), 0, s, g->d_agg, g->d_agg_s, (size_t)128 * 2048);
         auto tro = [&](const float* src, float* dst, int K) {      // [k][18] -> [18][k]
