@@ -399,6 +399,9 @@ __global__ __launch_bounds__(256) void al_conv3x3_mfma_kernel(
 //      and output (planar fp32 x2) are those of the 32-row shape above.  Relative error per product ~2^-22.
 // ------------------------------------------------------------------------ //
 constexpr int C32_PS = 40;                          // halves per tile pixel (32 channels + 8 pad)
+#ifndef AL_C32_FILL
+#define AL_C32_FILL 8
+#endif
 __global__ void al_conv32_wfrag_kernel(const float* __restrict__ w /*[ci 32][tap 9][co 32]*/, _Float16* __restrict__ wf) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;       // one element (co, k)
     if (i >= 32 * 288) return;
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(256) void al_conv32_h_kernel(const _Float16* __rest
     const size_t plane = (size_t)H * W * 32;
     // tile fill: 16-byte chunks, (plane, row, pixel, chunk) with the chunk fastest: 64 contiguous bytes per pixel
     constexpr int CHUNKS = 2 * TH * TW * 4;
-#pragma unroll 4
+#pragma unroll AL_C32_FILL
     for (int idx = t; idx < CHUNKS; idx += 256) {
         const int c4 = idx & 3, pxl = (idx >> 2) % TW, rr = ((idx >> 2) / TW) % TH, pl = (idx >> 2) / (TW * TH);
         const int yy = y0 + rr - 1, xx = x0 + pxl - 1;
@@ -1727,7 +1730,10 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
     hipLaunchKernelGGL((al_conv3x3_mfma_kernel<16, 32, 2, true, false, 1, true>), g2a, dim3(256), 0, s, g->x1, Hp, Wp, g->t2, H2, W2,
                        g->b2c1.w, g->b2c1.a, g->b2c1.b, g->b2dw, g->b2db, g->idn2, nullptr, fs);
     const _Float16* t2h = reinterpret_cast<const _Float16*>(g->t2);
-    if (F >= 2)
+#ifndef AL_C32_RPW
+#define AL_C32_RPW 1      // 4-row tiles for every batch size: 15.7 us per frame at F = 8 against 20.9 with 8-row tiles (more, smaller workgroups)
+#endif
+    if (F >= 2 && AL_C32_RPW == 2)
         hipLaunchKernelGGL(al_conv32_h_kernel<2>, g2b, dim3(256), 0, s, t2h, g->x2, H2, W2, g->b2c2f, g->b2c2.a, g->b2c2.b, g->idn2, fs);
     else        // one frame: 320 workgroups of 8 rows leave the chip half empty - 4-row tiles (same arithmetic per output)
         hipLaunchKernelGGL(al_conv32_h_kernel<1>, g2a, dim3(256), 0, s, t2h, g->x2, H2, W2, g->b2c2f, g->b2c2.a, g->b2c2.b, g->idn2, fs);
