@@ -583,8 +583,7 @@ __global__ __launch_bounds__(256) void al_offset_conv_kernel(const float* __rest
 // writes its partial product to slab z, the 1x1 branch to slab KS, and al_dcn_epilogue_kernel adds
 // the slabs in order (deterministic) and applies BN affine + residual + SELU.
 __global__ __launch_bounds__(256) void al_dcn_col_kernel(const float* __restrict__ in, const float* __restrict__ off,
-                                                         _Float16* __restrict__ col /* hi plane [HW][K + RC]; lo plane HW (K + RC) halves behind (r04) */,
-                                                         int CIN, int H, int W,
+                                                         float* __restrict__ col, int CIN, int H, int W,
                                                          const float* __restrict__ res_in, int RC, size_t fs) {
     in = fsh(in, blockIdx.y, fs); off = fsh(off, blockIdx.y, fs); col = fsh(col, blockIdx.y, fs); res_in = fsh(res_in, blockIdx.y, fs);
     // thread = (channel quad, tap slot, pixel), pixel fastest: the 16 gathers of a lane and of its
@@ -593,19 +592,12 @@ __global__ __launch_bounds__(256) void al_dcn_col_kernel(const float* __restrict
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= HW * slots * CQ) return;
     const int pix = i % HW, tap = (i / HW) % slots, cq = i / (HW * slots), c = 4 * cq;
-    _Float16* dst = col + (size_t)pix * KT;
-    const size_t lo_off = (size_t)HW * KT;
-    auto put4 = [&](_Float16* d, float a0, float a1, float a2, float a3) {       // four values -> (hi, lo) planes, 8 bytes each
-        unsigned h01, l01, h23, l23; float amax = 0.0f;
-        sslam::split2_fast(a0, a1, h01, l01, amax);
-        sslam::split2_fast(a2, a3, h23, l23, amax);
-        *reinterpret_cast<uint2*>(d) = make_uint2(h01, h23);
-        *reinterpret_cast<uint2*>(d + lo_off) = make_uint2(l01, l23);
-    };
+    float* dst = col + (size_t)pix * KT;
     if (tap == 9) {                                   // block input for the 1x1 branch
         if (c < RC)
-            put4(dst + K + c, res_in[(size_t)c * HW + pix], res_in[(size_t)(c + 1) * HW + pix],
-                 res_in[(size_t)(c + 2) * HW + pix], res_in[(size_t)(c + 3) * HW + pix]);
+            *reinterpret_cast<float4*>(dst + K + c) =
+                make_float4(res_in[(size_t)c * HW + pix], res_in[(size_t)(c + 1) * HW + pix],
+                            res_in[(size_t)(c + 2) * HW + pix], res_in[(size_t)(c + 3) * HW + pix]);
         return;
     }
     // torchvision deform_conv2d bilinear sample
@@ -627,41 +619,36 @@ __global__ __launch_bounds__(256) void al_dcn_col_kernel(const float* __restrict
             o[e] = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
         }
     }
-    put4(dst + tap * CIN + c, o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(dst + tap * CIN + c) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
-__global__ __launch_bounds__(256) void al_dcn_gemm_kernel(const _Float16* __restrict__ wt /* split [COUT][K]: hi, lo COUT K halves behind */, int K,
-                                                          const _Float16* __restrict__ col /* split [HW][K + RC] */, int ldc,
+__global__ __launch_bounds__(256) void al_dcn_gemm_kernel(const float* __restrict__ wt /*[COUT][K]*/, int K,
+                                                          const float* __restrict__ col /*[HW][K + RC]*/, int ldc,
                                                           int HW, int COUT, float* __restrict__ part /*[KS+1][COUT][HW]*/,
-                                                          const _Float16* __restrict__ wdt /* split [COUT][RC] */, int RC, int KS,
+                                                          const float* __restrict__ wdt /*[COUT][RC]*/, int RC, int KS,
                                                           size_t fs) {
-    // r04: on the split-precision matrix path (gemm_f16x3.hpp; the exact-fp32 MFMA loop ran at a third of a 157 TFLOP/s ceiling)
-    __shared__ sslam::GemmSmemH<64, 64> sm;
+    __shared__ GemmSmem<64, 64> sm;
     const int pix0 = blockIdx.x * 64, co0 = blockIdx.y * 64, z = blockIdx.z % KS, fr = blockIdx.z / KS;   // grid z = frame * KS + slice
     col = fsh(col, fr, fs); part = fsh(part, fr, fs);
     const int kper = K / KS, koff = z * kper;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
     const int pix = pix0 + wn * 32 + (lane & 31);
-    const size_t w_lo = (size_t)COUT * K, c_lo = (size_t)HW * ldc;
-    f32x16 c1[1][1], c2[1][1];
+    f32x16 acc[1][1];
     {
-        sslam::GemmAH ga{{wt + koff, wt + w_lo + koff}, {wt + koff, wt + w_lo + koff}, K, kper};
-        sslam::gemm_mainloop_h<64, 64, 1, 1>(ga, sslam::SplitPtr{col + koff, col + c_lo + koff}, ldc, kper, co0, COUT, pix0, HW, sm, c1, c2);
+        GemmA ga{wt + koff, K, wt + koff, K, kper};
+        gemm_mainloop<64, 64, 1, 1>(ga, col + koff, ldc, kper, co0, COUT, pix0, HW, sm, acc);
         float* dst = part + (size_t)z * COUT * HW;
         if (pix < HW)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                dst[(size_t)(co0 + wm * 32 + acc_row(r, lane)) * HW + pix] = c1[0][0][r] + c2[0][0][r] * sslam::SPLIT_INV;
+            for (int r = 0; r < 16; ++r) dst[(size_t)(co0 + wm * 32 + acc_row(r, lane)) * HW + pix] = acc[0][0][r];
     }
     if (RC && z == 0) {                               // block-uniform
-        const size_t wd_lo = (size_t)COUT * RC;
-        sslam::GemmAH gd{{wdt, wdt + wd_lo}, {wdt, wdt + wd_lo}, RC, RC};
-        sslam::gemm_mainloop_h<64, 64, 1, 1>(gd, sslam::SplitPtr{col + K, col + c_lo + K}, ldc, RC, co0, COUT, pix0, HW, sm, c1, c2);
+        GemmA gd{wdt, RC, wdt, RC, RC};
+        gemm_mainloop<64, 64, 1, 1>(gd, col + K, ldc, RC, co0, COUT, pix0, HW, sm, acc);
         float* dst = part + (size_t)KS * COUT * HW;
         if (pix < HW)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                dst[(size_t)(co0 + wm * 32 + acc_row(r, lane)) * HW + pix] = c1[0][0][r] + c2[0][0][r] * sslam::SPLIT_INV;
+            for (int r = 0; r < 16; ++r) dst[(size_t)(co0 + wm * 32 + acc_row(r, lane)) * HW + pix] = acc[0][0][r];
     }
 }
 
@@ -1642,7 +1629,6 @@ struct sslam_aliked {
     float *kp_norm, *kp_score, *patch, *h32, *pos, *sampled, *feats, *raw;
     _Float16 *d_sf_s, *d_agg_s;          // split (hi | lo) copies of the two large descriptor-head weight matrices
     _Float16* b2c2f;                     // block2.conv2 weights, split, fragment order (al_conv32_wfrag_kernel)
-    _Float16 *b3c1s, *b3c2s, *b4c1s, *b4c2s, *b3dws, *b4dws;   // split (hi | lo) copies of the [co][k] deformable-conv weights
     float *out_xy, *out_desc, *out_score;
     int32_t* out_n;
     Dims last{};
@@ -1752,12 +1738,11 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
     else        // one frame: 320 workgroups of 8 rows leave the chip half empty - 4-row tiles (same arithmetic per output)
         hipLaunchKernelGGL(al_conv32_h_kernel<1>, g2a, dim3(256), 0, s, t2h, g->x2, H2, W2, g->b2c2f, g->b2c2.a, g->b2c2.b, g->idn2, fs);
     // deformable conv = im2col of the bilinear samples + matrix-core GEMM (offsets in g->off)
-    auto dcn = [&](const float* in, int cin, float* outp, int cout, int Hh, int Ww, const _Float16* wt, const float* al_,
-                   const float* be_, const float* res, int rc, const _Float16* wdt, const float* bdp) {
-        _Float16* dcol = reinterpret_cast<_Float16*>(g->dcol);          // (hi, lo) planes of [HW][K + rc] in the fp32 buffer's bytes
+    auto dcn = [&](const float* in, int cin, float* outp, int cout, int Hh, int Ww, const float* wt, const float* al_,
+                   const float* be_, const float* res, int rc, const float* wdt, const float* bdp) {
         const int K = cin * 9, KT = K + rc, HWl = Hh * Ww, slots = rc ? 10 : 9;
         hipLaunchKernelGGL(al_dcn_col_kernel, dim3(sslam::cdiv(HWl * slots * (cin / 4), 256), uF), dim3(256), 0, s, in, g->off,
-                           dcol, cin, Hh, Ww, res, rc, fs);
+                           g->dcol, cin, Hh, Ww, res, rc, fs);
         // split K so that ONE frame's grid fills the chip: the largest divisor of the k-tile count that keeps it
         // within ~1 workgroup per CU.  (Not re-derived for a batch: the slice count fixes the summation order, and
         // a frame's result must not depend on how many frames travel with it.)
@@ -1765,7 +1750,7 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
         int ks = 1;
         for (int d_ = 1; d_ <= tiles && d_ <= DCN_KS_MAX; ++d_)
             if (tiles % d_ == 0 && base * d_ <= 288) ks = d_;
-        hipLaunchKernelGGL(al_dcn_gemm_kernel, dim3(sslam::cdiv(HWl, 64), cout / 64, ks * uF), dim3(256), 0, s, wt, K, dcol, KT,
+        hipLaunchKernelGGL(al_dcn_gemm_kernel, dim3(sslam::cdiv(HWl, 64), cout / 64, ks * uF), dim3(256), 0, s, wt, K, g->dcol, KT,
                            HWl, cout, g->dpart, wdt, rc, ks, fs);
         hipLaunchKernelGGL(al_dcn_epilogue_kernel, dim3(sslam::cdiv(cout * HWl, 256), uF), dim3(256), 0, s, g->dpart, ks, HWl, cout,
                            outp, al_, be_, res ? 1 : 0, bdp, fs);
@@ -1778,12 +1763,12 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
                        W3, g->b3c1ot, g->b3c1.ob, mo3, fs);
     else hipLaunchKernelGGL((al_offset_conv_kernel<32, 1>), dim3(sslam::cdiv(HW3, 4), uF), dim3(256), 0, s, g->p3, g->off, H3,
                        W3, g->b3c1ot, g->b3c1.ob, mo3, fs);
-    dcn(g->p3, 32, g->t3, 64, H3, W3, g->b3c1s, g->b3c1.a, g->b3c1.b, nullptr, 0, nullptr, nullptr);
+    dcn(g->p3, 32, g->t3, 64, H3, W3, g->b3c1t, g->b3c1.a, g->b3c1.b, nullptr, 0, nullptr, nullptr);
     if (F >= 4) hipLaunchKernelGGL((al_offset_conv_kernel<64, 4>), dim3(sslam::cdiv(HW3, 16), uF), dim3(256), 0, s, g->t3, g->off, H3,
                        W3, g->b3c2ot, g->b3c2.ob, mo3, fs);
     else hipLaunchKernelGGL((al_offset_conv_kernel<64, 1>), dim3(sslam::cdiv(HW3, 4), uF), dim3(256), 0, s, g->t3, g->off, H3,
                        W3, g->b3c2ot, g->b3c2.ob, mo3, fs);
-    dcn(g->t3, 64, g->x3, 64, H3, W3, g->b3c2s, g->b3c2.a, g->b3c2.b, g->p3, 32, g->b3dws, g->b3db);
+    dcn(g->t3, 64, g->x3, 64, H3, W3, g->b3c2t, g->b3c2.a, g->b3c2.b, g->p3, 32, g->b3dwt, g->b3db);
     // block4 at 1/32
     const int H4 = Hp / 32, W4 = Wp / 32, HW4 = H4 * W4;
     hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(64 * HW4, 256), uF), dim3(256), 0, s, g->x3, g->p4, 64, H3, W3, 4, fs);
@@ -1792,12 +1777,12 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
                        W4, g->b4c1ot, g->b4c1.ob, mo4, fs);
     else hipLaunchKernelGGL((al_offset_conv_kernel<64, 1>), dim3(sslam::cdiv(HW4, 4), uF), dim3(256), 0, s, g->p4, g->off, H4,
                        W4, g->b4c1ot, g->b4c1.ob, mo4, fs);
-    dcn(g->p4, 64, g->t4, 128, H4, W4, g->b4c1s, g->b4c1.a, g->b4c1.b, nullptr, 0, nullptr, nullptr);
+    dcn(g->p4, 64, g->t4, 128, H4, W4, g->b4c1t, g->b4c1.a, g->b4c1.b, nullptr, 0, nullptr, nullptr);
     if (F >= 4) hipLaunchKernelGGL((al_offset_conv_kernel<128, 4>), dim3(sslam::cdiv(HW4, 16), uF), dim3(256), 0, s, g->t4, g->off, H4,
                        W4, g->b4c2ot, g->b4c2.ob, mo4, fs);
     else hipLaunchKernelGGL((al_offset_conv_kernel<128, 1>), dim3(sslam::cdiv(HW4, 4), uF), dim3(256), 0, s, g->t4, g->off, H4,
                        W4, g->b4c2ot, g->b4c2.ob, mo4, fs);
-    dcn(g->t4, 128, g->x4, 128, H4, W4, g->b4c2s, g->b4c2.a, g->b4c2.b, g->p4, 64, g->b4dws, g->b4db);
+    dcn(g->t4, 128, g->x4, 128, H4, W4, g->b4c2t, g->b4c2.a, g->b4c2.b, g->p4, 64, g->b4dwt, g->b4db);
     // gates
     hipLaunchKernelGGL(al_gate_kernel, dim3(sslam::cdiv(H2 * W2, 256), uF), dim3(256), 0, s, g->x2, g->g2, 32, H2 * W2, g->gw2, g->g2cl, fs);
     hipLaunchKernelGGL(al_gate_small_kernel, dim3(sslam::cdiv(32 * HW3, 256), uF), dim3(256), 0, s, g->x3, g->g3, 64, HW3, g->gw3, g->g3cl, fs);
@@ -1889,8 +1874,6 @@ int sslam_aliked_create_batched(sslam_ctx* ctx, const float* weights, size_t n_f
         g->b4c2t = A.take<float>(1152 * 128); g->b3dwt = A.take<float>(32 * 64); g->b4dwt = A.take<float>(64 * 128);
         g->d_sf_s = A.take<_Float16>(2 * 128 * 128); g->d_agg_s = A.take<_Float16>((size_t)2 * 128 * 2048);
         g->b2c2f = A.take<_Float16>(2 * 32 * 288);
-        g->b3c1s = A.take<_Float16>(2 * 288 * 64); g->b3c2s = A.take<_Float16>(2 * 576 * 64); g->b4c1s = A.take<_Float16>(2 * 576 * 128);
-        g->b4c2s = A.take<_Float16>(2 * 1152 * 128); g->b3dws = A.take<_Float16>(2 * 32 * 64); g->b4dws = A.take<_Float16>(2 * 64 * 128);
         g->b3c1ot = A.take<float>(288 * 18); g->b3c2ot = A.take<float>(576 * 18); g->b4c1ot = A.take<float>(576 * 18); g->b4c2ot = A.take<float>(1152 * 18);
         g->gk = A.take<float>(64);
     };
@@ -1951,11 +1934,6 @@ int sslam_aliked_create_batched(sslam_ctx* ctx, const float* weights, size_t n_f
         tr(g->b4c1.w, g->b4c1t, 64, 9, 128); tr(g->b4c2.w, g->b4c2t, 128, 9, 128);
         tr(g->b3dw, g->b3dwt, 32, 1, 64); tr(g->b4dw, g->b4dwt, 64, 1, 128);
         hipLaunchKernelGGL(al_conv32_wfrag_kernel, dim3(sslam::cdiv(32 * 288, 256)), dim3(256), 0, s, g->b2c2.w, g->b2c2f);
-        auto sp = [&](const float* src, _Float16* dst, size_t n) {
-            hipLaunchKernelGGL(al_split_kernel, dim3((unsigned)sslam::cdiv((int)n, 256)), dim3(256), 0, s, src, dst, n);
-        };
-        sp(g->b3c1t, g->b3c1s, 288 * 64); sp(g->b3c2t, g->b3c2s, 576 * 64); sp(g->b4c1t, g->b4c1s, 576 * 128);
-        sp(g->b4c2t, g->b4c2s, 1152 * 128); sp(g->b3dwt, g->b3dws, 32 * 64); sp(g->b4dwt, g->b4dws, 64 * 128);
         hipLaunchKernelGGL(al_split_kernel, dim3(sslam::cdiv(128 * 128, 256)), dim3(256), 0, s, g->d_sf, g->d_sf_s, (size_t)128 * 128);
         hipLaunchKernelGGL(al_split_kernel, dim3(sslam::cdiv(128 * 2048, 256)), dim3(256), 0, s, g->d_agg, g->d_agg_s, (size_t)128 * 2048);
         auto tro = [&](const float* src, float* dst, int K) {      // [k][18] -> [18][k]
