@@ -240,7 +240,10 @@ int sslam_lightglue_set_conf(sslam_lightglue* lg, float depth_confidence, float 
 /* Arithmetic of the 9 transformer layers.  0: every contraction on the exact-fp32 matrix-core
  * instruction (v_mfma_f32_32x32x2_f32).  1 (default): fp16 hi/lo split operands, three
  * v_mfma_f32_32x32x16_f16 per product, fp32 accumulation (~2^-22 relative error per product).
- * The final assignment (final_proj, similarity, dual softmax, arg-max) is fp32 in both modes. */
+ * 2 (opt-in): as 1, but attention carries the softmax weights P as ONE fp16 plane in P.V (two MFMAs per product there, the
+ * row sum over the rounded weights): -12 % attention time; match indices identical on every parity case, token states
+ * 2.4e-5 from exact instead of 4e-6 (profiles/r04_split_study.md).
+ * The final assignment (final_proj, similarity, dual softmax, arg-max) is fp32 in every mode. */
 int sslam_lightglue_set_precision(sslam_lightglue* lg, int mode);
 /* xy0[M*2], desc0[M*128], xy1[N*2], desc1[N*128] float32.
  * ij_out[2*min(M,N)] int32 (queryIdx, trainIdx) pairs, ascending queryIdx;

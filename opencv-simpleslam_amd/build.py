@@ -65,7 +65,7 @@ def _build_asm_kernels(obj_dir: Path, force: bool, verbose: bool):
         name = gen.stem[4:]
         obj = obj_dir / f"{name}_hsaco.o"
         keyf = obj_dir / f"{name}_hsaco.key"
-        key = _digest(clang, lld, ARCH, gen.read_bytes())
+        key = _digest(clang, lld, ARCH, *[g_.read_bytes() for g_ in sorted(CSRC.glob("gen_*.py"))])     # (a generator may run another)
         if force or not obj.exists() or not keyf.exists() or keyf.read_text().strip() != key:
             keyf.unlink(missing_ok=True)
             env = {k: v for k, v in os.environ.items() if not k.startswith("ATTN_ASM_")}     # no experiment switches

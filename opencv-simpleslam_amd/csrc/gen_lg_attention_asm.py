@@ -43,17 +43,18 @@ WEIGHTED = int(os.environ.get("ATTN_ASM_WEIGHTED", "0"))     # 1: spread the VAL
 # {lifetime, tile-barrier wait, fragment wait at ODD, fragment wait at EVEN, stamp-pair overhead, tiles} (cycles) to the
 # buffer whose address sits at kernel-argument offset 96
 STAMP = os.environ.get("ATTN_ASM_STAMP", "0") == "1"
-# r04 timing experiment (never the product; build.py strips ATTN_ASM_* from the environment): P as ONE fp16 plane - the four
-# V^T.hi x P.lo MFMAs of a sub-step and the two fma_mix per element pair that form P.lo are not issued (20 MFMAs per sub-step
-# instead of 24).  The row sums stay fp32 sums of the unrounded weights here, so the results are NOT the study's P-one-plane
-# form (profiles/r04_split_study.md) - only its instruction stream, for the time it would take.
+# r04: P as ONE fp16 plane (the opt-in precision "f16x3p1", sslam_lightglue_set_precision(lg, 2); csrc/gen_lg_attention_asm_p1.py
+# generates that kernel): the four V^T.hi x P.lo MFMAs of a sub-step and the two fma_mix per element pair that form P.lo are
+# not issued (20 MFMAs per sub-step instead of 24), and the row sum runs over the ROUNDED weights (one v_fma_mix_f32 per
+# element from the packed halves) so that o / l stays an exact softmax of slightly perturbed logits - the arithmetic of
+# lg_attention_p_kernel with p_single (profiles/r04_split_study.md: zero index flips on every case, token state 2.4e-5).
 P1 = os.environ.get("ATTN_ASM_P1", "0") == "1"
 
 out = []
 def e(s=""):
     out.append(s)
 
-KERNEL = "lg_attention_asm_kernel"
+KERNEL = os.environ.get("ATTN_ASM_KERNEL", "lg_attention_asm_kernel")
 
 # ---------------------------------------------------------------- register map
 # arch VGPRs
@@ -223,6 +224,14 @@ def softmax_sum(pair):
         return [f"v_pk_add_f32 {v(V_PS0, 2)}, {v(V_PS0, 2)}, {v(r0, 2)}"]
     return [f"v_add_f32_e32 {v(V_PS0)}, {v(V_PS0)}, {v(r0)}", f"v_add_f32_e32 {v(V_PS1)}, {v(V_PS1)}, {v(r1)}"]
 
+def softmax_sum_p1(pair):
+    """P1: psum0 += float(ph[even element]), psum1 += float(ph[odd element]) - the sums of the ROUNDED weights, from the packed halves"""
+    hreg = PH + pair
+    c0 = "0" if pair == 0 else v(V_PS0)
+    c1 = "0" if pair == 0 else v(V_PS1)
+    return [f"v_fma_mix_f32 {v(V_PS0)}, {v(hreg)}, 1.0, {c0} op_sel_hi:[1,0,0]",
+            f"v_fma_mix_f32 {v(V_PS1)}, {v(hreg)}, 1.0, {c1} op_sel:[1,0,0] op_sel_hi:[1,0,0]"]
+
 def softmax_split(pair):
     """hi = fp16(p) packed, lo = fp16(p - hi) (one fma_mix each): P fragment registers."""
     r0, r1 = SV + 2 * pair, SV + 2 * pair + 1
@@ -350,7 +359,8 @@ def body(b, last, mask, tag):
         ex, sm = [], []
         for p in range(NEXP_ODD):
             ex += softmax_exp(p)
-            sm += softmax_sum(p)
+            if not P1:
+                sm += softmax_sum(p)
         if DEFER:
             emit_half(mfma_pv(), kr, softmax_part1(mask, st) + ex + sm, valu_start=3, head=deferred_block(),
                       comment=f"ODD  buf {b} sub {sub}: PV(j-1) | K frags(j+1) | sums(j-1), softmax part 1")
@@ -378,7 +388,14 @@ def body(b, last, mask, tag):
         for p in range(NEXP_ODD, 8):
             rest += softmax_split(p)
         # exp2 of the remaining elements under the split of the ODD half's, then (sums and) the rest
-        valu = interleave(ex, first) + ([] if DEFER else sm) + rest + ([] if DEFER else softmax_lsum())
+        if P1:
+            assert not DEFER
+            sums = []
+            for p in range(8):
+                sums += softmax_sum_p1(p)
+            valu = interleave(ex, first) + rest + sums + softmax_lsum()
+        else:
+            valu = interleave(ex, first) + ([] if DEFER else sm) + rest + ([] if DEFER else softmax_lsum())
         for x in stamped(["s_waitcnt lgkmcnt(0)"], S_ACC_EVEN): e("    " + x)
         emit_half(mfma_qk() if do_qk else [], v_reads(sub, b), valu, dma=dma, valu_start=0,
                   comment=f"EVEN buf {b} sub {sub}: QK(j+1) | V frags(j) | softmax part 2")

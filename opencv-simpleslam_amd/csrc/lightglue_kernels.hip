@@ -1790,6 +1790,7 @@ struct sslam_lightglue {
     int dbg_self_only = 0;           // test hook: stop after the self block of the last executed layer
     int force_ks = 0;                // test hook: key split of the attention launches (0 = by batch size)
     hipError_t launch_error = hipSuccess;   // first failure of a module-API launch (checked with hipGetLastError at the end of an enqueue)
+    int p_single = 0;                // precision "f16x3p1" (set_precision 2): P as one fp16 plane in P.V, row sums over the rounded weights
     int study = 0;                   // precision study (sslam_lightglue_debug_split_form): which cross terms of the split products are dropped
     _Float16* zero_plane = nullptr;  // study only: an all-zero fp16 plane standing in for a dropped low plane
     int big_gemm = -1;               // test hook: -1 by batch size, 0 / 1 force the single-pair (ring) / batched form of the linears;
@@ -1971,6 +1972,7 @@ LinearArgsH linh(const sslam_lightglue* g, SplitPtr A0, SplitPtr A1, int lda, in
 // assembled and embedded by build.py (`sslam_lg_attention_asm_hsaco`), loaded once per device at instance creation
 // (never inside a stream capture) and launched through the module API - which a capture records like any launch.
 extern "C" const unsigned char sslam_lg_attention_asm_hsaco[];
+extern "C" const unsigned char sslam_lg_attention_asm_p1_hsaco[];     // the kernel of precision "f16x3p1" (gen_lg_attention_asm_p1.py)
 struct AttnAsmArgs {                // the kernel's argument segment (gen_lg_attention_asm.py: s_load offsets 0x0 .. 0x5c)
     const _Float16 *q_hi, *q_lo, *k_hi, *k_lo, *vt_hi, *vt_lo;
     _Float16 *msg_hi, *msg_lo;
@@ -1983,14 +1985,17 @@ struct AttnAsmArgs {                // the kernel's argument segment (gen_lg_att
 static_assert(sizeof(AttnAsmArgs) == 128, "kernel argument segment of lg_attention_asm_kernel");
 constexpr int ASM_MAX_DEVICES = 64;
 hipFunction_t g_attn_asm_fn[ASM_MAX_DEVICES] = {};
+hipFunction_t g_attn_asm_p1_fn[ASM_MAX_DEVICES] = {};
 std::mutex g_attn_asm_mutex;
 
 int lg_load_attention_asm(int device) {
     SSLAM_REQUIRE(device >= 0 && device < ASM_MAX_DEVICES, "device %d out of range", device);
     std::lock_guard<std::mutex> lock(g_attn_asm_mutex);
     if (g_attn_asm_fn[device]) return 0;
-    hipModule_t mod;
+    hipModule_t mod, mod1;
     SSLAM_HIP_CHECK(hipModuleLoadData(&mod, sslam_lg_attention_asm_hsaco));
+    SSLAM_HIP_CHECK(hipModuleLoadData(&mod1, sslam_lg_attention_asm_p1_hsaco));
+    SSLAM_HIP_CHECK(hipModuleGetFunction(&g_attn_asm_p1_fn[device], mod1, "lg_attention_asm_p1_kernel"));
     SSLAM_HIP_CHECK(hipModuleGetFunction(&g_attn_asm_fn[device], mod, "lg_attention_asm_kernel"));
     return 0;
 }
@@ -2003,7 +2008,7 @@ void launch_attention_h(sslam_lightglue* g, hipStream_t s, int NI, SplitPtr Q, S
         if (g->study & 0x08) VT.lo = g->zero_plane;         // O = vh.ph + vh.pl          (V as one fp16 plane)
     }
     AttnArgsH a{Q, K, VT, cross, g->o_part, g->m_part, g->l_part, SplitOut{g->msgs_hi, g->msgs_lo}, KS, g->Kc,
-                g->NIc, g->ctrl, (g->study & 0x04) ? 1 : 0};     // 0x04: O = vh.ph + vl.ph (P as one fp16 plane; 4-wave kernel only)
+                g->NIc, g->ctrl, ((g->study & 0x04) || g->p_single) ? 1 : 0};     // O = vh.ph + vl.ph: study bit 0x04 (4-wave kernel only) or precision "f16x3p1"
     attn_event(g, s, true);
     if (!(g->study & 0x04) && (g->force_ks == 0 || g->force_ks == -3 || g->force_ks > 100)) {
         // the hand-scheduled assembly kernel - the arithmetic, LDS images and results of lg_attention_p_kernel (no key split: batched
@@ -2015,7 +2020,8 @@ void launch_attention_h(sslam_lightglue* g, hipStream_t s, int NI, SplitPtr Q, S
         k.magic = k.nqb > 1 ? (unsigned)((1ull << 32) / (unsigned)k.nqb + 1) : 0u;
         size_t sz = sizeof(k);
         void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-        const hipError_t e = hipModuleLaunchKernel(g_attn_asm_fn[g->ctx->device], (unsigned)k.nqb, (unsigned)k.nslab, 1,
+        const hipFunction_t fn = g->p_single ? g_attn_asm_p1_fn[g->ctx->device] : g_attn_asm_fn[g->ctx->device];
+        const hipError_t e = hipModuleLaunchKernel(fn, (unsigned)k.nqb, (unsigned)k.nslab, 1,
                                                    256, 1, 1, 0, s, nullptr, cfg);
         if (e != hipSuccess && g->launch_error == hipSuccess) g->launch_error = e;
     } else {
@@ -2527,11 +2533,14 @@ int sslam_lightglue_profile_read(sslam_lightglue* g, float* total_ms_out, int32_
 }
 
 /* 0: every contraction on the exact-fp32 matrix-core instruction; 1 (default): transformer layers on
- * the fp16 hi/lo split path (3 MFMA per product, ~2^-22 relative error), assignment stays fp32. */
+ * the fp16 hi/lo split path (3 MFMA per product, ~2^-22 relative error), assignment stays fp32; 2 (opt-in, r04): as 1, but
+ * attention carries P as ONE fp16 plane in P.V (2 MFMA per product there, row sums over the rounded weights): -12 % attention
+ * time, match indices identical on every parity case, token states 2.4e-5 instead of 4e-6 from exact (profiles/r04_split_study.md). */
 int sslam_lightglue_set_precision(sslam_lightglue* g, int mode) {
-    SSLAM_REQUIRE(g != nullptr && (mode == 0 || mode == 1), "sslam_lightglue_set_precision: bad argument");
+    SSLAM_REQUIRE(g != nullptr && (mode == 0 || mode == 1 || mode == 2), "sslam_lightglue_set_precision: bad argument");
     g->settings_changed();
-    g->precision = mode;
+    g->precision = mode == 0 ? 0 : 1;
+    g->p_single = mode == 2;
     return 0;
 }
 

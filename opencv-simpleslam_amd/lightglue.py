@@ -147,8 +147,10 @@ class LightGlueHIP:
         return out
 
     def set_precision(self, mode: str | int):
-        """'f32' / 0: exact-fp32 matrix-core path; 'f16x3' / 1 (default): fp16 hi/lo split path."""
-        m = {"f32": 0, "f16x3": 1}.get(mode, mode)
+        """'f32' / 0: exact-fp32 matrix-core path; 'f16x3' / 1 (default): fp16 hi/lo split path; 'f16x3p1' / 2 (opt-in): the
+        split path with the softmax weights as ONE fp16 plane in P.V (-12 % attention time, same match indices on every parity
+        case, token states 2.4e-5 from exact instead of 4e-6)."""
+        m = {"f32": 0, "f16x3": 1, "f16x3p1": 2}.get(mode, mode)
         _native.check(_native.lib().sslam_lightglue_set_precision(self.handle, int(m)))
         self.precision = int(m)
 

@@ -305,3 +305,35 @@ def test_token_heads_in_the_fused_ffn_decide_like_the_separate_kernel(gpu_ctx, s
         assert info[1] == s_stop
     assert not batch.range_overflow()
     dev.free(); batch.close(); single.close()
+
+
+def test_precision_f16x3p1_assembly_kernel_equals_the_4_wave_kernel_and_keeps_the_matches(gpu_ctx):
+    """r04 opt-in precision "f16x3p1": P as ONE fp16 plane in P.V (row sums over the rounded weights).  Its hand-scheduled
+    kernel (gen_lg_attention_asm_p1.py) gives what the 4-wave kernel's `p_single` branch gives, bit for bit - un-split (batch)
+    and in key ranges (single-pair policy) - and the matches of the default precision and of the oracle."""
+    W, LG = load_pkg("weights"), load_pkg("lightglue").LightGlueHIP
+    sd = W.random_lightglue_state_dict(1, match_gain=4.0, match_bias=3.0)
+    sizes = [(512, 512), (300, 417), (64, 33), (640, 1), (129, 128), (640, 640)]
+    pairs = [lg_inputs.make_pair(m, n, seed=m + n) for m, n in sizes]
+    batch = LG(sd, max_kpts=640, max_pairs=6, ctx=gpu_ctx)
+    dev = DevBatch(gpu_ctx, pairs, 640)
+    ref = dev.run(batch, 0.0)                                   # default precision
+    batch.set_precision("f16x3p1")
+    got = {}
+    for ks in (-3, -1, 102, 2):                                 # assembly / 4-wave kernel: no split, two key ranges
+        batch.debug_key_split(ks)
+        got[ks] = dev.run(batch, 0.0)
+    for a, b in ((-3, -1), (102, 2)):
+        for p, (x, y) in enumerate(zip(got[a], got[b])):
+            np.testing.assert_array_equal(x[0], y[0], err_msg=f"pair {p} ks {a}/{b}")
+            np.testing.assert_array_equal(x[1], y[1], err_msg=f"pair {p} ks {a}/{b}")
+            np.testing.assert_array_equal(x[2], y[2])
+    assert any(not np.array_equal(a[1], b[1]) for a, b in zip(ref, got[-3]))      # another arithmetic: the scores move ...
+    for p, (a, b) in enumerate(zip(ref, got[-3])):                                 # ... the matches do not
+        np.testing.assert_array_equal(a[0], b[0], err_msg=f"pair {p}")
+        np.testing.assert_allclose(a[1], b[1], atol=2e-4)
+    for p in (0, 1, 5):
+        o_ij, o_sc, o_stop = _oracle(sd, pairs[p], 0.0)
+        np.testing.assert_array_equal(got[-3][p][0], o_ij)
+    batch.debug_key_split(0)
+    dev.free(); batch.close()

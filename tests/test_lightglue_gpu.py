@@ -254,3 +254,32 @@ def test_index_parity_over_seeds(W, LG, seed):
     ij, ref = _compare(lg, sd, k0, d0, k1, d1, min_conf=0.2, check_state=False)
     assert len(ij) > 100
     lg.close()
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106])
+def test_index_parity_over_seeds_f16x3p1(W, LG, seed):
+    """The opt-in precision "f16x3p1" (P as one fp16 plane in P.V) on the six-seed set: same match indices as the oracle."""
+    sd = W.random_lightglue_state_dict(seed, match_gain=4.0, match_bias=3.0)
+    lg = LG(sd, max_kpts=1024)
+    lg.set_precision("f16x3p1")
+    k0, d0, k1, d1 = lg_inputs.make_pair(1024, 960, seed=seed)
+    ij, ref = _compare(lg, sd, k0, d0, k1, d1, min_conf=0.2, check_state=False)
+    assert len(ij) > 100
+    lg.close()
+
+
+def test_token_state_f16x3p1_is_within_3e_5(W, LG):
+    """What "f16x3p1" costs: the token state after 9 layers against the oracle stays within 3e-5 (the default: 2e-5 bound,
+    ~8e-6 measured; profiles/r04_split_study.md: 2.4e-5 for this form)."""
+    sd = W.random_lightglue_state_dict(5, match_gain=4.0, match_bias=3.0)
+    n = 512
+    k0, d0, k1, d1 = lg_inputs.make_pair(n, seed=21)
+    ref = R.lightglue_forward(sd, k0, d0, k1, d1, {"depth_confidence": -1, "width_confidence": -1}, return_debug=True)
+    lg = LG(sd, max_kpts=n, depth_confidence=-1.0, width_confidence=-1.0)
+    lg.set_precision("f16x3p1")
+    ij, sc, stop = lg.match(k0, d0, k1, d1, min_conf=0.0)
+    x = lg.debug_read(0, (2, lg.capacity, 256))
+    for img in (0, 1):
+        np.testing.assert_allclose(x[img, :n], ref["debug"]["layers"][8][f"cross{img}"].numpy(), atol=3e-5, rtol=0)
+    np.testing.assert_array_equal(ij, ref["matches"].numpy())
+    lg.close()
