@@ -23,7 +23,7 @@ def test_bench_contract_single_rank():
     d = _run_bench({}, [sys.executable, "bench.py", "--steps", "2", "--warmup", "4", "--no-cpu-baseline"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                 "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "structured_input",
-                "exact_f32", "ba", "reproject", "step_ms", "timed_region_s", "early_stop", "dropin", "pcie", "c5", "kpts4000",
+                "exact_f32", "ba", "reproject", "step_ms", "timed_region_s", "early_stop", "dropin", "pcie", "c5", "kpts4000", "p1",
                 "gpu_busy_s"):
         assert key in d
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["unit"] == "frames/s"
@@ -39,6 +39,7 @@ def test_bench_contract_single_rank():
     assert d["pcie"]["value"] > 0 and d["pcie"]["h2d_bytes_per_round"] == 6 * 1241 * 376 * 3, d["pcie"]
     for leg in ("c5", "kpts4000"):
         assert d[leg].get("value", 0) > 0 and 0 < d[leg]["aliked_hbm"]["frac"] < 1, d[leg]
+    assert d["p1"]["value"] > 0 and 0 < d["p1"]["attention"]["frac"] < 1
     assert d["kpts4000"]["max_kpts"] == 4000 and 0 < d["kpts4000"]["attention"]["frac"] < 1
     es = d["early_stop"]
     assert es["value"] > 0 and es["lightglue_layers_histogram"] and set(es["lightglue_layers_histogram"]) != {"9"}, es
