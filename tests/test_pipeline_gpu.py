@@ -107,6 +107,13 @@ def test_two_rank_pipeline_equals_sequential_api():
     _run_dist_check("gloo", 2, 29613)
 
 
+def test_four_rank_pipeline_equals_sequential_api():
+    """The same check with FOUR gloo ranks on the one GPU (r04): ranks 1 - 3 take their halo from the neighbour's last frame of
+    the same round, rank 0 from the previous round's collation - the shard / halo / batch-order logic of the 8-GPU run
+    beyond world size 2."""
+    _run_dist_check("gloo", 4, 29619)
+
+
 def test_two_rank_pipeline_over_rccl(native):
     """The same check with backend `nccl` (= RCCL over xGMI), one GPU per rank: runs wherever >= 2 devices are
     visible (the driver's 8-GPU node), skipped on a 1-GPU box - so the first multi-GPU lease produces evidence
