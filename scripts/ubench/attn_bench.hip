@@ -12,7 +12,8 @@
 #include <vector>
 #include <algorithm>
 namespace sslam { void set_error(const char*, ...) {} void ctx_retain(sslam_ctx*) {} void ctx_release(sslam_ctx*) {} }
-extern "C" const unsigned char sslam_lg_attention_asm_hsaco[1] = {0};      // (the product embeds the code object; here it is loaded from a file)
+extern "C" const unsigned char sslam_lg_attention_asm_hsaco[1] = {0};      // (the product embeds the code objects; here one is loaded from a file)
+extern "C" const unsigned char sslam_lg_attention_asm_p1_hsaco[1] = {0};
 
 // the hand-scheduled kernel (opencv-simpleslam_amd/csrc/gen_lg_attention_asm.py): loaded from the code object named by ATTN_HSACO
 struct AsmArgs {
