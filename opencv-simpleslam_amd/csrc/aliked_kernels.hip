@@ -481,8 +481,8 @@ __global__ __launch_bounds__(256) void al_conv32_h_kernel(const _Float16* __rest
 //     deformable conv (torchvision deform_conv2d semantics) + BN + residual + SELU
 // ------------------------------------------------------------------------ //
 __global__ void al_avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int H, int W,
-                                  int P, size_t fs) {   // out [C][H/P][W/P]
-    in = fsh(in, blockIdx.y, fs); out = fsh(out, blockIdx.y, fs);
+                                  int P, size_t fs, float* __restrict__ out_cl /* [pixel][C] copy for al_dcn_col (r04) */) {   // out [C][H/P][W/P]
+    in = fsh(in, blockIdx.y, fs); out = fsh(out, blockIdx.y, fs); out_cl = fsh(out_cl, blockIdx.y, fs);
     const int oh = H / P, ow = W / P;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= C * oh * ow) return;
@@ -501,6 +501,7 @@ __global__ void al_avgpool_kernel(const float* __restrict__ in, float* __restric
             for (int b = 0; b < P; ++b) s += in[((size_t)c * H + y * P + a) * W + x * P + b];
     }
     out[i] = s / (float)(P * P);
+    if (out_cl) out_cl[(size_t)(y * ow + x) * C + c] = s / (float)(P * P);
 }
 
 // offset conv: 3x3, zero pad, bias, clamp to +-max_off.  One wave per pixel: lanes stride over the
@@ -582,22 +583,23 @@ __global__ __launch_bounds__(256) void al_offset_conv_kernel(const float* __rest
 // The maps are small (5120 / 320 pixels), so K is split over blockIdx.z to fill the chip; slice z
 // writes its partial product to slab z, the 1x1 branch to slab KS, and al_dcn_epilogue_kernel adds
 // the slabs in order (deterministic) and applies BN affine + residual + SELU.
-__global__ __launch_bounds__(256) void al_dcn_col_kernel(const float* __restrict__ in, const float* __restrict__ off,
+__global__ __launch_bounds__(256) void al_dcn_col_kernel(const float* __restrict__ in /* channel-last [pixel][CIN] (r04) */,
+                                                         const float* __restrict__ off,
                                                          float* __restrict__ col, int CIN, int H, int W,
-                                                         const float* __restrict__ res_in, int RC, size_t fs) {
+                                                         const float* __restrict__ res_in /* channel-last [pixel][RC] */, int RC, size_t fs) {
     in = fsh(in, blockIdx.y, fs); off = fsh(off, blockIdx.y, fs); col = fsh(col, blockIdx.y, fs); res_in = fsh(res_in, blockIdx.y, fs);
-    // thread = (channel quad, tap slot, pixel), pixel fastest: the 16 gathers of a lane and of its
-    // neighbours fall into the same few rows of one channel plane (16 reads vs 1 write per thread)
+    // r04: thread = (pixel, tap slot, channel quad) with the QUAD fastest and the input channel-last: the four corner loads of
+    // a lane are 16 bytes of a pixel's channel vector (16 - 32 lanes share a 256 - 512-byte run) and the float4 it writes is
+    // the next 16 bytes of the pixel's im2col row - loads and stores of a wave are whole runs.  (r03: pixel fastest over
+    // planar input - coalesced gathers, but every lane's store went to another row of `col`: 64 scattered 16-byte pieces per
+    // instruction, 39 us per launch.)  Same arithmetic per element: bit-identical rows.
     const int K = CIN * 9, KT = K + RC, HW = H * W, slots = RC ? 10 : 9, CQ = CIN / 4;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= HW * slots * CQ) return;
-    const int pix = i % HW, tap = (i / HW) % slots, cq = i / (HW * slots), c = 4 * cq;
+    const int cq = i % CQ, tap = (i / CQ) % slots, pix = i / (CQ * slots), c = 4 * cq;
     float* dst = col + (size_t)pix * KT;
     if (tap == 9) {                                   // block input for the 1x1 branch
-        if (c < RC)
-            *reinterpret_cast<float4*>(dst + K + c) =
-                make_float4(res_in[(size_t)c * HW + pix], res_in[(size_t)(c + 1) * HW + pix],
-                            res_in[(size_t)(c + 2) * HW + pix], res_in[(size_t)(c + 3) * HW + pix]);
+        if (c < RC) *reinterpret_cast<float4*>(dst + K + c) = *reinterpret_cast<const float4*>(res_in + (size_t)pix * RC + c);
         return;
     }
     // torchvision deform_conv2d bilinear sample
@@ -612,12 +614,15 @@ __global__ __launch_bounds__(256) void al_dcn_col_kernel(const float* __restrict
         const bool m1 = y0 >= 0 && x0 >= 0, m2 = y0 >= 0 && x1 <= W - 1, m3 = y1 <= H - 1 && x0 >= 0, m4 = y1 <= H - 1 && x1 <= W - 1;
         const int i1 = m1 ? y0 * W + x0 : 0, i2 = m2 ? y0 * W + x1 : 0, i3 = m3 ? y1 * W + x0 : 0, i4 = m4 ? y1 * W + x1 : 0;
         const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+        const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float4 q1 = m1 ? *reinterpret_cast<const float4*>(in + (size_t)i1 * CIN + c) : z;
+        const float4 q2 = m2 ? *reinterpret_cast<const float4*>(in + (size_t)i2 * CIN + c) : z;
+        const float4 q3 = m3 ? *reinterpret_cast<const float4*>(in + (size_t)i3 * CIN + c) : z;
+        const float4 q4 = m4 ? *reinterpret_cast<const float4*>(in + (size_t)i4 * CIN + c) : z;
+        const float v1[4] = {q1.x, q1.y, q1.z, q1.w}, v2[4] = {q2.x, q2.y, q2.z, q2.w};
+        const float v3[4] = {q3.x, q3.y, q3.z, q3.w}, v4[4] = {q4.x, q4.y, q4.z, q4.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float* p = in + (size_t)(c + e) * HW;
-            const float v1 = m1 ? p[i1] : 0.0f, v2 = m2 ? p[i2] : 0.0f, v3 = m3 ? p[i3] : 0.0f, v4 = m4 ? p[i4] : 0.0f;
-            o[e] = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
-        }
+        for (int e = 0; e < 4; ++e) o[e] = w1 * v1[e] + w2 * v2[e] + w3 * v3[e] + w4 * v4[e];
     }
     *reinterpret_cast<float4*>(dst + tap * CIN + c) = make_float4(o[0], o[1], o[2], o[3]);
 }
@@ -655,17 +660,19 @@ __global__ __launch_bounds__(256) void al_dcn_gemm_kernel(const float* __restric
 __global__ __launch_bounds__(256) void al_dcn_epilogue_kernel(const float* __restrict__ part, int KS, int HW, int COUT,
                                                               float* __restrict__ out, const float* __restrict__ alpha,
                                                               const float* __restrict__ beta, int resid,
-                                                              const float* __restrict__ bd, size_t fs) {
+                                                              const float* __restrict__ bd, size_t fs, float* __restrict__ out_cl) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= COUT * HW) return;
-    part = fsh(part, blockIdx.y, fs); out = fsh(out, blockIdx.y, fs);
+    part = fsh(part, blockIdx.y, fs); out = fsh(out, blockIdx.y, fs); out_cl = fsh(out_cl, blockIdx.y, fs);
     const int co = i / HW;
     float acc = part[i];
 #pragma unroll 6
     for (int z = 1; z < KS; ++z) acc += part[(size_t)z * COUT * HW + i];
     float v = fmaf(acc, alpha[co], beta[co]);
     if (resid) v += part[(size_t)KS * COUT * HW + i] + bd[co];
-    out[i] = selu(v);
+    v = selu(v);
+    out[i] = v;
+    if (out_cl) out_cl[(size_t)(i % HW) * COUT + co] = v;       // [pixel][COUT] copy for the next layer's al_dcn_col
 }
 
 __global__ void al_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C) {
@@ -1629,6 +1636,7 @@ struct sslam_aliked {
     float *kp_norm, *kp_score, *patch, *h32, *pos, *sampled, *feats, *raw;
     _Float16 *d_sf_s, *d_agg_s;          // split (hi | lo) copies of the two large descriptor-head weight matrices
     _Float16* b2c2f;                     // block2.conv2 weights, split, fragment order (al_conv32_wfrag_kernel)
+    float *p3cl, *t3cl, *p4cl, *t4cl;    // channel-last copies of the deformable layers' inputs (al_dcn_col)
     float *out_xy, *out_desc, *out_score;
     int32_t* out_n;
     Dims last{};
@@ -1738,8 +1746,8 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
     else        // one frame: 320 workgroups of 8 rows leave the chip half empty - 4-row tiles (same arithmetic per output)
         hipLaunchKernelGGL(al_conv32_h_kernel<1>, g2a, dim3(256), 0, s, t2h, g->x2, H2, W2, g->b2c2f, g->b2c2.a, g->b2c2.b, g->idn2, fs);
     // deformable conv = im2col of the bilinear samples + matrix-core GEMM (offsets in g->off)
-    auto dcn = [&](const float* in, int cin, float* outp, int cout, int Hh, int Ww, const float* wt, const float* al_,
-                   const float* be_, const float* res, int rc, const float* wdt, const float* bdp) {
+    auto dcn = [&](const float* in /* channel-last */, int cin, float* outp, int cout, int Hh, int Ww, const float* wt, const float* al_,
+                   const float* be_, const float* res /* channel-last */, int rc, const float* wdt, const float* bdp, float* outp_cl) {
         const int K = cin * 9, KT = K + rc, HWl = Hh * Ww, slots = rc ? 10 : 9;
         hipLaunchKernelGGL(al_dcn_col_kernel, dim3(sslam::cdiv(HWl * slots * (cin / 4), 256), uF), dim3(256), 0, s, in, g->off,
                            g->dcol, cin, Hh, Ww, res, rc, fs);
@@ -1753,36 +1761,36 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
         hipLaunchKernelGGL(al_dcn_gemm_kernel, dim3(sslam::cdiv(HWl, 64), cout / 64, ks * uF), dim3(256), 0, s, wt, K, g->dcol, KT,
                            HWl, cout, g->dpart, wdt, rc, ks, fs);
         hipLaunchKernelGGL(al_dcn_epilogue_kernel, dim3(sslam::cdiv(cout * HWl, 256), uF), dim3(256), 0, s, g->dpart, ks, HWl, cout,
-                           outp, al_, be_, res ? 1 : 0, bdp, fs);
+                           outp, al_, be_, res ? 1 : 0, bdp, fs, outp_cl);
     };
     // block3 at 1/8 (deformable)
     const int H3 = Hp / 8, W3 = Wp / 8, HW3 = H3 * W3;
-    hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(32 * HW3, 256), uF), dim3(256), 0, s, g->x2, g->p3, 32, H2, W2, 4, fs);
+    hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(32 * HW3, 256), uF), dim3(256), 0, s, g->x2, g->p3, 32, H2, W2, 4, fs, g->p3cl);
     const float mo3 = (float)(H3 > W3 ? H3 : W3) / 4.0f;
     if (F >= 4) hipLaunchKernelGGL((al_offset_conv_kernel<32, 4>), dim3(sslam::cdiv(HW3, 16), uF), dim3(256), 0, s, g->p3, g->off, H3,
                        W3, g->b3c1ot, g->b3c1.ob, mo3, fs);
     else hipLaunchKernelGGL((al_offset_conv_kernel<32, 1>), dim3(sslam::cdiv(HW3, 4), uF), dim3(256), 0, s, g->p3, g->off, H3,
                        W3, g->b3c1ot, g->b3c1.ob, mo3, fs);
-    dcn(g->p3, 32, g->t3, 64, H3, W3, g->b3c1t, g->b3c1.a, g->b3c1.b, nullptr, 0, nullptr, nullptr);
+    dcn(g->p3cl, 32, g->t3, 64, H3, W3, g->b3c1t, g->b3c1.a, g->b3c1.b, nullptr, 0, nullptr, nullptr, g->t3cl);
     if (F >= 4) hipLaunchKernelGGL((al_offset_conv_kernel<64, 4>), dim3(sslam::cdiv(HW3, 16), uF), dim3(256), 0, s, g->t3, g->off, H3,
                        W3, g->b3c2ot, g->b3c2.ob, mo3, fs);
     else hipLaunchKernelGGL((al_offset_conv_kernel<64, 1>), dim3(sslam::cdiv(HW3, 4), uF), dim3(256), 0, s, g->t3, g->off, H3,
                        W3, g->b3c2ot, g->b3c2.ob, mo3, fs);
-    dcn(g->t3, 64, g->x3, 64, H3, W3, g->b3c2t, g->b3c2.a, g->b3c2.b, g->p3, 32, g->b3dwt, g->b3db);
+    dcn(g->t3cl, 64, g->x3, 64, H3, W3, g->b3c2t, g->b3c2.a, g->b3c2.b, g->p3cl, 32, g->b3dwt, g->b3db, nullptr);
     // block4 at 1/32
     const int H4 = Hp / 32, W4 = Wp / 32, HW4 = H4 * W4;
-    hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(64 * HW4, 256), uF), dim3(256), 0, s, g->x3, g->p4, 64, H3, W3, 4, fs);
+    hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(64 * HW4, 256), uF), dim3(256), 0, s, g->x3, g->p4, 64, H3, W3, 4, fs, g->p4cl);
     const float mo4 = (float)(H4 > W4 ? H4 : W4) / 4.0f;
     if (F >= 4) hipLaunchKernelGGL((al_offset_conv_kernel<64, 4>), dim3(sslam::cdiv(HW4, 16), uF), dim3(256), 0, s, g->p4, g->off, H4,
                        W4, g->b4c1ot, g->b4c1.ob, mo4, fs);
     else hipLaunchKernelGGL((al_offset_conv_kernel<64, 1>), dim3(sslam::cdiv(HW4, 4), uF), dim3(256), 0, s, g->p4, g->off, H4,
                        W4, g->b4c1ot, g->b4c1.ob, mo4, fs);
-    dcn(g->p4, 64, g->t4, 128, H4, W4, g->b4c1t, g->b4c1.a, g->b4c1.b, nullptr, 0, nullptr, nullptr);
+    dcn(g->p4cl, 64, g->t4, 128, H4, W4, g->b4c1t, g->b4c1.a, g->b4c1.b, nullptr, 0, nullptr, nullptr, g->t4cl);
     if (F >= 4) hipLaunchKernelGGL((al_offset_conv_kernel<128, 4>), dim3(sslam::cdiv(HW4, 16), uF), dim3(256), 0, s, g->t4, g->off, H4,
                        W4, g->b4c2ot, g->b4c2.ob, mo4, fs);
     else hipLaunchKernelGGL((al_offset_conv_kernel<128, 1>), dim3(sslam::cdiv(HW4, 4), uF), dim3(256), 0, s, g->t4, g->off, H4,
                        W4, g->b4c2ot, g->b4c2.ob, mo4, fs);
-    dcn(g->t4, 128, g->x4, 128, H4, W4, g->b4c2t, g->b4c2.a, g->b4c2.b, g->p4, 64, g->b4dwt, g->b4db);
+    dcn(g->t4cl, 128, g->x4, 128, H4, W4, g->b4c2t, g->b4c2.a, g->b4c2.b, g->p4cl, 64, g->b4dwt, g->b4db, nullptr);
     // gates
     hipLaunchKernelGGL(al_gate_kernel, dim3(sslam::cdiv(H2 * W2, 256), uF), dim3(256), 0, s, g->x2, g->g2, 32, H2 * W2, g->gw2, g->g2cl, fs);
     hipLaunchKernelGGL(al_gate_small_kernel, dim3(sslam::cdiv(32 * HW3, 256), uF), dim3(256), 0, s, g->x3, g->g3, 64, HW3, g->gw3, g->g3cl, fs);
@@ -1886,6 +1894,8 @@ int sslam_aliked_create_batched(sslam_ctx* ctx, const float* weights, size_t n_f
         g->t2 = A.take<float>(32 * HWp / 4); g->idn2 = A.take<float>(32 * HWp / 4); g->x2 = A.take<float>(32 * HWp / 4);
         g->p3 = A.take<float>(32 * HWp / 64); g->off = A.take<float>(18 * HWp / 64);
         g->t3 = A.take<float>(64 * HWp / 64); g->x3 = A.take<float>(64 * HWp / 64);
+        g->p3cl = A.take<float>(32 * HWp / 64); g->t3cl = A.take<float>(64 * HWp / 64);
+        g->p4cl = A.take<float>(64 * HWp / 1024); g->t4cl = A.take<float>(128 * HWp / 1024);
         g->p4 = A.take<float>(64 * HWp / 1024); g->t4 = A.take<float>(128 * HWp / 1024); g->x4 = A.take<float>(128 * HWp / 1024);
         {   // im2col rows: 1/8 level (64*9 + 32) floats per pixel, 1/32 level (128*9 + 64)
             const size_t a = (HWp / 64) * (size_t)(576 + 32), b = (HWp / 1024) * (size_t)(1152 + 64);
