@@ -32,9 +32,9 @@ Rank 0 prints ONE JSON line with the contract fields plus
   dropin       - the six names of slam/core/features_utils.py driven as
                  slam/monocular/main_revamped.py drives them (one frame at a
                  time, host objects in and out): frames/s of that literal path
-  early_stop   - the pipeline with random weights whose token-confidence heads
-                 are biased so that pairs stop early and points are pruned
-                 (the data-dependent-depth machinery under load)
+  early_stop   - the pipeline with random weights whose token-confidence biases
+                 are calibrated on one pair of the stream so that points are
+                 pruned and pairs stop early (depth AND width control under load)
   p1           - the same pipeline in the opt-in precision "f16x3p1" (P as one fp16 plane in P.V), with the attention launch's
                  roofline figure in that mode (never `value`)
   pcie         - the same pipeline with the host in the loop: every round's frames uploaded from page-locked host
@@ -69,8 +69,10 @@ F16_MFMA_PEAK_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense BF16/F16 MFM
 F32_MFMA_PEAK_TFLOPS = 157.3           # same table: v_mfma_f32_32x32x2_f32, the exact-fp32 matrix-core rate
 HBM_PEAK_GBS = 8000.0
 ALIKED_GFLOP_PER_FRAME = 8.9           # 6.56 dense conv + 2.34 SDDH at 2048 keypoints
-EARLY_STOP_CONF_BIAS = float(os.environ.get("SSLAM_BENCH_CONF_BIAS", 1.7))   # early_stop leg (scripts/probe_early_stop.py)
-EARLY_STOP_MATCH_BIAS = float(os.environ.get("SSLAM_BENCH_MATCH_BIAS", -4.6))
+# early_stop leg: the fraction of a pair's points each token-confidence head is calibrated to call "confident" (layers 0..7) and
+# the matchability bias (every point unmatchable -> confident points are pruned); calibrated_confidence_heads() below
+EARLY_STOP_CONFIDENT = [float(v) for v in os.environ.get("SSLAM_BENCH_CONFIDENT", "0.4,0.4,0.5,0.6,0.8,0.97,0.97,0.97").split(",")]
+EARLY_STOP_MATCH_BIAS = float(os.environ.get("SSLAM_BENCH_MATCH_BIAS", -9.0))
 
 
 def _pmc_traffic():
@@ -422,6 +424,34 @@ def _self_launch(args):
     raise SystemExit(0)
 
 
+def calibrated_confidence_heads(sd, feats, ctx):
+    """Random-init token-confidence heads cannot be confident about anything, so the depth / width control never fires on them.
+    For the early_stop leg the BIAS of head i is set from data: one pair of the stream runs i + 1 layers (debug hook), the head's
+    logits over both images' token states are read back, and the bias is shifted so that the fraction EARLY_STOP_CONFIDENT[i] of
+    them lies above the layer's confidence threshold (0.8 + 0.1 exp(-4 i / 9), upstream lightglue.py confidence_threshold).  The
+    weights stay the seeded random ones; every kernel of the control path (lg_token_heads -> lg_decide -> lg_gather) then runs on
+    genuinely data-dependent decisions."""
+    (xy0, d0), (xy1, d1) = feats
+    n = min(len(xy0), len(xy1))
+    if n < 64:
+        return sd
+    probe = importlib.import_module("opencv-simpleslam_amd.lightglue").LightGlueHIP(
+        sd, max_kpts=MAX_KPTS, ctx=ctx, depth_confidence=-1.0, width_confidence=-1.0)
+    sd = dict(sd)
+    for i in range(8):
+        probe.debug_layers(i + 1, False)
+        probe.match(xy0, d0, xy1, d1, min_conf=0.0)
+        x = probe.debug_read(0, (2, probe.capacity, 256))
+        w = np.asarray(sd[f"token_confidence.{i}.token.0.weight"], np.float64).reshape(-1)
+        z = np.concatenate([x[0, :len(xy0)], x[1, :len(xy1)]]).astype(np.float64) @ w
+        thr = min(max(0.8 + 0.1 * np.exp(-4.0 * i / 9), 0.0), 1.0)
+        frac = EARLY_STOP_CONFIDENT[min(i, len(EARLY_STOP_CONFIDENT) - 1)]
+        sd[f"token_confidence.{i}.token.0.bias"] = np.asarray([np.log(thr / (1 - thr)) - np.quantile(z, 1.0 - frac)], np.float32)
+    probe.debug_layers(9, False)
+    probe.close()
+    return sd
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -615,8 +645,9 @@ def main():
     # (lg_token_heads -> lg_decide -> lg_gather) actually stops pairs early and compacts token sets
     e_dt = e_info = None
     if extras:
-        sd_e = W.random_lightglue_state_dict(4, match_gain=4.0, match_bias=EARLY_STOP_MATCH_BIAS, conf_bias=EARLY_STOP_CONF_BIAS)
         ctx_x = [nat.Context(device_index) for _ in range(N_MAT)]
+        sd_e = calibrated_confidence_heads(W.random_lightglue_state_dict(4, match_gain=4.0, match_bias=EARLY_STOP_MATCH_BIAS, conf_gain=16.0),
+                                           pipe.features()[:2], ctx_x[0])
         mats_e = [LightGlueHIP(sd_e, max_kpts=MAX_KPTS, ctx=c, max_pairs=BATCH_PAIRS) for c in ctx_x]
         pipe_e = fs.FrameStreamPipeline(dets, mats_e, plan, MAX_KPTS, MIN_CONF, batch_pairs=BATCH_PAIRS)
         e_steps = max(4, args.steps // 4)
@@ -858,8 +889,9 @@ def main():
             pruned = bool(ok.any() and int(e_info[ok, 2:4].min()) < MAX_KPTS)
             out["early_stop"] = {
                 "value": round(e_steps * plan.frames_per_round() / e_dt_max, 2), "unit": "frames/s", "steps": e_steps,
-                "what": f"same pipeline, structured stream, random-init weights with token-confidence bias {EARLY_STOP_CONF_BIAS} / "
-                        f"matchability bias {EARLY_STOP_MATCH_BIAS}: pairs stop early"
+                "what": f"same pipeline, structured stream, random-init weights whose token-confidence biases are calibrated on one pair "
+                        f"of the stream to call {EARLY_STOP_CONFIDENT} of the points confident after layers 0..7 (matchability bias "
+                        f"{EARLY_STOP_MATCH_BIAS}): pairs stop early"
                         + (" and points are pruned on the device" if pruned else " (no point was pruned before the stop on these inputs)"),
                 "points_pruned": pruned,
                 "lightglue_layers_histogram": {str(int(k)): int(v) for k, v in zip(*np.unique(e_info[ok, 1], return_counts=True))},

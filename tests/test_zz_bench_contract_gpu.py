@@ -43,6 +43,7 @@ def test_bench_contract_single_rank():
     assert d["kpts4000"]["max_kpts"] == 4000 and 0 < d["kpts4000"]["attention"]["frac"] < 1
     es = d["early_stop"]
     assert es["value"] > 0 and es["lightglue_layers_histogram"] and set(es["lightglue_layers_histogram"]) != {"9"}, es
+    assert es["points_pruned"] and es["kpts_after_pruning_min_max"][0] < 2048, es          # the width control fired under load
 
 
 def test_bench_self_launches_its_ranks():
