@@ -18,6 +18,7 @@
 //   score [h][w]         un-padded score map     nms [h][w]
 #include "common.hpp"
 #include "gemm_f32.hpp"
+#include <type_traits>
 #include "gemm_f16x3.hpp"
 
 namespace {
@@ -60,7 +61,15 @@ struct Dims {
 // for bit.
 constexpr int MAX_FRAMES = 16;
 template <typename T> __device__ __forceinline__ T* fsh(T* p, int f, size_t fs) {
-    return p ? reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + (size_t)f * fs) : p;
+    // byte arithmetic on the POINTER, and no null test: a round trip through an integer, or a phi with a null constant, loses
+    // the global address space - every load behind it becomes a flat_load, which also counts against the LDS counter, so
+    // LDS reads wait for global loads in flight (r04: 1 175 flat operations in this file before).  A null optional argument
+    // becomes a non-null garbage pointer: such arguments are only touched under the template flag / `fsh0` below.
+    using B = std::conditional_t<std::is_const_v<T>, const char, char>;
+    return reinterpret_cast<T*>(reinterpret_cast<B*>(p) + (size_t)f * fs);
+}
+template <typename T> __device__ __forceinline__ T* fsh0(T* p, int f, size_t fs) {      // null stays null (run-time optional outputs)
+    return p ? fsh(p, f, fs) : nullptr;
 }
 struct FrameIn { const uint8_t* img[MAX_FRAMES]; };
 struct FrameOut { float* xy[MAX_FRAMES]; float* desc[MAX_FRAMES]; float* score[MAX_FRAMES]; int32_t* n[MAX_FRAMES]; };
@@ -388,6 +397,242 @@ __global__ __launch_bounds__(256) void al_conv3x3_mfma_kernel(
 }
 
 // ------------------------------------------------------------------------ //
+//  1a. the same convolution as a vertical SWEEP (r04): a workgroup owns a 32-pixel column strip of 4 NS rows and walks it in
+//      NS steps of 4 rows.  The one-tile kernel above runs load -> LDS -> MFMA -> store once per workgroup and the phases of
+//      the workgroups of a CU do not overlap (ablations, 16 -> 16 at F = 8: 192 us per launch; without the loads 145, without
+//      the MFMA loop 147, without the stores 150).  Here the global loads of step s + 1 are issued into registers BEFORE the
+//      MFMA loop of step s and land in the second LDS tile after its stores, the [k][co] weights are staged once per strip.
+//      Arithmetic per output: identical (same operands, same accumulation order).  Requires W % 4 == 0.
+// ------------------------------------------------------------------------ //
+// global -> registers; nothing waits on the data here.  Loads are UNCONDITIONAL from clamped addresses and the validity goes
+// into a bit mask applied at stash time: with predicated loads the optimiser folds the pooling adds of the stash into the
+// load's block (phi of a constant and a load), and the wait for the data lands in front of the matrix loop.
+template <int CIN, int CINP, int POOL, int NI, int NH, int NR>
+__device__ __forceinline__ unsigned sweep_load(const float* __restrict__ in, int inH, int inW, int H, int W, int x0, int y0, int t,
+                                               float4 (&ri)[NI][NR], float (&rh)[NH][NR]) {
+    constexpr int TH = 6, ROWS = CINP * TH;
+    unsigned ok = 0;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int idx = min(t + 256 * j, ROWS * 8 - 1), row = idx >> 3, v4 = idx & 7;
+        const int c = row / TH, rr = row % TH;
+        const int yy = y0 + rr - 1, xx = x0 + 4 * v4;
+        ok |= (unsigned)(t + 256 * j < ROWS * 8 && c < CIN && yy >= 0 && yy < H && xx < W) << j;
+        const int cc = min(c, CIN - 1), yc = min(max(yy, 0), H - 1), xc = min(xx, W - 4);
+        if (POOL == 1) {
+            ri[j][0] = *reinterpret_cast<const float4*>(in + ((size_t)cc * inH + yc) * inW + xc);
+        } else {
+            const float* r0 = in + ((size_t)cc * inH + yc * 2) * inW + xc * 2;
+            const float* r1 = r0 + inW;
+            ri[j][0] = *reinterpret_cast<const float4*>(r0); ri[j][NR > 1 ? 1 : 0] = *reinterpret_cast<const float4*>(r0 + 4);
+            ri[j][NR > 2 ? 2 : 0] = *reinterpret_cast<const float4*>(r1); ri[j][NR > 3 ? 3 : 0] = *reinterpret_cast<const float4*>(r1 + 4);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+        const int idx = min(t + 256 * j, ROWS * 2 - 1), row = idx >> 1, side = idx & 1;
+        const int c = row / TH, rr = row % TH;
+        const int yy = y0 + rr - 1, xx = side ? x0 + CT_W : x0 - 1;
+        ok |= (unsigned)(t + 256 * j < ROWS * 2 && c < CIN && yy >= 0 && yy < H && xx >= 0 && xx < W) << (16 + j);
+        const int cc = min(c, CIN - 1), yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
+        if (POOL == 1) {
+            rh[j][0] = in[((size_t)cc * inH + yc) * inW + xc];
+        } else {
+            const float* r0 = in + ((size_t)cc * inH + yc * 2) * inW + xc * 2;
+            rh[j][0] = r0[0]; rh[j][NR > 1 ? 1 : 0] = r0[1]; rh[j][NR > 2 ? 2 : 0] = r0[inW]; rh[j][NR > 3 ? 3 : 0] = r0[inW + 1];
+        }
+    }
+    return ok;
+}
+
+template <int CINP, int POOL, bool M16, int NI, int NH, int NR>
+__device__ __forceinline__ void sweep_stash(float* __restrict__ tl, int t, unsigned ok, const float4 (&ri)[NI][NR], const float (&rh)[NH][NR]) {
+    // registers -> LDS (2x2 average in the order (0,0) (0,1) (1,0) (1,1)); invalid positions (outside the map, padding channels) = 0
+    constexpr int TH = 6, ROWS = CINP * TH, CT_TW = M16 ? CT_W + 8 : CT_W + 2, IC = M16 ? 4 : 1;
+    constexpr int CHS = M16 ? (TH * CT_TW + 63 - 16) / 64 * 64 + 16 : TH * CT_TW;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int idx = t + 256 * j, row = idx >> 3, v4 = idx & 7;
+        if (idx >= ROWS * 8) continue;
+        const int c = row / TH, rr = row % TH;
+        float4 v;
+        if (POOL == 1) v = ri[j][0];
+        else {
+            const float4 a0 = ri[j][0], a1 = ri[j][NR > 1 ? 1 : 0], b0 = ri[j][NR > 2 ? 2 : 0], b1 = ri[j][NR > 3 ? 3 : 0];
+            v = make_float4((((a0.x + a0.y) + b0.x) + b0.y) / 4.0f, (((a0.z + a0.w) + b0.z) + b0.w) / 4.0f,
+                            (((a1.x + a1.y) + b1.x) + b1.y) / 4.0f, (((a1.z + a1.w) + b1.z) + b1.w) / 4.0f);
+        }
+        if (!((ok >> j) & 1u)) v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float* dst = &tl[c * CHS + rr * CT_TW + IC + 4 * v4];
+        if constexpr (M16) *reinterpret_cast<float4*>(dst) = v;
+        else { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
+    }
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+        const int idx = t + 256 * j, row = idx >> 1, side = idx & 1;
+        if (idx >= ROWS * 2) continue;
+        const int c = row / TH, rr = row % TH;
+        float v = POOL == 1 ? rh[j][0] : (((rh[j][0] + rh[j][NR > 1 ? 1 : 0]) + rh[j][NR > 2 ? 2 : 0]) + rh[j][NR > 3 ? 3 : 0]) / 4.0f;
+        if (!((ok >> (16 + j)) & 1u)) v = 0.0f;
+        tl[c * CHS + rr * CT_TW + (side ? IC + CT_W : IC - 1)] = v;
+    }
+}
+
+template <int CIN, int COUT, int POOL, bool DOWN, int NS, bool CLOUT = false>
+__global__ __launch_bounds__(256) void al_conv3x3_sweep_kernel(
+    const float* __restrict__ in, int inH, int inW, float* __restrict__ out, int H, int W,
+    const float* __restrict__ w /*[ci][tap][COUT]*/, const float* __restrict__ alpha, const float* __restrict__ beta,
+    const float* __restrict__ wd /*[ci][COUT]*/, const float* __restrict__ bd, float* __restrict__ idn, size_t fs) {
+    static_assert(COUT == 16 || COUT == 32, "two matrix-core shapes");
+    static_assert(!(DOWN && COUT == 16), "the 1x1 branch is only built for the 32-row shape");
+    in = fsh(in, blockIdx.z, fs); out = fsh(out, blockIdx.z, fs); idn = fsh(idn, blockIdx.z, fs);
+    constexpr bool M16 = COUT == 16;
+    constexpr int KG = M16 ? 4 : 2;
+    constexpr int CINP = (CIN + KG - 1) / KG * KG;
+    constexpr int TH = 6;
+    constexpr int CT_TW = M16 ? CT_W + 8 : CT_W + 2;
+    constexpr int IC = M16 ? 4 : 1;
+    constexpr int CHS = M16 ? (TH * CT_TW + 63 - 16) / 64 * 64 + 16 : TH * CT_TW;
+    constexpr int K = 9 * CINP;
+    constexpr int WLD = COUT;
+    constexpr bool WG = false;       // weights in LDS, staged once per strip (global A operands would queue behind the prefetch: loads return in order)
+    __shared__ __attribute__((aligned(16))) float tile[2][CINP * CHS];
+    __shared__ float wl[WG ? 1 : (K + (DOWN ? CINP : 0)) * WLD];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int x0 = blockIdx.x * CT_W, yb = blockIdx.y * (4 * NS);
+    constexpr int ROWS = CINP * TH, NI = (ROWS * 8 + 255) / 256, NH = (ROWS * 2 + 255) / 256, NR = POOL == 2 ? 4 : 1;
+    float4 ri[NI][NR]; float rh[NH][NR];
+
+    unsigned ok = sweep_load<CIN, CINP, POOL>(in, inH, inW, H, W, x0, yb, t, ri, rh);
+    if constexpr (!WG) {
+#pragma unroll AL_CONV_UNROLL
+        for (int i = t; i < K * WLD; i += 256) {
+            const int co = i % WLD, k = i / WLD, tap = k / CINP, ci = k % CINP;
+            wl[i] = ci < CIN ? w[(ci * 9 + tap) * COUT + co] : 0.0f;
+        }
+        if (DOWN)
+            for (int i = t; i < CINP * WLD; i += 256) {
+                const int co = i % WLD, ci = i / WLD;
+                wl[K * WLD + i] = ci < CIN ? wd[ci * COUT + co] : 0.0f;
+            }
+    }
+    sweep_stash<CINP, POOL, M16>(tile[0], t, ok, ri, rh);
+    __syncthreads();
+
+    // the BN affine of the lane's own output channels, once (r04: inside the epilogue each alpha[co] / beta[co] was a global load
+    // with a full s_waitcnt vmcnt(0) behind it - 8 / 16 serial memory round trips per wave and step, and the wait also drained the
+    // prefetch and the stores in flight)
+    constexpr int NCO = M16 ? 4 : 16;
+    float alr[NCO], ber[NCO], bdr[DOWN ? NCO : 1];
+#pragma unroll
+    for (int r = 0; r < NCO; ++r) {
+        const int co = M16 ? 4 * (lane >> 4) + r : acc_row(r, lane);
+        alr[r] = alpha[co]; ber[r] = beta[co];
+        if (DOWN) bdr[r] = bd[co];
+    }
+#pragma unroll 1
+    for (int st = 0; st < NS; ++st) {
+        const int y0 = yb + 4 * st;
+        if (y0 >= H) break;                                    // (uniform)
+        const bool more = st + 1 < NS && y0 + 4 < H;
+        // (unconditional: under `if (more)` the registers become phis whose copies wait for the loads in front of the matrix loop;
+        //  the last step re-reads its own tile from the caches and drops it)
+        ok = sweep_load<CIN, CINP, POOL>(in, inH, inW, H, W, x0, more ? y0 + 4 : y0, t, ri, rh);
+        __builtin_amdgcn_sched_barrier(0);     // (the scheduler would pull the pooling adds of the stash - and the wait for these loads - up here)
+        const float* tl = tile[st & 1];
+        const int y = y0 + wave;
+        if constexpr (M16) {
+            const int kk = lane >> 4, n = lane & 15;
+            f32x4 acc[2];
+            acc[0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; acc[1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            const float* bbase = tl + kk * CHS + wave * CT_TW + (IC - 1) + n;
+            const float* abase = wl + kk * WLD + n;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+                for (int g4 = 0; g4 < CINP / 4; ++g4) {
+                    const float a = abase[(tap * CINP + 4 * g4) * WLD];
+                    const int boff = (4 * g4) * CHS + (tap / 3) * CT_TW + (tap % 3);
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf)
+                        acc[hf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bbase[boff + 16 * hf], acc[hf], 0, 0, 0);
+                }
+            }
+            if (y < H) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int x = x0 + 16 * hf + n;
+                    if (x >= W) continue;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int co = 4 * kk + i;
+                        out[((size_t)co * H + y) * W + x] = selu(fmaf(acc[hf][i], alr[i], ber[i]));
+                    }
+                }
+            }
+        } else {
+            const int h = lane >> 5, px = lane & 31;
+            f32x16 acc, dn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; dn[r] = 0.0f; }
+            const float* bbase = tl + h * CHS + wave * CT_TW + (IC - 1) + px;
+            const float* abase = wl + h * WLD + px;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+                for (int c2 = 0; c2 < CINP / 2; ++c2) {
+                    const int koff = (tap * CINP + 2 * c2) * WLD;
+                    const int boff = (2 * c2) * CHS + (tap / 3) * CT_TW + (tap % 3);
+                    const float a = WG ? w[((2 * c2 + h) * 9 + tap) * COUT + px] : abase[koff];
+                    acc = sslam::mfma32(a, bbase[boff], acc);
+                }
+            }
+            if (DOWN) {
+#pragma unroll
+                for (int c2 = 0; c2 < CINP / 2; ++c2) {
+                    const float a = WG ? wd[(2 * c2 + h) * COUT + px] : abase[(K + 2 * c2) * WLD];
+                    dn = sslam::mfma32(a, bbase[(2 * c2) * CHS + CT_TW + 1], dn);
+                }
+            }
+            const int x = x0 + px;
+            if (x < W && y < H) {
+                if constexpr (CLOUT) {
+                    _Float16* oh = reinterpret_cast<_Float16*>(out);
+                    const size_t plane = (size_t)H * W * 32;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        float vv[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = 4 * g4 + e, co = acc_row(r, lane);
+                            vv[e] = selu(fmaf(acc[r], alr[r], ber[r]));
+                            if (DOWN) idn[((size_t)co * H + y) * W + x] = dn[r] + bdr[r];
+                        }
+                        unsigned h01, l01, h23, l23; float amax = 0.0f;
+                        sslam::split2_fast(vv[0], vv[1], h01, l01, amax);
+                        sslam::split2_fast(vv[2], vv[3], h23, l23, amax);
+                        const size_t o = ((size_t)y * W + x) * 32 + 8 * g4 + 4 * (lane >> 5);
+                        *reinterpret_cast<uint2*>(oh + o) = make_uint2(h01, h23);
+                        *reinterpret_cast<uint2*>(oh + plane + o) = make_uint2(l01, l23);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = acc_row(r, lane);
+                        const size_t o = ((size_t)co * H + y) * W + x;
+                        out[o] = selu(fmaf(acc[r], alr[r], ber[r]));
+                        if (DOWN) idn[o] = dn[r] + bdr[r];
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) sweep_stash<CINP, POOL, M16>(tile[(st + 1) & 1], t, ok, ri, rh);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------ //
 //  1b. block2.conv2 (32 -> 32 at 1/2 resolution, + BN + residual + SELU) on the SPLIT-PRECISION matrix path (r04).
 //      The exact-fp32 MFMA form above spent 23 of its 29 us per frame in the matrix loop (144 v_mfma_f32_32x32x2_f32 of 64
 //      cycles per 32 x 32 output tile, the fp32 matrix rate is 1/16 of the f16 rate; CONV_ABL = 1: 6 us without the loop).
@@ -401,6 +646,9 @@ __global__ __launch_bounds__(256) void al_conv3x3_mfma_kernel(
 constexpr int C32_PS = 40;                          // halves per tile pixel (32 channels + 8 pad)
 #ifndef AL_C32_FILL
 #define AL_C32_FILL 8
+#endif
+#ifndef AL_C32_ABL
+#define AL_C32_ABL 0       // experiments: 1 two k-steps instead of 18, 2 no tile loads, 4 no residual read / output stores
 #endif
 __global__ void al_conv32_wfrag_kernel(const float* __restrict__ w /*[ci 32][tap 9][co 32]*/, _Float16* __restrict__ wf) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;       // one element (co, k)
@@ -432,7 +680,7 @@ __global__ __launch_bounds__(256) void al_conv32_h_kernel(const _Float16* __rest
         const int c4 = idx & 3, pxl = (idx >> 2) % TW, rr = ((idx >> 2) / TW) % TH, pl = (idx >> 2) / (TW * TH);
         const int yy = y0 + rr - 1, xx = x0 + pxl - 1;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W && !(AL_C32_ABL & 2))
             v = *reinterpret_cast<const uint4*>(in + pl * plane + ((size_t)yy * W + xx) * 32 + 8 * c4);
         *reinterpret_cast<uint4*>(&tile[pl][(rr * TW + pxl) * C32_PS + 8 * c4]) = v;
     }
@@ -446,8 +694,22 @@ __global__ __launch_bounds__(256) void al_conv32_h_kernel(const _Float16* __rest
     const _Float16* bh = &tile[0][((RPW * wave) * TW + px) * C32_PS + 8 * h];
     const _Float16* bl = &tile[1][((RPW * wave) * TW + px) * C32_PS + 8 * h];
     const _Float16* af = wf + (h * 32 + px) * 8;               // + ((ks * 2 + plane) * 2) * 32 * 8
+    // BN affine and residual of the lane's own outputs: loaded here, in flight under the matrix loop (r04: inside the epilogue
+    // every alpha[co] / beta[co] / resid[o] was a load with a full s_waitcnt behind it - 16 serial round trips per wave; the
+    // epilogue was 73 of the kernel's 125 us per launch)
+    float alr[16], ber[16], rsd[RPW][16];
+    {
+        const int xq = min(x0 + px, W - 1);
 #pragma unroll
-    for (int ks = 0; ks < 18; ++ks) {
+        for (int r = 0; r < 16; ++r) {
+            const int co = acc_row(r, lane);
+            alr[r] = alpha[co]; ber[r] = beta[co];
+#pragma unroll
+            for (int q = 0; q < RPW; ++q) rsd[q][r] = resid[((size_t)co * H + min(y0 + RPW * wave + q, H - 1)) * W + xq];
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < ((AL_C32_ABL & 1) ? 2 : 18); ++ks) {
         const int tap = ks >> 1, boff = ((tap / 3) * TW + (tap % 3)) * C32_PS + 16 * (ks & 1);
         const sslam::half8 ah = *reinterpret_cast<const sslam::half8*>(af + (size_t)(ks * 2 + 0) * 2 * 32 * 8);
         const sslam::half8 al = *reinterpret_cast<const sslam::half8*>(af + (size_t)(ks * 2 + 1) * 2 * 32 * 8);
@@ -471,7 +733,11 @@ __global__ __launch_bounds__(256) void al_conv32_h_kernel(const _Float16* __rest
             const int co = acc_row(r, lane);
             const size_t o = ((size_t)co * H + y) * W + x;
             const float acc = c1[q][r] + c2[q][r] * sslam::SPLIT_INV;
-            out[o] = selu(fmaf(acc, alpha[co], beta[co]) + resid[o]);
+#if AL_C32_ABL & 4
+            if (acc == 123.456f) out[o] = acc;
+#else
+            out[o] = selu(fmaf(acc, alr[r], ber[r]) + rsd[q][r]);
+#endif
         }
     }
 }
@@ -482,7 +748,7 @@ __global__ __launch_bounds__(256) void al_conv32_h_kernel(const _Float16* __rest
 // ------------------------------------------------------------------------ //
 __global__ void al_avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int H, int W,
                                   int P, size_t fs, float* __restrict__ out_cl /* [pixel][C] copy for al_dcn_col (r04) */) {   // out [C][H/P][W/P]
-    in = fsh(in, blockIdx.y, fs); out = fsh(out, blockIdx.y, fs); out_cl = fsh(out_cl, blockIdx.y, fs);
+    in = fsh(in, blockIdx.y, fs); out = fsh(out, blockIdx.y, fs); out_cl = fsh0(out_cl, blockIdx.y, fs);
     const int oh = H / P, ow = W / P;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= C * oh * ow) return;
@@ -663,7 +929,7 @@ __global__ __launch_bounds__(256) void al_dcn_epilogue_kernel(const float* __res
                                                               const float* __restrict__ bd, size_t fs, float* __restrict__ out_cl) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= COUT * HW) return;
-    part = fsh(part, blockIdx.y, fs); out = fsh(out, blockIdx.y, fs); out_cl = fsh(out_cl, blockIdx.y, fs);
+    part = fsh(part, blockIdx.y, fs); out = fsh(out, blockIdx.y, fs); out_cl = fsh0(out_cl, blockIdx.y, fs);
     const int co = i / HW;
     float acc = part[i];
 #pragma unroll 6
@@ -696,7 +962,7 @@ __global__ __launch_bounds__(256) void al_gate_kernel(const float* __restrict__ 
                                                       float* __restrict__ out_cl /*[HW][32]*/, size_t fs) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= HW) return;
-    in = fsh(in, blockIdx.y, fs); out = fsh(out, blockIdx.y, fs); out_cl = fsh(out_cl, blockIdx.y, fs);
+    in = fsh(in, blockIdx.y, fs); out = fsh(out, blockIdx.y, fs); out_cl = fsh0(out_cl, blockIdx.y, fs);
     float acc[32];
 #pragma unroll
     for (int o = 0; o < 32; ++o) acc[o] = 0.0f;
@@ -720,7 +986,7 @@ __global__ void al_gate_small_kernel(const float* __restrict__ in, float* __rest
                                      const float* __restrict__ w /*[ci][32]*/, float* __restrict__ out_cl, size_t fs) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 32 * HW) return;
-    in = fsh(in, blockIdx.y, fs); out = fsh(out, blockIdx.y, fs); out_cl = fsh(out_cl, blockIdx.y, fs);
+    in = fsh(in, blockIdx.y, fs); out = fsh(out, blockIdx.y, fs); out_cl = fsh0(out_cl, blockIdx.y, fs);
     const int co = i / HW, p = i % HW;
     float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll 8                 // 16 loads in flight per thread: the loop is pure load latency otherwise
@@ -1726,17 +1992,35 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
     //  more workgroups per CU whose load / MFMA / store phases overlap: 16 -> 16 with RPW 1: 36 -> 27 us per frame,
     //  3 -> 16 with 2: 10.9 -> 9.7, 16 -> 32 with 1: 18.3 -> 16.9; 32 -> 32 stays at 2 (1: 32.7 vs 30.9))
     dim3 g1a(sslam::cdiv(Wp, CT_W), sslam::cdiv(Hp, 8), uF), g1b(sslam::cdiv(Wp, CT_W), sslam::cdiv(Hp, 4), uF);
+#ifndef AL_SWEEP_NS
+#define AL_SWEEP_NS 4
+#endif
+#if AL_SWEEP_NS > 0
+    hipLaunchKernelGGL((al_conv3x3_sweep_kernel<3, 16, 1, false, AL_SWEEP_NS>), dim3(sslam::cdiv(Wp, CT_W), sslam::cdiv(Hp, 4 * AL_SWEEP_NS), uF),
+                       dim3(256), 0, s, g->img, Hp, Wp, g->x1a, Hp, Wp, g->b1c1.w, g->b1c1.a, g->b1c1.b, nullptr, nullptr, nullptr, fs);
+#else
     hipLaunchKernelGGL((al_conv3x3_mfma_kernel<3, 16, 1, false, false, 2>), g1a, dim3(256), 0, s, g->img, Hp, Wp, g->x1a, Hp,
                        Wp, g->b1c1.w, g->b1c1.a, g->b1c1.b, nullptr, nullptr, nullptr, nullptr, fs);
+#endif
+#if AL_SWEEP_NS > 0
+    hipLaunchKernelGGL((al_conv3x3_sweep_kernel<16, 16, 1, false, AL_SWEEP_NS>), dim3(sslam::cdiv(Wp, CT_W), sslam::cdiv(Hp, 4 * AL_SWEEP_NS), uF),
+                       dim3(256), 0, s, g->x1a, Hp, Wp, g->x1, Hp, Wp, g->b1c2.w, g->b1c2.a, g->b1c2.b, nullptr, nullptr, nullptr, fs);
+#else
     hipLaunchKernelGGL((al_conv3x3_mfma_kernel<16, 16, 1, false, false, 1>), g1b, dim3(256), 0, s, g->x1a, Hp, Wp, g->x1, Hp,
                        Wp, g->b1c2.w, g->b1c2.a, g->b1c2.b, nullptr, nullptr, nullptr, nullptr, fs);
+#endif
     // block2 at 1/2: conv1 pools on load and also emits the downsample branch
     const int H2 = Hp / 2, W2 = Wp / 2;
     dim3 g2a(sslam::cdiv(W2, CT_W), sslam::cdiv(H2, 4), uF), g2b(sslam::cdiv(W2, CT_W), sslam::cdiv(H2, 8), uF);
     // (r04: t2 leaves block2.conv1 channel-last as fp16 (hi, lo) planes - the bytes of the planar fp32 map - for the
     //  split-precision form of block2.conv2)
+#if AL_SWEEP_NS > 0
+    hipLaunchKernelGGL((al_conv3x3_sweep_kernel<16, 32, 2, true, AL_SWEEP_NS, true>), dim3(sslam::cdiv(W2, CT_W), sslam::cdiv(H2, 4 * AL_SWEEP_NS), uF),
+                       dim3(256), 0, s, g->x1, Hp, Wp, g->t2, H2, W2, g->b2c1.w, g->b2c1.a, g->b2c1.b, g->b2dw, g->b2db, g->idn2, fs);
+#else
     hipLaunchKernelGGL((al_conv3x3_mfma_kernel<16, 32, 2, true, false, 1, true>), g2a, dim3(256), 0, s, g->x1, Hp, Wp, g->t2, H2, W2,
                        g->b2c1.w, g->b2c1.a, g->b2c1.b, g->b2dw, g->b2db, g->idn2, nullptr, fs);
+#endif
     const _Float16* t2h = reinterpret_cast<const _Float16*>(g->t2);
 #ifndef AL_C32_RPW
 #define AL_C32_RPW 1      // 4-row tiles for every batch size: 15.7 us per frame at F = 8 against 20.9 with 8-row tiles (more, smaller workgroups)
