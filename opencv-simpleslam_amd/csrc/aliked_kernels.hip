@@ -478,8 +478,30 @@ __device__ __forceinline__ void sweep_stash(float* __restrict__ tl, int t, unsig
     }
 }
 
+#ifndef AL_SWEEP_ABL
+#define AL_SWEEP_ABL 0     // experiments: 1 one tap instead of nine, 2 no prefetch loads, 4 no output stores, 8 no SELU
+#endif
+#ifndef AL_FAST_SELU
+#define AL_FAST_SELU 1
+#endif
+// SELU of the sweep epilogues: exp(x) - 1 on the hardware exponential (v_exp_f32, 1 ulp) instead of expm1f - 7 instead of 30
+// vector instructions per output; the sweeps are bound by vector-instruction issue (471 per wave and step next to 72
+// MFMAs; one MFMA hides ~6).  Absolute error <= 1.2e-7 x 1.76 (the subtraction near x = 0), i.e. fp32 rounding of an O(1) value.
+__device__ __forceinline__ float selu_fast(float x) {
+    return SELU_SCALE * (x > 0.0f ? x : SELU_ALPHA * (__expf(x) - 1.0f));
+}
+#if AL_SWEEP_ABL & 8
+#define SWEEP_SELU(v) (v)
+#elif AL_FAST_SELU
+#define SWEEP_SELU(v) selu_fast(v)
+#else
+#define SWEEP_SELU(v) selu(v)
+#endif
+#ifndef AL_SWEEP_WPE
+#define AL_SWEEP_WPE 2      // 228 registers, two waves per SIMD: 129 us per launch against 135 squeezed into 168 with spills
+#endif
 template <int CIN, int COUT, int POOL, bool DOWN, int NS, bool CLOUT = false>
-__global__ __launch_bounds__(256) void al_conv3x3_sweep_kernel(
+__global__ __launch_bounds__(256, COUT == 32 ? AL_SWEEP_WPE : 4) void al_conv3x3_sweep_kernel(
     const float* __restrict__ in, int inH, int inW, float* __restrict__ out, int H, int W,
     const float* __restrict__ w /*[ci][tap][COUT]*/, const float* __restrict__ alpha, const float* __restrict__ beta,
     const float* __restrict__ wd /*[ci][COUT]*/, const float* __restrict__ bd, float* __restrict__ idn, size_t fs) {
@@ -496,7 +518,11 @@ __global__ __launch_bounds__(256) void al_conv3x3_sweep_kernel(
     constexpr int K = 9 * CINP;
     constexpr int WLD = COUT;
     constexpr bool WG = false;       // weights in LDS, staged once per strip (global A operands would queue behind the prefetch: loads return in order)
-    __shared__ __attribute__((aligned(16))) float tile[2][CINP * CHS];
+#ifndef AL_SWEEP_DB
+#define AL_SWEEP_DB 1      // 2: two LDS tiles (one barrier per step); 1: one tile, two barriers per step, twice the workgroups per CU
+#endif
+    constexpr int DB = AL_SWEEP_DB;
+    __shared__ __attribute__((aligned(16))) float tile[DB][CINP * CHS];
     __shared__ float wl[WG ? 1 : (K + (DOWN ? CINP : 0)) * WLD];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int x0 = blockIdx.x * CT_W, yb = blockIdx.y * (4 * NS);
@@ -519,16 +545,19 @@ __global__ __launch_bounds__(256) void al_conv3x3_sweep_kernel(
     sweep_stash<CINP, POOL, M16>(tile[0], t, ok, ri, rh);
     __syncthreads();
 
-    // the BN affine of the lane's own output channels, once (r04: inside the epilogue each alpha[co] / beta[co] was a global load
-    // with a full s_waitcnt vmcnt(0) behind it - 8 / 16 serial memory round trips per wave and step, and the wait also drained the
-    // prefetch and the stores in flight)
-    constexpr int NCO = M16 ? 4 : 16;
-    float alr[NCO], ber[NCO], bdr[DOWN ? NCO : 1];
+    // the BN affine of the output channels, once per strip: in registers for the 16-row shape (4 + 4 per lane), in LDS for the
+    // 32-row shape (48 registers there would leave one wave per SIMD).  (r04: inside the epilogue each alpha[co] / beta[co]
+    // was a global load with a full s_waitcnt vmcnt(0) behind it - 8 / 16 serial memory round trips per wave and step, and
+    // the wait also drained the prefetch and the stores in flight)
+    constexpr int NCO = M16 ? 4 : 1;
+    float alr[NCO], ber[NCO];
+    __shared__ float aff[M16 ? 1 : 3 * 32];
+    if constexpr (M16) {
 #pragma unroll
-    for (int r = 0; r < NCO; ++r) {
-        const int co = M16 ? 4 * (lane >> 4) + r : acc_row(r, lane);
-        alr[r] = alpha[co]; ber[r] = beta[co];
-        if (DOWN) bdr[r] = bd[co];
+        for (int r = 0; r < 4; ++r) { alr[r] = alpha[4 * (lane >> 4) + r]; ber[r] = beta[4 * (lane >> 4) + r]; }
+    } else {
+        if (t < 32) { aff[t] = alpha[t]; aff[32 + t] = beta[t]; aff[64 + t] = DOWN ? bd[t] : 0.0f; }
+        __syncthreads();
     }
 #pragma unroll 1
     for (int st = 0; st < NS; ++st) {
@@ -537,9 +566,9 @@ __global__ __launch_bounds__(256) void al_conv3x3_sweep_kernel(
         const bool more = st + 1 < NS && y0 + 4 < H;
         // (unconditional: under `if (more)` the registers become phis whose copies wait for the loads in front of the matrix loop;
         //  the last step re-reads its own tile from the caches and drops it)
-        ok = sweep_load<CIN, CINP, POOL>(in, inH, inW, H, W, x0, more ? y0 + 4 : y0, t, ri, rh);
+        if (!(AL_SWEEP_ABL & 2)) ok = sweep_load<CIN, CINP, POOL>(in, inH, inW, H, W, x0, more ? y0 + 4 : y0, t, ri, rh);
         __builtin_amdgcn_sched_barrier(0);     // (the scheduler would pull the pooling adds of the stash - and the wait for these loads - up here)
-        const float* tl = tile[st & 1];
+        const float* tl = tile[DB == 2 ? (st & 1) : 0];
         const int y = y0 + wave;
         if constexpr (M16) {
             const int kk = lane >> 4, n = lane & 15;
@@ -548,7 +577,7 @@ __global__ __launch_bounds__(256) void al_conv3x3_sweep_kernel(
             const float* bbase = tl + kk * CHS + wave * CT_TW + (IC - 1) + n;
             const float* abase = wl + kk * WLD + n;
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
+            for (int tap = 0; tap < ((AL_SWEEP_ABL & 1) ? 1 : 9); ++tap) {
 #pragma unroll
                 for (int g4 = 0; g4 < CINP / 4; ++g4) {
                     const float a = abase[(tap * CINP + 4 * g4) * WLD];
@@ -558,16 +587,15 @@ __global__ __launch_bounds__(256) void al_conv3x3_sweep_kernel(
                         acc[hf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bbase[boff + 16 * hf], acc[hf], 0, 0, 0);
                 }
             }
-            if (y < H) {
+            if (y < H && !((AL_SWEEP_ABL & 4) && acc[0][0] != 123.456f)) {
+                // wave-uniform row pointer + a 32-bit lane offset that does not depend on the step (channel plane + column)
+                float* orow = out + (size_t)y * W + x0;
+                const unsigned HW = (unsigned)H * W, lo = (unsigned)(4 * kk) * HW + n;
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
-                    const int x = x0 + 16 * hf + n;
-                    if (x >= W) continue;
+                    if (x0 + 16 * hf + n >= W) continue;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int co = 4 * kk + i;
-                        out[((size_t)co * H + y) * W + x] = selu(fmaf(acc[hf][i], alr[i], ber[i]));
-                    }
+                    for (int i = 0; i < 4; ++i) orow[lo + i * HW + 16 * hf] = SWEEP_SELU(fmaf(acc[hf][i], alr[i], ber[i]));
                 }
             }
         } else {
@@ -578,7 +606,7 @@ __global__ __launch_bounds__(256) void al_conv3x3_sweep_kernel(
             const float* bbase = tl + h * CHS + wave * CT_TW + (IC - 1) + px;
             const float* abase = wl + h * WLD + px;
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
+            for (int tap = 0; tap < ((AL_SWEEP_ABL & 1) ? 1 : 9); ++tap) {
 #pragma unroll
                 for (int c2 = 0; c2 < CINP / 2; ++c2) {
                     const int koff = (tap * CINP + 2 * c2) * WLD;
@@ -595,7 +623,11 @@ __global__ __launch_bounds__(256) void al_conv3x3_sweep_kernel(
                 }
             }
             const int x = x0 + px;
-            if (x < W && y < H) {
+            if (x < W && y < H && !((AL_SWEEP_ABL & 4) && acc[0] != 123.456f)) {
+                // planar outputs: wave-uniform row pointer + 32-bit lane offset (channel plane of the lane half + column);
+                // register r adds the plane of acc_row(r, .) = 8 (r / 4) + r % 4 (+ 4 h in the lane part)
+                const unsigned HW = (unsigned)H * W, lo = (unsigned)(4 * h) * HW + px;
+                float* irow = DOWN ? idn + (size_t)y * W + x0 : nullptr;
                 if constexpr (CLOUT) {
                     _Float16* oh = reinterpret_cast<_Float16*>(out);
                     const size_t plane = (size_t)H * W * 32;
@@ -605,8 +637,8 @@ __global__ __launch_bounds__(256) void al_conv3x3_sweep_kernel(
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int r = 4 * g4 + e, co = acc_row(r, lane);
-                            vv[e] = selu(fmaf(acc[r], alr[r], ber[r]));
-                            if (DOWN) idn[((size_t)co * H + y) * W + x] = dn[r] + bdr[r];
+                            vv[e] = SWEEP_SELU(fmaf(acc[r], aff[co], aff[32 + co]));
+                            if (DOWN) irow[lo + (8 * (r / 4) + r % 4) * HW] = dn[r] + aff[64 + co];
                         }
                         unsigned h01, l01, h23, l23; float amax = 0.0f;
                         sslam::split2_fast(vv[0], vv[1], h01, l01, amax);
@@ -619,16 +651,249 @@ __global__ __launch_bounds__(256) void al_conv3x3_sweep_kernel(
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int co = acc_row(r, lane);
-                        const size_t o = ((size_t)co * H + y) * W + x;
-                        out[o] = selu(fmaf(acc[r], alr[r], ber[r]));
-                        if (DOWN) idn[o] = dn[r] + bdr[r];
+                        float* orow = out + (size_t)y * W + x0;
+                        orow[lo + (8 * (r / 4) + r % 4) * HW] = SWEEP_SELU(fmaf(acc[r], aff[co], aff[32 + co]));
+                        if (DOWN) irow[lo + (8 * (r / 4) + r % 4) * HW] = dn[r] + aff[64 + co];
                     }
                 }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (more) sweep_stash<CINP, POOL, M16>(tile[(st + 1) & 1], t, ok, ri, rh);
+        if (DB == 1) __syncthreads();          // every wave is done reading the tile
+        if (more) sweep_stash<CINP, POOL, M16>(tile[DB == 2 ? ((st + 1) & 1) : 0], t, ok, ri, rh);
         __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------ //
+//  1a'. the 16-output-channel convolutions (block1) as ONE WAVE per workgroup rolling down a 32-pixel column strip (r04).
+//      The sweep above still synchronises four waves twice per step and reads its A operands from LDS; its waves wait at
+//      barriers while the SIMDs they share with other workgroups are busy.  Here a wave owns `hs` output rows: a ring of three
+//      input rows in LDS (row y + 2 replaces row y - 1 after step y; wave-local, no workgroup barrier), the weights of the
+//      lane's A fragments in REGISTERS for the whole strip (9 taps x CINP / 4 groups), the next row prefetched into registers
+//      under the matrix loop, no halo rows re-read.  Accumulation order per output as in the kernels above (bit-identical).
+//      LDS row stride 48 floats: the four k-lanes (channels 4 g + kk) land on banks 0 / 48 / 32 / 16 + n.
+// ------------------------------------------------------------------------ //
+template <int CIN, bool SPLIT_OUT = false>      // SPLIT_OUT: the map leaves channel-last as fp16 (hi, lo) planes [H][W][16] for al_conv16h_rows_kernel
+__global__ __launch_bounds__(64) void al_conv16_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, int hs,
+                                                           const float* __restrict__ w /*[ci][tap][16]*/,
+                                                           const float* __restrict__ alpha, const float* __restrict__ beta, size_t fs) {
+    in = fsh(in, blockIdx.z, fs); out = fsh(out, blockIdx.z, fs);
+    constexpr int CINP = (CIN + 3) / 4 * 4, G = CINP / 4, RS = 48, SLOT = CINP * RS, NI = (CINP * 8 + 63) / 64;
+    __shared__ __attribute__((aligned(16))) float ring[3 * SLOT];
+    const int lane = threadIdx.x, kk = lane >> 4, n = lane & 15;
+    const int x0 = blockIdx.x * CT_W, yb = blockIdx.y * hs, ye = min(yb + hs, H);
+    float a[9][G];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int g = 0; g < G; ++g) a[tap][g] = 4 * g + kk < CIN ? w[((4 * g + kk) * 9 + tap) * 16 + n] : 0.0f;
+    float alr[4], ber[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { alr[i] = alpha[4 * kk + i]; ber[i] = beta[4 * kk + i]; }
+    // the lane's pieces of an input row: NI float4 of the interior (channel = idx / 8, 4 pixels) + one halo value
+    int ich[NI], iv4[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) { const int idx = min(lane + 64 * j, CINP * 8 - 1); ich[j] = idx >> 3; iv4[j] = idx & 7; }
+    const int hl = min(lane, CINP * 2 - 1), hch = hl >> 1, hside = hl & 1;
+    const int hx = hside ? x0 + CT_W : x0 - 1;
+    const bool hok = lane < CINP * 2 && hch < CIN && hx >= 0 && hx < W;
+    const size_t HW = (size_t)H * W;
+    float4 ri[NI]; float rh;
+    auto load_row = [&](int yy) {               // unconditional, clamped (validity applied at stash time)
+        const int yc = min(max(yy, 0), H - 1);
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+            ri[j] = *reinterpret_cast<const float4*>(in + (size_t)min(ich[j], CIN - 1) * HW + (size_t)yc * W + x0 + 4 * iv4[j]);
+        rh = in[(size_t)min(hch, CIN - 1) * HW + (size_t)yc * W + min(max(hx, 0), W - 1)];
+    };
+    auto stash_row = [&](int slot, int yy) {
+        const bool rowok = yy >= 0 && yy < H;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            if (lane + 64 * j >= CINP * 8) continue;
+            const float4 v = rowok && ich[j] < CIN ? ri[j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            *reinterpret_cast<float4*>(&ring[slot * SLOT + ich[j] * RS + 4 + 4 * iv4[j]]) = v;
+        }
+        if (lane < CINP * 2) ring[slot * SLOT + hch * RS + (hside ? 4 + CT_W : 3)] = rowok && hok ? rh : 0.0f;
+    };
+    // rows yb - 1, yb, yb + 1 -> slots 0, 1, 2
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { load_row(yb - 1 + r); stash_row(r, yb - 1 + r); }
+    __syncthreads();
+    const float* bl = ring + kk * RS + 3 + n;
+    const unsigned HWu = (unsigned)HW, lo = (unsigned)(4 * kk) * HWu + n;
+    auto step = [&](auto ph, int y) {           // rows y - 1, y, y + 1 in slots PH, PH + 1, PH + 2 (mod 3); row y + 2 -> slot PH
+        constexpr int PH = decltype(ph)::value;
+        load_row(y + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[2];
+        acc[0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; acc[1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            constexpr int dummy = 0; (void)dummy;
+            const int slot = (PH + tap / 3) % 3;
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+                    acc[hf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tap][g], bl[slot * SLOT + 4 * g * RS + tap % 3 + 16 * hf], acc[hf], 0, 0, 0);
+        }
+        if constexpr (SPLIT_OUT) {
+            // a lane holds channels 4 kk .. 4 kk + 3 of its pixel: 8 bytes per plane, the four k-lanes of a pixel side by side
+            _Float16* oh = reinterpret_cast<_Float16*>(out) + ((size_t)y * W + x0) * 16 + 4 * kk;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                if (x0 + 16 * hf + n >= W) continue;
+                float vv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) vv[i] = SWEEP_SELU(fmaf(acc[hf][i], alr[i], ber[i]));
+                unsigned h01, l01, h23, l23; float amax = 0.0f;
+                sslam::split2_fast(vv[0], vv[1], h01, l01, amax);
+                sslam::split2_fast(vv[2], vv[3], h23, l23, amax);
+                *reinterpret_cast<uint2*>(oh + (16 * hf + n) * 16) = make_uint2(h01, h23);
+                *reinterpret_cast<uint2*>(oh + HW * 16 + (16 * hf + n) * 16) = make_uint2(l01, l23);
+            }
+        } else {
+        float* orow = out + (size_t)y * W + x0;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            if (x0 + 16 * hf + n >= W) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) orow[lo + i * HWu + 16 * hf] = SWEEP_SELU(fmaf(acc[hf][i], alr[i], ber[i]));
+        }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                         // (one wave: orders this step's LDS reads before the overwrite of slot PH)
+        stash_row(PH, y + 2);
+        __syncthreads();
+    };
+    for (int y = yb; y < ye; y += 3) {
+        step(std::integral_constant<int, 0>{}, y);
+        if (y + 1 >= ye) break;
+        step(std::integral_constant<int, 1>{}, y + 1);
+        if (y + 2 >= ye) break;
+        step(std::integral_constant<int, 2>{}, y + 2);
+    }
+}
+
+// ------------------------------------------------------------------------ //
+//  1a''. block1.conv2 (16 -> 16 at full resolution) on the SPLIT-PRECISION matrix path (r04), rolling rows as above.
+//      On the exact-fp32 instruction the layer is matrix-bound (36 v_mfma_f32_16x16x4_f32 of 32 cycles per 16 x 16 outputs:
+//      77 us per launch of 8 frames at the nominal clock, 143 - 150 measured in three different kernel structures).  Here
+//      k = (tap, channel) runs in 5 steps of 32 = two taps x 16 channels on v_mfma_f32_16x16x32_f16, three per step
+//      (hi.hi, hi.lo, lo.hi): 15 MFMAs of 16 cycles.  The input arrives channel-last as fp16 (hi, lo) planes from
+//      al_conv16_rows_kernel<3, true>, so a row of the ring is two contiguous runs of 34 x 32 bytes, copied as they are, and a
+//      B fragment (8 consecutive channels of one tap of one pixel) is one ds_read_b128; ring pixel stride 48 bytes (the 16
+//      lanes of a k-group on distinct 16-byte bank groups).  A fragments (weights) in registers for the whole strip, from a
+//      fragment-ordered split copy [k-step][plane][lane][8].  Relative error per product ~2^-22 (gemm_f16x3.hpp).
+// ------------------------------------------------------------------------ //
+__global__ void al_conv16_wfrag_kernel(const float* __restrict__ w /*[ci 16][tap 9][co 16]*/, _Float16* __restrict__ wf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // (k-step, lane, e)
+    if (i >= 5 * 64 * 8) return;
+    const int e = i & 7, lane = (i >> 3) & 63, ks = i >> 9;
+    const int kk = lane >> 4, co = lane & 15, tap = 2 * ks + (kk >> 1), ci = 8 * (kk & 1) + e;
+    const float v = tap < 9 ? w[(ci * 9 + tap) * 16 + co] : 0.0f;
+    const _Float16 hi = fabsf(v) < 6.103515625e-5f ? (_Float16)0.0f : (_Float16)v;
+    const _Float16 lo = (_Float16)((v - (float)hi) * sslam::SPLIT_SCALE);
+    wf[((ks * 2 + 0) * 64 + lane) * 8 + e] = hi;
+    wf[((ks * 2 + 1) * 64 + lane) * 8 + e] = lo;
+}
+
+__global__ __launch_bounds__(64) void al_conv16h_rows_kernel(const _Float16* __restrict__ in /* hi plane [H][W][16]; lo plane H W 16 halves behind */,
+                                                            float* __restrict__ out, int H, int W, int hs, const _Float16* __restrict__ wf,
+                                                            const float* __restrict__ alpha, const float* __restrict__ beta, size_t fs) {
+    in = fsh(in, blockIdx.z, fs); out = fsh(out, blockIdx.z, fs);
+    constexpr int PXS = 24, ROWH = (CT_W + 2) * PXS, PLH = 3 * ROWH;       // halves: pixel stride, row, plane (3 ring rows)
+    __shared__ __attribute__((aligned(16))) _Float16 ring[2 * PLH];
+    const int lane = threadIdx.x, kk = lane >> 4, n = lane & 15;
+    const int x0 = blockIdx.x * CT_W, yb = blockIdx.y * hs, ye = min(yb + hs, H);
+    const size_t HW = (size_t)H * W;
+    sslam::half8 ah[5], al[5];
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+        ah[ks] = *reinterpret_cast<const sslam::half8*>(wf + ((ks * 2 + 0) * 64 + lane) * 8);
+        al[ks] = *reinterpret_cast<const sslam::half8*>(wf + ((ks * 2 + 1) * 64 + lane) * 8);
+    }
+    float alr[4], ber[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { alr[i] = alpha[4 * kk + i]; ber[i] = beta[4 * kk + i]; }
+    // an input row = 2 planes x 34 pixels x two 16-byte pieces = 136 pieces, three per lane (the last one on 8 lanes)
+    int pofs[3], lofs[3]; bool pok[3], pin[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int idx = lane + 64 * j;
+        pin[j] = idx < 136;
+        const int id = min(idx, 135), pl = id / 68, rem = id % 68, px = rem >> 1, hf8 = rem & 1, xx = x0 - 1 + px;
+        pok[j] = pin[j] && xx >= 0 && xx < W;
+        pofs[j] = min(max(xx, 0), W - 1) * 16 + 8 * hf8;          // halves inside the row of the plane
+        lofs[j] = pl * PLH + px * PXS + 8 * hf8;
+        if (pl) pofs[j] += 0;                                      // (plane offset added as a 64-bit term below)
+    }
+    const size_t plane = HW * 16;
+    uint4 ri[3];
+    auto load_row = [&](int yy) {
+        const int yc = min(max(yy, 0), H - 1);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int id = min(lane + 64 * j, 135);
+            ri[j] = *reinterpret_cast<const uint4*>(in + (id >= 68 ? plane : (size_t)0) + (size_t)yc * W * 16 + pofs[j]);
+        }
+    };
+    auto stash_row = [&](int slot, int yy) {
+        const bool rowok = yy >= 0 && yy < H;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (pin[j]) *reinterpret_cast<uint4*>(&ring[lofs[j] + slot * ROWH]) = rowok && pok[j] ? ri[j] : make_uint4(0u, 0u, 0u, 0u);
+    };
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { load_row(yb - 1 + r); stash_row(r, yb - 1 + r); }
+    __syncthreads();
+    // B fragment of lane (kk, n) in k-step ks: tap 2 ks + (kk >> 1), channels 8 (kk & 1) .. + 7, pixel n (+ 16 hf) + dx
+    int boff[5][3];
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+        const int tap = min(2 * ks + (kk >> 1), 8);                // (the tenth tap has zero weights: any valid address)
+#pragma unroll
+        for (int ph = 0; ph < 3; ++ph) boff[ks][ph] = ((ph + tap / 3) % 3) * ROWH + (n + tap % 3) * PXS + 8 * (kk & 1);
+    }
+    const unsigned HWu = (unsigned)HW, lo = (unsigned)(4 * kk) * HWu + n;
+    auto step = [&](auto ph, int y) {
+        constexpr int PH = decltype(ph)::value;
+        load_row(y + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 c1[2], c2[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) { c1[hf] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; c2[hf] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const sslam::half8 xh = *reinterpret_cast<const sslam::half8*>(&ring[boff[ks][PH] + 16 * hf * PXS]);
+                const sslam::half8 xl = *reinterpret_cast<const sslam::half8*>(&ring[boff[ks][PH] + 16 * hf * PXS + PLH]);
+                c1[hf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], xh, c1[hf], 0, 0, 0);
+                c2[hf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], xl, c2[hf], 0, 0, 0);
+                c2[hf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks], xh, c2[hf], 0, 0, 0);
+            }
+        float* orow = out + (size_t)y * W + x0;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            if (x0 + 16 * hf + n >= W) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                orow[lo + i * HWu + 16 * hf] = SWEEP_SELU(fmaf(c1[hf][i] + c2[hf][i] * sslam::SPLIT_INV, alr[i], ber[i]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        stash_row(PH, y + 2);
+        __syncthreads();
+    };
+    for (int y = yb; y < ye; y += 3) {
+        step(std::integral_constant<int, 0>{}, y);
+        if (y + 1 >= ye) break;
+        step(std::integral_constant<int, 1>{}, y + 1);
+        if (y + 2 >= ye) break;
+        step(std::integral_constant<int, 2>{}, y + 2);
     }
 }
 
@@ -1902,6 +2167,7 @@ struct sslam_aliked {
     float *kp_norm, *kp_score, *patch, *h32, *pos, *sampled, *feats, *raw;
     _Float16 *d_sf_s, *d_agg_s;          // split (hi | lo) copies of the two large descriptor-head weight matrices
     _Float16* b2c2f;                     // block2.conv2 weights, split, fragment order (al_conv32_wfrag_kernel)
+    _Float16* b1c2f;                     // block1.conv2 weights, split, fragment order (al_conv16_wfrag_kernel)
     float *p3cl, *t3cl, *p4cl, *t4cl;    // channel-last copies of the deformable layers' inputs (al_dcn_col)
     float *out_xy, *out_desc, *out_score;
     int32_t* out_n;
@@ -1995,14 +2261,35 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
 #ifndef AL_SWEEP_NS
 #define AL_SWEEP_NS 4
 #endif
-#if AL_SWEEP_NS > 0
+#ifndef AL_ROWS_HS
+#define AL_ROWS_HS 20
+#endif
+#if AL_ROWS_HS > 0
+    // one wave per workgroup, `hs` rows each: ~4 096 waves (four per SIMD) when the batch allows
+    const int hs = std::max(4, std::min(AL_ROWS_HS, (int)((size_t)Hp * (Wp / CT_W) * uF / 4096)));
+#ifndef AL_B1C2_SPLIT
+#define AL_B1C2_SPLIT 1
+#endif
+#if AL_B1C2_SPLIT
+    hipLaunchKernelGGL((al_conv16_rows_kernel<3, true>), dim3(sslam::cdiv(Wp, CT_W), sslam::cdiv(Hp, hs), uF), dim3(64), 0, s, g->img, g->x1a, Hp, Wp,
+                       hs, g->b1c1.w, g->b1c1.a, g->b1c1.b, fs);
+    hipLaunchKernelGGL(al_conv16h_rows_kernel, dim3(sslam::cdiv(Wp, CT_W), sslam::cdiv(Hp, hs), uF), dim3(64), 0, s,
+                       reinterpret_cast<const _Float16*>(g->x1a), g->x1, Hp, Wp, hs, g->b1c2f, g->b1c2.a, g->b1c2.b, fs);
+#else
+    hipLaunchKernelGGL((al_conv16_rows_kernel<3>), dim3(sslam::cdiv(Wp, CT_W), sslam::cdiv(Hp, hs), uF), dim3(64), 0, s, g->img, g->x1a, Hp, Wp,
+                       hs, g->b1c1.w, g->b1c1.a, g->b1c1.b, fs);
+    hipLaunchKernelGGL((al_conv16_rows_kernel<16>), dim3(sslam::cdiv(Wp, CT_W), sslam::cdiv(Hp, hs), uF), dim3(64), 0, s, g->x1a, g->x1, Hp, Wp,
+                       hs, g->b1c2.w, g->b1c2.a, g->b1c2.b, fs);
+#endif
+#elif AL_SWEEP_NS > 0
     hipLaunchKernelGGL((al_conv3x3_sweep_kernel<3, 16, 1, false, AL_SWEEP_NS>), dim3(sslam::cdiv(Wp, CT_W), sslam::cdiv(Hp, 4 * AL_SWEEP_NS), uF),
                        dim3(256), 0, s, g->img, Hp, Wp, g->x1a, Hp, Wp, g->b1c1.w, g->b1c1.a, g->b1c1.b, nullptr, nullptr, nullptr, fs);
 #else
     hipLaunchKernelGGL((al_conv3x3_mfma_kernel<3, 16, 1, false, false, 2>), g1a, dim3(256), 0, s, g->img, Hp, Wp, g->x1a, Hp,
                        Wp, g->b1c1.w, g->b1c1.a, g->b1c1.b, nullptr, nullptr, nullptr, nullptr, fs);
 #endif
-#if AL_SWEEP_NS > 0
+#if AL_ROWS_HS > 0
+#elif AL_SWEEP_NS > 0
     hipLaunchKernelGGL((al_conv3x3_sweep_kernel<16, 16, 1, false, AL_SWEEP_NS>), dim3(sslam::cdiv(Wp, CT_W), sslam::cdiv(Hp, 4 * AL_SWEEP_NS), uF),
                        dim3(256), 0, s, g->x1a, Hp, Wp, g->x1, Hp, Wp, g->b1c2.w, g->b1c2.a, g->b1c2.b, nullptr, nullptr, nullptr, fs);
 #else
@@ -2166,6 +2453,7 @@ int sslam_aliked_create_batched(sslam_ctx* ctx, const float* weights, size_t n_f
         g->b4c2t = A.take<float>(1152 * 128); g->b3dwt = A.take<float>(32 * 64); g->b4dwt = A.take<float>(64 * 128);
         g->d_sf_s = A.take<_Float16>(2 * 128 * 128); g->d_agg_s = A.take<_Float16>((size_t)2 * 128 * 2048);
         g->b2c2f = A.take<_Float16>(2 * 32 * 288);
+        g->b1c2f = A.take<_Float16>(5 * 2 * 64 * 8);
         g->b3c1ot = A.take<float>(288 * 18); g->b3c2ot = A.take<float>(576 * 18); g->b4c1ot = A.take<float>(576 * 18); g->b4c2ot = A.take<float>(1152 * 18);
         g->gk = A.take<float>(64);
     };
@@ -2228,6 +2516,7 @@ int sslam_aliked_create_batched(sslam_ctx* ctx, const float* weights, size_t n_f
         tr(g->b4c1.w, g->b4c1t, 64, 9, 128); tr(g->b4c2.w, g->b4c2t, 128, 9, 128);
         tr(g->b3dw, g->b3dwt, 32, 1, 64); tr(g->b4dw, g->b4dwt, 64, 1, 128);
         hipLaunchKernelGGL(al_conv32_wfrag_kernel, dim3(sslam::cdiv(32 * 288, 256)), dim3(256), 0, s, g->b2c2.w, g->b2c2f);
+        hipLaunchKernelGGL(al_conv16_wfrag_kernel, dim3(sslam::cdiv(5 * 64 * 8, 256)), dim3(256), 0, s, g->b1c2.w, g->b1c2f);
         hipLaunchKernelGGL(al_split_kernel, dim3(sslam::cdiv(128 * 128, 256)), dim3(256), 0, s, g->d_sf, g->d_sf_s, (size_t)128 * 128);
         hipLaunchKernelGGL(al_split_kernel, dim3(sslam::cdiv(128 * 2048, 256)), dim3(256), 0, s, g->d_agg, g->d_agg_s, (size_t)128 * 2048);
         auto tro = [&](const float* src, float* dst, int K) {      // [k][18] -> [18][k]
