@@ -71,6 +71,12 @@ template <typename T> __device__ __forceinline__ T* fsh(T* p, int f, size_t fs) 
 template <typename T> __device__ __forceinline__ T* fsh0(T* p, int f, size_t fs) {      // null stays null (run-time optional outputs)
     return p ? fsh(p, f, fs) : nullptr;
 }
+// element at a wave-uniform base + a 32-bit BYTE offset of the lane: the compiler can then use the scalar-base addressing mode
+// (an `unsigned` element index is widened to 64 bits before the shift and costs a register pair per distinct offset)
+template <typename T> __device__ __forceinline__ T& at_b(T* base, unsigned byte_off) {
+    using B = std::conditional_t<std::is_const_v<T>, const char, char>;
+    return *reinterpret_cast<T*>(reinterpret_cast<B*>(base) + byte_off);
+}
 struct FrameIn { const uint8_t* img[MAX_FRAMES]; };
 struct FrameOut { float* xy[MAX_FRAMES]; float* desc[MAX_FRAMES]; float* score[MAX_FRAMES]; int32_t* n[MAX_FRAMES]; };
 
@@ -800,7 +806,10 @@ __global__ void al_conv16_wfrag_kernel(const float* __restrict__ w /*[ci 16][tap
     wf[((ks * 2 + 1) * 64 + lane) * 8 + e] = lo;
 }
 
-__global__ __launch_bounds__(64) void al_conv16h_rows_kernel(const _Float16* __restrict__ in /* hi plane [H][W][16]; lo plane H W 16 halves behind */,
+#ifndef AL_C16H_WPE
+#define AL_C16H_WPE 1
+#endif
+__global__ __launch_bounds__(64, AL_C16H_WPE) void al_conv16h_rows_kernel(const _Float16* __restrict__ in /* hi plane [H][W][16]; lo plane H W 16 halves behind */,
                                                             float* __restrict__ out, int H, int W, int hs, const _Float16* __restrict__ wf,
                                                             const float* __restrict__ alpha, const float* __restrict__ beta, size_t fs) {
     in = fsh(in, blockIdx.z, fs); out = fsh(out, blockIdx.z, fs);
@@ -882,6 +891,168 @@ __global__ __launch_bounds__(64) void al_conv16h_rows_kernel(const _Float16* __r
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 orow[lo + i * HWu + 16 * hf] = SWEEP_SELU(fmaf(c1[hf][i] + c2[hf][i] * sslam::SPLIT_INV, alr[i], ber[i]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        stash_row(PH, y + 2);
+        __syncthreads();
+    };
+    for (int y = yb; y < ye; y += 3) {
+        step(std::integral_constant<int, 0>{}, y);
+        if (y + 1 >= ye) break;
+        step(std::integral_constant<int, 1>{}, y + 1);
+        if (y + 2 >= ye) break;
+        step(std::integral_constant<int, 2>{}, y + 2);
+    }
+}
+
+// ------------------------------------------------------------------------ //
+//  1a-3. block2.conv1 (2 x 2 average pooling on load, 16 -> 32 at 1/2 resolution, + the 1 x 1 downsample branch) as rolling
+//      rows on the split-precision matrix path (r04).  One wave per workgroup owns 32 half-resolution pixels x `hs` rows; a
+//      step pools two full-resolution rows of the planar fp32 input into one ring row (channel-last fp16 (hi, lo), as above),
+//      runs 9 k-steps (tap = k-step, 16 channels) + 1 (the 1 x 1 branch on the B fragment of the centre tap) of three
+//      v_mfma_f32_32x32x16_f16 each - 30 MFMAs of 32 cycles against 80 + 8 of 64 on the exact-fp32 instruction - and leaves
+//      t2 channel-last split (for al_conv32_h_kernel) and the identity branch planar.  A fragments in registers.
+// ------------------------------------------------------------------------ //
+__global__ void al_conv32p_wfrag_kernel(const float* __restrict__ w /*[ci 16][tap 9][co 32]*/, const float* __restrict__ wd /*[ci 16][co 32]*/,
+                                        _Float16* __restrict__ wf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // (k-step, lane, e)
+    if (i >= 10 * 64 * 8) return;
+    const int e = i & 7, lane = (i >> 3) & 63, ks = i >> 9;
+    const int co = lane & 31, ci = 8 * (lane >> 5) + e;
+    const float v = ks < 9 ? w[(ci * 9 + ks) * 32 + co] : wd[ci * 32 + co];
+    const _Float16 hi = fabsf(v) < 6.103515625e-5f ? (_Float16)0.0f : (_Float16)v;
+    const _Float16 lo = (_Float16)((v - (float)hi) * sslam::SPLIT_SCALE);
+    wf[((ks * 2 + 0) * 64 + lane) * 8 + e] = hi;
+    wf[((ks * 2 + 1) * 64 + lane) * 8 + e] = lo;
+}
+
+#ifndef AL_C32P_WPE
+#define AL_C32P_WPE 1
+#endif
+__global__ __launch_bounds__(64, AL_C32P_WPE) void al_conv32p_rows_kernel(const float* __restrict__ in /*[16][2 H][2 W]*/, float* __restrict__ out /* t2: split planes [H][W][32] */,
+                                                            float* __restrict__ idn /*[32][H][W]*/, int H, int W, int hs, const _Float16* __restrict__ wf,
+                                                            const float* __restrict__ alpha, const float* __restrict__ beta, const float* __restrict__ bd, size_t fs) {
+    in = fsh(in, blockIdx.z, fs); out = fsh(out, blockIdx.z, fs); idn = fsh(idn, blockIdx.z, fs);
+    constexpr int PXS = 24, ROWH = (CT_W + 2) * PXS, PLH = 3 * ROWH;
+    __shared__ __attribute__((aligned(16))) _Float16 ring[2 * PLH];
+    __shared__ float aff[96];
+    const int lane = threadIdx.x, h = lane >> 5, px = lane & 31;
+    const int x0 = blockIdx.x * CT_W, yb = blockIdx.y * hs, ye = min(yb + hs, H);
+    const int inW = 2 * W, inH = 2 * H;
+    // A fragments: the hi planes in registers for the whole strip, the lo planes in LDS (both in registers: spills at 256)
+    __shared__ __attribute__((aligned(16))) _Float16 wlo[10 * 64 * 8];
+    sslam::half8 ah[10];
+#pragma unroll
+    for (int ks = 0; ks < 10; ++ks) {
+        ah[ks] = *reinterpret_cast<const sslam::half8*>(wf + ((ks * 2 + 0) * 64 + lane) * 8);
+        *reinterpret_cast<sslam::half8*>(&wlo[(ks * 64 + lane) * 8]) = *reinterpret_cast<const sslam::half8*>(wf + ((ks * 2 + 1) * 64 + lane) * 8);
+    }
+    const _Float16* wl = wlo + lane * 8;
+    if (lane < 32) { aff[lane] = alpha[lane]; aff[32 + lane] = beta[lane]; aff[64 + lane] = bd[lane]; }
+    // a ring row = the 2 x 2 averages of two input rows: 16 channels x 16 float4 (= 2 pooled pixels) x 2 rows, four items per lane,
+    // + the halo columns (x0 - 1, x0 + 32): 16 channels x 2 sides on lanes 0 .. 31
+    const int hch = (lane & 31) >> 1, hside = lane & 1, hx = hside ? x0 + CT_W : x0 - 1;
+    const bool hok = lane < 32 && hx >= 0 && hx < W;
+    const size_t inHW = (size_t)inH * inW;
+    float4 ra[4], rb[4]; float2 ha, hb;
+    // (wave-uniform row pointers + 32-bit lane offsets: 64-bit lane pointers per item spill at two waves per SIMD)
+    unsigned iofs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int idx = lane + 64 * j; iofs[j] = 4u * ((unsigned)(idx >> 4) * (unsigned)inHW + 2 * x0 + 4 * (idx & 15)); }
+    const unsigned hofs = 4u * ((unsigned)hch * (unsigned)inHW + 2 * min(max(hx, 0), W - 1));
+    auto load_row = [&](int yy) {
+        const int yc = min(max(yy, 0), H - 1);
+        const float* r0 = in + (size_t)(2 * yc) * inW;
+        const float* r1 = r0 + inW;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ra[j] = at_b(reinterpret_cast<const float4*>(r0), iofs[j]); rb[j] = at_b(reinterpret_cast<const float4*>(r1), iofs[j]);
+        }
+        ha = at_b(reinterpret_cast<const float2*>(r0), hofs); hb = at_b(reinterpret_cast<const float2*>(r1), hofs);
+    };
+    auto put = [&](int o, float v0, float v1, bool two) {      // pooled values of one channel at ring pixels o, o + PXS
+        unsigned h2, l2; float amax = 0.0f;
+        sslam::split2_fast(v0, v1, h2, l2, amax);
+        ring[o] = __builtin_bit_cast(_Float16, (unsigned short)(h2 & 0xffffu));
+        ring[o + PLH] = __builtin_bit_cast(_Float16, (unsigned short)(l2 & 0xffffu));
+        if (two) {
+            ring[o + PXS] = __builtin_bit_cast(_Float16, (unsigned short)(h2 >> 16));
+            ring[o + PXS + PLH] = __builtin_bit_cast(_Float16, (unsigned short)(l2 >> 16));
+        }
+    };
+    auto stash_row = [&](int slot, int yy) {
+        const bool rowok = yy >= 0 && yy < H;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = lane + 64 * j, ch = idx >> 4, v4 = idx & 15;
+            // 2 x 2 average summed in the order (0,0) (0,1) (1,0) (1,1)
+            const float p0 = rowok ? (((ra[j].x + ra[j].y) + rb[j].x) + rb[j].y) / 4.0f : 0.0f;
+            const float p1 = rowok ? (((ra[j].z + ra[j].w) + rb[j].z) + rb[j].w) / 4.0f : 0.0f;
+            put(slot * ROWH + (1 + 2 * v4) * PXS + ch, p0, p1, true);
+        }
+        if (lane < 32) {
+            const float p = rowok && hok ? (((ha.x + ha.y) + hb.x) + hb.y) / 4.0f : 0.0f;
+            put(slot * ROWH + (hside ? CT_W + 1 : 0) * PXS + hch, p, 0.0f, false);
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { load_row(yb - 1 + r); stash_row(r, yb - 1 + r); }
+    __syncthreads();
+    const _Float16* bl = ring + px * PXS + 8 * h;
+    const size_t HW = (size_t)H * W;
+    const unsigned HWb = 4u * (unsigned)HW, lo = (unsigned)(4 * h) * HWb + 4u * px;      // bytes
+    auto step = [&](auto ph, int y) {
+        constexpr int PH = decltype(ph)::value;
+        load_row(y + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 c1, c2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { c1[r] = 0.0f; c2[r] = 0.0f; }
+#pragma unroll
+        for (int ks = 0; ks < 9; ++ks) {
+            const int o = ((PH + ks / 3) % 3) * ROWH + (ks % 3) * PXS;
+            const sslam::half8 xh = *reinterpret_cast<const sslam::half8*>(bl + o);
+            const sslam::half8 xl = *reinterpret_cast<const sslam::half8*>(bl + o + PLH);
+            c1 = sslam::mfma16(ah[ks], xh, c1);
+            c2 = sslam::mfma16(ah[ks], xl, c2);
+            c2 = sslam::mfma16(*reinterpret_cast<const sslam::half8*>(wl + ks * 64 * 8), xh, c2);
+        }
+        const bool live = x0 + px < W;
+        if (live) {
+            _Float16* orow = reinterpret_cast<_Float16*>(out) + ((size_t)y * W + x0) * 32;
+            const unsigned ol = 2u * (px * 32 + 4 * h), opl = 2u * (unsigned)HW * 32;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float vv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g4 + e, co = acc_row(r, lane);
+                    vv[e] = SWEEP_SELU(fmaf(c1[r] + c2[r] * sslam::SPLIT_INV, aff[co], aff[32 + co]));
+                }
+                unsigned h01, l01, h23, l23; float amax = 0.0f;
+                sslam::split2_fast(vv[0], vv[1], h01, l01, amax);
+                sslam::split2_fast(vv[2], vv[3], h23, l23, amax);
+                at_b(reinterpret_cast<uint2*>(orow), ol + 16 * g4) = make_uint2(h01, h23);
+                at_b(reinterpret_cast<uint2*>(orow), opl + ol + 16 * g4) = make_uint2(l01, l23);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {   // the 1 x 1 branch on the centre tap, in the same accumulator registers (they would not fit twice at two waves per SIMD)
+            const int o = ((PH + 1) % 3) * ROWH + PXS;
+            const sslam::half8 xh = *reinterpret_cast<const sslam::half8*>(bl + o);
+            const sslam::half8 xl = *reinterpret_cast<const sslam::half8*>(bl + o + PLH);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { c1[r] = 0.0f; c2[r] = 0.0f; }
+            c1 = sslam::mfma16(ah[9], xh, c1);
+            c2 = sslam::mfma16(ah[9], xl, c2);
+            c2 = sslam::mfma16(*reinterpret_cast<const sslam::half8*>(wl + 9 * 64 * 8), xh, c2);
+            if (live) {
+                float* irow = idn + (size_t)y * W + x0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    at_b(irow, lo + (8 * (r / 4) + r % 4) * HWb) = (c1[r] + c2[r] * sslam::SPLIT_INV) + aff[64 + acc_row(r, lane)];
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
@@ -2168,6 +2339,7 @@ struct sslam_aliked {
     _Float16 *d_sf_s, *d_agg_s;          // split (hi | lo) copies of the two large descriptor-head weight matrices
     _Float16* b2c2f;                     // block2.conv2 weights, split, fragment order (al_conv32_wfrag_kernel)
     _Float16* b1c2f;                     // block1.conv2 weights, split, fragment order (al_conv16_wfrag_kernel)
+    _Float16* b2c1f;                     // block2.conv1 + downsample weights, split, fragment order (al_conv32p_wfrag_kernel)
     float *p3cl, *t3cl, *p4cl, *t4cl;    // channel-last copies of the deformable layers' inputs (al_dcn_col)
     float *out_xy, *out_desc, *out_score;
     int32_t* out_n;
@@ -2301,7 +2473,16 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
     dim3 g2a(sslam::cdiv(W2, CT_W), sslam::cdiv(H2, 4), uF), g2b(sslam::cdiv(W2, CT_W), sslam::cdiv(H2, 8), uF);
     // (r04: t2 leaves block2.conv1 channel-last as fp16 (hi, lo) planes - the bytes of the planar fp32 map - for the
     //  split-precision form of block2.conv2)
-#if AL_SWEEP_NS > 0
+#ifndef AL_B2C1_SPLIT
+#define AL_B2C1_SPLIT 1
+#endif
+#if AL_B2C1_SPLIT
+    {
+        const int hs2 = std::max(2, std::min(8, (int)((size_t)H2 * (W2 / CT_W) * uF / 4096)));
+        hipLaunchKernelGGL(al_conv32p_rows_kernel, dim3(sslam::cdiv(W2, CT_W), sslam::cdiv(H2, hs2), uF), dim3(64), 0, s, g->x1, g->t2, g->idn2, H2, W2,
+                           hs2, g->b2c1f, g->b2c1.a, g->b2c1.b, g->b2db, fs);
+    }
+#elif AL_SWEEP_NS > 0
     hipLaunchKernelGGL((al_conv3x3_sweep_kernel<16, 32, 2, true, AL_SWEEP_NS, true>), dim3(sslam::cdiv(W2, CT_W), sslam::cdiv(H2, 4 * AL_SWEEP_NS), uF),
                        dim3(256), 0, s, g->x1, Hp, Wp, g->t2, H2, W2, g->b2c1.w, g->b2c1.a, g->b2c1.b, g->b2dw, g->b2db, g->idn2, fs);
 #else
@@ -2454,6 +2635,7 @@ int sslam_aliked_create_batched(sslam_ctx* ctx, const float* weights, size_t n_f
         g->d_sf_s = A.take<_Float16>(2 * 128 * 128); g->d_agg_s = A.take<_Float16>((size_t)2 * 128 * 2048);
         g->b2c2f = A.take<_Float16>(2 * 32 * 288);
         g->b1c2f = A.take<_Float16>(5 * 2 * 64 * 8);
+        g->b2c1f = A.take<_Float16>(10 * 2 * 64 * 8);
         g->b3c1ot = A.take<float>(288 * 18); g->b3c2ot = A.take<float>(576 * 18); g->b4c1ot = A.take<float>(576 * 18); g->b4c2ot = A.take<float>(1152 * 18);
         g->gk = A.take<float>(64);
     };
@@ -2517,6 +2699,7 @@ int sslam_aliked_create_batched(sslam_ctx* ctx, const float* weights, size_t n_f
         tr(g->b3dw, g->b3dwt, 32, 1, 64); tr(g->b4dw, g->b4dwt, 64, 1, 128);
         hipLaunchKernelGGL(al_conv32_wfrag_kernel, dim3(sslam::cdiv(32 * 288, 256)), dim3(256), 0, s, g->b2c2.w, g->b2c2f);
         hipLaunchKernelGGL(al_conv16_wfrag_kernel, dim3(sslam::cdiv(5 * 64 * 8, 256)), dim3(256), 0, s, g->b1c2.w, g->b1c2f);
+        hipLaunchKernelGGL(al_conv32p_wfrag_kernel, dim3(sslam::cdiv(10 * 64 * 8, 256)), dim3(256), 0, s, g->b2c1.w, g->b2dw, g->b2c1f);
         hipLaunchKernelGGL(al_split_kernel, dim3(sslam::cdiv(128 * 128, 256)), dim3(256), 0, s, g->d_sf, g->d_sf_s, (size_t)128 * 128);
         hipLaunchKernelGGL(al_split_kernel, dim3(sslam::cdiv(128 * 2048, 256)), dim3(256), 0, s, g->d_agg, g->d_agg_s, (size_t)128 * 2048);
         auto tro = [&](const float* src, float* dst, int K) {      // [k][18] -> [18][k]
