@@ -1179,6 +1179,186 @@ __global__ __launch_bounds__(256) void al_conv32_h_kernel(const _Float16* __rest
 }
 
 // ------------------------------------------------------------------------ //
+//  1c. block2 FUSED (r04): pooling + conv1 (16 -> 32) + the 1 x 1 branch + conv2 (32 -> 32) + residual, rolling rows.
+//      As two kernels the block moved 934 bytes per half-resolution pixel through HBM (t2 and the identity branch written,
+//      then re-read with a halo); fused it reads x1 (256 B) and writes x2 (128 B).  A wave owns a strip of 30 output pixels x
+//      `hs` rows and keeps two rings in LDS: three pooled input rows (34 pixels, 16 channels) and three rows of t2 (32
+//      pixels = the strip + one on each side, 32 channels), both channel-last fp16 (hi, lo).  Step y: prefetch the input of
+//      pooled row y + 3; conv1 -> t2 row y + 1 (zero outside the map: conv2's padding) into the t2 ring; the 1 x 1 branch on
+//      pooled row y; conv2 row y from the t2 ring; + BN + residual + SELU -> x2 (planar fp32).  Split-precision matrix path
+//      throughout (3 x (27 + 3 + 54) v_mfma_f32_32x32x16_f16 per step).  Four independent waves per workgroup share the A
+//      fragments in LDS (conv1 lo planes 10 KB, conv2 36 KB; conv1 hi planes in registers): 147 KB, one workgroup per CU,
+//      no workgroup barrier after the weights are staged.
+// ------------------------------------------------------------------------ //
+constexpr int B2_SW = 30;                                   // output pixels per strip
+constexpr int B2_PXP = 24, B2_ROWP = 34 * B2_PXP, B2_PLP = 3 * B2_ROWP;          // pooled ring (halves)
+constexpr int B2_PXT = 40, B2_ROWT = 32 * B2_PXT, B2_PLT = 3 * B2_ROWT;          // t2 ring (halves)
+constexpr int B2_RING = 2 * B2_PLP + 2 * B2_PLT;                                   // halves per wave
+constexpr int B2_W1 = 10 * 64 * 8, B2_W2 = 36 * 64 * 8;                            // shared A fragments (halves)
+constexpr size_t B2_LDS = (size_t)(B2_W1 + B2_W2 + 4 * B2_RING) * 2 + 5 * 32 * 4;
+
+__global__ __launch_bounds__(256, 1) void al_block2_rows_kernel(const float* __restrict__ in /* x1 [16][2 H][2 W] */, float* __restrict__ out /* x2 [32][H][W] */,
+                                                               int H, int W, int hs, int nblk, int strips, int n_waves,
+                                                               const _Float16* __restrict__ wf1 /*[10][2][64][8]*/, const _Float16* __restrict__ wf2 /*[18][2][64][8]*/,
+                                                               const float* __restrict__ a1, const float* __restrict__ b1, const float* __restrict__ bd,
+                                                               const float* __restrict__ a2, const float* __restrict__ b2, size_t fs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char b2_lds[];
+    _Float16* w1lo = reinterpret_cast<_Float16*>(b2_lds);
+    _Float16* w2 = w1lo + B2_W1;
+    float* aff = reinterpret_cast<float*>(w2 + B2_W2 + 4 * B2_RING);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, px = lane & 31;
+    // stage the shared A fragments and the affine tables
+    for (int i = t; i < B2_W1 / 8; i += 256)
+        *reinterpret_cast<uint4*>(w1lo + i * 8) = *reinterpret_cast<const uint4*>(wf1 + (((i >> 6) * 2 + 1) * 64 + (i & 63)) * 8);
+    for (int i = t; i < B2_W2 / 8; i += 256) *reinterpret_cast<uint4*>(w2 + i * 8) = *reinterpret_cast<const uint4*>(wf2 + (size_t)i * 8);
+    if (t < 32) { aff[t] = a1[t]; aff[32 + t] = b1[t]; aff[64 + t] = bd[t]; aff[96 + t] = a2[t]; aff[128 + t] = b2[t]; }
+    __syncthreads();
+    const int gw = blockIdx.x * 4 + wave;
+    if (gw >= n_waves) return;                               // (no barrier below)
+    const int strip = gw % strips, blk = (gw / strips) % nblk, f = gw / (strips * nblk);
+    in = fsh(in, f, fs); out = fsh(out, f, fs);
+    _Float16* P = w2 + B2_W2 + wave * B2_RING;               // [plane][slot][34][24]
+    _Float16* T = P + 2 * B2_PLP;                            // [plane][slot][32][40]
+    const int x0 = strip * B2_SW, yb = blk * hs, ye = min(yb + hs, H);
+    const int inW = 2 * W, inH = 2 * H;
+    const unsigned inHW = (unsigned)inH * inW;
+    sslam::half8 ah1[10];
+#pragma unroll
+    for (int ks = 0; ks < 10; ++ks) ah1[ks] = *reinterpret_cast<const sslam::half8*>(wf1 + ((ks * 2 + 0) * 64 + lane) * 8);
+    const _Float16* w1l = w1lo + lane * 8;
+    const _Float16* w2l = w2 + lane * 8;
+    // a pooled row = 16 channels x 17 float4 pairs (34 pooled pixels from x0 - 2): 272 items, five rounds
+    unsigned iofs[5]; bool iok[5]; int ipo[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int idx = min(lane + 64 * j, 271), ch = idx / 17, v4 = idx % 17, x = x0 - 2 + 2 * v4;
+        iok[j] = lane + 64 * j < 272 && x >= 0 && x < W;
+        iofs[j] = 4u * ((unsigned)ch * inHW + 2u * (unsigned)min(max(x, 0), W - 2));
+        ipo[j] = 2 * v4 * B2_PXP + ch;
+    }
+    float4 ra[5], rb[5];
+    auto load_row = [&](int yy) {
+        const int yc = min(max(yy, 0), H - 1);
+        const float* r0 = in + (size_t)(2 * yc) * inW;
+        const float* r1 = r0 + inW;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { ra[j] = at_b(reinterpret_cast<const float4*>(r0), iofs[j]); rb[j] = at_b(reinterpret_cast<const float4*>(r1), iofs[j]); }
+    };
+    auto stash_row = [&](int slot, int yy) {
+        const bool rowok = yy >= 0 && yy < H;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            if (lane + 64 * j >= 272) continue;
+            const bool ok = rowok && iok[j];
+            // 2 x 2 average summed in the order (0,0) (0,1) (1,0) (1,1)
+            const float p0 = ok ? (((ra[j].x + ra[j].y) + rb[j].x) + rb[j].y) / 4.0f : 0.0f;
+            const float p1 = ok ? (((ra[j].z + ra[j].w) + rb[j].z) + rb[j].w) / 4.0f : 0.0f;
+            unsigned h2, l2; float amax = 0.0f;
+            sslam::split2_fast(p0, p1, h2, l2, amax);
+            const int o = slot * B2_ROWP + ipo[j];
+            P[o] = __builtin_bit_cast(_Float16, (unsigned short)(h2 & 0xffffu));
+            P[o + B2_PXP] = __builtin_bit_cast(_Float16, (unsigned short)(h2 >> 16));
+            P[o + B2_PLP] = __builtin_bit_cast(_Float16, (unsigned short)(l2 & 0xffffu));
+            P[o + B2_PLP + B2_PXP] = __builtin_bit_cast(_Float16, (unsigned short)(l2 >> 16));
+        }
+    };
+    // pooled rows yb - 2, yb - 1, yb -> slots 0, 1, 2; the first two steps only build t2 rows yb - 1 and yb
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { load_row(yb - 2 + r); stash_row(r, yb - 2 + r); }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    const _Float16* pb = P + px * B2_PXP + 8 * h;            // conv1 B fragments: pooled pixel q + dx
+    const _Float16* tb = T + px * B2_PXT + 8 * h;            // conv2 B fragments: t2 pixel j + dx
+    const bool tq_ok = x0 - 1 + px >= 0 && x0 - 1 + px < W;  // t2 pixel of this lane inside the map
+    const bool live = px < B2_SW && x0 + px < W;
+    const unsigned HWb = 4u * (unsigned)H * W, lo = (unsigned)(4 * h) * HWb + 4u * px;
+    auto step = [&](auto ph, int y) {
+        // pooled rows y, y + 1, y + 2 in slots PH, PH + 1, PH + 2 (mod 3); t2 rows y - 1, y in slots PH, PH + 1; t2 row y + 1 -> slot PH + 2
+        constexpr int PH = decltype(ph)::value;
+        load_row(y + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 c1, c2;
+        {   // conv1 -> t2 row y + 1
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { c1[r] = 0.0f; c2[r] = 0.0f; }
+#pragma unroll
+            for (int ks = 0; ks < 9; ++ks) {
+                const int o = ((PH + ks / 3) % 3) * B2_ROWP + (ks % 3) * B2_PXP;
+                const sslam::half8 xh = *reinterpret_cast<const sslam::half8*>(pb + o);
+                const sslam::half8 xl = *reinterpret_cast<const sslam::half8*>(pb + o + B2_PLP);
+                c1 = sslam::mfma16(ah1[ks], xh, c1);
+                c2 = sslam::mfma16(ah1[ks], xl, c2);
+                c2 = sslam::mfma16(*reinterpret_cast<const sslam::half8*>(w1l + ks * 512), xh, c2);
+            }
+            const bool ok = tq_ok && y + 1 >= 0 && y + 1 < H;
+            _Float16* trow = T + ((PH + 2) % 3) * B2_ROWT + px * B2_PXT + 4 * h;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float vv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g4 + e, co = acc_row(r, lane);
+                    vv[e] = ok ? SWEEP_SELU(fmaf(c1[r] + c2[r] * sslam::SPLIT_INV, aff[co], aff[32 + co])) : 0.0f;
+                }
+                unsigned h01, l01, h23, l23; float amax = 0.0f;
+                sslam::split2_fast(vv[0], vv[1], h01, l01, amax);
+                sslam::split2_fast(vv[2], vv[3], h23, l23, amax);
+                *reinterpret_cast<uint2*>(trow + 8 * g4) = make_uint2(h01, h23);
+                *reinterpret_cast<uint2*>(trow + B2_PLT + 8 * g4) = make_uint2(l01, l23);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (y >= yb) {
+            float idv[16];
+            {   // the 1 x 1 branch: pooled row y (slot PH), pixel j + 2
+                const int o = PH * B2_ROWP + 2 * B2_PXP;
+                const sslam::half8 xh = *reinterpret_cast<const sslam::half8*>(pb + o);
+                const sslam::half8 xl = *reinterpret_cast<const sslam::half8*>(pb + o + B2_PLP);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { c1[r] = 0.0f; c2[r] = 0.0f; }
+                c1 = sslam::mfma16(ah1[9], xh, c1);
+                c2 = sslam::mfma16(ah1[9], xl, c2);
+                c2 = sslam::mfma16(*reinterpret_cast<const sslam::half8*>(w1l + 9 * 512), xh, c2);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) idv[r] = (c1[r] + c2[r] * sslam::SPLIT_INV) + aff[64 + acc_row(r, lane)];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { c1[r] = 0.0f; c2[r] = 0.0f; }
+#pragma unroll
+            for (int ks = 0; ks < 18; ++ks) {
+                const int tap = ks >> 1, o = ((PH + tap / 3) % 3) * B2_ROWT + (tap % 3) * B2_PXT + 16 * (ks & 1);
+                const sslam::half8 xh = *reinterpret_cast<const sslam::half8*>(tb + o);
+                const sslam::half8 xl = *reinterpret_cast<const sslam::half8*>(tb + o + B2_PLT);
+                const sslam::half8 wh = *reinterpret_cast<const sslam::half8*>(w2l + (ks * 2 + 0) * 512);
+                const sslam::half8 wl = *reinterpret_cast<const sslam::half8*>(w2l + (ks * 2 + 1) * 512);
+                c1 = sslam::mfma16(wh, xh, c1);
+                c2 = sslam::mfma16(wh, xl, c2);
+                c2 = sslam::mfma16(wl, xh, c2);
+            }
+            if (live) {
+                float* orow = out + (size_t)y * W + x0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = acc_row(r, lane);
+                    at_b(orow, lo + (8 * (r / 4) + r % 4) * HWb) =
+                        SWEEP_SELU(fmaf(c1[r] + c2[r] * sslam::SPLIT_INV, aff[96 + co], aff[128 + co]) + idv[r]);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // this step's LDS reads before the overwrite of pooled slot PH
+        stash_row(PH, y + 3);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    };
+    for (int y = yb - 2; y < ye; y += 3) {
+        step(std::integral_constant<int, 0>{}, y);
+        if (y + 1 >= ye) break;
+        step(std::integral_constant<int, 1>{}, y + 1);
+        if (y + 2 >= ye) break;
+        step(std::integral_constant<int, 2>{}, y + 2);
+    }
+}
+
+// ------------------------------------------------------------------------ //
 //  2. small-map stages (1/8 and 1/32 resolution): pooling, offset conv,
 //     deformable conv (torchvision deform_conv2d semantics) + BN + residual + SELU
 // ------------------------------------------------------------------------ //
@@ -2473,6 +2653,18 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
     dim3 g2a(sslam::cdiv(W2, CT_W), sslam::cdiv(H2, 4), uF), g2b(sslam::cdiv(W2, CT_W), sslam::cdiv(H2, 8), uF);
     // (r04: t2 leaves block2.conv1 channel-last as fp16 (hi, lo) planes - the bytes of the planar fp32 map - for the
     //  split-precision form of block2.conv2)
+#ifndef AL_B2_FUSED
+#define AL_B2_FUSED 1
+#endif
+    const bool b2_fused = AL_B2_FUSED && W2 % 2 == 0;
+    if (b2_fused) {
+        // one wave per SIMD when the batch allows; at least six rows per wave (two extra t2 rows per block)
+        const int strips = sslam::cdiv(W2, B2_SW);
+        const int nblk = std::max(1, std::min(sslam::cdiv(H2, 6), 1024 / std::max(1, strips * F)));
+        const int hs2 = sslam::cdiv(H2, nblk), nb = sslam::cdiv(H2, hs2), n_waves = strips * nb * F;
+        hipLaunchKernelGGL(al_block2_rows_kernel, dim3(sslam::cdiv(n_waves, 4)), dim3(256), B2_LDS, s, g->x1, g->x2, H2, W2, hs2, nb, strips, n_waves,
+                           g->b2c1f, g->b2c2f, g->b2c1.a, g->b2c1.b, g->b2db, g->b2c2.a, g->b2c2.b, fs);
+    } else {
 #ifndef AL_B2C1_SPLIT
 #define AL_B2C1_SPLIT 1
 #endif
@@ -2497,6 +2689,7 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
         hipLaunchKernelGGL(al_conv32_h_kernel<2>, g2b, dim3(256), 0, s, t2h, g->x2, H2, W2, g->b2c2f, g->b2c2.a, g->b2c2.b, g->idn2, fs);
     else        // one frame: 320 workgroups of 8 rows leave the chip half empty - 4-row tiles (same arithmetic per output)
         hipLaunchKernelGGL(al_conv32_h_kernel<1>, g2a, dim3(256), 0, s, t2h, g->x2, H2, W2, g->b2c2f, g->b2c2.a, g->b2c2.b, g->idn2, fs);
+    }
     // deformable conv = im2col of the bilinear samples + matrix-core GEMM (offsets in g->off)
     auto dcn = [&](const float* in /* channel-last */, int cin, float* outp, int cout, int Hh, int Ww, const float* wt, const float* al_,
                    const float* be_, const float* res /* channel-last */, int rc, const float* wdt, const float* bdp, float* outp_cl) {
@@ -2709,6 +2902,7 @@ int sslam_aliked_create_batched(sslam_ctx* ctx, const float* weights, size_t n_f
         tro(g->b4c2.ow, g->b4c2ot, 1152);
         SSLAM_HIP_CHECK(hipStreamSynchronize(s));
     }
+    SSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)al_block2_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B2_LDS));
     SSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)al_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (SEL_CAP + EDGE_CAP) * 8));
     sslam::ctx_retain(ctx);
