@@ -1194,9 +1194,47 @@ constexpr int B2_SW = 30;                                   // output pixels per
 constexpr int B2_PXP = 24, B2_ROWP = 34 * B2_PXP, B2_PLP = 3 * B2_ROWP;          // pooled ring (halves)
 constexpr int B2_PXT = 40, B2_ROWT = 32 * B2_PXT, B2_PLT = 3 * B2_ROWT;          // t2 ring (halves)
 constexpr int B2_RING = 2 * B2_PLP + 2 * B2_PLT;                                   // halves per wave
-constexpr int B2_W1 = 10 * 64 * 8, B2_W2 = 36 * 64 * 8;                            // shared A fragments (halves)
+#ifndef AL_B2_WREG
+#define AL_B2_WREG 1       // 1: every A fragment in registers (224 of the wave's 512; one wave per SIMD either way) - the LDS then only serves B fragments
+#endif
+constexpr int B2_W1 = AL_B2_WREG ? 0 : 10 * 64 * 8, B2_W2 = AL_B2_WREG ? 0 : 36 * 64 * 8;      // shared A fragments (halves)
 constexpr size_t B2_LDS = (size_t)(B2_W1 + B2_W2 + 4 * B2_RING) * 2 + 5 * 32 * 4;
 
+#ifndef AL_B2_ASM
+#define AL_B2_ASM 1
+#endif
+// The 224 registers of A fragments live in the accumulation-register file: written once, read by the MFMAs directly.  Through the
+// builtin the compiler copies each fragment to an arch register first (257 v_accvgpr_read per step) and zeroes every chain's
+// accumulator with 16 moves; here the first MFMA of a chain takes the literal 0 as C.  An asm MFMA is opaque to the hazard
+// recogniser: nothing writes the A registers inside the loop, B fragments arrive by ds_read (waited for by register use), and
+// b2_mfma_done() pads the MFMA -> VALU read distance after the last MFMA of a chain.
+#if AL_B2_ASM && AL_B2_WREG
+#define B2_AREG "a"
+#else
+#define B2_AREG "v"
+#endif
+__device__ __forceinline__ void b2_mfma0(f32x16& c, const sslam::half8& a_, const sslam::half8& b_) {
+#if AL_B2_ASM
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : B2_AREG(a_), "v"(b_));
+#else
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+    c = sslam::mfma16(a_, b_, z);
+#endif
+}
+__device__ __forceinline__ void b2_mfma(f32x16& c, const sslam::half8& a_, const sslam::half8& b_) {
+#if AL_B2_ASM
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : B2_AREG(a_), "v"(b_));
+#else
+    c = sslam::mfma16(a_, b_, c);
+#endif
+}
+__device__ __forceinline__ void b2_mfma_done() {
+#if AL_B2_ASM
+    asm volatile("s_nop 15\n\ts_nop 3");
+#endif
+}
 __global__ __launch_bounds__(256, 1) void al_block2_rows_kernel(const float* __restrict__ in /* x1 [16][2 H][2 W] */, float* __restrict__ out /* x2 [32][H][W] */,
                                                                int H, int W, int hs, int nblk, int strips, int n_waves,
                                                                const _Float16* __restrict__ wf1 /*[10][2][64][8]*/, const _Float16* __restrict__ wf2 /*[18][2][64][8]*/,
@@ -1206,11 +1244,13 @@ __global__ __launch_bounds__(256, 1) void al_block2_rows_kernel(const float* __r
     _Float16* w1lo = reinterpret_cast<_Float16*>(b2_lds);
     _Float16* w2 = w1lo + B2_W1;
     float* aff = reinterpret_cast<float*>(w2 + B2_W2 + 4 * B2_RING);
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, px = lane & 31;
+    // (the wave index as a SCALAR: strip, block, frame and every row pointer derived from it stay in scalar registers)
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), h = lane >> 5, px = lane & 31;
     // stage the shared A fragments and the affine tables
     for (int i = t; i < B2_W1 / 8; i += 256)
         *reinterpret_cast<uint4*>(w1lo + i * 8) = *reinterpret_cast<const uint4*>(wf1 + (((i >> 6) * 2 + 1) * 64 + (i & 63)) * 8);
     for (int i = t; i < B2_W2 / 8; i += 256) *reinterpret_cast<uint4*>(w2 + i * 8) = *reinterpret_cast<const uint4*>(wf2 + (size_t)i * 8);
+    (void)w1lo;
     if (t < 32) { aff[t] = a1[t]; aff[32 + t] = b1[t]; aff[64 + t] = bd[t]; aff[96 + t] = a2[t]; aff[128 + t] = b2[t]; }
     __syncthreads();
     const int gw = blockIdx.x * 4 + wave;
@@ -1225,8 +1265,20 @@ __global__ __launch_bounds__(256, 1) void al_block2_rows_kernel(const float* __r
     sslam::half8 ah1[10];
 #pragma unroll
     for (int ks = 0; ks < 10; ++ks) ah1[ks] = *reinterpret_cast<const sslam::half8*>(wf1 + ((ks * 2 + 0) * 64 + lane) * 8);
+#if AL_B2_WREG
+    sslam::half8 al1[10], wr2[36];
+#pragma unroll
+    for (int ks = 0; ks < 10; ++ks) al1[ks] = *reinterpret_cast<const sslam::half8*>(wf1 + ((ks * 2 + 1) * 64 + lane) * 8);
+#pragma unroll
+    for (int i = 0; i < 36; ++i) wr2[i] = *reinterpret_cast<const sslam::half8*>(wf2 + (i * 64 + lane) * 8);
+#define B2_A1LO(ks) al1[ks]
+#define B2_A2(i) wr2[i]
+#else
     const _Float16* w1l = w1lo + lane * 8;
     const _Float16* w2l = w2 + lane * 8;
+#define B2_A1LO(ks) (*reinterpret_cast<const sslam::half8*>(w1l + (ks) * 512))
+#define B2_A2(i) (*reinterpret_cast<const sslam::half8*>(w2l + (i) * 512))
+#endif
     // a pooled row = 16 channels x 17 float4 pairs (34 pooled pixels from x0 - 2): 272 items, five rounds
     unsigned iofs[5]; bool iok[5]; int ipo[5];
 #pragma unroll
@@ -1279,16 +1331,15 @@ __global__ __launch_bounds__(256, 1) void al_block2_rows_kernel(const float* __r
         f32x16 c1, c2;
         {   // conv1 -> t2 row y + 1
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { c1[r] = 0.0f; c2[r] = 0.0f; }
-#pragma unroll
             for (int ks = 0; ks < 9; ++ks) {
                 const int o = ((PH + ks / 3) % 3) * B2_ROWP + (ks % 3) * B2_PXP;
                 const sslam::half8 xh = *reinterpret_cast<const sslam::half8*>(pb + o);
                 const sslam::half8 xl = *reinterpret_cast<const sslam::half8*>(pb + o + B2_PLP);
-                c1 = sslam::mfma16(ah1[ks], xh, c1);
-                c2 = sslam::mfma16(ah1[ks], xl, c2);
-                c2 = sslam::mfma16(*reinterpret_cast<const sslam::half8*>(w1l + ks * 512), xh, c2);
+                if (ks == 0) { b2_mfma0(c1, ah1[ks], xh); b2_mfma0(c2, ah1[ks], xl); }
+                else { b2_mfma(c1, ah1[ks], xh); b2_mfma(c2, ah1[ks], xl); }
+                b2_mfma(c2, B2_A1LO(ks), xh);
             }
+            b2_mfma_done();
             const bool ok = tq_ok && y + 1 >= 0 && y + 1 < H;
             _Float16* trow = T + ((PH + 2) % 3) * B2_ROWT + px * B2_PXT + 4 * h;
 #pragma unroll
@@ -1313,27 +1364,23 @@ __global__ __launch_bounds__(256, 1) void al_block2_rows_kernel(const float* __r
                 const int o = PH * B2_ROWP + 2 * B2_PXP;
                 const sslam::half8 xh = *reinterpret_cast<const sslam::half8*>(pb + o);
                 const sslam::half8 xl = *reinterpret_cast<const sslam::half8*>(pb + o + B2_PLP);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { c1[r] = 0.0f; c2[r] = 0.0f; }
-                c1 = sslam::mfma16(ah1[9], xh, c1);
-                c2 = sslam::mfma16(ah1[9], xl, c2);
-                c2 = sslam::mfma16(*reinterpret_cast<const sslam::half8*>(w1l + 9 * 512), xh, c2);
+                b2_mfma0(c1, ah1[9], xh);
+                b2_mfma0(c2, ah1[9], xl);
+                b2_mfma(c2, B2_A1LO(9), xh);
+                b2_mfma_done();
 #pragma unroll
                 for (int r = 0; r < 16; ++r) idv[r] = (c1[r] + c2[r] * sslam::SPLIT_INV) + aff[64 + acc_row(r, lane)];
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { c1[r] = 0.0f; c2[r] = 0.0f; }
 #pragma unroll
             for (int ks = 0; ks < 18; ++ks) {
                 const int tap = ks >> 1, o = ((PH + tap / 3) % 3) * B2_ROWT + (tap % 3) * B2_PXT + 16 * (ks & 1);
                 const sslam::half8 xh = *reinterpret_cast<const sslam::half8*>(tb + o);
                 const sslam::half8 xl = *reinterpret_cast<const sslam::half8*>(tb + o + B2_PLT);
-                const sslam::half8 wh = *reinterpret_cast<const sslam::half8*>(w2l + (ks * 2 + 0) * 512);
-                const sslam::half8 wl = *reinterpret_cast<const sslam::half8*>(w2l + (ks * 2 + 1) * 512);
-                c1 = sslam::mfma16(wh, xh, c1);
-                c2 = sslam::mfma16(wh, xl, c2);
-                c2 = sslam::mfma16(wl, xh, c2);
+                if (ks == 0) { b2_mfma0(c1, B2_A2(0), xh); b2_mfma0(c2, B2_A2(0), xl); }
+                else { b2_mfma(c1, B2_A2(ks * 2 + 0), xh); b2_mfma(c2, B2_A2(ks * 2 + 0), xl); }
+                b2_mfma(c2, B2_A2(ks * 2 + 1), xh);
             }
+            b2_mfma_done();
             if (live) {
                 float* orow = out + (size_t)y * W + x0;
 #pragma unroll
