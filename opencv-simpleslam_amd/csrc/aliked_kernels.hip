@@ -33,8 +33,19 @@ constexpr float SELU_SCALE = 1.0507009873554804934193349852946f;
 constexpr float SELU_ALPHA = 1.6732632423543772848170429916717f;
 // (r04: a ~18-instruction expm1 - Taylor near zero, exact-argument exp2 below - instead of ocml's expm1f changed no kernel's
 //  time by more than 4 %: these kernels wait on memory, their vector pipe is not the limit; ocml's stays)
+#ifndef AL_FAST_SELU
+#define AL_FAST_SELU 1
+#endif
+// SELU.  r04: exp(x) - 1 on the hardware exponential (v_exp_f32, 1 ulp) instead of expm1f - 7 instead of ~30 vector instructions
+// per value; the dense stages are bound by vector-instruction issue (the aggregation evaluates 40 SELUs per pixel, the
+// descriptor GEMM epilogue 4 M per frame).  Absolute error <= 1.2e-7 x 1.76 (the subtraction near x = 0): fp32 rounding of an
+// O(1) value.  AL_FAST_SELU=0 restores expm1f.
 __device__ __forceinline__ float selu(float x) {
+#if AL_FAST_SELU
+    return SELU_SCALE * (x > 0.0f ? x : SELU_ALPHA * (__expf(x) - 1.0f));
+#else
     return SELU_SCALE * (x > 0.0f ? x : SELU_ALPHA * expm1f(x));
+#endif
 }
 
 constexpr int HBINS = 4096;        // score histogram bins (uniform in score, monotone)
@@ -487,19 +498,8 @@ __device__ __forceinline__ void sweep_stash(float* __restrict__ tl, int t, unsig
 #ifndef AL_SWEEP_ABL
 #define AL_SWEEP_ABL 0     // experiments: 1 one tap instead of nine, 2 no prefetch loads, 4 no output stores, 8 no SELU
 #endif
-#ifndef AL_FAST_SELU
-#define AL_FAST_SELU 1
-#endif
-// SELU of the sweep epilogues: exp(x) - 1 on the hardware exponential (v_exp_f32, 1 ulp) instead of expm1f - 7 instead of 30
-// vector instructions per output; the sweeps are bound by vector-instruction issue (471 per wave and step next to 72
-// MFMAs; one MFMA hides ~6).  Absolute error <= 1.2e-7 x 1.76 (the subtraction near x = 0), i.e. fp32 rounding of an O(1) value.
-__device__ __forceinline__ float selu_fast(float x) {
-    return SELU_SCALE * (x > 0.0f ? x : SELU_ALPHA * (__expf(x) - 1.0f));
-}
 #if AL_SWEEP_ABL & 8
 #define SWEEP_SELU(v) (v)
-#elif AL_FAST_SELU
-#define SWEEP_SELU(v) selu_fast(v)
 #else
 #define SWEEP_SELU(v) selu(v)
 #endif
