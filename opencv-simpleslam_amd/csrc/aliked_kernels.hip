@@ -1406,6 +1406,138 @@ __global__ __launch_bounds__(256, 1) void al_block2_rows_kernel(const float* __r
 }
 
 // ------------------------------------------------------------------------ //
+//  1d. block1 FUSED (r04): conv1 (3 -> 16, exact-fp32 MFMA) + conv2 (16 -> 16, split-precision pipe) in one rolling-rows kernel -
+//      the intermediate map (64 bytes per pixel written and read back: two thirds of the block's HBM traffic) stays in an LDS
+//      ring, as t2 does in al_block2_rows_kernel.  One wave per workgroup owns 30 output pixels x `hs` rows: a ring of three
+//      image rows (planar fp32, 34 pixels from x0 - 2) and a ring of three rows of conv1's output (channel-last fp16 (hi, lo),
+//      32 pixels from x0 - 1, zero outside the map = conv2's padding).  Step y: prefetch image row y + 3; conv1 -> ring row
+//      y + 1; conv2 row y -> x1 (planar fp32).  Arithmetic per output as in al_conv16_rows_kernel<3, true> + al_conv16h_rows_kernel.
+// ------------------------------------------------------------------------ //
+constexpr int B1_SW = 30;
+__global__ __launch_bounds__(64) void al_block1_rows_kernel(const float* __restrict__ in /* image [3][H][W] */, float* __restrict__ out /* x1 [16][H][W] */,
+                                                           int H, int W, int hs, const float* __restrict__ w1 /*[3][9][16]*/,
+                                                           const float* __restrict__ a1, const float* __restrict__ b1,
+                                                           const _Float16* __restrict__ wf2 /*[5][2][64][8]*/,
+                                                           const float* __restrict__ a2, const float* __restrict__ b2, size_t fs) {
+    in = fsh(in, blockIdx.z, fs); out = fsh(out, blockIdx.z, fs);
+    constexpr int RS = 48, SLOTI = 4 * RS;                                   // image ring: [slot][4 channels (one zero)][48 floats]
+    constexpr int PXS = 24, ROWH = 34 * PXS, PLH = 3 * ROWH;                 // conv1-output ring (halves): [plane][slot][34 pixels][24]
+    __shared__ __attribute__((aligned(16))) float iring[3 * SLOTI];
+    __shared__ __attribute__((aligned(16))) _Float16 tring[2 * PLH];
+    const int lane = threadIdx.x, kk = lane >> 4, n = lane & 15;
+    const int x0 = blockIdx.x * B1_SW, yb = blockIdx.y * hs, ye = min(yb + hs, H);
+    const size_t HW = (size_t)H * W;
+    float aw[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) aw[tap] = kk < 3 ? w1[(kk * 9 + tap) * 16 + n] : 0.0f;
+    sslam::half8 ah[5], al[5];
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+        ah[ks] = *reinterpret_cast<const sslam::half8*>(wf2 + ((ks * 2 + 0) * 64 + lane) * 8);
+        al[ks] = *reinterpret_cast<const sslam::half8*>(wf2 + ((ks * 2 + 1) * 64 + lane) * 8);
+    }
+    float alr1[4], ber1[4], alr2[4], ber2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { alr1[i] = a1[4 * kk + i]; ber1[i] = b1[4 * kk + i]; alr2[i] = a2[4 * kk + i]; ber2[i] = b2[4 * kk + i]; }
+    for (int i = lane; i < 3 * SLOTI; i += 64) iring[i] = 0.0f;               // (the fourth channel and the row tails stay zero)
+    for (int i = lane; i < 2 * PLH / 2; i += 64) reinterpret_cast<unsigned*>(tring)[i] = 0u;      // (pixels 32, 33 are never written)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // an image row: 3 channels x 17 pixel pairs (34 pixels from x0 - 2; x0 - 2 and W are even: a pair is inside or outside)
+    const int ich = min(lane, 50) / 17, iv2 = min(lane, 50) % 17, ix = x0 - 2 + 2 * iv2;
+    const bool iok = lane < 51 && ix >= 0 && ix < W;
+    const unsigned iofs = 4u * ((unsigned)ich * (unsigned)HW + (unsigned)min(max(ix, 0), W - 2));
+    float2 ri;
+    auto load_row = [&](int yy) {
+        const int yc = min(max(yy, 0), H - 1);
+        ri = at_b(reinterpret_cast<const float2*>(in + (size_t)yc * W), iofs);
+    };
+    auto stash_row = [&](int slot, int yy) {
+        if (lane < 51) {
+            const bool ok = iok && yy >= 0 && yy < H;
+            *reinterpret_cast<float2*>(&iring[slot * SLOTI + ich * RS + 2 * iv2]) = ok ? ri : make_float2(0.0f, 0.0f);
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { load_row(yb - 2 + r); stash_row(r, yb - 2 + r); }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    const float* ib = iring + kk * RS + n;                                      // conv1 B operand: channel kk, image-ring pixel q + dx
+    int boff[5][3];                                                             // conv2 B fragments (as al_conv16h_rows_kernel)
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+        const int tap = min(2 * ks + (kk >> 1), 8);
+#pragma unroll
+        for (int ph = 0; ph < 3; ++ph) boff[ks][ph] = ((ph + tap / 3) % 3) * ROWH + (n + tap % 3) * PXS + 8 * (kk & 1);
+    }
+    const unsigned HWb = 4u * (unsigned)HW, lo = (unsigned)(4 * kk) * HWb + 4u * n;
+    auto step = [&](auto ph, int y) {
+        // image rows y, y + 1, y + 2 in slots PH, PH + 1, PH + 2 (mod 3); conv1 rows y - 1, y in slots PH, PH + 1; conv1 row y + 1 -> slot PH + 2
+        constexpr int PH = decltype(ph)::value;
+        load_row(y + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            f32x4 acc[2];
+            acc[0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; acc[1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+                    acc[hf] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[tap], ib[((PH + tap / 3) % 3) * SLOTI + tap % 3 + 16 * hf], acc[hf], 0, 0, 0);
+            const bool rowok = y + 1 >= 0 && y + 1 < H;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int q = 16 * hf + n, x = x0 - 1 + q;
+                const bool ok = rowok && x >= 0 && x < W;
+                float vv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) vv[i] = ok ? SWEEP_SELU(fmaf(acc[hf][i], alr1[i], ber1[i])) : 0.0f;
+                unsigned h01, l01, h23, l23; float amax = 0.0f;
+                sslam::split2_fast(vv[0], vv[1], h01, l01, amax);
+                sslam::split2_fast(vv[2], vv[3], h23, l23, amax);
+                _Float16* tq = tring + ((PH + 2) % 3) * ROWH + q * PXS + 4 * kk;
+                *reinterpret_cast<uint2*>(tq) = make_uint2(h01, h23);
+                *reinterpret_cast<uint2*>(tq + PLH) = make_uint2(l01, l23);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (y >= yb) {
+            f32x4 c1[2], c2[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) { c1[hf] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; c2[hf] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+#pragma unroll
+            for (int ks = 0; ks < 5; ++ks)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const sslam::half8 xh = *reinterpret_cast<const sslam::half8*>(&tring[boff[ks][PH] + 16 * hf * PXS]);
+                    const sslam::half8 xl = *reinterpret_cast<const sslam::half8*>(&tring[boff[ks][PH] + 16 * hf * PXS + PLH]);
+                    c1[hf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], xh, c1[hf], 0, 0, 0);
+                    c2[hf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], xl, c2[hf], 0, 0, 0);
+                    c2[hf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks], xh, c2[hf], 0, 0, 0);
+                }
+            float* orow = out + (size_t)y * W + x0;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int j = 16 * hf + n;
+                if (j >= B1_SW || x0 + j >= W) continue;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    at_b(orow, lo + i * HWb + 64u * hf) = SWEEP_SELU(fmaf(c1[hf][i] + c2[hf][i] * sslam::SPLIT_INV, alr2[i], ber2[i]));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        stash_row(PH, y + 3);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    };
+    for (int y = yb - 2; y < ye; y += 3) {
+        step(std::integral_constant<int, 0>{}, y);
+        if (y + 1 >= ye) break;
+        step(std::integral_constant<int, 1>{}, y + 1);
+        if (y + 2 >= ye) break;
+        step(std::integral_constant<int, 2>{}, y + 2);
+    }
+}
+
+// ------------------------------------------------------------------------ //
 //  2. small-map stages (1/8 and 1/32 resolution): pooling, offset conv,
 //     deformable conv (torchvision deform_conv2d semantics) + BN + residual + SELU
 // ------------------------------------------------------------------------ //
@@ -2669,11 +2801,26 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
 #ifndef AL_B1C2_SPLIT
 #define AL_B1C2_SPLIT 1
 #endif
+#ifndef AL_B1_FUSED
+#define AL_B1_FUSED 1
+#endif
+#if AL_B1_FUSED
+    if (Wp % 2 == 0) {
+        // ~3 waves per SIMD when the batch allows; at least eight rows per wave (two extra conv1 rows per block)
+        const int strips = sslam::cdiv(Wp, B1_SW);
+        const int nblk = std::max(1, std::min(sslam::cdiv(Hp, 8), 3072 / std::max(1, strips * F)));
+        const int hs1 = sslam::cdiv(Hp, nblk);
+        hipLaunchKernelGGL(al_block1_rows_kernel, dim3(strips, sslam::cdiv(Hp, hs1), uF), dim3(64), 0, s, g->img, g->x1, Hp, Wp, hs1,
+                           g->b1c1.w, g->b1c1.a, g->b1c1.b, g->b1c2f, g->b1c2.a, g->b1c2.b, fs);
+    } else
+#endif
 #if AL_B1C2_SPLIT
+    {
     hipLaunchKernelGGL((al_conv16_rows_kernel<3, true>), dim3(sslam::cdiv(Wp, CT_W), sslam::cdiv(Hp, hs), uF), dim3(64), 0, s, g->img, g->x1a, Hp, Wp,
                        hs, g->b1c1.w, g->b1c1.a, g->b1c1.b, fs);
     hipLaunchKernelGGL(al_conv16h_rows_kernel, dim3(sslam::cdiv(Wp, CT_W), sslam::cdiv(Hp, hs), uF), dim3(64), 0, s,
                        reinterpret_cast<const _Float16*>(g->x1a), g->x1, Hp, Wp, hs, g->b1c2f, g->b1c2.a, g->b1c2.b, fs);
+    }
 #else
     hipLaunchKernelGGL((al_conv16_rows_kernel<3>), dim3(sslam::cdiv(Wp, CT_W), sslam::cdiv(Hp, hs), uF), dim3(64), 0, s, g->img, g->x1a, Hp, Wp,
                        hs, g->b1c1.w, g->b1c1.a, g->b1c1.b, fs);
