@@ -1751,29 +1751,41 @@ __global__ void al_dcn_wt_kernel(const float* __restrict__ src, float* __restric
 }
 
 // 1x1 conv (no bias) + SELU: one thread per pixel produces all 32 outputs (inputs read once,
-// weights [ci][32] as wave-uniform scalar loads)
-__global__ __launch_bounds__(256) void al_gate_kernel(const float* __restrict__ in, float* __restrict__ out, int CIN,
+// weights [ci][32] as wave-uniform scalar loads).  r04: the channel loop is unrolled with every input of the pixel loaded up
+// front (rolled, each of its 32 trips waited for its own load: 32 serial memory latencies per thread), and the channel-last
+// copy leaves through LDS as whole 128-byte lines per 8 lanes (direct, every lane wrote 16-byte pieces of its own line).
+template <int CIN>
+__global__ __launch_bounds__(256) void al_gate_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                       int HW, const float* __restrict__ w /*[ci][32]*/,
                                                       float* __restrict__ out_cl /*[HW][32]*/, size_t fs) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= HW) return;
-    in = fsh(in, blockIdx.y, fs); out = fsh(out, blockIdx.y, fs); out_cl = fsh0(out_cl, blockIdx.y, fs);
+    __shared__ float cl[256 * 33];
+    const int p0 = blockIdx.x * blockDim.x, p = p0 + threadIdx.x, pc = min(p, HW - 1);
+    in = fsh(in, blockIdx.y, fs); out = fsh(out, blockIdx.y, fs); out_cl = fsh(out_cl, blockIdx.y, fs);
+    float v[CIN];
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) v[ci] = in[(size_t)ci * HW + pc];
     float acc[32];
 #pragma unroll
     for (int o = 0; o < 32; ++o) acc[o] = 0.0f;
+#pragma unroll
     for (int ci = 0; ci < CIN; ++ci) {
-        const float v = in[(size_t)ci * HW + p];
         const float* wp = w + ci * 32;
 #pragma unroll
-        for (int o = 0; o < 32; ++o) acc[o] = fmaf(v, wp[o], acc[o]);
+        for (int o = 0; o < 32; ++o) acc[o] = fmaf(v[ci], wp[o], acc[o]);
     }
 #pragma unroll
-    for (int o = 0; o < 32; ++o) acc[o] = selu(acc[o]);
+    for (int o = 0; o < 32; ++o) { acc[o] = selu(acc[o]); cl[threadIdx.x * 33 + o] = acc[o]; }
+    if (p < HW) {
 #pragma unroll
-    for (int o = 0; o < 32; ++o) out[(size_t)o * HW + p] = acc[o];
-#pragma unroll
-    for (int o = 0; o < 32; o += 4)
-        *reinterpret_cast<float4*>(out_cl + (size_t)p * 32 + o) = make_float4(acc[o], acc[o + 1], acc[o + 2], acc[o + 3]);
+        for (int o = 0; o < 32; ++o) out[(size_t)o * HW + p] = acc[o];
+    }
+    __syncthreads();
+    const int npx = min(256, HW - p0);
+    float* dst = out_cl + (size_t)p0 * 32;
+    for (int i = threadIdx.x; i < npx * 8; i += 256) {
+        const int q = i >> 3, c4 = (i & 7) * 4;
+        *reinterpret_cast<float4*>(dst + (size_t)q * 32 + c4) = make_float4(cl[q * 33 + c4], cl[q * 33 + c4 + 1], cl[q * 33 + c4 + 2], cl[q * 33 + c4 + 3]);
+    }
 }
 
 // small-map variant (1/8, 1/32 resolution): one thread per (co, pixel), more parallelism
@@ -2931,7 +2943,7 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
                        W4, g->b4c2ot, g->b4c2.ob, mo4, fs);
     dcn(g->t4cl, 128, g->x4, 128, H4, W4, g->b4c2t, g->b4c2.a, g->b4c2.b, g->p4cl, 64, g->b4dwt, g->b4db, nullptr);
     // gates
-    hipLaunchKernelGGL(al_gate_kernel, dim3(sslam::cdiv(H2 * W2, 256), uF), dim3(256), 0, s, g->x2, g->g2, 32, H2 * W2, g->gw2, g->g2cl, fs);
+    hipLaunchKernelGGL(al_gate_kernel<32>, dim3(sslam::cdiv(H2 * W2, 256), uF), dim3(256), 0, s, g->x2, g->g2, H2 * W2, g->gw2, g->g2cl, fs);
     hipLaunchKernelGGL(al_gate_small_kernel, dim3(sslam::cdiv(32 * HW3, 256), uF), dim3(256), 0, s, g->x3, g->g3, 64, HW3, g->gw3, g->g3cl, fs);
     hipLaunchKernelGGL(al_gate_small_kernel, dim3(sslam::cdiv(32 * HW4, 256), uF), dim3(256), 0, s, g->x4, g->g4, 128, HW4, g->gw4, g->g4cl, fs);
     // aggregation + score head
