@@ -110,6 +110,7 @@ __global__ void al_to_float_kernel(FrameIn srcs, float* __restrict__ dst, Dims d
         } else {
             v = 0.0f;
             const int r = kx / 2;
+#pragma unroll 8            // (rolled, every tap waited for its own byte load)
             for (int k = 0; k < kx; ++k) {
                 int xx = x + k - r;
                 xx = xx < 0 ? -xx : (xx >= d.W ? 2 * d.W - 2 - xx : xx);       // reflect
@@ -144,6 +145,7 @@ __global__ void al_resize_pad_kernel(const float* __restrict__ src, float* __res
         } else {
             v00 = v01 = v10 = v11 = 0.0f;
             const int r = ky / 2;
+#pragma unroll 4            // (16 loads in flight per trip group; rolled, each tap row waited for its own four)
             for (int k = 0; k < ky; ++k) {
                 int ya = y0 + k - r, yb = y1 + k - r;
                 ya = ya < 0 ? -ya : (ya >= d.H ? 2 * d.H - 2 - ya : ya);
@@ -1633,6 +1635,102 @@ __global__ __launch_bounds__(256) void al_offset_conv_kernel(const float* __rest
     }
 }
 
+// ------------------------------------------------------------------------ //
+//  2a. the offset convolutions of the deformable blocks (3 x 3, CIN -> 18, + bias, clamp) on the split-precision matrix pipe
+//      (r04).  The direct form above spreads k = (channel, tap) over the lanes and reduces 18 sums over 64 lanes per pixel
+//      group: 40 us per launch for 53 MFLOP.  Here ONE WAVE computes one output row segment of 32 pixels x all 18 (of 32)
+//      channels: it converts its 3 x 34 pixel neighbourhood of the channel-last fp32 input (the copies the im2col kernel reads)
+//      to fp16 (hi, lo) planes in LDS once, then runs 9 x CIN / 16 k-steps of three v_mfma_f32_32x32x16_f16; A fragments
+//      (weights) stream from a fragment-ordered split copy through L1.  Offsets move by ~1e-6 pixel (2^-22 relative).
+// ------------------------------------------------------------------------ //
+template <int CIN>
+__global__ void al_offc_wfrag_kernel(const float* __restrict__ ow /*[ci*9 + tap][18]*/, _Float16* __restrict__ wf) {
+    constexpr int KS = 9 * CIN / 16;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // (k-step, lane, e)
+    if (i >= KS * 64 * 8) return;
+    const int e = i & 7, lane = (i >> 3) & 63, ks = i >> 9;
+    const int co = lane & 31, tap = ks / (CIN / 16), ci = 16 * (ks % (CIN / 16)) + 8 * (lane >> 5) + e;
+    const float v = co < 18 ? ow[(ci * 9 + tap) * 18 + co] : 0.0f;
+    const _Float16 hi = fabsf(v) < 6.103515625e-5f ? (_Float16)0.0f : (_Float16)v;
+    const _Float16 lo = (_Float16)((v - (float)hi) * sslam::SPLIT_SCALE);
+    wf[((ks * 2 + 0) * 64 + lane) * 8 + e] = hi;
+    wf[((ks * 2 + 1) * 64 + lane) * 8 + e] = lo;
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256) void al_offset_conv_h_kernel(const float* __restrict__ in /* channel-last [H W][CIN] */, float* __restrict__ off /*[18][H W]*/,
+                                                              int H, int W, const _Float16* __restrict__ wf, const float* __restrict__ b,
+                                                              float max_off, size_t fs) {
+    // four waves per output tile (32 pixels of one row x 18 channels): they fill the tile together and split the k-steps
+    // (wave w takes k-steps w, w + 4, ...); the partial sums meet in LDS in wave order.  The maps are small (40 x 128 and
+    // 10 x 32 pixels): with one wave per tile the 1/32 levels were 80 waves of 216 serial MFMAs.
+    in = fsh(in, blockIdx.z, fs); off = fsh(off, blockIdx.z, fs);
+    constexpr int CP = CIN + 8, ROWH = 34 * CP, PLH = 3 * ROWH, C8 = CIN / 8, NFR = 3 * 34 * C8, KSC = CIN / 16, KS = 9 * KSC;
+    constexpr int TILEH = 2 * PLH > 4 * 16 * 64 * 2 ? 2 * PLH : 4 * 16 * 64 * 2;      // (the partial sums reuse the tile: 4 x 16 x 64 floats)
+    __shared__ __attribute__((aligned(16))) _Float16 tile[TILEH];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), h = lane >> 5, px = lane & 31;
+    const int x0 = blockIdx.x * 32, y = blockIdx.y;
+    // fill: fragments of 8 channels, (row, pixel, c8) with c8 fastest - 32 contiguous bytes per thread, whole pixels per thread group
+    constexpr int NR = (NFR + 255) / 256, CH = NR < 4 ? NR : 4;      // rounds; CH of them with their loads in flight together
+    for (int j0 = 0; j0 < NR; j0 += CH) {
+        float4 va[CH], vb[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int idx = min(t + 256 * (j0 + j), NFR - 1), c8 = idx % C8, q = (idx / C8) % 34, row = idx / (C8 * 34);
+            const int yy = min(max(y + row - 1, 0), H - 1), xx = min(max(x0 + q - 1, 0), W - 1);
+            const float* p = in + ((size_t)yy * W + xx) * CIN + 8 * c8;
+            va[j] = *reinterpret_cast<const float4*>(p); vb[j] = *reinterpret_cast<const float4*>(p + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int idx = t + 256 * (j0 + j);
+            if (idx >= NFR) continue;
+            const int c8 = idx % C8, q = (idx / C8) % 34, row = idx / (C8 * 34);
+            const int yy = y + row - 1, xx = x0 + q - 1;
+            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const float v[8] = {va[j].x, va[j].y, va[j].z, va[j].w, vb[j].x, vb[j].y, vb[j].z, vb[j].w};
+            uint4 hi, lo; float amax = 0.0f;
+            sslam::split8_fast(v, hi, lo, amax);
+            if (!ok) { hi = make_uint4(0u, 0u, 0u, 0u); lo = hi; }
+            *reinterpret_cast<uint4*>(&tile[row * ROWH + q * CP + 8 * c8]) = hi;
+            *reinterpret_cast<uint4*>(&tile[PLH + row * ROWH + q * CP + 8 * c8]) = lo;
+        }
+    }
+    __syncthreads();
+    f32x16 c1, c2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { c1[r] = 0.0f; c2[r] = 0.0f; }
+    const _Float16* bl = tile + px * CP + 8 * h;
+    const _Float16* af = wf + lane * 8;
+#pragma unroll
+    for (int i = 0; i < (KS + 3) / 4; ++i) {
+        const int ks = wave + 4 * i;
+        if (ks >= KS) break;
+        const int tap = ks / KSC, o = (tap / 3) * ROWH + (tap % 3) * CP + 16 * (ks % KSC);
+        const sslam::half8 xh = *reinterpret_cast<const sslam::half8*>(bl + o);
+        const sslam::half8 xl = *reinterpret_cast<const sslam::half8*>(bl + o + PLH);
+        const sslam::half8 ah = *reinterpret_cast<const sslam::half8*>(af + (size_t)(ks * 2 + 0) * 512);
+        const sslam::half8 al = *reinterpret_cast<const sslam::half8*>(af + (size_t)(ks * 2 + 1) * 512);
+        c1 = sslam::mfma16(ah, xh, c1);
+        c2 = sslam::mfma16(ah, xl, c2);
+        c2 = sslam::mfma16(al, xh, c2);
+    }
+    __syncthreads();                                          // every wave is done reading the tile: it becomes the reduction buffer
+    float* red = reinterpret_cast<float*>(tile);             // [wave][r][lane]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = c1[r] + c2[r] * sslam::SPLIT_INV;
+    __syncthreads();
+    if (x0 + px < W) {
+        const size_t HW = (size_t)H * W;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {                     // wave w finishes registers 4 w .. 4 w + 3
+            const int r = 4 * wave + rr, co = acc_row(r, lane);
+            const float v = ((red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane]) + red[(2 * 16 + r) * 64 + lane]) + red[(3 * 16 + r) * 64 + lane];
+            if (co < 18) off[(size_t)co * HW + (size_t)y * W + x0 + px] = fminf(fmaxf(v + b[co], -max_off), max_off);
+        }
+    }
+}
+
 // ---- deformable conv as im2col + matrix-core GEMM --------------------------------------------
 // A direct kernel (weights streamed per pixel group) re-reads the whole weight tensor for every
 // 2-4 pixels: 189 MB of L2 traffic for the 64 -> 64 layer at 1/8 resolution.  Here the bilinear
@@ -2692,6 +2790,7 @@ struct sslam_aliked {
     ALDcnW b3c1, b3c2, b4c1, b4c2;
     const float *b3dw, *b3db, *b4dw, *b4db;
     float *b3c1ot, *b3c2ot, *b4c1ot, *b4c2ot;                              // offset-conv weights as [18][CIN*9]
+    _Float16 *b3c1of, *b3c2of, *b4c1of, *b4c2of;                          // the same, split, fragment order (al_offc_wfrag_kernel)
     float *b3c1t, *b3c2t, *b4c1t, *b4c2t, *b3dwt, *b4dwt, *dcol, *dpart;   // [co][k] copies, im2col buffer, split-K slabs
     const float *gw1, *gw2, *gw3, *gw4;
     const float *sh0, *sh2, *sh4, *sh6;
@@ -2914,16 +3013,23 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
         hipLaunchKernelGGL(al_dcn_epilogue_kernel, dim3(sslam::cdiv(cout * HWl, 256), uF), dim3(256), 0, s, g->dpart, ks, HWl, cout,
                            outp, al_, be_, res ? 1 : 0, bdp, fs, outp_cl);
     };
+#ifndef AL_OFFC_SPLIT
+#define AL_OFFC_SPLIT 1
+#endif
     // block3 at 1/8 (deformable)
     const int H3 = Hp / 8, W3 = Wp / 8, HW3 = H3 * W3;
     hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(32 * HW3, 256), uF), dim3(256), 0, s, g->x2, g->p3, 32, H2, W2, 4, fs, g->p3cl);
     const float mo3 = (float)(H3 > W3 ? H3 : W3) / 4.0f;
-    if (F >= 4) hipLaunchKernelGGL((al_offset_conv_kernel<32, 4>), dim3(sslam::cdiv(HW3, 16), uF), dim3(256), 0, s, g->p3, g->off, H3,
+    if (AL_OFFC_SPLIT) hipLaunchKernelGGL((al_offset_conv_h_kernel<32>), dim3(sslam::cdiv(W3, 32), H3, uF), dim3(256), 0, s, g->p3cl, g->off, H3,
+                       W3, g->b3c1of, g->b3c1.ob, mo3, fs);
+    else if (F >= 4) hipLaunchKernelGGL((al_offset_conv_kernel<32, 4>), dim3(sslam::cdiv(HW3, 16), uF), dim3(256), 0, s, g->p3, g->off, H3,
                        W3, g->b3c1ot, g->b3c1.ob, mo3, fs);
     else hipLaunchKernelGGL((al_offset_conv_kernel<32, 1>), dim3(sslam::cdiv(HW3, 4), uF), dim3(256), 0, s, g->p3, g->off, H3,
                        W3, g->b3c1ot, g->b3c1.ob, mo3, fs);
     dcn(g->p3cl, 32, g->t3, 64, H3, W3, g->b3c1t, g->b3c1.a, g->b3c1.b, nullptr, 0, nullptr, nullptr, g->t3cl);
-    if (F >= 4) hipLaunchKernelGGL((al_offset_conv_kernel<64, 4>), dim3(sslam::cdiv(HW3, 16), uF), dim3(256), 0, s, g->t3, g->off, H3,
+    if (AL_OFFC_SPLIT) hipLaunchKernelGGL((al_offset_conv_h_kernel<64>), dim3(sslam::cdiv(W3, 32), H3, uF), dim3(256), 0, s, g->t3cl, g->off, H3,
+                       W3, g->b3c2of, g->b3c2.ob, mo3, fs);
+    else if (F >= 4) hipLaunchKernelGGL((al_offset_conv_kernel<64, 4>), dim3(sslam::cdiv(HW3, 16), uF), dim3(256), 0, s, g->t3, g->off, H3,
                        W3, g->b3c2ot, g->b3c2.ob, mo3, fs);
     else hipLaunchKernelGGL((al_offset_conv_kernel<64, 1>), dim3(sslam::cdiv(HW3, 4), uF), dim3(256), 0, s, g->t3, g->off, H3,
                        W3, g->b3c2ot, g->b3c2.ob, mo3, fs);
@@ -2932,12 +3038,16 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
     const int H4 = Hp / 32, W4 = Wp / 32, HW4 = H4 * W4;
     hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(64 * HW4, 256), uF), dim3(256), 0, s, g->x3, g->p4, 64, H3, W3, 4, fs, g->p4cl);
     const float mo4 = (float)(H4 > W4 ? H4 : W4) / 4.0f;
-    if (F >= 4) hipLaunchKernelGGL((al_offset_conv_kernel<64, 4>), dim3(sslam::cdiv(HW4, 16), uF), dim3(256), 0, s, g->p4, g->off, H4,
+    if (AL_OFFC_SPLIT) hipLaunchKernelGGL((al_offset_conv_h_kernel<64>), dim3(sslam::cdiv(W4, 32), H4, uF), dim3(256), 0, s, g->p4cl, g->off, H4,
+                       W4, g->b4c1of, g->b4c1.ob, mo4, fs);
+    else if (F >= 4) hipLaunchKernelGGL((al_offset_conv_kernel<64, 4>), dim3(sslam::cdiv(HW4, 16), uF), dim3(256), 0, s, g->p4, g->off, H4,
                        W4, g->b4c1ot, g->b4c1.ob, mo4, fs);
     else hipLaunchKernelGGL((al_offset_conv_kernel<64, 1>), dim3(sslam::cdiv(HW4, 4), uF), dim3(256), 0, s, g->p4, g->off, H4,
                        W4, g->b4c1ot, g->b4c1.ob, mo4, fs);
     dcn(g->p4cl, 64, g->t4, 128, H4, W4, g->b4c1t, g->b4c1.a, g->b4c1.b, nullptr, 0, nullptr, nullptr, g->t4cl);
-    if (F >= 4) hipLaunchKernelGGL((al_offset_conv_kernel<128, 4>), dim3(sslam::cdiv(HW4, 16), uF), dim3(256), 0, s, g->t4, g->off, H4,
+    if (AL_OFFC_SPLIT) hipLaunchKernelGGL((al_offset_conv_h_kernel<128>), dim3(sslam::cdiv(W4, 32), H4, uF), dim3(256), 0, s, g->t4cl, g->off, H4,
+                       W4, g->b4c2of, g->b4c2.ob, mo4, fs);
+    else if (F >= 4) hipLaunchKernelGGL((al_offset_conv_kernel<128, 4>), dim3(sslam::cdiv(HW4, 16), uF), dim3(256), 0, s, g->t4, g->off, H4,
                        W4, g->b4c2ot, g->b4c2.ob, mo4, fs);
     else hipLaunchKernelGGL((al_offset_conv_kernel<128, 1>), dim3(sslam::cdiv(HW4, 4), uF), dim3(256), 0, s, g->t4, g->off, H4,
                        W4, g->b4c2ot, g->b4c2.ob, mo4, fs);
@@ -3035,6 +3145,7 @@ int sslam_aliked_create_batched(sslam_ctx* ctx, const float* weights, size_t n_f
         g->b2c2f = A.take<_Float16>(2 * 32 * 288);
         g->b1c2f = A.take<_Float16>(5 * 2 * 64 * 8);
         g->b2c1f = A.take<_Float16>(10 * 2 * 64 * 8);
+        g->b3c1of = A.take<_Float16>(18 * 2 * 512); g->b3c2of = A.take<_Float16>(36 * 2 * 512); g->b4c1of = A.take<_Float16>(36 * 2 * 512); g->b4c2of = A.take<_Float16>(72 * 2 * 512);
         g->b3c1ot = A.take<float>(288 * 18); g->b3c2ot = A.take<float>(576 * 18); g->b4c1ot = A.take<float>(576 * 18); g->b4c2ot = A.take<float>(1152 * 18);
         g->gk = A.take<float>(64);
     };
@@ -3106,6 +3217,10 @@ int sslam_aliked_create_batched(sslam_ctx* ctx, const float* weights, size_t n_f
         };
         tro(g->b3c1.ow, g->b3c1ot, 288); tro(g->b3c2.ow, g->b3c2ot, 576); tro(g->b4c1.ow, g->b4c1ot, 576);
         tro(g->b4c2.ow, g->b4c2ot, 1152);
+        hipLaunchKernelGGL(al_offc_wfrag_kernel<32>, dim3(sslam::cdiv(18 * 512, 256)), dim3(256), 0, s, g->b3c1.ow, g->b3c1of);
+        hipLaunchKernelGGL(al_offc_wfrag_kernel<64>, dim3(sslam::cdiv(36 * 512, 256)), dim3(256), 0, s, g->b3c2.ow, g->b3c2of);
+        hipLaunchKernelGGL(al_offc_wfrag_kernel<64>, dim3(sslam::cdiv(36 * 512, 256)), dim3(256), 0, s, g->b4c1.ow, g->b4c1of);
+        hipLaunchKernelGGL(al_offc_wfrag_kernel<128>, dim3(sslam::cdiv(72 * 512, 256)), dim3(256), 0, s, g->b4c2.ow, g->b4c2of);
         SSLAM_HIP_CHECK(hipStreamSynchronize(s));
     }
     SSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)al_block2_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B2_LDS));
