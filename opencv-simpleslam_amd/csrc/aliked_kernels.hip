@@ -1834,6 +1834,163 @@ __global__ __launch_bounds__(256) void al_dcn_epilogue_kernel(const float* __res
     if (out_cl) out_cl[(size_t)(i % HW) * COUT + co] = v;       // [pixel][COUT] copy for the next layer's al_dcn_col
 }
 
+// ------------------------------------------------------------------------ //
+//  2b. deformable conv FUSED (r04): bilinear sampling + the K = 9 CIN (+ RC) contraction + BN + residual branch + SELU in ONE
+//      kernel on the split-precision matrix pipe.  As im2col + split-K GEMM + epilogue the layer wrote and re-read its
+//      im2col rows (11.8 MB per frame and layer at 1/8 resolution) and its split-K slabs (as much again) through three
+//      launches of latency-bound small kernels (60 us per layer and batch of 8 frames).  Here a workgroup owns 32 pixels of a
+//      row x all COUT channels; wave w takes the taps w, w + 4, w + 8 (slot 9 = the 1 x 1 residual branch on the block input):
+//      per tap it samples its 32 x CIN values (torchvision deform_conv2d semantics, the arithmetic of al_dcn_col_kernel),
+//      splits them into a wave-private LDS buffer and runs CIN / 16 k-steps x COUT / 32 tiles of three MFMAs; the four
+//      partial sums meet in LDS in wave order.  The BN scale is folded into the main weights at fragment time
+//      (w' = fl(alpha w), one more rounding at 2^-24), so main and residual share one accumulator: v = acc + beta + bd.
+// ------------------------------------------------------------------------ //
+template <int CIN, int COUT, int RC>
+__global__ void al_dcn_wfrag_kernel(const float* __restrict__ w /*[ci][tap][co]*/, const float* __restrict__ alpha,
+                                    const float* __restrict__ wd /*[ci RC][co]*/, _Float16* __restrict__ wf) {
+    constexpr int KSC = CIN / 16, MT = COUT / 32, KSR = RC / 16, NF = (9 * KSC + KSR) * MT;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // (fragment, lane, e)
+    if (i >= NF * 512) return;
+    const int e = i & 7, lane = (i >> 3) & 63, fr = i >> 9;
+    const int mt = fr % MT, ksg = fr / MT;                     // global k-step: 9 taps x KSC, then the residual's KSR
+    const int co = 32 * mt + (lane & 31);
+    float v;
+    if (ksg < 9 * KSC) { const int tap = ksg / KSC, ci = 16 * (ksg % KSC) + 8 * (lane >> 5) + e; v = alpha[co] * w[(ci * 9 + tap) * COUT + co]; }
+    else { const int ci = 16 * (ksg - 9 * KSC) + 8 * (lane >> 5) + e; v = wd[ci * COUT + co]; }
+    const _Float16 hi = fabsf(v) < 6.103515625e-5f ? (_Float16)0.0f : (_Float16)v;
+    const _Float16 lo = (_Float16)((v - (float)hi) * sslam::SPLIT_SCALE);
+    wf[((size_t)fr * 2 + 0) * 512 + lane * 8 + e] = hi;
+    wf[((size_t)fr * 2 + 1) * 512 + lane * 8 + e] = lo;
+}
+
+template <int CIN, int COUT, int RC>
+__global__ __launch_bounds__(256) void al_dcn_h_kernel(const float* __restrict__ in /* channel-last [H W][CIN] */, const float* __restrict__ off /*[18][H W]*/,
+                                                      const float* __restrict__ res_in /* channel-last [H W][RC] */, int H, int W,
+                                                      const _Float16* __restrict__ wf, const float* __restrict__ beta, const float* __restrict__ bd,
+                                                      float* __restrict__ out /*[COUT][H W]*/, float* __restrict__ out_cl /*[H W][COUT] or null*/, size_t fs) {
+    in = fsh(in, blockIdx.z, fs); off = fsh(off, blockIdx.z, fs); res_in = fsh(res_in, blockIdx.z, fs);
+    out = fsh(out, blockIdx.z, fs); out_cl = fsh0(out_cl, blockIdx.z, fs);
+    constexpr int CP = CIN + 8, KSC = CIN / 16, MT = COUT / 32, KSR = RC / 16, C8 = CIN / 8, PLH = 32 * CP;
+    constexpr int BUFH = 2 * PLH;                                              // one wave's tap buffer (halves): [plane][32 px][CP]
+    constexpr int REDF = 4 * MT * 16 * 64;                                     // reduction floats
+    constexpr int LDSH = 4 * BUFH > 2 * REDF ? 4 * BUFH : 2 * REDF;
+    __shared__ __attribute__((aligned(16))) _Float16 lds[LDSH];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), h = lane >> 5, px = lane & 31;
+    const int x0 = blockIdx.x * 32, y = blockIdx.y, HW = H * W;
+    _Float16* buf = lds + wave * BUFH;
+    __shared__ float offs[18 * 32];                           // the tile's offsets, once (they were a dependent global load in front of every sample)
+    for (int i = t; i < 18 * 32; i += 256) offs[i] = off[(size_t)(i >> 5) * HW + y * W + min(x0 + (i & 31), W - 1)];
+    __syncthreads();
+    f32x16 c1[MT], c2[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { c1[m][r] = 0.0f; c2[m][r] = 0.0f; }
+    const _Float16* bl = buf + px * CP + 8 * h;
+    const _Float16* af = wf + lane * 8;
+#pragma unroll 1
+    for (int slot = wave; slot < (RC ? 10 : 9); slot += 4) {
+        const int nks = slot == 9 ? KSR : KSC;
+        // ---- fill: 32 pixels x (channels / 8) fragments of this slot, G items of a lane at a time with all their corner loads in
+        //      flight (one item after the other, every fragment waited out two dependent memory latencies: 50 us per workgroup)
+        const int c8n = slot == 9 ? RC / 8 : C8;
+        constexpr int G = C8 >= 8 ? 4 : C8 / 2;                 // items per lane and group (32 C8 / 64 items per lane in all)
+        for (int it0 = 0; it0 < 32 * c8n / 64; it0 += G) {
+            float4 qa[G][4], qb[G][4]; float wq[G][4]; int cq[G], pq[G];
+#pragma unroll
+            for (int g2 = 0; g2 < G; ++g2) {
+                const int idx = min(lane + 64 * (it0 + g2), 32 * c8n - 1);
+                const int c8 = idx % c8n, q = idx / c8n, xq = min(x0 + q, W - 1), pix = y * W + xq, c = 8 * c8;
+                cq[g2] = c; pq[g2] = q;
+                const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { qa[g2][k] = z; qb[g2][k] = z; wq[g2][k] = 0.0f; }
+                if (slot == 9) {
+                    qa[g2][0] = *reinterpret_cast<const float4*>(res_in + (size_t)pix * RC + c);
+                    qb[g2][0] = *reinterpret_cast<const float4*>(res_in + (size_t)pix * RC + c + 4);
+                    wq[g2][0] = 1.0f;
+                } else {
+                    // torchvision deform_conv2d bilinear sample (al_dcn_col_kernel's arithmetic); offsets from the tile's LDS copy
+                    const float ys = (float)(y - 1 + slot / 3) + offs[(2 * slot) * 32 + q];
+                    const float xs = (float)(xq - 1 + slot % 3) + offs[(2 * slot + 1) * 32 + q];
+                    if (!(ys <= -1.0f || ys >= (float)H || xs <= -1.0f || xs >= (float)W)) {
+                        const float fy = floorf(ys), fx = floorf(xs);
+                        const int y0 = (int)fy, xx0 = (int)fx, y1 = y0 + 1, xx1 = xx0 + 1;
+                        const float ly = ys - fy, lx = xs - fx, hy = 1.0f - ly, hx = 1.0f - lx;
+                        const bool m1 = y0 >= 0 && xx0 >= 0, m2 = y0 >= 0 && xx1 <= W - 1, m3 = y1 <= H - 1 && xx0 >= 0, m4 = y1 <= H - 1 && xx1 <= W - 1;
+                        const int i1 = m1 ? y0 * W + xx0 : 0, i2 = m2 ? y0 * W + xx1 : 0, i3 = m3 ? y1 * W + xx0 : 0, i4 = m4 ? y1 * W + xx1 : 0;
+                        wq[g2][0] = hy * hx; wq[g2][1] = hy * lx; wq[g2][2] = ly * hx; wq[g2][3] = ly * lx;
+                        const float* p1 = in + (size_t)i1 * CIN + c; const float* p2 = in + (size_t)i2 * CIN + c;
+                        const float* p3 = in + (size_t)i3 * CIN + c; const float* p4 = in + (size_t)i4 * CIN + c;
+                        if (m1) { qa[g2][0] = *reinterpret_cast<const float4*>(p1); qb[g2][0] = *reinterpret_cast<const float4*>(p1 + 4); }
+                        if (m2) { qa[g2][1] = *reinterpret_cast<const float4*>(p2); qb[g2][1] = *reinterpret_cast<const float4*>(p2 + 4); }
+                        if (m3) { qa[g2][2] = *reinterpret_cast<const float4*>(p3); qb[g2][2] = *reinterpret_cast<const float4*>(p3 + 4); }
+                        if (m4) { qa[g2][3] = *reinterpret_cast<const float4*>(p4); qb[g2][3] = *reinterpret_cast<const float4*>(p4 + 4); }
+                    }
+                }
+            }
+#pragma unroll
+            for (int g2 = 0; g2 < G; ++g2) {
+                if (lane + 64 * (it0 + g2) >= 32 * c8n) continue;
+                float o[8];
+                if (slot == 9) {
+                    o[0] = qa[g2][0].x; o[1] = qa[g2][0].y; o[2] = qa[g2][0].z; o[3] = qa[g2][0].w;
+                    o[4] = qb[g2][0].x; o[5] = qb[g2][0].y; o[6] = qb[g2][0].z; o[7] = qb[g2][0].w;
+                } else {
+                    const float w1 = wq[g2][0], w2 = wq[g2][1], w3 = wq[g2][2], w4 = wq[g2][3];
+                    const float v1[8] = {qa[g2][0].x, qa[g2][0].y, qa[g2][0].z, qa[g2][0].w, qb[g2][0].x, qb[g2][0].y, qb[g2][0].z, qb[g2][0].w};
+                    const float v2[8] = {qa[g2][1].x, qa[g2][1].y, qa[g2][1].z, qa[g2][1].w, qb[g2][1].x, qb[g2][1].y, qb[g2][1].z, qb[g2][1].w};
+                    const float v3[8] = {qa[g2][2].x, qa[g2][2].y, qa[g2][2].z, qa[g2][2].w, qb[g2][2].x, qb[g2][2].y, qb[g2][2].z, qb[g2][2].w};
+                    const float v4[8] = {qa[g2][3].x, qa[g2][3].y, qa[g2][3].z, qa[g2][3].w, qb[g2][3].x, qb[g2][3].y, qb[g2][3].z, qb[g2][3].w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = w1 * v1[e] + w2 * v2[e] + w3 * v3[e] + w4 * v4[e];
+                }
+                uint4 hi, lo; float amax = 0.0f;
+                sslam::split8_fast(o, hi, lo, amax);
+                *reinterpret_cast<uint4*>(&buf[pq[g2] * CP + cq[g2]]) = hi;
+                *reinterpret_cast<uint4*>(&buf[PLH + pq[g2] * CP + cq[g2]]) = lo;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        // ---- this slot's k-steps
+        const _Float16* afs = af + (size_t)(slot == 9 ? 9 * KSC : slot * KSC) * MT * 2 * 512;
+        for (int s = 0; s < nks; ++s) {
+            const sslam::half8 xh = *reinterpret_cast<const sslam::half8*>(bl + 16 * s);
+            const sslam::half8 xl = *reinterpret_cast<const sslam::half8*>(bl + 16 * s + PLH);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const sslam::half8 ah = *reinterpret_cast<const sslam::half8*>(afs + (size_t)((s * MT + m) * 2 + 0) * 512);
+                const sslam::half8 al = *reinterpret_cast<const sslam::half8*>(afs + (size_t)((s * MT + m) * 2 + 1) * 512);
+                c1[m] = sslam::mfma16(ah, xh, c1[m]);
+                c2[m] = sslam::mfma16(ah, xl, c2[m]);
+                c2[m] = sslam::mfma16(al, xh, c2[m]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");            // the reads above, before the next slot overwrites the buffer
+    }
+    __syncthreads();                                          // every wave is done with its buffer: the memory becomes the reduction buffer
+    float* red = reinterpret_cast<float*>(lds);              // [wave][tile][r][lane]
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave * MT + m) * 16 + r) * 64 + lane] = c1[m][r] + c2[m][r] * sslam::SPLIT_INV;
+    __syncthreads();
+    if (x0 + px < W) {
+        const int pix = y * W + x0 + px;
+#pragma unroll
+        for (int j = 0; j < MT * 4; ++j) {                   // wave w finishes accumulator registers w MT 4 .. + MT 4 - 1 (of MT x 16)
+            const int qi = wave * MT * 4 + j, m = qi / 16, r = qi % 16, co = 32 * m + acc_row(r, lane);
+            const int o = (m * 16 + r) * 64 + lane;
+            float v = ((red[o] + red[o + MT * 1024]) + red[o + 2 * MT * 1024]) + red[o + 3 * MT * 1024];
+            v += beta[co];
+            if (RC) v += bd[co];
+            v = selu(v);
+            out[(size_t)co * HW + pix] = v;
+            if (out_cl) out_cl[(size_t)pix * COUT + co] = v;
+        }
+    }
+}
+
 __global__ void al_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;      // src [R][C] -> dst [C][R]
     if (i >= R * C) return;
@@ -2791,6 +2948,7 @@ struct sslam_aliked {
     const float *b3dw, *b3db, *b4dw, *b4db;
     float *b3c1ot, *b3c2ot, *b4c1ot, *b4c2ot;                              // offset-conv weights as [18][CIN*9]
     _Float16 *b3c1of, *b3c2of, *b4c1of, *b4c2of;                          // the same, split, fragment order (al_offc_wfrag_kernel)
+    _Float16 *b3c1f, *b3c2f, *b4c1f, *b4c2f;                              // deformable-conv weights (BN scale folded, + 1 x 1 branch), split, fragment order
     float *b3c1t, *b3c2t, *b4c1t, *b4c2t, *b3dwt, *b4dwt, *dcol, *dpart;   // [co][k] copies, im2col buffer, split-K slabs
     const float *gw1, *gw2, *gw3, *gw4;
     const float *sh0, *sh2, *sh4, *sh6;
@@ -3016,6 +3174,9 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
 #ifndef AL_OFFC_SPLIT
 #define AL_OFFC_SPLIT 1
 #endif
+#ifndef AL_DCN_FUSED
+#define AL_DCN_FUSED 1
+#endif
     // block3 at 1/8 (deformable)
     const int H3 = Hp / 8, W3 = Wp / 8, HW3 = H3 * W3;
     hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(32 * HW3, 256), uF), dim3(256), 0, s, g->x2, g->p3, 32, H2, W2, 4, fs, g->p3cl);
@@ -3026,14 +3187,18 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
                        W3, g->b3c1ot, g->b3c1.ob, mo3, fs);
     else hipLaunchKernelGGL((al_offset_conv_kernel<32, 1>), dim3(sslam::cdiv(HW3, 4), uF), dim3(256), 0, s, g->p3, g->off, H3,
                        W3, g->b3c1ot, g->b3c1.ob, mo3, fs);
-    dcn(g->p3cl, 32, g->t3, 64, H3, W3, g->b3c1t, g->b3c1.a, g->b3c1.b, nullptr, 0, nullptr, nullptr, g->t3cl);
+    if (AL_DCN_FUSED) hipLaunchKernelGGL((al_dcn_h_kernel<32, 64, 0>), dim3(sslam::cdiv(W3, 32), H3, uF), dim3(256), 0, s, g->p3cl, g->off, nullptr, H3, W3,
+                                         g->b3c1f, g->b3c1.b, nullptr, g->t3, g->t3cl, fs);
+    else dcn(g->p3cl, 32, g->t3, 64, H3, W3, g->b3c1t, g->b3c1.a, g->b3c1.b, nullptr, 0, nullptr, nullptr, g->t3cl);
     if (AL_OFFC_SPLIT) hipLaunchKernelGGL((al_offset_conv_h_kernel<64>), dim3(sslam::cdiv(W3, 32), H3, uF), dim3(256), 0, s, g->t3cl, g->off, H3,
                        W3, g->b3c2of, g->b3c2.ob, mo3, fs);
     else if (F >= 4) hipLaunchKernelGGL((al_offset_conv_kernel<64, 4>), dim3(sslam::cdiv(HW3, 16), uF), dim3(256), 0, s, g->t3, g->off, H3,
                        W3, g->b3c2ot, g->b3c2.ob, mo3, fs);
     else hipLaunchKernelGGL((al_offset_conv_kernel<64, 1>), dim3(sslam::cdiv(HW3, 4), uF), dim3(256), 0, s, g->t3, g->off, H3,
                        W3, g->b3c2ot, g->b3c2.ob, mo3, fs);
-    dcn(g->t3cl, 64, g->x3, 64, H3, W3, g->b3c2t, g->b3c2.a, g->b3c2.b, g->p3cl, 32, g->b3dwt, g->b3db, nullptr);
+    if (AL_DCN_FUSED) hipLaunchKernelGGL((al_dcn_h_kernel<64, 64, 32>), dim3(sslam::cdiv(W3, 32), H3, uF), dim3(256), 0, s, g->t3cl, g->off, g->p3cl, H3, W3,
+                                         g->b3c2f, g->b3c2.b, g->b3db, g->x3, nullptr, fs);
+    else dcn(g->t3cl, 64, g->x3, 64, H3, W3, g->b3c2t, g->b3c2.a, g->b3c2.b, g->p3cl, 32, g->b3dwt, g->b3db, nullptr);
     // block4 at 1/32
     const int H4 = Hp / 32, W4 = Wp / 32, HW4 = H4 * W4;
     hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(64 * HW4, 256), uF), dim3(256), 0, s, g->x3, g->p4, 64, H3, W3, 4, fs, g->p4cl);
@@ -3044,14 +3209,18 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
                        W4, g->b4c1ot, g->b4c1.ob, mo4, fs);
     else hipLaunchKernelGGL((al_offset_conv_kernel<64, 1>), dim3(sslam::cdiv(HW4, 4), uF), dim3(256), 0, s, g->p4, g->off, H4,
                        W4, g->b4c1ot, g->b4c1.ob, mo4, fs);
-    dcn(g->p4cl, 64, g->t4, 128, H4, W4, g->b4c1t, g->b4c1.a, g->b4c1.b, nullptr, 0, nullptr, nullptr, g->t4cl);
+    if (AL_DCN_FUSED) hipLaunchKernelGGL((al_dcn_h_kernel<64, 128, 0>), dim3(sslam::cdiv(W4, 32), H4, uF), dim3(256), 0, s, g->p4cl, g->off, nullptr, H4, W4,
+                                         g->b4c1f, g->b4c1.b, nullptr, g->t4, g->t4cl, fs);
+    else dcn(g->p4cl, 64, g->t4, 128, H4, W4, g->b4c1t, g->b4c1.a, g->b4c1.b, nullptr, 0, nullptr, nullptr, g->t4cl);
     if (AL_OFFC_SPLIT) hipLaunchKernelGGL((al_offset_conv_h_kernel<128>), dim3(sslam::cdiv(W4, 32), H4, uF), dim3(256), 0, s, g->t4cl, g->off, H4,
                        W4, g->b4c2of, g->b4c2.ob, mo4, fs);
     else if (F >= 4) hipLaunchKernelGGL((al_offset_conv_kernel<128, 4>), dim3(sslam::cdiv(HW4, 16), uF), dim3(256), 0, s, g->t4, g->off, H4,
                        W4, g->b4c2ot, g->b4c2.ob, mo4, fs);
     else hipLaunchKernelGGL((al_offset_conv_kernel<128, 1>), dim3(sslam::cdiv(HW4, 4), uF), dim3(256), 0, s, g->t4, g->off, H4,
                        W4, g->b4c2ot, g->b4c2.ob, mo4, fs);
-    dcn(g->t4cl, 128, g->x4, 128, H4, W4, g->b4c2t, g->b4c2.a, g->b4c2.b, g->p4cl, 64, g->b4dwt, g->b4db, nullptr);
+    if (AL_DCN_FUSED) hipLaunchKernelGGL((al_dcn_h_kernel<128, 128, 64>), dim3(sslam::cdiv(W4, 32), H4, uF), dim3(256), 0, s, g->t4cl, g->off, g->p4cl, H4, W4,
+                                         g->b4c2f, g->b4c2.b, g->b4db, g->x4, nullptr, fs);
+    else dcn(g->t4cl, 128, g->x4, 128, H4, W4, g->b4c2t, g->b4c2.a, g->b4c2.b, g->p4cl, 64, g->b4dwt, g->b4db, nullptr);
     // gates
     hipLaunchKernelGGL(al_gate_kernel<32>, dim3(sslam::cdiv(H2 * W2, 256), uF), dim3(256), 0, s, g->x2, g->g2, H2 * W2, g->gw2, g->g2cl, fs);
     hipLaunchKernelGGL(al_gate_small_kernel, dim3(sslam::cdiv(32 * HW3, 256), uF), dim3(256), 0, s, g->x3, g->g3, 64, HW3, g->gw3, g->g3cl, fs);
@@ -3145,6 +3314,8 @@ int sslam_aliked_create_batched(sslam_ctx* ctx, const float* weights, size_t n_f
         g->b2c2f = A.take<_Float16>(2 * 32 * 288);
         g->b1c2f = A.take<_Float16>(5 * 2 * 64 * 8);
         g->b2c1f = A.take<_Float16>(10 * 2 * 64 * 8);
+        g->b3c1f = A.take<_Float16>((size_t)(9 * 2 + 0) * 2 * 2 * 512); g->b3c2f = A.take<_Float16>((size_t)(9 * 4 + 2) * 2 * 2 * 512);
+        g->b4c1f = A.take<_Float16>((size_t)(9 * 4 + 0) * 4 * 2 * 512); g->b4c2f = A.take<_Float16>((size_t)(9 * 8 + 4) * 4 * 2 * 512);
         g->b3c1of = A.take<_Float16>(18 * 2 * 512); g->b3c2of = A.take<_Float16>(36 * 2 * 512); g->b4c1of = A.take<_Float16>(36 * 2 * 512); g->b4c2of = A.take<_Float16>(72 * 2 * 512);
         g->b3c1ot = A.take<float>(288 * 18); g->b3c2ot = A.take<float>(576 * 18); g->b4c1ot = A.take<float>(576 * 18); g->b4c2ot = A.take<float>(1152 * 18);
         g->gk = A.take<float>(64);
@@ -3217,6 +3388,10 @@ int sslam_aliked_create_batched(sslam_ctx* ctx, const float* weights, size_t n_f
         };
         tro(g->b3c1.ow, g->b3c1ot, 288); tro(g->b3c2.ow, g->b3c2ot, 576); tro(g->b4c1.ow, g->b4c1ot, 576);
         tro(g->b4c2.ow, g->b4c2ot, 1152);
+        hipLaunchKernelGGL((al_dcn_wfrag_kernel<32, 64, 0>), dim3(sslam::cdiv((9 * 2 + 0) * 2 * 512, 256)), dim3(256), 0, s, g->b3c1.w, g->b3c1.a, nullptr, g->b3c1f);
+        hipLaunchKernelGGL((al_dcn_wfrag_kernel<64, 64, 32>), dim3(sslam::cdiv((9 * 4 + 2) * 2 * 512, 256)), dim3(256), 0, s, g->b3c2.w, g->b3c2.a, g->b3dw, g->b3c2f);
+        hipLaunchKernelGGL((al_dcn_wfrag_kernel<64, 128, 0>), dim3(sslam::cdiv((9 * 4 + 0) * 4 * 512, 256)), dim3(256), 0, s, g->b4c1.w, g->b4c1.a, nullptr, g->b4c1f);
+        hipLaunchKernelGGL((al_dcn_wfrag_kernel<128, 128, 64>), dim3(sslam::cdiv((9 * 8 + 4) * 4 * 512, 256)), dim3(256), 0, s, g->b4c2.w, g->b4c2.a, g->b4dw, g->b4c2f);
         hipLaunchKernelGGL(al_offc_wfrag_kernel<32>, dim3(sslam::cdiv(18 * 512, 256)), dim3(256), 0, s, g->b3c1.ow, g->b3c1of);
         hipLaunchKernelGGL(al_offc_wfrag_kernel<64>, dim3(sslam::cdiv(36 * 512, 256)), dim3(256), 0, s, g->b3c2.ow, g->b3c2of);
         hipLaunchKernelGGL(al_offc_wfrag_kernel<64>, dim3(sslam::cdiv(36 * 512, 256)), dim3(256), 0, s, g->b4c1.ow, g->b4c1of);
