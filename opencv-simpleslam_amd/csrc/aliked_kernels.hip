@@ -2247,6 +2247,30 @@ __device__ __forceinline__ float2 feat_pair(const Pyr& P, const float* __restric
     return make_float2(a * r, b * r);        // channels: lane<32: (c, 64+c) ; lane>=32: (32+c, 96+c)
 }
 
+// r04: the same value with every gather addressed as (wave-uniform map pointer) + (32-bit byte offset of the lane): one vector
+// add per tap instead of a 64-bit multiply-add chain (the descriptor head's kernels are bound by vector-instruction issue,
+// and ~250 of al_sample_kernel's 489 vector instructions were address arithmetic).  Maps are < 4 GB.
+__device__ __forceinline__ float up_eval_cl32(const float* __restrict__ p, const UpTap& t, unsigned cb) {
+    return t.w10 * (t.w00 * at_b(p, (unsigned)t.o00 * 128u + cb) + t.w01 * at_b(p, (unsigned)t.o01 * 128u + cb)) +
+           t.w11 * (t.w00 * at_b(p, (unsigned)t.o10 * 128u + cb) + t.w01 * at_b(p, (unsigned)t.o11 * 128u + cb));
+}
+__device__ __forceinline__ float2 feat_pair32(const Pyr& P, const float* __restrict__ rnorm, int pl, int pt,
+                                              int y, int x, int lane) {
+    const int yp = y + pt, xp = x + pl;
+    const unsigned pix = (unsigned)(yp * P.Wp + xp);
+    float a, b;
+    const unsigned cb = 4u * (lane & 31);
+    if (lane < 32) {
+        a = at_b(P.g1cl, pix * 128u + cb);
+        b = up_eval_cl32(P.g3cl, up_tap(yp, xp, P.Hp, P.Wp, 8, P.sy8, P.sx8), cb);
+    } else {
+        a = up_eval_cl32(P.g2cl, up_tap(yp, xp, P.Hp, P.Wp, 2, P.sy2, P.sx2), cb);
+        b = up_eval_cl32(P.g4cl, up_tap(yp, xp, P.Hp, P.Wp, 32, P.sy32, P.sx32), cb);
+    }
+    const float r = rnorm[pix];
+    return make_float2(a * r, b * r);
+}
+
 // ------------------------------------------------------------------------ //
 //  4. score head tail: 3x3 (8->4) SELU, 3x3 (4->4) SELU, 3x3 (4->1), sigmoid.
 //     One kernel, intermediate layers kept in LDS; zero padding at the padded-map border.
@@ -2704,7 +2728,7 @@ __global__ __launch_bounds__(256) void al_patch_kernel(Pyr P0, const float* __re
     ctrl = fsh(ctrl, blockIdx.y, fs);
     // one wave per (keypoint, patch row): its three taps' 42 gathers are in flight together (one wave per tap was pure
     // latency: three quarters of the wave cycles parked in s_waitcnt)
-    const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (a scalar)
     const int n = gw / 3, trow = gw % 3;
     if (n >= ctrl->n_kp) return;
     const float kx = (kp_norm[2 * n] / 2.0f + 0.5f) * (float)(w - 1);
@@ -2715,7 +2739,7 @@ __global__ __launch_bounds__(256) void al_patch_kernel(Pyr P0, const float* __re
     cy = min(max(cy, 0), h - 1 - 3);
     float2 f[3];
 #pragma unroll
-    for (int tc = 0; tc < 3; ++tc) f[tc] = feat_pair(P, rnorm, pl, pt, cy + trow, cx + tc, lane);
+    for (int tc = 0; tc < 3; ++tc) f[tc] = feat_pair32(P, rnorm, pl, pt, cy + trow, cx + tc, lane);
     const int c = lane & 31;
     const int ca = lane < 32 ? c : 32 + c, cb = lane < 32 ? 64 + c : 96 + c;
     float* dst = patch + (size_t)n * 1152;
@@ -2761,7 +2785,7 @@ __global__ __launch_bounds__(256) void al_sample_kernel(Pyr P0, const float* __r
                                                         size_t lo_off, const ALCtrl* __restrict__ ctrl, size_t fs) {
     const Pyr P = pyr_at(P0, blockIdx.y, fs);
     rnorm = fsh(rnorm, blockIdx.y, fs); pos = fsh(pos, blockIdx.y, fs); sampled = fsh(sampled, blockIdx.y, fs); ctrl = fsh(ctrl, blockIdx.y, fs);
-    const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (a scalar)
     if (gw >= ctrl->n_kp * 16) return;
     // pos -> normalised -> back to pixels exactly as grid_sample does
     const float gx = 2.0f * pos[gw * 2] / (float)(w - 1) - 1.0f, gy = 2.0f * pos[gw * 2 + 1] / (float)(h - 1) - 1.0f;
@@ -2777,7 +2801,7 @@ __global__ __launch_bounds__(256) void al_sample_kernel(Pyr P0, const float* __r
         const int yy = y0 + (q >> 1), xx = x0 + (q & 1);
         const bool inside = yy >= 0 && yy < h && xx >= 0 && xx < w;
         wgt[q] = inside ? ((q & 1) ? wx1 : wx0) * ((q >> 1) ? wy1 : wy0) : 0.0f;
-        f[q] = feat_pair(P, rnorm, pl, pt, min(max(yy, 0), h - 1), min(max(xx, 0), w - 1), lane);
+        f[q] = feat_pair32(P, rnorm, pl, pt, min(max(yy, 0), h - 1), min(max(xx, 0), w - 1), lane);
     }
     float ax = 0.0f, bx = 0.0f;
 #pragma unroll
