@@ -48,6 +48,12 @@ __device__ __forceinline__ float selu(float x) {
 #endif
 }
 
+// SELU on ocml's expm1f: al_aggregate_kernel keeps it.  With the hardware-exponential form IN THAT KERNEL, 1 / ||F|| came out
+// wrong by 0.2 - 3 % on 16 consecutive pixels (one quarter of a wave) about once in 150 frames when several extractor
+// streams share the GPU - g1, s8 and every other kernel's output stayed bit-stable over 1 200 frames
+// (scripts/stress_aliked_repeat.py, bisected over commits and call sites; not explained: the ISA of both variants reads
+// correctly, a wait state behind v_exp_f32 and other unroll factors change nothing).  With expm1f there: 0 differences.
+__device__ __forceinline__ float selu_precise(float x) { return SELU_SCALE * (x > 0.0f ? x : SELU_ALPHA * expm1f(x)); }
 constexpr int HBINS = 4096;        // score histogram bins (uniform in score, monotone)
 
 struct ALCtrl {
@@ -2202,7 +2208,7 @@ __global__ __launch_bounds__(256) void al_aggregate_kernel(Pyr P0, const float* 
         float a = 0.0f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) a = fmaf(xv[k], P.w1[k * 32 + c], a);
-        a = selu(a);
+        a = selu_precise(a);
         g1s[threadIdx.x * 33 + c] = a;     // the descriptor head gathers this instead of redoing the 16x32 product
         n2 = fmaf(a, a, n2);
 #pragma unroll
@@ -2215,7 +2221,7 @@ __global__ __launch_bounds__(256) void al_aggregate_kernel(Pyr P0, const float* 
     agg_level(P.pre4, (int)(HW / 1024), t4, s, n2);
     if (live) {
 #pragma unroll
-        for (int o = 0; o < 8; ++o) s8[o * HW + pix] = selu(s[o]);
+        for (int o = 0; o < 8; ++o) s8[o * HW + pix] = selu_precise(s[o]);
         rnorm[pix] = 1.0f / fmaxf(sqrtf(n2), 1e-12f);            // F.normalize eps
     }
     __syncthreads();
@@ -3549,6 +3555,15 @@ int sslam_aliked_debug_read(sslam_aliked* g, int which, void* dst, size_t bytes)
         case 7: src = g->img; cap = 3 * HWp * 4; break;
         case 8: src = g->nms; cap = (size_t)d.h * d.w * 4; break;
         case 9: src = g->kp_norm; cap = (size_t)g->max_kpts * 8; break;
+        case 10: src = g->g1cl; cap = 32 * HWp * 4; break;           // (r04: the aggregation's outputs and the gated levels, for determinism checks)
+        case 11: src = g->rnorm; cap = HWp * 4; break;
+        case 12: src = g->g2; cap = 32 * HWp / 4 * 4; break;
+        case 13: src = g->g3; cap = 32 * HWp / 64 * 4; break;
+        case 14: src = g->g4; cap = 32 * HWp / 1024 * 4; break;
+        case 15: src = g->pre2; cap = AGG_PRE * HWp / 4 * 4; break;
+        case 16: src = g->pre3; cap = AGG_PRE * HWp / 64 * 4; break;
+        case 17: src = g->pre4; cap = AGG_PRE * HWp / 1024 * 4; break;
+        case 18: src = g->s8; cap = 8 * HWp * 4; break;
         default: SSLAM_REQUIRE(false, "sslam_aliked_debug_read: unknown buffer %d", which);
     }
     SSLAM_REQUIRE(bytes <= cap, "sslam_aliked_debug_read: %zu bytes requested, buffer has %zu", bytes, cap);

@@ -223,3 +223,16 @@ def test_batched_entry_gives_the_single_frame_results_bit_for_bit(W, AL, gpu_ctx
         al.close(); single.close()
     for p in dev:
         gpu_ctx.free(p)
+
+
+def test_extraction_is_deterministic_under_concurrency():
+    """Three extractor instances on streams of their own, four un-synchronised batched calls each per repeat: every repeat
+    reproduces the first bit for bit - outputs AND the stage buffers of the debug hook (r04: a SELU variant made 1 / ||F||
+    wrong on 16 consecutive pixels about once in 150 frames, only with several streams on the GPU; the sequential tests
+    never saw it, the four-rank pipeline test did)."""
+    import subprocess, sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, str(ROOT / "scripts" / "stress_aliked_repeat.py"), "80", "3", "2"], cwd=str(ROOT),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "0 mismatching frame results" in out.stdout and "stage buffers differ" not in out.stdout, out.stdout[-2000:]

@@ -97,6 +97,9 @@ def _run_dist_check(backend, nproc, port):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
                           "--master-addr", "127.0.0.1", "--master-port", str(port), "tests/dist_pipeline_check.py"],
                          cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
+    if out.returncode != 0:                                   # the assertion message truncates: keep the whole log where gpurun collects it
+        (ROOT / "gpurun_out").mkdir(exist_ok=True)
+        (ROOT / "gpurun_out" / f"dist_check_fail_{backend}_{nproc}.log").write_text(out.stdout + "\n---- stderr ----\n" + out.stderr)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     assert out.stdout.count("pairs identical to the sequential API") == nproc
 
