@@ -1543,31 +1543,49 @@ __global__ __launch_bounds__(256) void al_refine_kernel(const float* __restrict_
     const int p = blockIdx.x * REFINE_KPB + (threadIdx.x >> 3), c = threadIdx.x & 7;
     if (blockIdx.x * REFINE_KPB >= n) return;
     const unsigned long long key = sel_keys[p < n ? p : 0];
+    // rank = number of larger keys.  r04: the keys pass through LDS in chunks of 2 048 (read straight from global memory each of
+    // a thread's n / 8 compares waited for its own load: 28 us for one frame's 2 048 keypoints, now ~6)
+    __shared__ unsigned long long sk[2048];
     int above = 0;
-#pragma unroll 4
-    for (int j = c; j < n; j += 8) above += sel_keys[j] > key;
+    for (int j0 = 0; j0 < n; j0 += 2048) {
+        const int m = min(2048, n - j0);
+        __syncthreads();
+#pragma unroll 8
+        for (int j = threadIdx.x; j < m; j += 256) sk[j] = sel_keys[j0 + j];
+        __syncthreads();
+#pragma unroll 8
+        for (int j = c; j < m; j += 8) above += sk[j] > key;
+    }
     above += __shfl_xor(above, 1);
     above += __shfl_xor(above, 2);
     above += __shfl_xor(above, 4);
-    if (p >= n || c != 0) return;
+    // the 5 x 5 soft-argmax of a keypoint on its eight lanes: lane c loads and exponentiates elements c, c + 8, c + 16 (, 24); the
+    // sums run on lane 0 over the elements in raster order, as one lane computed them before (bit-identical; the 25 dependent
+    // loads and 25 expf of one lane in eight were 17 of the kernel's 28 us)
+    const bool live = p < n;
     const int i = above;
     const int idx = (int)(0xffffffffu - (unsigned)(key & 0xffffffffull)), x = idx % w, y = idx / w;
-    kp_index[i] = idx;
-    float patch[25], mx = -INFINITY;
+    float pe[4], mx = -INFINITY;
 #pragma unroll
-    for (int k = 0; k < 25; ++k) {
-        const int yy = y + k / 5 - 2, xx = x + k % 5 - 2;
-        patch[k] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? score[(size_t)yy * w + xx] : 0.0f;   // unfold zero pad
-        mx = fmaxf(mx, patch[k]);
+    for (int j = 0; j < 4; ++j) {
+        const int k = c + 8 * j, yy = y + k / 5 - 2, xx = x + k % 5 - 2;
+        pe[j] = (live && k < 25 && yy >= 0 && yy < h && xx >= 0 && xx < w) ? score[(size_t)yy * w + xx] : 0.0f;   // unfold zero pad
+        if (k < 25) mx = fmaxf(mx, pe[j]);
     }
+    mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 4));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pe[j] = expf((pe[j] - mx) / 0.1f);
     float se = 0.0f, sx = 0.0f, sy = 0.0f;
+    const int lane0 = (threadIdx.x & 63) & ~7;
 #pragma unroll
     for (int k = 0; k < 25; ++k) {
-        const float e = expf((patch[k] - mx) / 0.1f);
+        const float e = __shfl(pe[k >> 3], lane0 + (k & 7));
         se += e;
         sx += e * (float)(k % 5 - 2);
         sy += e * (float)(k / 5 - 2);
     }
+    if (!live || c != 0) return;
+    kp_index[i] = idx;
     const float kx = ((float)x + sx / se) / (float)(w - 1) * 2.0f - 1.0f;
     const float ky = ((float)y + sy / se) / (float)(h - 1) * 2.0f - 1.0f;
     kp_norm[2 * i] = kx;
