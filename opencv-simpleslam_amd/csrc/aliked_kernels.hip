@@ -740,20 +740,20 @@ __global__ void al_dcn_wfrag_kernel(const float* __restrict__ w /*[ci][tap][co]*
     wf[((size_t)fr * 2 + 1) * 512 + lane * 8 + e] = lo;
 }
 
-template <int CIN, int COUT, int RC>
+template <int CIN, int COUT, int RC, int CS = 1>      // CS: workgroups per pixel tile, each with COUT / CS output channels (the 1/32 levels: 10 tiles per frame)
 __global__ __launch_bounds__(256) void al_dcn_h_kernel(const float* __restrict__ in /* channel-last [H W][CIN] */, const float* __restrict__ off /*[18][H W]*/,
                                                       const float* __restrict__ res_in /* channel-last [H W][RC] */, int H, int W,
                                                       const _Float16* __restrict__ wf, const float* __restrict__ beta, const float* __restrict__ bd,
                                                       float* __restrict__ out /*[COUT][H W]*/, float* __restrict__ out_cl /*[H W][COUT] or null*/, size_t fs) {
     in = fsh(in, blockIdx.z, fs); off = fsh(off, blockIdx.z, fs); res_in = fsh(res_in, blockIdx.z, fs);
     out = fsh(out, blockIdx.z, fs); out_cl = fsh0(out_cl, blockIdx.z, fs);
-    constexpr int CP = CIN + 8, KSC = CIN / 16, MT = COUT / 32, KSR = RC / 16, C8 = CIN / 8, PLH = 32 * CP;
+    constexpr int CP = CIN + 8, KSC = CIN / 16, MTA = COUT / 32, MT = MTA / CS, KSR = RC / 16, C8 = CIN / 8, PLH = 32 * CP;      // MTA: 32-channel tiles of the layer, MT: of this workgroup
     constexpr int BUFH = 2 * PLH;                                              // one wave's tap buffer (halves): [plane][32 px][CP]
     constexpr int REDF = 4 * MT * 16 * 64;                                     // reduction floats
     constexpr int LDSH = 4 * BUFH > 2 * REDF ? 4 * BUFH : 2 * REDF;
     __shared__ __attribute__((aligned(16))) _Float16 lds[LDSH];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), h = lane >> 5, px = lane & 31;
-    const int x0 = blockIdx.x * 32, y = blockIdx.y, HW = H * W;
+    const int x0 = (blockIdx.x / CS) * 32, y = blockIdx.y, HW = H * W, mt0 = (blockIdx.x % CS) * MT;
     _Float16* buf = lds + wave * BUFH;
     __shared__ float offs[18 * 32];                           // the tile's offsets, once (they were a dependent global load in front of every sample)
     for (int i = t; i < 18 * 32; i += 256) offs[i] = off[(size_t)(i >> 5) * HW + y * W + min(x0 + (i & 31), W - 1)];
@@ -830,14 +830,14 @@ __global__ __launch_bounds__(256) void al_dcn_h_kernel(const float* __restrict__
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         // ---- this slot's k-steps
-        const _Float16* afs = af + (size_t)(slot == 9 ? 9 * KSC : slot * KSC) * MT * 2 * 512;
+        const _Float16* afs = af + (size_t)(slot == 9 ? 9 * KSC : slot * KSC) * MTA * 2 * 512;
         for (int s = 0; s < nks; ++s) {
             const sslam::half8 xh = *reinterpret_cast<const sslam::half8*>(bl + 16 * s);
             const sslam::half8 xl = *reinterpret_cast<const sslam::half8*>(bl + 16 * s + PLH);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const sslam::half8 ah = *reinterpret_cast<const sslam::half8*>(afs + (size_t)((s * MT + m) * 2 + 0) * 512);
-                const sslam::half8 al = *reinterpret_cast<const sslam::half8*>(afs + (size_t)((s * MT + m) * 2 + 1) * 512);
+                const sslam::half8 ah = *reinterpret_cast<const sslam::half8*>(afs + (size_t)((s * MTA + mt0 + m) * 2 + 0) * 512);
+                const sslam::half8 al = *reinterpret_cast<const sslam::half8*>(afs + (size_t)((s * MTA + mt0 + m) * 2 + 1) * 512);
                 c1[m] = sslam::mfma16(ah, xh, c1[m]);
                 c2[m] = sslam::mfma16(ah, xl, c2[m]);
                 c2[m] = sslam::mfma16(al, xh, c2[m]);
@@ -856,7 +856,7 @@ __global__ __launch_bounds__(256) void al_dcn_h_kernel(const float* __restrict__
         const int pix = y * W + x0 + px;
 #pragma unroll
         for (int j = 0; j < MT * 4; ++j) {                   // wave w finishes accumulator registers w MT 4 .. + MT 4 - 1 (of MT x 16)
-            const int qi = wave * MT * 4 + j, m = qi / 16, r = qi % 16, co = 32 * m + acc_row(r, lane);
+            const int qi = wave * MT * 4 + j, m = qi / 16, r = qi % 16, co = 32 * (mt0 + m) + acc_row(r, lane);
             const int o = (m * 16 + r) * 64 + lane;
             float v = ((red[o] + red[o + MT * 1024]) + red[o + 2 * MT * 1024]) + red[o + 3 * MT * 1024];
             v += beta[co];
@@ -1977,24 +1977,31 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
         hipLaunchKernelGGL(al_block2_rows_kernel, dim3(sslam::cdiv(n_waves, 4)), dim3(256), B2_LDS, s, g->x1, g->x2, H2, W2, hs2, nb, strips, n_waves,
                            g->b2c1f, g->b2c2f, g->b2c1.a, g->b2c1.b, g->b2db, g->b2c2.a, g->b2c2.b, fs);
     }
+#ifndef AL_DCN4_CS
+#define AL_DCN4_CS 4      // workgroups per pixel tile of the 1/32 deformable layers (output channels split: 10 tiles per frame there)
+#endif
+#ifndef AL_DCN3_CS
+#define AL_DCN3_CS 1
+#endif
     // block3 at 1/8 (deformable): per layer the offset conv, then sampling + contraction + BN (+ 1 x 1 residual branch) + SELU fused
     const int H3 = Hp / 8, W3 = Wp / 8, HW3 = H3 * W3;
     const dim3 g3(sslam::cdiv(W3, 32), H3, uF);
     hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(32 * HW3, 256), uF), dim3(256), 0, s, g->x2, g->p3, 32, H2, W2, 4, fs, g->p3cl);
     const float mo3 = (float)(H3 > W3 ? H3 : W3) / 4.0f;
     hipLaunchKernelGGL((al_offset_conv_h_kernel<32>), g3, dim3(256), 0, s, g->p3cl, g->off, H3, W3, g->b3c1of, g->b3c1.ob, mo3, fs);
-    hipLaunchKernelGGL((al_dcn_h_kernel<32, 64, 0>), g3, dim3(256), 0, s, g->p3cl, g->off, nullptr, H3, W3, g->b3c1f, g->b3c1.b, nullptr, g->t3, g->t3cl, fs);
+    hipLaunchKernelGGL((al_dcn_h_kernel<32, 64, 0, AL_DCN3_CS>), dim3(AL_DCN3_CS * sslam::cdiv(W3, 32), H3, uF), dim3(256), 0, s, g->p3cl, g->off, nullptr, H3, W3, g->b3c1f, g->b3c1.b, nullptr, g->t3, g->t3cl, fs);
     hipLaunchKernelGGL((al_offset_conv_h_kernel<64>), g3, dim3(256), 0, s, g->t3cl, g->off, H3, W3, g->b3c2of, g->b3c2.ob, mo3, fs);
-    hipLaunchKernelGGL((al_dcn_h_kernel<64, 64, 32>), g3, dim3(256), 0, s, g->t3cl, g->off, g->p3cl, H3, W3, g->b3c2f, g->b3c2.b, g->b3db, g->x3, nullptr, fs);
+    hipLaunchKernelGGL((al_dcn_h_kernel<64, 64, 32, AL_DCN3_CS>), dim3(AL_DCN3_CS * sslam::cdiv(W3, 32), H3, uF), dim3(256), 0, s, g->t3cl, g->off, g->p3cl, H3, W3, g->b3c2f, g->b3c2.b, g->b3db, g->x3, nullptr, fs);
     // block4 at 1/32
     const int H4 = Hp / 32, W4 = Wp / 32, HW4 = H4 * W4;
     const dim3 g4(sslam::cdiv(W4, 32), H4, uF);
     hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(64 * HW4, 256), uF), dim3(256), 0, s, g->x3, g->p4, 64, H3, W3, 4, fs, g->p4cl);
     const float mo4 = (float)(H4 > W4 ? H4 : W4) / 4.0f;
     hipLaunchKernelGGL((al_offset_conv_h_kernel<64>), g4, dim3(256), 0, s, g->p4cl, g->off, H4, W4, g->b4c1of, g->b4c1.ob, mo4, fs);
-    hipLaunchKernelGGL((al_dcn_h_kernel<64, 128, 0>), g4, dim3(256), 0, s, g->p4cl, g->off, nullptr, H4, W4, g->b4c1f, g->b4c1.b, nullptr, g->t4, g->t4cl, fs);
+    const dim3 g4s(AL_DCN4_CS * sslam::cdiv(W4, 32), H4, uF);  // AL_DCN4_CS workgroups per tile, 128 / AL_DCN4_CS output channels each
+    hipLaunchKernelGGL((al_dcn_h_kernel<64, 128, 0, AL_DCN4_CS>), g4s, dim3(256), 0, s, g->p4cl, g->off, nullptr, H4, W4, g->b4c1f, g->b4c1.b, nullptr, g->t4, g->t4cl, fs);
     hipLaunchKernelGGL((al_offset_conv_h_kernel<128>), g4, dim3(256), 0, s, g->t4cl, g->off, H4, W4, g->b4c2of, g->b4c2.ob, mo4, fs);
-    hipLaunchKernelGGL((al_dcn_h_kernel<128, 128, 64>), g4, dim3(256), 0, s, g->t4cl, g->off, g->p4cl, H4, W4, g->b4c2f, g->b4c2.b, g->b4db, g->x4, nullptr, fs);
+    hipLaunchKernelGGL((al_dcn_h_kernel<128, 128, 64, AL_DCN4_CS>), g4s, dim3(256), 0, s, g->t4cl, g->off, g->p4cl, H4, W4, g->b4c2f, g->b4c2.b, g->b4db, g->x4, nullptr, fs);
     // gates
     hipLaunchKernelGGL(al_gate_kernel<32>, dim3(sslam::cdiv(H2 * W2, 256), uF), dim3(256), 0, s, g->x2, g->g2, H2 * W2, g->gw2, g->g2cl, fs);
     hipLaunchKernelGGL(al_gate_small_kernel, dim3(sslam::cdiv(32 * HW3, 256), uF), dim3(256), 0, s, g->x3, g->g3, 64, HW3, g->gw3, g->g3cl, fs);
