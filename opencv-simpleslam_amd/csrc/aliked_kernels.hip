@@ -1959,20 +1959,21 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
                        g->gk, rp.kx, rp.blur, fs);
     hipLaunchKernelGGL(al_resize_pad_kernel, dim3(sslam::cdiv(Wp, 256), Hp, uF), dim3(256), 0, s, g->fsrc, g->img, d,
                        g->gk + 32, rp.ky, rp.blur, fs);
-    // block1 (conv1 + conv2 fused): ~3 waves per SIMD when the batch allows; at least eight rows per wave (two extra conv1 rows per block)
+    // block1 (conv1 + conv2 fused): ~3 waves per SIMD when the batch allows; at least four rows per wave (two extra conv1 rows per block:
+    // short blocks only when one or two frames have to fill the chip)
     {
         const int strips = sslam::cdiv(Wp, B1_SW);
-        const int nblk = std::max(1, std::min(sslam::cdiv(Hp, 8), 3072 / std::max(1, strips * F)));
+        const int nblk = std::max(1, std::min(sslam::cdiv(Hp, 4), 3072 / std::max(1, strips * F)));
         const int hs1 = sslam::cdiv(Hp, nblk);
         hipLaunchKernelGGL(al_block1_rows_kernel, dim3(strips, sslam::cdiv(Hp, hs1), uF), dim3(64), 0, s, g->img, g->x1, Hp, Wp, hs1,
                            g->b1c1.w, g->b1c1.a, g->b1c1.b, g->b1c2f, g->b1c2.a, g->b1c2.b, fs);
     }
     // block2 at 1/2 (pooling + conv1 + 1 x 1 branch + conv2 + residual fused): one wave per SIMD when the batch allows; at least
-    // six rows per wave (two extra t2 rows per block).  (A frame's values do not depend on these splits: no sum is re-associated.)
+    // three rows per wave (two extra t2 rows per block).  (A frame's values do not depend on these splits: no sum is re-associated.)
     const int H2 = Hp / 2, W2 = Wp / 2;
     {
         const int strips = sslam::cdiv(W2, B2_SW);
-        const int nblk = std::max(1, std::min(sslam::cdiv(H2, 6), 1024 / std::max(1, strips * F)));
+        const int nblk = std::max(1, std::min(sslam::cdiv(H2, 3), 1024 / std::max(1, strips * F)));
         const int hs2 = sslam::cdiv(H2, nblk), nb = sslam::cdiv(H2, hs2), n_waves = strips * nb * F;
         hipLaunchKernelGGL(al_block2_rows_kernel, dim3(sslam::cdiv(n_waves, 4)), dim3(256), B2_LDS, s, g->x1, g->x2, H2, W2, hs2, nb, strips, n_waves,
                            g->b2c1f, g->b2c2f, g->b2c1.a, g->b2c1.b, g->b2db, g->b2c2.a, g->b2c2.b, fs);
