@@ -611,17 +611,29 @@ __global__ __launch_bounds__(1024) void lg_decide_kernel(
     const int per = (Kc + 511) / 512;
     // thread owns the contiguous chunk [th*per, th*per+per) of its image
     int cnt = 0;
-    if (act)
-        for (int j = 0; j < per; ++j) {
-            const int i = th * per + j;
-            if (i < n) {
-                const float sc = sigmoidf_(mat[img * Kc + i]);
-                int k = sc > (1.0f - width_conf);
-                if (do_stop) k |= conf[img * Kc + i] <= conf_thr;
-                s_ind[img][i] = (unsigned short)(ind[img * Kc + i] | (k << 15));
-                cnt += k;
+    if (act) {
+        // (r04: the chunk's loads first, four elements at a time - rolled, every element waited for its own three loads: this
+        //  one-workgroup kernel is nothing but a chain of memory latencies)
+        for (int j0 = 0; j0 < per; j0 += 4) {
+            float mv[4], cv[4]; int iv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(th * per + j0 + u, Kc - 1);
+                mv[u] = mat[img * Kc + i]; cv[u] = do_stop ? conf[img * Kc + i] : 0.0f; iv[u] = ind[img * Kc + i];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = th * per + j0 + u;
+                if (j0 + u < per && i < n) {
+                    const float sc = sigmoidf_(mv[u]);
+                    int k = sc > (1.0f - width_conf);
+                    if (do_stop) k |= cv[u] <= conf_thr;
+                    s_ind[img][i] = (unsigned short)(iv[u] | (k << 15));
+                    cnt += k;
+                }
             }
         }
+    }
     int incl = cnt;
     for (int o = 1; o < 64; o <<= 1) {
         const int v = __shfl_up(incl, o);
