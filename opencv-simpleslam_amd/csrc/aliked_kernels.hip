@@ -2050,8 +2050,14 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
                        d.w, g->pos, sampled_h, plane, g->ctrl, fs);
     hipLaunchKernelGGL((al_gemm_h_kernel<64, 128, 1, 2, true>), dim3(1, sslam::cdiv(NK * 16, 64), uF), dim3(256), 0, s, sampled_h, plane,
                        128, g->d_sf_s, (size_t)128 * 128, 128, nullptr, feats_h, plane, 16, NK * 16, g->ctrl, 1, fs);
-    hipLaunchKernelGGL((al_gemm_h_kernel<64, 64, 1, 1, false>), dim3(2, sslam::cdiv(NK, 64), SDDH_KSPLIT * uF), dim3(256), 0, s, feats_h,
-                       plane, 2048, g->d_agg_s, (size_t)128 * 2048, 128, g->raw, nullptr, 0, 1, NK, g->ctrl, SDDH_KSPLIT, fs);
+    // (batches: 64 x 128 tiles - the 16.8 MB of sampled-feature planes are read once; with two column blocks the PMC counters showed
+    //  35.7 MB fetched per frame.  One or two frames: 64 x 64 tiles, twice the workgroups.  Same k-split, same order: bit-identical)
+    if (F >= 4)
+        hipLaunchKernelGGL((al_gemm_h_kernel<64, 128, 1, 2, false>), dim3(1, sslam::cdiv(NK, 64), SDDH_KSPLIT * uF), dim3(256), 0, s, feats_h,
+                           plane, 2048, g->d_agg_s, (size_t)128 * 2048, 128, g->raw, nullptr, 0, 1, NK, g->ctrl, SDDH_KSPLIT, fs);
+    else
+        hipLaunchKernelGGL((al_gemm_h_kernel<64, 64, 1, 1, false>), dim3(2, sslam::cdiv(NK, 64), SDDH_KSPLIT * uF), dim3(256), 0, s, feats_h,
+                           plane, 2048, g->d_agg_s, (size_t)128 * 2048, 128, g->raw, nullptr, 0, 1, NK, g->ctrl, SDDH_KSPLIT, fs);
     const float scale_x = (float)d.w / (float)W, scale_y = (float)d.h / (float)H;
     hipLaunchKernelGGL(al_finalize_kernel, dim3(sslam::cdiv(NK, 4), uF), dim3(256), 0, s, g->raw, NK, g->kp_norm, g->kp_score,
                        d.h, d.w, scale_x, scale_y, outs, g->ctrl, fs);
