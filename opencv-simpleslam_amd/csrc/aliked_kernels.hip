@@ -1329,6 +1329,114 @@ __global__ __launch_bounds__(256) void al_nms_kernel(const float* __restrict__ s
     if (threadIdx.x == 0) block_sum[blockIdx.y * gridDim.x + blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
 }
 
+// r04: the same NMS with a WAVE owning a tile and no LDS: lane = column (64 of them, 44 + the 10-pixel halo either side), the
+// R rows of the column in registers.  A 5-wide row maximum is four DPP wave shifts fused into v_max (lanes shifted in from
+// outside the wave see themselves = an absent neighbour, as the LDS tile's rim was), a 5-tall column maximum three register
+// v_max per row (pairs, pairs of pairs, + one), and the 0/1 maps (max_mask, supp) are ONE 64-bit word per lane - bit y = row y
+// of the lane's column - so their 5 x 5 dilation is ten shifts and eight DPP ORs for the whole tile instead of a pooled
+// float map (r03 form above: 3.7 x halo redundancy, ~60 LDS operations per element, 9.6 us per frame; max is exact and
+// associative, so the order of the pooling steps changes nothing: nms is bit-identical.  block_sum's partition changes, i.e.
+// the rounding of the mean score the no-candidate fallback thresholds on).
+#ifndef AL_NMS_ROWS
+#define AL_NMS_ROWS 48
+#endif
+constexpr int NW_R = AL_NMS_ROWS, NW_OW = 64 - 2 * NHALO, NW_OH = NW_R - 2 * NHALO;
+static_assert(NW_R <= 64 && NW_OH > 0, "a column's rows are the bits of one 64-bit word");
+
+// lane i <- lane i - 1 / lane i + 1; the wave's first / last lane reads 0 (bound_ctrl): the identity of the mask ORs, and for the
+// float maxima one more wrong value in a rim lane, which the halo keeps out of the central columns like the rest of the rim
+__device__ __forceinline__ unsigned nw_up(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ unsigned nw_dn(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
+__device__ __forceinline__ float nw_up(float v) { return __builtin_bit_cast(float, nw_up(__builtin_bit_cast(unsigned, v))); }
+__device__ __forceinline__ float nw_dn(float v) { return __builtin_bit_cast(float, nw_dn(__builtin_bit_cast(unsigned, v))); }
+__device__ __forceinline__ float nw_row5(float v) {
+    const float l1 = fmaxf(v, nw_up(v)), l2 = fmaxf(l1, nw_up(l1));       // columns x-2 .. x
+    const float r1 = fmaxf(v, nw_dn(v)), r2 = fmaxf(r1, nw_dn(r1));       // columns x .. x+2
+    return fmaxf(l2, r2);
+}
+// 5 x 5 maximum of the tile held as in[row] per lane
+__device__ __forceinline__ void nw_pool5(const float (&in)[NW_R], float (&v)[NW_R]) {
+    float hrow[NW_R], p[NW_R], q[NW_R];
+#pragma unroll
+    for (int y = 0; y < NW_R; ++y) hrow[y] = nw_row5(in[y]);
+#pragma unroll
+    for (int y = 0; y + 1 < NW_R; ++y) p[y] = fmaxf(hrow[y], hrow[y + 1]);          // rows y, y+1
+#pragma unroll
+    for (int y = 0; y + 3 < NW_R; ++y) q[y] = fmaxf(p[y], p[y + 2]);                // rows y .. y+3
+#pragma unroll
+    for (int y = 0; y < NW_R; ++y) {
+        if (y == 0) v[y] = fmaxf(p[0], hrow[2]);
+        else if (y == 1) v[y] = q[0];
+        else if (y + 2 < NW_R) v[y] = fmaxf(q[y - 2], hrow[y + 2]);                 // rows y-2 .. y+2
+        else if (y + 2 == NW_R) v[y] = q[NW_R - 4];
+        else v[y] = fmaxf(hrow[NW_R - 3], p[NW_R - 2]);
+    }
+}
+__device__ __forceinline__ unsigned long long nw_dilate5(unsigned long long c) {
+    const unsigned long long vv = c | (c << 1) | (c << 2) | (c >> 1) | (c >> 2);
+    unsigned lo = (unsigned)vv, hi = (unsigned)(vv >> 32);
+    const unsigned l1 = lo | nw_up(lo), l2 = l1 | nw_up(l1), r1 = lo | nw_dn(lo), r2 = r1 | nw_dn(r1);
+    const unsigned h1 = hi | nw_up(hi), h2 = h1 | nw_up(h1), g1 = hi | nw_dn(hi), g2 = g1 | nw_dn(g1);
+    return ((unsigned long long)(h2 | g2) << 32) | (l2 | r2);
+}
+
+__global__ __launch_bounds__(64) void al_nms_wave_kernel(const float* __restrict__ score, int h, int w,
+                                                         float* __restrict__ nms, float* __restrict__ block_sum, size_t fs) {
+    score = fsh(score, blockIdx.z, fs); nms = fsh(nms, blockIdx.z, fs); block_sum = fsh(block_sum, blockIdx.z, fs);
+    const int lane = threadIdx.x;
+    const int xx = (int)blockIdx.x * NW_OW - NHALO + lane, y0 = (int)blockIdx.y * NW_OH - NHALO;
+    const bool xin = xx >= 0 && xx < w;
+    const unsigned xc = (unsigned)min(max(xx, 0), w - 1);
+    float s[NW_R];
+#pragma unroll
+    for (int y = 0; y < NW_R; ++y) {            // unconditional loads at a clamped address: all R in flight
+        const int yy = y0 + y;
+        const float v = score[(unsigned)min(max(yy, 0), h - 1) * (unsigned)w + xc];
+        // a row outside the map: + (-inf) from a scalar register (one lane mask per row would spill the scalar file)
+        s[y] = (xin ? v : -INFINITY) + ((yy >= 0 && yy < h) ? 0.0f : -INFINITY);
+    }
+    auto equal_bits = [](const float (&a)[NW_R], const float (&b)[NW_R]) {          // bit y: a[y] == b[y] and a[y] is a score
+        unsigned lo = 0u, hi = 0u;
+#pragma unroll
+        for (int y = 0; y < NW_R; ++y) {
+            const bool e = a[y] == b[y] && a[y] > -INFINITY;
+            if (y < 32) lo |= e ? (1u << y) : 0u; else hi |= e ? (1u << (y - 32)) : 0u;
+        }
+        return ((unsigned long long)hi << 32) | lo;
+    };
+    float t[NW_R];
+    nw_pool5(s, t);
+    unsigned long long mask = equal_bits(s, t);                    // max_mask = scores == max_pool(scores)
+#pragma unroll 1
+    for (int round = 0; round < 2; ++round) {
+        const unsigned long long supp = nw_dilate5(mask);         // supp = max_pool(max_mask) > 0
+        float q[NW_R];
+#pragma unroll
+        for (int y = 0; y < NW_R; ++y) {
+            const bool sp = (y < 32 ? ((unsigned)supp >> y) : ((unsigned)(supp >> 32) >> (y - 32))) & 1u;
+            q[y] = (s[y] == -INFINITY) ? -INFINITY : (sp ? 0.0f : s[y]);
+        }
+        nw_pool5(q, t);
+        mask |= equal_bits(q, t) & ~supp;                          // max_mask |= new_max & ~supp
+    }
+    float lsum = 0.0f;
+    const bool xout = lane >= NHALO && lane < NHALO + NW_OW && xx < w;
+    if (xout)
+#pragma unroll
+    for (int y = NHALO; y < NHALO + NW_OH; ++y) {
+        const int yy = y0 + y;
+        if (yy < h) {
+            const bool mk = (y < 32 ? ((unsigned)mask >> y) : ((unsigned)(mask >> 32) >> (y - 32))) & 1u;
+            float v = mk ? s[y] : 0.0f;
+            if (yy < 2 || xx < 2 || yy >= h - 2 || xx >= w - 2) v = 0.0f;          // border of `radius`
+            nms[(unsigned)yy * (unsigned)w + (unsigned)xx] = v;
+            lsum += s[y];
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+    if (lane == 0) block_sum[blockIdx.y * gridDim.x + blockIdx.x] = lsum;
+}
+
 // collect pixels with nms > thr into an (unordered) candidate list of 64-bit keys:
 // key = score_bits << 32 | (0xffffffff - index)  -> larger key = better (score desc, index asc)
 constexpr int COLLECT_PPT = 16;     // pixels per thread: 4096 per block -> ~80 blocks, one same-address atomic each
@@ -2071,8 +2179,12 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
     hipLaunchKernelGGL(al_score_tail_kernel, dim3(sslam::cdiv(Wp, ST_W), sslam::cdiv(Hp, ST_H), uF), dim3(256), 0, s, g->s8,
                        Hp, Wp, g->sh2, g->sh4, g->sh6, g->score, d.h, d.w, d.pl, d.pt, fs);
     // DKD
-    const int nbx = sslam::cdiv(d.w, NT_W), nby = sslam::cdiv(d.h, NT_H), npx = d.h * d.w;
-    hipLaunchKernelGGL(al_nms_kernel, dim3(nbx, nby, uF), dim3(256), 0, s, g->score, d.h, d.w, g->nms, g->bsum, fs);
+#ifndef AL_NMS_WAVE
+#define AL_NMS_WAVE 1
+#endif
+    const int nbx = sslam::cdiv(d.w, AL_NMS_WAVE ? NW_OW : NT_W), nby = sslam::cdiv(d.h, AL_NMS_WAVE ? NW_OH : NT_H), npx = d.h * d.w;
+    if (AL_NMS_WAVE) hipLaunchKernelGGL(al_nms_wave_kernel, dim3(nbx, nby, uF), dim3(64), 0, s, g->score, d.h, d.w, g->nms, g->bsum, fs);
+    else hipLaunchKernelGGL(al_nms_kernel, dim3(nbx, nby, uF), dim3(256), 0, s, g->score, d.h, d.w, g->nms, g->bsum, fs);
     hipLaunchKernelGGL(al_collect_kernel, dim3(sslam::cdiv(npx, 256 * COLLECT_PPT), uF), dim3(256), 0, s, g->nms, npx, 0.2f, 0, g->bsum,
                        nbx * nby, g->cand, g->cand_cap, g->ctrl, g->hist, fs);
     hipLaunchKernelGGL(al_fallback_flag_kernel, dim3(uF), dim3(1), 0, s, g->ctrl, fs);
