@@ -60,7 +60,7 @@ struct ALCtrl {
     int n_cand;       // candidates above threshold
     int n_kp;         // keypoints emitted
     int overflow;     // candidate buffer overflow flag
-    int need_fallback;  // no pixel above detection_threshold -> threshold = mean(score map)
+    int found;        // the detection threshold found candidates (else the second collect launch thresholds on mean(score map))
     int pad[12];
 };
 
@@ -1380,11 +1380,23 @@ __device__ __forceinline__ unsigned long long nw_dilate5(unsigned long long c) {
     return ((unsigned long long)(h2 | g2) << 32) | (l2 | r2);
 }
 
-__global__ __launch_bounds__(64) void al_nms_wave_kernel(const float* __restrict__ score, int h, int w,
-                                                         float* __restrict__ nms, float* __restrict__ block_sum, size_t fs) {
-    score = fsh(score, blockIdx.z, fs); nms = fsh(nms, blockIdx.z, fs); block_sum = fsh(block_sum, blockIdx.z, fs);
-    const int lane = threadIdx.x;
-    const int xx = (int)blockIdx.x * NW_OW - NHALO + lane, y0 = (int)blockIdx.y * NW_OH - NHALO;
+// The tile's pixels above the detection threshold go straight into the candidate list (what the first al_collect_kernel
+// launch did from the nms map: one more pass over it, 10 us of a single-frame extraction): the list is unordered either way.
+// (Four tiles = four independent waves per workgroup, so that the list's counter sees one returning atomic per four tiles:
+//  ~300 of them on one address per frame were 10 us.)
+__global__ __launch_bounds__(256) void al_nms_wave_kernel(const float* __restrict__ score, int h, int w, int nbx, int n_tiles,
+                                                          float* __restrict__ nms, float* __restrict__ block_sum, float thr,
+                                                         unsigned long long* __restrict__ cand, int cap,
+                                                         ALCtrl* __restrict__ ctrl, unsigned* __restrict__ hist, size_t fs) {
+    score = fsh(score, blockIdx.y, fs); nms = fsh(nms, blockIdx.y, fs); block_sum = fsh(block_sum, blockIdx.y, fs);
+    cand = fsh(cand, blockIdx.y, fs); ctrl = fsh(ctrl, blockIdx.y, fs); hist = fsh(hist, blockIdx.y, fs);
+    __shared__ int wtot[4];
+    __shared__ int s_base;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile_raw = (int)blockIdx.x * 4 + wv;
+    const bool act = tile_raw < n_tiles;                           // (a spare wave of the last workgroup redoes tile 0 and keeps nothing)
+    const int tile = act ? tile_raw : 0, tbx = tile % nbx, tby = tile / nbx;
+    const int xx = tbx * NW_OW - NHALO + lane, y0 = tby * NW_OH - NHALO;
     const bool xin = xx >= 0 && xx < w;
     const unsigned xc = (unsigned)min(max(xx, 0), w - 1);
     float s[NW_R];
@@ -1420,21 +1432,59 @@ __global__ __launch_bounds__(64) void al_nms_wave_kernel(const float* __restrict
         mask |= equal_bits(q, t) & ~supp;                          // max_mask |= new_max & ~supp
     }
     float lsum = 0.0f;
-    const bool xout = lane >= NHALO && lane < NHALO + NW_OW && xx < w;
+    const bool xout = act && lane >= NHALO && lane < NHALO + NW_OW && xx < w;
+    const bool xkeep = xout & (xx >= 2) & (xx < w - 2);
+    auto kept = [&](int y, int yy) {                               // the nms map's value at row y of this lane's column
+        const bool mk = (y < 32 ? ((unsigned)mask >> y) : ((unsigned)(mask >> 32) >> (y - 32))) & 1u;
+        const bool rowkeep = (yy >= 2) & (yy < h - 2);             // border of `radius` (bitwise: no short-circuit branches)
+        return (mk & xkeep & rowkeep) ? s[y] : 0.0f;
+    };
+    // order: count, claim the list range (one returning atomic per workgroup), THEN write the nms rows - the atomic's round
+    // trip and the stores' are in flight together - and only then use the range
+    int cnt = 0;
+#pragma unroll
+    for (int y = NHALO; y < NHALO + NW_OH; ++y) cnt += kept(y, y0 + y) > thr;
+    int incl = cnt;
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+    if (lane == 63) wtot[wv] = incl;
+    __syncthreads();
+    int woff = 0, total = 0;
+    for (int i = 0; i < 4; ++i) { if (i < wv) woff += wtot[i]; total += wtot[i]; }
+    int base = 0;
+    if (threadIdx.x == 0 && total) base = atomicAdd(&ctrl->n_cand, total);
     if (xout)
 #pragma unroll
     for (int y = NHALO; y < NHALO + NW_OH; ++y) {
         const int yy = y0 + y;
         if (yy < h) {
-            const bool mk = (y < 32 ? ((unsigned)mask >> y) : ((unsigned)(mask >> 32) >> (y - 32))) & 1u;
-            float v = mk ? s[y] : 0.0f;
-            if (yy < 2 || xx < 2 || yy >= h - 2 || xx >= w - 2) v = 0.0f;          // border of `radius`
-            nms[(unsigned)yy * (unsigned)w + (unsigned)xx] = v;
+            nms[(unsigned)yy * (unsigned)w + (unsigned)xx] = kept(y, yy);
             lsum += s[y];
         }
     }
     for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
-    if (lane == 0) block_sum[blockIdx.y * gridDim.x + blockIdx.x] = lsum;
+    if (lane == 0 && act) block_sum[tile] = lsum;
+    if (total == 0) return;                                        // (the same answer in every wave)
+    if (threadIdx.x == 0) { s_base = base; ctrl->found = 1; }
+    __syncthreads();
+    int pos = s_base + woff + incl - cnt;
+    // (a wave alone on its SIMD issues an instruction every ~5 cycles: this pass is kept to a dozen per row - the capacity
+    //  test is made once for the workgroup)
+    const bool fits = s_base + total <= cap;
+    if (!fits && threadIdx.x == 0) ctrl->overflow = 1;
+#pragma unroll
+    for (int y = NHALO; y < NHALO + NW_OH; ++y) {
+        const int yy = y0 + y;
+        const float v = kept(y, yy);                               // (0 outside the tile's own pixels: rows >= h - 2, columns with !xout)
+        const bool c = v > thr;
+        if (c & (fits | (pos < cap))) {
+            const unsigned i = (unsigned)yy * (unsigned)w + (unsigned)xx;
+            cand[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (0xffffffffu - i);
+        }
+        if (c) {
+            atomicAdd(&hist[min((int)(v * (float)HBINS), HBINS - 1)], 1u);     // scores are in (0, 1]
+            ++pos;
+        }
+    }
 }
 
 // collect pixels with nms > thr into an (unordered) candidate list of 64-bit keys:
@@ -1451,7 +1501,8 @@ __global__ __launch_bounds__(256) void al_collect_kernel(const float* __restrict
     nms = fsh(nms, blockIdx.y, fs); block_sum = fsh(block_sum, blockIdx.y, fs); cand = fsh(cand, blockIdx.y, fs);
     ctrl = fsh(ctrl, blockIdx.y, fs); hist = fsh(hist, blockIdx.y, fs);
     if (fallback) {
-        if (!ctrl->need_fallback) return;           // the normal threshold found keypoints
+        if (ctrl->found) return;                    // the normal threshold found keypoints (written by the FIRST launch only:
+                                                    // every thread of this one sees one answer)
         float s = 0.0f;                             // mean of the raw score map, fixed summation order
         for (int i = 0; i < n_blocks; ++i) s += block_sum[i];
         thr = s / (float)n_px;
@@ -1473,7 +1524,10 @@ __global__ __launch_bounds__(256) void al_collect_kernel(const float* __restrict
     __syncthreads();
     int woff = 0, total = 0;
     for (int w = 0; w < 4; ++w) { if (w < wave) woff += wcnt[w]; total += wcnt[w]; }
-    if (t == 0) s_base = total ? atomicAdd(&ctrl->n_cand, total) : 0;
+    if (t == 0) {
+        s_base = total ? atomicAdd(&ctrl->n_cand, total) : 0;
+        if (total && !fallback) ctrl->found = 1;
+    }
     __syncthreads();
     int pos = s_base + woff + incl - cnt;
 #pragma unroll
@@ -1487,21 +1541,8 @@ __global__ __launch_bounds__(256) void al_collect_kernel(const float* __restrict
         }
     }
 }
-// decided between the two collect launches so every thread of the fallback launch sees one answer
-__global__ void al_fallback_flag_kernel(ALCtrl* __restrict__ ctrl, size_t fs) {
-    ctrl = fsh(ctrl, blockIdx.x, fs);
-    ctrl->need_fallback = ctrl->n_cand == 0;
-}
-// per-frame control block and score histogram back to zero (one block per frame)
-__global__ void al_reset_kernel(ALCtrl* __restrict__ ctrl, unsigned* __restrict__ hist, size_t fs) {
-    ctrl = fsh(ctrl, blockIdx.x, fs); hist = fsh(hist, blockIdx.x, fs);
-    if (threadIdx.x < sizeof(ALCtrl) / 4) reinterpret_cast<int*>(ctrl)[threadIdx.x] = 0;
-    for (int i = threadIdx.x; i < HBINS; i += blockDim.x) hist[i] = 0u;
-}
-
 // kornia get_gaussian_kernel1d in fp32: gk[0..kx) horizontal taps, gk[32..32+ky) vertical taps
-__global__ void al_taps_kernel(float* __restrict__ gk, int kx, float sx, int ky, float sy) {
-    if (threadIdx.x != 0) return;
+__device__ void al_taps(float* __restrict__ gk, int kx, float sx, int ky, float sy) {
     for (int pass = 0; pass < 2; ++pass) {
         const int ks = pass ? ky : kx;
         const float sigma = pass ? sy : sx;
@@ -1515,6 +1556,16 @@ __global__ void al_taps_kernel(float* __restrict__ gk, int kx, float sx, int ky,
         }
         for (int i = 0; i < ks; ++i) o[i] /= sum;
     }
+}
+// first launch of a sequence: per-frame control block and score histogram back to zero (one block per frame); the first block
+// also writes the blur taps (r04: three launches - reset, taps, the fallback flag between the collects - were 14 us of a
+// single-frame extraction's 405)
+__global__ void al_reset_kernel(ALCtrl* __restrict__ ctrl, unsigned* __restrict__ hist, size_t fs, float* __restrict__ gk,
+                                int kx, float sx, int ky, float sy) {
+    if (blockIdx.x == 0 && threadIdx.x == 64) al_taps(gk, kx, sx, ky, sy);
+    ctrl = fsh(ctrl, blockIdx.x, fs); hist = fsh(hist, blockIdx.x, fs);
+    if (threadIdx.x < sizeof(ALCtrl) / 4) reinterpret_cast<int*>(ctrl)[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < HBINS; i += blockDim.x) hist[i] = 0u;
 }
 
 // ------------------------------------------------------------------------ //
@@ -2108,9 +2159,8 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
     const int Hp = d.Hp, Wp = d.Wp;
     const unsigned uF = (unsigned)F;
     const size_t fs = g->fs;
-    hipLaunchKernelGGL(al_reset_kernel, dim3(uF), dim3(256), 0, s, g->ctrl, g->hist, fs);
     SSLAM_REQUIRE(rp.kx <= 31 && rp.ky <= 31, "sslam_aliked: blur kernel too large (%d,%d)", rp.kx, rp.ky);
-    hipLaunchKernelGGL(al_taps_kernel, dim3(1), dim3(64), 0, s, g->gk, rp.kx, rp.sx, rp.ky, rp.sy);
+    hipLaunchKernelGGL(al_reset_kernel, dim3(uF), dim3(256), 0, s, g->ctrl, g->hist, fs, g->gk, rp.kx, rp.sx, rp.ky, rp.sy);
 
     hipLaunchKernelGGL(al_to_float_kernel, dim3(sslam::cdiv(W, 256), H, uF), dim3(256), 0, s, srcs, g->fsrc, d,
                        g->gk, rp.kx, rp.blur, fs);
@@ -2183,11 +2233,14 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
 #define AL_NMS_WAVE 1
 #endif
     const int nbx = sslam::cdiv(d.w, AL_NMS_WAVE ? NW_OW : NT_W), nby = sslam::cdiv(d.h, AL_NMS_WAVE ? NW_OH : NT_H), npx = d.h * d.w;
-    if (AL_NMS_WAVE) hipLaunchKernelGGL(al_nms_wave_kernel, dim3(nbx, nby, uF), dim3(64), 0, s, g->score, d.h, d.w, g->nms, g->bsum, fs);
-    else hipLaunchKernelGGL(al_nms_kernel, dim3(nbx, nby, uF), dim3(256), 0, s, g->score, d.h, d.w, g->nms, g->bsum, fs);
-    hipLaunchKernelGGL(al_collect_kernel, dim3(sslam::cdiv(npx, 256 * COLLECT_PPT), uF), dim3(256), 0, s, g->nms, npx, 0.2f, 0, g->bsum,
-                       nbx * nby, g->cand, g->cand_cap, g->ctrl, g->hist, fs);
-    hipLaunchKernelGGL(al_fallback_flag_kernel, dim3(uF), dim3(1), 0, s, g->ctrl, fs);
+    if (AL_NMS_WAVE) {
+        hipLaunchKernelGGL(al_nms_wave_kernel, dim3(sslam::cdiv(nbx * nby, 4), uF), dim3(256), 0, s, g->score, d.h, d.w, nbx, nbx * nby,
+                           g->nms, g->bsum, 0.2f, g->cand, g->cand_cap, g->ctrl, g->hist, fs);
+    } else {
+        hipLaunchKernelGGL(al_nms_kernel, dim3(nbx, nby, uF), dim3(256), 0, s, g->score, d.h, d.w, g->nms, g->bsum, fs);
+        hipLaunchKernelGGL(al_collect_kernel, dim3(sslam::cdiv(npx, 256 * COLLECT_PPT), uF), dim3(256), 0, s, g->nms, npx, 0.2f, 0, g->bsum,
+                           nbx * nby, g->cand, g->cand_cap, g->ctrl, g->hist, fs);
+    }
     hipLaunchKernelGGL(al_collect_kernel, dim3(sslam::cdiv(npx, 256 * COLLECT_PPT), uF), dim3(256), 0, s, g->nms, npx, 0.0f, 1, g->bsum,
                        nbx * nby, g->cand, g->cand_cap, g->ctrl, g->hist, fs);
     hipLaunchKernelGGL(al_select_kernel, dim3(uF), dim3(1024), (SEL_CAP + EDGE_CAP) * 8, s, g->cand, g->cand_cap, n_limit,
