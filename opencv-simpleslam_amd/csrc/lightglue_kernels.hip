@@ -747,6 +747,68 @@ __global__ __launch_bounds__(256) void lg_sim_kernel(SimArgs p) {
         }
 }
 
+// r04: the same product on the split-precision pipe (precision 1).  The fp32 matrix instruction ran this GEMM at 63 % of ITS
+// peak (17.2 GFLOP per 8 pairs in 175 us = 98 TFLOP/s of 157) - a twentieth of the forward's FLOPs for 2.8 % of its time.  The
+// matching descriptors are split once (lg_split_md_kernel: row-major (hi, lo) planes in the q planes, free by now), three
+// f16 MFMAs per product into two fp32 accumulators as everywhere else (gemm_f16x3.hpp).
+struct SimArgsH { const _Float16* md_hi; const _Float16* md_lo; float* sim; int Kc; const LGCtrl* ctrl; };
+
+__global__ __launch_bounds__(256) void lg_split_md_kernel(const float* __restrict__ md, _Float16* __restrict__ hi,
+                                                          _Float16* __restrict__ lo, int Kc, const LGCtrl* __restrict__ ctrl) {
+    const int img = blockIdx.y;
+    const LGCtrl& pc = ctrl_of(ctrl, img);
+    if (pc.stop == 2) return;
+    const size_t total = (size_t)pc.n[img & 1] * (D / 8), base = (size_t)img * Kc * D;
+    float amax = 0.0f;
+    for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += (size_t)gridDim.x * blockDim.x) {
+        const float4 a = *reinterpret_cast<const float4*>(md + base + u * 8);
+        const float4 b = *reinterpret_cast<const float4*>(md + base + u * 8 + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint4 hh, ll;
+        sslam::split8_fast(v, hh, ll, amax);
+        *reinterpret_cast<uint4*>(hi + base + u * 8) = hh;
+        *reinterpret_cast<uint4*>(lo + base + u * 8) = ll;
+    }
+    sslam::split_range_check(amax, range_flag_of(ctrl, img));
+}
+
+template <int BM, int BN, int TM, int TN>
+__global__ __launch_bounds__(256) void lg_sim_h_kernel(SimArgsH p) {
+    __shared__ sslam::GemmSmemH<BM, BN> sm;
+    int pair = blockIdx.z, bx = blockIdx.x, by = blockIdx.y;         // XCD-aware order: see lg_sim_kernel
+    if ((gridDim.z & 7) == 0) {
+        const unsigned T = gridDim.x * gridDim.y;
+        const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned grp = L / (8 * T), rem = L % (8 * T);
+        pair = (int)(grp * 8 + (rem & 7));
+        const unsigned tix = rem >> 3;
+        bx = (int)(tix % gridDim.x); by = (int)(tix / gridDim.x);
+    }
+    const LGCtrl& pc = p.ctrl[pair];
+    if (pc.stop == 2) return;
+    const int n0 = pc.n[0], n1 = pc.n[1];
+    const int row0 = by * BM, col0 = bx * BN;
+    if (row0 >= n0 || col0 >= n1) return;
+    const size_t o0 = (size_t)pair * 2 * p.Kc * D, o1 = o0 + (size_t)p.Kc * D;
+    float* simp = p.sim + (size_t)pair * p.Kc * p.Kc;
+    const sslam::SplitPtr a{p.md_hi + o0, p.md_lo + o0};
+    sslam::GemmAH ga{a, a, D, D};
+    f32x16 c1[TM][TN], c2[TM][TN];
+    sslam::gemm_mainloop_h<BM, BN, TM, TN>(ga, sslam::SplitPtr{p.md_hi + o1, p.md_lo + o1}, D, D, row0, p.Kc, col0, p.Kc, sm, c1, c2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = col0 + wn * 32 * TN + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wm * 32 * TM + i * 32 + acc_row(r, lane);
+                if (row < n0 && col < n1) simp[(size_t)row * p.Kc + col] = c1[i][j][r] + c2[i][j][r] * sslam::SPLIT_INV;
+            }
+        }
+}
+
 constexpr int STAT_CACHE = 32;    // values of `sim` a thread keeps between the max and the sum pass (rows / column slabs up to 2048)
 
 // row statistics: one wave per row i: max_j, log(sum_j exp(sim - max))
@@ -1801,6 +1863,7 @@ struct sslam_lightglue {
     int32_t *out_ij, *out_info;
     // split-precision planes (precision == 1)
     int precision = 1;               // 0: fp32 MFMA everywhere; 1: fp16 hi/lo split, 3 MFMA per product
+    bool sim_exact = false;          // SSLAM_LG_SIM_EXACT=1 (experiments): the similarity GEMM stays on the fp32 matrix instruction at precision 1
     int dbg_layers = NL;             // test hook: run only the first dbg_layers layers
     int dbg_self_only = 0;           // test hook: stop after the self block of the last executed layer
     int force_ks = 0;                // test hook: key split of the attention launches (0 = by batch size)
@@ -2209,7 +2272,15 @@ int lg_enqueue(sslam_lightglue* g, int pairs, const StageSrc& src, float min_con
     }
     hipLaunchKernelGGL(lg_token_heads_kernel, headgrid, dim3(256), 0, s, g->x, nullptr, nullptr,
                        g->mt_w, g->mt_b, g->mt_stride, 1, 0.0f, g->conf, g->mat, g->ctrl, Kc, 0);
-    {
+    if (g->precision == 1 && !g->sim_exact) {
+        hipLaunchKernelGGL(lg_split_md_kernel, dim3(32, NI), dim3(256), 0, s, g->md, g->qs_hi, g->qs_lo, Kc, g->ctrl);
+        SimArgsH a{g->qs_hi, g->qs_lo, g->sim, Kc, g->ctrl};
+#ifndef LG_SIM_BM
+#define LG_SIM_BM 128
+#endif
+        dim3 grid(sslam::cdiv(Kc, 128), sslam::cdiv(Kc, LG_SIM_BM), pairs);
+        hipLaunchKernelGGL((lg_sim_h_kernel<LG_SIM_BM, 128, LG_SIM_BM / 64, 2>), grid, dim3(256), 0, s, a);
+    } else {
         SimArgs a{g->md, g->sim, Kc, g->ctrl};
         dim3 grid(sslam::cdiv(Kc, 128), sslam::cdiv(Kc, 64), pairs);
         hipLaunchKernelGGL((lg_sim_kernel<64, 128, 1, 2>), grid, dim3(256), 0, s, a);
@@ -2291,6 +2362,7 @@ int sslam_lightglue_create_batched(sslam_ctx* ctx, const float* weights, size_t 
     g->Kc = Kc;
     g->NB = max_pairs; g->NIc = 2 * max_pairs;
     g->KSmax = Kc >= 1024 ? 4 : (Kc >= 512 ? 2 : 1);
+    if (const char* e = getenv("SSLAM_LG_SIM_EXACT")) g->sim_exact = e[0] == '1';
     const size_t K = (size_t)Kc, NI = (size_t)g->NIc, NB = (size_t)max_pairs;
     auto carve = [&](sslam::Arena& A) {
         g->blob = A.take<float>(n_floats);
