@@ -110,6 +110,25 @@ def test_raster_order_branch_small_image(W, AL):
     al.close()
 
 
+def test_no_candidate_fallback_thresholds_on_the_mean_score(W, AL):
+    """DKD's second branch (`if mask.sum() == 0: mask = nms > mean(score_map)`): a score head with all-positive inner layers and an
+    all-negative last layer puts every score below the 0.2 detection threshold, so the candidates are the local maxima above the
+    MEAN score - the list the NMS waves append is empty, `ctrl->found` stays 0 and the second collect launch does the work.  (The
+    mean is a sum whose order is the implementation's: a local maximum within ~1e-7 of it could land on either side; none does
+    here.)"""
+    sd = W.random_aliked_state_dict(0)
+    for k in ("score_head.0.weight", "score_head.2.weight", "score_head.4.weight"):
+        sd[k] = np.abs(sd[k])
+    sd["score_head.6.weight"] = (-3e-4 / 0.17 * np.abs(sd["score_head.6.weight"])).astype(np.float32)
+    al = AL(sd, max_num_keypoints=4096, max_h=256, max_w=320)
+    img = np.ascontiguousarray(frames.structured_frame(0)[:200, :300])
+    xy, desc, ref = _check(al, sd, img, 4096)
+    d = _dims(al)
+    assert al.debug_read(0, (d["h"], d["w"])).max() < 0.2
+    assert 0 < len(xy) == d["n_cand"] < 4096
+    al.close()
+
+
 def test_reference_disc_pair_degenerate_ties(W, AL):
     """The reference test's own input (tests/test_lightglue_vs_manual.py:16-27): 200x200, four
     white discs on black.  Large constant regions give exactly tied scores; the stage-exact DKD
