@@ -69,3 +69,14 @@ def test_dev_entry_raises_the_flag_instead(gpu_ctx):
     for p in dev + out:
         gpu_ctx.free(p)
     lg.close()
+
+
+def test_weights_past_the_fp16_range_are_refused_at_creation(gpu_ctx, native):
+    """Every weight matrix that feeds a split contraction is split once when the matcher is created (the transformer layers and,
+    since the projections moved onto the split pipe, input_proj / final_proj): a weight that does not fit the planes is an error
+    there, not a silent inf later."""
+    W, LG = load_pkg("weights"), load_pkg("lightglue").LightGlueHIP
+    sd = dict(W.random_lightglue_state_dict(1))
+    sd["input_proj.weight"] = sd["input_proj.weight"] * np.float32(1e7)
+    with pytest.raises(native.NativeError, match="weight"):
+        LG(sd, max_kpts=128, ctx=gpu_ctx)

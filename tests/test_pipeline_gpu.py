@@ -143,7 +143,7 @@ def test_one_rank_pipeline_over_rccl_directly():
 
 def test_pipeline_reports_a_split_precision_range_overflow(native):
     """the headline path must not hand on matches computed past the fp16 range of the
-    split-precision planes.  Token states scaled by 1e7 through the PIPELINE: `results()` / `infos()` raise,
+    split-precision planes.  Token states shifted by 1e7 through the PIPELINE: `results()` / `infos()` raise,
     the per-instance flags are raised (and cleared by the report), a second matcher instance that never saw
     the data stays clean, and the next (sane) round is served normally."""
     W = load_pkg("weights"); fs = load_pkg("frame_shard")
@@ -152,7 +152,9 @@ def test_pipeline_reports_a_split_precision_range_overflow(native):
     sd_a = W.random_aliked_state_dict(0)
     sd_l = W.random_lightglue_state_dict(1, match_gain=4.0, match_bias=3.0)
     sd_big = dict(sd_l)
-    sd_big["input_proj.weight"] = sd_big["input_proj.weight"] * 1e7           # every token state x 1e7: far past 65520
+    # every token state + 1e7: far past 65520 (through the BIAS, which stays fp32: since the input projection runs on the
+    # split pipe too its weights are split at creation, and a weight past the fp16 range is refused there)
+    sd_big["input_proj.bias"] = sd_big["input_proj.bias"] + np.float32(1e7)
     dets = [AL(sd_a, max_num_keypoints=K, max_h=H, max_w=Wd, ctx=native.Context(0))]
     imgs = np.stack([frames.structured_frame(i, h=H, w=Wd) for i in range(B)])
     for sd, expect in ((sd_big, True), (sd_l, False)):
