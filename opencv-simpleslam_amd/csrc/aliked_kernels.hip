@@ -1221,120 +1221,14 @@ __global__ __launch_bounds__(256) void al_score_tail_kernel(const float* __restr
 // ------------------------------------------------------------------------ //
 //  5. DKD: simple_nms (5x5, two recovery rounds) + border + threshold -> candidates
 // ------------------------------------------------------------------------ //
-#ifndef AL_NT_W
-#define AL_NT_W 32      // 32 x 16 tiles: 30 KB of LDS, five workgroups per CU (64 x 16: 48 KB, three; 11.5 -> 9.6 us per frame)
-#endif
-#ifndef AL_NT_H
-#define AL_NT_H 16
-#endif
-constexpr int NT_W = AL_NT_W, NT_H = AL_NT_H, NHALO = 10;     // dependency radius 2 + 4 + 4
-constexpr int NE_W = NT_W + 2 * NHALO, NE_H = NT_H + 2 * NHALO;
-constexpr int NE = NE_H * NE_W;
-constexpr int NPASS = (NE + 255) / 256;
+constexpr int NHALO = 10;     // dependency radius of simple_nms: 2 + 4 + 4
 
-// 5x5 max-pool of an LDS tile, separable: rows into `tmp`, then columns (-inf outside the tile,
-// which is what F.max_pool2d's implicit padding does at the map border)
-__device__ __forceinline__ void pool5_rows(const float* __restrict__ a, float* __restrict__ tmp) {
-#pragma unroll
-    for (int k = 0; k < NPASS; ++k) {
-        const int i = threadIdx.x + 256 * k;
-        if (i < NE) {
-            const int lx = i % NE_W;
-            float m = a[i];
-            if (lx >= 1) m = fmaxf(m, a[i - 1]);
-            if (lx >= 2) m = fmaxf(m, a[i - 2]);
-            if (lx + 1 < NE_W) m = fmaxf(m, a[i + 1]);
-            if (lx + 2 < NE_W) m = fmaxf(m, a[i + 2]);
-            tmp[i] = m;
-        }
-    }
-}
-__device__ __forceinline__ float pool5_col(const float* __restrict__ tmp, int i) {
-    const int ly = i / NE_W;
-    float m = tmp[i];
-    if (ly >= 1) m = fmaxf(m, tmp[i - NE_W]);
-    if (ly >= 2) m = fmaxf(m, tmp[i - 2 * NE_W]);
-    if (ly + 1 < NE_H) m = fmaxf(m, tmp[i + NE_W]);
-    if (ly + 2 < NE_H) m = fmaxf(m, tmp[i + 2 * NE_W]);
-    return m;
-}
-
-__global__ __launch_bounds__(256) void al_nms_kernel(const float* __restrict__ score, int h, int w,
-                                                     float* __restrict__ nms, float* __restrict__ block_sum, size_t fs) {
-    score = fsh(score, blockIdx.z, fs); nms = fsh(nms, blockIdx.z, fs); block_sum = fsh(block_sum, blockIdx.z, fs);
-    // s: scores (-inf outside the map); m: max_mask (0/1); q: suppressed scores; tmp: row-pooled scratch.
-    // Values at the LDS-tile rim are wrong (missing neighbours) but the 10-pixel halo keeps them out
-    // of the dependency cone of the central NT_H x NT_W outputs.
-    __shared__ float s[NE], m[NE], q[NE], tmp[NE];
-    const int x0 = blockIdx.x * NT_W - NHALO, y0 = blockIdx.y * NT_H - NHALO;
-#pragma unroll
-    for (int k = 0; k < NPASS; ++k) {
-        const int i = threadIdx.x + 256 * k;
-        if (i < NE) {
-            const int yy = y0 + i / NE_W, xx = x0 + i % NE_W;
-            s[i] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? score[(size_t)yy * w + xx] : -INFINITY;
-        }
-    }
-    __syncthreads();
-    pool5_rows(s, tmp);
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NPASS; ++k) {
-        const int i = threadIdx.x + 256 * k;
-        if (i < NE) m[i] = (s[i] == pool5_col(tmp, i) && s[i] > -INFINITY) ? 1.0f : 0.0f;
-    }
-    __syncthreads();
-    for (int round = 0; round < 2; ++round) {
-        pool5_rows(m, tmp);
-        __syncthreads();
-        bool supp_r[NPASS];
-#pragma unroll
-        for (int k = 0; k < NPASS; ++k) {
-            const int i = threadIdx.x + 256 * k;
-            supp_r[k] = false;
-            if (i < NE) {
-                supp_r[k] = pool5_col(tmp, i) > 0.0f;                 // supp = maxpool(max_mask) > 0
-                q[i] = (s[i] == -INFINITY) ? -INFINITY : (supp_r[k] ? 0.0f : s[i]);
-            }
-        }
-        __syncthreads();
-        pool5_rows(q, tmp);
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < NPASS; ++k) {
-            const int i = threadIdx.x + 256 * k;
-            if (i < NE) {
-                const bool newmax = q[i] == pool5_col(tmp, i) && q[i] > -INFINITY;
-                if (newmax && !supp_r[k]) m[i] = 1.0f;                 // max_mask |= new_max & ~supp
-            }
-        }
-        __syncthreads();
-    }
-    float lsum = 0.0f;
-    for (int i = threadIdx.x; i < NT_H * NT_W; i += 256) {
-        const int ly = i / NT_W + NHALO, lx = i % NT_W + NHALO;
-        const int yy = y0 + ly, xx = x0 + lx;
-        if (yy < h && xx < w) {
-            const float sv = s[ly * NE_W + lx];
-            float v = m[ly * NE_W + lx] > 0.0f ? sv : 0.0f;
-            if (yy < 2 || xx < 2 || yy >= h - 2 || xx >= w - 2) v = 0.0f;      // border of `radius`
-            nms[(size_t)yy * w + xx] = v;
-            lsum += sv;
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
-    __shared__ float ws[4];
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = lsum;
-    __syncthreads();
-    if (threadIdx.x == 0) block_sum[blockIdx.y * gridDim.x + blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
-}
-
-// r04: the same NMS with a WAVE owning a tile and no LDS: lane = column (64 of them, 44 + the 10-pixel halo either side), the
+// r04: NMS with a WAVE owning a tile and no LDS (the LDS-tile form it replaced: scripts/ubench/aliked_superseded_r04.hpp, al_nms_kernel): lane = column (64 of them, 44 + the 10-pixel halo either side), the
 // R rows of the column in registers.  A 5-wide row maximum is four DPP wave shifts fused into v_max (lanes shifted in from
 // outside the wave see themselves = an absent neighbour, as the LDS tile's rim was), a 5-tall column maximum three register
 // v_max per row (pairs, pairs of pairs, + one), and the 0/1 maps (max_mask, supp) are ONE 64-bit word per lane - bit y = row y
 // of the lane's column - so their 5 x 5 dilation is ten shifts and eight DPP ORs for the whole tile instead of a pooled
-// float map (r03 form above: 3.7 x halo redundancy, ~60 LDS operations per element, 9.6 us per frame; max is exact and
+// float map (r03 form: 3.7 x halo redundancy, ~60 LDS operations per element, 9.6 us per frame; max is exact and
 // associative, so the order of the pooling steps changes nothing: nms is bit-identical.  block_sum's partition changes, i.e.
 // the rounding of the mean score the no-candidate fallback thresholds on).
 #ifndef AL_NMS_ROWS
@@ -1489,6 +1383,8 @@ __global__ __launch_bounds__(256) void al_nms_wave_kernel(const float* __restric
 
 // collect pixels with nms > thr into an (unordered) candidate list of 64-bit keys:
 // key = score_bits << 32 | (0xffffffff - index)  -> larger key = better (score desc, index asc)
+// (end of r04: launched for the mean-score fallback only - `fallback` = 1, returns at once when the NMS waves found candidates
+//  above the detection threshold; the detection-threshold pass itself is the tail of al_nms_wave_kernel)
 constexpr int COLLECT_PPT = 16;     // pixels per thread: 4096 per block -> ~80 blocks, one same-address atomic each
 
 __global__ __launch_bounds__(256) void al_collect_kernel(const float* __restrict__ nms, int n_px, float thr,
@@ -2229,18 +2125,9 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
     hipLaunchKernelGGL(al_score_tail_kernel, dim3(sslam::cdiv(Wp, ST_W), sslam::cdiv(Hp, ST_H), uF), dim3(256), 0, s, g->s8,
                        Hp, Wp, g->sh2, g->sh4, g->sh6, g->score, d.h, d.w, d.pl, d.pt, fs);
     // DKD
-#ifndef AL_NMS_WAVE
-#define AL_NMS_WAVE 1
-#endif
-    const int nbx = sslam::cdiv(d.w, AL_NMS_WAVE ? NW_OW : NT_W), nby = sslam::cdiv(d.h, AL_NMS_WAVE ? NW_OH : NT_H), npx = d.h * d.w;
-    if (AL_NMS_WAVE) {
-        hipLaunchKernelGGL(al_nms_wave_kernel, dim3(sslam::cdiv(nbx * nby, 4), uF), dim3(256), 0, s, g->score, d.h, d.w, nbx, nbx * nby,
-                           g->nms, g->bsum, 0.2f, g->cand, g->cand_cap, g->ctrl, g->hist, fs);
-    } else {
-        hipLaunchKernelGGL(al_nms_kernel, dim3(nbx, nby, uF), dim3(256), 0, s, g->score, d.h, d.w, g->nms, g->bsum, fs);
-        hipLaunchKernelGGL(al_collect_kernel, dim3(sslam::cdiv(npx, 256 * COLLECT_PPT), uF), dim3(256), 0, s, g->nms, npx, 0.2f, 0, g->bsum,
-                           nbx * nby, g->cand, g->cand_cap, g->ctrl, g->hist, fs);
-    }
+    const int nbx = sslam::cdiv(d.w, NW_OW), nby = sslam::cdiv(d.h, NW_OH), npx = d.h * d.w;
+    hipLaunchKernelGGL(al_nms_wave_kernel, dim3(sslam::cdiv(nbx * nby, 4), uF), dim3(256), 0, s, g->score, d.h, d.w, nbx, nbx * nby,
+                       g->nms, g->bsum, 0.2f, g->cand, g->cand_cap, g->ctrl, g->hist, fs);
     hipLaunchKernelGGL(al_collect_kernel, dim3(sslam::cdiv(npx, 256 * COLLECT_PPT), uF), dim3(256), 0, s, g->nms, npx, 0.0f, 1, g->bsum,
                        nbx * nby, g->cand, g->cand_cap, g->ctrl, g->hist, fs);
     hipLaunchKernelGGL(al_select_kernel, dim3(uF), dim3(1024), (SEL_CAP + EDGE_CAP) * 8, s, g->cand, g->cand_cap, n_limit,

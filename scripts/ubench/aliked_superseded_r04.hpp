@@ -1099,4 +1099,117 @@ __device__ __forceinline__ void sweep_stash(float* __restrict__ tl, int t, unsig
     }
 }
 
+
+// ---- the LDS-tile NMS (r01 - r04; superseded by al_nms_wave_kernel at the end of r04: one wave per tile, rows in registers, 0/1 maps
+// as 64-bit words; the two forms gave bit-identical nms maps on scripts/ab_hash_aliked.sh).  The first al_collect_kernel launch
+// (threshold pass over the nms map) went with it: the NMS waves append the candidates themselves.
+#ifndef AL_NT_W
+#define AL_NT_W 32      // 32 x 16 tiles: 30 KB of LDS, five workgroups per CU (64 x 16: 48 KB, three; 11.5 -> 9.6 us per frame)
+#endif
+#ifndef AL_NT_H
+#define AL_NT_H 16
+#endif
+constexpr int NT_W = AL_NT_W, NT_H = AL_NT_H, NHALO = 10;     // dependency radius 2 + 4 + 4
+constexpr int NE_W = NT_W + 2 * NHALO, NE_H = NT_H + 2 * NHALO;
+constexpr int NE = NE_H * NE_W;
+constexpr int NPASS = (NE + 255) / 256;
+
+// 5x5 max-pool of an LDS tile, separable: rows into `tmp`, then columns (-inf outside the tile,
+// which is what F.max_pool2d's implicit padding does at the map border)
+__device__ __forceinline__ void pool5_rows(const float* __restrict__ a, float* __restrict__ tmp) {
+#pragma unroll
+    for (int k = 0; k < NPASS; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        if (i < NE) {
+            const int lx = i % NE_W;
+            float m = a[i];
+            if (lx >= 1) m = fmaxf(m, a[i - 1]);
+            if (lx >= 2) m = fmaxf(m, a[i - 2]);
+            if (lx + 1 < NE_W) m = fmaxf(m, a[i + 1]);
+            if (lx + 2 < NE_W) m = fmaxf(m, a[i + 2]);
+            tmp[i] = m;
+        }
+    }
+}
+__device__ __forceinline__ float pool5_col(const float* __restrict__ tmp, int i) {
+    const int ly = i / NE_W;
+    float m = tmp[i];
+    if (ly >= 1) m = fmaxf(m, tmp[i - NE_W]);
+    if (ly >= 2) m = fmaxf(m, tmp[i - 2 * NE_W]);
+    if (ly + 1 < NE_H) m = fmaxf(m, tmp[i + NE_W]);
+    if (ly + 2 < NE_H) m = fmaxf(m, tmp[i + 2 * NE_W]);
+    return m;
+}
+
+__global__ __launch_bounds__(256) void al_nms_kernel(const float* __restrict__ score, int h, int w,
+                                                     float* __restrict__ nms, float* __restrict__ block_sum, size_t fs) {
+    score = fsh(score, blockIdx.z, fs); nms = fsh(nms, blockIdx.z, fs); block_sum = fsh(block_sum, blockIdx.z, fs);
+    // s: scores (-inf outside the map); m: max_mask (0/1); q: suppressed scores; tmp: row-pooled scratch.
+    // Values at the LDS-tile rim are wrong (missing neighbours) but the 10-pixel halo keeps them out
+    // of the dependency cone of the central NT_H x NT_W outputs.
+    __shared__ float s[NE], m[NE], q[NE], tmp[NE];
+    const int x0 = blockIdx.x * NT_W - NHALO, y0 = blockIdx.y * NT_H - NHALO;
+#pragma unroll
+    for (int k = 0; k < NPASS; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        if (i < NE) {
+            const int yy = y0 + i / NE_W, xx = x0 + i % NE_W;
+            s[i] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? score[(size_t)yy * w + xx] : -INFINITY;
+        }
+    }
+    __syncthreads();
+    pool5_rows(s, tmp);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NPASS; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        if (i < NE) m[i] = (s[i] == pool5_col(tmp, i) && s[i] > -INFINITY) ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+    for (int round = 0; round < 2; ++round) {
+        pool5_rows(m, tmp);
+        __syncthreads();
+        bool supp_r[NPASS];
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            supp_r[k] = false;
+            if (i < NE) {
+                supp_r[k] = pool5_col(tmp, i) > 0.0f;                 // supp = maxpool(max_mask) > 0
+                q[i] = (s[i] == -INFINITY) ? -INFINITY : (supp_r[k] ? 0.0f : s[i]);
+            }
+        }
+        __syncthreads();
+        pool5_rows(q, tmp);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            if (i < NE) {
+                const bool newmax = q[i] == pool5_col(tmp, i) && q[i] > -INFINITY;
+                if (newmax && !supp_r[k]) m[i] = 1.0f;                 // max_mask |= new_max & ~supp
+            }
+        }
+        __syncthreads();
+    }
+    float lsum = 0.0f;
+    for (int i = threadIdx.x; i < NT_H * NT_W; i += 256) {
+        const int ly = i / NT_W + NHALO, lx = i % NT_W + NHALO;
+        const int yy = y0 + ly, xx = x0 + lx;
+        if (yy < h && xx < w) {
+            const float sv = s[ly * NE_W + lx];
+            float v = m[ly * NE_W + lx] > 0.0f ? sv : 0.0f;
+            if (yy < 2 || xx < 2 || yy >= h - 2 || xx >= w - 2) v = 0.0f;      // border of `radius`
+            nms[(size_t)yy * w + xx] = v;
+            lsum += sv;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+    __shared__ float ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sum[blockIdx.y * gridDim.x + blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+
 #endif
