@@ -99,8 +99,6 @@ struct GemmAH {                      // A operand: optional concat of two split 
     SplitPtr A1;
     int lda;                         // same leading dimension for both
     int K0;                          // columns [0,K0) from A0, [K0,K) from A1 (K0 % 32 == 0)
-    size_t kts = 32;                 // halves between consecutive 32-deep k-tiles of a row: 32 = row-major planes (lda = K);
-                                     // rows_total * 32 with lda = 32 = the k-panel layout below (PANEL_K = 32)
 };
 
 #define LDH8(dst, ptr) dst = *reinterpret_cast<const uint4*>(ptr)
@@ -134,9 +132,8 @@ __device__ __forceinline__ void gemm_mainloop_h(const GemmAH& ga, SplitPtr W, in
     {                                                                             \
         const int k_ = (kt_) * HBK;                                               \
         const bool f_ = k_ < ga.K0;                                               \
-        const size_t ka_ = (size_t)(f_ ? (kt_) : (kt_) - ga.K0 / HBK) * ga.kts;   \
-        const _Float16* pah_ = (f_ ? ga.A0.hi : ga.A1.hi) + ka_;                  \
-        const _Float16* pal_ = (f_ ? ga.A0.lo : ga.A1.lo) + ka_;                  \
+        const _Float16* pah_ = f_ ? ga.A0.hi + k_ : ga.A1.hi + (k_ - ga.K0);      \
+        const _Float16* pal_ = f_ ? ga.A0.lo + k_ : ga.A1.lo + (k_ - ga.K0);      \
         LDH8(ah0, pah_ + oa[0]); LDH8(al0, pal_ + oa[0]);                         \
         if constexpr (NA > 1) { LDH8(ah1, pah_ + oa[1]); LDH8(al1, pal_ + oa[1]); } \
         LDH8(wh0, W.hi + k_ + ow[0]); LDH8(wl0, W.lo + k_ + ow[0]);               \

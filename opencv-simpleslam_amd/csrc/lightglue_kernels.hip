@@ -747,141 +747,6 @@ __global__ __launch_bounds__(256) void lg_sim_kernel(SimArgs p) {
         }
 }
 
-// r04: the same product on the split-precision pipe (precision 1).  The fp32 matrix instruction ran this GEMM at 63 % of ITS
-// peak (17.2 GFLOP per 8 pairs in 175 us = 98 TFLOP/s of 157) - a twentieth of the forward's FLOPs for 2.8 % of its time.  The
-// matching descriptors are split once (lg_split_md_kernel: row-major (hi, lo) planes in the q planes, free by now), three
-// f16 MFMAs per product into two fp32 accumulators as everywhere else (gemm_f16x3.hpp).
-struct SimArgsH { const _Float16* md_hi; const _Float16* md_lo; float* sim; int Kc; const LGCtrl* ctrl; };
-
-__global__ __launch_bounds__(256) void lg_split_md_kernel(const float* __restrict__ md, _Float16* __restrict__ hi,
-                                                          _Float16* __restrict__ lo, int ld, int Kc, const LGCtrl* __restrict__ ctrl) {
-    const int img = blockIdx.y;
-    const LGCtrl& pc = ctrl_of(ctrl, img);
-    if (pc.stop == 2) return;
-    const size_t total = (size_t)pc.n[img & 1] * (ld / 8), base = (size_t)img * Kc * ld;
-    float amax = 0.0f;
-    for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += (size_t)gridDim.x * blockDim.x) {
-        const float4 a = *reinterpret_cast<const float4*>(md + base + u * 8);
-        const float4 b = *reinterpret_cast<const float4*>(md + base + u * 8 + 4);
-        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        uint4 hh, ll;
-        sslam::split8_fast(v, hh, ll, amax);
-        *reinterpret_cast<uint4*>(hi + base + u * 8) = hh;
-        *reinterpret_cast<uint4*>(lo + base + u * 8) = ll;
-    }
-    sslam::split_range_check(amax, range_flag_of(ctrl, img));
-}
-
-template <int BM, int BN, int TM, int TN>
-__global__ __launch_bounds__(256) void lg_sim_h_kernel(SimArgsH p) {
-    __shared__ sslam::GemmSmemH<BM, BN> sm;
-    int pair = blockIdx.z, bx = blockIdx.x, by = blockIdx.y;         // XCD-aware order: see lg_sim_kernel
-    if ((gridDim.z & 7) == 0) {
-        const unsigned T = gridDim.x * gridDim.y;
-        const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const unsigned grp = L / (8 * T), rem = L % (8 * T);
-        pair = (int)(grp * 8 + (rem & 7));
-        const unsigned tix = rem >> 3;
-        bx = (int)(tix % gridDim.x); by = (int)(tix / gridDim.x);
-    }
-    const LGCtrl& pc = p.ctrl[pair];
-    if (pc.stop == 2) return;
-    const int n0 = pc.n[0], n1 = pc.n[1];
-    const int row0 = by * BM, col0 = bx * BN;
-    if (row0 >= n0 || col0 >= n1) return;
-    const size_t o0 = (size_t)pair * 2 * p.Kc * D, o1 = o0 + (size_t)p.Kc * D;
-    float* simp = p.sim + (size_t)pair * p.Kc * p.Kc;
-    const sslam::SplitPtr a{p.md_hi + o0, p.md_lo + o0};
-    sslam::GemmAH ga{a, a, D, D};
-    f32x16 c1[TM][TN], c2[TM][TN];
-    sslam::gemm_mainloop_h<BM, BN, TM, TN>(ga, sslam::SplitPtr{p.md_hi + o1, p.md_lo + o1}, D, D, row0, p.Kc, col0, p.Kc, sm, c1, c2);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = col0 + wn * 32 * TN + j * 32 + (lane & 31);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + wm * 32 * TM + i * 32 + acc_row(r, lane);
-                if (row < n0 && col < n1) simp[(size_t)row * p.Kc + col] = c1[i][j][r] + c2[i][j][r] * sslam::SPLIT_INV;
-            }
-        }
-}
-
-// r04: the input and the final projection (Linear 128 -> 256 on the descriptors, Linear 256 -> 256 x 256^-1/4 of the stop layer
-// on the final states) on the split pipe at precision 1.  On the fp32 matrix instruction they took 45 us per 8 pairs each, and
-// each was followed by a pass that split its output for the next consumer (lg_split_rows_kernel 13 us, lg_split_md_kernel 14 us):
-// here the epilogue writes the fp32 result AND its planes - k-panel layout (the token state) or row-major (the matching
-// descriptors) - so those passes are gone.  A planes: row-major (`a_kts` = 32, lda = K) or k-panel (`a_kts` = plane rows x 32,
-// lda = 32); W planes row-major [256][K] (lg_split_weight_rm_kernel at create time), chosen by the pair's stop layer.
-struct ProjArgsH {
-    const _Float16 *a_hi, *a_lo; int lda; size_t a_kts; int K;
-    const _Float16 *w_hi, *w_lo; long w_layer_stride;          // halves between consecutive layers' W (by_stop_layer)
-    const float* bias; long b_layer_stride; int by_stop_layer; int ignore_stop;
-    float out_scale;
-    float* out;                                                // fp32 [NI Kc][256]
-    _Float16 *o_hi, *o_lo; int o_panel_rows;                    // > 0: k-panel layout over that many plane rows; 0: row-major [NI Kc][256]
-    const LGCtrl* ctrl; int Kc;
-};
-
-template <int BM, int BN, int TM, int TN>
-__global__ __launch_bounds__(256) void lg_proj_h_kernel(ProjArgsH p) {
-    __shared__ sslam::GemmSmemH<BM, BN> sm;
-    const int img = blockIdx.z;
-    const LGCtrl& pc = ctrl_of(p.ctrl, img);
-    if (pc.stop == 2 || (pc.stop && !p.ignore_stop)) return;
-    const int n = pc.n[img & 1], row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
-    if (row0 >= n) return;
-    const size_t lw = p.by_stop_layer ? (size_t)pc.stop_layer * p.w_layer_stride : 0;
-    const float* bias = p.bias + (p.by_stop_layer ? (size_t)pc.stop_layer * p.b_layer_stride : 0);
-    const int g0 = img * p.Kc;                                 // plane / output row of the image's token 0
-    const sslam::SplitPtr a{p.a_hi, p.a_lo};
-    sslam::GemmAH ga{a, a, p.lda, p.K, p.a_kts};
-    f32x16 c1[TM][TN], c2[TM][TN];
-    sslam::gemm_mainloop_h<BM, BN, TM, TN>(ga, sslam::SplitPtr{p.w_hi + lw, p.w_lo + lw}, p.K, p.K, g0 + row0, g0 + p.Kc, col0, D, sm, c1, c2);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
-    float amax = 0.0f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = col0 + wn * 32 * TN + j * 32 + (lane & 31);
-            const float b = bias[col];
-            // a lane holds ONE column of 16 rows; neighbouring lanes trade every other value so that the even lane finishes
-            // columns (c, c + 1) of row r and the odd lane the same two columns of row r + 1: 8-byte fp32 and 4-byte plane
-            // stores, half as many
-            const bool odd = lane & 1;
-            const int cpair = col & ~1;
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const float va = (c1[i][j][r] + c2[i][j][r] * sslam::SPLIT_INV + b) * p.out_scale;
-                const float vb = (c1[i][j][r + 1] + c2[i][j][r + 1] * sslam::SPLIT_INV + b) * p.out_scale;
-                const float got = __shfl_xor(odd ? va : vb, 1);        // even lane: the odd column of row r; odd lane: the even column of row r + 1
-                const int row = row0 + wm * 32 * TM + i * 32 + acc_row(odd ? r + 1 : r, lane);
-                // (rows past the image's count were computed from whatever the planes hold there: kept out of the range check)
-                const bool live = row < n;
-                const float x0 = live ? (odd ? got : va) : 0.0f, x1 = live ? (odd ? vb : got) : 0.0f;
-                unsigned h2, l2;
-                sslam::split2_fast(x0, x1, h2, l2, amax);
-                if (live) {
-                    const size_t o = p.o_panel_rows ? panel_index(g0 + row, cpair, p.o_panel_rows) : (size_t)(g0 + row) * D + cpair;
-                    *reinterpret_cast<float2*>(p.out + (size_t)(g0 + row) * D + cpair) = make_float2(x0, x1);
-                    *reinterpret_cast<unsigned*>(p.o_hi + o) = h2;
-                    *reinterpret_cast<unsigned*>(p.o_lo + o) = l2;
-                }
-            }
-        }
-    sslam::split_range_check(amax, range_flag_of(p.ctrl, img));
-}
-
-// weight matrix -> row-major split planes at the same offsets as the fp32 blob (the projections above)
-__global__ void lg_split_weight_rm_kernel(const float* __restrict__ src, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
-                                          size_t n, int* __restrict__ range_flag) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) split_f32(src[i], hi[i], lo[i], range_flag);
-}
-
 constexpr int STAT_CACHE = 32;    // values of `sim` a thread keeps between the max and the sum pass (rows / column slabs up to 2048)
 
 // row statistics: one wave per row i: max_j, log(sum_j exp(sim - max))
@@ -1448,6 +1313,113 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void lg_linear_big_kernel(LinearAr
     if (c1[0][0][0] != 123456.0f) return;
 #endif
     linear_h_epilogue<BM, BN, TM, TN, WN, NW * 64, EPI>(p, rd, col0, ibase, c1, c2, lg_ring);
+}
+
+// ---- r04: the input projection, the final projection and the similarity GEMM on the split pipe (precision 1).  On the fp32 matrix
+// instruction the similarity ran at 63 % of ITS peak (17.2 GFLOP per 8 pairs in 175 us = 98 TFLOP/s of 157) and the two projections
+// took 45 us each, each followed by a pass that split its output for the next consumer (lg_split_rows 13 us, a split of md 14 us).
+// Here: three f16 MFMAs per product into two fp32 accumulators as everywhere else (gemm_f16x3.hpp), on the big-tile main loop
+// (gemm_f16x3_big.hpp: LDS-DMA ring, two workgroups per CU - a register-staged loop spends one global -> LDS round trip per 32-deep
+// k-tile, and at K = 128 / 256 that round trip is the kernel: 75 / 32 us against 66 / 26), and the projections' epilogues write
+// the fp32 result AND the planes the next consumer reads.  Every plane in k-panel layout (A: token-state / descriptor planes over
+// NIc Kc rows; W: the weight's own panel block, chosen by the pair's stop layer, or - similarity - the other image's rows of the
+// same planes).  Bit-identical to the register-staged form; match indices unchanged against the fp32 kernels on every parity test.
+struct ProjBigArgs {
+    const _Float16 *a_hi, *a_lo; int a_rows; int K;
+    const _Float16 *w_hi, *w_lo; long w_layer_stride;
+    const float* bias; long b_layer_stride; int by_stop_layer; int ignore_stop;
+    float out_scale; float* out;
+    _Float16 *o_hi, *o_lo; int o_rows;                          // output planes: k-panel layout over o_rows rows
+    const LGCtrl* ctrl; int Kc;
+};
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64, 2) void lg_proj_big_kernel(ProjBigArgs p) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lg_ring[];
+    constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+    const int img = blockIdx.z;
+    const LGCtrl& pc = ctrl_of(p.ctrl, img);
+    if (pc.stop == 2 || (pc.stop && !p.ignore_stop)) return;
+    const int n = pc.n[img & 1], row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
+    if (row0 >= n) return;
+    const size_t lw = p.by_stop_layer ? (size_t)pc.stop_layer * p.w_layer_stride : 0;
+    const float* bias = p.bias + (p.by_stop_layer ? (size_t)pc.stop_layer * p.b_layer_stride : 0);
+    const int g0 = img * p.Kc;
+    const sslam::SplitPtr a{p.a_hi, p.a_lo};
+    GemmAH ga{a, a, 0, p.K};
+    f32x16 c1[TM][TN], c2[TM][TN];
+    sslam::gemm_mainloop_big<BM, BN, WM, WN>(ga, sslam::SplitPtr{p.w_hi + lw, p.w_lo + lw}, p.a_rows, p.K, g0 + row0, g0 + p.Kc, col0, D,
+                                             lg_ring, c1, c2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave / WN, wn = wave % WN;
+    float amax = 0.0f;
+    const bool odd = lane & 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = col0 + wn * 32 * TN + j * 32 + (lane & 31), cpair = col & ~1;
+            const float b = bias[col];
+            // (neighbouring lanes trade every other value: the even lane finishes columns (c, c + 1) of row r, the odd lane of row r + 1)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float va = (c1[i][j][r] + c2[i][j][r] * sslam::SPLIT_INV + b) * p.out_scale;
+                const float vb = (c1[i][j][r + 1] + c2[i][j][r + 1] * sslam::SPLIT_INV + b) * p.out_scale;
+                const float got = __shfl_xor(odd ? va : vb, 1);
+                const int row = row0 + wm * 32 * TM + i * 32 + acc_row(odd ? r + 1 : r, lane);
+                const bool live = row < n;                     // (rows past the count: kept out of the range check)
+                const float x0 = live ? (odd ? got : va) : 0.0f, x1 = live ? (odd ? vb : got) : 0.0f;
+                unsigned h2, l2;
+                sslam::split2_fast(x0, x1, h2, l2, amax);
+                if (live) {
+                    const size_t o = panel_index(g0 + row, cpair, p.o_rows);
+                    *reinterpret_cast<float2*>(p.out + (size_t)(g0 + row) * D + cpair) = make_float2(x0, x1);
+                    *reinterpret_cast<unsigned*>(p.o_hi + o) = h2;
+                    *reinterpret_cast<unsigned*>(p.o_lo + o) = l2;
+                }
+            }
+        }
+    sslam::split_range_check(amax, range_flag_of(p.ctrl, img));
+}
+
+struct SimBigArgs { const _Float16* md_hi; const _Float16* md_lo; float* sim; int Kc; int rows_total; const LGCtrl* ctrl; };
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64, 2) void lg_sim_big_kernel(SimBigArgs p) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lg_ring[];
+    constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+    int pair = blockIdx.z, bx = blockIdx.x, by = blockIdx.y;         // XCD-aware order: see lg_sim_kernel
+    if ((gridDim.z & 7) == 0) {
+        const unsigned T = gridDim.x * gridDim.y;
+        const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned grp = L / (8 * T), rem = L % (8 * T);
+        pair = (int)(grp * 8 + (rem & 7));
+        const unsigned tix = rem >> 3;
+        bx = (int)(tix % gridDim.x); by = (int)(tix / gridDim.x);
+    }
+    const LGCtrl& pc = p.ctrl[pair];
+    if (pc.stop == 2) return;
+    const int n0 = pc.n[0], n1 = pc.n[1];
+    const int row0 = by * BM, col0 = bx * BN;
+    if (row0 >= n0 || col0 >= n1) return;
+    const int g0 = 2 * pair * p.Kc;                                  // plane row of image 0's token 0; image 1 follows
+    float* simp = p.sim + (size_t)pair * p.Kc * p.Kc;
+    const sslam::SplitPtr a{p.md_hi, p.md_lo};
+    GemmAH ga{a, a, 0, D};
+    // W = image 1's rows of the same planes: the pointer moved by its first row inside every panel, `col_cap` = the planes' row count
+    const size_t w0 = (size_t)(g0 + p.Kc) * sslam::PANEL_K;
+    f32x16 c1[TM][TN], c2[TM][TN];
+    sslam::gemm_mainloop_big<BM, BN, WM, WN>(ga, sslam::SplitPtr{p.md_hi + w0, p.md_lo + w0}, p.rows_total, D, g0 + row0, g0 + p.Kc, col0,
+                                             p.rows_total, lg_ring, c1, c2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave / WN, wn = wave % WN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = col0 + wn * 32 * TN + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wm * 32 * TM + i * 32 + acc_row(r, lane);
+                if (row < n0 && col < n1) simp[(size_t)row * p.Kc + col] = c1[i][j][r] + c2[i][j][r] * sslam::SPLIT_INV;
+            }
+        }
 }
 
 // ---- the whole FFN of a block as one kernel (ffn_fused.hpp): batched token sets.  One workgroup = 32 TT tokens:
@@ -2274,21 +2246,17 @@ int lg_enqueue(sslam_lightglue* g, int pairs, const StageSrc& src, float min_con
     hipLaunchKernelGGL(lg_posenc_kernel, dim3(sslam::cdiv(NI * Kc * ENC, 256)), dim3(256), 0, s, g->in_xy,
                        g->bbox, g->w_r, g->enc_cos, g->enc_sin, Kc, NI, g->ctrl);
     const bool proj_h = g->precision == 1 && !g->sim_exact;       // the projections and the similarity GEMM on the split pipe
-#ifndef LG_PROJ_BM
-#define LG_PROJ_BM 64        // (128 x 128: 36.6 us per launch, 64 x 128: 31.6, 64 x 64: 32.5 - short K, latency-bound: more workgroups per CU)
-#endif
-#ifndef LG_PROJ_BN
-#define LG_PROJ_BN 128
-#endif
-    const dim3 projgrid(D / LG_PROJ_BN, sslam::cdiv(Kc, LG_PROJ_BM), NI);
-    if (proj_h) {   // input_proj: descriptors split into the (idle) k planes, x and its k-panel planes from the epilogue
-        hipLaunchKernelGGL(lg_split_md_kernel, dim3(32, NI), dim3(256), 0, s, g->in_desc, g->ks_hi, g->ks_lo, DIN, Kc, g->ctrl);
-        ProjArgsH a{};
-        a.a_hi = g->ks_hi; a.a_lo = g->ks_lo; a.lda = DIN; a.a_kts = 32; a.K = DIN;
+    constexpr size_t big_lds = (size_t)sslam::BIG_STAGES * sslam::big_stage_halves<128, 128>() * sizeof(_Float16);
+    const dim3 biggrid(D / 128, sslam::cdiv(Kc, 128), NI);
+    if (proj_h) {   // input_proj: descriptors split into the (idle) k planes (k-panels), x and its planes from the epilogue
+        hipLaunchKernelGGL(lg_split_rows_kernel, dim3(SPLIT_BLOCKS_PER_IMAGE, NI), dim3(256), 0, s, g->in_desc, g->ks_hi, g->ks_lo, DIN, Kc,
+                           NI, g->NIc, g->ctrl, 0);
+        ProjBigArgs a{};
+        a.a_hi = g->ks_hi; a.a_lo = g->ks_lo; a.a_rows = g->NIc * Kc; a.K = DIN;
         a.w_hi = g->w_hi + (g->w_in - g->blob); a.w_lo = g->w_lo + (g->w_in - g->blob); a.bias = g->b_in;
-        a.out_scale = 1.0f; a.out = g->x; a.o_hi = g->xs_hi; a.o_lo = g->xs_lo; a.o_panel_rows = g->NIc * Kc;
+        a.out_scale = 1.0f; a.out = g->x; a.o_hi = g->xs_hi; a.o_lo = g->xs_lo; a.o_rows = g->NIc * Kc;
         a.ctrl = g->ctrl; a.Kc = Kc;
-        hipLaunchKernelGGL((lg_proj_h_kernel<LG_PROJ_BM, LG_PROJ_BN, LG_PROJ_BM / 64, LG_PROJ_BN / 64>), projgrid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((lg_proj_big_kernel<128, 128, 2, 2>), biggrid, dim3(256), big_lds, s, a);
     } else {   // input_proj (lightglue.py: desc = self.input_proj(desc))
         LinearArgs a = lin(g, NI, g->in_desc, DIN, nullptr, 0, DIN, DIN, g->w_in, g->b_in, D);
         a.out = g->x; a.ldo = D;
@@ -2352,14 +2320,14 @@ int lg_enqueue(sslam_lightglue* g, int pairs, const StageSrc& src, float min_con
         }
     }
     // ---- assignment with log_assignment[stop_layer]
-    if (proj_h) {   // final_proj of the stop layer: the token state's k-panel planes in, md and its row-major planes (the q planes) out
-        ProjArgsH a{};
-        a.a_hi = g->xs_hi; a.a_lo = g->xs_lo; a.lda = 32; a.a_kts = (size_t)g->NIc * Kc * 32; a.K = D;
+    if (proj_h) {   // final_proj of the stop layer: the token state's planes in, md and its planes (the idle q planes) out
+        ProjBigArgs a{};
+        a.a_hi = g->xs_hi; a.a_lo = g->xs_lo; a.a_rows = g->NIc * Kc; a.K = D;
         a.w_hi = g->w_hi + (g->fp_w - g->blob); a.w_lo = g->w_lo + (g->fp_w - g->blob); a.w_layer_stride = g->fp_stride;
         a.bias = g->fp_b; a.b_layer_stride = g->fp_stride; a.by_stop_layer = 1; a.ignore_stop = 1;
         a.out_scale = 0.25f;                    // 1 / 256^0.25
-        a.out = g->md; a.o_hi = g->qs_hi; a.o_lo = g->qs_lo; a.o_panel_rows = 0; a.ctrl = g->ctrl; a.Kc = Kc;
-        hipLaunchKernelGGL((lg_proj_h_kernel<LG_PROJ_BM, LG_PROJ_BN, LG_PROJ_BM / 64, LG_PROJ_BN / 64>), projgrid, dim3(256), 0, s, a);
+        a.out = g->md; a.o_hi = g->qs_hi; a.o_lo = g->qs_lo; a.o_rows = g->NIc * Kc; a.ctrl = g->ctrl; a.Kc = Kc;
+        hipLaunchKernelGGL((lg_proj_big_kernel<128, 128, 2, 2>), biggrid, dim3(256), big_lds, s, a);
     } else {
         LinearArgs a = lin(g, NI, g->x, D, nullptr, 0, D, D, g->fp_w, g->fp_b, D);
         a.by_stop_layer = 1; a.w_layer_stride = g->fp_stride; a.b_layer_stride = g->fp_stride;
@@ -2370,12 +2338,8 @@ int lg_enqueue(sslam_lightglue* g, int pairs, const StageSrc& src, float min_con
     hipLaunchKernelGGL(lg_token_heads_kernel, headgrid, dim3(256), 0, s, g->x, nullptr, nullptr,
                        g->mt_w, g->mt_b, g->mt_stride, 1, 0.0f, g->conf, g->mat, g->ctrl, Kc, 0);
     if (proj_h) {
-        SimArgsH a{g->qs_hi, g->qs_lo, g->sim, Kc, g->ctrl};
-#ifndef LG_SIM_BM
-#define LG_SIM_BM 128
-#endif
-        dim3 grid(sslam::cdiv(Kc, 128), sslam::cdiv(Kc, LG_SIM_BM), pairs);
-        hipLaunchKernelGGL((lg_sim_h_kernel<LG_SIM_BM, 128, LG_SIM_BM / 64, 2>), grid, dim3(256), 0, s, a);
+        SimBigArgs a{g->qs_hi, g->qs_lo, g->sim, Kc, g->NIc * Kc, g->ctrl};
+        hipLaunchKernelGGL((lg_sim_big_kernel<128, 128, 2, 2>), dim3(sslam::cdiv(Kc, 128), sslam::cdiv(Kc, 128), pairs), dim3(256), big_lds, s, a);
     } else {
         SimArgs a{g->md, g->sim, Kc, g->ctrl};
         dim3 grid(sslam::cdiv(Kc, 128), sslam::cdiv(Kc, 64), pairs);
@@ -2413,6 +2377,11 @@ void lg_configure_kernels() {
     launch_linear_h<64, 128, 1, 2, EPH_F32>(s, 0, cfg);   launch_linear_h<64, 64, 1, 1, EPH_RESID>(s, 0, cfg);
     launch_linear_h<64, 192, 1, 3, EPH_QKV>(s, 0, cfg);   launch_linear_h<64, 128, 1, 2, EPH_CROSS>(s, 0, cfg);
     launch_linear_big<128, 128, 2, 2, EPH_QKV>(s, 0, cfg); launch_linear_big<128, 128, 2, 2, EPH_CROSS>(s, 0, cfg);
+    {
+        constexpr int big_lds = sslam::BIG_STAGES * sslam::big_stage_halves<128, 128>() * (int)sizeof(_Float16);
+        (void)hipFuncSetAttribute((const void*)lg_proj_big_kernel<128, 128, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+        (void)hipFuncSetAttribute((const void*)lg_sim_big_kernel<128, 128, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+    }
     (void)hipFuncSetAttribute((const void*)lg_ffn_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, sslam::FFN_LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)lg_ffn_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, sslam::FFN_LDS_BYTES);
 }
@@ -2521,13 +2490,8 @@ int sslam_lightglue_create_batched(sslam_ctx* ctx, const float* weights, size_t 
             hipLaunchKernelGGL(lg_pack_ffn_kernel, dim3(4 * D * D / 256), dim3(256), 0, ctx->stream, l.cw1, l.cw2,
                                g->ffn_w1f[i][1], g->ffn_w2f[i][1], g->range_sticky);
         }
-        auto splitw_rm = [&](const float* w, size_t n) {       // the input / final projections' W: row-major planes (lg_proj_h_kernel)
-            const size_t off = (size_t)(w - g->blob);
-            hipLaunchKernelGGL(lg_split_weight_rm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, w,
-                               g->w_hi + off, g->w_lo + off, n, g->range_sticky);
-        };
-        splitw_rm(g->w_in, (size_t)D * DIN);
-        for (int i = 0; i < NL; ++i) splitw_rm(g->fp_w + (size_t)i * g->fp_stride, (size_t)D * D);
+        splitw(g->w_in, D, DIN);                               // the input / final projections (lg_proj_big_kernel)
+        for (int i = 0; i < NL; ++i) splitw(g->fp_w + (size_t)i * g->fp_stride, D, D);
         int wflag = 0;
         if (int rc = lg_take_range_flag(g, &wflag)) { g->arena.release(); delete g; return rc; }
         if (wflag) {
