@@ -162,81 +162,101 @@ def _cpu_leg(threads, warmup, timed, budget_s, probe_limit_s=6.0):
             "p90_s": round(float(np.percentile(a, 90)), 4), "frames_per_s": round(1.0 / float(np.median(a)), 4)}
 
 
-def dropin_leg(n_frames=40):
-    """The literal drop-in path: init_feature_pipeline / feature_extractor /
-    feature_matcher / filter_matches_ransac exactly as slam/monocular/main_revamped.py:118-126, :321-330 calls them - one
-    frame at a time, host arrays and KeyPoint / DMatch objects in and out, nothing overlapped by the caller.
+def dropin_leg(n_frames=48):
+    """The literal drop-in path: init_feature_pipeline / feature_extractor / feature_matcher / filter_matches_ransac exactly as
+    slam/monocular/main_revamped.py calls them - one frame at a time, host arrays and KeyPoint / DMatch objects in and out,
+    nothing overlapped by the caller.  Three loops over the same 1241x376 frames:
 
-    Two loops.  `frame_loop`: real frames through all three calls - with random-init networks almost nothing matches (an
-    untrained ALIKED head gives descriptors with pairwise cosine 0.9995; profiles/r04 notes), so its filter / DMatch / read-back
-    work is empty and the figure is extract + match only.  `value`: the same three calls per frame where the device records of
-    the extracted frames are overwritten, after each extraction, with the synthetic matched features of the parity tests
-    (tests/lg_inputs.py, 2048 keypoints, ~40 % true correspondences): the matcher returns hundreds of matches, the F-matrix
-    RANSAC runs on them (on the device, behind the match, once the loop's pattern is known), the DMatch objects are built and
-    filtered - the work of the reference's loop.  The overwrite itself is outside the timed calls."""
+      frame_loop   real extracted features through all three calls.  With random-init networks almost nothing matches (an
+                   untrained ALIKED head gives descriptors with pairwise cosine 0.9995), so the filter / DMatch / read-back work is
+                   empty: extract + match only.
+      value        one match per frame (main_revamped.py:325-330 prev -> cur + RANSAC) on PLANTED features: right behind every
+                   extraction, on the extractor's own stream, the frame's device record is overwritten with the next frame of a
+                   synthetic chain (tests/lg_inputs.py::PlantedExtractor - 2048 keypoints, any two frames share true
+                   correspondences), so the matcher returns hundreds of matches, the F-matrix RANSAC runs on them, the DMatch
+                   objects are built and filtered.  The overwrite (three asynchronous uploads, ~1 MB) is INSIDE the timed calls.
+      slam_loop    the reference's real call pattern on the same planted chain: per frame extract +
+                   prev -> cur + RANSAC; beyond the keyframe cooldown (kf_cooldown 5, main_revamped.py:221) additionally
+                   keyframe -> cur + RANSAC (keyframe_utils.py:153-154) and - the frame being promoted - the same pair again
+                   (triangulation_utils.py:131-132); the new frame becomes the keyframe.  frames/s over ALL frames, the keyframe
+                   frames' extra calls included."""
     os.environ.setdefault("SSLAM_ALLOW_RANDOM_WEIGHTS", "1")         # no checkpoints in the image
     # random-init weights whose assignment head is sharp enough to match the synthetic features (as the parity tests use them)
     os.environ.setdefault("SSLAM_RANDOM_LIGHTGLUE_ARGS", "seed=1,match_gain=4.0,match_bias=3.0")
     from types import SimpleNamespace
     fu = importlib.import_module("opencv-simpleslam_amd.slam.core.features_utils")
-    ty = importlib.import_module("opencv-simpleslam_amd.slam.core.types")
     args = SimpleNamespace(use_lightglue=True, max_features=MAX_KPTS, min_conf=MIN_CONF)
     import logging
     logging.getLogger("opencv_simpleslam_amd").setLevel(logging.ERROR)
     det, mat = fu.init_feature_pipeline(args)
+    ring = fu._ring_of(det)
     imgs = [structured_frame(i) for i in range(n_frames + 3)]
     med = lambda a: round(float(np.median(a)) * 1e3, 3)
+    KF_COOLDOWN, RANSAC_THR = 5, 2.5                                   # main_revamped.py:221, :212
 
-    def loop(plant):
+    def loop(keyframes):
+        ring.forget_patterns()
+        stats0 = dict(ring.stats)
         kp_prev, des_prev = fu.feature_extractor(args, imgs[0], det)
-        if plant:
-            kp_prev = plant(kp_prev, des_prev, 0)
-        te, tm, tr, tot, nm, nf = [], [], [], [], [], []
+        kf, last_kf = (kp_prev, des_prev), 0
+        te, tm, tr, tk, tot, nm, nf, nk = [], [], [], [], [], [], [], []
         for i, im in enumerate(imgs[1:]):
+            f = i + 1
             t0 = time.perf_counter(); kp, des = fu.feature_extractor(args, im, det); t1 = time.perf_counter()
-            if plant:
-                kp = plant(kp, des, i + 1)
-            t1b = time.perf_counter()
             m = fu.feature_matcher(args, kp_prev, kp, des_prev, des, mat); t2 = time.perf_counter()
-            f = fu.filter_matches_ransac(kp_prev, kp, m, 1.0); t3 = time.perf_counter()
+            flt = fu.filter_matches_ransac(kp_prev, kp, m, RANSAC_THR); t3 = time.perf_counter()
+            extra = 0
+            if keyframes and f - last_kf > KF_COOLDOWN:
+                r1 = fu.feature_matcher(args, kf[0], kp, kf[1], des, mat)                       # select_keyframe
+                k1 = fu.filter_matches_ransac(kf[0], kp, r1, RANSAC_THR)
+                r2 = fu.feature_matcher(args, kf[0], kp, kf[1], des, mat)                       # triangulate_between_kfs_2view
+                k2 = fu.filter_matches_ransac(kf[0], kp, r2, RANSAC_THR)
+                kf, last_kf, extra = (kp, des), f, 1
+                if f >= 2 * (KF_COOLDOWN + 1):
+                    nk.append((len(r1), len(k1), len(r2), len(k2)))
+            t4 = time.perf_counter()
             kp_prev, des_prev = kp, des
-            if i >= 2:                                                    # two warm-up frames (graph capture, first touches)
-                te.append(t1 - t0); tm.append(t2 - t1b); tr.append(t3 - t2); tot.append(t3 - t1b + t1 - t0)
-                nm.append(len(m)); nf.append(len(f))
-        return {"value": round(1.0 / float(np.median(tot)), 1), "unit": "frames/s", "frames_timed": len(tot),
-                "feature_extractor_ms": med(te), "feature_matcher_ms": med(tm), "filter_matches_ransac_ms": med(tr),
-                "keypoints": len(kp), "matches_median": int(np.median(nm)), "ransac_inliers_median": int(np.median(nf))}
+            if f >= (2 * (KF_COOLDOWN + 1) if keyframes else 3):            # warm-up: graph capture, first touches, the learned patterns
+                te.append(t1 - t0); tm.append(t2 - t1); tr.append(t3 - t2); tot.append(t4 - t0)
+                if extra:
+                    tk.append(t4 - t3)
+                nm.append(len(m)); nf.append(len(flt))
+        out = {"value": round(len(tot) / float(np.sum(tot)), 1) if keyframes else round(1.0 / float(np.median(tot)), 1),
+               "unit": "frames/s", "frames_timed": len(tot),
+               "feature_extractor_ms": med(te), "feature_matcher_ms": med(tm), "filter_matches_ransac_ms": med(tr),
+               "keypoints": len(kp), "matches_median": int(np.median(nm)), "ransac_inliers_median": int(np.median(nf)),
+               "answered_from": {k: ring.stats[k] - stats0[k] for k in ring.stats}}
+        if keyframes:
+            out["keyframe_frames"] = len(tk)
+            out["keyframe_extra_calls_ms"] = med(tk)
+            out["keyframe_matches_median"] = [int(v) for v in np.median(np.array(nk), axis=0)] if nk else None
+            out["mean_ms_per_frame"] = round(float(np.mean(tot)) * 1e3, 3)
+        return out
 
-    frame_loop = loop(None)
+    frame_loop = loop(False)
 
     sys.path.insert(0, str(ROOT / "tests"))
     import lg_inputs
-    ring = fu._ring_of(det)
-    chain = lg_inputs.make_pair(MAX_KPTS, seed=7)
-    feats = [(chain[0], chain[1]), (chain[2], chain[3])]          # frame parity -> (xy, desc): consecutive frames always form the matched pair
-
-    def plant(kps, des, idx):
-        xy, desc = feats[idx & 1]
-        e = ring.by_id[id(des)]
-        sl = e["slot"]
-        ring.ctx.h2d(sl["xy"], xy); ring.ctx.h2d(sl["desc"], desc)
-        ring.ctx.h2d(sl["cnt"], np.array([len(xy), 0, 0, 0], np.int32))
-        e["n"], e["xy"] = len(xy), xy
-        if ring.ahead is not None:                                   # (the look-ahead ran on the un-planted records)
-            ring.mctx.sync(); ring.ahead = None
-        ring.ahead_on = False
-        return ty.KeyPointList(ty.keypoints_from_xy(xy), xy)
-
-    planted = loop(plant)
+    planter = lg_inputs.PlantedExtractor(det, lg_inputs.make_chain(16, MAX_KPTS, seed=7))
+    try:
+        planted = loop(False)
+        planter.i = 0
+        slam = loop(True)
+    finally:
+        planter.restore()
     det.close(); mat.close()
     out = dict(planted)
     out["frame_loop"] = dict(frame_loop, what="real structured frames through all three calls; random-init networks match (almost) "
                              "nothing, so this is extract + match only (the prev -> cur match rides behind the extraction)")
+    out["slam_loop"] = dict(slam, what="main_revamped.py's call pattern with kf_cooldown 5 on the planted chain: every frame extract + "
+                            "prev -> cur + RANSAC, every 6th frame also keyframe -> cur + RANSAC twice (select_keyframe, then the "
+                            "triangulation's repeat of the same pair), the frame becoming the keyframe; value = timed frames / their "
+                            "summed time (median x 1 would hide the keyframe frames)")
     out["matches_last_pair"] = planted["matches_median"]
     out["what"] = ("sequential host API as main_revamped.py drives it, one frame at a time, host objects in and out: feature_extractor on "
-                   "1241x376 frames, then feature_matcher + filter_matches_ransac on the frame's device record overwritten with synthetic "
-                   "MATCHED features (2048 keypoints; the overwrite is not timed) so that RANSAC, DMatch construction and the read-back do "
-                   "real work; no look-ahead overlap in this loop (the records change after the extraction)")
+                   "1241x376 frames whose device record is overwritten, on the extractor's stream inside the timed call, with the next "
+                   "frame of a synthetic MATCHED chain (2048 keypoints) so that RANSAC, DMatch construction and the read-back do real "
+                   "work; then feature_matcher + filter_matches_ransac (threshold 2.5 px, the reference's default)")
     return out
 
 

@@ -33,9 +33,11 @@ class LightGlueHIP:
         self.max_kpts = int(max_kpts)
         self.conf = dict(self.default_conf)
         self.precision = 1
+        self.epoch = 0                   # bumped by every call that changes what a match returns (memoised results go stale)
         self.set_conf(**conf)
 
     def set_conf(self, **conf):
+        self.epoch += 1
         self.conf.update(conf)
         c = self.conf
         _native.check(_native.lib().sslam_lightglue_set_conf(
@@ -128,10 +130,12 @@ class LightGlueHIP:
         ranges + a merge for one pair) on the hand-scheduled assembly kernel; -4 = the same policy on the r02 4-wave
         kernel; 1 / 2 / 4 = that many ranges (4-wave kernel); 101 / 102 / 104 = that many (assembly kernel); no split at
         any size: -1 the 4-wave kernel, -3 the assembly kernel - for A/B and bit-identity checks."""
+        self.epoch += 1
         _native.check(_native.lib().sslam_lightglue_debug_key_split(self.handle, int(ks)))
 
     def debug_split_form(self, mask: int):
         """Precision-study hook (profiles/r04_split_study.md): drop cross terms of the split products; 0 = product."""
+        self.epoch += 1
         _native.check(_native.lib().sslam_lightglue_debug_split_form(self.handle, int(mask)))
 
     def debug_big_gemm(self, mode: int):
@@ -139,6 +143,7 @@ class LightGlueHIP:
         batched form (128 x 128 projections + the whole FFN as one kernel, its tile by token count), 2 / 3 the batched
         form with 64- / 32-token FFN tiles forced (bit-identical results), 5 the batched form with the token heads as a
         launch of their own (by default the cross block's fused FFN evaluates them on the state it writes)."""
+        self.epoch += 1
         _native.check(_native.lib().sslam_lightglue_debug_big_gemm(self.handle, int(mode)))
 
     def debug_read(self, which: int, shape, dtype=np.float32):
@@ -150,6 +155,7 @@ class LightGlueHIP:
         """'f32' / 0: exact-fp32 matrix-core path; 'f16x3' / 1 (default): fp16 hi/lo split path; 'f16x3p1' / 2 (opt-in): the
         split path with the softmax weights as ONE fp16 plane in P.V (-12 % attention time, same match indices on every parity
         case, token states 2.4e-5 from exact instead of 4e-6)."""
+        self.epoch += 1
         m = {"f32": 0, "f16x3": 1, "f16x3p1": 2}.get(mode, mode)
         _native.check(_native.lib().sslam_lightglue_set_precision(self.handle, int(m)))
         self.precision = int(m)
@@ -157,6 +163,7 @@ class LightGlueHIP:
     def debug_layers(self, layers: int, self_only: bool = False):
         """Test hook: stop the next matches after `layers` layers (after the self block of the last
         one when `self_only`), so `debug_read(0, ...)` returns that intermediate token state."""
+        self.epoch += 1
         _native.check(_native.lib().sslam_lightglue_debug_layers(self.handle, int(layers), int(bool(self_only))))
 
     def profile(self, enable: bool):

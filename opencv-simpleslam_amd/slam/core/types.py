@@ -256,3 +256,45 @@ class KeyPointList(list):
                 self._dirty = True
                 return None
         return self._xy
+
+
+class MatchList(list):
+    """The list `feature_matcher` returns on the device-resident path: an ordinary list of DMatch that also remembers the
+    int32 [K,2] (queryIdx, trainIdx) array it was built from and whether it has been edited since (every list mutator sets
+    `_dirty`), so that `filter_matches_ransac` may apply the inlier mask the device computed for exactly these pairs in
+    exactly this order.  A sorted / filtered / copied list is an ordinary or dirty list and is filtered from scratch.  (An
+    in-place edit of an ELEMENT - `m.queryIdx = ...` - cannot be seen by the list; eight elements are spot-checked.)"""
+    __slots__ = ("_ij", "_dirty")
+
+    def __init__(self, items=(), ij=None):
+        super().__init__(items)
+        self._ij = ij
+        self._dirty = ij is None
+
+    def _touch(self):
+        self._dirty = True
+
+    def __setitem__(self, i, v): self._touch(); super().__setitem__(i, v)
+    def __delitem__(self, i): self._touch(); super().__delitem__(i)
+    def __iadd__(self, o): self._touch(); return super().__iadd__(o)
+    def __imul__(self, o): self._touch(); return super().__imul__(o)
+    def append(self, v): self._touch(); super().append(v)
+    def extend(self, v): self._touch(); super().extend(v)
+    def insert(self, i, v): self._touch(); super().insert(i, v)
+    def pop(self, *a): self._touch(); return super().pop(*a)
+    def remove(self, v): self._touch(); super().remove(v)
+    def reverse(self): self._touch(); super().reverse()
+    def sort(self, **kw): self._touch(); super().sort(**kw)
+    def clear(self): self._touch(); super().clear()
+
+    def pristine_ij(self):
+        """The pair array this list was built from if it is provably still what the list holds, else None."""
+        if self._dirty or self._ij is None or len(self) != len(self._ij):
+            return None
+        n = len(self)
+        for i in range(0, n, max(1, n // 8)):              # spot check against in-place element edits
+            m = self[i]
+            if m.queryIdx != int(self._ij[i, 0]) or m.trainIdx != int(self._ij[i, 1]):
+                self._dirty = True
+                return None
+        return self._ij

@@ -22,3 +22,60 @@ def make_pair(m, n=None, seed=0, noise=0.05, drop=0.2):
     k1[:nd] = np.column_stack([rng.uniform(2, W_IMG - 3, nd), rng.uniform(2, H_IMG - 3, nd)])
     d1 /= np.linalg.norm(d1, axis=1, keepdims=True)
     return k0, d0, k1.astype(np.float32), d1.astype(np.float32)
+
+
+def make_chain(n_frames, m, seed=0, noise=0.05, drop=0.2, period=8):
+    """A frame sequence for the reference's frame-loop call pattern (prev -> cur on every frame, keyframe -> cur a few
+    frames apart): every frame is a shuffled, jittered, partly replaced view of ONE base set of keypoints, translated by
+    (3, 1) px per step of a `period`-frame cycle - so any two frames of the chain share true correspondences and are related
+    by a pure translation (one F-matrix model fits them all).  -> [(xy [m,2] f32, desc [m,128] f32 unit rows)] * n_frames"""
+    rng = np.random.default_rng(seed)
+    base_xy = np.column_stack([rng.uniform(2, W_IMG - 3 - 3 * period, m), rng.uniform(2, H_IMG - 3 - period, m)])
+    base_d = rng.standard_normal((m, 128))
+    base_d /= np.linalg.norm(base_d, axis=1, keepdims=True)
+    out = []
+    nd = int(drop * m)
+    for f in range(n_frames):
+        r = np.random.default_rng(1000 * (seed + 1) + f)
+        src = r.permutation(m)
+        xy = base_xy[src] + np.float64([3.0, 1.0]) * (f % period) + r.normal(0, 0.5, (m, 2))
+        d = base_d[src] + noise * r.standard_normal((m, 128))
+        d[:nd] = r.standard_normal((nd, 128))
+        xy[:nd] = np.column_stack([r.uniform(2, W_IMG - 3, nd), r.uniform(2, H_IMG - 3, nd)])
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        out.append((np.ascontiguousarray(xy, np.float32), np.ascontiguousarray(d, np.float32)))
+    return out
+
+
+class PlantedExtractor:
+    """Random-init ALIKED descriptors are all alike (pairwise cosine 0.9995), so nothing matches on extracted frames.  To give
+    the calls after `feature_extractor` real work, this wraps the detector's `extract_dev`: the extraction runs as always and,
+    right behind it ON THE SAME STREAM, the frame's device record {count, keypoints, descriptors} is overwritten with the next
+    set of a synthetic chain.  Everything downstream - the record read back into the caller's arrays, the look-ahead match the
+    extraction enqueues, the device-resident keyframe matches - then sees one consistent frame, with no white-box access to
+    the product's state.  `frames`: [(xy, desc)]; the sets are served round-robin (page-locked copies, asynchronous uploads)."""
+
+    def __init__(self, detector, frames):
+        self.det, self.ctx = detector, detector.ctx
+        self.real = detector.extract_dev
+        self.i = 0
+        self.sets = []
+        for xy, desc in frames:
+            n = len(xy)
+            blk = self.ctx.host_alloc(16 + n * 8 + n * 512)
+            blk[:16].view(np.int32)[:] = (n, 0, 0, 0)
+            blk[16:16 + n * 8].view(np.float32)[:] = xy.reshape(-1)
+            blk[16 + n * 8:].view(np.float32)[:] = desc.reshape(-1)
+            self.sets.append((n, blk))
+        detector.extract_dev = self
+
+    def __call__(self, img_dev, H, Wd, Cn, xy_out, desc_out, score_out, n_out, max_kpts=None):
+        self.real(img_dev, H, Wd, Cn, xy_out, desc_out, score_out, n_out, max_kpts=max_kpts)
+        n, blk = self.sets[self.i % len(self.sets)]
+        self.i += 1
+        self.ctx.h2d_async(n_out, blk[:16])
+        self.ctx.h2d_async(xy_out, blk[16:16 + n * 8])
+        self.ctx.h2d_async(desc_out, blk[16 + n * 8:])
+
+    def restore(self):
+        del self.det.extract_dev

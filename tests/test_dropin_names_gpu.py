@@ -153,12 +153,21 @@ def test_matcher_reads_the_extractor_device_records_when_it_can(fu, pipeline, mo
     m_ph = fu.feature_matcher(args, list(kp0), list(kp1), des0.copy(), des1.copy(), mat)
     assert pairs(m_p) == pairs(m_ph)
     kp1[0].pt = orig
-    # frames older than the ring (4 slots) fall back to the host path
-    for im in frames_[2:7]:
-        kpn, desn = fu.feature_extractor(args, im, det)
-    n_before = len(host_calls)
-    fu.feature_matcher(args, kp0, kpn, des0, desn, mat)
-    assert len(host_calls) == n_before + 1
+    # a frame held longer than the ring (8 slots, least recently used first) is uploaded again on its next use - the
+    # descriptor array is read-only, so the host copy is still the truth - and answered on the device like any other
+    held = [fu.feature_extractor(args, im, det) for im in (frames_[2:7] + frames_[2:7])]      # all kept alive: frame 0 falls out
+    ring = fu._ring_of(det)
+    assert ring.records[id(des0)].slot is None
+    n_before, up_before = len(host_calls), ring.stats["reupload"]
+    m_old = fu.feature_matcher(args, kp0, held[-1][0], des0, held[-1][1], mat)
+    assert len(host_calls) == n_before and ring.stats["reupload"] == up_before + 1 and ring.records[id(des0)].slot is not None
+    m_oldh = fu.feature_matcher(args, list(kp0), list(held[-1][0]), des0.copy(), held[-1][1].copy(), mat)
+    assert pairs(m_old) == pairs(m_oldh)
+    # a dropped descriptor array frees its frame at once (it can never be asked for again)
+    key = id(held[3][1])
+    assert key in ring.records
+    held[3] = None
+    assert key not in ring.records
 
 
 def test_legacy_pair_entry_normalises_by_the_image_size(fu, pipeline):
@@ -216,7 +225,7 @@ def test_look_ahead_match_of_the_frame_loop_gives_the_same_matches(fu, pipeline)
     kp[5], des[5] = fu.feature_extractor(args, fr[5], det)
     assert ring.ahead is not None
     m35 = pairs(fu.feature_matcher(args, kp[3], kp[5], des[3], des[5], mat))
-    assert ring.ahead is None and not ring.ahead_on                               # not the frame loop's pattern
+    assert ring.ahead is None and ring.kf is ring.records[id(des[3])]              # frame 3 is in the keyframe role now
     assert m35 == host(kp[3], kp[5], des[3], des[5])
     loose = SimpleNamespace(use_lightglue=True, min_conf=0.2)
     m45 = pairs(fu.feature_matcher(loose, kp[4], kp[5], des[4], des[5], mat))
@@ -241,43 +250,135 @@ def test_filter_matches_ransac_behind_the_match_equals_the_host_filter(fu, pipel
     device records of the extracted frames are overwritten with the synthetic matched features of the parity tests
     (white box: slot contents, entry["xy"], a KeyPointList built from the planted keypoints)."""
     import lg_inputs
-    types = load_pkg("slam.core.types")
     args, det, mat = pipeline
     ring = fu._ring_of(det)
     ring.ransac_thr = None
     pairs = lambda ms: [(m.queryIdx, m.trainIdx) for m in ms]
     host = lambda k0, k1, ms, thr: pairs(fu.filter_matches_ransac(list(k0), list(k1), list(ms), thr))   # plain lists: host path
     strict = SimpleNamespace(use_lightglue=True, min_conf=0.7)
-
-    def planted(img, xy, desc):
-        ring.ahead_on = False                                          # (a look-ahead would match the un-planted records)
-        kps, des = fu.feature_extractor(args, img, det)
-        e = ring.by_id[id(des)]
-        sl = e["slot"]
-        xy = np.ascontiguousarray(xy, np.float32)
-        ring.ctx.h2d(sl["xy"], xy); ring.ctx.h2d(sl["desc"], np.ascontiguousarray(desc, np.float32))
-        ring.ctx.h2d(sl["cnt"], np.array([len(xy), 0, 0, 0], np.int32))
-        e["n"], e["xy"] = len(xy), xy
-        return types.KeyPointList(types.keypoints_from_xy(xy), xy), des
-
     img = frames.structured_frame(40)
     fast = []
     for i in range(1, 6):
         k0, d0, k1, d1 = lg_inputs.make_pair(900, 860, seed=50 + i)
-        kp0, des0 = planted(img, k0, d0)
-        kp1, des1 = planted(img, k1, d1)
+        planter = lg_inputs.PlantedExtractor(det, [(k0, d0), (k1, d1)])
+        try:
+            kp0, des0 = fu.feature_extractor(args, img, det)
+            kp1, des1 = fu.feature_extractor(args, img, det)
+        finally:
+            planter.restore()
+        np.testing.assert_array_equal(des0, d0); np.testing.assert_array_equal(kp1._xy, k1)      # the planted frames came back
         m = fu.feature_matcher(strict, kp0, kp1, des0, des1, mat)
         assert len(m) >= 100                                           # the RANSAC branch with real work
         thr = 2.5 if i == 3 else 1.0
-        on_device = ring.filtered is not None and ring.filtered["thr"] == thr
+        on_device = ring.results[-1]["matches"] is m and ring.results[-1]["thr"] == thr
         fast.append(on_device)
         f = fu.filter_matches_ransac(kp0, kp1, m, thr)
         assert pairs(f) == host(kp0, kp1, m, thr), f"pair {i}"
         ids = {id(x) for x in m}
         assert all(id(x) in ids for x in f) and 0 < len(f) <= len(m)
+        if on_device:
+            # an edited match list must not get the mask of the list that was handed out (ADVICE r04): same answer as the
+            # host filter on the edited list
+            m2 = fu.feature_matcher(strict, kp0, kp1, des0, des1, mat)            # (the memo: a new list, same pairs)
+            assert m2 is not m and pairs(m2) == pairs(m)
+            m2.reverse()
+            assert pairs(fu.filter_matches_ransac(kp0, kp1, m2, thr)) == host(kp0, kp1, m2, thr)
     # call 1 teaches the threshold (host), 2 rides behind the match, 3 asks another threshold (host, teaches 2.5), 4 asks 1.0
     # again while 2.5 was enqueued (host), 5 rides again
     assert fast == [False, True, False, False, True], fast
+    ring.ransac_thr = None
+
+
+def test_few_matches_with_no_model_give_nothing_on_both_paths(fu, pipeline):
+    """8 - 14 matches take OpenCV's LMedS branch, and a best model with fewer than 7 inliers means `mask is None`
+    -> the reference returns [] (features_utils.py:196-198).  The device-side filter signals that as info[3] == -1; the
+    fast path must honour it like the host path does."""
+    import lg_inputs
+    args, det, mat = pipeline
+    ring = fu._ring_of(det)
+    pairs = lambda ms: [(m.queryIdx, m.trainIdx) for m in ms]
+    strict = SimpleNamespace(use_lightglue=True, min_conf=0.7)
+    img = frames.structured_frame(41)
+    ring.ransac_thr = 0.01                               # (as if the loop had already asked for this threshold)
+    seen = 0
+    for seed in range(12):
+        # ~10 true correspondences whose second view is scattered by tens of pixels: no epipolar model fits 7 of them at 0.01 px
+        k0, d0, k1, d1 = lg_inputs.make_pair(300, 300, seed=900 + seed, drop=0.965)
+        rng = np.random.default_rng(seed)
+        k1 = (k1 + rng.uniform(-40, 40, k1.shape)).astype(np.float32)
+        planter = lg_inputs.PlantedExtractor(det, [(k0, d0), (k1, d1)])
+        try:
+            kp0, des0 = fu.feature_extractor(args, img, det)
+            kp1, des1 = fu.feature_extractor(args, img, det)
+        finally:
+            planter.restore()
+        m = fu.feature_matcher(strict, kp0, kp1, des0, des1, mat)
+        if not 8 <= len(m) <= 14:
+            continue
+        seen += 1
+        assert ring.results[-1]["matches"] is m and ring.results[-1]["thr"] == 0.01
+        got = pairs(fu.filter_matches_ransac(kp0, kp1, m, 0.01))
+        want = pairs(fu.filter_matches_ransac(list(kp0), list(kp1), list(m), 0.01))
+        assert got == want
+    ring.ransac_thr = None
+    assert seen >= 1, "no pair with 8..14 matches among the seeds - retune the drop rate"
+
+
+def test_keyframe_pattern_of_the_frame_loop_stays_on_the_device(fu, pipeline, monkeypatch):
+    """the reference's loop is not one match per frame.  Beyond the cooldown `select_keyframe` matches
+    the KEYFRAME against the current frame (keyframe_utils.py:153-154), a promoted frame makes
+    `triangulate_between_kfs_2view` match THE SAME pair again (triangulation_utils.py:131-132), and every match is
+    filtered (main_revamped.py:118-126).  Replayed here with cooldown 5 over 13 frames (keyframes at 0, 6, 12): every call
+    is answered from the device-resident records - the keyframe is still resident six frames later, the duplicate pair
+    comes from the memo, the second keyframe match rides in the look-ahead's launch - with the matches and the kept
+    matches of the host path."""
+    import lg_inputs
+    args, det, mat = pipeline
+    ring = fu._ring_of(det)
+    ring.forget_patterns()
+    strict = SimpleNamespace(use_lightglue=True, min_conf=0.7)
+    pairs = lambda ms: [(m.queryIdx, m.trainIdx) for m in ms]
+    host_calls = []
+    real_match = mat.match
+    monkeypatch.setattr(mat, "match", lambda *a, **k: (host_calls.append(1), real_match(*a, **k))[1])
+    chain = lg_inputs.make_chain(13, 1500, seed=3)
+    img = frames.structured_frame(42)
+    stats0 = dict(ring.stats)
+    calls = []                                             # (kp0, kp1, des0, des1, raw pairs, kept pairs, what)
+
+    def match_and_filter(k0, k1, d0, d1, what):
+        raw = fu.feature_matcher(strict, k0, k1, d0, d1, mat)
+        kept = fu.filter_matches_ransac(k0, k1, raw, 2.5)
+        calls.append((k0, k1, d0, d1, pairs(raw), pairs(kept), what))
+        return raw
+
+    planter = lg_inputs.PlantedExtractor(det, chain)
+    try:
+        kp_prev, des_prev = fu.feature_extractor(args, img, det)
+        kf, last_kf = (kp_prev, des_prev), 0
+        for f in range(1, 13):
+            kp, des = fu.feature_extractor(args, img, det)
+            match_and_filter(kp_prev, kp, des_prev, des, "prev->cur")
+            if f - last_kf > 5:                            # (frame_no - last_kf_frame_no) > kf_cooldown
+                r1 = match_and_filter(kf[0], kp, kf[1], des, "kf->cur")
+                r2 = match_and_filter(kf[0], kp, kf[1], des, "kf->cur again")      # promoted: the triangulation's match
+                assert r2 is not r1 and pairs(r2) == pairs(r1)
+                kf, last_kf = (kp, des), f
+            kp_prev, des_prev = kp, des
+    finally:
+        planter.restore()
+    assert host_calls == []                                # nothing took the host path
+    d = {k: ring.stats[k] - stats0[k] for k in ring.stats}
+    assert d["reupload"] == 0                              # the keyframes were still resident six frames later
+    assert d["memo"] == 2                                  # both duplicate pairs
+    assert d["ahead_kf"] == 1                              # the second keyframe match was predicted (the learned gap)
+    assert d["ahead"] >= 10 and d["wasted"] == 0
+    assert sum(1 for c in calls if c[6] != "prev->cur") == 4
+    for k0, k1, d0, d1, raw, kept, what in calls:
+        ms = fu.feature_matcher(strict, list(k0), list(k1), d0.copy(), d1.copy(), mat)          # host path
+        assert pairs(ms) == raw and len(raw) >= 100, what
+        assert pairs(fu.filter_matches_ransac(list(k0), list(k1), ms, 2.5)) == kept, what
+    assert len(host_calls) == len(calls)
     ring.ransac_thr = None
 
 
