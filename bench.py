@@ -237,7 +237,7 @@ def dropin_leg(n_frames=48):
 
     sys.path.insert(0, str(ROOT / "tests"))
     import lg_inputs
-    planter = lg_inputs.PlantedExtractor(det, lg_inputs.make_chain(16, MAX_KPTS, seed=7))
+    planter = lg_inputs.PlantedExtractor(det, lg_inputs.make_chain(16, MAX_KPTS, seed=7, noise=0.035, drop=0.1))   # (two frames: the noise and 81 % co-visibility of the parity pairs)
     try:
         planted = loop(False)
         planter.i = 0

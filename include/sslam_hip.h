@@ -108,8 +108,9 @@ int sslam_ba_residual_jacobian_dev(sslam_ctx* ctx, int n_obs,
  * optimised poses; linearisation, reduction, Cholesky, step evaluation and the accept / reject /
  * terminate logic all run on the GPU as one enqueue (no host round trip per iteration).
  *   q[n_poses*4], t[n_poses*3], X[n_points*3] : in = initial values, out = optimised
- *   pose_const[n_poses] : 1 = held fixed.  At most 12 non-constant poses (more -> rc 2;
- *                         global BA keeps the host Schur loop around the residual kernel)
+ *   pose_const[n_poses] : 1 = held fixed.  At most 256 non-constant poses (more is refused with an error;
+ *                         up to 12 - local BA - the reduced pose system is factored in LDS, beyond that in
+ *                         device memory by one workgroup; the dense Schur blocks must fit 32 GiB)
  *   summary[8] : iterations, successful steps, initial cost, final cost (0.5 sum rho),
  *                termination (0 max iterations, 1 gradient, 2 parameter, 3 function tolerance,
  *                4 trust region collapsed), final radius, #optimised poses, 0 */
@@ -195,7 +196,7 @@ int sslam_aliked_destroy(sslam_aliked* al);
  * xy_out[2*max_kpts] (x, y) in input-image pixels, desc_out[128*max_kpts]
  * unit-norm rows, score_out[max_kpts] (may be NULL), n_out = keypoints found
  * (<= max_kpts; threshold mode, ordered as upstream: raster order, or by
- * descending score when more than max_kpts pass the detection threshold). */
+ * descending score when more than max_kpts pass the detection threshold; -1 on the _dev entries: range overflow, below). */
 int sslam_aliked_extract_host(sslam_aliked* al, const uint8_t* img, int H, int W, int C, int max_kpts,
                               float* xy_out, float* desc_out, float* score_out, int32_t* n_out);
 /* Device-pointer variant (all pointers device, n_out[1] device int32); enqueue only. */
@@ -210,6 +211,14 @@ int sslam_aliked_extract_dev(sslam_aliked* al, const uint8_t* img, int H, int W,
 int sslam_aliked_extract_batch_dev(sslam_aliked* al, int n_frames, const uint8_t* const* imgs, int H, int W, int C,
                                    int max_kpts, float* const* xy_out, float* const* desc_out,
                                    float* const* score_out, int32_t* const* n_out);
+/* RANGE.  The dense stages, the deformable layers and the descriptor head carry their operands as fp16 (hi, lo) plane pairs
+ * (the split-precision matrix path): a FINITE activation with |value| >= 65520 does not fit.  Such a value raises the frame's
+ * flag on the device; the frame's keypoint count n_out then reads -1 (sslam_lightglue_match_dev treats a negative count as an
+ * empty frame), sslam_aliked_extract_host fails with a message, and the instance keeps a sticky word that this call returns
+ * and clears (synchronises the stream) - for callers of the _dev / _batch_dev entries that do not read the counts.
+ * sslam_aliked_create refuses weights (BN scales folded) that do not fit.  No trained checkpoint comes near the limit; the
+ * guard exists so that a silent inf / NaN descriptor cannot happen. */
+int sslam_aliked_range_overflow(sslam_aliked* al, int* flag_out);
 /* Replay the launch sequence of sslam_aliked_extract_dev as a cached hipGraph (one graph per distinct
  * argument tuple; for callers that cycle through a fixed set of buffers).  Same results, ~10 us of
  * host time per call instead of ~45 launches. */
@@ -243,7 +252,8 @@ int sslam_lightglue_set_conf(sslam_lightglue* lg, float depth_confidence, float 
  * 2 (opt-in): as 1, but attention carries the softmax weights P as ONE fp16 plane in P.V (two MFMAs per product there, the
  * row sum over the rounded weights): -12 % attention time; match indices identical on every parity case, token states
  * 2.4e-5 from exact instead of 4e-6 (profiles/r04_split_study.md).
- * The final assignment (final_proj, similarity, dual softmax, arg-max) is fp32 in every mode. */
+ * final_proj and the similarity GEMM run on the same split-operand pipe in modes 1 and 2 (exact-fp32 instruction in
+ * mode 0); the dual softmax, the arg-max and the score arithmetic are fp32 in every mode. */
 int sslam_lightglue_set_precision(sslam_lightglue* lg, int mode);
 /* xy0[M*2], desc0[M*128], xy1[N*2], desc1[N*128] float32.
  * ij_out[2*min(M,N)] int32 (queryIdx, trainIdx) pairs, ascending queryIdx;

@@ -71,6 +71,7 @@ def _signatures():
         "sslam_aliked_extract_dev": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
         "sslam_aliked_debug_read": (i32, [vp, i32, vp, sz]),
         "sslam_aliked_use_graphs": (i32, [vp, i32]),
+        "sslam_aliked_range_overflow": (i32, [vp, c_int_p]),
         "sslam_lightglue_use_graphs": (i32, [vp, i32]),
         "sslam_lightglue_create": (i32, [vp, vp, sz, i32, c_void_pp]),
         "sslam_lightglue_create_batched": (i32, [vp, vp, sz, i32, i32, c_void_pp]),

@@ -88,6 +88,13 @@ class AlikedHIP:
         """Replay `extract_dev` as a cached hipGraph per distinct argument tuple (same results)."""
         _native.check(_native.lib().sslam_aliked_use_graphs(self.handle, int(bool(enable))))
 
+    def range_overflow(self) -> bool:
+        """True if, since the last call, a finite activation left the fp16 range of the split-precision stages in some frame
+        (that frame's count read -1, its features are void).  Synchronises; clears the flag."""
+        f = C.c_int(0)
+        _native.check(_native.lib().sslam_aliked_range_overflow(self.handle, C.byref(f)), "sslam_aliked_range_overflow")
+        return bool(f.value)
+
     def debug_read(self, which: int, shape, dtype=np.float32):
         out = np.empty(shape, dtype)
         _native.check(_native.lib().sslam_aliked_debug_read(self.handle, which, _native.ptr(out), out.nbytes))

@@ -105,6 +105,12 @@ def build_native(force: bool = False, verbose: bool = False) -> Path:
         raise RuntimeError(f"no .hip sources under {CSRC}")
 
     extra = os.environ.get("SSLAM_EXTRA_HIPCC_FLAGS", "").split()     # experiments only (e.g. -DSSLAM_DBG=1)
+    if extra and os.environ.get("SSLAM_EXPERIMENT_BUILD") != "1":
+        # the ablation switches in csrc/ (FFN_ABL, SSLAM_DBG_NOMFMA, AL_B2_ASM, AL_AGG_FAST_SELU ...) change ARITHMETIC: a flag
+        # variable left in the environment must not leak into a product build.  The A/B scripts under scripts/ say so.
+        raise RuntimeError(f"SSLAM_EXTRA_HIPCC_FLAGS={' '.join(extra)!r} is set but SSLAM_EXPERIMENT_BUILD is not 1: refusing to build "
+                           "the product library with experiment flags (unset the variable, or export SSLAM_EXPERIMENT_BUILD=1 "
+                           "for an A/B run under scripts/)")
     base_key = _digest(hipcc, *HIPCC_FLAGS, "|", *extra, *[h.read_bytes() for h in headers])
 
     def compile_one(src: Path):

@@ -53,7 +53,15 @@ __device__ __forceinline__ float selu(float x) {
 // streams share the GPU - g1, s8 and every other kernel's output stayed bit-stable over 1 200 frames
 // (scripts/stress_aliked_repeat.py, bisected over commits and call sites; not explained: the ISA of both variants reads
 // correctly, a wait state behind v_exp_f32 and other unroll factors change nothing).  With expm1f there: 0 differences.
-__device__ __forceinline__ float selu_precise(float x) { return SELU_SCALE * (x > 0.0f ? x : SELU_ALPHA * expm1f(x)); }
+#ifndef AL_AGG_FAST_SELU
+#define AL_AGG_FAST_SELU 0
+#endif
+// (AL_AGG_FAST_SELU, experiments only - scripts/ab_stress_aliked.sh: bit 0 = the hardware-exponential form in the kernel's channel
+//  loop, bit 1 = in its tail)
+template <int SITE> __device__ __forceinline__ float selu_precise(float x) {
+    if ((AL_AGG_FAST_SELU >> SITE) & 1) return selu(x);
+    return SELU_SCALE * (x > 0.0f ? x : SELU_ALPHA * expm1f(x));
+}
 constexpr int HBINS = 4096;        // score histogram bins (uniform in score, monotone)
 
 struct ALCtrl {
@@ -61,8 +69,24 @@ struct ALCtrl {
     int n_kp;         // keypoints emitted
     int overflow;     // candidate buffer overflow flag
     int found;        // the detection threshold found candidates (else the second collect launch thresholds on mean(score map))
-    int pad[12];
+    int range_overflow;   // a finite activation with |value| >= 65520 reached a split (fp16 hi/lo) operand: the frame's features are void
+    int pad[11];
 };
+
+// RANGE of the split-precision stages (gemm_f16x3.hpp): split2_fast / split8_fast do not saturate, they report the largest
+// magnitude they saw.  Every kernel that splits keeps that maximum per thread over its whole run (`amax` below) and raises the
+// frame's flag once at its end; al_finalize_kernel turns a raised flag into keypoint count -1 (and the instance's sticky word),
+// so the verdict travels with the result exactly as in the matcher (LGCtrl::range_overflow).
+__device__ __forceinline__ void al_range_note(float amax, ALCtrl* ctrl) {
+    if (amax >= 65520.0f && amax < INFINITY) ctrl->range_overflow = 1;
+}
+// a WEIGHT into its (hi, lo) planes, once at instance creation (BN scales already folded where the kernel folds them): a finite
+// |v| >= 65520 does not fit and raises the instance's flag - sslam_aliked_create refuses such weights, as the matcher does
+__device__ __forceinline__ void al_split_weight(float v, _Float16& hi, _Float16& lo, int* range_flag) {
+    if (fabsf(v) >= 65520.0f && fabsf(v) < INFINITY) *range_flag = 1;
+    hi = fabsf(v) < 6.103515625e-5f ? (_Float16)0.0f : (_Float16)v;
+    lo = (_Float16)((v - (float)hi) * sslam::SPLIT_SCALE);
+}
 
 struct Dims {
     int H, W, C;          // input image
@@ -177,14 +201,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //      A fragment copy is [k-step][plane (hi, lo)][lane][8 halves]: the 16 bytes a lane feeds one MFMA with.
 // ------------------------------------------------------------------------ //
 // block1.conv2 (16 -> 16): k = (tap, channel) in 5 steps of 32 = two taps x 16 channels (v_mfma_f32_16x16x32_f16)
-__global__ void al_conv16_wfrag_kernel(const float* __restrict__ w /*[ci 16][tap 9][co 16]*/, _Float16* __restrict__ wf) {
+__global__ void al_conv16_wfrag_kernel(const float* __restrict__ w /*[ci 16][tap 9][co 16]*/, _Float16* __restrict__ wf, int* range_flag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;       // (k-step, lane, e)
     if (i >= 5 * 64 * 8) return;
     const int e = i & 7, lane = (i >> 3) & 63, ks = i >> 9;
     const int kk = lane >> 4, co = lane & 15, tap = 2 * ks + (kk >> 1), ci = 8 * (kk & 1) + e;
     const float v = tap < 9 ? w[(ci * 9 + tap) * 16 + co] : 0.0f;
-    const _Float16 hi = fabsf(v) < 6.103515625e-5f ? (_Float16)0.0f : (_Float16)v;
-    const _Float16 lo = (_Float16)((v - (float)hi) * sslam::SPLIT_SCALE);
+    _Float16 hi, lo;
+    al_split_weight(v, hi, lo, range_flag);
     wf[((ks * 2 + 0) * 64 + lane) * 8 + e] = hi;
     wf[((ks * 2 + 1) * 64 + lane) * 8 + e] = lo;
 }
@@ -192,27 +216,27 @@ __global__ void al_conv16_wfrag_kernel(const float* __restrict__ w /*[ci 16][tap
 
 // block2.conv1 + the 1 x 1 downsample branch (16 -> 32): k-step = tap (16 channels), the tenth k-step = the 1 x 1 weights
 __global__ void al_conv32p_wfrag_kernel(const float* __restrict__ w /*[ci 16][tap 9][co 32]*/, const float* __restrict__ wd /*[ci 16][co 32]*/,
-                                        _Float16* __restrict__ wf) {
+                                        _Float16* __restrict__ wf, int* range_flag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;       // (k-step, lane, e)
     if (i >= 10 * 64 * 8) return;
     const int e = i & 7, lane = (i >> 3) & 63, ks = i >> 9;
     const int co = lane & 31, ci = 8 * (lane >> 5) + e;
     const float v = ks < 9 ? w[(ci * 9 + ks) * 32 + co] : wd[ci * 32 + co];
-    const _Float16 hi = fabsf(v) < 6.103515625e-5f ? (_Float16)0.0f : (_Float16)v;
-    const _Float16 lo = (_Float16)((v - (float)hi) * sslam::SPLIT_SCALE);
+    _Float16 hi, lo;
+    al_split_weight(v, hi, lo, range_flag);
     wf[((ks * 2 + 0) * 64 + lane) * 8 + e] = hi;
     wf[((ks * 2 + 1) * 64 + lane) * 8 + e] = lo;
 }
 
 
 // block2.conv2 (32 -> 32): k = tap x 32 + channel in 18 steps of 16
-__global__ void al_conv32_wfrag_kernel(const float* __restrict__ w /*[ci 32][tap 9][co 32]*/, _Float16* __restrict__ wf) {
+__global__ void al_conv32_wfrag_kernel(const float* __restrict__ w /*[ci 32][tap 9][co 32]*/, _Float16* __restrict__ wf, int* range_flag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;       // one element (co, k)
     if (i >= 32 * 288) return;
     const int co = i / 288, k = i % 288, tap = k / 32, ci = k % 32;
     const float v = w[(ci * 9 + tap) * 32 + co];
-    const _Float16 hi = fabsf(v) < 6.103515625e-5f ? (_Float16)0.0f : (_Float16)v;
-    const _Float16 lo = (_Float16)((v - (float)hi) * sslam::SPLIT_SCALE);
+    _Float16 hi, lo;
+    al_split_weight(v, hi, lo, range_flag);
     const int ks = k >> 4, hh = (k >> 3) & 1, e = k & 7;
     wf[(((ks * 2 + 0) * 2 + hh) * 32 + co) * 8 + e] = hi;
     wf[(((ks * 2 + 1) * 2 + hh) * 32 + co) * 8 + e] = lo;
@@ -248,7 +272,7 @@ constexpr size_t B2_LDS = (size_t)(B2_W1 + B2_W2 + 4 * B2_RING) * 2 + 5 * 32 * 4
 // builtin the compiler copies each fragment to an arch register first (257 v_accvgpr_read per step) and zeroes every chain's
 // accumulator with 16 moves; here the first MFMA of a chain takes the literal 0 as C.  An asm MFMA is opaque to the hazard
 // recogniser: nothing writes the A registers inside the loop, B fragments arrive by ds_read (waited for by register use), and
-// b2_mfma_done() pads the MFMA -> VALU read distance after the last MFMA of a chain.
+// b2_mfma_done(c1, c2) pads the MFMA -> VALU read distance after the last MFMA of a chain (as an in/out of both accumulators).
 #if AL_B2_ASM && AL_B2_WREG
 #define B2_AREG "a"
 #else
@@ -271,16 +295,19 @@ __device__ __forceinline__ void b2_mfma(f32x16& c, const sslam::half8& a_, const
     c = sslam::mfma16(a_, b_, c);
 #endif
 }
-__device__ __forceinline__ void b2_mfma_done() {
+__device__ __forceinline__ void b2_mfma_done(f32x16& c1, f32x16& c2) {
 #if AL_B2_ASM
-    asm volatile("s_nop 15\n\ts_nop 3");
+    // the 19 wait states between the last MFMA of a chain and the first vector read of its accumulators, TIED to the
+    // accumulators: every later read of c1 / c2 depends on this statement's outputs, so the compiler cannot schedule one
+    // between the (opaque) MFMA statements and the padding
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(c1), "+v"(c2));
 #endif
 }
 __global__ __launch_bounds__(256, 1) void al_block2_rows_kernel(const float* __restrict__ in /* x1 [16][2 H][2 W] */, float* __restrict__ out /* x2 [32][H][W] */,
                                                                int H, int W, int hs, int nblk, int strips, int n_waves,
                                                                const _Float16* __restrict__ wf1 /*[10][2][64][8]*/, const _Float16* __restrict__ wf2 /*[18][2][64][8]*/,
                                                                const float* __restrict__ a1, const float* __restrict__ b1, const float* __restrict__ bd,
-                                                               const float* __restrict__ a2, const float* __restrict__ b2, size_t fs) {
+                                                               const float* __restrict__ a2, const float* __restrict__ b2, ALCtrl* ctrl, size_t fs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char b2_lds[];
     _Float16* w1lo = reinterpret_cast<_Float16*>(b2_lds);
     _Float16* w2 = w1lo + B2_W1;
@@ -297,7 +324,8 @@ __global__ __launch_bounds__(256, 1) void al_block2_rows_kernel(const float* __r
     const int gw = blockIdx.x * 4 + wave;
     if (gw >= n_waves) return;                               // (no barrier below)
     const int strip = gw % strips, blk = (gw / strips) % nblk, f = gw / (strips * nblk);
-    in = fsh(in, f, fs); out = fsh(out, f, fs);
+    in = fsh(in, f, fs); out = fsh(out, f, fs); ctrl = fsh(ctrl, f, fs);
+    float amax = 0.0f;                                       // largest magnitude this thread split (al_range_note at the end)
     _Float16* P = w2 + B2_W2 + wave * B2_RING;               // [plane][slot][34][24]
     _Float16* T = P + 2 * B2_PLP;                            // [plane][slot][32][40]
     const int x0 = strip * B2_SW, yb = blk * hs, ye = min(yb + hs, H);
@@ -346,7 +374,7 @@ __global__ __launch_bounds__(256, 1) void al_block2_rows_kernel(const float* __r
             // 2 x 2 average summed in the order (0,0) (0,1) (1,0) (1,1)
             const float p0 = ok ? (((ra[j].x + ra[j].y) + rb[j].x) + rb[j].y) / 4.0f : 0.0f;
             const float p1 = ok ? (((ra[j].z + ra[j].w) + rb[j].z) + rb[j].w) / 4.0f : 0.0f;
-            unsigned h2, l2; float amax = 0.0f;
+            unsigned h2, l2;
             sslam::split2_fast(p0, p1, h2, l2, amax);
             const int o = slot * B2_ROWP + ipo[j];
             P[o] = __builtin_bit_cast(_Float16, (unsigned short)(h2 & 0xffffu));
@@ -380,7 +408,7 @@ __global__ __launch_bounds__(256, 1) void al_block2_rows_kernel(const float* __r
                 else { b2_mfma(c1, ah1[ks], xh); b2_mfma(c2, ah1[ks], xl); }
                 b2_mfma(c2, B2_A1LO(ks), xh);
             }
-            b2_mfma_done();
+            b2_mfma_done(c1, c2);
             const bool ok = tq_ok && y + 1 >= 0 && y + 1 < H;
             _Float16* trow = T + ((PH + 2) % 3) * B2_ROWT + px * B2_PXT + 4 * h;
 #pragma unroll
@@ -391,7 +419,7 @@ __global__ __launch_bounds__(256, 1) void al_block2_rows_kernel(const float* __r
                     const int r = 4 * g4 + e, co = acc_row(r, lane);
                     vv[e] = ok ? selu(fmaf(c1[r] + c2[r] * sslam::SPLIT_INV, aff[co], aff[32 + co])) : 0.0f;
                 }
-                unsigned h01, l01, h23, l23; float amax = 0.0f;
+                unsigned h01, l01, h23, l23;
                 sslam::split2_fast(vv[0], vv[1], h01, l01, amax);
                 sslam::split2_fast(vv[2], vv[3], h23, l23, amax);
                 *reinterpret_cast<uint2*>(trow + 8 * g4) = make_uint2(h01, h23);
@@ -408,7 +436,7 @@ __global__ __launch_bounds__(256, 1) void al_block2_rows_kernel(const float* __r
                 b2_mfma0(c1, ah1[9], xh);
                 b2_mfma0(c2, ah1[9], xl);
                 b2_mfma(c2, B2_A1LO(9), xh);
-                b2_mfma_done();
+                b2_mfma_done(c1, c2);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) idv[r] = (c1[r] + c2[r] * sslam::SPLIT_INV) + aff[64 + acc_row(r, lane)];
             }
@@ -421,7 +449,7 @@ __global__ __launch_bounds__(256, 1) void al_block2_rows_kernel(const float* __r
                 else { b2_mfma(c1, B2_A2(ks * 2 + 0), xh); b2_mfma(c2, B2_A2(ks * 2 + 0), xl); }
                 b2_mfma(c2, B2_A2(ks * 2 + 1), xh);
             }
-            b2_mfma_done();
+            b2_mfma_done(c1, c2);
             if (live) {
                 float* orow = out + (size_t)y * W + x0;
 #pragma unroll
@@ -444,6 +472,7 @@ __global__ __launch_bounds__(256, 1) void al_block2_rows_kernel(const float* __r
         if (y + 2 >= ye) break;
         step(std::integral_constant<int, 2>{}, y + 2);
     }
+    al_range_note(amax, ctrl);
 }
 
 // ------------------------------------------------------------------------ //
@@ -459,8 +488,9 @@ __global__ __launch_bounds__(64) void al_block1_rows_kernel(const float* __restr
                                                            int H, int W, int hs, const float* __restrict__ w1 /*[3][9][16]*/,
                                                            const float* __restrict__ a1, const float* __restrict__ b1,
                                                            const _Float16* __restrict__ wf2 /*[5][2][64][8]*/,
-                                                           const float* __restrict__ a2, const float* __restrict__ b2, size_t fs) {
-    in = fsh(in, blockIdx.z, fs); out = fsh(out, blockIdx.z, fs);
+                                                           const float* __restrict__ a2, const float* __restrict__ b2, ALCtrl* ctrl, size_t fs) {
+    in = fsh(in, blockIdx.z, fs); out = fsh(out, blockIdx.z, fs); ctrl = fsh(ctrl, blockIdx.z, fs);
+    float amax = 0.0f;                                                       // (al_range_note at the end)
     constexpr int RS = 48, SLOTI = 4 * RS;                                   // image ring: [slot][4 channels (one zero)][48 floats]
     constexpr int PXS = 24, ROWH = 34 * PXS, PLH = 3 * ROWH;                 // conv1-output ring (halves): [plane][slot][34 pixels][24]
     __shared__ __attribute__((aligned(16))) float iring[3 * SLOTI];
@@ -531,7 +561,7 @@ __global__ __launch_bounds__(64) void al_block1_rows_kernel(const float* __restr
                 float vv[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) vv[i] = ok ? selu(fmaf(acc[hf][i], alr1[i], ber1[i])) : 0.0f;
-                unsigned h01, l01, h23, l23; float amax = 0.0f;
+                unsigned h01, l01, h23, l23;
                 sslam::split2_fast(vv[0], vv[1], h01, l01, amax);
                 sslam::split2_fast(vv[2], vv[3], h23, l23, amax);
                 _Float16* tq = tring + ((PH + 2) % 3) * ROWH + q * PXS + 4 * kk;
@@ -576,6 +606,7 @@ __global__ __launch_bounds__(64) void al_block1_rows_kernel(const float* __restr
         if (y + 2 >= ye) break;
         step(std::integral_constant<int, 2>{}, y + 2);
     }
+    al_range_note(amax, ctrl);
 }
 
 // ------------------------------------------------------------------------ //
@@ -621,15 +652,15 @@ __global__ void al_avgpool_kernel(const float* __restrict__ in, float* __restric
 //      (weights) stream from a fragment-ordered split copy through L1.  Offsets move by ~1e-6 pixel (2^-22 relative).
 // ------------------------------------------------------------------------ //
 template <int CIN>
-__global__ void al_offc_wfrag_kernel(const float* __restrict__ ow /*[ci*9 + tap][18]*/, _Float16* __restrict__ wf) {
+__global__ void al_offc_wfrag_kernel(const float* __restrict__ ow /*[ci*9 + tap][18]*/, _Float16* __restrict__ wf, int* range_flag) {
     constexpr int KS = 9 * CIN / 16;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;       // (k-step, lane, e)
     if (i >= KS * 64 * 8) return;
     const int e = i & 7, lane = (i >> 3) & 63, ks = i >> 9;
     const int co = lane & 31, tap = ks / (CIN / 16), ci = 16 * (ks % (CIN / 16)) + 8 * (lane >> 5) + e;
     const float v = co < 18 ? ow[(ci * 9 + tap) * 18 + co] : 0.0f;
-    const _Float16 hi = fabsf(v) < 6.103515625e-5f ? (_Float16)0.0f : (_Float16)v;
-    const _Float16 lo = (_Float16)((v - (float)hi) * sslam::SPLIT_SCALE);
+    _Float16 hi, lo;
+    al_split_weight(v, hi, lo, range_flag);
     wf[((ks * 2 + 0) * 64 + lane) * 8 + e] = hi;
     wf[((ks * 2 + 1) * 64 + lane) * 8 + e] = lo;
 }
@@ -637,11 +668,12 @@ __global__ void al_offc_wfrag_kernel(const float* __restrict__ ow /*[ci*9 + tap]
 template <int CIN>
 __global__ __launch_bounds__(256) void al_offset_conv_h_kernel(const float* __restrict__ in /* channel-last [H W][CIN] */, float* __restrict__ off /*[18][H W]*/,
                                                               int H, int W, const _Float16* __restrict__ wf, const float* __restrict__ b,
-                                                              float max_off, size_t fs) {
+                                                              float max_off, ALCtrl* ctrl, size_t fs) {
     // four waves per output tile (32 pixels of one row x 18 channels): they fill the tile together and split the k-steps
     // (wave w takes k-steps w, w + 4, ...); the partial sums meet in LDS in wave order.  The maps are small (40 x 128 and
     // 10 x 32 pixels): with one wave per tile the 1/32 levels were 80 waves of 216 serial MFMAs.
-    in = fsh(in, blockIdx.z, fs); off = fsh(off, blockIdx.z, fs);
+    in = fsh(in, blockIdx.z, fs); off = fsh(off, blockIdx.z, fs); ctrl = fsh(ctrl, blockIdx.z, fs);
+    float amax = 0.0f;                                        // (al_range_note below)
     constexpr int CP = CIN + 8, ROWH = 34 * CP, PLH = 3 * ROWH, C8 = CIN / 8, NFR = 3 * 34 * C8, KSC = CIN / 16, KS = 9 * KSC;
     constexpr int TILEH = 2 * PLH > 4 * 16 * 64 * 2 ? 2 * PLH : 4 * 16 * 64 * 2;      // (the partial sums reuse the tile: 4 x 16 x 64 floats)
     __shared__ __attribute__((aligned(16))) _Float16 tile[TILEH];
@@ -666,13 +698,14 @@ __global__ __launch_bounds__(256) void al_offset_conv_h_kernel(const float* __re
             const int yy = y + row - 1, xx = x0 + q - 1;
             const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
             const float v[8] = {va[j].x, va[j].y, va[j].z, va[j].w, vb[j].x, vb[j].y, vb[j].z, vb[j].w};
-            uint4 hi, lo; float amax = 0.0f;
+            uint4 hi, lo;
             sslam::split8_fast(v, hi, lo, amax);
             if (!ok) { hi = make_uint4(0u, 0u, 0u, 0u); lo = hi; }
             *reinterpret_cast<uint4*>(&tile[row * ROWH + q * CP + 8 * c8]) = hi;
             *reinterpret_cast<uint4*>(&tile[PLH + row * ROWH + q * CP + 8 * c8]) = lo;
         }
     }
+    al_range_note(amax, ctrl);
     __syncthreads();
     f32x16 c1, c2;
 #pragma unroll
@@ -724,7 +757,7 @@ __global__ __launch_bounds__(256) void al_offset_conv_h_kernel(const float* __re
 // ------------------------------------------------------------------------ //
 template <int CIN, int COUT, int RC>
 __global__ void al_dcn_wfrag_kernel(const float* __restrict__ w /*[ci][tap][co]*/, const float* __restrict__ alpha,
-                                    const float* __restrict__ wd /*[ci RC][co]*/, _Float16* __restrict__ wf) {
+                                    const float* __restrict__ wd /*[ci RC][co]*/, _Float16* __restrict__ wf, int* range_flag) {
     constexpr int KSC = CIN / 16, MT = COUT / 32, KSR = RC / 16, NF = (9 * KSC + KSR) * MT;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;       // (fragment, lane, e)
     if (i >= NF * 512) return;
@@ -734,8 +767,8 @@ __global__ void al_dcn_wfrag_kernel(const float* __restrict__ w /*[ci][tap][co]*
     float v;
     if (ksg < 9 * KSC) { const int tap = ksg / KSC, ci = 16 * (ksg % KSC) + 8 * (lane >> 5) + e; v = alpha[co] * w[(ci * 9 + tap) * COUT + co]; }
     else { const int ci = 16 * (ksg - 9 * KSC) + 8 * (lane >> 5) + e; v = wd[ci * COUT + co]; }
-    const _Float16 hi = fabsf(v) < 6.103515625e-5f ? (_Float16)0.0f : (_Float16)v;
-    const _Float16 lo = (_Float16)((v - (float)hi) * sslam::SPLIT_SCALE);
+    _Float16 hi, lo;
+    al_split_weight(v, hi, lo, range_flag);
     wf[((size_t)fr * 2 + 0) * 512 + lane * 8 + e] = hi;
     wf[((size_t)fr * 2 + 1) * 512 + lane * 8 + e] = lo;
 }
@@ -744,9 +777,11 @@ template <int CIN, int COUT, int RC, int CS = 1>      // CS: workgroups per pixe
 __global__ __launch_bounds__(256) void al_dcn_h_kernel(const float* __restrict__ in /* channel-last [H W][CIN] */, const float* __restrict__ off /*[18][H W]*/,
                                                       const float* __restrict__ res_in /* channel-last [H W][RC] */, int H, int W,
                                                       const _Float16* __restrict__ wf, const float* __restrict__ beta, const float* __restrict__ bd,
-                                                      float* __restrict__ out /*[COUT][H W]*/, float* __restrict__ out_cl /*[H W][COUT] or null*/, size_t fs) {
+                                                      float* __restrict__ out /*[COUT][H W]*/, float* __restrict__ out_cl /*[H W][COUT] or null*/,
+                                                      ALCtrl* ctrl, size_t fs) {
     in = fsh(in, blockIdx.z, fs); off = fsh(off, blockIdx.z, fs); res_in = fsh(res_in, blockIdx.z, fs);
-    out = fsh(out, blockIdx.z, fs); out_cl = fsh0(out_cl, blockIdx.z, fs);
+    out = fsh(out, blockIdx.z, fs); out_cl = fsh0(out_cl, blockIdx.z, fs); ctrl = fsh(ctrl, blockIdx.z, fs);
+    float amax = 0.0f;                                        // (al_range_note below)
     constexpr int CP = CIN + 8, KSC = CIN / 16, MTA = COUT / 32, MT = MTA / CS, KSR = RC / 16, C8 = CIN / 8, PLH = 32 * CP;      // MTA: 32-channel tiles of the layer, MT: of this workgroup
     constexpr int BUFH = 2 * PLH;                                              // one wave's tap buffer (halves): [plane][32 px][CP]
     constexpr int REDF = 4 * MT * 16 * 64;                                     // reduction floats
@@ -822,7 +857,7 @@ __global__ __launch_bounds__(256) void al_dcn_h_kernel(const float* __restrict__
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = w1 * v1[e] + w2 * v2[e] + w3 * v3[e] + w4 * v4[e];
                 }
-                uint4 hi, lo; float amax = 0.0f;
+                uint4 hi, lo;
                 sslam::split8_fast(o, hi, lo, amax);
                 *reinterpret_cast<uint4*>(&buf[pq[g2] * CP + cq[g2]]) = hi;
                 *reinterpret_cast<uint4*>(&buf[PLH + pq[g2] * CP + cq[g2]]) = lo;
@@ -845,6 +880,7 @@ __global__ __launch_bounds__(256) void al_dcn_h_kernel(const float* __restrict__
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");            // the reads above, before the next slot overwrites the buffer
     }
+    al_range_note(amax, ctrl);
     __syncthreads();                                          // every wave is done with its buffer: the memory becomes the reduction buffer
     float* red = reinterpret_cast<float*>(lds);              // [wave][tile][r][lane]
 #pragma unroll
@@ -1068,7 +1104,7 @@ __global__ __launch_bounds__(256) void al_aggregate_kernel(Pyr P0, const float* 
         float a = 0.0f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) a = fmaf(xv[k], P.w1[k * 32 + c], a);
-        a = selu_precise(a);
+        a = selu_precise<0>(a);
         g1s[threadIdx.x * 33 + c] = a;     // the descriptor head gathers this instead of redoing the 16x32 product
         n2 = fmaf(a, a, n2);
 #pragma unroll
@@ -1081,7 +1117,7 @@ __global__ __launch_bounds__(256) void al_aggregate_kernel(Pyr P0, const float* 
     agg_level(P.pre4, (int)(HW / 1024), t4, s, n2);
     if (live) {
 #pragma unroll
-        for (int o = 0; o < 8; ++o) s8[o * HW + pix] = selu_precise(s[o]);
+        for (int o = 0; o < 8; ++o) s8[o * HW + pix] = selu_precise<1>(s[o]);
         rnorm[pix] = 1.0f / fmaxf(sqrtf(n2), 1e-12f);            // F.normalize eps
     }
     __syncthreads();
@@ -1727,7 +1763,7 @@ __global__ void al_offsets_kernel(const float* __restrict__ h32 /*[KSPLIT][cap][
 __global__ __launch_bounds__(256) void al_sample_kernel(Pyr P0, const float* __restrict__ rnorm, int pl, int pt,
                                                         int h, int w, const float* __restrict__ pos,
                                                         _Float16* __restrict__ sampled /* hi plane [rows][128]; lo plane `lo_off` halves behind */,
-                                                        size_t lo_off, const ALCtrl* __restrict__ ctrl, size_t fs) {
+                                                        size_t lo_off, ALCtrl* ctrl, size_t fs) {
     const Pyr P = pyr_at(P0, blockIdx.y, fs);
     rnorm = fsh(rnorm, blockIdx.y, fs); pos = fsh(pos, blockIdx.y, fs); sampled = fsh(sampled, blockIdx.y, fs); ctrl = fsh(ctrl, blockIdx.y, fs);
     const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (a scalar)
@@ -1800,6 +1836,7 @@ __global__ __launch_bounds__(256) void al_sample_kernel(Pyr P0, const float* __r
     // (same bytes as the fp32 row they replace)
     unsigned h2, l2; float amax = 0.0f;
     sslam::split2_fast(ax, bx, h2, l2, amax);
+    al_range_note(amax, ctrl);
     const _Float16 hv[2] = {__builtin_bit_cast(sslam::half2v, h2)[0], __builtin_bit_cast(sslam::half2v, h2)[1]};
     const _Float16 lv[2] = {__builtin_bit_cast(sslam::half2v, l2)[0], __builtin_bit_cast(sslam::half2v, l2)[1]};
     sampled[(size_t)gw * 128 + ca] = hv[0]; sampled[(size_t)gw * 128 + cb] = hv[1];
@@ -1852,7 +1889,7 @@ template <int BM, int BN, int TM, int TN, bool SPLIT_OUT>
 __global__ __launch_bounds__(256) void al_gemm_h_kernel(const _Float16* __restrict__ A, size_t a_lo, int K,
                                                         const _Float16* __restrict__ W, size_t w_lo, int N,
                                                         float* __restrict__ C, _Float16* __restrict__ Ch, size_t c_lo,
-                                                        int rows_per_kp, int row_cap, const ALCtrl* __restrict__ ctrl, int KS,
+                                                        int rows_per_kp, int row_cap, ALCtrl* ctrl, int KS,
                                                         size_t fs) {
     __shared__ sslam::GemmSmemH<BM, BN> sm;
     const int zs = blockIdx.z % KS, fr = blockIdx.z / KS;
@@ -1866,6 +1903,7 @@ __global__ __launch_bounds__(256) void al_gemm_h_kernel(const _Float16* __restri
     sslam::gemm_mainloop_h<BM, BN, TM, TN>(ga, sslam::SplitPtr{W + koff, W + w_lo + koff}, K, kper, row0, row_cap, col0, N, sm, c1, c2);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
     if constexpr (!SPLIT_OUT) C += (size_t)zs * row_cap * N;
+    float amax = 0.0f;                                        // (SPLIT_OUT: al_range_note at the end)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1879,7 +1917,8 @@ __global__ __launch_bounds__(256) void al_gemm_h_kernel(const _Float16* __restri
                 if constexpr (SPLIT_OUT) {
                     v = selu(v);
                     const float aa = fabsf(v);
-                    const _Float16 hi = aa < 6.103515625e-5f ? (_Float16)0.0f : (_Float16)v;      // (as sslam::split_f32; |v| is O(1) here)
+                    amax = fmaxf(amax, aa);
+                    const _Float16 hi = aa < 6.103515625e-5f ? (_Float16)0.0f : (_Float16)v;      // (as sslam::split_f32)
                     Ch[(size_t)row * N + col] = hi;
                     Ch[c_lo + (size_t)row * N + col] = (_Float16)((v - (float)hi) * sslam::SPLIT_SCALE);
                 } else {
@@ -1887,16 +1926,17 @@ __global__ __launch_bounds__(256) void al_gemm_h_kernel(const _Float16* __restri
                 }
             }
         }
+    if constexpr (SPLIT_OUT) al_range_note(amax, ctrl);
 }
 
 // fp32 [n] -> (hi, lo) planes (weights of the split GEMMs, once at create time)
-__global__ void al_split_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, size_t n) {
+__global__ void al_split_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, size_t n, int* range_flag) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float v = src[i];
-    const _Float16 hi = fabsf(v) < 6.103515625e-5f ? (_Float16)0.0f : (_Float16)v;
+    _Float16 hi, lo;
+    al_split_weight(src[i], hi, lo, range_flag);
     dst[i] = hi;
-    dst[n + i] = (_Float16)((v - (float)hi) * sslam::SPLIT_SCALE);
+    dst[n + i] = lo;
 }
 
 // L2 normalise (F.normalize), the reference's second normalisation (features_utils.py:100),
@@ -1905,13 +1945,18 @@ __global__ __launch_bounds__(256) void al_finalize_kernel(const float* __restric
                                                           const float* __restrict__ kp_norm,
                                                           const float* __restrict__ kp_score, int h, int w, float scale_x,
                                                           float scale_y, FrameOut outs, const ALCtrl* __restrict__ ctrl,
-                                                          size_t fs) {
+                                                          int* range_sticky, size_t fs) {
     raw = fsh(raw, blockIdx.y, fs); kp_norm = fsh(kp_norm, blockIdx.y, fs); kp_score = fsh(kp_score, blockIdx.y, fs);
     ctrl = fsh(ctrl, blockIdx.y, fs);
     float* __restrict__ xy_out = outs.xy[blockIdx.y]; float* __restrict__ desc_out = outs.desc[blockIdx.y];
     float* __restrict__ score_out = outs.score[blockIdx.y]; int32_t* __restrict__ n_out = outs.n[blockIdx.y];
     const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (blockIdx.x == 0 && threadIdx.x == 0) n_out[0] = ctrl->n_kp;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // a raised range flag voids the frame: count -1 travels with the result (and the instance's sticky word is set for
+        // callers that never look at the count); the keypoints below are still written, nobody may use them
+        n_out[0] = ctrl->range_overflow ? -1 : ctrl->n_kp;
+        if (ctrl->range_overflow) *range_sticky = 1;
+    }
     if (n >= ctrl->n_kp) return;
     float a = 0.0f, b = 0.0f;
     for (int z = 0; z < SDDH_KSPLIT; ++z) {
@@ -1972,6 +2017,7 @@ struct sslam_aliked {
     unsigned* hist;
     int cand_cap;
     int* kp_index;
+    int* range_sticky;                 // device word (shared by the frames of a batch): a frame of some call raised its range flag since the last read
     unsigned long long* sel_keys;      // the selected keys, unordered (al_select -> al_refine)
     float *kp_norm, *kp_score, *patch, *h32, *pos, *sampled, *feats, *raw;
     _Float16 *d_sf_s, *d_agg_s;          // split (hi | lo) copies of the two large descriptor-head weight matrices
@@ -2069,7 +2115,7 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
         const int nblk = std::max(1, std::min(sslam::cdiv(Hp, 4), 3072 / std::max(1, strips * F)));
         const int hs1 = sslam::cdiv(Hp, nblk);
         hipLaunchKernelGGL(al_block1_rows_kernel, dim3(strips, sslam::cdiv(Hp, hs1), uF), dim3(64), 0, s, g->img, g->x1, Hp, Wp, hs1,
-                           g->b1c1.w, g->b1c1.a, g->b1c1.b, g->b1c2f, g->b1c2.a, g->b1c2.b, fs);
+                           g->b1c1.w, g->b1c1.a, g->b1c1.b, g->b1c2f, g->b1c2.a, g->b1c2.b, g->ctrl, fs);
     }
     // block2 at 1/2 (pooling + conv1 + 1 x 1 branch + conv2 + residual fused): one wave per SIMD when the batch allows; at least
     // three rows per wave (two extra t2 rows per block).  (A frame's values do not depend on these splits: no sum is re-associated.)
@@ -2079,7 +2125,7 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
         const int nblk = std::max(1, std::min(sslam::cdiv(H2, 3), 1024 / std::max(1, strips * F)));
         const int hs2 = sslam::cdiv(H2, nblk), nb = sslam::cdiv(H2, hs2), n_waves = strips * nb * F;
         hipLaunchKernelGGL(al_block2_rows_kernel, dim3(sslam::cdiv(n_waves, 4)), dim3(256), B2_LDS, s, g->x1, g->x2, H2, W2, hs2, nb, strips, n_waves,
-                           g->b2c1f, g->b2c2f, g->b2c1.a, g->b2c1.b, g->b2db, g->b2c2.a, g->b2c2.b, fs);
+                           g->b2c1f, g->b2c2f, g->b2c1.a, g->b2c1.b, g->b2db, g->b2c2.a, g->b2c2.b, g->ctrl, fs);
     }
 #ifndef AL_DCN4_CS
 #define AL_DCN4_CS 4      // workgroups per pixel tile of the 1/32 deformable layers (output channels split: 10 tiles per frame there)
@@ -2092,20 +2138,20 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
     const dim3 g3(sslam::cdiv(W3, 32), H3, uF);
     hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(32 * HW3, 256), uF), dim3(256), 0, s, g->x2, g->p3, 32, H2, W2, 4, fs, g->p3cl);
     const float mo3 = (float)(H3 > W3 ? H3 : W3) / 4.0f;
-    hipLaunchKernelGGL((al_offset_conv_h_kernel<32>), g3, dim3(256), 0, s, g->p3cl, g->off, H3, W3, g->b3c1of, g->b3c1.ob, mo3, fs);
-    hipLaunchKernelGGL((al_dcn_h_kernel<32, 64, 0, AL_DCN3_CS>), dim3(AL_DCN3_CS * sslam::cdiv(W3, 32), H3, uF), dim3(256), 0, s, g->p3cl, g->off, nullptr, H3, W3, g->b3c1f, g->b3c1.b, nullptr, g->t3, g->t3cl, fs);
-    hipLaunchKernelGGL((al_offset_conv_h_kernel<64>), g3, dim3(256), 0, s, g->t3cl, g->off, H3, W3, g->b3c2of, g->b3c2.ob, mo3, fs);
-    hipLaunchKernelGGL((al_dcn_h_kernel<64, 64, 32, AL_DCN3_CS>), dim3(AL_DCN3_CS * sslam::cdiv(W3, 32), H3, uF), dim3(256), 0, s, g->t3cl, g->off, g->p3cl, H3, W3, g->b3c2f, g->b3c2.b, g->b3db, g->x3, nullptr, fs);
+    hipLaunchKernelGGL((al_offset_conv_h_kernel<32>), g3, dim3(256), 0, s, g->p3cl, g->off, H3, W3, g->b3c1of, g->b3c1.ob, mo3, g->ctrl, fs);
+    hipLaunchKernelGGL((al_dcn_h_kernel<32, 64, 0, AL_DCN3_CS>), dim3(AL_DCN3_CS * sslam::cdiv(W3, 32), H3, uF), dim3(256), 0, s, g->p3cl, g->off, nullptr, H3, W3, g->b3c1f, g->b3c1.b, nullptr, g->t3, g->t3cl, g->ctrl, fs);
+    hipLaunchKernelGGL((al_offset_conv_h_kernel<64>), g3, dim3(256), 0, s, g->t3cl, g->off, H3, W3, g->b3c2of, g->b3c2.ob, mo3, g->ctrl, fs);
+    hipLaunchKernelGGL((al_dcn_h_kernel<64, 64, 32, AL_DCN3_CS>), dim3(AL_DCN3_CS * sslam::cdiv(W3, 32), H3, uF), dim3(256), 0, s, g->t3cl, g->off, g->p3cl, H3, W3, g->b3c2f, g->b3c2.b, g->b3db, g->x3, nullptr, g->ctrl, fs);
     // block4 at 1/32
     const int H4 = Hp / 32, W4 = Wp / 32, HW4 = H4 * W4;
     const dim3 g4(sslam::cdiv(W4, 32), H4, uF);
     hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(64 * HW4, 256), uF), dim3(256), 0, s, g->x3, g->p4, 64, H3, W3, 4, fs, g->p4cl);
     const float mo4 = (float)(H4 > W4 ? H4 : W4) / 4.0f;
-    hipLaunchKernelGGL((al_offset_conv_h_kernel<64>), g4, dim3(256), 0, s, g->p4cl, g->off, H4, W4, g->b4c1of, g->b4c1.ob, mo4, fs);
+    hipLaunchKernelGGL((al_offset_conv_h_kernel<64>), g4, dim3(256), 0, s, g->p4cl, g->off, H4, W4, g->b4c1of, g->b4c1.ob, mo4, g->ctrl, fs);
     const dim3 g4s(AL_DCN4_CS * sslam::cdiv(W4, 32), H4, uF);  // AL_DCN4_CS workgroups per tile, 128 / AL_DCN4_CS output channels each
-    hipLaunchKernelGGL((al_dcn_h_kernel<64, 128, 0, AL_DCN4_CS>), g4s, dim3(256), 0, s, g->p4cl, g->off, nullptr, H4, W4, g->b4c1f, g->b4c1.b, nullptr, g->t4, g->t4cl, fs);
-    hipLaunchKernelGGL((al_offset_conv_h_kernel<128>), g4, dim3(256), 0, s, g->t4cl, g->off, H4, W4, g->b4c2of, g->b4c2.ob, mo4, fs);
-    hipLaunchKernelGGL((al_dcn_h_kernel<128, 128, 64, AL_DCN4_CS>), g4s, dim3(256), 0, s, g->t4cl, g->off, g->p4cl, H4, W4, g->b4c2f, g->b4c2.b, g->b4db, g->x4, nullptr, fs);
+    hipLaunchKernelGGL((al_dcn_h_kernel<64, 128, 0, AL_DCN4_CS>), g4s, dim3(256), 0, s, g->p4cl, g->off, nullptr, H4, W4, g->b4c1f, g->b4c1.b, nullptr, g->t4, g->t4cl, g->ctrl, fs);
+    hipLaunchKernelGGL((al_offset_conv_h_kernel<128>), g4, dim3(256), 0, s, g->t4cl, g->off, H4, W4, g->b4c2of, g->b4c2.ob, mo4, g->ctrl, fs);
+    hipLaunchKernelGGL((al_dcn_h_kernel<128, 128, 64, AL_DCN4_CS>), g4s, dim3(256), 0, s, g->t4cl, g->off, g->p4cl, H4, W4, g->b4c2f, g->b4c2.b, g->b4db, g->x4, nullptr, g->ctrl, fs);
     // gates
     hipLaunchKernelGGL(al_gate_kernel<32>, dim3(sslam::cdiv(H2 * W2, 256), uF), dim3(256), 0, s, g->x2, g->g2, H2 * W2, g->gw2, g->g2cl, fs);
     hipLaunchKernelGGL(al_gate_small_kernel, dim3(sslam::cdiv(32 * HW3, 256), uF), dim3(256), 0, s, g->x3, g->g3, 64, HW3, g->gw3, g->g3cl, fs);
@@ -2161,7 +2207,7 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
                            plane, 2048, g->d_agg_s, (size_t)128 * 2048, 128, g->raw, nullptr, 0, 1, NK, g->ctrl, SDDH_KSPLIT, fs);
     const float scale_x = (float)d.w / (float)W, scale_y = (float)d.h / (float)H;
     hipLaunchKernelGGL(al_finalize_kernel, dim3(sslam::cdiv(NK, 4), uF), dim3(256), 0, s, g->raw, NK, g->kp_norm, g->kp_score,
-                       d.h, d.w, scale_x, scale_y, outs, g->ctrl, fs);
+                       d.h, d.w, scale_x, scale_y, outs, g->ctrl, g->range_sticky, fs);
     SSLAM_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -2205,6 +2251,7 @@ int sslam_aliked_create_batched(sslam_ctx* ctx, const float* weights, size_t n_f
         g->b4c1f = A.take<_Float16>((size_t)(9 * 4 + 0) * 4 * 2 * 512); g->b4c2f = A.take<_Float16>((size_t)(9 * 8 + 4) * 4 * 2 * 512);
         g->b3c1of = A.take<_Float16>(18 * 2 * 512); g->b3c2of = A.take<_Float16>(36 * 2 * 512); g->b4c1of = A.take<_Float16>(36 * 2 * 512); g->b4c2of = A.take<_Float16>(72 * 2 * 512);
         g->gk = A.take<float>(64);
+        g->range_sticky = A.take<int>(4);
     };
     // one workspace block per frame of a batch (frame f's copy of a buffer = frame 0's + f * g->fs bytes)
     auto carve_frame = [&](sslam::Arena& A) {
@@ -2250,20 +2297,28 @@ int sslam_aliked_create_batched(sslam_ctx* ctx, const float* weights, size_t n_f
     if (int rc = al_bind_weights(g, n_floats)) { g->arena.release(); delete g; return rc; }
     {   // split-precision weight fragments of the matrix-core kernels (once)
         hipStream_t s = ctx->stream;
-        hipLaunchKernelGGL(al_conv32_wfrag_kernel, dim3(sslam::cdiv(32 * 288, 256)), dim3(256), 0, s, g->b2c2.w, g->b2c2f);
-        hipLaunchKernelGGL(al_conv16_wfrag_kernel, dim3(sslam::cdiv(5 * 64 * 8, 256)), dim3(256), 0, s, g->b1c2.w, g->b1c2f);
-        hipLaunchKernelGGL(al_conv32p_wfrag_kernel, dim3(sslam::cdiv(10 * 64 * 8, 256)), dim3(256), 0, s, g->b2c1.w, g->b2dw, g->b2c1f);
-        hipLaunchKernelGGL(al_split_kernel, dim3(sslam::cdiv(128 * 128, 256)), dim3(256), 0, s, g->d_sf, g->d_sf_s, (size_t)128 * 128);
-        hipLaunchKernelGGL(al_split_kernel, dim3(sslam::cdiv(128 * 2048, 256)), dim3(256), 0, s, g->d_agg, g->d_agg_s, (size_t)128 * 2048);
-        hipLaunchKernelGGL((al_dcn_wfrag_kernel<32, 64, 0>), dim3(sslam::cdiv((9 * 2 + 0) * 2 * 512, 256)), dim3(256), 0, s, g->b3c1.w, g->b3c1.a, nullptr, g->b3c1f);
-        hipLaunchKernelGGL((al_dcn_wfrag_kernel<64, 64, 32>), dim3(sslam::cdiv((9 * 4 + 2) * 2 * 512, 256)), dim3(256), 0, s, g->b3c2.w, g->b3c2.a, g->b3dw, g->b3c2f);
-        hipLaunchKernelGGL((al_dcn_wfrag_kernel<64, 128, 0>), dim3(sslam::cdiv((9 * 4 + 0) * 4 * 512, 256)), dim3(256), 0, s, g->b4c1.w, g->b4c1.a, nullptr, g->b4c1f);
-        hipLaunchKernelGGL((al_dcn_wfrag_kernel<128, 128, 64>), dim3(sslam::cdiv((9 * 8 + 4) * 4 * 512, 256)), dim3(256), 0, s, g->b4c2.w, g->b4c2.a, g->b4dw, g->b4c2f);
-        hipLaunchKernelGGL(al_offc_wfrag_kernel<32>, dim3(sslam::cdiv(18 * 512, 256)), dim3(256), 0, s, g->b3c1.ow, g->b3c1of);
-        hipLaunchKernelGGL(al_offc_wfrag_kernel<64>, dim3(sslam::cdiv(36 * 512, 256)), dim3(256), 0, s, g->b3c2.ow, g->b3c2of);
-        hipLaunchKernelGGL(al_offc_wfrag_kernel<64>, dim3(sslam::cdiv(36 * 512, 256)), dim3(256), 0, s, g->b4c1.ow, g->b4c1of);
-        hipLaunchKernelGGL(al_offc_wfrag_kernel<128>, dim3(sslam::cdiv(72 * 512, 256)), dim3(256), 0, s, g->b4c2.ow, g->b4c2of);
+        SSLAM_HIP_CHECK(hipMemsetAsync(g->range_sticky, 0, 4 * sizeof(int), s));
+        hipLaunchKernelGGL(al_conv32_wfrag_kernel, dim3(sslam::cdiv(32 * 288, 256)), dim3(256), 0, s, g->b2c2.w, g->b2c2f, g->range_sticky);
+        hipLaunchKernelGGL(al_conv16_wfrag_kernel, dim3(sslam::cdiv(5 * 64 * 8, 256)), dim3(256), 0, s, g->b1c2.w, g->b1c2f, g->range_sticky);
+        hipLaunchKernelGGL(al_conv32p_wfrag_kernel, dim3(sslam::cdiv(10 * 64 * 8, 256)), dim3(256), 0, s, g->b2c1.w, g->b2dw, g->b2c1f, g->range_sticky);
+        hipLaunchKernelGGL(al_split_kernel, dim3(sslam::cdiv(128 * 128, 256)), dim3(256), 0, s, g->d_sf, g->d_sf_s, (size_t)128 * 128, g->range_sticky);
+        hipLaunchKernelGGL(al_split_kernel, dim3(sslam::cdiv(128 * 2048, 256)), dim3(256), 0, s, g->d_agg, g->d_agg_s, (size_t)128 * 2048, g->range_sticky);
+        hipLaunchKernelGGL((al_dcn_wfrag_kernel<32, 64, 0>), dim3(sslam::cdiv((9 * 2 + 0) * 2 * 512, 256)), dim3(256), 0, s, g->b3c1.w, g->b3c1.a, nullptr, g->b3c1f, g->range_sticky);
+        hipLaunchKernelGGL((al_dcn_wfrag_kernel<64, 64, 32>), dim3(sslam::cdiv((9 * 4 + 2) * 2 * 512, 256)), dim3(256), 0, s, g->b3c2.w, g->b3c2.a, g->b3dw, g->b3c2f, g->range_sticky);
+        hipLaunchKernelGGL((al_dcn_wfrag_kernel<64, 128, 0>), dim3(sslam::cdiv((9 * 4 + 0) * 4 * 512, 256)), dim3(256), 0, s, g->b4c1.w, g->b4c1.a, nullptr, g->b4c1f, g->range_sticky);
+        hipLaunchKernelGGL((al_dcn_wfrag_kernel<128, 128, 64>), dim3(sslam::cdiv((9 * 8 + 4) * 4 * 512, 256)), dim3(256), 0, s, g->b4c2.w, g->b4c2.a, g->b4dw, g->b4c2f, g->range_sticky);
+        hipLaunchKernelGGL(al_offc_wfrag_kernel<32>, dim3(sslam::cdiv(18 * 512, 256)), dim3(256), 0, s, g->b3c1.ow, g->b3c1of, g->range_sticky);
+        hipLaunchKernelGGL(al_offc_wfrag_kernel<64>, dim3(sslam::cdiv(36 * 512, 256)), dim3(256), 0, s, g->b3c2.ow, g->b3c2of, g->range_sticky);
+        hipLaunchKernelGGL(al_offc_wfrag_kernel<64>, dim3(sslam::cdiv(36 * 512, 256)), dim3(256), 0, s, g->b4c1.ow, g->b4c1of, g->range_sticky);
+        hipLaunchKernelGGL(al_offc_wfrag_kernel<128>, dim3(sslam::cdiv(72 * 512, 256)), dim3(256), 0, s, g->b4c2.ow, g->b4c2of, g->range_sticky);
+        int wflag = 0;
+        SSLAM_HIP_CHECK(hipMemcpyAsync(&wflag, g->range_sticky, sizeof(int), hipMemcpyDeviceToHost, s));
         SSLAM_HIP_CHECK(hipStreamSynchronize(s));
+        if (wflag) {
+            g->arena.release(); delete g;
+            SSLAM_REQUIRE(false, "sslam_aliked_create: a weight (BN scale folded) with |value| >= 65520 does not fit the fp16 planes "
+                                 "of the split-precision stages");
+        }
     }
     SSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)al_block2_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B2_LDS));
     SSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)al_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2334,6 +2389,20 @@ int sslam_aliked_extract_batch_dev(sslam_aliked* g, int n_frames, const uint8_t*
 /* Replay the launch sequence of sslam_aliked_extract_dev as a cached hipGraph (one graph per
  * distinct argument tuple, LRU of 128): for callers that cycle through a fixed set of buffers,
  * as the frame pipeline does.  Results are identical; only the host cost of a call changes. */
+int sslam_aliked_range_overflow(sslam_aliked* g, int* flag_out) {
+    SSLAM_REQUIRE(g && flag_out, "sslam_aliked_range_overflow: NULL argument");
+    hipStream_t s = g->ctx->stream;
+    int flag = 0;
+    SSLAM_HIP_CHECK(hipMemcpyAsync(&flag, g->range_sticky, sizeof(int), hipMemcpyDeviceToHost, s));
+    SSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    if (flag) {
+        SSLAM_HIP_CHECK(hipMemsetAsync(g->range_sticky, 0, sizeof(int), s));
+        SSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    *flag_out = flag;
+    return 0;
+}
+
 int sslam_aliked_use_graphs(sslam_aliked* g, int enable) {
     SSLAM_REQUIRE(g != nullptr, "sslam_aliked_use_graphs: NULL instance");
     if (!enable) { (void)hipStreamSynchronize(g->ctx->stream); g->graphs.clear(); }
@@ -2353,6 +2422,12 @@ int sslam_aliked_extract_host(sslam_aliked* g, const uint8_t* img, int H, int W,
     int32_t n = 0;
     SSLAM_HIP_CHECK(hipMemcpyAsync(&n, g->out_n, 4, hipMemcpyDeviceToHost, s));
     SSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    if (n == -1) {                           // (al_finalize_kernel: the frame's range flag)
+        (void)hipMemsetAsync(g->range_sticky, 0, sizeof(int), s);
+        (void)hipStreamSynchronize(s);
+        SSLAM_REQUIRE(false, "sslam_aliked_extract_host: an activation left the fp16 range of the split-precision stages "
+                             "(|value| >= 65520): the frame's features are void");
+    }
     SSLAM_REQUIRE(n >= 0 && n <= max_kpts, "sslam_aliked_extract_host: corrupt keypoint count %d", n);
     if (n) {
         SSLAM_HIP_CHECK(hipMemcpyAsync(xy_out, g->out_xy, (size_t)n * 8, hipMemcpyDeviceToHost, s));

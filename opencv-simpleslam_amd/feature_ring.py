@@ -237,6 +237,10 @@ class DeviceFeatureRing:
         ctx.sync()
         del staged                           # the upload is done: the caller's image may change from here on
         n = int(self.pin_cnt[0])
+        if n < 0:                            # (al_finalize_kernel: the frame's range flag; a look-ahead on it matched an empty frame)
+            det.range_overflow()             # reported here: clear the instance's sticky word
+            raise _native.NativeError("feature_extractor: an activation left the fp16 range of the split-precision stages "
+                                      "(|value| >= 65520): the frame's features are void")
         xy = self.pin_xy[:n].copy(); desc = self.pin_desc[:n].copy()
         desc.setflags(write=False)
         if shells is not None:

@@ -93,6 +93,9 @@ def unpack_record(rec, max_kpts):
         rec = rec.detach().cpu().numpy()
     rec = np.ascontiguousarray(rec, np.float32)
     n = int(rec[K * ROW:K * ROW + 1].view(np.int32)[0])
+    if n < 0:                                        # (al_finalize_kernel: the extractor's range flag for this frame)
+        raise RangeOverflowError("ALIKED split-precision range overflow: this frame's features are void (|activation| >= 65520 "
+                                 "does not fit the fp16 planes)")
     return n, rec[:2 * K].reshape(K, 2)[:n], rec[2 * K:K * ROW].reshape(K, DESC_DIM)[:n]
 
 
@@ -420,9 +423,9 @@ class FrameStreamPipeline:
         return self._checked_infos()
 
     def range_overflow(self) -> bool:
-        """True if any matcher of the pipeline raised its range flag since the last poll (every round, not
-        only the last one whose `info` is still on the device); synchronises the matcher streams, clears."""
-        return any([m.range_overflow() for m in self.mats])
+        """True if any matcher or extractor of the pipeline raised its range flag since the last poll (every round, not
+        only the last one whose `info` is still on the device); synchronises their streams, clears."""
+        return any([m.range_overflow() for m in self.mats] + [d.range_overflow() for d in self.dets])
 
     def features(self):
         """Host copy of the last round's features: list of (xy [n,2], desc [n,128]) per local frame."""

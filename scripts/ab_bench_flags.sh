@@ -1,4 +1,5 @@
 # A/B of build flags on the BENCH itself (the pipeline, where kernels of four streams share the chip): ab_bench_flags.sh "<flags A>" "<flags B>" ...
+export SSLAM_EXPERIMENT_BUILD=1     # build.py refuses SSLAM_EXTRA_HIPCC_FLAGS without it
 cd $GRAFT_REPO_ROOT
 for rep in 1 2; do
 for fl in "$@"; do

@@ -1,4 +1,5 @@
 # bit-identity of an ALIKED kernel change on ONE box: ab_hash_aliked.sh "<flags A>" "<flags B>"  (SSLAM_EXTRA_HIPCC_FLAGS values); prints the diff of the hashes
+export SSLAM_EXPERIMENT_BUILD=1     # build.py refuses SSLAM_EXTRA_HIPCC_FLAGS without it
 cd $GRAFT_REPO_ROOT
 i=0
 for fl in "$@"; do

@@ -1,4 +1,5 @@
 # A/B of LightGlue build flags on ONE box: ab_lg_flags.sh <kernel-name-pattern> "<flags A>" "<flags B>" ...
+export SSLAM_EXPERIMENT_BUILD=1     # build.py refuses SSLAM_EXTRA_HIPCC_FLAGS without it
 cd $GRAFT_REPO_ROOT
 PAT=$1; shift
 for fl in "$@"; do

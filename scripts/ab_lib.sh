@@ -2,6 +2,7 @@
 # kernel-level effects): ab_lib.sh "<hipcc flags A>" "<hipcc flags B>" [pairs=8]
 # Builds each variant in place (content-keyed objects), profiles the batched LightGlue forward with
 # rocprofv3 and prints the per-kernel table of each; the default build is restored at the end.
+export SSLAM_EXPERIMENT_BUILD=1     # build.py refuses SSLAM_EXTRA_HIPCC_FLAGS without it
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 B=${3:-8}

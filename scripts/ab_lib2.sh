@@ -1,6 +1,7 @@
 # A/B of builds of libsslam_hip.so on ONE GPU box: ab_lib2.sh [pairs] "<flags A>" "<flags B>" ...
 # Each variant is built in place (content-keyed objects), the batched LightGlue forward is profiled once
 # with rocprofv3 --kernel-trace --stats and its per-kernel table printed; the default build is restored.
+export SSLAM_EXPERIMENT_BUILD=1     # build.py refuses SSLAM_EXTRA_HIPCC_FLAGS without it
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 B=$1; shift

@@ -1,4 +1,5 @@
 # which build switch makes ALIKED non-deterministic under concurrency: ab_stress_aliked.sh <repeats> "<flags A>" "<flags B>" ...
+export SSLAM_EXPERIMENT_BUILD=1     # build.py refuses SSLAM_EXTRA_HIPCC_FLAGS without it
 cd $GRAFT_REPO_ROOT
 R=$1; shift
 for fl in "$@"; do

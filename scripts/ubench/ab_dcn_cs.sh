@@ -1,3 +1,4 @@
+export SSLAM_EXPERIMENT_BUILD=1     # build.py refuses SSLAM_EXTRA_HIPCC_FLAGS without it
 cd $GRAFT_REPO_ROOT
 for fl in "-DAL_DCN4_CS=2" "-DAL_DCN4_CS=4"; do
   echo "=== $fl"

@@ -1,4 +1,5 @@
 # A/B of the 4-wave FFN kernel's build knobs on one box: kernel time per 8-pair launch under the tracer
+export SSLAM_EXPERIMENT_BUILD=1     # build.py refuses SSLAM_EXTRA_HIPCC_FLAGS without it
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 for fl in "" "-DFFN4_D2=8" "-DFFN4_D1=4" "-DFFN4_D1=4 -DFFN4_D2=8"; do
   SSLAM_EXTRA_HIPCC_FLAGS="$fl" python opencv-simpleslam_amd/build.py > /tmp/ab_build.log 2>&1 || { tail -5 /tmp/ab_build.log; continue; }

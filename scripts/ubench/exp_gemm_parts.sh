@@ -1,3 +1,4 @@
+export SSLAM_EXPERIMENT_BUILD=1     # build.py refuses SSLAM_EXTRA_HIPCC_FLAGS without it
 set -e
 cd $GRAFT_REPO_ROOT
 for flags in "" "-DSSLAM_DBG_NOMFMA=1" "-DSSLAM_DBG_NOEPI=1" "-DSSLAM_DBG_NOMFMA=1 -DSSLAM_DBG_NOEPI=1"; do
