@@ -493,13 +493,16 @@ def main():
     # SSLAM_BENCH_FORCE_DIST=1 (tests): take the N > 1 branches - process group, collective barrier, max-reduce of the
     # time, the pipeline's collation path - with ONE rank, so the RCCL code has run on a single-GPU box
     distributed = world > 1 or os.environ.get("SSLAM_BENCH_FORCE_DIST") == "1"
-    # ONE default for `bench.py --gpus N`: RCCL driven directly (the ranks keep the system HIP runtime; measured 950 vs 947
-    # frames/s against torch's `nccl` with one rank, r03).  SSLAM_DIST_BACKEND=nccl / gloo select torch.distributed.
+    # ONE collation path (frame_shard.FrameStreamPipeline + a `comm`): RCCL driven directly (opencv-simpleslam_amd/rccl.py) -
+    # the library, and with it the SYSTEM HIP runtime, loads first; torch serves the CPU-side rendezvous over gloo (the
+    # 128-byte communicator id, the barrier, the max-reduce of the times) and never initialises its GPU side.
+    # SSLAM_DIST_BACKEND=gloo is a test-only mode for ranks that share a GPU: the same choreography with the rows
+    # exchanged through the host (frame_shard.GlooRowsComm).
     backend = os.environ.get("SSLAM_DIST_BACKEND", "rccl")
     comm = None
-    if distributed and backend == "rccl":
-        # RCCL driven directly (opencv-simpleslam_amd/rccl.py): the library - and with it the SYSTEM HIP runtime - first,
-        # torch only for the CPU-side rendezvous (gloo); its GPU side is never initialised in this process
+    if distributed:
+        if backend not in ("rccl", "gloo"):
+            raise SystemExit(f"SSLAM_DIST_BACKEND={backend!r}: 'rccl' (default) or 'gloo' (ranks sharing a GPU, tests)")
         pkg_ = importlib.import_module("opencv-simpleslam_amd")
         if pkg_._native.device_count() < 1:
             raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
@@ -510,30 +513,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29621")
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        rccl = importlib.import_module("opencv-simpleslam_amd.rccl")
+        if backend == "rccl":
+            rccl = importlib.import_module("opencv-simpleslam_amd.rccl")
 
-        def _exchange(payload):
-            box = [payload]
-            dist.broadcast_object_list(box, src=0)
-            return box[0]
-        comm = rccl.RcclComm.create(rank, world, _exchange)
-    elif distributed:
-        # one process per GPU; SSLAM_DIST_BACKEND=gloo + fewer GPUs than ranks is a test-only mode that
-        # exercises the N > 1 code path on a single-GPU box (ranks share device local_rank % n_gpus).
-        # torch brings its own HIP runtime: it must initialise BEFORE libsslam_hip.so touches the
-        # device (the other order leaves torch with "No HIP GPUs are available").
-        import torch
-        import torch.distributed as dist
-        if not torch.cuda.is_available():
-            raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-        device_index = local_rank % torch.cuda.device_count()
-        torch.cuda.set_device(device_index)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29621")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+            def _exchange(payload):
+                box = [payload]
+                dist.broadcast_object_list(box, src=0)
+                return box[0]
+            comm = rccl.RcclComm.create(rank, world, _exchange)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            comm = importlib.import_module("opencv-simpleslam_amd.frame_shard").GlooRowsComm(rank, world)
 
     pkg = importlib.import_module("opencv-simpleslam_amd")
     nat = pkg._native
@@ -575,12 +564,8 @@ def main():
         pipe.sync()
         if p_ is not None and p_ is not pipe:
             p_.sync()                                            # (a leg's own matcher streams)
-        if comm is not None:
+        if distributed:
             dist.barrier()                                       # (gloo, host side; the device is idle after pipe.sync())
-        elif distributed:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
 
     col = nat.Context(device_index)                          # collector stream: stamps the end of every round
     stamps = []
@@ -829,7 +814,7 @@ def main():
 
     times = np.array([dt, s_dt, x_dt or 0.0, e_dt or 0.0])
     if distributed:
-        t = torch.tensor(times, dtype=torch.float64, device="cpu" if comm is not None else "cuda")
+        t = torch.tensor(times, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         times = t.cpu().numpy()
     dt_max, s_dt_max, x_dt_max, e_dt_max = (float(v) for v in times)
@@ -870,11 +855,11 @@ def main():
                        "pairs_per_lightglue_launch": BATCH_PAIRS, "frames_per_aliked_launch": pipe.EF,
                        "parallelism": f"frame-shard x{world}; per GPU {N_EXT} extractor + {N_MAT} matcher streams, "
                                       f"ALIKED in batches of {pipe.EF} frames, LightGlue in batches of {BATCH_PAIRS} pairs"
-                                      + (f"; collation: {'RCCL directly' if comm is not None else backend + ' through torch.distributed'}"
+                                      + (f"; collation: {'RCCL directly' if backend == 'rccl' else 'rows through the host over gloo (test mode)'}"
                                          if distributed else ""),
                        # N > 1: the size of the communicator the collation ran on, as the communicator reports it
-                       "rccl_ranks": (comm.count() if comm is not None else (dist.get_world_size() if distributed else None)),
-                       "collation_backend": (("rccl (direct)" if comm is not None else dist.get_backend()) if distributed else None)},
+                       "rccl_ranks": (comm.count() if distributed and backend == "rccl" else None),
+                       "collation_backend": (("rccl (direct)" if backend == "rccl" else "gloo (host round trip, test mode)") if distributed else None)},
             # achieved = ALGORITHMIC flops (8 n0 n1 256 per pair, x pairs per launch) / HIP-event launch
             # duration on an otherwise idle GPU; the kernel issues 3 v_mfma_f32_32x32x16_f16 per
             # algorithmic product (executed = 3x)

@@ -48,11 +48,18 @@ __device__ __forceinline__ float selu(float x) {
 #endif
 }
 
-// SELU on ocml's expm1f: al_aggregate_kernel keeps it.  With the hardware-exponential form IN THAT KERNEL, 1 / ||F|| came out
-// wrong by 0.2 - 3 % on 16 consecutive pixels (one quarter of a wave) about once in 150 frames when several extractor
-// streams share the GPU - g1, s8 and every other kernel's output stayed bit-stable over 1 200 frames
-// (scripts/stress_aliked_repeat.py, bisected over commits and call sites; not explained: the ISA of both variants reads
-// correctly, a wait state behind v_exp_f32 and other unroll factors change nothing).  With expm1f there: 0 differences.
+// SELU on ocml's expm1f (a polynomial + v_ldexp: no transcendental instruction): al_aggregate_kernel keeps it.  With the
+// hardware-exponential form IN THAT KERNEL, 1 / ||F|| came out wrong by 0.2 - 3 % on 16 consecutive pixels (one quarter of a
+// wave) about once in 150 frames when several extractor streams share the GPU - g1, s8 and every other kernel's output stayed
+// bit-stable (scripts/stress_aliked_repeat.py, r04: bisected over commits and call sites).  r05 narrowed it
+// (profiles/r05_aggregate_selu_hazard.md, scripts/ab_stress_aliked.sh with -DAL_AGG_FAST_SELU=<bits>): the channel LOOP on
+// v_exp_f32 is stable (0 of 1 440 frames); the eight v_exp_f32 of the TAIL (the s8 outputs, a few dozen instructions in
+// front of the v_sqrt_f32 / v_div_scale / v_rcp_f32 / v_div_fmas chain of the norm) reproduce it (3 - 5 events per 1 440
+// frames) - with the norm moved in front of them in the source and with 32 idle cycles tied to its operand as well.  n2 is
+// final ~500 instructions earlier and only `rnorm` is affected, so the fault is inside that sqrt / divide chain when
+// transcendental instructions of the same wave precede it; every static wait-state rule of the ISA is met in the
+// compiler's output.  Not explained further: the kernel is not issue-bound (no time difference), so it stays on the
+// polynomial form, and the concurrency stress is a GPU test (test_extraction_is_deterministic_under_concurrency).
 #ifndef AL_AGG_FAST_SELU
 #define AL_AGG_FAST_SELU 0
 #endif
@@ -1116,9 +1123,17 @@ __global__ __launch_bounds__(256) void al_aggregate_kernel(Pyr P0, const float* 
     agg_level(P.pre3, (int)(HW / 64), t3, s, n2);
     agg_level(P.pre4, (int)(HW / 1024), t4, s, n2);
     if (live) {
+#if (AL_AGG_FAST_SELU >> 2) & 1          // (experiment: the norm first, the eight exponentials of the tail behind it)
+        rnorm[pix] = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+#endif
 #pragma unroll
         for (int o = 0; o < 8; ++o) s8[o * HW + pix] = selu_precise<1>(s[o]);
+#if (AL_AGG_FAST_SELU >> 3) & 1          // (experiment: 32 idle cycles between the last exponential's chain and the square root)
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(n2));
+#endif
+#if !((AL_AGG_FAST_SELU >> 2) & 1)
         rnorm[pix] = 1.0f / fmaxf(sqrtf(n2), 1e-12f);            // F.normalize eps
+#endif
     }
     __syncthreads();
     const int npx = min(256, P.Wp - (int)(blockIdx.x * blockDim.x));

@@ -10,9 +10,9 @@ with no data-path collective: in every round rank r owns the contiguous chunk
 
 and matches each of its frames against the previous one.  The only exchange
 is the collation of the per-frame feature records of all frames back into
-the shared map every rank keeps (RCCL all-gather over xGMI through
-torch.distributed); the pair that straddles a chunk boundary is matched after
-that gather against the neighbour's last frame.
+the shared map every rank keeps (RCCL all-gather over xGMI, driven directly:
+rccl.py); the pair that straddles a chunk boundary is matched after that
+gather against the neighbour's last frame.
 
 Inside one GPU a round is
   * B extracts, dealt round-robin over the extractor instances (each on its own HIP stream:
@@ -29,9 +29,10 @@ Per-frame feature record (the unit of the exchange, device resident, float32 wor
 The extractor writes straight into the record of its slot and the matcher reads straight from it,
 so collation is ONE all-gather of the round's B records with no packing pass.
 
-On one GPU the pipeline runs on the C-ABI alone (streams, events, buffers through
-`_native.Context`); torch is imported only for the N > 1 collective.  `ShardPlan`, the record
-helpers and `collate` are pure host logic and are covered by the world_size-2 gloo tests on CPU.
+The pipeline runs on the C-ABI alone at every N (streams, events, buffers through `_native.Context`); the exchange is a
+`comm` object with ONE method, `all_gather_rows` - `rccl.RcclComm` in production, `GlooRowsComm` (torch.distributed over
+gloo, rows through the host) where ranks share a GPU or there is none: the choreography around it is one code path.
+`ShardPlan`, the record helpers and `GlooRowsComm` are covered by the world_size-2 gloo tests on CPU.
 """
 from __future__ import annotations
 
@@ -99,32 +100,37 @@ def unpack_record(rec, max_kpts):
     return n, rec[:2 * K].reshape(K, 2)[:n], rec[2 * K:K * ROW].reshape(K, DESC_DIM)[:n]
 
 
-def collate(local_records, plan: ShardPlan, group=None, out=None, part=None, always=False):
-    """All-gather the per-frame records of one round (or of a part of it).
+class GlooRowsComm:
+    """The collation's exchange over torch.distributed (gloo, host memory), with `rccl.RcclComm.all_gather_rows`'s signature:
+    for ranks that SHARE a GPU (RCCL wants one device per rank) and for the CPU tests.  The rows make a round trip through
+    the host, synchronously behind whatever is already enqueued on the collation context - slow, and the same data in the
+    same places as the RCCL form, so `FrameStreamPipeline.round` is one code path for both."""
 
-    local_records: [B, REC] float32 tensor of this rank's frames (frame order).
-    Returns [world*B, REC] in GLOBAL frame order of the round.  With world == 1 this is the
-    input (no collective).
-    out:  optional preallocated [world*B, REC] tensor to gather into (the caller keeps it alive: no
-          allocation and no copy per round);
-    part: optional (lo, hi) - gather only local frames lo..hi-1 of every rank, into rows
-          r*B + lo .. r*B + hi - 1 of `out`, so a round can be collated in pieces as its extracts finish.
-    always: run the collective with one rank too (tests: the RCCL path on a single GPU)."""
-    if plan.world == 1 and not always:
-        return local_records
-    import torch
-    import torch.distributed as dist
-    B = local_records.shape[0]
-    if out is None:
-        out = torch.empty((plan.world * B,) + tuple(local_records.shape[1:]),
-                          dtype=local_records.dtype, device=local_records.device)
-    if part is None or (part[0] == 0 and part[1] == B):
-        dist.all_gather_into_tensor(out, local_records.contiguous(), group=group)   # rank-major = frame order
-    else:
-        lo, hi = part
-        views = [out[r * B + lo:r * B + hi] for r in range(plan.world)]             # each contiguous
-        dist.all_gather(views, local_records[lo:hi].contiguous(), group=group)
-    return out
+    def __init__(self, rank: int, world: int, group=None):
+        self.rank, self.world, self.group = int(rank), int(world), group
+
+    def count(self) -> int:
+        import torch.distributed as dist
+        return dist.get_world_size(self.group)
+
+    def all_gather_rows(self, cctx, src_ptr: int, dst_ptr: int, rows_per_rank: int, lo: int, hi: int, row_bytes: int):
+        """Every rank contributes rows lo .. hi-1 of its `rows_per_rank` local rows (src_ptr = row 0 of the local block); they
+        land in rows r * rows_per_rank + lo .. of dst_ptr on every rank (global frame order).  `cctx`: the context whose
+        stream the exchange is ordered on."""
+        if hi <= lo:
+            return
+        import torch
+        import torch.distributed as dist
+        n = (hi - lo) * row_bytes
+        send = np.empty(n, np.uint8)
+        cctx.d2h(send, src_ptr + lo * row_bytes)                 # (waits for the stream: the extracts' events were enqueued on it)
+        parts = [torch.empty(n, dtype=torch.uint8) for _ in range(self.world)]
+        dist.all_gather(parts, torch.from_numpy(send), group=self.group)
+        for r, t in enumerate(parts):
+            cctx.h2d(dst_ptr + (r * rows_per_rank + lo) * row_bytes, t.numpy())
+
+    def close(self):
+        pass
 
 
 class RangeOverflowError(RuntimeError):
@@ -141,16 +147,18 @@ class FrameStreamPipeline:
     matcher needs max_pairs >= batch_pairs)."""
 
     def __init__(self, detectors, matchers, plan: ShardPlan, max_kpts: int, min_conf: float = 0.7,
-                 batch_pairs: int | None = None, group=None, use_graphs: bool = True, collate_always: bool = False,
-                 comm=None):
+                 batch_pairs: int | None = None, use_graphs: bool = True, collate_always: bool = False, comm=None):
         self.dets = list(detectors) if isinstance(detectors, (list, tuple)) else [detectors]
         self.mats = list(matchers) if isinstance(matchers, (list, tuple)) else [matchers]
-        self.plan, self.group = plan, group
-        # collate_always: take the multi-GPU path (torch-owned slab, collation stream, per-half all-gathers, halo record)
-        # with ONE rank too - how the tests run the RCCL branch on a single GPU
-        # comm: an `rccl.RcclComm` - the collation runs on RCCL directly, over memory of the C-ABI (no torch in the data
-        # path); without it the exchange goes through torch.distributed (`group`; gloo in the CPU / shared-GPU tests)
+        self.plan = plan
+        # comm: the exchange of the collation - `rccl.RcclComm` (RCCL over xGMI on memory of the C-ABI, no tensor library in
+        # the data path) or `GlooRowsComm` (ranks sharing a GPU / tests); needed when world > 1
+        # collate_always: take the multi-GPU path (collation stream, per-half all-gathers, halo record) with ONE rank too -
+        # how the tests run the RCCL branch on a single GPU
         self.distributed = plan.world > 1 or bool(collate_always)
+        if self.distributed and comm is None:
+            raise ValueError("a frame-sharded pipeline over more than one rank needs a `comm` (rccl.RcclComm, or GlooRowsComm "
+                             "for ranks that share a GPU)")
         self.comm = comm if self.distributed else None
         # every round cycles through the same record slots: each extractor / matcher call sequence is
         # replayed as a cached hipGraph (one hipGraphLaunch instead of 45 / 190 launches per call)
@@ -171,40 +179,22 @@ class FrameStreamPipeline:
         # round r; + two halo slots for the N > 1 boundary record.  Outputs are double-buffered alike.
         self.NSLOT = 2 * B + 2
         dev_bytes = self.NSLOT * self.REC * 4
-        self.torch = None
         self.cctx = None
-        if self.distributed and self.comm is not None:
+        self.slab = self.ctx.malloc(dev_bytes)
+        self.ctx.memset_async(self.slab, 0, dev_bytes)
+        if self.distributed:
             from . import _native
-            self.slab = self.ctx.malloc(dev_bytes)
-            self.ctx.memset_async(self.slab, 0, dev_bytes)
-            self.cctx = _native.Context(self.ctx.device)         # the collation has a stream of its own (see below)
+            # the collation has a stream of its own: on an extractor's stream the first half-round gather would hold back
+            # that extractor's second half
+            self.cctx = _native.Context(self.ctx.device)
+            # gathered rounds, one buffer per round parity: the previous round's last record (the halo of this round's
+            # first pair on rank 0) is read where it was gathered - no copy of the map, no allocation
             gbytes = plan.world * B * self.REC * 4
             self._gathered_ptr = [self.ctx.malloc(gbytes), self.ctx.malloc(gbytes)]
             for g_ in self._gathered_ptr:
                 self.ctx.memset_async(g_, 0, gbytes)
             self.halves = [(0, (B + 1) // 2), ((B + 1) // 2, B)] if B > 1 else [(0, B)]
-            self.ctx.sync()
-        elif self.distributed:
-            # the exchange goes through torch.distributed: its tensors own the record slab
-            import torch
-            self.torch = torch
-            dev = torch.device("cuda", self.ctx.device)
-            self._slab_t = torch.zeros((self.NSLOT, self.REC), dtype=torch.float32, device=dev)
-            self.slab = int(self._slab_t.data_ptr())
-            # the collation has a stream of its own (a context of this package, seen by torch as an external
-            # stream): on an extractor's stream the first half-round gather would hold back that extractor's
-            # second half
-            from . import _native
-            self.cctx = _native.Context(self.ctx.device)
-            self._cstream = torch.cuda.ExternalStream(self.cctx.stream, device=self.ctx.device)
-            # gathered rounds, one buffer per round parity: the previous round's last record (the halo of
-            # this round's first pair on rank 0) is read where it was gathered - no clone, no allocation
-            self._gathered = [torch.zeros((plan.world * B, self.REC), dtype=torch.float32, device=dev) for _ in range(2)]
-            self.halves = [(0, (B + 1) // 2), ((B + 1) // 2, B)] if B > 1 else [(0, B)]
-            torch.cuda.synchronize()
-        else:
-            self.slab = self.ctx.malloc(dev_bytes)
-            self.ctx.memset_async(self.slab, 0, dev_bytes)
+        self.ctx.sync()
         self.score = self.ctx.malloc(2 * B * K * 4)
         self._ij = self.ctx.malloc(2 * B * K * 8)
         self._msc = self.ctx.malloc(2 * B * K * 4)
@@ -220,8 +210,7 @@ class FrameStreamPipeline:
         self.have_halo = False
         self.rounds = 0
         self.batches = 0                                         # global batch counter (matcher round-robin)
-        self.shared_map = None          # last collated round [world*B, REC] (torch tensor; torch.distributed path only)
-        self.shared_map_ptr = 0         # ... its device address (both paths)
+        self.shared_map_ptr = 0         # device address of the last collated round [world*B, REC] (N > 1)
 
     # ---- record addressing (slot = index into the slab; set p holds slots p*B .. p*B + B-1)
     def rec_ptr(self, slot: int) -> int:
@@ -296,11 +285,14 @@ class FrameStreamPipeline:
                     d.ctx.record(self.ev_ext[p][s])
         have_halo = self.have_halo
         prev_slot = (1 - p) * B + B - 1                  # last frame of the previous round (one GPU)
-        if not single and self.comm is not None:
-            # ---- multi-GPU, RCCL directly: the same choreography as below on raw device memory
+        if not single:
+            # ---- multi-GPU: collate each HALF of the round as soon as its extracts are done (the first all-gather runs
+            # under the second half's extracts, the second under the matches) on the collation stream; the matches run on
+            # their own streams underneath.  (G was last written two rounds ago; its readers since - that round's halo copy
+            # and, on rank 0, the next round's - are on this same stream.)
             G = self._gathered_ptr[p]
             rb = self.REC * 4
-            prev = plan.rank * B - 1
+            prev = plan.rank * B - 1                         # index inside the gathered round
             if prev < 0:
                 # rank 0: the halo is the LAST record of the previous round's collation - in place already, so the copy
                 # (and the halo event the first batch waits for) goes in front of this round's gathers
@@ -310,44 +302,13 @@ class FrameStreamPipeline:
             for (lo, hi) in self.halves:
                 for s in range(lo, hi):
                     self.cctx.wait(self.ev_ext[p][s])
-                self.comm.all_gather_rows(self.cctx.stream, self.rec_ptr(s_base), G, B, lo, hi, rb)
+                self.comm.all_gather_rows(self.cctx, self.rec_ptr(s_base), G, B, lo, hi, rb)
             self.shared_map_ptr = G
             if prev >= 0:
                 # other ranks: the last frame of the neighbour, gathered in this round's second half
                 self.cctx.d2d_async(self.rec_ptr(halo_slot), G + prev * rb, rb)
                 have_halo = True
                 self.cctx.record(self.ev_halo[p])
-            self.cctx.record(self.ev_collated[p])
-            prev_slot = halo_slot
-        elif not single:
-            # ---- multi-GPU: collate each HALF of the round as soon as its extracts are done (the first
-            # all-gather runs under the second half's extracts, the second under the matches), on the
-            # collation stream; the matches run on their own streams underneath.
-            torch = self.torch
-            G = self._gathered[p]
-            if rnd >= 2:
-                # G was last written two rounds ago; its readers since: that round's halo copy (same stream) and
-                # the NEXT round's halo copy on rank 0 (same stream too) - stream order covers both
-                pass
-            prev = plan.rank * B - 1                         # index inside the gathered round
-            with torch.cuda.stream(self._cstream):
-                if prev < 0:
-                    # rank 0: the halo is the LAST record of the previous round's collation - in place already, so the
-                    # copy (and the halo event the first batch waits for) goes in front of this round's gathers
-                    if have_halo:
-                        self._slab_t[halo_slot].copy_(self._gathered[1 - p][plan.world * B - 1])
-                    self.cctx.record(self.ev_halo[p])
-                for (lo, hi) in self.halves:
-                    for s in range(lo, hi):
-                        self.cctx.wait(self.ev_ext[p][s])
-                    collate(self._slab_t[s_base:s_base + B], plan, self.group, out=G, part=(lo, hi), always=True)
-                self.shared_map = G
-                self.shared_map_ptr = int(G.data_ptr())
-                if prev >= 0:
-                    # other ranks: the last frame of the neighbour, gathered in this round's second half
-                    self._slab_t[halo_slot].copy_(G[prev])
-                    have_halo = True
-                    self.cctx.record(self.ev_halo[p])
             self.cctx.record(self.ev_collated[p])
             prev_slot = halo_slot
         # ---- batched matches: pair s = (s-1, s); pair 0 = (previous frame, 0)

@@ -10,7 +10,7 @@ the collation stream of the pipeline, and torch - if it is there at all - only c
 between the ranks over gloo (CPU).
 
     comm = RcclComm.create(rank, world, exchange)     # exchange(bytes | None) -> bytes: rank 0's id to everybody
-    comm.all_gather_rows(stream, src_ptr, dst_ptr, rows_per_rank, lo, hi, row_bytes)
+    comm.all_gather_rows(cctx, src_ptr, dst_ptr, rows_per_rank, lo, hi, row_bytes)      # cctx: the _native.Context of the collation stream
 """
 from __future__ import annotations
 
@@ -92,12 +92,13 @@ class RcclComm:
         _check(lib().ncclCommCount(self.handle, C.byref(n)), "ncclCommCount")
         return int(n.value)
 
-    def all_gather_rows(self, stream: int, src_ptr: int, dst_ptr: int, rows_per_rank: int, lo: int, hi: int, row_bytes: int):
+    def all_gather_rows(self, cctx, src_ptr: int, dst_ptr: int, rows_per_rank: int, lo: int, hi: int, row_bytes: int):
         """Every rank contributes rows lo .. hi-1 of its `rows_per_rank` local rows (src_ptr = row 0 of the local block);
-        they land in rows r * rows_per_rank + lo .. of dst_ptr on every rank (global frame order).  Enqueued on `stream`
-        (a hipStream_t as an integer); float32 rows."""
+        they land in rows r * rows_per_rank + lo .. of dst_ptr on every rank (global frame order).  Enqueued on the stream
+        of `cctx` (a `_native.Context`; or a raw hipStream_t as an integer); float32 rows."""
         if hi <= lo:
             return
+        stream = cctx if isinstance(cctx, int) else int(cctx.stream)
         L = lib()
         count = (hi - lo) * row_bytes // 4
         if lo == 0 and hi == rows_per_rank:                    # whole blocks: one all-gather, rank-major = frame order

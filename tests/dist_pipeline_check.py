@@ -6,9 +6,10 @@ checks its own frames against the sequential host API - keypoints, the match ind
 the ones that straddle a rank / round boundary (which need the gathered features of the neighbour) - and the
 collated shared map of every round.
 
-    SSLAM_DIST_BACKEND = gloo (default; ranks may share GPU 0) | nccl (= RCCL through torch: one GPU per rank)
-                       | rccl (RCCL driven directly, opencv-simpleslam_amd/rccl.py: records in C-ABI memory, torch only
-                         carries the communicator id over gloo and never touches the GPU)
+    SSLAM_DIST_BACKEND = gloo (default; ranks may share GPU 0: frame_shard.GlooRowsComm, the rows through the host)
+                       | rccl (RCCL driven directly, opencv-simpleslam_amd/rccl.py: one GPU per rank)
+Both are a `comm` handed to the SAME pipeline code; records and the gathered map live in C-ABI memory either way, torch
+only carries the rendezvous (and, for gloo, the rows) on the CPU and never touches the GPU.
 """
 import importlib
 import os
@@ -25,14 +26,14 @@ import frames                                                      # noqa: E402
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 backend = os.environ.get("SSLAM_DIST_BACKEND", "gloo")
-comm = None
+assert backend in ("gloo", "rccl"), backend
+# the system HIP runtime first (the library), then torch for the CPU-side rendezvous only
+pkg = importlib.import_module("opencv-simpleslam_amd")
+nat = pkg._native
+dev = int(os.environ.get("LOCAL_RANK", rank)) % nat.device_count() if backend == "rccl" else 0
+ctx_first = nat.default_context(dev)
+dist.init_process_group("gloo", rank=rank, world_size=world)
 if backend == "rccl":
-    # the system HIP runtime first (the library), then torch for the CPU-side rendezvous only
-    pkg = importlib.import_module("opencv-simpleslam_amd")
-    nat = pkg._native
-    dev = int(os.environ.get("LOCAL_RANK", rank)) % nat.device_count()
-    ctx_first = nat.default_context(dev)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
     rccl = importlib.import_module("opencv-simpleslam_amd.rccl")
 
     def _exchange(payload):
@@ -41,12 +42,7 @@ if backend == "rccl":
         return box[0]
     comm = rccl.RcclComm.create(rank, world, _exchange)
 else:
-    dev = int(os.environ.get("LOCAL_RANK", rank)) % torch.cuda.device_count() if backend == "nccl" else 0
-    torch.cuda.set_device(dev)
-    if backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
-    else:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = importlib.import_module("opencv-simpleslam_amd.frame_shard").GlooRowsComm(rank, world)
 pkg = importlib.import_module("opencv-simpleslam_amd")
 nat = pkg._native
 W = importlib.import_module("opencv-simpleslam_amd.weights")
@@ -119,6 +115,5 @@ for c_ in chunks:
 assert sum(len(r[0]) for r in ref[1:]) > 5, "vacuous: the sequential reference found no matches"
 dist.barrier()
 print(f"rank {rank} ({backend}, device {dev}): {checked} pairs identical to the sequential API over {ROUNDS} un-synchronised rounds", flush=True)
-if comm is not None:
-    comm.close()
+comm.close()
 dist.destroy_process_group()

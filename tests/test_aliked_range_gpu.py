@@ -42,7 +42,12 @@ def test_scaled_activations_are_fp32_grade_or_reported(gpu_ctx, native, scale):
         for which, name, div, ch in ((3, "x1", 1, 16), (4, "x2", 2, 32), (5, "x3", 8, 64), (6, "x4", 32, 128)):
             want = ref[name][0].numpy()
             got = al.debug_read(which, (ch, Hp // div, Wp // div))
-            np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-3 * max(1.0, float(np.abs(want).max()) * 1e-2), err_msg=name)
+            # rtol on the value + atol relative to the stage's largest magnitude (an output is a cancelling sum of terms of that
+            # size): 1e-4 for the plain convolutions; 1e-3 for the deformable stages, whose sampling positions are
+            # offset-conv outputs that grow with the activations - a 2^-22 relative change of an offset of ~100 px moves
+            # the bilinear sample by ~1e-5 px of a map with values in the thousands (the fp32 oracle is as sensitive)
+            rel = 1e-4 if name in ("x1", "x2") else 1e-3
+            np.testing.assert_allclose(got, want, rtol=1e-3, atol=rel * max(1.0, float(np.abs(want).max())), err_msg=name)
     if peak < 2e4:
         assert not reported, f"largest stage activation {peak:.3g} fits the fp16 planes but the call was rejected"
     if scale >= 1e5:

@@ -118,26 +118,20 @@ def test_four_rank_pipeline_equals_sequential_api():
 
 
 def test_two_rank_pipeline_over_rccl(native):
-    """The same check with backend `nccl` (= RCCL over xGMI), one GPU per rank: runs wherever >= 2 devices are
-    visible (the driver's 8-GPU node), skipped on a 1-GPU box - so the first multi-GPU lease produces evidence
+    """The same check with the production exchange (`rccl.RcclComm`, RCCL over xGMI), one GPU per rank: runs wherever >= 2
+    devices are visible (the driver's 8-GPU node), skipped on a 1-GPU box - so the first multi-GPU lease produces evidence
     for the collation path instead of being its first execution."""
     n = native.device_count()
     if n < 2:
-        pytest.skip(f"{n} GPU visible: the RCCL path needs two")
-    _run_dist_check("nccl", 2, 29615)
-
-
-def test_one_rank_pipeline_over_rccl():
-    """The RCCL branch on the one GPU of a test box: the same check with backend `nccl` and world size 1 - process-group
-    creation on the device, the per-half all-gathers on the collation stream (RCCL kernels, one rank), the torch
-    ExternalStream plumbing around them - so that code has executed before the first multi-GPU lease."""
-    _run_dist_check("nccl", 1, 29617)
+        pytest.skip(f"{n} GPU visible: RCCL wants one device per rank")
+    _run_dist_check("rccl", 2, 29615)
 
 
 def test_one_rank_pipeline_over_rccl_directly():
-    """The collation on RCCL driven directly (opencv-simpleslam_amd/rccl.py, backend `rccl`): communicator from an id
-    exchanged over gloo, per-half gathers as broadcast groups on the collation stream, records and the gathered map in
-    C-ABI memory, torch never touching the GPU (the ranks keep the system HIP runtime) - with one rank on the test box."""
+    """The production exchange on the one GPU of a test box: communicator from an id exchanged over gloo, per-half gathers as
+    RCCL broadcast groups on the collation stream, records and the gathered map in C-ABI memory, torch never touching the
+    GPU (the ranks keep the system HIP runtime) - world size 1, through the SAME `FrameStreamPipeline.round` branch the
+    gloo-rank tests above take."""
     _run_dist_check("rccl", 1, 29625)
 
 
