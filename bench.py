@@ -35,8 +35,8 @@ Rank 0 prints ONE JSON line with the contract fields plus
   early_stop   - the pipeline with random weights whose token-confidence biases
                  are calibrated on one pair of the stream so that points are
                  pruned and pairs stop early (depth AND width control under load)
-  p1           - the same pipeline in the opt-in precision "f16x3p1" (P as one fp16 plane in P.V), with the attention launch's
-                 roofline figure in that mode (never `value`)
+  f16x3        - the same pipeline in the other split form "f16x3" (three MFMAs per product in P.V too; the default until r04),
+                 with the attention launch's roofline figure in that mode (never `value`)
   pcie         - the same pipeline with the host in the loop: every round's frames uploaded from page-locked host
                  memory and its {count, pairs} read back, both on copy streams of their own (never `value`)
   c5, kpts4000 - the other stated sizes: 1920x1080 frames and the reference CLI's default of 4000
@@ -77,13 +77,29 @@ EARLY_STOP_MATCH_BIAS = float(os.environ.get("SSLAM_BENCH_MATCH_BIAS", -9.0))
 
 def _pmc_traffic():
     """Per-launch HBM-side bytes of the attention kernel at the bench size, from profiles/ (None when absent)."""
-    for name in ("r04_attention_traffic.json", "r03_attention_traffic.json", "r02final_attention_traffic.json", "r02_attention_traffic.json", "r01_attention_traffic.json"):
+    for name in ("r05_attention_traffic.json", "r04_attention_traffic.json", "r03_attention_traffic.json", "r02final_attention_traffic.json", "r02_attention_traffic.json", "r01_attention_traffic.json"):
         try:
             d = json.loads((ROOT / "profiles" / name).read_text())
             return int(d["fetch_bytes_per_launch"]) + int(d["write_bytes_per_launch"]), name
         except Exception:
             continue
     return None, None
+
+
+def _source_digest():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sslam_build", ROOT / "opencv-simpleslam_amd" / "build.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.source_digest()
+
+
+def _git_head():
+    try:
+        r = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=str(ROOT), capture_output=True, text=True, timeout=5)
+        return r.stdout.strip() or None if r.returncode == 0 else None
+    except Exception:
+        return None
 
 
 def lightglue_gflop(n, layers):
@@ -693,14 +709,14 @@ def main():
         x_steps = max(2, args.steps // 8)
         x_dt = timed_rounds(pool, x_steps, 1)
         for mat in mats:
-            mat.set_precision("f16x3")
+            mat.set_precision("f16x3p1")                     # (the default)
 
-    # opt-in precision "f16x3p1" (P as one fp16 plane in P.V, row sums over the rounded weights): same pipeline, and the attention
-    # launches of one batch bracketed on an otherwise idle GPU like the headline's roofline figure
+    # the other split form, "f16x3" (three MFMAs per product in P.V too - the default until r04; profiles/r05_flip_soak.md): same
+    # pipeline, and the attention launches of one batch bracketed on an otherwise idle GPU like the headline's roofline figure
     p1 = None
     if extras:
         for mat in mats:
-            mat.set_precision("f16x3p1")
+            mat.set_precision("f16x3")
         q_steps = max(4, args.steps // 4)
         q_dt = timed_rounds(pool, q_steps, 2)
         q_info = pipe.infos()
@@ -713,12 +729,13 @@ def main():
         p1 = {"value": round(q_steps * plane_frames / q_dt, 2), "unit": "frames/s", "steps": q_steps,
               "attention": {"avg_launch_us": round(q_ms / max(q_n, 1) * 1e3, 2), "achieved": round(q_tf, 2) if q_tf else None,
                             "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(q_tf / F16_MFMA_PEAK_TFLOPS, 4) if q_tf else None,
-                            "executed_mfma_frac": round(2.5 * q_tf / F16_MFMA_PEAK_TFLOPS, 4) if q_tf else None},
-              "what": "same pipeline with sslam_lightglue_set_precision(lg, 2): the softmax weights as ONE fp16 plane in P.V (20 instead of 24 "
-                      "MFMAs per 32-key sub-step, 2.5 executed per algorithmic product on average); match indices identical on every parity "
-                      "case, token states 2.4e-5 from exact instead of 4e-6 (profiles/r04_split_study.md) - opt-in, never `value`"}
+                            "executed_mfma_frac": round(3 * q_tf / F16_MFMA_PEAK_TFLOPS, 4) if q_tf else None},
+              "what": "same pipeline with sslam_lightglue_set_precision(lg, 1): three MFMAs per product in P.V as well (24 instead of 20 "
+                      "MFMAs per 32-key sub-step) - the default until r04; the same match indices as the shipped form over 131 199 oracle "
+                      "matches, score error 4.4e-5 against 1.06e-4, token states 4e-6 from exact against 2.4e-5 "
+                      "(profiles/r05_flip_soak.md) - selectable, never `value`"}
         for mat in mats:
-            mat.set_precision("f16x3")
+            mat.set_precision("f16x3p1")
 
     # PCIe-inclusive leg: the same pipeline with the host in the loop - every round's frames come up from page-locked
     # host memory and its {info, pairs} go back, on copy streams of their own, double-buffered like the record sets
@@ -864,7 +881,11 @@ def main():
                         "p90": round(float(np.percentile(step_ms, 90)), 3), "max": round(float(step_ms.max()), 3),
                         "what": "per-round durations on rank 0 (timing events on a collector stream, no host sync in the region)"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (contractions: f16 hi/lo split operands, 3 MFMA per product, f32 accumulate)",
+            # which sources were measured: digest of csrc/ + the C-ABI header (build.py --digest; the GPU box has no .git)
+            # and, when the caller passed it along (SSLAM_GIT_HEAD, scripts/final_evidence.sh), the commit
+            "build": {"csrc_digest": _source_digest(), "git_head": os.environ.get("SSLAM_GIT_HEAD") or _git_head()},
+            "dtype": "f32 (contractions: f16 hi/lo split operands, f32 accumulate; 3 MFMA per product, 2 in attention's P.V = "
+                     "precision 'f16x3p1', the default since r05: profiles/r05_flip_soak.md)",
             "data": "synthetic",
             "config": {"workload": "C2/C4: synthetic 1241x376x3 uint8 frame stream, ALIKED-n16 extract + "
                                    "LightGlue match (t-1,t), 2048 kpts/frame, min_conf 0.7, random-init weights; "
@@ -885,15 +906,15 @@ def main():
                        "rccl_ranks": (comm.count() if distributed and backend == "rccl" else None),
                        "collation_backend": (("rccl (direct)" if backend == "rccl" else "gloo (host round trip, test mode)") if distributed else None)},
             # achieved = ALGORITHMIC flops (8 n0 n1 256 per pair, x pairs per launch) / HIP-event launch
-            # duration on an otherwise idle GPU; the kernel issues 3 v_mfma_f32_32x32x16_f16 per
-            # algorithmic product (executed = 3x)
-            "roofline": {"bound": "mfma", "kernel": "lg_attention_asm_kernel (hand-scheduled gfx950 assembly; v_mfma_f32_32x32x16_f16 x3 per product)",
+            # duration on an otherwise idle GPU; the kernel issues 20 v_mfma_f32_32x32x16_f16 per 32-key sub-step for 8
+            # algorithmic products' worth (3 per product in K.Q^T, 2 in P.V): executed = 2.5x
+            "roofline": {"bound": "mfma", "kernel": "lg_attention_asm_p1_kernel (hand-scheduled gfx950 assembly; v_mfma_f32_32x32x16_f16: 3 per product in K.Q^T, 2 in P.V)",
                          "achieved": round(ach, 2) if ach else None, "peak": F16_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(ach / F16_MFMA_PEAK_TFLOPS, 4) if ach else None,
                          # HBM-side bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
                          # scripts/pmc_traffic.sh); not re-measured here: PMC collection needs rocprofv3
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "executed_mfma_frac": round(3 * ach / F16_MFMA_PEAK_TFLOPS, 4) if ach else None,
+                         "executed_mfma_frac": round(2.5 * ach / F16_MFMA_PEAK_TFLOPS, 4) if ach else None,
                          "pairs_per_launch": P, "launches_timed": iso_n,
                          "avg_launch_us": round(iso_ms / max(iso_n, 1) * 1e3, 2),
                          # the same launches inside the running pipeline (other streams' kernels share the chip)
@@ -933,7 +954,7 @@ def main():
         if pcie is not None:
             out["pcie"] = pcie
         if p1 is not None:
-            out["p1"] = p1
+            out["f16x3"] = p1
         out.update(sized)
         if extras:
             try:

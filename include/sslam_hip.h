@@ -247,11 +247,12 @@ int sslam_lightglue_batch_capacity(sslam_lightglue* lg, int* pairs_out);
 int sslam_lightglue_set_conf(sslam_lightglue* lg, float depth_confidence, float width_confidence,
                              float filter_threshold, int prune_min_kpts);
 /* Arithmetic of the 9 transformer layers.  0: every contraction on the exact-fp32 matrix-core
- * instruction (v_mfma_f32_32x32x2_f32).  1 (default): fp16 hi/lo split operands, three
+ * instruction (v_mfma_f32_32x32x2_f32).  1: fp16 hi/lo split operands, three
  * v_mfma_f32_32x32x16_f16 per product, fp32 accumulation (~2^-22 relative error per product).
- * 2 (opt-in): as 1, but attention carries the softmax weights P as ONE fp16 plane in P.V (two MFMAs per product there, the
- * row sum over the rounded weights): -12 % attention time; match indices identical on every parity case, token states
- * 2.4e-5 from exact instead of 4e-6 (profiles/r04_split_study.md).
+ * 2 (DEFAULT since r05): as 1, but attention carries the softmax weights P as ONE fp16 plane in P.V (two MFMAs per product
+ * there, the row sum over the rounded weights): -12 % attention time.  On north_star's bar (match indices, floats within 1e-3)
+ * modes 1 and 2 are indistinguishable over 131 199 oracle matches - the same two score-at-threshold events, score error
+ * 4.4e-5 / 1.06e-4 (profiles/r05_flip_soak.md); token states 2.4e-5 from exact in mode 2, 4e-6 in mode 1.
  * final_proj and the similarity GEMM run on the same split-operand pipe in modes 1 and 2 (exact-fp32 instruction in
  * mode 0); the dual softmax, the arg-max and the score arithmetic are fp32 in every mode. */
 int sslam_lightglue_set_precision(sslam_lightglue* lg, int mode);

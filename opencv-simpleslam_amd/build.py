@@ -41,6 +41,14 @@ def _digest(*parts) -> str:
     return h.hexdigest()
 
 
+def source_digest() -> str:
+    """12 hex digits over everything the library is built from (csrc/*.hip, *.hpp, the assembly generators, the C-ABI header),
+    names and contents: what a profile or a bench line records to say WHICH kernels it measured (the snapshot on the GPU box
+    has no .git), and what tests/test_profiles_fresh.py compares with the digest stored beside the committed profiles."""
+    files = sorted(CSRC.glob("*.hip")) + sorted(CSRC.glob("*.hpp")) + sorted(CSRC.glob("gen_*.py")) + [PKG_DIR.parent / "include" / "sslam_hip.h"]
+    return _digest(*[x for f in files for x in (f.name, f.read_bytes())])[:12]
+
+
 def _llvm_bin() -> Path:
     """clang / ld.lld of the SAME ROCm install as the hipcc in use (ROCM_PATH, else next to the resolved hipcc)."""
     roots = [os.environ.get("ROCM_PATH"), str(Path(os.path.realpath(_hipcc())).parent.parent), "/opt/rocm"]
@@ -153,5 +161,8 @@ def build_native(force: bool = False, verbose: bool = False) -> Path:
 
 
 if __name__ == "__main__":
+    if "--digest" in sys.argv:
+        print(source_digest())
+        sys.exit(0)
     p = build_native(force="--force" in sys.argv, verbose=True)
     print("built", p)

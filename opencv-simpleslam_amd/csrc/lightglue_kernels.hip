@@ -1907,13 +1907,13 @@ struct sslam_lightglue {
     float *in_xy, *in_desc, *up_xy, *up_desc, *out_score;
     int32_t *out_ij, *out_info;
     // split-precision planes (precision == 1)
-    int precision = 1;               // 0: fp32 MFMA everywhere; 1: fp16 hi/lo split, 3 MFMA per product
+    int precision = 1;               // 0: fp32 MFMA everywhere; 1: fp16 hi/lo split planes (three MFMAs per product; with p_single two in P.V)
     bool sim_exact = false;          // SSLAM_LG_SIM_EXACT=1 (experiments): the similarity GEMM stays on the fp32 matrix instruction at precision 1
     int dbg_layers = NL;             // test hook: run only the first dbg_layers layers
     int dbg_self_only = 0;           // test hook: stop after the self block of the last executed layer
     int force_ks = 0;                // test hook: key split of the attention launches (0 = by batch size)
     hipError_t launch_error = hipSuccess;   // first failure of a module-API launch (checked with hipGetLastError at the end of an enqueue)
-    int p_single = 0;                // precision "f16x3p1" (set_precision 2): P as one fp16 plane in P.V, row sums over the rounded weights
+    int p_single = 1;                // precision "f16x3p1" (set_precision 2, the DEFAULT since r05 - profiles/r05_flip_soak.md): P as one fp16 plane in P.V, row sums over the rounded weights
     int study = 0;                   // precision study (sslam_lightglue_debug_split_form): which cross terms of the split products are dropped
     _Float16* zero_plane = nullptr;  // study only: an all-zero fp16 plane standing in for a dropped low plane
     int big_gemm = -1;               // test hook: -1 by batch size, 0 / 1 force the single-pair (ring) / batched form of the linears;

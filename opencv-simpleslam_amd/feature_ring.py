@@ -30,12 +30,13 @@ from __future__ import annotations
 
 import weakref
 from collections import deque
+from itertools import compress
 
 import numpy as np
 
 from . import _native, epipolar
-from .slam.core.types import (KeyPointList, MatchList, keypoint_shells, keypoints_from_xy, match_shells, matches_from_ij,
-                              xy_from_keypoints)
+from .slam.core.types import (KeyPointList, MatchList, dmatch_edit_epoch, keypoint_shells, keypoints_from_xy, match_shells,
+                              matches_from_ij, xy_from_keypoints)
 
 
 class FrameRecord:
@@ -387,12 +388,19 @@ class DeviceFeatureRing:
             raise _native.NativeError("feature_matcher: an activation left the fp16 range of the split-precision path "
                                       "(|value| >= 65520); rescale the descriptors or use matcher.set_precision('f32')")
         ij = e["ij"]
-        if shells is not None:
+        epoch = dmatch_edit_epoch()
+        if e.get("objs") is not None and epoch is not None and e["objs_epoch"] == epoch:
+            # asked again and no DMatch anywhere has been edited since: a new list of the SAME objects (a list copy instead of
+            # hundreds of constructions - the duplicate keyframe pair of the triangulation)
+            out = MatchList(e["objs"], ij)
+        elif shells is not None:
             src.ij = ij
             del shells[k:]
             out = MatchList(shells, ij)
         else:
             out = MatchList(matches_from_ij(ij), ij)
+        if known and epoch is not None:
+            e["objs"], e["objs_epoch"] = list(out), epoch
         if known:
             self._learn(ra, rb, thr, first_ask)
             self.results.append(dict(matches=out, k=k, ij=ij, a=ra, b=rb, thr=e["filter_thr"], none=e["none"], mask=e["mask"]))
@@ -435,6 +443,6 @@ class DeviceFeatureRing:
         if r["thr"] is not None and r["thr"] == float(thresh):
             if r["none"]:                         # no model: cv2 returns mask None, the reference returns []
                 return []
-            return [m for m, ok in zip(matches, r["mask"].tolist()) if ok]
+            return list(compress(matches, r["mask"].tolist()))
         self.ransac_thr = float(thresh)
         return None

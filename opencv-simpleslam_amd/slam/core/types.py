@@ -103,6 +103,7 @@ except Exception:                          # noqa: BLE001
         its two indices from the call's [K,2] pair array on first use (then keeps them), so the objects can be
         built while the GPU is still matching."""
         __slots__ = ("_q", "_t", "imgIdx", "distance", "_src", "_i")
+        edits = 0          # bumped by every index assignment on any instance (see dmatch_edit_epoch)
 
         def __init__(self, queryIdx=-1, trainIdx=-1, imgIdx=0, distance=0.0):
             self._q = int(queryIdx)
@@ -127,6 +128,7 @@ except Exception:                          # noqa: BLE001
             if not hasattr(self, "_t"):
                 self._resolve()
             self._q = int(v)
+            DMatch.edits += 1
 
         @property
         def trainIdx(self):
@@ -141,6 +143,7 @@ except Exception:                          # noqa: BLE001
             if not hasattr(self, "_q"):
                 self._resolve()
             self._t = int(v)
+            DMatch.edits += 1
 
         def __repr__(self):
             return f"DMatch({self.queryIdx}->{self.trainIdx})"
@@ -173,6 +176,12 @@ except Exception:                          # noqa: BLE001
             m.distance = 0.0
             add(m)
         return out, src
+
+
+def dmatch_edit_epoch():
+    """A counter that moves whenever the indices of ANY DMatch of this module's duck type are assigned (None with cv2's own
+    class, which cannot be watched): match objects built before an edit may only be handed out again while it stands still."""
+    return None if HAVE_CV2 else DMatch.edits
 
 
 def keypoints_from_xy(xy):

@@ -11,7 +11,9 @@ the same C-ABI entry and the kernels the product picks at that size.  Reported p
   score   max |score difference| on the common matches
 With 0 flips in n matches the one-sided 95 % bound on the flip rate is 3 / n (rule of three).
 
-    python scripts/flip_soak.py [pairs_per_cell=17] > gpurun_out/r05_flip_soak.md
+    python scripts/flip_soak.py [pairs_per_cell=17] [cells] > gpurun_out/r05_flip_soak.md
+`cells`: optional comma list of gamma:weight-seed (gamma 0 = diffuse) restricting the run, e.g. "0:4,4:2" - to look at the
+pairs that flipped: every flipped match is printed with its score on the side that has it and the oracle's fp64 score.
 """
 import importlib
 import sys
@@ -25,7 +27,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests")); sys.path.insert(0, str(ROOT / "scripts"))
 import lg_inputs
 from oracle import lightglue_ref as R
-from split_study import sharpen
+from split_study import sharpen, fwd64
 
 W = importlib.import_module("opencv-simpleslam_amd.weights")
 LG = importlib.import_module("opencv-simpleslam_amd.lightglue").LightGlueHIP
@@ -34,6 +36,9 @@ MODES = ("f16x3", "f16x3p1")
 
 def main():
     per_cell = int(sys.argv[1]) if len(sys.argv) > 1 else 17
+    only = None
+    if len(sys.argv) > 2:
+        only = {(float(c.split(":")[0]), int(c.split(":")[1])) for c in sys.argv[2].split(",")}
     torch.set_num_threads(min(32, torch.get_num_threads()))
     t0 = time.time()
     rows = []
@@ -44,6 +49,8 @@ def main():
         acc = {m: dict(flips=0, stop=0, score=0.0, bad_pairs=0) for m in MODES}
         g_matches = g_pairs = 0
         for wseed in (1, 2, 3, 4):
+            if only is not None and (float(gamma or 0), wseed) not in only:
+                continue
             sd = W.random_lightglue_state_dict(wseed, match_gain=4.0, match_bias=3.0)
             if gamma:
                 sd = sharpen(sd, gamma)
@@ -68,7 +75,17 @@ def main():
                     ds = max((abs(got[k] - want[k]) for k in got.keys() & want.keys()), default=0.0)
                     a["score"] = max(a["score"], ds)
                     if f:
-                        worst.append((mode, gname, wseed, m_, n_, f, len(want)))
+                        if "r64" not in locals() or r64_key != (wseed, gamma, p):
+                            r64 = fwd64(sd, k0, d0, k1, d1, None)
+                            r64_key = (wseed, gamma, p)
+                            s64 = {(int(i), int(j)): float(v) for (i, j), v in zip(r64["matches"].numpy().tolist(), r64["scores"].numpy())}
+                        det = []
+                        for k in sorted(set(got) ^ set(want)):
+                            side = "HIP only" if k in got else "oracle only"
+                            val = got.get(k, want.get(k))
+                            det.append(f"({k[0]}, {k[1]}) {side}, score {val:.7f}; the oracle evaluated in fp64: "
+                                       + (f"kept, score {s64[k]:.7f}" if k in s64 else "not a match"))
+                        worst.append((mode, gname, wseed, m_, n_, f, len(want), det))
                 print(f"<!-- {gname} w{wseed} pair {p}: {m_} x {n_}, {len(want)} oracle matches, stop {ref['stop']}, {time.time() - t0:.0f} s -->", flush=True)
             lg.close()
         rows.append((gname, g_pairs, g_matches, acc))
@@ -97,6 +114,8 @@ def main():
         print("\nPairs with flips:")
         for w_ in worst:
             print(f"* {w_[0]}: {w_[1]}, weights seed {w_[2]}, {w_[3]} x {w_[4]}: {w_[5]} flips of {w_[6]} matches")
+            for d_ in w_[7]:
+                print(f"    * {d_}")
 
 
 if __name__ == "__main__":

@@ -185,6 +185,9 @@ def test_edited_match_list_is_filtered_from_scratch(rig):
     me = fu.feature_matcher(ARGS, k0, k1, d0, d1, mat)
     me[0].trainIdx = me[1].trainIdx                                                  # an element edited in place: spot check
     assert pairs(fu.filter_matches_ransac(k0, k1, me, 2.5)) == host_filter(rig, k0, k1, me, 2.5)
+    # ... and the edited OBJECT is never handed out again: the next answer is built from scratch
+    fresh = fu.feature_matcher(ARGS, k0, k1, d0, d1, mat)
+    assert pairs(fresh) == host_match(rig, k0, k1, d0, d1) and all(a is not b for a, b in zip(fresh, me))      # (`m` shares the edited object)
     # other keypoint lists (copies) for the same match list: host path
     n_host = rig.ep.host_calls
     mc = fu.feature_matcher(ARGS, k0, k1, d0, d1, mat)

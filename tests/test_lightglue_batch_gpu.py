@@ -308,16 +308,18 @@ def test_token_heads_in_the_fused_ffn_decide_like_the_separate_kernel(gpu_ctx, s
 
 
 def test_precision_f16x3p1_assembly_kernel_equals_the_4_wave_kernel_and_keeps_the_matches(gpu_ctx):
-    """r04 opt-in precision "f16x3p1": P as ONE fp16 plane in P.V (row sums over the rounded weights).  Its hand-scheduled
-    kernel (gen_lg_attention_asm_p1.py) gives what the 4-wave kernel's `p_single` branch gives, bit for bit - un-split (batch)
-    and in key ranges (single-pair policy) - and the matches of the default precision and of the oracle."""
+    """Precision "f16x3p1" (r04 opt-in, the default since r05): P as ONE fp16 plane in P.V (row sums over the rounded weights).
+    Its hand-scheduled kernel (gen_lg_attention_asm_p1.py) gives what the 4-wave kernel's `p_single` branch gives, bit for bit -
+    un-split (batch) and in key ranges (single-pair policy) - and the matches of "f16x3" and of the oracle."""
     W, LG = load_pkg("weights"), load_pkg("lightglue").LightGlueHIP
     sd = W.random_lightglue_state_dict(1, match_gain=4.0, match_bias=3.0)
     sizes = [(512, 512), (300, 417), (64, 33), (640, 1), (129, 128), (640, 640)]
     pairs = [lg_inputs.make_pair(m, n, seed=m + n) for m, n in sizes]
     batch = LG(sd, max_kpts=640, max_pairs=6, ctx=gpu_ctx)
     dev = DevBatch(gpu_ctx, pairs, 640)
-    ref = dev.run(batch, 0.0)                                   # default precision
+    assert batch.precision == 2                                 # "f16x3p1" is what an instance starts in (r05)
+    batch.set_precision("f16x3")
+    ref = dev.run(batch, 0.0)                                   # three MFMAs per product everywhere
     batch.set_precision("f16x3p1")
     got = {}
     for ks in (-3, -1, 102, 2):                                 # assembly / 4-wave kernel: no split, two key ranges

@@ -23,7 +23,7 @@ def test_bench_contract_single_rank():
     d = _run_bench({}, [sys.executable, "bench.py", "--steps", "2", "--warmup", "4", "--no-cpu-baseline"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                 "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "structured_input",
-                "exact_f32", "ba", "reproject", "step_ms", "timed_region_s", "early_stop", "dropin", "pcie", "c5", "kpts4000", "p1",
+                "exact_f32", "ba", "reproject", "step_ms", "timed_region_s", "early_stop", "dropin", "pcie", "c5", "kpts4000", "f16x3", "build",
                 "gpu_busy_s"):
         assert key in d
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["unit"] == "frames/s"
@@ -35,11 +35,15 @@ def test_bench_contract_single_rank():
     assert d["dropin"]["value"] > 0 and d["dropin"]["feature_matcher_ms"] > 0, d["dropin"]
     # the drop-in leg does the work of the reference's loop: real matches, so RANSAC / DMatch / read-back are in the number
     assert d["dropin"]["matches_median"] > 100 and d["dropin"]["filter_matches_ransac_ms"] > 0, d["dropin"]
+    # ... and the reference's real call pattern: keyframe -> cur (+ its duplicate) beyond the cooldown, answered from the device
+    sl = d["dropin"]["slam_loop"]
+    assert sl["value"] > 0 and sl["keyframe_frames"] >= 3 and sl["answered_from"]["memo"] >= 3 and sl["answered_from"]["reupload"] == 0, sl
     assert "resident in HBM" in d["config"]["workload"] and d["gpu_busy_s"] > 0
     assert d["pcie"]["value"] > 0 and d["pcie"]["h2d_bytes_per_round"] == 6 * 1241 * 376 * 3, d["pcie"]
     for leg in ("c5", "kpts4000"):
         assert d[leg].get("value", 0) > 0 and 0 < d[leg]["aliked_hbm"]["frac"] < 1, d[leg]
-    assert d["p1"]["value"] > 0 and 0 < d["p1"]["attention"]["frac"] < 1
+    assert d["f16x3"]["value"] > 0 and 0 < d["f16x3"]["attention"]["frac"] < 1 and "f16x3p1" in d["dtype"]
+    assert len(d["build"]["csrc_digest"]) == 12
     assert d["kpts4000"]["max_kpts"] == 4000 and 0 < d["kpts4000"]["attention"]["frac"] < 1
     es = d["early_stop"]
     assert es["value"] > 0 and es["lightglue_layers_histogram"] and set(es["lightglue_layers_histogram"]) != {"9"}, es
@@ -68,20 +72,10 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     assert d["config"]["frames_per_step_per_gpu"] == 6
 
 
-def test_bench_rccl_branches_with_one_rank():
-    """bench.py's N > 1 branches over RCCL on one GPU (SSLAM_BENCH_FORCE_DIST=1): `nccl` process group on the device,
-    collective barrier around the timed region, max-reduce of the times, the pipeline's collation path - same JSON
-    contract, a positive rate."""
-    import sys
-    d = _run_bench({"SSLAM_BENCH_FORCE_DIST": "1", "SSLAM_DIST_BACKEND": "nccl", "MASTER_ADDR": "127.0.0.1",
-                    "MASTER_PORT": "29623"},
-                   [sys.executable, "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "4", "--no-cpu-baseline", "--no-extras"])
-    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["frames_per_step_per_gpu"] == 6
-
-
 def test_bench_direct_rccl_with_one_rank():
-    """The default backend of `bench.py --gpus N` (RCCL driven directly, no torch in the data path) with one rank on this
-    box: the line reports the communicator's own rank count."""
+    """bench.py's N > 1 branches (SSLAM_BENCH_FORCE_DIST=1: gloo rendezvous, collective barrier around the timed region,
+    max-reduce of the times, the pipeline's collation path) on the production exchange - RCCL driven directly, no torch in
+    the data path - with one rank on this box: same JSON contract, and the line reports the communicator's own rank count."""
     import sys
     d = _run_bench({"SSLAM_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29627"},
                    [sys.executable, "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "4", "--no-cpu-baseline", "--no-extras"])
