@@ -99,6 +99,16 @@ struct FfnFusedArgs {
 #ifndef FFN_D2
 #define FFN_D2 8        // W2 fragment sets in flight per wave (steps of 2 KB)
 #endif
+// Ring depths of the 32-token tile (TT = 1: one or two pairs, pruned sets).  r05 measured twice the depth there (8 / 16 sets:
+// the tile's accumulators and LayerNorm values need 96 registers less, so it fits - 255 VGPRs, no spill - and the results are
+// bit-identical): 25.6 against 24.3 us per launch for one pair, 32.8 against 31.4 for two.  The 32-token tile does not wait
+// for its weights; what it cannot hide is the prologue / LayerNorm-GELU / epilogue chain that runs without an MFMA beside it.
+#ifndef FFN_D1_SMALL
+#define FFN_D1_SMALL FFN_D1
+#endif
+#ifndef FFN_D2_SMALL
+#define FFN_D2_SMALL FFN_D2
+#endif
 
 __device__ __forceinline__ auto ffn_rsrc(const void* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
@@ -160,17 +170,17 @@ constexpr int FFN_LEADC = FFN_LEADC_N;
 // Program order: prologue = W1 set 0 (4 loads), chunk 0 (two pieces), W1 sets 1 .. FFN_D1 - 1, chunks 1 .. LEADC - 1 -
 // what step 0 needs first in the queue; step s = [wait point] MFMAs, W1 refill (4 loads, while s + FFN_D1 < 32), then
 // chunk s / 4 + LEADC when s % 4 == 0.
-constexpr int ffn_ops_after_chunk(int c) {
+constexpr int ffn_ops_after_chunk(int c, int d1) {
     int n = 0; bool seen = false;
     for (int k = 0; k < FFN_LEADC; ++k) {
         if (seen) n += 2;
         if (k == c) seen = true;
-        if (k == 0 && seen) n += 4 * (FFN_D1 - 1);
+        if (k == 0 && seen) n += 4 * (d1 - 1);
     }
     if (c == 0) return n;
     for (int s = 0; s < 32; ++s) {
         if (s == 4 * c - 1) return n;
-        if (s + FFN_D1 < 32 && seen) n += 4;
+        if (s + d1 < 32 && seen) n += 4;
         if (s % 4 == 0 && s / 4 + FFN_LEADC < 8) { if (seen) n += 2; if (s / 4 + FFN_LEADC == c) seen = true; }
     }
     return n;
@@ -193,7 +203,7 @@ template <class F, int... I> __device__ __forceinline__ void ffn_static_for(F&& 
 // token's arithmetic is the same in both forms, bit for bit).  grow0: plane row of token 0; grow_cap: one past the
 // last plane row that may be read (rows are clamped to it); n_valid: tokens of the tile that exist (stores are masked
 // to them).  512 threads; `smem` = FFN_LDS_BYTES of dynamic LDS, 16-byte aligned.
-template <int TT = 2>
+template <int TT = 2, int D1 = (TT == 1 ? FFN_D1_SMALL : FFN_D1), int D2 = (TT == 1 ? FFN_D2_SMALL : FFN_D2)>
 __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0, int grow_cap, int n_valid,
                                                int* range_flag, _Float16* smem) {
     static_assert(TT == 1 || TT == 2, "one or two 32-token tiles per workgroup");
@@ -225,7 +235,7 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
     // W1 fragment set of step ks: [hi jt0, hi jt1, lo jt0, lo jt1], 1 KiB each, 4 KiB per (step, wave)
     auto load_w1 = [&](int ks, half8 (&dst)[4]) {
 #if FFN_ABL & 2
-        if (ks >= FFN_D1) return;
+        if (ks >= D1) return;
 #endif
         const int base = (ks * 8 + wave) * 4096;
 #pragma unroll
@@ -233,7 +243,7 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
     };
     auto load_w2 = [&](int ks, half8 (&dst)[2]) {
 #if FFN_ABL & 2
-        if (ks >= FFN_D2) return;
+        if (ks >= D2) return;
 #endif
         const int base = (ks * 8 + wave) * 2048;
         dst[0] = ffn_ldfrag(r_w2, lane16, base);
@@ -243,7 +253,7 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
     // ------------------------------------------------------------------ prologue
     // the first W1 fragment sets (plain loads, to registers), then the operand tile by LDS-DMA: wave w
     // brings rows 16 (w & 3) .. + 15 of plane (w >> 2) of every k-panel (16 pieces of 16 rows x 64 B)
-    half8 wq[FFN_D1][4];
+    half8 wq[D1][4];
     load_w1(0, wq[0]);
     const int prow = lane >> 2, pc = lane & 3;
     const int psw = (pc ^ ((prow >> 2) & 3)) * 8;
@@ -267,11 +277,11 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
     issue_chunk(0);
     __builtin_amdgcn_sched_barrier(0);                 // (the queue order is the point: set 0, chunk 0, then the rest)
 #pragma unroll
-    for (int d = 1; d < FFN_D1; ++d) load_w1(d, wq[d]);
+    for (int d = 1; d < D1; ++d) load_w1(d, wq[d]);
 #pragma unroll
     for (int c = 1; c < FFN_LEADC; ++c) issue_chunk(c);
     __builtin_amdgcn_sched_barrier(0);
-    ffn_wait_vm<ffn_ops_after_chunk(0)>();             // own pieces of chunk 0 (and W1 set 0, older) have landed
+    ffn_wait_vm<ffn_ops_after_chunk(0, D1)>();             // own pieces of chunk 0 (and W1 set 0, older) have landed
     __builtin_amdgcn_s_barrier();
     FFN_STAMP_AT(1);
 
@@ -312,12 +322,12 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
     {
         half8 ah0[TT], al0[TT], ah1[TT], al1[TT];
         read_a(0, ah0, al0);
-        static_assert(32 % FFN_D1 == 0 && FFN_D1 % 2 == 0, "the ring of W1 fragment sets divides the 32 steps, even depth");
+        static_assert(32 % D1 == 0 && D1 % 2 == 0, "the ring of W1 fragment sets divides the 32 steps, even depth");
         ffn_static_for([&](auto ks_c) {
-            constexpr int ks = decltype(ks_c)::value, u = ks % FFN_D1;
+            constexpr int ks = decltype(ks_c)::value, u = ks % D1;
             if constexpr (ks % 4 == 3 && (ks + 1) / 4 < 8) {
                 // the next step's fragments come from chunk (ks + 1) / 4: own pieces landed, then everybody's
-                ffn_wait_vm<ffn_ops_after_chunk((ks + 1) / 4)>();
+                ffn_wait_vm<ffn_ops_after_chunk((ks + 1) / 4, D1)>();
                 __builtin_amdgcn_s_barrier();
             }
             if constexpr (ks & 1) {
@@ -327,9 +337,9 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
                 read_a(ks + 1, ah1, al1);
                 mma1(wq[u], ah0, al0);
             }
-            if constexpr (ks + FFN_D1 < 32) load_w1(ks + FFN_D1, wq[u]);
+            if constexpr (ks + D1 < 32) load_w1(ks + D1, wq[u]);
             if constexpr (ks % 4 == 0 && ks / 4 + FFN_LEADC < 8) issue_chunk(ks / 4 + FFN_LEADC);
-            // keep the refill HERE, FFN_D1 steps ahead of its use: left alone the scheduler sinks it to just
+            // keep the refill HERE, D1 steps ahead of its use: left alone the scheduler sinks it to just
             // in front of the consuming MFMAs (fewer live registers, one exposed L2 round trip per step)
             __builtin_amdgcn_sched_barrier(0);
         }, std::make_integer_sequence<int, 32>{});
@@ -337,9 +347,9 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
     FFN_STAMP_AT(2);
 
     // W2 starts streaming now: its first fragment sets land while the LayerNorm / GELU arithmetic runs
-    half8 vq[FFN_D2][2];
+    half8 vq[D2][2];
 #pragma unroll
-    for (int d = 0; d < FFN_D2; ++d) load_w2(d, vq[d]);
+    for (int d = 0; d < D2; ++d) load_w2(d, vq[d]);
 
     // ------------------------------------------------------------------ LayerNorm + GELU + split, in registers
     // v[jt][tt][r] = h[j = 64 w + 32 jt + (r & 3) + 8 (r >> 2) + 4 h][tok = 32 tt + lr]
@@ -470,10 +480,10 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
     {
         half8 gh0[TT], gl0[TT], gh1[TT], gl1[TT];
         read_g(0, gh0, gl0);
-        static_assert(32 % FFN_D2 == 0 && FFN_D2 % 2 == 0, "the ring of W2 fragment sets divides the 32 steps, even depth");
-        for (int ks0 = 0; ks0 < 32; ks0 += FFN_D2) {
+        static_assert(32 % D2 == 0 && D2 % 2 == 0, "the ring of W2 fragment sets divides the 32 steps, even depth");
+        for (int ks0 = 0; ks0 < 32; ks0 += D2) {
 #pragma unroll
-            for (int u = 0; u < FFN_D2; ++u) {
+            for (int u = 0; u < D2; ++u) {
                 const int ks = ks0 + u;
                 if (u & 1) {
                     if (ks + 1 < 32) read_g(ks + 1, gh0, gl0);
@@ -482,7 +492,7 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
                     read_g(ks + 1, gh1, gl1);
                     mma2(vq[u], gh0, gl0);
                 }
-                if (ks + FFN_D2 < 32) load_w2(ks + FFN_D2, vq[u]);
+                if (ks + D2 < 32) load_w2(ks + D2, vq[u]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
