@@ -21,8 +21,9 @@ def tick(name, t0):
     t1 = time.perf_counter(); T.setdefault(name, []).append(t1 - t0); return t1
 K = ring.K
 prev = None
-for im in imgs[3:]:
-    sl = ring.slots[ring.turn % ring.SLOTS]; ring.turn += 1
+ring.forget_patterns()
+for turn, im in enumerate(imgs[3:]):
+    sl = ring.slots[turn % ring.SLOTS]                # (white box: the ring's device records used directly, step by step)
     ctx.sync()
     t = time.perf_counter()
     ctx.h2d(ring.img_dev, im); t = tick("h2d image (pageable, synchronous)", t)

@@ -1,5 +1,5 @@
 """Device-side timing of the batched LightGlue entry (B pairs per enqueue, HIP events).
-usage: time_lightglue_batch.py [N=2048] [B=4] [iters=10] [precision=1]"""
+usage: time_lightglue_batch.py [N=2048] [B=4] [iters=10] [precision=2]   (2 = "f16x3p1", the default of an instance since r05; 1 = "f16x3"; 0 = "f32")"""
 import importlib, sys
 from pathlib import Path
 import numpy as np
@@ -9,7 +9,7 @@ import lg_inputs
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
-prec = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+prec = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 pkg = importlib.import_module("opencv-simpleslam_amd")
 W = importlib.import_module("opencv-simpleslam_amd.weights")
 LG = importlib.import_module("opencv-simpleslam_amd.lightglue").LightGlueHIP
