@@ -37,9 +37,9 @@ with open(f"gpurun_out/{tag}_pmc_traffic.csv", "w") as fh:
         fh.write(f"\"{r[0]}\",{r[1]},{r[2]:.3f},{r[3]:.3f}\n")
         print(f"{r[0]:90s} n={r[1]:4d} fetch {r[2]:8.2f} MB  write {r[3]:8.2f} MB per launch")
 for r in rows:
-    if "lg_attention_asm_kernel" in r[0]:
+    if "lg_attention_asm" in r[0]:                       # (lg_attention_asm_kernel = f16x3, lg_attention_asm_p1_kernel = f16x3p1, the default)
         K, NI = 2048, 2 * B
-        json.dump({"kernel": "lg_attention_asm_kernel", "workload": f"{B} pairs of 2048 x 2048 per launch, 4 heads x 64, no key split",
+        json.dump({"kernel": r[0].strip('"'), "workload": f"{B} pairs of 2048 x 2048 per launch, 4 heads x 64, no key split",
                    "fetch_bytes_per_launch": int(r[2] * 1e6), "write_bytes_per_launch": int(r[3] * 1e6),
                    "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes with --kernel-trace "
                              "(scripts/pmc_traffic.sh); FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md; counters in KiB",
