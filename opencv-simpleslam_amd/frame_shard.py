@@ -323,7 +323,7 @@ class FrameStreamPipeline:
             # multi-GPU: the batch with the halo pair (previous frame = a neighbour's record, in place only after this
             # round's all-gathers) goes LAST; the others need local extracts only and start under the collation
             # (r03: enqueued first, it held every matcher stream back until the whole round was extracted and gathered -
-            # 957 -> see DESIGN section 7)
+            # 957 -> see HISTORY.md section 7)
             spans = spans[1:] + spans[:1]
         j = 0
         for s0, s1 in spans:

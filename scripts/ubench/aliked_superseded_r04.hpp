@@ -1,4 +1,4 @@
-// ALIKED kernels superseded during round 4 - kept OUTSIDE the product as the record DESIGN section 4 refers to (not compiled by
+// ALIKED kernels superseded during round 4 - kept OUTSIDE the product as the record HISTORY.md section 4 refers to (not compiled by
 // build.py; they need the helpers of csrc/aliked_kernels.hip at the commit named below to build again).
 //   al_conv3x3_mfma_kernel     r03 implicit-GEMM 3 x 3 convolution on the exact-fp32 MFMA, one tile per workgroup
 //   al_conv3x3_sweep_kernel    the same as a four-wave vertical sweep with register prefetch (+ sweep_load / sweep_stash)
