@@ -183,10 +183,9 @@ class FrameStreamPipeline:
         self.slab = self.ctx.malloc(dev_bytes)
         self.ctx.memset_async(self.slab, 0, dev_bytes)
         if self.distributed:
-            from . import _native
-            # the collation has a stream of its own: on an extractor's stream the first half-round gather would hold back
-            # that extractor's second half
-            self.cctx = _native.Context(self.ctx.device)
+            # the collation has a stream of its own (a context of the same kind as the extractors'): on an extractor's stream
+            # the first half-round gather would hold back that extractor's second half
+            self.cctx = type(self.ctx)(self.ctx.device)
             # gathered rounds, one buffer per round parity: the previous round's last record (the halo of this round's
             # first pair on rank 0) is read where it was gathered - no copy of the map, no allocation
             gbytes = plan.world * B * self.REC * 4

@@ -1,7 +1,7 @@
 """A CPU stand-in for the native layer UNDER the drop-in names, for tests of the host logic only (feature_ring.py:
 residency, memo, look-ahead scheduling; features_utils.py: argument handling) where there is no GPU.
 
-"Device memory" is one numpy byte arena (addresses are offsets into it); streams execute at enqueue time, so every
+"Device memory" is a process-wide heap of numpy buffers found by address; streams execute at enqueue time, so every
 `sync()` is a no-op and ordering bugs are NOT what this catches - the -m gpu tests run the same scenarios on the real
 library.  The fake extractor / matcher / filter are deterministic functions of their inputs, the same function on the
 "device" and on the "host" entry, so the tests can demand that every path returns the same thing.  Nothing here is the
@@ -11,27 +11,52 @@ import numpy as np
 BASE = 0x10000
 
 
-class FakeContext:
-    def __init__(self, arena_bytes=96 << 20):
-        self.mem = np.zeros(arena_bytes, np.uint8)
-        self.top = 0
-        self.device = 0
-        self.syncs = 0
+class _Heap:
+    """The "device memory" of a process: every FakeContext of the process allocates from it (as every stream of a GPU sees
+    the same memory), allocations are separate numpy buffers found by address."""
 
-    def view(self, dptr, nbytes):
-        o = int(dptr) - BASE
-        assert 0 <= o and o + nbytes <= self.top, "fake device: access outside allocated memory"
-        return self.mem[o:o + nbytes]
+    def __init__(self):
+        self.blocks = []                 # sorted (start address, uint8 buffer)
+        self.top = BASE
 
     def malloc(self, nbytes):
-        p = BASE + self.top
-        self.top += (int(nbytes) + 255) // 256 * 256
-        assert self.top <= len(self.mem), "fake device arena exhausted"
+        n = (int(nbytes) + 255) // 256 * 256
+        p = self.top
+        self.blocks.append((p, np.zeros(n, np.uint8)))
+        self.top += n + 256              # (a guard gap: running off the end of a block is an error, not a neighbour's data)
         return p
+
+    def view(self, dptr, nbytes):
+        import bisect
+        dptr = int(dptr)
+        i = bisect.bisect_right(self.blocks, dptr, key=lambda b: b[0]) - 1
+        assert i >= 0, "fake device: address below every allocation"
+        start, buf = self.blocks[i]
+        o = dptr - start
+        assert 0 <= o and o + nbytes <= len(buf), "fake device: access outside an allocation"
+        return buf[o:o + nbytes]
+
+
+_HEAP = _Heap()
+
+
+class FakeContext:
+    def __init__(self, device=0, stream=None):
+        self.heap = _HEAP
+        self.device = int(device)
+        self.syncs = 0
+        self.stream = 0
+
+    def view(self, dptr, nbytes):
+        return self.heap.view(dptr, nbytes)
+
+    def malloc(self, nbytes):
+        return self.heap.malloc(nbytes)
 
     def free(self, dptr): pass
     def sync(self): self.syncs += 1
     def event(self): return 1
+    def timing_event(self): return 1
     def record(self, ev): pass
     def wait(self, ev): pass
 
@@ -44,36 +69,59 @@ class FakeContext:
 
     h2d_async = h2d
 
+    def upload(self, arr):
+        a = np.ascontiguousarray(arr)
+        p = self.malloc(max(a.nbytes, 1))
+        if a.nbytes:
+            self.h2d(p, a)
+        return p
+
     def d2h_async(self, arr, dptr, nbytes=None):
         n = arr.nbytes if nbytes is None else int(nbytes)
         arr.view(np.uint8).reshape(-1)[:n] = self.view(dptr, n)
 
     d2h = d2h_async
 
+    def d2d_async(self, dst, src, nbytes):
+        self.view(dst, nbytes)[:] = self.view(src, nbytes).copy()
+
+    def memset_async(self, dst, value, nbytes):
+        self.view(dst, nbytes)[:] = value
+
     def f32(self, dptr, n): return self.view(dptr, 4 * n).view(np.float32)
     def i32(self, dptr, n): return self.view(dptr, 4 * n).view(np.int32)
 
 
 class FakeAliked:
-    """Serves the frames of a synthetic chain (tests/lg_inputs.py::make_chain) in extraction order, so that frames match;
-    the image only has to be a valid uint8 array."""
+    """Serves the frames of a synthetic chain (tests/lg_inputs.py::make_chain) so that frames match: in extraction order, or -
+    `by_image=True` - the chain frame whose index the image carries in its first two bytes (the frame-sharded pipeline
+    extracts frames in any order on any rank).  The image only has to be a valid uint8 array in allocated memory."""
 
-    def __init__(self, ctx, chain, max_num_keypoints=256):
+    def __init__(self, ctx, chain, max_num_keypoints=256, by_image=False, max_frames=1):
         self.ctx, self.max_num_keypoints, self.chain = ctx, int(max_num_keypoints), chain
+        self.by_image, self.max_frames = by_image, int(max_frames)
         self.calls = 0
 
     def use_graphs(self, enable=True): pass
     def close(self): pass
+    def range_overflow(self): return False
 
     def extract_dev(self, img_dev, H, Wd, Cn, xy_out, desc_out, score_out, n_out, max_kpts=None):
-        xy, d = self.chain[self.calls % len(self.chain)]
+        img = self.ctx.view(img_dev, H * Wd * Cn)      # (the image must have been uploaded into allocated memory)
+        idx = int(img[0]) + 256 * int(img[1]) if self.by_image else self.calls
+        xy, d = self.chain[idx % len(self.chain)]
         self.calls += 1
-        self.ctx.view(img_dev, H * Wd * Cn)            # (the image must have been uploaded into allocated memory)
         n = len(xy)
         assert n <= int(max_kpts or self.max_num_keypoints)
         self.ctx.f32(xy_out, 2 * n)[:] = xy.reshape(-1)
         self.ctx.f32(desc_out, 128 * n)[:] = d.reshape(-1)
-        self.ctx.i32(n_out, 4)[:] = (n, 0, 0, 0)
+        self.ctx.i32(n_out, 1)[:] = n
+
+    def extract_batch_dev(self, imgs_dev, H, Wd, Cn, xy_out, desc_out, score_out, n_out, max_kpts=None):
+        assert 1 <= len(imgs_dev) <= self.max_frames
+        for f in range(len(imgs_dev)):
+            self.extract_dev(imgs_dev[f], H, Wd, Cn, xy_out[f], desc_out[f], None if score_out is None else score_out[f],
+                             n_out[f], max_kpts=max_kpts)
 
 
 def fake_match(xy0, d0, xy1, d1, min_conf):
@@ -102,6 +150,7 @@ class FakeLightGlue:
         self.dev_calls, self.dev_pairs, self.host_calls = 0, 0, 0
 
     def close(self): pass
+    def use_graphs(self, enable=True): pass
     def range_overflow(self): return False
     def parameters(self): return iter(())
 

@@ -63,7 +63,7 @@ def _worker(rank, world, port, out_dir):
     plan = fs.ShardPlan(world, rank, B)
     comm = fs.GlooRowsComm(rank, world)
     assert comm.count() == world
-    ctx = fake_device.FakeContext(8 << 20)                 # "device memory" of this rank: the exchange works on raw addresses
+    ctx = fake_device.FakeContext()                        # "device memory" of this rank: the exchange works on raw addresses
     rb = fs.record_floats(K) * 4
     local, gathered = ctx.malloc(B * rb), ctx.malloc(world * B * rb)
     for rnd in range(2):
@@ -112,3 +112,68 @@ def test_a_multi_rank_pipeline_needs_an_exchange():
     fs = load_pkg("frame_shard")
     with pytest.raises(ValueError, match="comm"):
         fs.FrameStreamPipeline([], [], fs.ShardPlan(2, 0, 3), 8)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The WHOLE pipeline choreography at world size 8 on CPU: FrameStreamPipeline.round itself (frame ownership, record sets,
+# per-half collation, the halo record - rank 0's from the previous round's map, the others' from the neighbour's last frame
+# of the same round -, batch spans and their order) over stand-ins for the extractor / matcher / device memory
+# (tests/fake_device.py: everything executes at enqueue time, so stream ORDERING is not what this covers - the shared-GPU
+# and RCCL tests of tests/test_pipeline_gpu.py do) and the gloo exchange.  The driver's 8-GPU SCALE run is the first
+# execution of this choreography on eight real devices; this is its rehearsal.
+def _pipeline_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+    import importlib
+    import fake_device as fd
+    import lg_inputs
+    torch.set_num_threads(1)
+    fs = importlib.import_module("opencv-simpleslam_amd.frame_shard")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, K, P, ROUNDS, H, Wd = 3, 64, 2, 3, 4, 4
+    n_frames = ROUNDS * world * B
+    chain = lg_inputs.make_chain(n_frames, K, seed=9, period=4)
+    plan = fs.ShardPlan(world, rank, B)
+    dets = [fd.FakeAliked(fd.FakeContext(), chain, K, by_image=True, max_frames=2) for _ in range(2)]
+    mats = [fd.FakeLightGlue(fd.FakeContext(), K, max_pairs=P) for _ in range(2)]
+    pipe = fs.FrameStreamPipeline(dets, mats, plan, K, 0.3, batch_pairs=P, comm=fs.GlooRowsComm(rank, world))
+    ctx = pipe.ctx
+
+    def image(f):
+        img = np.zeros((H, Wd, 3), np.uint8)
+        img.reshape(-1)[:2] = (f % 256, f // 256)
+        return img
+    checked = 0
+    for rnd in range(ROUNDS):
+        mine = list(plan.frames(rnd))
+        pipe.round(ctx.upload(np.stack([image(f) for f in mine])), H, Wd, 3)
+        pipe.sync()
+        info = pipe.infos()
+        res = pipe.results()
+        feats = pipe.features()
+        smap = np.empty((world * B, pipe.REC), np.float32)
+        ctx.d2h(smap, pipe.shared_map_ptr)
+        for s, f in enumerate(mine):
+            np.testing.assert_array_equal(feats[s][0], chain[f][0])
+            np.testing.assert_array_equal(feats[s][1], chain[f][1])
+            if f == 0:
+                continue
+            want_ij, want_sc = fd.fake_match(chain[f - 1][0], chain[f - 1][1], chain[f][0], chain[f][1], 0.3)
+            assert info[s, 0] == len(want_ij) > 8, (rank, rnd, f, info[s])
+            np.testing.assert_array_equal(res[s][0], want_ij, err_msg=f"rank {rank} round {rnd} frame {f} (pair with frame {f - 1})")
+            checked += 1
+        for j in range(world * B):                           # the collated map: every rank's frames of the round, frame order
+            f = rnd * world * B + j
+            n, xy, desc = fs.unpack_record(smap[j], K)
+            assert n == K
+            np.testing.assert_array_equal(xy, chain[f][0]); np.testing.assert_array_equal(desc, chain[f][1])
+    np.save(Path(out_dir) / f"checked_{rank}.npy", np.array([checked]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_pipeline_choreography_world_n_on_cpu(tmp_path, world):
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    checked = [int(np.load(tmp_path / f"checked_{r}.npy")[0]) for r in range(world)]
+    assert checked[0] == 3 * 3 - 1 and all(c == 3 * 3 for c in checked[1:])          # every pair of every rank, frame 0 excepted
