@@ -108,47 +108,88 @@ __device__ int update_num_iters(double p, double ep, int model_points, int max_i
 }
 
 // ---- 1. replay the sample stream for samples [h0, h1) (one lane) ------------------------------
-__global__ void rs_subsets_kernel(RSArgs a) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// r05: the lane's collinearity tests read 2 x 7 points per attempt - dependent global loads, ~3 us per sample, 50 us for the
+// 16-sample first chunk that is all a matcher's inlier ratios ever need.  The workgroup now copies both point sets into LDS
+// first (when they fit: RS_LDS_POINTS) and the lane reads them from there; a chunk that has nothing to do (budget already
+// below its first sample) leaves before the copy.
+constexpr int RS_LDS_POINTS = 4096;      // 2 x 4096 x 8 bytes = 64 KB of dynamic LDS at most
+__global__ __launch_bounds__(256) void rs_subsets_kernel(RSArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float rs_pts[];      // [p1: n x 2 | p2: n x 2] when n <= RS_LDS_POINTS
+    __shared__ int go;
     RSCtrl* c = a.ctrl;
     const int n = rs_n(a);
-    if (a.h0 == 0) {
-        c->lmeds = n <= RS_LMEDS_MAX;
-        c->budget = max(a.max_iters, 1);
-        if (c->lmeds) c->budget = max(update_num_iters(a.confidence, 0.45, RS_MP, a.max_iters), 1);   // LMeDS: fixed budget
-        c->rng_state = 0xffffffffffffffffULL;
-        c->n_subsets = 0; c->exhausted = 0;
-        c->best_h = c->best_k = -1;
-        c->best_count = 0; c->niters = 0; c->max_good = 0;
-        c->min_median = DBL_MAX;
-        if (n < 8) c->exhausted = 1;          // _dev entry with a device count: fewer than 8 matches pass through unfiltered
+    if (threadIdx.x == 0) {
+        if (a.h0 == 0) {
+            c->lmeds = n <= RS_LMEDS_MAX;
+            c->budget = max(a.max_iters, 1);
+            if (c->lmeds) c->budget = max(update_num_iters(a.confidence, 0.45, RS_MP, a.max_iters), 1);   // LMeDS: fixed budget
+            c->rng_state = 0xffffffffffffffffULL;
+            c->n_subsets = 0; c->exhausted = 0;
+            c->best_h = c->best_k = -1;
+            c->best_count = 0; c->niters = 0; c->max_good = 0;
+            c->min_median = DBL_MAX;
+            if (n < 8) c->exhausted = 1;          // _dev entry with a device count: fewer than 8 matches pass through unfiltered
+        }
+        go = !c->exhausted && a.h0 < min(a.h1, c->budget);
     }
-    if (c->exhausted) return;
+    __syncthreads();
+    if (!go) return;
+    const bool in_lds = n <= RS_LDS_POINTS;
+    if (in_lds) {
+        for (int i = threadIdx.x; i < 2 * n; i += blockDim.x) { rs_pts[i] = a.p1[i]; rs_pts[2 * n + i] = a.p2[i]; }
+        __syncthreads();
+    }
+    if (threadIdx.x >= 64) return;                 // one wave samples: lane 0 owns the RNG, lanes 0 .. 29 share the collinearity tests
+    const int lane = threadIdx.x;
+    const float* p1 = in_lds ? rs_pts : a.p1;
+    const float* p2 = in_lds ? rs_pts + 2 * n : a.p2;
+    // haveCollinearPoints tests the LAST point of the subset against every earlier pair (j, k < j): 15 pairs x 2 point sets =
+    // 30 independent tests, one per lane (a single lane spent ~1 200 instructions per sample on them, most of the 46 us of the
+    // first chunk); the verdict is their OR, as in last_point_collinear
+    const int q = lane % 15, set = lane / 15;
+    int tj = 1, tk = 0;
+    for (int t = 0; t < q; ++t) { if (++tk == tj) { ++tj; tk = 0; } }        // q -> (j, k): (1,0) (2,0) (2,1) (3,0) ...
     CvRng rng{c->rng_state};
     const int end = min(a.h1, c->budget);
     int made = c->n_subsets;
+    bool exhausted = false;
     for (int it = a.h0; it < end; ++it) {
         int idx[RS_MP];
         int attempts = 0;
         for (; attempts < RS_SUBSET_ATTEMPTS; ++attempts) {
-            for (int i = 0; i < RS_MP; ++i) {
-                int v;
-                bool dup;
-                do {
-                    v = rng.uniform(0, n);
-                    dup = false;
-                    for (int j = 0; j < i; ++j) dup |= idx[j] == v;
-                } while (dup);
-                idx[i] = v;
+            if (lane == 0) {
+                for (int i = 0; i < RS_MP; ++i) {
+                    int v;
+                    bool dup;
+                    do {
+                        v = rng.uniform(0, n);
+                        dup = false;
+                        for (int j = 0; j < i; ++j) dup |= idx[j] == v;
+                    } while (dup);
+                    idx[i] = v;
+                }
             }
-            if (!last_point_collinear(a.p1, idx, RS_MP) && !last_point_collinear(a.p2, idx, RS_MP)) break;
+#pragma unroll
+            for (int i = 0; i < RS_MP; ++i) idx[i] = __shfl(idx[i], 0);
+            bool bad = false;
+            if (lane < 30) {
+                const float* p = set ? p2 : p1;
+                const float xi = p[2 * idx[RS_MP - 1]], yi = p[2 * idx[RS_MP - 1] + 1];
+                const double dx1 = p[2 * idx[tj]] - xi, dy1 = p[2 * idx[tj] + 1] - yi;
+                const double dx2 = p[2 * idx[tk]] - xi, dy2 = p[2 * idx[tk] + 1] - yi;
+                bad = fabs(dx2 * dy1 - dy2 * dx1) <= (double)FLT_EPSILON * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2));
+            }
+            if (!__any(bad)) break;
         }
-        if (attempts == RS_SUBSET_ATTEMPTS) { c->exhausted = 1; break; }   // getSubset failed: the loop ends here
-        for (int i = 0; i < RS_MP; ++i) a.subsets[it * RS_MP + i] = idx[i];
+        if (attempts == RS_SUBSET_ATTEMPTS) { exhausted = true; break; }   // getSubset failed: the loop ends here
+        if (lane < RS_MP) a.subsets[it * RS_MP + lane] = idx[lane];
         ++made;
     }
-    c->n_subsets = made;
-    c->rng_state = rng.state;
+    if (lane == 0) {
+        if (exhausted) c->exhausted = 1;
+        c->n_subsets = made;
+        c->rng_state = rng.state;
+    }
 }
 
 // ---- 2. 7-point solver (thread / sample) -------------------------------------------------------
@@ -208,15 +249,19 @@ __device__ int solve_cubic(const double* c, double* r) {
 }
 
 __global__ __launch_bounds__(64) void rs_models_kernel(RSArgs a) {
+    // The 7 x 9 system of a sample, element-major / lane-minor in LDS: the elimination below indexes it with the PIVOT's row
+    // and column, which are per-lane values - as a private array it lived in scratch memory (512 bytes per thread, every access
+    // a ~1 us round trip: 33 us for the eight samples of the first chunk, r05 kernel trace); LDS takes per-lane indices as is.
+    __shared__ double As[RS_MP * 9 * 64];
+#define RS_A(i, j) As[((i) * 9 + (j)) * 64 + threadIdx.x]
     const int h = a.h0 + blockIdx.x * 64 + threadIdx.x;
     if (h >= a.h1 || h >= a.ctrl->n_subsets) return;
     // rows: (m2, 1)^T F (m1, 1) = 0
-    double A[RS_MP][9];
     for (int i = 0; i < RS_MP; ++i) {
         const int id = a.subsets[h * RS_MP + i];
         const double x0 = a.p1[2 * id], y0 = a.p1[2 * id + 1], x1 = a.p2[2 * id], y1 = a.p2[2 * id + 1];
-        A[i][0] = x1 * x0; A[i][1] = x1 * y0; A[i][2] = x1; A[i][3] = y1 * x0; A[i][4] = y1 * y0; A[i][5] = y1;
-        A[i][6] = x0; A[i][7] = y0; A[i][8] = 1;
+        RS_A(i, 0) = x1 * x0; RS_A(i, 1) = x1 * y0; RS_A(i, 2) = x1; RS_A(i, 3) = y1 * x0; RS_A(i, 4) = y1 * y0; RS_A(i, 5) = y1;
+        RS_A(i, 6) = x0; RS_A(i, 7) = y0; RS_A(i, 8) = 1;
     }
     // Gauss-Jordan with complete pivoting -> two free columns span the null space
     int colp[9];
@@ -227,27 +272,27 @@ __global__ __launch_bounds__(64) void rs_models_kernel(RSArgs a) {
         double best = -1.0;
         for (int i = k; i < RS_MP; ++i)
             for (int j = k; j < 9; ++j) {
-                const double v = fabs(A[i][j]);
+                const double v = fabs(RS_A(i, j));
                 if (v > best) { best = v; pr = i; pc = j; }
             }
         if (!(best > 0.0)) { ok = false; break; }
-        for (int j = 0; j < 9; ++j) { const double tmp = A[k][j]; A[k][j] = A[pr][j]; A[pr][j] = tmp; }
-        for (int i = 0; i < RS_MP; ++i) { const double tmp = A[i][k]; A[i][k] = A[i][pc]; A[i][pc] = tmp; }
+        for (int j = 0; j < 9; ++j) { const double tmp = RS_A(k, j); RS_A(k, j) = RS_A(pr, j); RS_A(pr, j) = tmp; }
+        for (int i = 0; i < RS_MP; ++i) { const double tmp = RS_A(i, k); RS_A(i, k) = RS_A(i, pc); RS_A(i, pc) = tmp; }
         { const int tmp = colp[k]; colp[k] = colp[pc]; colp[pc] = tmp; }
-        const double inv = 1.0 / A[k][k];
-        for (int j = k; j < 9; ++j) A[k][j] *= inv;
+        const double inv = 1.0 / RS_A(k, k);
+        for (int j = k; j < 9; ++j) RS_A(k, j) *= inv;
         for (int i = 0; i < RS_MP; ++i) {
             if (i == k) continue;
-            const double f = A[i][k];
+            const double f = RS_A(i, k);
             if (f != 0.0)
-                for (int j = k; j < 9; ++j) A[i][j] -= f * A[k][j];
+                for (int j = k; j < 9; ++j) RS_A(i, j) -= f * RS_A(k, j);
         }
     }
     int nm = 0;
     double* out = a.models + (size_t)h * 27;
     if (ok) {
         double f1[9], f2[9];             // null vectors for free columns 7 and 8 (permuted order)
-        for (int k = 0; k < RS_MP; ++k) { f1[colp[k]] = -A[k][7]; f2[colp[k]] = -A[k][8]; }
+        for (int k = 0; k < RS_MP; ++k) { f1[colp[k]] = -RS_A(k, 7); f2[colp[k]] = -RS_A(k, 8); }
         f1[colp[7]] = 1.0; f1[colp[8]] = 0.0;
         f2[colp[7]] = 0.0; f2[colp[8]] = 1.0;
         // F(lambda) = lambda f1 + (1 - lambda) f2 = lambda (f1 - f2) + f2; det F = 0 is a cubic
@@ -280,6 +325,7 @@ __global__ __launch_bounds__(64) void rs_models_kernel(RSArgs a) {
         }
     }
     a.nmodels[h] = nm;
+#undef RS_A
 }
 
 // symmetric epipolar error of FMEstimatorCallback::computeError (double arithmetic, float result)
@@ -453,12 +499,15 @@ void rs_enqueue(hipStream_t s, RSArgs a, int max_iters) {
     // chunk is small - with the inlier ratios a matcher's output has, OpenCV's budget drops below 16 after the first good
     // model and the 128-sample first chunk of r03 spent 180 us drawing samples the loop never looks at (r04: a call on ~600
     // matches 324 -> ~90 us of GPU time) - and the rest are few and large: the result does not depend on the chunking.
-    const int bounds[] = {0, 16, 128, 512, max_iters};
+    // (r05: three chunks instead of four - a chunk that has nothing to do still costs its four launches, ~19 us - and a first
+    //  chunk of 8: at a matcher's inlier ratios the budget is 3 - 5 after the first all-inlier sample)
+    const int bounds[] = {0, 8, 128, max_iters};
+    const size_t pts_lds = (size_t)std::min(a.n, RS_LDS_POINTS) * 16;
     (void)hipGetLastError();     // (a stale error of another library on this thread is not ours)
-    for (int ci = 0; ci < 4; ++ci) {
+    for (int ci = 0; ci < 3; ++ci) {
         a.h0 = std::min(bounds[ci], max_iters); a.h1 = std::min(bounds[ci + 1], max_iters);
         if (a.h1 <= a.h0) continue;
-        hipLaunchKernelGGL(rs_subsets_kernel, dim3(1), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(rs_subsets_kernel, dim3(1), dim3(256), pts_lds, s, a);
         hipLaunchKernelGGL(rs_models_kernel, dim3(sslam::cdiv(a.h1 - a.h0, 64)), dim3(64), 0, s, a);
         hipLaunchKernelGGL(rs_score_kernel, dim3(a.h1 - a.h0, 3), dim3(RS_T), 0, s, a);
         hipLaunchKernelGGL(rs_select_kernel, dim3(1), dim3(64), 0, s, a);
