@@ -215,7 +215,7 @@ def dropin_leg(n_frames=48):
         stats0 = dict(ring.stats)
         kp_prev, des_prev = fu.feature_extractor(args, imgs[0], det)
         kf, last_kf = (kp_prev, des_prev), 0
-        te, tm, tr, tk, tot, nm, nf, nk = [], [], [], [], [], [], [], []
+        te, tm, tr, tk, tot, nm, nf, nk, kf_flags = [], [], [], [], [], [], [], [], []
         for i, im in enumerate(imgs[1:]):
             f = i + 1
             t0 = time.perf_counter(); kp, des = fu.feature_extractor(args, im, det); t1 = time.perf_counter()
@@ -233,7 +233,7 @@ def dropin_leg(n_frames=48):
             t4 = time.perf_counter()
             kp_prev, des_prev = kp, des
             if f >= (2 * (KF_COOLDOWN + 1) if keyframes else 3):            # warm-up: graph capture, first touches, the learned patterns
-                te.append(t1 - t0); tm.append(t2 - t1); tr.append(t3 - t2); tot.append(t4 - t0)
+                te.append(t1 - t0); tm.append(t2 - t1); tr.append(t3 - t2); tot.append(t4 - t0); kf_flags.append(bool(extra))
                 if extra:
                     tk.append(t4 - t3)
                 nm.append(len(m)); nf.append(len(flt))
@@ -247,8 +247,17 @@ def dropin_leg(n_frames=48):
             out["keyframe_extra_calls_ms"] = med(tk)
             out["keyframe_matches_median"] = [int(v) for v in np.median(np.array(nk), axis=0)] if nk else None
             out["mean_ms_per_frame"] = round(float(np.mean(tot)) * 1e3, 3)
+            plain = [t for t, k in zip(tot, kf_flags) if not k]
+            out["frame_ms"] = {"plain_median": med(plain), "keyframe_median": med([t for t, k in zip(tot, kf_flags) if k]),
+                               "p90": round(float(np.percentile(tot, 90)) * 1e3, 3), "max": round(float(np.max(tot)) * 1e3, 3)}
         return out
 
+    # the loops below create ~4 000 small objects per frame (KeyPoint / DMatch), so the cyclic collector runs all the time; what
+    # must NOT be in these per-call latencies is its full pass over everything the OTHER legs of this process left alive
+    # (millions of objects: tens of ms every ~17 frames).  gc.freeze() parks the objects that exist now in the permanent
+    # generation; collection of what the loops themselves allocate stays on, as in a caller's process.
+    import gc
+    gc.collect(); gc.freeze()
     frame_loop = loop(False)
 
     sys.path.insert(0, str(ROOT / "tests"))
@@ -260,6 +269,7 @@ def dropin_leg(n_frames=48):
         slam = loop(True)
     finally:
         planter.restore()
+        gc.unfreeze()
     det.close(); mat.close()
     out = dict(planted)
     out["frame_loop"] = dict(frame_loop, what="real structured frames through all three calls; random-init networks match (almost) "
