@@ -210,7 +210,7 @@ def dropin_leg(n_frames=48):
     med = lambda a: round(float(np.median(a)) * 1e3, 3)
     KF_COOLDOWN, RANSAC_THR = 5, 2.5                                   # main_revamped.py:221, :212
 
-    def loop(keyframes):
+    def loop(keyframes, mat=mat):
         ring.forget_patterns()
         stats0 = dict(ring.stats)
         kp_prev, des_prev = fu.feature_extractor(args, imgs[0], det)
@@ -262,11 +262,33 @@ def dropin_leg(n_frames=48):
 
     sys.path.insert(0, str(ROOT / "tests"))
     import lg_inputs
-    planter = lg_inputs.PlantedExtractor(det, lg_inputs.make_chain(16, MAX_KPTS, seed=7, noise=0.035, drop=0.1))   # (two frames: the noise and 81 % co-visibility of the parity pairs)
+    chain = lg_inputs.make_chain(16, MAX_KPTS, seed=7, noise=0.035, drop=0.1)      # (two frames: the noise and 81 % co-visibility of the parity pairs)
+    planter = lg_inputs.PlantedExtractor(det, chain)
+    adaptive = None
     try:
         planted = loop(False)
         planter.i = 0
         slam = loop(True)
+        # the same slam loop with LightGlue's own DEPTH control able to fire.  Random-init token-confidence heads are never
+        # confident, so every pair above runs all 9 layers - the worst case; trained weights on overlapping frames stop after a
+        # few.  Here the BIAS of each confidence head is set from one pair of the chain (calibrated_confidence_heads: the
+        # fractions EARLY_STOP_CONFIDENT of the points above the layer's threshold), matchability untouched: the decisions
+        # are data dependent, pairs stop early, matches survive.  Never `value`.
+        try:
+            Wm = importlib.import_module("opencv-simpleslam_amd.weights")
+            LightGlueHIP = importlib.import_module("opencv-simpleslam_amd.lightglue").LightGlueHIP
+            sd_e = calibrated_confidence_heads(Wm.random_lightglue_state_dict(1, match_gain=4.0, match_bias=3.0, conf_gain=16.0),
+                                               chain[:2], mat.ctx)
+            mat_e = LightGlueHIP(sd_e, max_kpts=MAX_KPTS, ctx=mat.ctx, max_pairs=ring.PAIRS)
+            mat_e._feature_ring = ring
+            ring.attach_matcher(mat_e)
+            planter.i = 0
+            adaptive = loop(True, mat=mat_e)
+            adaptive["lightglue_layers_last_pair"] = int(ring.pin_info[0, 1])
+            ring.attach_matcher(mat)
+            mat_e.close()
+        except Exception as e:                       # (an auxiliary figure must not cost the leg)
+            adaptive = {"error": repr(e)}
     finally:
         planter.restore()
         gc.unfreeze()
@@ -278,6 +300,11 @@ def dropin_leg(n_frames=48):
                             "prev -> cur + RANSAC, every 6th frame also keyframe -> cur + RANSAC twice (select_keyframe, then the "
                             "triangulation's repeat of the same pair), the frame becoming the keyframe; value = timed frames / their "
                             "summed time (median x 1 would hide the keyframe frames)")
+    if adaptive is not None:
+        out["slam_loop_depth_control"] = dict(adaptive, what="slam_loop with token-confidence heads whose BIASES are calibrated on one pair of "
+                                              "the chain so that LightGlue's early stop fires (matchability untouched: no pruning, matches kept): "
+                                              "what the same calls cost when the network's own depth control is active, as it is with trained "
+                                              "weights on overlapping frames; an illustration, never `value`")
     out["matches_last_pair"] = planted["matches_median"]
     out["what"] = ("sequential host API as main_revamped.py drives it, one frame at a time, host objects in and out: feature_extractor on "
                    "1241x376 frames whose device record is overwritten, on the extractor's stream inside the timed call, with the next "
