@@ -81,6 +81,11 @@ struct FfnFusedArgs {
     //   mat[row] = hm . x + hm_b ; hc != nullptr: conf[row] = sigmoid(hc . x + hc_b), *unconf += #(conf < conf_thr)
     const float* hm; const float* hm_b; const float* hc; const float* hc_b;
     float conf_thr; float* conf; float* mat; int* unconf;
+    // FOLD form (r05, one pair): the attention ran over `ks` key ranges and left unnormalised partials (o, m, l) per range
+    // (lg_attn_merge_h_kernel's inputs); the tile merges its own 32 tokens in the prologue instead of reading `msgs`.
+    // partial of (range z, head hd, token tok): index z * part_zs + part_base + hd * part_kc + tok, o_part 64 floats each.
+    const float* o_part; const float* m_part; const float* l_part;
+    int ks; int part_kc; long part_zs; long part_base;
 };
 
 #ifdef FFN_STAMP
@@ -170,7 +175,7 @@ constexpr int FFN_LEADC = FFN_LEADC_N;
 // Program order: prologue = W1 set 0 (4 loads), chunk 0 (two pieces), W1 sets 1 .. FFN_D1 - 1, chunks 1 .. LEADC - 1 -
 // what step 0 needs first in the queue; step s = [wait point] MFMAs, W1 refill (4 loads, while s + FFN_D1 < 32), then
 // chunk s / 4 + LEADC when s % 4 == 0.
-constexpr int ffn_ops_after_chunk(int c, int d1) {
+constexpr int ffn_ops_after_chunk(int c, int d1, int nch = 8) {     // nch: chunks that arrive by LDS-DMA (FOLD: the x half only)
     int n = 0; bool seen = false;
     for (int k = 0; k < FFN_LEADC; ++k) {
         if (seen) n += 2;
@@ -181,7 +186,7 @@ constexpr int ffn_ops_after_chunk(int c, int d1) {
     for (int s = 0; s < 32; ++s) {
         if (s == 4 * c - 1) return n;
         if (s + d1 < 32 && seen) n += 4;
-        if (s % 4 == 0 && s / 4 + FFN_LEADC < 8) { if (seen) n += 2; if (s / 4 + FFN_LEADC == c) seen = true; }
+        if (s % 4 == 0 && s / 4 + FFN_LEADC < nch) { if (seen) n += 2; if (s / 4 + FFN_LEADC == c) seen = true; }
     }
     return n;
 }
@@ -203,10 +208,15 @@ template <class F, int... I> __device__ __forceinline__ void ffn_static_for(F&& 
 // token's arithmetic is the same in both forms, bit for bit).  grow0: plane row of token 0; grow_cap: one past the
 // last plane row that may be read (rows are clamped to it); n_valid: tokens of the tile that exist (stores are masked
 // to them).  512 threads; `smem` = FFN_LDS_BYTES of dynamic LDS, 16-byte aligned.
-template <int TT = 2, int D1 = (TT == 1 ? FFN_D1_SMALL : FFN_D1), int D2 = (TT == 1 ? FFN_D2_SMALL : FFN_D2)>
+// FOLD (TT = 1 only): the message half of the operand tile does not come from `msgs` - the tile merges the key-range
+// partials of its 32 tokens itself (lg_attn_merge_h_kernel's arithmetic, expression for expression) and writes the planes
+// straight into the LDS image: one launch and one HBM round trip of the context planes less per block of a single pair.
+template <int TT = 2, bool FOLD = false, int D1 = (TT == 1 ? FFN_D1_SMALL : FFN_D1), int D2 = (TT == 1 ? FFN_D2_SMALL : FFN_D2)>
 __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0, int grow_cap, int n_valid,
                                                int* range_flag, _Float16* smem) {
     static_assert(TT == 1 || TT == 2, "one or two 32-token tiles per workgroup");
+    static_assert(!FOLD || TT == 1, "the merge prologue is laid out for 32 tokens x 4 heads x 4 quarter-heads = 512 threads");
+    constexpr int NCH = FOLD ? 4 : 8;              // operand chunks that arrive by LDS-DMA
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int h = lane >> 5, lr = lane & 31;
@@ -253,6 +263,26 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
     // ------------------------------------------------------------------ prologue
     // the first W1 fragment sets (plain loads, to registers), then the operand tile by LDS-DMA: wave w
     // brings rows 16 (w & 3) .. + 15 of plane (w >> 2) of every k-panel (16 pieces of 16 rows x 64 B)
+    // FOLD: thread = (token t >> 4, head (t >> 2) & 3, quarter q = t & 3 of the head's 64 columns); its partials go into
+    // the queue FIRST (the oldest operations: every later counted wait covers them)
+    float4 po[4][4]; float pm[4], pl[4];
+    const int ftok = t >> 4, fhead = (t >> 2) & 3, fq = t & 3;
+    if constexpr (FOLD) {
+        const size_t rid = (size_t)p.part_base + (size_t)fhead * p.part_kc + min(ftok, max(n_valid - 1, 0));
+#pragma unroll
+        for (int z = 0; z < 4; ++z) {
+            pm[z] = -INFINITY; pl[z] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) po[z][c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (z < p.ks) {
+                const size_t pb = (size_t)z * p.part_zs + rid;
+                pm[z] = p.m_part[pb]; pl[z] = p.l_part[pb];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) po[z][c] = *reinterpret_cast<const float4*>(p.o_part + pb * 64 + fq * 16 + 4 * c);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     half8 wq[D1][4];
     load_w1(0, wq[0]);
     const int prow = lane >> 2, pc = lane & 3;
@@ -265,7 +295,7 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
     const bool dma_wave = TT == 2 || (wave & 3) < 2;                // (TT = 1: rows 32 .. 63 of the image are never read)
     // chunk c = k-panels 2 c, 2 c + 1 (panels 0 - 7: x, 8 - 15: message): this wave's two pieces of 16 rows x 64 B each
     auto issue_chunk = [&](int c) {
-        if (!dma_wave) return;
+        if (!dma_wave || c >= NCH) return;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int kp = 2 * c + j;
@@ -281,7 +311,44 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
 #pragma unroll
     for (int c = 1; c < FFN_LEADC; ++c) issue_chunk(c);
     __builtin_amdgcn_sched_barrier(0);
-    ffn_wait_vm<ffn_ops_after_chunk(0, D1)>();             // own pieces of chunk 0 (and W1 set 0, older) have landed
+    ffn_wait_vm<ffn_ops_after_chunk(0, D1, NCH)>();        // own pieces of chunk 0 (and W1 set 0, older) have landed
+    float amax = 0.0f;
+    if constexpr (FOLD) {
+        // lg_attn_merge_h_kernel: M = max m_z ; acc = sum o_z 2^(m_z - M) ; L = sum l_z 2^(m_z - M) ; context = acc / L
+        float M = -INFINITY;
+#pragma unroll
+        for (int z = 0; z < 4; ++z) M = fmaxf(M, pm[z]);                // (ranges >= ks hold -inf)
+        float acc[16]; float L = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+        for (int z = 0; z < 4; ++z)
+            if (z < p.ks) {
+                const float wz = (pm[z] == -INFINITY) ? 0.0f : exp2f(pm[z] - M);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    acc[4 * c] += po[z][c].x * wz; acc[4 * c + 1] += po[z][c].y * wz;
+                    acc[4 * c + 2] += po[z][c].z * wz; acc[4 * c + 3] += po[z][c].w * wz;
+                }
+                L += pl[z] * wz;
+            }
+        const float inv = 1.0f / L;
+        const bool fvalid = ftok < n_valid;            // (rows past the image's tokens: no partials exist - exact zeros)
+        float v0[8], v1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v0[e] = fvalid ? acc[e] * inv : 0.0f; v1[e] = fvalid ? acc[8 + e] * inv : 0.0f; }
+        uint4 h0, l0, h1, l1;
+        split8_fast(v0, h0, l0, amax);
+        split8_fast(v1, h1, l1, amax);
+        // columns 64 head + 16 q .. + 15 of the message = k-panel 8 + 2 head + (q >> 1), logical chunks 2 (q & 1), + 1
+        const int kp = 8 + 2 * fhead + (fq >> 1), lc = 2 * (fq & 1), sw = (ftok >> 2) & 3;
+        _Float16* dh = smem + ((kp * 2) * 64 + ftok) * 32;
+        *reinterpret_cast<uint4*>(dh + ((lc ^ sw) * 8)) = h0;
+        *reinterpret_cast<uint4*>(dh + (((lc + 1) ^ sw) * 8)) = h1;
+        *reinterpret_cast<uint4*>(dh + 64 * 32 + ((lc ^ sw) * 8)) = l0;
+        *reinterpret_cast<uint4*>(dh + 64 * 32 + (((lc + 1) ^ sw) * 8)) = l1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     FFN_STAMP_AT(1);
 
@@ -325,9 +392,9 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
         static_assert(32 % D1 == 0 && D1 % 2 == 0, "the ring of W1 fragment sets divides the 32 steps, even depth");
         ffn_static_for([&](auto ks_c) {
             constexpr int ks = decltype(ks_c)::value, u = ks % D1;
-            if constexpr (ks % 4 == 3 && (ks + 1) / 4 < 8) {
+            if constexpr (ks % 4 == 3 && (ks + 1) / 4 < NCH) {
                 // the next step's fragments come from chunk (ks + 1) / 4: own pieces landed, then everybody's
-                ffn_wait_vm<ffn_ops_after_chunk((ks + 1) / 4, D1)>();
+                ffn_wait_vm<ffn_ops_after_chunk((ks + 1) / 4, D1, NCH)>();
                 __builtin_amdgcn_s_barrier();
             }
             if constexpr (ks & 1) {
@@ -338,7 +405,7 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
                 mma1(wq[u], ah0, al0);
             }
             if constexpr (ks + D1 < 32) load_w1(ks + D1, wq[u]);
-            if constexpr (ks % 4 == 0 && ks / 4 + FFN_LEADC < 8) issue_chunk(ks / 4 + FFN_LEADC);
+            if constexpr (ks % 4 == 0 && ks / 4 + FFN_LEADC < NCH) issue_chunk(ks / 4 + FFN_LEADC);
             // keep the refill HERE, D1 steps ahead of its use: left alone the scheduler sinks it to just
             // in front of the consuming MFMAs (fewer live registers, one exposed L2 round trip per step)
             __builtin_amdgcn_sched_barrier(0);
@@ -416,7 +483,6 @@ __device__ __forceinline__ void ffn_fused_tile(const FfnFusedArgs& p, int grow0,
     }
     // g = GELU(v * gamma + beta), split, and out to LDS as the B fragments of phase 2: fragment (plane, ks, tt)
     // = registers 8 s .. 8 s + 7 of tile (jt, tt), ks = 2 (2 w + jt) + s; image [plane][ks 32][tt 2][lane 64][8]
-    float amax = 0.0f;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll

@@ -589,8 +589,21 @@ __global__ __launch_bounds__(1024) void lg_decide_kernel(
     ctrl += pair;                                    // this pair's control block and 2 Kc-row slices
     conf += (size_t)pair * 2 * Kc; mat += (size_t)pair * 2 * Kc; ind += (size_t)pair * 2 * Kc;
     gmap += (size_t)pair * 2 * Kc; prune += (size_t)pair * 2 * Kc;
-    if (ctrl->stop) return;
     const int t = threadIdx.x;
+    const int img = t >> 9, th = t & 511, lane = th & 63, wave = th >> 6;
+    const int per = (Kc + 511) / 512;
+    // r05: this one-workgroup kernel is a chain of memory latencies on the single-pair path's critical path (9 us x 8 layers):
+    // every thread issues the loads of its first four elements and of the image's row count BEFORE the stop decision is
+    // known - they do not depend on it, and a stopped pair simply drops them
+    const int stopped = ctrl->stop;
+    const int n = ctrl->n[img];
+    float mv[4], cv[4]; int iv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = min(th * per + u, Kc - 1);
+        mv[u] = mat[img * Kc + i]; cv[u] = do_stop ? conf[img * Kc + i] : 0.0f; iv[u] = ind[img * Kc + i];
+    }
+    if (stopped) return;
     if (t == 0) {
         int stop = 0;
         if (do_stop) {
@@ -605,21 +618,18 @@ __global__ __launch_bounds__(1024) void lg_decide_kernel(
     }
     __syncthreads();
     if (s_stop || width_conf <= 0.0f) return;
-    const int img = t >> 9, th = t & 511, lane = th & 63, wave = th >> 6;
-    const int n = ctrl->n[img];
     const bool act = n > prune_min;                  // (uniform over the image's eight waves)
-    const int per = (Kc + 511) / 512;
     // thread owns the contiguous chunk [th*per, th*per+per) of its image
     int cnt = 0;
     if (act) {
-        // (r04: the chunk's loads first, four elements at a time - rolled, every element waited for its own three loads: this
-        //  one-workgroup kernel is nothing but a chain of memory latencies)
+        // (r04: the chunk's loads first, four elements at a time - rolled, every element waited for its own three loads)
         for (int j0 = 0; j0 < per; j0 += 4) {
-            float mv[4], cv[4]; int iv[4];
+            if (j0 > 0) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = min(th * per + j0 + u, Kc - 1);
-                mv[u] = mat[img * Kc + i]; cv[u] = do_stop ? conf[img * Kc + i] : 0.0f; iv[u] = ind[img * Kc + i];
+                for (int u = 0; u < 4; ++u) {
+                    const int i = min(th * per + j0 + u, Kc - 1);
+                    mv[u] = mat[img * Kc + i]; cv[u] = do_stop ? conf[img * Kc + i] : 0.0f; iv[u] = ind[img * Kc + i];
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -864,17 +874,40 @@ __device__ __forceinline__ float score_ij(float s, float rm, float rl, float cm,
     return (((s - rm) - rl) + ((s - cm) - cl)) + (a + b);
 }
 
+// merge of the CSLAB slab partials of column `col` by the first CSLAB lanes of a wave (one load pair each, then a 16-lane
+// butterfly: larger value wins, equal values -> the smaller row, as the sequential scan over the slabs); valid in lane 0
+static_assert(CSLAB == 16, "the butterfly below spans 16 lanes");
+__device__ __forceinline__ int col_argmax_merge_wave(const float* __restrict__ pval, const int* __restrict__ parg,
+                                                     int Kc, int col, int lane) {
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    if (lane < CSLAB) { bv = pval[(size_t)lane * Kc + col]; bi = parg[(size_t)lane * Kc + col]; }
+    for (int o = 8; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    return bi;
+}
+
+// Runs AFTER lg_col_argmax_kernel (r05): the wave of row r also merges the slab partials of column r into arg1[r] - the single
+// workgroup of lg_emit_kernel did that merge per candidate match, 2 x CSLAB scattered 4-byte loads each, ~65 k of them through
+// one CU's L1: most of its 19 us.
 __global__ __launch_bounds__(256) void lg_row_argmax_kernel(
     const float* __restrict__ sim, const float* __restrict__ rmax, const float* __restrict__ rlog,
     const float* __restrict__ cmax, const float* __restrict__ clog, const float* __restrict__ z,
-    float* __restrict__ best0, int* __restrict__ arg0, int Kc, const LGCtrl* __restrict__ ctrl) {
+    float* __restrict__ best0, int* __restrict__ arg0, const float* __restrict__ pval, const int* __restrict__ parg,
+    int* __restrict__ arg1, int Kc, const LGCtrl* __restrict__ ctrl) {
     const int pair = blockIdx.y;
     ctrl += pair; sim += (size_t)pair * Kc * Kc; rmax += (size_t)pair * Kc; rlog += (size_t)pair * Kc;
     cmax += (size_t)pair * Kc; clog += (size_t)pair * Kc; z += (size_t)pair * 2 * Kc;
     best0 += (size_t)pair * Kc; arg0 += (size_t)pair * Kc;
+    pval += (size_t)pair * CSLAB * Kc; parg += (size_t)pair * CSLAB * Kc; arg1 += (size_t)pair * Kc;
     if (ctrl->stop == 2) return;
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n0 = ctrl->n[0], n1 = ctrl->n[1];
+    if (row < n1 && row < Kc) {                                      // (column `row` of the pair; uniform over the wave)
+        const int ci = col_argmax_merge_wave(pval, parg, Kc, row, lane);
+        if (lane == 0) arg1[row] = ci;
+    }
     if (row >= n0) return;
     const float rm = rmax[row], rl = rlog[row], a = z[row];          // z: log sigmoid(matchability), per token
     float bv = -INFINITY; int bj = 0x7fffffff;
@@ -928,44 +961,43 @@ __global__ __launch_bounds__(256) void lg_col_argmax_kernel(
     }
 }
 
-__device__ __forceinline__ int col_argmax_merge(const float* __restrict__ pval, const int* __restrict__ parg,
-                                                int Kc, int col) {
-    float bv = -INFINITY; int bi = 0x7fffffff;
-    for (int z = 0; z < CSLAB; ++z) {
-        const float ov = pval[(size_t)z * Kc + col]; const int oi = parg[(size_t)z * Kc + col];
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
-    return bi;
-}
-
 // single block: mutual check, thresholds, ordered emission in original indices
 __global__ __launch_bounds__(1024) void lg_emit_kernel(
-    const float* __restrict__ best0, const int* __restrict__ arg0, const float* __restrict__ pval,
-    const int* __restrict__ parg, const int* __restrict__ ind, float filter_thr, float min_conf, int32_t* __restrict__ ij_out,
+    const float* __restrict__ best0, const int* __restrict__ arg0, const int* __restrict__ arg1, const int* __restrict__ ind, float filter_thr, float min_conf, int32_t* __restrict__ ij_out,
     float* __restrict__ score_out, int32_t* __restrict__ info_out, LGCtrl* __restrict__ ctrl, int Kc,
     long out_stride, int* __restrict__ range_sticky) {
     __shared__ int wsum[16];
     const int pair = blockIdx.x;
     ctrl += pair; best0 += (size_t)pair * Kc; arg0 += (size_t)pair * Kc;
-    pval += (size_t)pair * CSLAB * Kc; parg += (size_t)pair * CSLAB * Kc; ind += (size_t)pair * 2 * Kc;
+    arg1 += (size_t)pair * Kc; ind += (size_t)pair * 2 * Kc;
     ij_out += (size_t)pair * out_stride * 2; score_out += (size_t)pair * out_stride; info_out += pair * 4;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int per = (Kc + 1023) / 1024;               // <= 8 (max_kpts <= 8192)
+    // r05: (a one-workgroup chain of memory latencies, 19 us at the end of every forward) the row results are loaded before
+    // the row counts are known, and the per-thread lists are unrolled into registers (rolled, they lived in scratch memory)
+    int a0[8]; float b0[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        if (q < per) { const int i = min(t * per + q, Kc - 1); a0[q] = arg0[i]; b0[q] = best0[i]; }
     const int n0 = ctrl->stop == 2 ? 0 : ctrl->n[0];
     const int n1 = ctrl->n[1];
-    const int per = (Kc + 1023) / 1024;
     int keep[8], jj[8], cnt = 0; float sc[8];
-    for (int q = 0; q < per; ++q) {
-        const int i = t * per + q;
-        int k = 0;
-        if (i < n0) {
-            const int j = arg0[i];
-            const float s = expf(best0[i]);
-            // a row whose scores are all NaN (non-finite input) has no arg-max: no match, no lookup
-            const bool valid = (unsigned)j < (unsigned)n1;
-            k = valid && (col_argmax_merge(pval, parg, Kc, j) == i) && (s > filter_thr) && (s > min_conf);
-            jj[q] = valid ? j : 0; sc[q] = s;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        keep[q] = 0; jj[q] = 0; sc[q] = 0.0f;
+        if (q < per) {
+            const int i = t * per + q;
+            int k = 0;
+            if (i < n0) {
+                const int j = a0[q];
+                const float s = expf(b0[q]);
+                // a row whose scores are all NaN (non-finite input) has no arg-max: no match, no lookup
+                const bool valid = (unsigned)j < (unsigned)n1;
+                k = valid && (arg1[j] == i) && (s > filter_thr) && (s > min_conf);
+                jj[q] = valid ? j : 0; sc[q] = s;
+            }
+            keep[q] = k; cnt += k;
         }
-        keep[q] = k; cnt += k;
     }
     int incl = cnt;
     for (int o = 1; o < 64; o <<= 1) {
@@ -977,9 +1009,10 @@ __global__ __launch_bounds__(1024) void lg_emit_kernel(
     int base = 0, total = 0;
     for (int w = 0; w < 16; ++w) { if (w < wave) base += wsum[w]; total += wsum[w]; }
     int pos = base + incl - cnt;
-    for (int q = 0; q < per; ++q) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
         const int i = t * per + q;
-        if (i < n0 && keep[q]) {
+        if (q < per && i < n0 && keep[q]) {
             ij_out[2 * pos] = ind[i];
             ij_out[2 * pos + 1] = ind[Kc + jj[q]];
             score_out[pos] = sc[q];
@@ -1426,7 +1459,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void lg_sim_big_kernel(SimBigArgs 
 // 64 when the token set gives every CU a tile, 32 below that (one pair: 64 -> 128 workgroups of half the work).
 struct FfnKArgs { sslam::FfnFusedArgs f; const LGCtrl* ctrl; int Kc; };
 
-template <int TT>
+template <int TT, bool FOLD = false>
 __global__ __launch_bounds__(512, 2) void lg_ffn_fused_kernel(FfnKArgs p) {
     extern __shared__ __attribute__((aligned(16))) _Float16 lg_ring[];
     constexpr int TOK = 32 * TT;
@@ -1439,7 +1472,8 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_fused_kernel(FfnKArgs p) {
     const int ibase = img * p.Kc;
     sslam::FfnFusedArgs f = p.f;
     f.unconf = &const_cast<LGCtrl*>(p.ctrl)[img >> 1].unconf;          // (used with the token heads only)
-    sslam::ffn_fused_tile<TT>(f, ibase + row0, ibase + p.Kc, min(TOK, n - row0), range_flag_of(p.ctrl, img), lg_ring);
+    if constexpr (FOLD) { f.part_base = (long)img * NH * p.Kc + row0; f.part_kc = p.Kc; }
+    sslam::ffn_fused_tile<TT, FOLD>(f, ibase + row0, ibase + p.Kc, min(TOK, n - row0), range_flag_of(p.ctrl, img), lg_ring);
 }
 
 
@@ -1903,7 +1937,7 @@ struct sslam_lightglue {
     float *o_part, *m_part, *l_part, *conf, *mat, *md, *sim, *rmax, *rlog, *cmax, *clog, *best0;
     float *cpmax, *cpsum, *cpval, *bbox;
     int* cparg;
-    int *ind, *gmap, *prune, *arg0;
+    int *ind, *gmap, *prune, *arg0, *arg1;
     float *in_xy, *in_desc, *up_xy, *up_desc, *out_score;
     int32_t *out_ij, *out_info;
     // split-precision planes (precision == 1)
@@ -1916,6 +1950,7 @@ struct sslam_lightglue {
     int p_single = 1;                // precision "f16x3p1" (set_precision 2, the DEFAULT since r05 - profiles/r05_flip_soak.md): P as one fp16 plane in P.V, row sums over the rounded weights
     int study = 0;                   // precision study (sslam_lightglue_debug_split_form): which cross terms of the split products are dropped
     _Float16* zero_plane = nullptr;  // study only: an all-zero fp16 plane standing in for a dropped low plane
+    int fold_merge = 1;              // test hook (SSLAM_LG_FOLD_MERGE=0 at creation): 0 = key-range partials merged by lg_attn_merge_h_kernel
     int big_gemm = -1;               // test hook: -1 by batch size, 0 / 1 force the single-pair (ring) / batched form of the linears;
                                      // 2 / 3: batched form with 64- / 32-token FFN tiles whatever the size
     _Float16 *w_hi, *w_lo;           // whole weight blob, split
@@ -2123,7 +2158,8 @@ int lg_load_attention_asm(int device) {
     return 0;
 }
 
-void launch_attention_h(sslam_lightglue* g, hipStream_t s, int NI, SplitPtr Q, SplitPtr K, SplitPtr VT, int cross) {
+void launch_attention_h(sslam_lightglue* g, hipStream_t s, int NI, SplitPtr Q, SplitPtr K, SplitPtr VT, int cross,
+                        bool merge_in_ffn = false) {
     const int KS = attn_key_split(g, NI);
     if (g->study) {       // precision study: a dropped cross term = its low-plane operand replaced by zeros (bit-identical to not issuing the MFMA)
         if (g->study & 0x01) K.lo = g->zero_plane;          // S = kh.qh + kh.ql          (K as one fp16 plane)
@@ -2153,7 +2189,7 @@ void launch_attention_h(sslam_lightglue* g, hipStream_t s, int NI, SplitPtr Q, S
         hipLaunchKernelGGL(lg_attention_p_kernel, grid, dim3(256), 0, s, a);
     }
     attn_event(g, s, false);
-    if (KS == 1) return;                   // the kernel wrote the context planes itself
+    if (KS == 1 || merge_in_ffn) return;   // the kernel wrote the context planes itself / the fused FFN merges the partials
     const long n4 = (long)NI * NH * g->Kc * 16;
     hipLaunchKernelGGL(lg_attn_merge_h_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, g->o_part,
                        g->m_part, g->l_part, SplitOut{g->msgs_hi, g->msgs_lo}, KS, g->Kc, NI, g->NIc, g->ctrl);
@@ -2176,6 +2212,11 @@ bool lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, in
     // enough token rows for 128-row tiles to fill the chip (a batch of pairs): 128 x 128 projections and the
     // whole FFN as ONE kernel (ffn_fused.hpp); a single pair keeps the 64-row ring kernels (r01 form)
     const bool big = g->big_gemm >= 0 ? g->big_gemm != 0 : ((long)NI * g->Kc >= 4096 && g->Kc % 128 == 0);
+    // one pair: the attention's key-range partials are merged by the FFN tiles (ffn_fused.hpp FOLD), not by a launch of their own
+    const int KS = attn_key_split(g, NI);
+    const bool small_tiles = g->big_gemm == 3 || (g->big_gemm != 2 && NI * (g->Kc / 64) <= 128);
+    const bool fold = big && small_tiles && KS > 1 && st == 0 && g->fold_merge != 0 &&
+                      (g->force_ks == 0 || g->force_ks == -3 || g->force_ks > 100);      // (the assembly kernel's partial layout)
     auto ffn = [&](int cross, const float* w1, const float* b1, const float* lnw, const float* lnb, const float* w2,
                    const float* b2) {
         if (big) {
@@ -2191,8 +2232,11 @@ bool lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, in
                 k.f.conf_thr = conf_threshold(layer); k.f.conf = g->conf; k.f.mat = g->mat;
             }
             k.ctrl = g->ctrl; k.Kc = g->Kc;
-            const bool small_tiles = g->big_gemm == 3 || (g->big_gemm != 2 && NI * (g->Kc / 64) <= 128);
-            if (small_tiles)                       // too few 64-token tiles for the chip: 32-token tiles (same results)
+            if (fold) {                            // one pair, keys split into ranges: the tile merges the partials itself
+                k.f.o_part = g->o_part; k.f.m_part = g->m_part; k.f.l_part = g->l_part;
+                k.f.ks = KS; k.f.part_zs = (long)g->NIc * NH * g->Kc;
+                hipLaunchKernelGGL((lg_ffn_fused_kernel<1, true>), dim3(NI * (g->Kc / 32)), dim3(512), sslam::FFN_LDS_BYTES, s, k);
+            } else if (small_tiles)                // too few 64-token tiles for the chip: 32-token tiles (same results)
                 hipLaunchKernelGGL(lg_ffn_fused_kernel<1>, dim3(NI * (g->Kc / 32)), dim3(512), sslam::FFN_LDS_BYTES, s, k);
             else
                 hipLaunchKernelGGL(lg_ffn_fused_kernel<2>, dim3(NI * (g->Kc / 64)), dim3(512), sslam::FFN_LDS_BYTES, s, k);
@@ -2217,7 +2261,7 @@ bool lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, in
         if (big) launch_linear_big<128, 128, 2, 2, EPH_QKV>(s, NI, a);
         else launch_linear_h<64, 192, 1, 3, EPH_QKV>(s, NI, a);  // 768 / 192 = 4 column tiles
     }
-    launch_attention_h(g, s, NI, qs, ks, vts, 0);
+    launch_attention_h(g, s, NI, qs, ks, vts, 0, fold);
     ffn(0, l.w1, l.b1, l.lnw, l.lnb, l.w2, l.b2);
     if (self_only) return false;
     {   // cross block: the shared qk projection is both query and key -> sqrt(scale) on it
@@ -2228,7 +2272,7 @@ bool lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, in
         if (big) launch_linear_big<128, 128, 2, 2, EPH_CROSS>(s, NI, a);
         else launch_linear_h<64, 128, 1, 2, EPH_CROSS>(s, NI, a);
     }
-    launch_attention_h(g, s, NI, qs, qs, vts, 1);
+    launch_attention_h(g, s, NI, qs, qs, vts, 1, fold);
     ffn(1, l.cw1, l.cb1, l.clnw, l.clnb, l.cw2, l.cb2);
     return big && heads;
 }
@@ -2351,11 +2395,11 @@ int lg_enqueue(sslam_lightglue* g, int pairs, const StageSrc& src, float min_con
                        g->cpmax, g->cpsum, Kc, g->ctrl);
     hipLaunchKernelGGL(lg_col_stats_merge_kernel, dim3(sslam::cdiv(Kc, 256), pairs), dim3(256), 0, s, g->cpmax,
                        g->cpsum, g->cmax, g->clog, Kc, g->ctrl);
-    hipLaunchKernelGGL(lg_row_argmax_kernel, dim3(sslam::cdiv(Kc, 4), pairs), dim3(256), 0, s, g->sim, g->rmax,
-                       g->rlog, g->cmax, g->clog, g->conf, g->best0, g->arg0, Kc, g->ctrl);
     hipLaunchKernelGGL(lg_col_argmax_kernel, dim3(sslam::cdiv(Kc, 64), CSLAB, pairs), dim3(256), 0, s, g->sim,
                        g->rmax, g->rlog, g->cmax, g->clog, g->conf, g->cpval, g->cparg, Kc, g->ctrl);
-    hipLaunchKernelGGL(lg_emit_kernel, dim3(pairs), dim3(1024), 0, s, g->best0, g->arg0, g->cpval, g->cparg, g->ind,
+    hipLaunchKernelGGL(lg_row_argmax_kernel, dim3(sslam::cdiv(Kc, 4), pairs), dim3(256), 0, s, g->sim, g->rmax,
+                       g->rlog, g->cmax, g->clog, g->conf, g->best0, g->arg0, g->cpval, g->cparg, g->arg1, Kc, g->ctrl);
+    hipLaunchKernelGGL(lg_emit_kernel, dim3(pairs), dim3(1024), 0, s, g->best0, g->arg0, g->arg1, g->ind,
                        g->filter_thr, min_conf, ij_out, score_out, info_out, g->ctrl, Kc, out_stride, g->range_sticky);
     SSLAM_HIP_CHECK(hipGetLastError());
     if (g->launch_error != hipSuccess) {                 // a module-API launch (the assembly attention kernel) failed
@@ -2383,6 +2427,7 @@ void lg_configure_kernels() {
         (void)hipFuncSetAttribute((const void*)lg_sim_big_kernel<128, 128, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
     }
     (void)hipFuncSetAttribute((const void*)lg_ffn_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, sslam::FFN_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)lg_ffn_fused_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sslam::FFN_LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)lg_ffn_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, sslam::FFN_LDS_BYTES);
 }
 
@@ -2428,6 +2473,7 @@ int sslam_lightglue_create_batched(sslam_ctx* ctx, const float* weights, size_t 
     g->NB = max_pairs; g->NIc = 2 * max_pairs;
     g->KSmax = Kc >= 1024 ? 4 : (Kc >= 512 ? 2 : 1);
     if (const char* e = getenv("SSLAM_LG_SIM_EXACT")) g->sim_exact = e[0] == '1';
+    if (const char* e = getenv("SSLAM_LG_FOLD_MERGE")) g->fold_merge = e[0] == '1';
     const size_t K = (size_t)Kc, NI = (size_t)g->NIc, NB = (size_t)max_pairs;
     auto carve = [&](sslam::Arena& A) {
         g->blob = A.take<float>(n_floats);
@@ -2447,7 +2493,7 @@ int sslam_lightglue_create_batched(sslam_ctx* ctx, const float* weights, size_t 
         g->rmax = A.take<float>(NB * K); g->rlog = A.take<float>(NB * K); g->cmax = A.take<float>(NB * K);
         g->clog = A.take<float>(NB * K); g->best0 = A.take<float>(NB * K);
         g->ind = A.take<int>(NI * K); g->gmap = A.take<int>(NI * K); g->prune = A.take<int>(NI * K);
-        g->arg0 = A.take<int>(NB * K);
+        g->arg0 = A.take<int>(NB * K); g->arg1 = A.take<int>(NB * K);
         g->cpmax = A.take<float>(NB * CSLAB * K); g->cpsum = A.take<float>(NB * CSLAB * K);
         g->cpval = A.take<float>(NB * CSLAB * K); g->cparg = A.take<int>(NB * CSLAB * K);
         g->in_xy = A.take<float>(NI * K * 2); g->in_desc = A.take<float>(NI * K * DIN);

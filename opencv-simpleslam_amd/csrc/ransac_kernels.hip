@@ -19,9 +19,11 @@
 //
 // The sequential loop is data-dependent only through (a) the RNG stream and (b) the running
 // best / iteration budget.  (a) is replayed by one lane (a few thousand integer ops); the
-// expensive part - solving every sample and scoring every model against every match - runs
-// wide (thread per sample, workgroup per model); (b) is then replayed exactly by one lane
-// over the stored scores.  The result is what the sequential loop would have produced.
+// expensive part - solving every sample and scoring its models against every match - runs
+// wide (workgroup per sample); (b) is then replayed exactly by one lane over the stored scores.
+// The result is what the sequential loop would have produced.  Seven launches per call (r05):
+// head [gather, control block, samples of chunk 0] - per chunk [solve + score] and [replay +
+// samples of the next chunk] - tail [replay, winner, mask, compaction].
 #include "common.hpp"
 
 #include <algorithm>
@@ -112,30 +114,17 @@ __device__ int update_num_iters(double p, double ep, int model_points, int max_i
 // 16-sample first chunk that is all a matcher's inlier ratios ever need.  The workgroup now copies both point sets into LDS
 // first (when they fit: RS_LDS_POINTS) and the lane reads them from there; a chunk that has nothing to do (budget already
 // below its first sample) leaves before the copy.
+// A step of the whole workgroup (256 threads; rs_pts = dynamic LDS, [p1: n x 2 | p2: n x 2] when n <= RS_LDS_POINTS;
+// pts_ready: the caller has already filled it).  Ends with every thread past the last use of rs_pts.
 constexpr int RS_LDS_POINTS = 4096;      // 2 x 4096 x 8 bytes = 64 KB of dynamic LDS at most
-__global__ __launch_bounds__(256) void rs_subsets_kernel(RSArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float rs_pts[];      // [p1: n x 2 | p2: n x 2] when n <= RS_LDS_POINTS
-    __shared__ int go;
+__device__ void rs_subsets_step(const RSArgs& a, int h0, int h1, float* rs_pts, bool pts_ready, int* go) {
     RSCtrl* c = a.ctrl;
     const int n = rs_n(a);
-    if (threadIdx.x == 0) {
-        if (a.h0 == 0) {
-            c->lmeds = n <= RS_LMEDS_MAX;
-            c->budget = max(a.max_iters, 1);
-            if (c->lmeds) c->budget = max(update_num_iters(a.confidence, 0.45, RS_MP, a.max_iters), 1);   // LMeDS: fixed budget
-            c->rng_state = 0xffffffffffffffffULL;
-            c->n_subsets = 0; c->exhausted = 0;
-            c->best_h = c->best_k = -1;
-            c->best_count = 0; c->niters = 0; c->max_good = 0;
-            c->min_median = DBL_MAX;
-            if (n < 8) c->exhausted = 1;          // _dev entry with a device count: fewer than 8 matches pass through unfiltered
-        }
-        go = !c->exhausted && a.h0 < min(a.h1, c->budget);
-    }
+    if (threadIdx.x == 0) *go = !c->exhausted && h0 < min(h1, c->budget) && h0 == c->niters;
     __syncthreads();
-    if (!go) return;
+    if (!*go) return;
     const bool in_lds = n <= RS_LDS_POINTS;
-    if (in_lds) {
+    if (in_lds && !pts_ready) {
         for (int i = threadIdx.x; i < 2 * n; i += blockDim.x) { rs_pts[i] = a.p1[i]; rs_pts[2 * n + i] = a.p2[i]; }
         __syncthreads();
     }
@@ -150,10 +139,10 @@ __global__ __launch_bounds__(256) void rs_subsets_kernel(RSArgs a) {
     int tj = 1, tk = 0;
     for (int t = 0; t < q; ++t) { if (++tk == tj) { ++tj; tk = 0; } }        // q -> (j, k): (1,0) (2,0) (2,1) (3,0) ...
     CvRng rng{c->rng_state};
-    const int end = min(a.h1, c->budget);
+    const int end = min(h1, c->budget);
     int made = c->n_subsets;
     bool exhausted = false;
-    for (int it = a.h0; it < end; ++it) {
+    for (int it = h0; it < end; ++it) {
         int idx[RS_MP];
         int attempts = 0;
         for (; attempts < RS_SUBSET_ATTEMPTS; ++attempts) {
@@ -248,14 +237,12 @@ __device__ int solve_cubic(const double* c, double* r) {
     return n;
 }
 
-__global__ __launch_bounds__(64) void rs_models_kernel(RSArgs a) {
-    // The 7 x 9 system of a sample, element-major / lane-minor in LDS: the elimination below indexes it with the PIVOT's row
-    // and column, which are per-lane values - as a private array it lived in scratch memory (512 bytes per thread, every access
-    // a ~1 us round trip: 33 us for the eight samples of the first chunk, r05 kernel trace); LDS takes per-lane indices as is.
-    __shared__ double As[RS_MP * 9 * 64];
-#define RS_A(i, j) As[((i) * 9 + (j)) * 64 + threadIdx.x]
-    const int h = a.h0 + blockIdx.x * 64 + threadIdx.x;
-    if (h >= a.h1 || h >= a.ctrl->n_subsets) return;
+// One lane solves sample h: the 7 x 9 system lives in LDS (`As`, 63 doubles) - the elimination below indexes it with the PIVOT's
+// row and column, which are run-time values: as a private array it lived in scratch memory (512 bytes per thread, every access
+// a ~1 us round trip: 33 us for the eight samples of the first chunk, r05 kernel trace).  Writes the sample's 1 - 3 models to
+// `out` (27 doubles) and returns their number.
+__device__ int rs_solve7(const RSArgs& a, int h, double* As, double* out) {
+#define RS_A(i, j) As[(i) * 9 + (j)]
     // rows: (m2, 1)^T F (m1, 1) = 0
     for (int i = 0; i < RS_MP; ++i) {
         const int id = a.subsets[h * RS_MP + i];
@@ -289,7 +276,6 @@ __global__ __launch_bounds__(64) void rs_models_kernel(RSArgs a) {
         }
     }
     int nm = 0;
-    double* out = a.models + (size_t)h * 27;
     if (ok) {
         double f1[9], f2[9];             // null vectors for free columns 7 and 8 (permuted order)
         for (int k = 0; k < RS_MP; ++k) { f1[colp[k]] = -RS_A(k, 7); f2[colp[k]] = -RS_A(k, 8); }
@@ -324,7 +310,7 @@ __global__ __launch_bounds__(64) void rs_models_kernel(RSArgs a) {
             }
         }
     }
-    a.nmodels[h] = nm;
+    return nm;
 #undef RS_A
 }
 
@@ -343,18 +329,41 @@ __device__ __forceinline__ float fm_error(const double* F, float x1, float y1, f
     return (float)fmax(d1 * d1 * s1, d2 * d2 * s2);
 }
 
-// ---- 3. score every model against every match (workgroup / model) ---------------------------
-__global__ __launch_bounds__(RS_T) void rs_score_kernel(RSArgs a) {
+// ---- 2 + 3. solve sample h and score its models against every match (workgroup / sample) -----------------------
+// r05: one launch instead of two (thread / sample, then workgroup / model): the solver is a serial fp64 chain of ~10 us
+// whatever the grid, and the 1 - 3 models of a sample are scored by the workgroup that has them in LDS.
+__device__ __forceinline__ int rs_block_sum(int v, int* sh) {      // sum over the workgroup (RS_T threads), valid in every thread
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = RS_T / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    const int tot = sh[0];
+    __syncthreads();
+    return tot;
+}
+
+__global__ __launch_bounds__(RS_T) void rs_models_score_kernel(RSArgs a) {
+    __shared__ double As[RS_MP * 9];
+    __shared__ double Fm[27];
     __shared__ int sh[RS_T];
-    const int h = a.h0 + blockIdx.x, k = blockIdx.y;
+    __shared__ int s_nm;
+    const int h = a.h0 + blockIdx.x;
     const RSCtrl* c = a.ctrl;
-    if (h >= c->n_subsets || k >= a.nmodels[h]) return;
-    const int n = rs_n(a);
-    double F[9];
-    for (int i = 0; i < 9; ++i) F[i] = a.models[(size_t)h * 27 + 9 * k + i];
+    if (h >= a.h1 || h >= c->n_subsets || a.h0 != c->niters) return;     // (beyond the samples drawn / the loop ended before this chunk)
+    if (threadIdx.x == 0) {
+        const int nm = rs_solve7(a, h, As, Fm);
+        for (int i = 0; i < 9 * nm; ++i) a.models[(size_t)h * 27 + i] = Fm[i];
+        a.nmodels[h] = nm;
+        s_nm = nm;
+    }
+    __syncthreads();
+    const int nm = s_nm, n = rs_n(a);
     if (c->lmeds) {
-        // n <= 14: one lane sorts the errors and takes the median
-        if (threadIdx.x == 0) {
+        // n <= 14: one lane per model sorts the errors and takes the median
+        if ((int)threadIdx.x < nm) {
+            const double* F = Fm + 9 * threadIdx.x;
             float e[RS_LMEDS_MAX];
             for (int i = 0; i < n; ++i) e[i] = fm_error(F, a.p1[2 * i], a.p1[2 * i + 1], a.p2[2 * i], a.p2[2 * i + 1]);
             for (int i = 1; i < n; ++i) {
@@ -364,38 +373,35 @@ __global__ __launch_bounds__(RS_T) void rs_score_kernel(RSArgs a) {
                 while (j >= 0 && e[j] > v) { e[j + 1] = e[j]; --j; }
                 e[j + 1] = v;
             }
-            a.medians[h * 3 + k] = n % 2 != 0 ? e[n / 2] : (e[n / 2 - 1] + e[n / 2]) * 0.5f;
+            a.medians[h * 3 + threadIdx.x] = n % 2 != 0 ? e[n / 2] : (e[n / 2 - 1] + e[n / 2]) * 0.5f;
         }
         return;
     }
     const float t = (float)(a.thresh * a.thresh);
-    int good = 0;
-    for (int i = threadIdx.x; i < n; i += RS_T)
-        good += fm_error(F, a.p1[2 * i], a.p1[2 * i + 1], a.p2[2 * i], a.p2[2 * i + 1]) <= t;
-    sh[threadIdx.x] = good;
-    __syncthreads();
-    for (int s = RS_T / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
-        __syncthreads();
+    for (int k = 0; k < nm; ++k) {
+        const double* F = Fm + 9 * k;
+        int good = 0;
+        for (int i = threadIdx.x; i < n; i += RS_T)
+            good += fm_error(F, a.p1[2 * i], a.p1[2 * i + 1], a.p2[2 * i], a.p2[2 * i + 1]) <= t;
+        good = rs_block_sum(good, sh);
+        if (threadIdx.x == 0) a.counts[h * 3 + k] = good;
     }
-    if (threadIdx.x == 0) a.counts[h * 3 + k] = sh[0];
 }
 
 // ---- 4. replay the sequential best / budget logic over samples [h0, h1) (one lane) -----------
-__global__ void rs_select_kernel(RSArgs a) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ void rs_select_step(const RSArgs& a, int h0, int h1) {
     RSCtrl* c = a.ctrl;
     const int n = rs_n(a);
-    int it = a.h0;
+    int it = h0;
     if (it != c->niters) return;                       // the loop already ended before this chunk
     if (c->lmeds) {
-        for (; it < a.h1 && it < c->n_subsets && it < c->budget; ++it)
+        for (; it < h1 && it < c->n_subsets && it < c->budget; ++it)
             for (int k = 0; k < a.nmodels[it]; ++k) {
                 const double med = a.medians[it * 3 + k];
                 if (med < c->min_median) { c->min_median = med; c->best_h = it; c->best_k = k; }
             }
     } else {
-        for (; it < a.h1 && it < c->n_subsets && it < c->budget; ++it)
+        for (; it < h1 && it < c->n_subsets && it < c->budget; ++it)
             for (int k = 0; k < a.nmodels[it]; ++k) {
                 const int good = a.counts[it * 3 + k];
                 if (good > max(c->max_good, RS_MP - 1)) {
@@ -408,43 +414,39 @@ __global__ void rs_select_kernel(RSArgs a) {
     c->niters = it;
 }
 
-__global__ void rs_finish_kernel(RSArgs a) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// ---- first launch: (device entry) the matched pixel pairs from the matcher's index pairs, the control block, the samples
+// of the first chunk.  The points go to LDS as they are gathered (and to `p1` / `p2` for the launches that follow).
+__global__ __launch_bounds__(RS_T) void rs_head_kernel(RSArgs a, float* p1w, float* p2w) {
+    extern __shared__ __attribute__((aligned(16))) float rs_pts[];
+    __shared__ int go;
     RSCtrl* c = a.ctrl;
-    c->thresh = a.thresh;
-    if (c->lmeds && c->best_h >= 0) {
-        double sigma = 2.5 * 1.4826 * (1 + 5. / (rs_n(a) - RS_MP)) * sqrt(c->min_median);
-        c->thresh = fmax(sigma, 0.001);
-    }
-    if (c->best_h >= 0)
-        for (int i = 0; i < 9; ++i) c->F[i] = a.models[(size_t)c->best_h * 27 + 9 * c->best_k + i];
-}
-
-// ---- 5. inlier mask of the winner ---------------------------------------------------------------
-__global__ __launch_bounds__(RS_T) void rs_mask_kernel(RSArgs a) {
-    __shared__ int sh[RS_T];
-    RSCtrl* c = a.ctrl;
-    const bool have = c->best_h >= 0;
-    const float t = (float)(c->thresh * c->thresh);
     const int n = rs_n(a);
-    const bool pass = n < 8;                   // features_utils.py:189-190: fewer than 8 matches are returned as they are
-    int good = 0;
-    for (int i = threadIdx.x; i < n; i += RS_T) {
-        const int in = pass || (have && fm_error(c->F, a.p1[2 * i], a.p1[2 * i + 1], a.p2[2 * i], a.p2[2 * i + 1]) <= t);
-        a.mask[i] = (unsigned char)in;
-        good += in;
+    const bool gather = a.ij != nullptr, in_lds = n <= RS_LDS_POINTS;
+    if (gather)
+        for (int i = threadIdx.x; i < n; i += RS_T) {
+            const int q = a.ij[2 * i], t = a.ij[2 * i + 1];
+            const float x1 = a.xy1[2 * q], y1 = a.xy1[2 * q + 1], x2 = a.xy2[2 * t], y2 = a.xy2[2 * t + 1];
+            p1w[2 * i] = x1; p1w[2 * i + 1] = y1; p2w[2 * i] = x2; p2w[2 * i + 1] = y2;
+            if (in_lds) { rs_pts[2 * i] = x1; rs_pts[2 * i + 1] = y1; rs_pts[2 * n + 2 * i] = x2; rs_pts[2 * n + 2 * i + 1] = y2; }
+        }
+    if (threadIdx.x == 0) {
+        c->lmeds = n <= RS_LMEDS_MAX;
+        c->budget = max(a.max_iters, 1);
+        if (c->lmeds) c->budget = max(update_num_iters(a.confidence, 0.45, RS_MP, a.max_iters), 1);   // LMeDS: fixed budget
+        c->rng_state = 0xffffffffffffffffULL;
+        c->n_subsets = 0; c->exhausted = 0;
+        c->best_h = c->best_k = -1;
+        c->best_count = 0; c->niters = 0; c->max_good = 0;
+        c->min_median = DBL_MAX;
+        if (n < 8) c->exhausted = 1;          // _dev entry with a device count: fewer than 8 matches pass through unfiltered
     }
-    sh[threadIdx.x] = good;
-    __syncthreads();
-    for (int s = RS_T / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) c->best_count = sh[0];
+    __syncthreads();                          // (the control block is read back by this workgroup only: same CU, no other cache)
+    // n > RS_LDS_POINTS with a gather: the sampler would read p1 / p2 from memory this workgroup has just written - the host
+    // entry point launches rs_gather_kernel first in that case and passes ij = NULL here
+    rs_subsets_step(a, a.h0, a.h1, rs_pts, gather && in_lds, &go);
 }
 
-// ---- device-resident front and back end (sslam_fmat_ransac_dev) -------------------------------------
-// matched pixel pairs from the matcher's index pairs
+// the separate gather of the sizes rs_head_kernel does not take (more matches than RS_LDS_POINTS)
 __global__ __launch_bounds__(RS_T) void rs_gather_kernel(RSArgs a, float* p1, float* p2) {
     const int n = rs_n(a);
     for (int i = blockIdx.x * RS_T + threadIdx.x; i < n; i += gridDim.x * RS_T) {
@@ -454,19 +456,59 @@ __global__ __launch_bounds__(RS_T) void rs_gather_kernel(RSArgs a, float* p1, fl
     }
 }
 
-// what filter_matches_ransac returns (features_utils.py:185-200): the pairs whose mask is set, in
-// order; all of them below 8 matches; none when OpenCV finds no model (mask None)
-__global__ __launch_bounds__(1024) void rs_compact_kernel(RSArgs a) {
-    __shared__ int wsum[16], base;
-    const RSCtrl* c = a.ctrl;
-    const int n = rs_n(a), lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const bool pass = n < 8;
-    const bool none = !pass && (c->best_h < 0 || (c->lmeds && c->best_count < RS_MP));
-    if (threadIdx.x == 0) base = 0;
+// ---- between chunks: the best / budget replay over the chunk just scored [h0, h1), then the samples of the next [h1, h2)
+__global__ __launch_bounds__(RS_T) void rs_step_kernel(RSArgs a, int h2) {
+    extern __shared__ __attribute__((aligned(16))) float rs_pts[];
+    __shared__ int go;
+    if (threadIdx.x == 0) rs_select_step(a, a.h0, a.h1);
     __syncthreads();
+    rs_subsets_step(a, a.h1, h2, rs_pts, false, &go);
+}
+
+// ---- last launch: the replay over the last chunk, the winner's threshold and matrix, its inlier mask and (device entry) what
+// filter_matches_ransac returns (features_utils.py:185-200): the pairs whose mask is set, in order; all of them below 8
+// matches; none when OpenCV finds no model (mask None)
+__global__ __launch_bounds__(1024) void rs_tail_kernel(RSArgs a) {
+    __shared__ int wsum[16], base;
+    __shared__ double Fw[9];
+    __shared__ float s_t;
+    RSCtrl* c = a.ctrl;
+    const int n = rs_n(a), lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) {
+        rs_select_step(a, a.h0, a.h1);
+        c->thresh = a.thresh;
+        if (c->lmeds && c->best_h >= 0) {
+            double sigma = 2.5 * 1.4826 * (1 + 5. / (n - RS_MP)) * sqrt(c->min_median);
+            c->thresh = fmax(sigma, 0.001);
+        }
+        if (c->best_h >= 0)
+            for (int i = 0; i < 9; ++i) { c->F[i] = a.models[(size_t)c->best_h * 27 + 9 * c->best_k + i]; Fw[i] = c->F[i]; }
+        s_t = (float)(c->thresh * c->thresh);
+        base = 0;
+    }
+    __syncthreads();
+    const bool have = c->best_h >= 0;
+    const float t = s_t;
+    const bool pass = n < 8;                   // features_utils.py:189-190: fewer than 8 matches are returned as they are
+    // inlier mask of the winner, then the order-preserving compaction of the index pairs, 1024 matches per turn
+    int good = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const int in = pass || (have && fm_error(Fw, a.p1[2 * i], a.p1[2 * i + 1], a.p2[2 * i], a.p2[2 * i + 1]) <= t);
+        a.mask[i] = (unsigned char)in;
+        good += in;
+    }
+    {
+        for (int o = 32; o > 0; o >>= 1) good += __shfl_xor(good, o);
+        if (lane == 0) wsum[w] = good;
+        __syncthreads();
+        if (threadIdx.x == 0) { int tot = 0; for (int j = 0; j < 16; ++j) tot += wsum[j]; c->best_count = tot; }
+        __syncthreads();
+    }
+    if (!a.ij_out && !a.info_out && !a.F_out) return;         // (host entry: mask and control block are read back as they are)
+    const bool none = !pass && (!have || (c->lmeds && c->best_count < RS_MP));
     for (int i0 = 0; i0 < n; i0 += 1024) {
         const int i = i0 + threadIdx.x;
-        const bool keep = i < n && !none && a.mask[i];
+        const bool keep = i < n && !none && a.mask[i];          // (this thread's own store above)
         const unsigned long long bal = __ballot(keep);
         if (lane == 0) wsum[w] = __popcll(bal);
         __syncthreads();
@@ -492,28 +534,32 @@ __global__ __launch_bounds__(1024) void rs_compact_kernel(RSArgs a) {
     }
 }
 
-// the sample loop + finish + mask (shared by the two entries)
-void rs_enqueue(hipStream_t s, RSArgs a, int max_iters) {
-    // the sample loop in chunks: a chunk whose first sample lies beyond the (shrinking) budget is a handful of early-exit
-    // launches.  The sample stream is replayed by ONE lane (cv::RNG is sequential: ~1.4 us per 7-point sample), so the first
-    // chunk is small - with the inlier ratios a matcher's output has, OpenCV's budget drops below 16 after the first good
-    // model and the 128-sample first chunk of r03 spent 180 us drawing samples the loop never looks at (r04: a call on ~600
-    // matches 324 -> ~90 us of GPU time) - and the rest are few and large: the result does not depend on the chunking.
-    // (r05: three chunks instead of four - a chunk that has nothing to do still costs its four launches, ~19 us - and a first
-    //  chunk of 8: at a matcher's inlier ratios the budget is 3 - 5 after the first all-inlier sample)
-    const int bounds[] = {0, 8, 128, max_iters};
+// the whole filter (shared by the two entries): 7 launches - head, then per chunk [solve + score], [replay + next samples] -
+// against the 17 of the thread / sample + workgroup / model form (r05 kernel trace: 116 us per call on ~600 matches, 40 of them
+// the eight early-exit launches of the two chunks a matcher's inlier ratios never reach).
+void rs_enqueue(hipStream_t s, RSArgs a, int max_iters, float* p1w, float* p2w) {
+    // the sample loop in chunks: a chunk whose first sample lies beyond the (shrinking) budget is two early-exit launches.
+    // The sample stream is replayed by ONE lane (cv::RNG is sequential: ~1.4 us per 7-point sample), so the first chunk is
+    // small - with the inlier ratios a matcher's output has, OpenCV's budget drops to 3 - 5 after the first all-inlier sample
+    // and the 128-sample first chunk of r03 spent 180 us drawing samples the loop never looks at - and the rest are few and
+    // large: the result does not depend on the chunking.
+    const int bounds[] = {0, std::min(8, max_iters), std::min(128, max_iters), max_iters};
     const size_t pts_lds = (size_t)std::min(a.n, RS_LDS_POINTS) * 16;
     (void)hipGetLastError();     // (a stale error of another library on this thread is not ours)
-    for (int ci = 0; ci < 3; ++ci) {
-        a.h0 = std::min(bounds[ci], max_iters); a.h1 = std::min(bounds[ci + 1], max_iters);
-        if (a.h1 <= a.h0) continue;
-        hipLaunchKernelGGL(rs_subsets_kernel, dim3(1), dim3(256), pts_lds, s, a);
-        hipLaunchKernelGGL(rs_models_kernel, dim3(sslam::cdiv(a.h1 - a.h0, 64)), dim3(64), 0, s, a);
-        hipLaunchKernelGGL(rs_score_kernel, dim3(a.h1 - a.h0, 3), dim3(RS_T), 0, s, a);
-        hipLaunchKernelGGL(rs_select_kernel, dim3(1), dim3(64), 0, s, a);
+    if (a.ij && a.n > RS_LDS_POINTS) {      // too many matches for the head kernel's LDS image: gather in a launch of its own
+        hipLaunchKernelGGL(rs_gather_kernel, dim3(std::min(sslam::cdiv(a.n, RS_T), 64)), dim3(RS_T), 0, s, a, p1w, p2w);
+        RSArgs h = a; h.ij = nullptr; h.h0 = bounds[0]; h.h1 = bounds[1];
+        hipLaunchKernelGGL(rs_head_kernel, dim3(1), dim3(RS_T), pts_lds, s, h, p1w, p2w);
+    } else {
+        RSArgs h = a; h.h0 = bounds[0]; h.h1 = bounds[1];
+        hipLaunchKernelGGL(rs_head_kernel, dim3(1), dim3(RS_T), pts_lds, s, h, p1w, p2w);
     }
-    hipLaunchKernelGGL(rs_finish_kernel, dim3(1), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(rs_mask_kernel, dim3(1), dim3(RS_T), 0, s, a);
+    for (int ci = 0; ci < 3; ++ci) {
+        a.h0 = bounds[ci]; a.h1 = bounds[ci + 1];
+        if (a.h1 > a.h0) hipLaunchKernelGGL(rs_models_score_kernel, dim3(a.h1 - a.h0), dim3(RS_T), 0, s, a);
+        if (ci < 2) hipLaunchKernelGGL(rs_step_kernel, dim3(1), dim3(RS_T), pts_lds, s, a, bounds[ci + 2]);
+    }
+    hipLaunchKernelGGL(rs_tail_kernel, dim3(1), dim3(1024), 0, s, a);       // (a.h0, a.h1: the last chunk)
 }
 
 struct RSScratch { size_t p1, p2, sub, mod, nm, cnt, med, mask, ctrl, total; };
@@ -555,7 +601,6 @@ extern "C" int sslam_fmat_ransac_dev(sslam_ctx* ctx, int n_max, const int32_t* n
     if (int rc = rs_reserve(ctx, L.total)) return rc;
     char* b = (char*)ctx->ba_scratch;
     hipStream_t s = ctx->stream;
-    SSLAM_HIP_CHECK(hipMemsetAsync(b + L.nm, 0, (size_t)max_iters * 4, s));
     RSArgs a{};
     a.n = n_max; a.n_dev = n_dev; a.max_iters = max_iters; a.thresh = thresh; a.confidence = confidence;
     a.xy1 = xy1_dev; a.xy2 = xy2_dev; a.ij = ij_dev; a.ij_out = ij_out_dev; a.info_out = info_out_dev; a.F_out = F_out_dev;
@@ -564,10 +609,7 @@ extern "C" int sslam_fmat_ransac_dev(sslam_ctx* ctx, int n_max, const int32_t* n
     a.counts = (int*)(b + L.cnt); a.medians = (float*)(b + L.med);
     a.mask = mask_out_dev ? mask_out_dev : (unsigned char*)(b + L.mask);
     a.ctrl = (RSCtrl*)(b + L.ctrl);
-    hipLaunchKernelGGL(rs_gather_kernel, dim3(std::min(sslam::cdiv(n_max, RS_T), 64)), dim3(RS_T), 0, s, a,
-                       (float*)(b + L.p1), (float*)(b + L.p2));
-    rs_enqueue(s, a, max_iters);
-    hipLaunchKernelGGL(rs_compact_kernel, dim3(1), dim3(1024), 0, s, a);
+    rs_enqueue(s, a, max_iters, (float*)(b + L.p1), (float*)(b + L.p2));
     SSLAM_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -591,14 +633,13 @@ extern "C" int sslam_fmat_ransac_host(sslam_ctx* ctx, int n, const float* pts1, 
     hipStream_t s = ctx->stream;
     SSLAM_HIP_CHECK(hipMemcpyAsync(b + o_p1, pts1, N * 8, hipMemcpyHostToDevice, s));
     SSLAM_HIP_CHECK(hipMemcpyAsync(b + o_p2, pts2, N * 8, hipMemcpyHostToDevice, s));
-    SSLAM_HIP_CHECK(hipMemsetAsync(b + L.nm, 0, (size_t)max_iters * 4, s));
     RSArgs a{};
     a.n = n; a.max_iters = max_iters; a.thresh = thresh; a.confidence = confidence;
     a.p1 = (const float*)(b + o_p1); a.p2 = (const float*)(b + o_p2);
     a.subsets = (int*)(b + L.sub); a.models = (double*)(b + L.mod); a.nmodels = (int*)(b + L.nm);
     a.counts = (int*)(b + L.cnt); a.medians = (float*)(b + L.med); a.mask = (unsigned char*)(b + o_mask);
     a.ctrl = (RSCtrl*)(b + o_ctrl);
-    rs_enqueue(s, a, max_iters);
+    rs_enqueue(s, a, max_iters, nullptr, nullptr);
     SSLAM_HIP_CHECK(hipGetLastError());
     RSCtrl h{};
     SSLAM_HIP_CHECK(hipMemcpyAsync(&h, b + o_ctrl, sizeof(RSCtrl), hipMemcpyDeviceToHost, s));

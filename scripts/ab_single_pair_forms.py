@@ -1,0 +1,54 @@
+"""A/B of the single-pair forms of the LightGlue forward (r05): the 4-stage ring of the big projections
+(SSLAM_LG_DEEP_RING) and the key-range merge folded into the fused FFN's prologue (SSLAM_LG_FOLD_MERGE), each read at
+instance creation.  For every combination: the match indices and scores of the same pairs (compared bit for bit with
+the combination 0/0 = the r04 form) and the device time of one forward.
+
+    python scripts/ab_single_pair_forms.py [N=2048] [iters=20]
+"""
+import importlib
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+import lg_inputs
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+pkg = importlib.import_module("opencv-simpleslam_amd")
+W = importlib.import_module("opencv-simpleslam_amd.weights")
+LG = importlib.import_module("opencv-simpleslam_amd.lightglue").LightGlueHIP
+ctx = pkg._native.default_context()
+sd = W.random_lightglue_state_dict(2, match_gain=4.0, match_bias=3.0)
+sizes = [(N, N), (N - 37, N - 411), (N // 2 + 5, N)]
+inputs = [lg_inputs.make_pair(m, n, seed=31 + i) for i, (m, n) in enumerate(sizes)]
+base = None
+for deep, fold in ((0, 0), (1, 0), (0, 1), (1, 1)):
+    os.environ["SSLAM_LG_DEEP_RING"] = str(deep); os.environ["SSLAM_LG_FOLD_MERGE"] = str(fold)
+    lg = LG(sd, max_kpts=N, max_pairs=1)
+    outs = [lg.match(k0, d0, k1, d1, min_conf=0.0) for (k0, d0, k1, d1) in inputs]
+    k0, d0, k1, d1 = inputs[0]
+    a = [ctx.upload(v) for v in (k0, d0, k1, d1)]
+    pair = [(a[0], a[1], N, a[2], a[3], N)]
+    ij = ctx.malloc(N * 8); sc = ctx.malloc(N * 4); info = ctx.malloc(16)
+    for _ in range(3):
+        lg.match_batch_dev(pair, ij, sc, info, N)
+    ctx.sync(); ctx.timer_start()
+    for _ in range(iters):
+        lg.match_batch_dev(pair, ij, sc, info, N)
+    ms = ctx.timer_stop() / iters
+    same = "reference form"
+    if base is None:
+        base = outs
+    else:
+        ok_ij = all(np.array_equal(o[0], b[0]) for o, b in zip(outs, base))
+        ok_sc = all(np.array_equal(o[1], b[1]) for o, b in zip(outs, base))
+        dmax = max((float(np.max(np.abs(o[1] - b[1]))) if o[1].shape == b[1].shape and len(o[1]) else 0.0) for o, b in zip(outs, base))
+        same = f"indices {'identical' if ok_ij else 'DIFFER'}, scores {'bit-identical' if ok_sc else f'differ (max {dmax:.2e})'}"
+    print(f"deep_ring={deep} fold_merge={fold}: {ms * 1e3:8.1f} us per forward, matches {[len(o[0]) for o in outs]}, stop {[o[2] for o in outs]}; {same}", flush=True)
+    for p_ in a + [ij, sc, info]:
+        ctx.free(p_)
+    lg.close()

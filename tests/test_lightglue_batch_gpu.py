@@ -339,3 +339,30 @@ def test_precision_f16x3p1_assembly_kernel_equals_the_4_wave_kernel_and_keeps_th
         np.testing.assert_array_equal(got[-3][p][0], o_ij)
     batch.debug_key_split(0)
     dev.free(); batch.close()
+
+
+@pytest.mark.parametrize("seed,kw", [(3, dict(match_gain=4.0, match_bias=3.0)),
+                                     (4, dict(match_gain=4.0, match_bias=-4.6, conf_bias=2.3))])
+def test_key_range_merge_inside_the_fused_ffn_equals_the_merge_launch(gpu_ctx, seed, kw):
+    """r05, one pair at the bench capacity (2048): the attention's key-range partials are merged by the fused FFN's
+    tiles in their prologue (ffn_fused.hpp FOLD) instead of by lg_attn_merge_h_kernel.  Same arithmetic, expression for
+    expression: indices, scores and stop layer identical to the form with the merge launch (debug_key_split(-4): the
+    4-wave kernel's partials + the launch) - full and ragged sizes, a tile with fewer than 32 live tokens, an image of one
+    keypoint, and (second weight set) pruning and an early stop that shrink the token sets from layer to layer."""
+    W, LG = load_pkg("weights"), load_pkg("lightglue").LightGlueHIP
+    sd = W.random_lightglue_state_dict(seed, **kw)
+    single = LG(sd, max_kpts=2048, ctx=gpu_ctx)
+    n_matches = 0
+    for m, n in [(2048, 2048), (1999, 1411), (2048, 1), (33, 2048), (1300, 1300)]:
+        pr = lg_inputs.make_pair(m, n, seed=7 * m + n)
+        single.debug_key_split(-4)
+        r_ij, r_sc, r_stop = single.match(*pr, min_conf=0.0)
+        single.debug_key_split(0)
+        ij, sc, stop = single.match(*pr, min_conf=0.0)
+        np.testing.assert_array_equal(ij, r_ij)
+        np.testing.assert_array_equal(sc, r_sc)
+        assert stop == r_stop
+        n_matches += len(ij)
+    assert n_matches > 100
+    assert not single.range_overflow()
+    single.close()
