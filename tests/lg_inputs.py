@@ -53,7 +53,10 @@ class PlantedExtractor:
     right behind it ON THE SAME STREAM, the frame's device record {count, keypoints, descriptors} is overwritten with the next
     set of a synthetic chain.  Everything downstream - the record read back into the caller's arrays, the look-ahead match the
     extraction enqueues, the device-resident keyframe matches - then sees one consistent frame, with no white-box access to
-    the product's state.  `frames`: [(xy, desc)]; the sets are served round-robin (page-locked copies, asynchronous uploads)."""
+    the product's state.  `frames`: [(xy, desc)]; the sets are served round-robin from DEVICE-resident copies made here, once
+    (r05: one device-to-device copy, ~10 us; as an upload from the host it put a copy-engine hand-over of ~18 us on either side
+    of a 1 MB transfer between every extraction and the match behind it.  A copy on a stream of its own, concurrent with the
+    extraction, was tried and measured the same frame time: not kept)."""
 
     def __init__(self, detector, frames):
         self.det, self.ctx = detector, detector.ctx
@@ -62,23 +65,30 @@ class PlantedExtractor:
         self.sets = []
         for xy, desc in frames:
             n = len(xy)
-            blk = self.ctx.host_alloc(16 + n * 8 + n * 512)
+            blk = np.empty(16 + n * 8 + n * 512, np.uint8)
             blk[:16].view(np.int32)[:] = (n, 0, 0, 0)
             blk[16:16 + n * 8].view(np.float32)[:] = xy.reshape(-1)
             blk[16 + n * 8:].view(np.float32)[:] = desc.reshape(-1)
-            self.sets.append((n, blk))
+            dev = self.ctx.malloc(blk.nbytes)
+            self.ctx.h2d(dev, blk)
+            self.sets.append((n, dev, blk.nbytes))
+        self.ctx.sync()
         detector.extract_dev = self
 
     def __call__(self, img_dev, H, Wd, Cn, xy_out, desc_out, score_out, n_out, max_kpts=None):
         self.real(img_dev, H, Wd, Cn, xy_out, desc_out, score_out, n_out, max_kpts=max_kpts)
-        n, blk = self.sets[self.i % len(self.sets)]
+        n, dev, nbytes = self.sets[self.i % len(self.sets)]
         self.i += 1
         if xy_out == n_out + 16 and desc_out == xy_out + n * 8:        # a full record [count | xy | desc] in one block: one copy
-            self.ctx.h2d_async(n_out, blk)
+            self.ctx.d2d_async(n_out, dev, nbytes)
             return
-        self.ctx.h2d_async(n_out, blk[:16])
-        self.ctx.h2d_async(xy_out, blk[16:16 + n * 8])
-        self.ctx.h2d_async(desc_out, blk[16 + n * 8:])
+        self.ctx.d2d_async(n_out, dev, 16)
+        self.ctx.d2d_async(xy_out, dev + 16, n * 8)
+        self.ctx.d2d_async(desc_out, dev + 16 + n * 8, n * 512)
 
     def restore(self):
         del self.det.extract_dev
+        self.ctx.sync()
+        for _, dev, _ in self.sets:
+            self.ctx.free(dev)
+        self.sets = []

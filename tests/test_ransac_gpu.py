@@ -33,7 +33,8 @@ def _check(E, p1, p2, thresh=1.0, conf=0.99):
     return mask
 
 
-@pytest.mark.parametrize("n,frac,seed", [(2048, 0.3, 0), (400, 0.5, 1), (100, 0.1, 2), (15, 0.2, 3), (900, 0.0, 4)])
+# (600 matches at 65 % outliers: the loop runs through all three chunks of the launch sequence - budget in the hundreds)
+@pytest.mark.parametrize("n,frac,seed", [(2048, 0.3, 0), (400, 0.5, 1), (100, 0.1, 2), (15, 0.2, 3), (900, 0.0, 4), (600, 0.65, 7)])
 def test_ransac_matches_oracle(E, n, frac, seed):
     p1, p2, truth = two_view.make_matches(n, outlier_frac=frac, noise=0.3, seed=seed)
     mask = _check(E, p1, p2)
@@ -110,7 +111,10 @@ def _dev_filter(E, ctx, kp1, kp2, ij, n_used, thresh=1.0):
     return h_ij[:h_info[0]], h_info, h_mask[:n_used].astype(bool), h_F.reshape(3, 3)
 
 
-@pytest.mark.parametrize("n,frac,seed,spare", [(2048, 0.3, 0, 0), (400, 0.5, 1, 37), (15, 0.2, 3, 5), (14, 0.15, 2, 0)])
+# (the last three: a loop that needs all three chunks; more matches than the head kernel's LDS image holds - the gather runs as
+#  a launch of its own and the sampler reads global memory; a bound above that limit with a device count below it)
+@pytest.mark.parametrize("n,frac,seed,spare", [(2048, 0.3, 0, 0), (400, 0.5, 1, 37), (15, 0.2, 3, 5), (14, 0.15, 2, 0),
+                                               (600, 0.65, 7, 0), (5000, 0.3, 5, 0), (3000, 0.4, 6, 2000)])
 def test_device_resident_filter_equals_the_host_entry(E, gpu_ctx, n, frac, seed, spare):
     """sslam_fmat_ransac_dev consumes the matcher's device outputs (keypoints, index pairs, a device
     count that may be below the buffer bound) and must leave exactly what the host entry returns for
