@@ -1,6 +1,7 @@
 """Repeatability stress of the batched LightGlue forward: the same 8-pair batch N times (plain and graph replay), every
 result compared bit for bit with the first - a race in the counted-wait streaming of the fused FFN or in the assembly
-attention kernel would show as a differing run.  usage: stress_lg_repeat.py [runs=60] [kpts=2048]"""
+attention kernel would show as a differing run.  usage: stress_lg_repeat.py [runs=60] [kpts=2048] [pairs=8]
+(pairs = 1: the single-pair path - key ranges in the attention, their merge inside the fused FFN's prologue; 2: the keyframe frames' launch)"""
 import importlib, sys
 from pathlib import Path
 import numpy as np
@@ -13,7 +14,7 @@ pkg = importlib.import_module("opencv-simpleslam_amd")
 W = importlib.import_module("opencv-simpleslam_amd.weights")
 LG = importlib.import_module("opencv-simpleslam_amd.lightglue").LightGlueHIP
 ctx = pkg._native.default_context()
-B = 8
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 lg = LG(W.random_lightglue_state_dict(2, match_gain=4.0, match_bias=3.0), max_kpts=N, max_pairs=B)
 pairs = []
 for b in range(B):
