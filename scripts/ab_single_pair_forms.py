@@ -1,7 +1,8 @@
-"""A/B of the single-pair forms of the LightGlue forward (r05): the 4-stage ring of the big projections
-(SSLAM_LG_DEEP_RING) and the key-range merge folded into the fused FFN's prologue (SSLAM_LG_FOLD_MERGE), each read at
-instance creation.  For every combination: the match indices and scores of the same pairs (compared bit for bit with
-the combination 0/0 = the r04 form) and the device time of one forward.
+"""A/B of the single-pair forms of the LightGlue forward (r05): the key-range merge as a launch of its own
+(SSLAM_LG_FOLD_MERGE=0, the r04 form) or folded into the fused FFN's prologue (1, the default), read at instance creation.
+For both: the match indices and scores of the same pairs (compared bit for bit) and the device time of one forward.
+(Measured with this script and not kept: a 4-stage LDS-DMA ring in the 128 x 128 projections - no faster; the 64-row ring
+projections with producer waves under the fused FFN - 1 356 against 1 338 us per forward.)
 
     python scripts/ab_single_pair_forms.py [N=2048] [iters=20]
 """
@@ -26,8 +27,8 @@ sd = W.random_lightglue_state_dict(2, match_gain=4.0, match_bias=3.0)
 sizes = [(N, N), (N - 37, N - 411), (N // 2 + 5, N)]
 inputs = [lg_inputs.make_pair(m, n, seed=31 + i) for i, (m, n) in enumerate(sizes)]
 base = None
-for deep, fold in ((0, 0), (1, 0), (0, 1), (1, 1)):
-    os.environ["SSLAM_LG_DEEP_RING"] = str(deep); os.environ["SSLAM_LG_FOLD_MERGE"] = str(fold)
+for deep, fold in ((0, 0), (0, 1)):
+    os.environ["SSLAM_LG_FOLD_MERGE"] = str(fold)
     lg = LG(sd, max_kpts=N, max_pairs=1)
     outs = [lg.match(k0, d0, k1, d1, min_conf=0.0) for (k0, d0, k1, d1) in inputs]
     k0, d0, k1, d1 = inputs[0]
@@ -48,7 +49,7 @@ for deep, fold in ((0, 0), (1, 0), (0, 1), (1, 1)):
         ok_sc = all(np.array_equal(o[1], b[1]) for o, b in zip(outs, base))
         dmax = max((float(np.max(np.abs(o[1] - b[1]))) if o[1].shape == b[1].shape and len(o[1]) else 0.0) for o, b in zip(outs, base))
         same = f"indices {'identical' if ok_ij else 'DIFFER'}, scores {'bit-identical' if ok_sc else f'differ (max {dmax:.2e})'}"
-    print(f"deep_ring={deep} fold_merge={fold}: {ms * 1e3:8.1f} us per forward, matches {[len(o[0]) for o in outs]}, stop {[o[2] for o in outs]}; {same}", flush=True)
+    print(f"fold_merge={fold}: {ms * 1e3:8.1f} us per forward, matches {[len(o[0]) for o in outs]}, stop {[o[2] for o in outs]}; {same}", flush=True)
     for p_ in a + [ij, sc, info]:
         ctx.free(p_)
     lg.close()
