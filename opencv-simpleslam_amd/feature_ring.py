@@ -102,6 +102,7 @@ class DeviceFeatureRing:
         self.ahead_on = False            # the prev -> cur pattern has been seen
         self.ahead = None                # outstanding look-ahead: dict(pairs=[(a, b), ...], thr, filter_thr)
         self.last_thr = None
+        self.shell_hint = 1 << 30        # DMatch shells to prepare behind a running match: from the last result (first time: all)
         # the keyframe role (the query side of non-consecutive matches against the newest frame)
         self.kf = None                   # the frame in that role
         self.kf_next = None              # a frame the loop has just promoted (its keyframe pair was asked twice)
@@ -358,8 +359,10 @@ class DeviceFeatureRing:
             ahead = self.ahead
             hit = ahead is not None and ahead["thr"] == thr and any(x is ra and y is rb for x, y in ahead["pairs"])
             if hit and match_shells is not None:
-                # the GPU may still be matching: build the DMatch objects meanwhile (indices resolve against the array below)
-                shells, src = match_shells(min(ra.n, rb.n))
+                # the GPU may still be matching: build the DMatch objects meanwhile (indices resolve against the array below) -
+                # as many as the last matches suggest, not one per keypoint: the unused ones are torn down AFTER the results
+                # have arrived, on the frame's critical path (1 400 of 2 048 at ~600 matches: ~30 us)
+                shells, src = match_shells(min(ra.n, rb.n, self.shell_hint))
             self._finish_ahead()
             e = self._memo_find(ra, rb, thr)
             if e is not None and not e["asked"]:         # a look-ahead's result, asked for the first time
@@ -395,12 +398,16 @@ class DeviceFeatureRing:
             out = MatchList(e["objs"], ij)
         elif shells is not None:
             src.ij = ij
-            del shells[k:]
+            if k < len(shells):
+                del shells[k:]
+            elif k > len(shells):                      # more matches than the hint prepared for
+                shells.extend(match_shells(k, src, len(shells))[0])
             out = MatchList(shells, ij)
         else:
             out = MatchList(matches_from_ij(ij), ij)
         if known and epoch is not None:
             e["objs"], e["objs_epoch"] = list(out), epoch
+        self.shell_hint = max(256, k + k // 4 + 64)
         if known:
             self._learn(ra, rb, thr, first_ask)
             self.results.append(dict(matches=out, k=k, ij=ij, a=ra, b=rb, thr=e["filter_thr"], none=e["none"], mask=e["mask"]))

@@ -161,14 +161,15 @@ except Exception:                          # noqa: BLE001
                 pairs = self.pairs = self.ij.tolist()
             return pairs[i]
 
-    def match_shells(n):
+    def match_shells(n, src=None, start=0):
         """n DMatch(-, -, 0, 0.0) objects without indices yet + the source to hand the [>= n, 2] int array to
-        (`src.ij = ij`) before anyone reads an index."""
-        src = _PairSource()
+        (`src.ij = ij`) before anyone reads an index.  With `src` and `start`: shells start .. n - 1 of an existing source
+        (more matches came back than shells had been prepared)."""
+        src = _PairSource() if src is None else src
         new = DMatch.__new__
         out = []
         add = out.append
-        for i in range(n):
+        for i in range(start, n):
             m = new(DMatch)
             m._src = src
             m._i = i

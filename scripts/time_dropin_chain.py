@@ -16,8 +16,8 @@ import bench
 args = SimpleNamespace(use_lightglue=True, max_features=bench.MAX_KPTS, min_conf=bench.MIN_CONF, ransac_thresh=2.5)
 det, mat = fu.init_feature_pipeline(args)
 ring = fu._ring_of(det)
-if os.environ.get("CHAIN_GRAPHS"):
-    det.use_graphs(True)
+if os.environ.get("CHAIN_GRAPHS"):                # (the ring replays the extraction as a hipGraph; CHAIN_GRAPHS=0: plain launches)
+    det.use_graphs(os.environ["CHAIN_GRAPHS"] != "0")
 planter = None if os.environ.get("CHAIN_NO_PLANT") else lg_inputs.PlantedExtractor(det, lg_inputs.make_chain(16, 2048, seed=7, noise=0.035, drop=0.1))
 imgs = [frames.noise_frame(i) for i in range(8)]
 ectx, mctx = ring.ctx, ring.mctx

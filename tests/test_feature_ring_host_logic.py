@@ -219,3 +219,24 @@ def test_dropped_frames_free_their_slots_and_recycled_ids_do_not_alias(rig):
     n = mat.host_calls
     fu.feature_matcher(ARGS, kp_prev, kp, des_prev.copy(), des, mat)
     assert mat.host_calls == n + 1
+
+
+def test_match_objects_prepared_from_the_last_count_are_topped_up_when_more_come_back(rig):
+    """The DMatch shells built behind a running match are sized from the last result (tearing down the unused ones is on the
+    frame's critical path), so a frame pair with many more matches than the last finds too few: the rest are built when the
+    results arrive, against the same index source."""
+    fu, det, mat, ring = rig.fu, rig.det, rig.mat, rig.ring
+    kp_prev, des_prev = fu.feature_extractor(ARGS, IMG, det)
+    seen = []
+    for f in range(1, 8):
+        kp, des = fu.feature_extractor(ARGS, IMG, det)
+        if f == 5:
+            ring.shell_hint = 3                       # as if the previous pairs had next to no matches
+        ms = fu.feature_matcher(ARGS, kp_prev, kp, des_prev, des, mat)
+        assert len(ms) >= 20
+        assert pairs(ms) == host_match(rig, kp_prev, kp, des_prev, des)
+        assert [m._i for m in ms if hasattr(m, "_i")] == list(range(len(ms)))       # one source, consecutive rows
+        seen.append(ring.shell_hint)
+        kp_prev, des_prev = kp, des
+    assert ring.stats["ahead"] >= 5                    # (the look-ahead path is the one that prepares shells)
+    assert all(h >= 256 for h in seen)                 # the hint follows the results again
