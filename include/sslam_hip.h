@@ -310,8 +310,9 @@ int sslam_lightglue_range_overflow(sslam_lightglue* lg, int* flag_out);
 int sslam_lightglue_profile(sslam_lightglue* lg, int enable);
 int sslam_lightglue_profile_read(sslam_lightglue* lg, float* total_ms_out, int32_t* launches_out);
 /* Test hooks: limit the executed layers; copy an internal buffer to the host.
- * debug_key_split: 0 = by batch size (no split for batched launches, 2 or 4 key ranges + a merge for one pair; the
- * hand-scheduled assembly attention kernel either way), -4 = the same policy on the r02 4-wave kernel, 1 / 2 / 4 = that
+ * debug_key_split: 0 = by batch size (no split for batched launches, 2 or 4 key ranges for one pair, merged by the fused
+ * FFN's tiles; the hand-scheduled assembly attention kernel either way), -5 = the same with the merge as a launch of its
+ * own, -4 = that policy on the r02 4-wave kernel, 1 / 2 / 4 = that
  * many key ranges (4-wave kernel), 101 / 102 / 104 = that many (assembly kernel), -1 = no split, r02 4-wave kernel,
  * -3 = no split, the assembly kernel at any batch size (for one split the two kernels give bit-identical results). */
 int sslam_lightglue_debug_layers(sslam_lightglue* lg, int layers, int self_only);

@@ -1950,7 +1950,6 @@ struct sslam_lightglue {
     int p_single = 1;                // precision "f16x3p1" (set_precision 2, the DEFAULT since r05 - profiles/r05_flip_soak.md): P as one fp16 plane in P.V, row sums over the rounded weights
     int study = 0;                   // precision study (sslam_lightglue_debug_split_form): which cross terms of the split products are dropped
     _Float16* zero_plane = nullptr;  // study only: an all-zero fp16 plane standing in for a dropped low plane
-    int fold_merge = 1;              // test hook (SSLAM_LG_FOLD_MERGE=0 at creation): 0 = key-range partials merged by lg_attn_merge_h_kernel
     int big_gemm = -1;               // test hook: -1 by batch size, 0 / 1 force the single-pair (ring) / batched form of the linears;
                                      // 2 / 3: batched form with 64- / 32-token FFN tiles whatever the size
     _Float16 *w_hi, *w_lo;           // whole weight blob, split
@@ -2024,8 +2023,8 @@ int attn_key_split(const sslam_lightglue* g, int NI) {
     int ks = 1;
     if (g->force_ks > 100) ks = g->force_ks - 100;     // (test hook: forced split, assembly kernel)
     else if (g->force_ks > 0) ks = g->force_ks;        // (test hook: forced split, the 4-wave r02 kernel)
-    else if (g->force_ks < 0 && g->force_ks != -4) ks = 1;   // (test hooks, no key split: -1 the 4-wave r02 kernel, -3 the assembly kernel)
-    else {                                             // 0, and -4 = the same policy on the 4-wave r02 kernel
+    else if (g->force_ks < 0 && g->force_ks > -4) ks = 1;    // (test hooks, no key split: -1 the 4-wave r02 kernel, -3 the assembly kernel)
+    else {                                             // 0, -4 = the same policy on the 4-wave r02 kernel, -5 = on the assembly kernel with the merge as a launch
         // one workgroup per CU is the measured optimum of the assembly kernel (2048-keypoint pair, 128 units: no split 1.68 ms
         // per forward, 2 ranges 1.59, 4 ranges 1.65; the 4-wave kernel 1.69 at 2 or 4)
         const int units = NI * NH * (g->Kc / AQ);
@@ -2169,7 +2168,7 @@ void launch_attention_h(sslam_lightglue* g, hipStream_t s, int NI, SplitPtr Q, S
     AttnArgsH a{Q, K, VT, cross, g->o_part, g->m_part, g->l_part, SplitOut{g->msgs_hi, g->msgs_lo}, KS, g->Kc,
                 g->NIc, g->ctrl, ((g->study & 0x04) || g->p_single) ? 1 : 0};     // O = vh.ph + vl.ph: study bit 0x04 (4-wave kernel only) or precision "f16x3p1"
     attn_event(g, s, true);
-    if (!(g->study & 0x04) && (g->force_ks == 0 || g->force_ks == -3 || g->force_ks > 100)) {
+    if (!(g->study & 0x04) && (g->force_ks == 0 || g->force_ks == -3 || g->force_ks == -5 || g->force_ks > 100)) {
         // the hand-scheduled assembly kernel - the arithmetic, LDS images and results of lg_attention_p_kernel (no key split: batched
         // launches, debug_key_split(lg, -3)) and of lg_attention_p_kernel's key ranges (single pairs) bit for bit, 8 - 10 % faster
         // (profiles/r03_attention_experiments.md)
@@ -2215,8 +2214,7 @@ bool lg_layer_h(sslam_lightglue* g, hipStream_t s, int NI, const LGLayerW& l, in
     // one pair: the attention's key-range partials are merged by the FFN tiles (ffn_fused.hpp FOLD), not by a launch of their own
     const int KS = attn_key_split(g, NI);
     const bool small_tiles = g->big_gemm == 3 || (g->big_gemm != 2 && NI * (g->Kc / 64) <= 128);
-    const bool fold = big && small_tiles && KS > 1 && st == 0 && g->fold_merge != 0 &&
-                      (g->force_ks == 0 || g->force_ks == -3 || g->force_ks > 100);      // (the assembly kernel's partial layout)
+    const bool fold = big && small_tiles && KS > 1 && st == 0 && (g->force_ks == 0 || g->force_ks > 100);   // (test hooks -4 / -5: the merge launch)
     auto ffn = [&](int cross, const float* w1, const float* b1, const float* lnw, const float* lnb, const float* w2,
                    const float* b2) {
         if (big) {
@@ -2473,7 +2471,6 @@ int sslam_lightglue_create_batched(sslam_ctx* ctx, const float* weights, size_t 
     g->NB = max_pairs; g->NIc = 2 * max_pairs;
     g->KSmax = Kc >= 1024 ? 4 : (Kc >= 512 ? 2 : 1);
     if (const char* e = getenv("SSLAM_LG_SIM_EXACT")) g->sim_exact = e[0] == '1';
-    if (const char* e = getenv("SSLAM_LG_FOLD_MERGE")) g->fold_merge = e[0] == '1';
     const size_t K = (size_t)Kc, NI = (size_t)g->NIc, NB = (size_t)max_pairs;
     auto carve = [&](sslam::Arena& A) {
         g->blob = A.take<float>(n_floats);
@@ -2755,8 +2752,9 @@ int sslam_lightglue_debug_layers(sslam_lightglue* g, int layers, int self_only) 
 
 /* Test hook: force the key split of the attention launches (0 = chosen by batch size). */
 int sslam_lightglue_debug_key_split(sslam_lightglue* g, int ks) {
-    SSLAM_REQUIRE(g != nullptr && ((ks >= -4 && ks <= 2 && ks != -2) || ks == 4 || ks == 101 || ks == 102 || ks == 104),
-                  "sslam_lightglue_debug_key_split: ks must be -4 (split by size, r02 4-wave kernel), -3 (no split, assembly kernel), "
+    SSLAM_REQUIRE(g != nullptr && ((ks >= -5 && ks <= 2 && ks != -2) || ks == 4 || ks == 101 || ks == 102 || ks == 104),
+                  "sslam_lightglue_debug_key_split: ks must be -5 (split by size, assembly kernel, the merge as a launch of its own), "
+                  "-4 (split by size, r02 4-wave kernel), -3 (no split, assembly kernel), "
                   "-1 (no split, r02 4-wave kernel), 0, 1, 2 or 4 (forced split, r02 4-wave kernel), 101, 102 or 104 (forced split, "
                   "assembly kernel)");
     g->settings_changed();

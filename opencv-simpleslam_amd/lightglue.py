@@ -127,8 +127,8 @@ class LightGlueHIP:
 
     def debug_key_split(self, ks: int):
         """Test hook: the key split of the attention launches.  0 = by batch size (none for batched launches, 2 or 4 key
-        ranges + a merge for one pair) on the hand-scheduled assembly kernel; -4 = the same policy on the r02 4-wave
-        kernel; 1 / 2 / 4 = that many ranges (4-wave kernel); 101 / 102 / 104 = that many (assembly kernel); no split at
+        ranges for one pair, merged by the fused FFN's tiles) on the hand-scheduled assembly kernel; -5 = the same with the
+        merge as a launch of its own (the r04 form); -4 = that policy on the r02 4-wave kernel (merge launch); 1 / 2 / 4 = that many ranges (4-wave kernel); 101 / 102 / 104 = that many (assembly kernel); no split at
         any size: -1 the 4-wave kernel, -3 the assembly kernel - for A/B and bit-identity checks."""
         self.epoch += 1
         _native.check(_native.lib().sslam_lightglue_debug_key_split(self.handle, int(ks)))

@@ -1,5 +1,5 @@
 """A/B of the single-pair forms of the LightGlue forward (r05): the key-range merge as a launch of its own
-(SSLAM_LG_FOLD_MERGE=0, the r04 form) or folded into the fused FFN's prologue (1, the default), read at instance creation.
+(debug_key_split(-5), the r04 form) or folded into the fused FFN's prologue (0, the default).
 For both: the match indices and scores of the same pairs (compared bit for bit) and the device time of one forward.
 (Measured with this script and not kept: a 4-stage LDS-DMA ring in the 128 x 128 projections - no faster; the 64-row ring
 projections with producer waves under the fused FFN - 1 356 against 1 338 us per forward.)
@@ -27,9 +27,9 @@ sd = W.random_lightglue_state_dict(2, match_gain=4.0, match_bias=3.0)
 sizes = [(N, N), (N - 37, N - 411), (N // 2 + 5, N)]
 inputs = [lg_inputs.make_pair(m, n, seed=31 + i) for i, (m, n) in enumerate(sizes)]
 base = None
-for deep, fold in ((0, 0), (0, 1)):
-    os.environ["SSLAM_LG_FOLD_MERGE"] = str(fold)
+for fold in (0, 1):
     lg = LG(sd, max_kpts=N, max_pairs=1)
+    lg.debug_key_split(0 if fold else -5)
     outs = [lg.match(k0, d0, k1, d1, min_conf=0.0) for (k0, d0, k1, d1) in inputs]
     k0, d0, k1, d1 = inputs[0]
     a = [ctx.upload(v) for v in (k0, d0, k1, d1)]

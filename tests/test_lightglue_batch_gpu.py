@@ -346,8 +346,8 @@ def test_precision_f16x3p1_assembly_kernel_equals_the_4_wave_kernel_and_keeps_th
 def test_key_range_merge_inside_the_fused_ffn_equals_the_merge_launch(gpu_ctx, seed, kw):
     """r05, one pair at the bench capacity (2048): the attention's key-range partials are merged by the fused FFN's
     tiles in their prologue (ffn_fused.hpp FOLD) instead of by lg_attn_merge_h_kernel.  Same arithmetic, expression for
-    expression: indices, scores and stop layer identical to the form with the merge launch (debug_key_split(-4): the
-    4-wave kernel's partials + the launch) - full and ragged sizes, a tile with fewer than 32 live tokens, an image of one
+    expression: indices, scores and stop layer identical to the forms with the merge launch (debug_key_split(-5): the same
+    assembly kernel's partials + the launch; -4: the 4-wave kernel's) - full and ragged sizes, a tile with fewer than 32 live tokens, an image of one
     keypoint, and (second weight set) pruning and an early stop that shrink the token sets from layer to layer."""
     W, LG = load_pkg("weights"), load_pkg("lightglue").LightGlueHIP
     sd = W.random_lightglue_state_dict(seed, **kw)
@@ -355,13 +355,14 @@ def test_key_range_merge_inside_the_fused_ffn_equals_the_merge_launch(gpu_ctx, s
     n_matches, stops = 0, []
     for m, n in [(2048, 2048), (1999, 1411), (2048, 1), (33, 2048), (1300, 1300)]:
         pr = lg_inputs.make_pair(m, n, seed=7 * m + n)
-        single.debug_key_split(-4)
-        r_ij, r_sc, r_stop = single.match(*pr, min_conf=0.0)
         single.debug_key_split(0)
         ij, sc, stop = single.match(*pr, min_conf=0.0)
-        np.testing.assert_array_equal(ij, r_ij)
-        np.testing.assert_array_equal(sc, r_sc)
-        assert stop == r_stop
+        for form in (-5, -4):
+            single.debug_key_split(form)
+            r_ij, r_sc, r_stop = single.match(*pr, min_conf=0.0)
+            np.testing.assert_array_equal(ij, r_ij)
+            np.testing.assert_array_equal(sc, r_sc)
+            assert stop == r_stop
         n_matches += len(ij); stops.append(stop)
     if seed == 3:
         assert n_matches > 100
