@@ -53,13 +53,14 @@ __device__ __forceinline__ float selu(float x) {
 // wave) about once in 150 frames when several extractor streams share the GPU - g1, s8 and every other kernel's output stayed
 // bit-stable (scripts/stress_aliked_repeat.py, r04: bisected over commits and call sites).  r05 narrowed it
 // (profiles/r05_aggregate_selu_hazard.md, scripts/ab_stress_aliked.sh with -DAL_AGG_FAST_SELU=<bits>): the channel LOOP on
-// v_exp_f32 is stable (0 of 1 440 frames); the eight v_exp_f32 of the TAIL (the s8 outputs, a few dozen instructions in
-// front of the v_sqrt_f32 / v_div_scale / v_rcp_f32 / v_div_fmas chain of the norm) reproduce it (3 - 5 events per 1 440
-// frames) - with the norm moved in front of them in the source and with 32 idle cycles tied to its operand as well.  n2 is
-// final ~500 instructions earlier and only `rnorm` is affected, so the fault is inside that sqrt / divide chain when
-// transcendental instructions of the same wave precede it; every static wait-state rule of the ISA is met in the
-// compiler's output.  Not explained further: the kernel is not issue-bound (no time difference), so it stays on the
-// polynomial form, and the concurrency stress is a GPU test (test_extraction_is_deterministic_under_concurrency).
+// v_exp_f32 is stable (0 of 1 440 frames); builds with the eight v_exp_f32 in the TAIL (the s8 outputs) reproduce it (3 - 5
+// events per 1 440 frames) - whatever the form of the norm behind them: moved in front, padded with idle cycles in front of or
+// behind v_sqrt / v_rcp, or made of FMAs only (scripts/ubench/r05_agg_norm_experiments.patch).  n2 does not change across the
+// exponentials and the norm is a consistent function of it: n2 is already slightly wrong when the tail begins.  The cheap
+// tail is a switch, not the place - it gives the compiler another schedule for the whole kernel, and that code shape is
+// sensitive to what else runs on the GPU.  Not explained beyond that: the kernel is not issue-bound (no time difference),
+// so it stays on the polynomial form - the code shape that is bit-stable in every stress run - and the concurrency stress
+// is a GPU test (test_extraction_is_deterministic_under_concurrency).
 #ifndef AL_AGG_FAST_SELU
 #define AL_AGG_FAST_SELU 0
 #endif
