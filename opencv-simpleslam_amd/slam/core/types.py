@@ -31,6 +31,7 @@ except Exception:                          # noqa: BLE001
         A keypoint made by `keypoint_shells` reads its `pt` from the frame's coordinate array on first use
         (then keeps it), so the objects can be built while the GPU is still extracting."""
         __slots__ = ("_pt", "_src", "_i", "__dict__")
+        edits = 0          # bumped by every `pt` assignment on any instance (see keypoint_edit_epoch)
 
         def __init__(self, x=0.0, y=0.0, size=1.0, angle=-1.0, response=0.0, octave=0, class_id=-1):
             self._pt = (float(x), float(y))
@@ -57,6 +58,7 @@ except Exception:                          # noqa: BLE001
         def pt(self, v):
             x, y = v
             self._pt = (float(x), float(y))
+            KeyPoint.edits += 1
 
         def __repr__(self):
             return f"KeyPoint(pt={self.pt})"
@@ -149,15 +151,23 @@ except Exception:                          # noqa: BLE001
             return f"DMatch({self.queryIdx}->{self.trainIdx})"
 
     class _PairSource:
-        __slots__ = ("ij", "pairs")
+        """The [K,2] index pairs a call's match shells resolve against.  The first few reads convert their own row (the
+        filter's spot check of eight matches must not pay for the list); from the 17th on, the whole array goes to python
+        ints in one C pass - as `_PointSource` does for the keypoints."""
+        __slots__ = ("ij", "pairs", "reads")
 
         def __init__(self):
             self.ij = None
             self.pairs = None
+            self.reads = 0
 
         def pair(self, i):
             pairs = self.pairs
             if pairs is None:
+                self.reads += 1
+                if self.reads <= 16:
+                    q, t = self.ij[i]
+                    return (int(q), int(t))
                 pairs = self.pairs = self.ij.tolist()
             return pairs[i]
 
@@ -177,6 +187,12 @@ except Exception:                          # noqa: BLE001
             m.distance = 0.0
             add(m)
         return out, src
+
+
+def keypoint_edit_epoch():
+    """A counter that moves whenever the `pt` of ANY KeyPoint of this module's duck type is assigned (None with cv2's own class,
+    which cannot be watched): a KeyPointList made at an epoch still holds what it was built from while the counter stands still."""
+    return None if HAVE_CV2 else KeyPoint.edits
 
 
 def dmatch_edit_epoch():
@@ -230,14 +246,16 @@ class KeyPointList(list):
     array it was built from and whether it has been edited since (every list mutator sets `_dirty`), so that
     `feature_matcher` can use the copy of the keypoints that is still on the GPU instead of rebuilding and
     re-uploading them.  A copy (`list(kps)`), a slice or an edited list is an ordinary / dirty list and takes
-    the rebuilding path.  (An in-place edit of an ELEMENT - `kps[i].pt = ...` - cannot be seen by the list;
-    the matcher spot-checks eight elements against the remembered array and falls back when they differ.)"""
-    __slots__ = ("_xy", "_dirty")
+    the rebuilding path.  (An in-place edit of an ELEMENT - `kps[i].pt = ...` - cannot be seen by the list: with this module's
+    duck type every `pt` assignment anywhere moves a counter the list compares with its own; with cv2's class eight elements
+    are spot-checked against the remembered array.)"""
+    __slots__ = ("_xy", "_dirty", "_epoch")
 
     def __init__(self, items=(), xy=None):
         super().__init__(items)
         self._xy = xy
         self._dirty = xy is None
+        self._epoch = keypoint_edit_epoch()
 
     def _touch(self):
         self._dirty = True
@@ -259,8 +277,13 @@ class KeyPointList(list):
         """The array this list was built from if it is provably still what the list holds, else None."""
         if self._dirty or self._xy is None or len(self) != len(self._xy):
             return None
+        if self._epoch is not None:                        # duck type: no `pt` has been assigned anywhere since the list was made
+            if self._epoch == KeyPoint.edits:
+                return self._xy
+            self._dirty = True
+            return None
         n = len(self)
-        for i in range(0, n, max(1, n // 8)):              # spot check against in-place element edits
+        for i in range(0, n, max(1, n // 8)):              # cv2's class: spot check against in-place element edits
             x, y = self[i].pt
             if x != float(self._xy[i, 0]) or y != float(self._xy[i, 1]):
                 self._dirty = True
@@ -273,13 +296,15 @@ class MatchList(list):
     int32 [K,2] (queryIdx, trainIdx) array it was built from and whether it has been edited since (every list mutator sets
     `_dirty`), so that `filter_matches_ransac` may apply the inlier mask the device computed for exactly these pairs in
     exactly this order.  A sorted / filtered / copied list is an ordinary or dirty list and is filtered from scratch.  (An
-    in-place edit of an ELEMENT - `m.queryIdx = ...` - cannot be seen by the list; eight elements are spot-checked.)"""
-    __slots__ = ("_ij", "_dirty")
+    in-place edit of an ELEMENT - `m.queryIdx = ...` - cannot be seen by the list: the duck type's edit counter is compared,
+    see dmatch_edit_epoch; with cv2's class eight elements are spot-checked.)"""
+    __slots__ = ("_ij", "_dirty", "_epoch")
 
     def __init__(self, items=(), ij=None):
         super().__init__(items)
         self._ij = ij
         self._dirty = ij is None
+        self._epoch = dmatch_edit_epoch()
 
     def _touch(self):
         self._dirty = True
@@ -301,8 +326,13 @@ class MatchList(list):
         """The pair array this list was built from if it is provably still what the list holds, else None."""
         if self._dirty or self._ij is None or len(self) != len(self._ij):
             return None
+        if self._epoch is not None:                        # duck type: no index has been assigned anywhere since the list was made
+            if self._epoch == DMatch.edits:
+                return self._ij
+            self._dirty = True
+            return None
         n = len(self)
-        for i in range(0, n, max(1, n // 8)):              # spot check against in-place element edits
+        for i in range(0, n, max(1, n // 8)):              # cv2's class: spot check against in-place element edits
             m = self[i]
             if m.queryIdx != int(self._ij[i, 0]) or m.trainIdx != int(self._ij[i, 1]):
                 self._dirty = True
