@@ -306,11 +306,49 @@ def dropin_leg(n_frames=48):
                                               "what the same calls cost when the network's own depth control is active, as it is with trained "
                                               "weights on overlapping frames; an illustration, never `value`")
     out["matches_last_pair"] = planted["matches_median"]
+    try:
+        out["value_kpts4000"] = dropin_value_at(4000, 20)
+    except Exception as e:                       # (an auxiliary figure must not cost the leg)
+        out["value_kpts4000"] = {"error": repr(e)}
     out["what"] = ("sequential host API as main_revamped.py drives it, one frame at a time, host objects in and out: feature_extractor on "
                    "1241x376 frames whose device record is overwritten, on the extractor's stream inside the timed call, with the next "
                    "frame of a synthetic MATCHED chain (2048 keypoints) so that RANSAC, DMatch construction and the read-back do real "
                    "work; then feature_matcher + filter_matches_ransac (threshold 2.5 px, the reference's default)")
     return out
+
+
+def dropin_value_at(max_kpts, n_frames):
+    """The `value` loop of the drop-in leg (one match per frame + the filter, planted chain) at another keypoint budget - 4000 is
+    the reference's own default (`main_revamped.py:206` --max_features); BASELINE.json quotes the metric at 2048."""
+    import gc
+    from types import SimpleNamespace
+    fu = importlib.import_module("opencv-simpleslam_amd.slam.core.features_utils")
+    sys.path.insert(0, str(ROOT / "tests"))
+    import lg_inputs
+    args = SimpleNamespace(use_lightglue=True, max_features=max_kpts, min_conf=MIN_CONF)
+    det, mat = fu.init_feature_pipeline(args)
+    planter = lg_inputs.PlantedExtractor(det, lg_inputs.make_chain(8, max_kpts, seed=7, noise=0.035, drop=0.1))
+    imgs = [structured_frame(i) for i in range(n_frames + 4)]
+    tot, nm, nf = [], [], []
+    gc.collect(); gc.freeze()
+    try:
+        kp_prev, des_prev = fu.feature_extractor(args, imgs[0], det)
+        for f, im in enumerate(imgs[1:], 1):
+            t0 = time.perf_counter()
+            kp, des = fu.feature_extractor(args, im, det)
+            m = fu.feature_matcher(args, kp_prev, kp, des_prev, des, mat)
+            flt = fu.filter_matches_ransac(kp_prev, kp, m, 2.5)
+            t1 = time.perf_counter()
+            kp_prev, des_prev = kp, des
+            if f >= 4:
+                tot.append(t1 - t0); nm.append(len(m)); nf.append(len(flt))
+    finally:
+        planter.restore()
+        gc.unfreeze()
+        det.close(); mat.close()
+    return {"value": round(1.0 / float(np.median(tot)), 1), "unit": "frames/s", "frames_timed": len(tot), "keypoints": len(kp),
+            "frame_ms": round(float(np.median(tot)) * 1e3, 3), "matches_median": int(np.median(nm)), "ransac_inliers_median": int(np.median(nf)),
+            "what": f"the one-match-per-frame loop of `dropin.value` at max_features = {max_kpts} (the reference's default is 4000)"}
 
 
 def cpu_baseline():

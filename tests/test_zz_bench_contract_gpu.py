@@ -40,6 +40,8 @@ def test_bench_contract_single_rank():
     assert sl["value"] > 0 and sl["keyframe_frames"] >= 3 and sl["answered_from"]["memo"] >= 3 and sl["answered_from"]["reupload"] == 0, sl
     dc = d["dropin"]["slam_loop_depth_control"]
     assert dc.get("value", 0) > 0 and dc["lightglue_layers_last_pair"] < 9 and dc["matches_median"] > 100, dc      # early stop fired, matches kept
+    v4 = d["dropin"]["value_kpts4000"]                   # the reference's default max_features
+    assert v4.get("value", 0) > 0 and v4["keypoints"] == 4000 and v4["matches_median"] > 100, v4
     assert "resident in HBM" in d["config"]["workload"] and d["gpu_busy_s"] > 0
     assert d["pcie"]["value"] > 0 and d["pcie"]["h2d_bytes_per_round"] == 6 * 1241 * 376 * 3, d["pcie"]
     for leg in ("c5", "kpts4000"):
