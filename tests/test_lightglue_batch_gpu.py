@@ -370,3 +370,24 @@ def test_key_range_merge_inside_the_fused_ffn_equals_the_merge_launch(gpu_ctx, s
         assert any(s_ < 9 for s_ in stops)                      # (this weight set stops early and prunes)
     assert not single.range_overflow()
     single.close()
+
+
+@pytest.mark.parametrize("cap,m,n", [(2100, 2100, 1977), (3000, 2950, 3000), (2300, 33, 2300)])
+def test_key_range_merge_inside_the_fused_ffn_at_other_capacities(gpu_ctx, cap, m, n):
+    """The same equality at capacities whose row count is not 2048 (Kc = 2176, 3072, 2304: other tile counts per image, other
+    partial strides), and the oracle's indices there."""
+    W, LG = load_pkg("weights"), load_pkg("lightglue").LightGlueHIP
+    sd = W.random_lightglue_state_dict(3, match_gain=4.0, match_bias=3.0)
+    single = LG(sd, max_kpts=cap, ctx=gpu_ctx)
+    pr = lg_inputs.make_pair(m, n, seed=3 * m + n)
+    ij, sc, stop = single.match(*pr, min_conf=0.5)
+    single.debug_key_split(-5)
+    r_ij, r_sc, r_stop = single.match(*pr, min_conf=0.5)
+    np.testing.assert_array_equal(ij, r_ij)
+    np.testing.assert_array_equal(sc, r_sc)
+    assert stop == r_stop
+    o_ij, o_sc, o_stop = _oracle(sd, pr, 0.5)
+    np.testing.assert_array_equal(ij, o_ij)
+    assert stop == o_stop and len(ij) > 10
+    assert not single.range_overflow()
+    single.close()
