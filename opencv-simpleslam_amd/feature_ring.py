@@ -153,9 +153,11 @@ class DeviceFeatureRing:
             key = (rec.desc_ref() is not None, rec.used)
             if victim is None or key < victim[0]:
                 victim = (key, sl)
-        sl = victim[1]                               # (SLOTS >= 6: at most newest + keyframe + promoted + 2 look-ahead operands are held)
-        sl["rec"].slot = None                        # evicted: the record stays known and is uploaded again on its next use
-        sl["rec"] = None
+        sl = victim[1]                               # (SLOTS >= 7: at most newest + keyframe + promoted + `keep` + 2 look-ahead operands are held)
+        rec = sl["rec"]                              # (None by now if a collection inside this loop ran the victim's drop callback)
+        if rec is not None:
+            rec.slot = None                          # evicted: the record stays known and is uploaded again on its next use
+            sl["rec"] = None
         return sl
 
     def _make_resident(self, rec, des, keep=None):
