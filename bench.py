@@ -32,6 +32,12 @@ Rank 0 prints ONE JSON line with the contract fields plus
   dropin       - the six names of slam/core/features_utils.py driven as
                  slam/monocular/main_revamped.py drives them (one frame at a
                  time, host objects in and out): frames/s of that literal path
+                 (+ `dropin.cv2_classes`: the same loops in a child interpreter where `cv2`
+                 is importable - a stand-in with C value classes - so the lists hold cv2's own
+                 KeyPoint / DMatch objects, as they do wherever the reference runs)
+  planted_matches - the pipeline of `value` on frames that MATCH (records overwritten
+                 behind every batched extraction with a synthetic matched chain, LightGlue
+                 weights with a sharp assignment head): hundreds of matches per pair
   early_stop   - the pipeline with random weights whose token-confidence biases
                  are calibrated on one pair of the stream so that points are
                  pruned and pairs stop early (depth AND width control under load)
@@ -178,7 +184,7 @@ def _cpu_leg(threads, warmup, timed, budget_s, probe_limit_s=6.0):
             "p90_s": round(float(np.percentile(a, 90)), 4), "frames_per_s": round(1.0 / float(np.median(a)), 4)}
 
 
-def dropin_leg(n_frames=48):
+def dropin_leg(n_frames=48, only_matched_loops=False):
     """The literal drop-in path: init_feature_pipeline / feature_extractor / feature_matcher / filter_matches_ransac exactly as
     slam/monocular/main_revamped.py calls them - one frame at a time, host arrays and KeyPoint / DMatch objects in and out,
     nothing overlapped by the caller.  Three loops over the same 1241x376 frames:
@@ -258,7 +264,7 @@ def dropin_leg(n_frames=48):
     # generation; collection of what the loops themselves allocate stays on, as in a caller's process.
     import gc
     gc.collect(); gc.freeze()
-    frame_loop = loop(False)
+    frame_loop = None if only_matched_loops else loop(False)
 
     sys.path.insert(0, str(ROOT / "tests"))
     import lg_inputs
@@ -275,6 +281,8 @@ def dropin_leg(n_frames=48):
         # fractions EARLY_STOP_CONFIDENT of the points above the layer's threshold), matchability untouched: the decisions
         # are data dependent, pairs stop early, matches survive.  Never `value`.
         try:
+            if only_matched_loops:
+                raise StopIteration
             Wm = importlib.import_module("opencv-simpleslam_amd.weights")
             LightGlueHIP = importlib.import_module("opencv-simpleslam_amd.lightglue").LightGlueHIP
             sd_e = calibrated_confidence_heads(Wm.random_lightglue_state_dict(1, match_gain=4.0, match_bias=3.0, conf_gain=16.0),
@@ -287,6 +295,8 @@ def dropin_leg(n_frames=48):
             adaptive["lightglue_layers_last_pair"] = int(ring.pin_info[0, 1])
             ring.attach_matcher(mat)
             mat_e.close()
+        except StopIteration:
+            pass
         except Exception as e:                       # (an auxiliary figure must not cost the leg)
             adaptive = {"error": repr(e)}
     finally:
@@ -294,6 +304,10 @@ def dropin_leg(n_frames=48):
         gc.unfreeze()
     det.close(); mat.close()
     out = dict(planted)
+    if only_matched_loops:
+        out["slam_loop"] = slam
+        out["matches_last_pair"] = planted["matches_median"]
+        return out
     out["frame_loop"] = dict(frame_loop, what="real structured frames through all three calls; random-init networks match (almost) "
                              "nothing, so this is extract + match only (the prev -> cur match rides behind the extraction)")
     out["slam_loop"] = dict(slam, what="main_revamped.py's call pattern with kf_cooldown 5 on the planted chain: every frame extract + "
@@ -314,6 +328,32 @@ def dropin_leg(n_frames=48):
                    "1241x376 frames whose device record is overwritten, on the extractor's stream inside the timed call, with the next "
                    "frame of a synthetic MATCHED chain (2048 keypoints) so that RANSAC, DMatch construction and the read-back do real "
                    "work; then feature_matcher + filter_matches_ransac (threshold 2.5 px, the reference's default)")
+    return out
+
+
+def dropin_cv2_classes_leg():
+    """`dropin.value` and `dropin.slam_loop` once more in a CHILD interpreter where `cv2` is importable, so that the overlay
+    hands out cv2's own KeyPoint / DMatch objects - the only environment slam/monocular/main_revamped.py runs in
+    (features_utils.py:2, :61-63, :80-83).  The wheel is absent from the image: `cv2` is tests/cv2_stub.py with the value
+    classes of tests/cv2like/cv2like.c (C structs behind python objects, eager construction, a fresh tuple per `pt` read,
+    KeyPoint_convert in one C pass - the cost model of the wheel's classes).  The child is a separate process on the same
+    GPU (scripts/dropin_bench_cv2.py); this process is idle meanwhile."""
+    res = subprocess.run([sys.executable, str(ROOT / "scripts" / "dropin_bench_cv2.py")], capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, SSLAM_ALLOW_RANDOM_WEIGHTS="1"))
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    if res.returncode != 0 or not lines:
+        return {"error": (res.stdout[-500:] + res.stderr[-1500:])}
+    r = json.loads(lines[-1])
+    keep = ("value", "unit", "frames_timed", "feature_extractor_ms", "feature_matcher_ms", "filter_matches_ransac_ms", "keypoints",
+            "matches_median", "ransac_inliers_median", "answered_from")
+    out = {k: r[k] for k in keep if k in r}
+    out["slam_loop"] = {k: r["slam_loop"][k] for k in ("value", "unit", "frames_timed", "mean_ms_per_frame", "frame_ms", "keyframe_frames",
+                                                       "keyframe_matches_median", "answered_from") if k in r["slam_loop"]}
+    out["classes"] = r.get("classes")
+    out["what"] = ("`dropin.value` / `dropin.slam_loop` in a child interpreter with `cv2` importable (a stand-in whose KeyPoint / DMatch are C "
+                   "structs built eagerly, like the wheel's): the lists handed out hold cv2's own classes - cv2.KeyPoint_convert builds a "
+                   "frame's keypoints in one C pass, DMatch objects are made behind the running match and their indices stored when it "
+                   "returns, every list is read back in full before a device-resident result is trusted")
     return out
 
 
@@ -776,6 +816,42 @@ def main():
         for m_ in mats_e:
             m_.close()
 
+    # matched frames through the SAME batched pipeline (`value`'s random-init networks emit no match, so
+    # emit / compaction / the per-pair outputs never carry anything in it): LightGlue weights whose assignment head is sharp
+    # enough to match (the parity tests' `match_gain` set), and behind every batched extraction - on the extractor's stream,
+    # INSIDE the timed region - each frame's record is overwritten with the next frame of a synthetic matched chain
+    # (tests/lg_inputs.py::PlantedBatchExtractor; tests/test_bench_config_gpu.py holds exactly this form to the oracle)
+    planted = None
+    if extras:
+        try:
+            sys.path.insert(0, str(ROOT / "tests"))
+            import lg_inputs
+            chain = lg_inputs.make_chain(FRAMES_PER_RANK, MAX_KPTS, seed=7, noise=0.035, drop=0.1)
+            sd_p = W.random_lightglue_state_dict(1, match_gain=4.0, match_bias=3.0)
+            mats_p = [LightGlueHIP(sd_p, max_kpts=MAX_KPTS, ctx=nat.Context(device_index), max_pairs=BATCH_PAIRS) for _ in range(N_MAT)]
+            pipe_p = fs.FrameStreamPipeline(dets, mats_p, plan, MAX_KPTS, MIN_CONF, batch_pairs=BATCH_PAIRS)
+            planters = [lg_inputs.PlantedBatchExtractor(d_, chain, MAX_KPTS) for d_ in dets]
+            try:
+                m_steps = max(4, args.steps // 4)
+                m_dt = timed_rounds(pool, m_steps, 4, p_=pipe_p)
+                m_info = pipe_p.infos()
+            finally:
+                for pl_ in planters:
+                    pl_.restore()
+            planted = {"value": round(m_steps * plane_frames / m_dt, 2), "unit": "frames/s", "steps": m_steps,
+                       "matches_per_pair": round(float(m_info[:, 0].mean()), 1),
+                       "matches_per_pair_min_max": [int(m_info[:, 0].min()), int(m_info[:, 0].max())],
+                       "lightglue_layers_executed": int(m_info[-1, 1]), "kpts_matched": [int(m_info[-1, 2]), int(m_info[-1, 3])],
+                       "what": "the pipeline of `value` (same extractor instance, same streams, graphs, batch sizes) on frames that MATCH: "
+                               "LightGlue weights with a sharp assignment head and every frame's record overwritten, behind its batched "
+                               "extraction on the extractor's stream inside the timed region, with the next frame of a synthetic matched "
+                               "chain (2048 keypoints, 81 % co-visible) - all nine layers run, every pair emits hundreds of matches; "
+                               "tests/test_bench_config_gpu.py holds this form to the oracle at this size"}
+            for m_ in mats_p:
+                m_.close()
+        except Exception as e:                           # never lose the headline line to an auxiliary leg
+            planted = {"error": repr(e)}
+
     # exact-fp32 leg (precision 0): same pipeline, every contraction on v_mfma_f32_32x32x2_f32
     x_dt = None
     if extras:
@@ -1026,6 +1102,8 @@ def main():
             out["exact_f32"] = {"value": round(x_steps * plan.frames_per_round() / x_dt_max, 2), "unit": "frames/s",
                                 "steps": x_steps, "peak": F32_MFMA_PEAK_TFLOPS,
                                 "what": "same pipeline, every contraction on v_mfma_f32_32x32x2_f32 (precision 0)"}
+        if planted is not None:
+            out["planted_matches"] = planted
         if pcie is not None:
             out["pcie"] = pcie
         if p1 is not None:
@@ -1041,6 +1119,14 @@ def main():
                 out["dropin"] = dropin_leg()
             except Exception as e:                       # never lose the headline line to an auxiliary leg
                 out["dropin"] = {"error": repr(e)}
+            try:
+                if "error" not in out["dropin"]:
+                    out["dropin"]["cv2_classes"] = dropin_cv2_classes_leg()
+                    v, c = out["dropin"]["value"], out["dropin"]["cv2_classes"].get("value")
+                    if c:
+                        out["dropin"]["cv2_classes"]["vs_duck_types"] = round(c / v, 3)
+            except Exception as e:
+                out["dropin"]["cv2_classes"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:        # the CPU leg is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

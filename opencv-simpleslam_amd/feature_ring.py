@@ -35,8 +35,8 @@ from itertools import compress
 import numpy as np
 
 from . import _native, epipolar
-from .slam.core.types import (KeyPointList, MatchList, dmatch_edit_epoch, keypoint_shells, keypoints_from_xy, match_shells,
-                              matches_from_ij, xy_from_keypoints)
+from .slam.core.types import (KeyPointList, MatchList, bind_matches, dmatch_edit_epoch, keypoint_shells, keypoints_from_xy,
+                              match_shells, matches_from_ij, xy_from_keypoints)
 
 
 class FrameRecord:
@@ -234,7 +234,9 @@ class DeviceFeatureRing:
             if kf is not None:
                 operands.append(kf)
             self._enqueue([(a.slot, a.n, sl, K) for a in operands], self.last_thr)
-            ahead = dict(pairs=operands, thr=self.last_thr, filter_thr=self.ransac_thr)
+            # published at once (operands only, the new frame has no record yet): from here on `_busy` keeps their slots out
+            # of the victim search, also for a drop callback that a collection runs before this call returns
+            ahead = self.ahead = dict(pairs=[(a, a) for a in operands], thr=self.last_thr, filter_thr=self.ransac_thr)
         # the GPU needs ~0.5 ms from here: build the frame's KeyPoint objects meanwhile (their coordinates resolve
         # against the array below on first use)
         shells, src = keypoint_shells(K) if keypoint_shells is not None else (None, None)
@@ -243,6 +245,10 @@ class DeviceFeatureRing:
         n = int(self.pin_cnt[0])
         if n < 0:                            # (al_finalize_kernel: the frame's range flag; a look-ahead on it matched an empty frame)
             det.range_overflow()             # reported here: clear the instance's sticky word
+            if ahead is not None:            # the look-ahead is still reading slot `sl` (and writing the match mirror): let it finish,
+                self.mctx.sync()             # discard it - the slot has no record and is free for the next call
+                self.ahead = None
+            self.seq -= 1                    # no record was made for this number
             raise _native.NativeError("feature_extractor: an activation left the fp16 range of the split-precision stages "
                                       "(|value| >= 65520): the frame's features are void")
         xy = self.pin_xy[:n].copy(); desc = self.pin_desc[:n].copy()
@@ -261,8 +267,7 @@ class DeviceFeatureRing:
         self.records[key] = rec
         self.last = rec
         if ahead is not None:
-            ahead["pairs"] = [(a, rec) for a in ahead["pairs"]]
-            self.ahead = ahead
+            ahead["pairs"] = [(a, rec) for a, _ in ahead["pairs"]]
         return kps, desc
 
     def _keyframe_due(self, prev):
@@ -312,9 +317,10 @@ class DeviceFeatureRing:
             self.mctx.d2h_async(self.pin_match[:self.o_rsi], self.out_info)
 
     def _harvest(self, pairs, thr, filter_thr, asked):
-        """After the matcher's stream has been synchronised: the results of `pairs` out of the page-locked mirror into the memo
-        (`asked` False: a look-ahead's results, nobody has asked for them yet)."""
+        """After the matcher's stream has been synchronised: the results of `pairs` out of the page-locked mirror as memo entries
+        (`asked` False: a look-ahead's results, nobody has asked for them yet) -> the entries; the caller decides which go into the memo."""
         epoch = self.matcher.epoch
+        out = []
         for p, (a, b) in enumerate(pairs):
             k = int(self.pin_info[p, 0])
             e = dict(a=a, b=b, thr=thr, epoch=epoch, k=k, ij=self.pin_ij[p, :max(k, 0)].copy(), filter_thr=None,
@@ -323,13 +329,14 @@ class DeviceFeatureRing:
                 e["filter_thr"] = filter_thr
                 e["none"] = int(self.pin_rs_info[p, 3]) == -1      # no model (cv2 returns mask None): nothing is kept
                 e["mask"] = self.pin_rs_mask[p, :k].copy()
-            self.memo.append(e)
+            out.append(e)
+        return out
 
     def _finish_ahead(self):
         ahead, self.ahead = self.ahead, None
         if ahead is not None:
             self.mctx.sync()
-            self._harvest(ahead["pairs"], ahead["thr"], ahead["filter_thr"], asked=False)
+            self.memo.extend(self._harvest(ahead["pairs"], ahead["thr"], ahead["filter_thr"], asked=False))
 
     def _retire_unasked(self):
         """Look-ahead results nobody asked for by the time the next frame arrives were wrong guesses: a keyframe pair
@@ -360,7 +367,7 @@ class DeviceFeatureRing:
             ra.used = rb.used = self.seq
             ahead = self.ahead
             hit = ahead is not None and ahead["thr"] == thr and any(x is ra and y is rb for x, y in ahead["pairs"])
-            if hit and match_shells is not None:
+            if hit:
                 # the GPU may still be matching: build the DMatch objects meanwhile (indices resolve against the array below) -
                 # as many as the last matches suggest, not one per keypoint: the unused ones are torn down AFTER the results
                 # have arrived, on the frame's critical path (1 400 of 2 048 at ~600 matches: ~30 us)
@@ -377,12 +384,12 @@ class DeviceFeatureRing:
             self._finish_ahead()
         if e is None:
             self._enqueue([(dict(xy=a[0], desc=a[1], cnt=a[3]), a[2], dict(xy=b[0], desc=b[1], cnt=b[3]), b[2])], thr)
-            if match_shells is not None:
-                shells, src = match_shells(min(a[2], b[2]))
+            shells, src = match_shells(min(a[2], b[2], self.shell_hint))
             mctx.sync()
             self.stats["resident"] += 1
-            self._harvest([(ra, rb)], thr, self.ransac_thr, asked=True)
-            e = self.memo.pop() if not known else self.memo[-1]     # (edited keypoint lists: this call's result only)
+            e = self._harvest([(ra, rb)], thr, self.ransac_thr, asked=True)[0]
+            if known:                                  # (edited keypoint lists: this call's result only - it must not push a
+                self.memo.append(e)                    #  pair the loop will ask for again out of the memo)
         first_ask = not e["asked"]
         e["asked"] = True
         k = e["k"]
@@ -399,12 +406,7 @@ class DeviceFeatureRing:
             # hundreds of constructions - the duplicate keyframe pair of the triangulation)
             out = MatchList(e["objs"], ij)
         elif shells is not None:
-            src.ij = ij
-            if k < len(shells):
-                del shells[k:]
-            elif k > len(shells):                      # more matches than the hint prepared for
-                shells.extend(match_shells(k, src, len(shells))[0])
-            out = MatchList(shells, ij)
+            out = MatchList(bind_matches(shells, src, ij), ij)     # (fewer or more matches than the hint prepared for: trimmed / made)
         else:
             out = MatchList(matches_from_ij(ij), ij)
         if known and epoch is not None:

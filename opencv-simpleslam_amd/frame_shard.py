@@ -30,7 +30,7 @@ The extractor writes straight into the record of its slot and the matcher reads 
 so collation is ONE all-gather of the round's B records with no packing pass.
 
 The pipeline runs on the C-ABI alone at every N (streams, events, buffers through `_native.Context`); the exchange is a
-`comm` object with ONE method, `all_gather_rows` - `rccl.RcclComm` in production, `GlooRowsComm` (torch.distributed over
+`comm` object with ONE method, `all_gather` - `rccl.RcclComm` (one `ncclAllGather` per half round) in production, `GlooRowsComm` (torch.distributed over
 gloo, rows through the host) where ranks share a GPU or there is none: the choreography around it is one code path.
 `ShardPlan`, the record helpers and `GlooRowsComm` are covered by the world_size-2 gloo tests on CPU.
 """
@@ -113,17 +113,32 @@ class GlooRowsComm:
         import torch.distributed as dist
         return dist.get_world_size(self.group)
 
+    def all_gather(self, cctx, src_ptr: int, dst_ptr: int, nbytes: int):
+        """THE exchange of the pipeline: every rank contributes `nbytes` at src_ptr; rank r's land at dst_ptr + r * nbytes on
+        every rank (one contiguous all-gather).  `cctx`: the context whose stream the exchange is ordered on."""
+        if nbytes <= 0:
+            return
+        import torch
+        import torch.distributed as dist
+        send = np.empty(nbytes, np.uint8)
+        cctx.d2h(send, src_ptr)                                  # (waits for the stream: the extracts' events were enqueued on it)
+        parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
+        dist.all_gather(parts, torch.from_numpy(send), group=self.group)
+        for r, t in enumerate(parts):
+            cctx.h2d(dst_ptr + r * nbytes, t.numpy())
+
     def all_gather_rows(self, cctx, src_ptr: int, dst_ptr: int, rows_per_rank: int, lo: int, hi: int, row_bytes: int):
-        """Every rank contributes rows lo .. hi-1 of its `rows_per_rank` local rows (src_ptr = row 0 of the local block); they
-        land in rows r * rows_per_rank + lo .. of dst_ptr on every rank (global frame order).  `cctx`: the context whose
-        stream the exchange is ordered on."""
+        """The rank-major form for a caller that wants PART of every rank's block in frame order: every rank contributes rows
+        lo .. hi-1 of its `rows_per_rank` local rows (src_ptr = row 0 of the local block); they land in rows
+        r * rows_per_rank + lo .. of dst_ptr on every rank.  (Not what the pipeline uses: its gathered round is laid out so
+        that each half is one `all_gather`.)"""
         if hi <= lo:
             return
         import torch
         import torch.distributed as dist
         n = (hi - lo) * row_bytes
         send = np.empty(n, np.uint8)
-        cctx.d2h(send, src_ptr + lo * row_bytes)                 # (waits for the stream: the extracts' events were enqueued on it)
+        cctx.d2h(send, src_ptr + lo * row_bytes)
         parts = [torch.empty(n, dtype=torch.uint8) for _ in range(self.world)]
         dist.all_gather(parts, torch.from_numpy(send), group=self.group)
         for r, t in enumerate(parts):
@@ -187,12 +202,14 @@ class FrameStreamPipeline:
             # the first half-round gather would hold back that extractor's second half
             self.cctx = type(self.ctx)(self.ctx.device)
             # gathered rounds, one buffer per round parity: the previous round's last record (the halo of this round's
-            # first pair on rank 0) is read where it was gathered - no copy of the map, no allocation
+            # first pair on rank 0) is read where it was gathered - no copy of the map, no allocation.  Layout
+            # [half][rank][rows of that half] (`map_row`): each half of a round is then ONE contiguous all-gather
+            # (ncclAllGather: on the full xGMI mesh every rank's block goes straight to every peer, one hop)
             gbytes = plan.world * B * self.REC * 4
             self._gathered_ptr = [self.ctx.malloc(gbytes), self.ctx.malloc(gbytes)]
             for g_ in self._gathered_ptr:
                 self.ctx.memset_async(g_, 0, gbytes)
-            self.halves = [(0, (B + 1) // 2), ((B + 1) // 2, B)] if B > 1 else [(0, B)]
+        self.halves = [(0, (B + 1) // 2), ((B + 1) // 2, B)] if B > 1 else [(0, B)]
         self.ctx.sync()
         self.score = self.ctx.malloc(2 * B * K * 4)
         self._ij = self.ctx.malloc(2 * B * K * 8)
@@ -209,7 +226,21 @@ class FrameStreamPipeline:
         self.have_halo = False
         self.rounds = 0
         self.batches = 0                                         # global batch counter (matcher round-robin)
-        self.shared_map_ptr = 0         # device address of the last collated round [world*B, REC] (N > 1)
+        self.shared_map_ptr = 0         # device address of the last collated round [world*B, REC] in `map_row` order (N > 1)
+
+    def map_row(self, frame_in_round: int) -> int:
+        """Row of the collated round (`shared_map_ptr`) that holds frame `frame_in_round` = rank * B + slot of the round: the map
+        is laid out [half][rank][rows of that half] so that each half-round collation is one contiguous all-gather."""
+        B, world = self.plan.frames_per_rank, self.plan.world
+        r, s = divmod(int(frame_in_round), B)
+        for lo, hi in self.halves:
+            if lo <= s < hi:
+                return world * lo + r * (hi - lo) + (s - lo)
+        raise IndexError(frame_in_round)
+
+    def map_rows(self):
+        """`map_row` of every frame of a round, in frame order: `shared_map[pipe.map_rows()]` is the round in frame order."""
+        return np.array([self.map_row(j) for j in range(self.plan.world * self.plan.frames_per_rank)], np.int64)
 
     # ---- record addressing (slot = index into the slab; set p holds slots p*B .. p*B + B-1)
     def rec_ptr(self, slot: int) -> int:
@@ -296,16 +327,18 @@ class FrameStreamPipeline:
                 # rank 0: the halo is the LAST record of the previous round's collation - in place already, so the copy
                 # (and the halo event the first batch waits for) goes in front of this round's gathers
                 if have_halo:
-                    self.cctx.d2d_async(self.rec_ptr(halo_slot), self._gathered_ptr[1 - p] + (plan.world * B - 1) * rb, rb)
+                    self.cctx.d2d_async(self.rec_ptr(halo_slot),
+                                        self._gathered_ptr[1 - p] + self.map_row(plan.world * B - 1) * rb, rb)
                 self.cctx.record(self.ev_halo[p])
             for (lo, hi) in self.halves:
                 for s in range(lo, hi):
                     self.cctx.wait(self.ev_ext[p][s])
-                self.comm.all_gather_rows(self.cctx, self.rec_ptr(s_base), G, B, lo, hi, rb)
+                # this half of every rank's records -> block [half] of the map, rank-major: ONE all-gather
+                self.comm.all_gather(self.cctx, self.rec_ptr(s_base + lo), G + plan.world * lo * rb, (hi - lo) * rb)
             self.shared_map_ptr = G
             if prev >= 0:
                 # other ranks: the last frame of the neighbour, gathered in this round's second half
-                self.cctx.d2d_async(self.rec_ptr(halo_slot), G + prev * rb, rb)
+                self.cctx.d2d_async(self.rec_ptr(halo_slot), G + self.map_row(prev) * rb, rb)
                 have_halo = True
                 self.cctx.record(self.ev_halo[p])
             self.cctx.record(self.ev_collated[p])
@@ -358,10 +391,24 @@ class FrameStreamPipeline:
     def _checked_infos(self):
         """[B, 4] int32 {matches, layers, n0, n1} of the last round.  A match count of -1 is the matcher's
         verdict that a finite activation left the fp16 range of the split-precision path while that pair
-        was processed (csrc/gemm_f16x3.hpp: its matches are not fp32-grade): never handed on silently."""
+        was processed (csrc/gemm_f16x3.hpp: its matches are not fp32-grade): never handed on silently.  Neither is a frame
+        an EXTRACTOR voided (keypoint count -1 in its record, which the matcher clamps to an empty frame): every extractor's
+        sticky range word is polled here."""
         self.sync()
         info = np.empty((self.plan.frames_per_rank, 4), np.int32)
         self.ctx.d2h(info, self.info)
+        if any([d.range_overflow() for d in self.dets]):             # (every instance polled: the poll clears its sticky word)
+            # an extractor voided a frame (count -1 in its record; the matcher reads such a frame as EMPTY, so `info` shows 0
+            # matches, not -1): name the frames of the round that is still on the device
+            B, void = self.plan.frames_per_rank, []
+            cnt = np.empty(4, np.int32)
+            for s in range(B):
+                self.ctx.d2h(cnt, self.count_ptr(self.last_set * B + s))
+                if cnt[0] < 0:
+                    void.append(s)
+            raise RangeOverflowError(
+                f"ALIKED split-precision range overflow: the features of frame(s) {void if void else '(of an earlier round)'} "
+                f"are void (|activation| >= 65520 does not fit the fp16 planes) and so are the matches against them")
         bad = np.flatnonzero(info[:, 0] < 0)
         if len(bad):
             for m in self.mats:

@@ -5,12 +5,12 @@ without a tensor library in the data path.
 runtime bundled with the torch wheel (same SONAME as the system one: whichever loads first serves the whole process);
 measured on one MI355X, that alone costs the pipeline 3 - 4 % (bench: 992 -> 961 frames/s with torch initialised
 first), the process group and the torch-side collation another 3 %.  Here the ranks keep the system runtime their
-kernels were built against: records live in memory of the C-ABI, the gathers are `ncclBroadcast` groups enqueued on
-the collation stream of the pipeline, and torch - if it is there at all - only carries the 128-byte communicator id
+kernels were built against: records live in memory of the C-ABI, the gathers are `ncclAllGather` calls enqueued on
+the collation stream of the pipeline (one per half round: frame_shard.py lays the gathered round out [half][rank][rows]), and torch - if it is there at all - only carries the 128-byte communicator id
 between the ranks over gloo (CPU).
 
     comm = RcclComm.create(rank, world, exchange)     # exchange(bytes | None) -> bytes: rank 0's id to everybody
-    comm.all_gather_rows(cctx, src_ptr, dst_ptr, rows_per_rank, lo, hi, row_bytes)      # cctx: the _native.Context of the collation stream
+    comm.all_gather(cctx, src_ptr, dst_ptr, nbytes)      # cctx: the _native.Context of the collation stream; dst block r = rank r's bytes
 """
 from __future__ import annotations
 
@@ -92,10 +92,24 @@ class RcclComm:
         _check(lib().ncclCommCount(self.handle, C.byref(n)), "ncclCommCount")
         return int(n.value)
 
+    def all_gather(self, cctx, src_ptr: int, dst_ptr: int, nbytes: int):
+        """THE exchange of the pipeline's collation: every rank contributes `nbytes` (a multiple of 4) at src_ptr; rank r's
+        land at dst_ptr + r * nbytes on every rank - ONE `ncclAllGather`, enqueued on the stream of `cctx` (a
+        `_native.Context`; or a raw hipStream_t as an integer)."""
+        if nbytes <= 0:
+            return
+        if nbytes % 4:
+            raise ValueError("all_gather: float32 words are exchanged (nbytes must be a multiple of 4)")
+        stream = cctx if isinstance(cctx, int) else int(cctx.stream)
+        _check(lib().ncclAllGather(C.c_void_p(src_ptr), C.c_void_p(dst_ptr), nbytes // 4, _NCCL_FLOAT32, self.handle,
+                                   C.c_void_p(stream)), "ncclAllGather")
+
     def all_gather_rows(self, cctx, src_ptr: int, dst_ptr: int, rows_per_rank: int, lo: int, hi: int, row_bytes: int):
-        """Every rank contributes rows lo .. hi-1 of its `rows_per_rank` local rows (src_ptr = row 0 of the local block);
-        they land in rows r * rows_per_rank + lo .. of dst_ptr on every rank (global frame order).  Enqueued on the stream
-        of `cctx` (a `_native.Context`; or a raw hipStream_t as an integer); float32 rows."""
+        """The rank-major form for a caller that wants PART of every rank's block in frame order (a ragged split: the
+        pipeline itself never needs it, its map is laid out so that each half round is one `all_gather`): every rank
+        contributes rows lo .. hi-1 of its `rows_per_rank` local rows (src_ptr = row 0 of the local block); they land in
+        rows r * rows_per_rank + lo .. of dst_ptr on every rank.  Whole blocks are one `ncclAllGather`; a part is a group
+        of `ncclBroadcast`s (ring / tree traffic - avoid on the data path).  float32 rows."""
         if hi <= lo:
             return
         stream = cctx if isinstance(cctx, int) else int(cctx.stream)

@@ -7,15 +7,28 @@ used so the rest of the reference pipeline keeps working unchanged.
 """
 from __future__ import annotations
 
-try:                                       # pragma: no cover - cv2 absent in the build image
+from collections import deque as _deque
+from itertools import repeat as _repeat
+from operator import attrgetter as _attrgetter
+
+import numpy as _np
+
+try:                                       # (cv2 is absent from the build image: tests/cv2_stub.py stands in for it)
     import cv2 as _cv2
     KeyPoint = _cv2.KeyPoint
     DMatch = _cv2.DMatch
     HAVE_CV2 = True
-    keypoint_shells = None                 # cv2.KeyPoint / cv2.DMatch store their fields at construction
-    match_shells = None
+    _kp_convert = getattr(_cv2, "KeyPoint_convert", None)      # both overloads: keypoints -> [N,2] float32, points2f -> keypoints
+    keypoint_shells = None                 # cv2.KeyPoint stores its fields at construction; KeyPoint_convert builds a frame's in one C pass
+
+    def match_shells(n, src=None, start=0):
+        """n - start cv2.DMatch(0, 0, 0, 0.0) objects to be filled by `bind_matches` once the pair array has arrived (cv2's fields
+        are writable): the constructions happen while the GPU is still matching, two attribute stores per match are left for
+        afterwards.  `src` is unused with cv2's class (the duck type resolves lazily against it)."""
+        return list(map(DMatch, _repeat(0, max(0, n - start)), _repeat(0), _repeat(0), _repeat(0.0))), None
 except Exception:                          # noqa: BLE001
     HAVE_CV2 = False
+    _kp_convert = None
 
     class _KeyPointDefaults:
         __slots__ = ()
@@ -104,14 +117,40 @@ except Exception:                          # noqa: BLE001
         """Duck type of cv2.DMatch(queryIdx, trainIdx, imgIdx, distance).  A match made by `match_shells` reads
         its two indices from the call's [K,2] pair array on first use (then keeps them), so the objects can be
         built while the GPU is still matching."""
-        __slots__ = ("_q", "_t", "imgIdx", "distance", "_src", "_i")
-        edits = 0          # bumped by every index assignment on any instance (see dmatch_edit_epoch)
+        __slots__ = ("_q", "_t", "_im", "_d", "_src", "_i")
+        edits = 0          # bumped by every attribute assignment on any instance (see dmatch_edit_epoch)
 
         def __init__(self, queryIdx=-1, trainIdx=-1, imgIdx=0, distance=0.0):
             self._q = int(queryIdx)
             self._t = int(trainIdx)
-            self.imgIdx = int(imgIdx)
-            self.distance = float(distance)
+            if imgIdx != 0:
+                self._im = int(imgIdx)
+            if distance != 0.0:
+                self._d = float(distance)
+
+        @property
+        def imgIdx(self):
+            try:
+                return self._im
+            except AttributeError:
+                return 0
+
+        @imgIdx.setter
+        def imgIdx(self, v):
+            self._im = int(v)
+            DMatch.edits += 1
+
+        @property
+        def distance(self):
+            try:
+                return self._d
+            except AttributeError:
+                return 0.0
+
+        @distance.setter
+        def distance(self, v):
+            self._d = float(v)
+            DMatch.edits += 1
 
         def _resolve(self):
             q, t = self._src.pair(self._i)
@@ -183,8 +222,6 @@ except Exception:                          # noqa: BLE001
             m = new(DMatch)
             m._src = src
             m._i = i
-            m.imgIdx = 0
-            m.distance = 0.0
             add(m)
         return out, src
 
@@ -204,9 +241,12 @@ def dmatch_edit_epoch():
 def keypoints_from_xy(xy):
     """[N,2] float array -> list of KeyPoint (size 1), the bulk form of the reference's
     `[cv2.KeyPoint(x, y, 1) for x, y in kps]` (features_utils.py:62)."""
-    pts = xy.tolist()                       # python floats in one C pass
     if HAVE_CV2:
-        return [KeyPoint(x, y, 1) for x, y in pts]
+        if _kp_convert is not None and len(xy):
+            # (the convert overload's own defaults are size 1, response 1: the constructor the reference calls leaves response 0)
+            return list(_kp_convert(_np.ascontiguousarray(xy, _np.float32), size=1, response=0))
+        return [KeyPoint(x, y, 1) for x, y in xy.tolist()]
+    pts = xy.tolist()                       # python floats in one C pass
     out = []
     new = KeyPoint.__new__
     for x, y in pts:
@@ -227,18 +267,52 @@ def xy_from_keypoints(kps):
     global _pt_of
     import itertools
     import operator
-    import numpy as _np
     if _pt_of is None:
         _pt_of = operator.attrgetter("pt")
     n = len(kps)
     if n == 0:
         return _np.empty((0, 2), _np.float32)
+    if _kp_convert is not None:
+        try:                                # cv2's own pass over its own class (anything else in the list: the generic pass below)
+            xy = _np.asarray(_kp_convert(kps), _np.float32)
+            if xy.shape == (n, 2):
+                return xy
+        except Exception:                   # noqa: BLE001
+            pass
     return _np.fromiter(itertools.chain.from_iterable(map(_pt_of, kps)), _np.float32, 2 * n).reshape(n, 2)
 
 
 def matches_from_ij(ij):
     """[K,2] int array -> list of DMatch(queryIdx, trainIdx, 0, 0.0) (features_utils.py:80-83)."""
-    return [DMatch(i, j, 0, 0.0) for i, j in ij.tolist()]
+    if len(ij) == 0:
+        return []
+    q, t = _np.asarray(ij).T.tolist()
+    return list(map(DMatch, q, t, _repeat(0), _repeat(0.0)))
+
+
+_set = setattr
+
+
+def bind_matches(shells, src, ij):
+    """The objects `match_shells` prepared while the GPU was matching -> the K matches of the [K,2] pair array that has arrived:
+    surplus objects dropped, missing ones made, the indices bound (the duck type: lazily, through `src`; cv2's class: two
+    attribute stores per match in C-level passes)."""
+    k = len(ij)
+    if k < len(shells):
+        del shells[k:]
+    if HAVE_CV2:
+        if k:
+            q, t = _np.asarray(ij).T.tolist()
+            n = len(shells)
+            _deque(map(_set, shells, _repeat("queryIdx"), q), maxlen=0)          # (map stops at the shorter: the prepared ones)
+            _deque(map(_set, shells, _repeat("trainIdx"), t), maxlen=0)
+            if k > n:                                                            # more matches than had been prepared
+                shells.extend(map(DMatch, q[n:], t[n:], _repeat(0), _repeat(0.0)))
+        return shells
+    src.ij = ij
+    if k > len(shells):
+        shells.extend(match_shells(k, src, len(shells))[0])
+    return shells
 
 
 class KeyPointList(list):
@@ -247,8 +321,8 @@ class KeyPointList(list):
     `feature_matcher` can use the copy of the keypoints that is still on the GPU instead of rebuilding and
     re-uploading them.  A copy (`list(kps)`), a slice or an edited list is an ordinary / dirty list and takes
     the rebuilding path.  (An in-place edit of an ELEMENT - `kps[i].pt = ...` - cannot be seen by the list: with this module's
-    duck type every `pt` assignment anywhere moves a counter the list compares with its own; with cv2's class eight elements
-    are spot-checked against the remembered array.)"""
+    duck type every `pt` assignment anywhere moves a counter the list compares with its own; with cv2's class EVERY element is
+    read back through cv2.KeyPoint_convert and compared with the remembered array.)"""
     __slots__ = ("_xy", "_dirty", "_epoch")
 
     def __init__(self, items=(), xy=None):
@@ -282,13 +356,19 @@ class KeyPointList(list):
                 return self._xy
             self._dirty = True
             return None
-        n = len(self)
-        for i in range(0, n, max(1, n // 8)):              # cv2's class: spot check against in-place element edits
-            x, y = self[i].pt
-            if x != float(self._xy[i, 0]) or y != float(self._xy[i, 1]):
-                self._dirty = True
-                return None
+        # cv2's class cannot be watched: read EVERY keypoint back (cv2.KeyPoint_convert: one C pass, microseconds) - an element
+        # edited in place, or replaced by something that is not a cv2.KeyPoint, makes the list an ordinary one
+        try:
+            cur = xy_from_keypoints(self)
+        except Exception:                                  # noqa: BLE001
+            cur = None
+        if cur is None or cur.shape != self._xy.shape or not _np.array_equal(cur, self._xy):
+            self._dirty = True
+            return None
         return self._xy
+
+
+_q_of, _t_of = _attrgetter("queryIdx"), _attrgetter("trainIdx")
 
 
 class MatchList(list):
@@ -297,7 +377,7 @@ class MatchList(list):
     `_dirty`), so that `filter_matches_ransac` may apply the inlier mask the device computed for exactly these pairs in
     exactly this order.  A sorted / filtered / copied list is an ordinary or dirty list and is filtered from scratch.  (An
     in-place edit of an ELEMENT - `m.queryIdx = ...` - cannot be seen by the list: the duck type's edit counter is compared,
-    see dmatch_edit_epoch; with cv2's class eight elements are spot-checked.)"""
+    see dmatch_edit_epoch; with cv2's class every element's indices are read back and compared.)"""
     __slots__ = ("_ij", "_dirty", "_epoch")
 
     def __init__(self, items=(), ij=None):
@@ -331,10 +411,13 @@ class MatchList(list):
                 return self._ij
             self._dirty = True
             return None
-        n = len(self)
-        for i in range(0, n, max(1, n // 8)):              # cv2's class: spot check against in-place element edits
-            m = self[i]
-            if m.queryIdx != int(self._ij[i, 0]) or m.trainIdx != int(self._ij[i, 1]):
+        # cv2's class cannot be watched: read EVERY match's two indices back (two C-level attribute passes)
+        if len(self):
+            try:
+                same = [list(map(_q_of, self)), list(map(_t_of, self))] == _np.asarray(self._ij).T.tolist()
+            except Exception:                              # noqa: BLE001
+                same = False
+            if not same:
                 self._dirty = True
                 return None
         return self._ij

@@ -1,4 +1,5 @@
 import importlib
+import os
 import sys
 from pathlib import Path
 
@@ -9,6 +10,14 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 PKG_NAME = "opencv-simpleslam_amd"
+
+if os.environ.get("SSLAM_TEST_CV2_CLASSES") == "1":
+    # a child run of tests/test_cv2_classes.py: `cv2` (absent from the image) is the stand-in of tests/cv2_stub.py with
+    # KeyPoint / DMatch / KeyPoint_convert from the C module - installed BEFORE the product binds cv2 at import, so the
+    # overlay takes the branch it takes wherever the reference really runs (slam/core/types.py: HAVE_CV2)
+    sys.path.insert(0, str(ROOT / "tests"))
+    import cv2_stub
+    cv2_stub.install(native_classes=True)
 
 
 def pytest_configure(config):

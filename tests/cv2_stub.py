@@ -3,13 +3,36 @@ branch - BASELINE config C1 "ORB + BF matcher" (reference slam/core/features_uti
 Only what that branch touches: ORB_create / SIFT_create / AKAZE_create -> detectAndCompute, BFMatcher(norm, crossCheck) /
 FlannBasedMatcher -> match, KeyPoint, DMatch, the two norm constants.  The "detector" is a deterministic toy (corner-ish
 pixels, 32-byte binary descriptors of their neighbourhood); it exists so that the calls have something to carry."""
+import importlib.util
+import subprocess
 import sys
+import sysconfig
 import types
+from pathlib import Path
 
 import numpy as np
 
+HERE = Path(__file__).resolve().parent
 
-def install():
+
+def build_cv2like():
+    """gcc-build tests/cv2like/cv2like.c (KeyPoint / DMatch as C structs behind python objects, KeyPoint_convert in one C
+    pass: the COST of the wheel's value classes, which python classes cannot stand in for) -> the loaded module."""
+    src = HERE / "cv2like" / "cv2like.c"
+    so = HERE / "cv2like" / "_cv2like.so"
+    if not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
+        subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-Wall", "-I", sysconfig.get_paths()["include"], str(src), "-o", str(so)],
+                       check=True, capture_output=True, text=True)
+    spec = importlib.util.spec_from_file_location("_cv2like", so)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def install(native_classes=False):
+    """Install the stand-in as `cv2`.  native_classes: KeyPoint / DMatch / KeyPoint_convert from the C module (the LightGlue
+    drop-in path with cv2's OWN classes present - the only environment main_revamped.py runs in - is tested and timed against
+    these); otherwise plain python classes."""
     cv2 = types.ModuleType("cv2")
     cv2.NORM_L2, cv2.NORM_HAMMING = 4, 6
     calls = cv2._calls = []
@@ -70,6 +93,23 @@ def install():
             calls.append(("FlannBasedMatcher", index_params, search_params))
             self.normType, self.crossCheck = cv2.NORM_L2, False
 
+    if native_classes:
+        like = build_cv2like()
+        KeyPoint, DMatch = like.KeyPoint, like.DMatch
+
+        def KeyPoint_convert(arg, *a, **kw):
+            """Both overloads of cv2.KeyPoint_convert: keypoints -> [N,2] float32; points2f[, size[, response[, octave[,
+            class_id]]]] -> tuple of KeyPoint (response defaults to 1, unlike the KeyPoint constructor's 0)."""
+            if isinstance(arg, np.ndarray):
+                order = ("size", "response", "octave", "class_id")
+                vals = dict(zip(order, a)); vals.update(kw)
+                pts = np.ascontiguousarray(arg, np.float32).reshape(-1, 2)
+                return like._xy_to_kp(pts, float(vals.get("size", 1)), float(vals.get("response", 1)), int(vals.get("octave", 0)),
+                                      int(vals.get("class_id", -1)))
+            out = np.empty((len(arg), 2), np.float32)
+            like._kp_to_xy(arg, out)
+            return out
+        cv2.KeyPoint_convert = KeyPoint_convert
     cv2.KeyPoint, cv2.DMatch, cv2.BFMatcher, cv2.FlannBasedMatcher = KeyPoint, DMatch, BFMatcher, FlannBasedMatcher
     cv2.ORB_create = lambda nfeatures=500: (calls.append(("ORB_create", nfeatures)), _Detector("orb", nfeatures))[1]
     cv2.SIFT_create = lambda nfeatures=0: (calls.append(("SIFT_create", nfeatures)), _Detector("sift", nfeatures or 500))[1]

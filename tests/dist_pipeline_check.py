@@ -41,7 +41,26 @@ if backend == "rccl":
         dist.broadcast_object_list(box, src=0)
         return box[0]
     comm = rccl.RcclComm.create(rank, world, _exchange)
+    # count what the collation really calls in librccl (each half round must be ONE ncclAllGather, no
+    # broadcast groups): a counting shim in front of the two entry points
+    L = rccl.lib()
+    rccl_calls = {"ncclAllGather": 0, "ncclBroadcast": 0}
+
+    class _Shim:
+        def __init__(self, L):
+            self.__dict__["_L"] = L
+
+        def __getattr__(self, name):
+            f = getattr(self._L, name)
+            if name in rccl_calls:
+                def counted(*a, _f=f, _n=name):
+                    rccl_calls[_n] += 1
+                    return _f(*a)
+                return counted
+            return f
+    rccl._lib = _Shim(L)
 else:
+    rccl_calls = None
     comm = importlib.import_module("opencv-simpleslam_amd.frame_shard").GlooRowsComm(rank, world)
 pkg = importlib.import_module("opencv-simpleslam_amd")
 nat = pkg._native
@@ -100,10 +119,10 @@ for rnd, h in enumerate(hist):
         assert info[s, 0] >= 0, (rank, f)
         np.testing.assert_array_equal(ij[s, :info[s, 0]], ref[f][0], err_msg=f"rank {rank} round {rnd} frame {f}")
         checked += 1
-    # the collated map holds every rank's features of this round, in global frame order
+    # the collated map holds every rank's features of this round ([half][rank][rows]: pipe.map_row)
     for j in range(world * B):
         f = rnd * world * B + j
-        n, xy, desc = fs.unpack_record(smap[j], K)
+        n, xy, desc = fs.unpack_record(smap[pipe.map_row(j)], K)
         assert n == len(feats[f][0]), (rank, rnd, j)
         np.testing.assert_array_equal(xy, feats[f][0])
         np.testing.assert_array_equal(desc, feats[f][1])
@@ -113,6 +132,9 @@ for h in hist:
 for c_ in chunks:
     ctx.free(c_)
 assert sum(len(r[0]) for r in ref[1:]) > 5, "vacuous: the sequential reference found no matches"
+if rccl_calls is not None:
+    assert rccl_calls == {"ncclAllGather": 2 * ROUNDS, "ncclBroadcast": 0}, rccl_calls      # one all-gather per half round
+    print(f"rank {rank}: librccl calls over {ROUNDS} rounds: {rccl_calls}", flush=True)
 dist.barrier()
 print(f"rank {rank} ({backend}, device {dev}): {checked} pairs identical to the sequential API over {ROUNDS} un-synchronised rounds", flush=True)
 comm.close()

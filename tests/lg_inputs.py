@@ -92,3 +92,50 @@ class PlantedExtractor:
         for _, dev, _ in self.sets:
             self.ctx.free(dev)
         self.sets = []
+
+
+class PlantedBatchExtractor:
+    """`PlantedExtractor` for the BATCHED extractor entry the frame pipeline drives (`extract_batch_dev`, frame_shard.py): the F
+    extractions run as always and, right behind them on the same stream, every frame's pipeline record [xy K x 2 | desc K x 128 |
+    count] is overwritten with the next set of a synthetic MATCHED chain - one device-to-device copy per frame when the chain's
+    sets fill the record (n == max_kpts: xy, descriptors and count are contiguous), three otherwise.  What the batched matches,
+    the read-back and the collation see is then one consistent stream of frames that really match (~600 matches per pair with
+    the `match_gain` weights), at the cost of F small copies per call inside the timed region."""
+
+    def __init__(self, detector, frames, max_kpts):
+        self.det, self.ctx = detector, detector.ctx
+        self.real = detector.extract_batch_dev
+        self.K = K = int(max_kpts)
+        self.i = 0
+        self.sets = []
+        for xy, desc in frames:
+            n = len(xy)
+            rec = np.zeros(K * 130 + 4, np.float32)
+            rec[:2 * n] = xy.reshape(-1)
+            rec[2 * K:2 * K + 128 * n] = desc.reshape(-1)
+            rec[K * 130:K * 130 + 1].view(np.int32)[0] = n
+            dev = self.ctx.malloc(rec.nbytes)
+            self.ctx.h2d(dev, rec)
+            self.sets.append((n, dev))
+        self.ctx.sync()
+        detector.extract_batch_dev = self
+
+    def __call__(self, imgs_dev, H, Wd, Cn, xy_out, desc_out, score_out, n_out, max_kpts=None):
+        self.real(imgs_dev, H, Wd, Cn, xy_out, desc_out, score_out, n_out, max_kpts=max_kpts)
+        K = self.K
+        for xy_p, de_p, n_p in zip(xy_out, desc_out, n_out):
+            n, dev = self.sets[self.i % len(self.sets)]
+            self.i += 1
+            if de_p == xy_p + K * 8 and n_p == xy_p + K * 520:          # one pipeline record: one copy
+                self.ctx.d2d_async(xy_p, dev, K * 520 + 16)
+            else:
+                self.ctx.d2d_async(xy_p, dev, n * 8)
+                self.ctx.d2d_async(de_p, dev + K * 8, n * 512)
+                self.ctx.d2d_async(n_p, dev + K * 520, 16)
+
+    def restore(self):
+        del self.det.extract_batch_dev
+        self.ctx.sync()
+        for _, dev in self.sets:
+            self.ctx.free(dev)
+        self.sets = []

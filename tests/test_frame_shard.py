@@ -77,6 +77,17 @@ def _worker(rank, world, port, out_dir):
         full = np.empty((world * B, fs.record_floats(K)), np.float32)
         ctx.d2h(full, gathered)
         np.save(Path(out_dir) / f"r{rank}_round{rnd}.npy", full)
+        # THE exchange of the pipeline: each half is one contiguous all-gather into block [half] of a map laid out
+        # [half][rank][rows]; read back through the same row arithmetic as FrameStreamPipeline.map_row it is the same round
+        ctx.view(gathered, world * B * rb)[:] = 0xff
+        for lo, hi in ((0, 2), (2, 3)):
+            comm.all_gather(ctx, local + lo * rb, gathered + world * lo * rb, (hi - lo) * rb)
+        blocked = np.empty_like(full)
+        ctx.d2h(blocked, gathered)
+        rows = [world * lo + r * (hi - lo) + (s - lo) for r in range(world) for s in range(B)
+                for lo, hi in ((0, 2), (2, 3)) if lo <= s < hi]
+        assert np.array_equal(blocked[rows].view(np.int32), full.view(np.int32)), f"rank {rank} round {rnd}: half-blocked gather differs"
+        comm.all_gather(ctx, local, gathered, 0)                              # an empty part is a no-op on every rank
         # whole blocks in one call give the same map
         ctx.view(gathered, world * B * rb)[:] = 0xff
         comm.all_gather_rows(ctx, local, gathered, B, 0, B, rb)
@@ -162,9 +173,10 @@ def _pipeline_worker(rank, world, port, out_dir):
             assert info[s, 0] == len(want_ij) > 8, (rank, rnd, f, info[s])
             np.testing.assert_array_equal(res[s][0], want_ij, err_msg=f"rank {rank} round {rnd} frame {f} (pair with frame {f - 1})")
             checked += 1
-        for j in range(world * B):                           # the collated map: every rank's frames of the round, frame order
+        assert sorted(pipe.map_rows().tolist()) == list(range(world * B))
+        for j in range(world * B):                           # the collated map: every rank's frames of the round ([half][rank][rows])
             f = rnd * world * B + j
-            n, xy, desc = fs.unpack_record(smap[j], K)
+            n, xy, desc = fs.unpack_record(smap[pipe.map_row(j)], K)
             assert n == K
             np.testing.assert_array_equal(xy, chain[f][0]); np.testing.assert_array_equal(desc, chain[f][1])
     np.save(Path(out_dir) / f"checked_{rank}.npy", np.array([checked]))

@@ -128,8 +128,9 @@ def test_two_rank_pipeline_over_rccl(native):
 
 
 def test_one_rank_pipeline_over_rccl_directly():
-    """The production exchange on the one GPU of a test box: communicator from an id exchanged over gloo, per-half gathers as
-    RCCL broadcast groups on the collation stream, records and the gathered map in C-ABI memory, torch never touching the
+    """The production exchange on the one GPU of a test box: communicator from an id exchanged over gloo, each half round ONE
+    `ncclAllGather` on the collation stream (counted through a shim in front of librccl: 2 all-gathers and 0 broadcasts per
+    round - tests/dist_pipeline_check.py), records and the gathered map in C-ABI memory, torch never touching the
     GPU (the ranks keep the system HIP runtime) - world size 1, through the SAME `FrameStreamPipeline.round` branch the
     gloo-rank tests above take."""
     _run_dist_check("rccl", 1, 29625)
