@@ -82,6 +82,9 @@ def _ffn(sd, p, x):
     return F.linear(h, sd[p + ".ffn.3.weight"], sd[p + ".ffn.3.bias"])
 
 
+PROBE = None      # a dict while a caller wants statistics of the cross-attention logits (never set by the tests)
+
+
 def self_block(sd, i, x, enc, heads):
     p = f"transformers.{i}.self_attn"
     qkv = F.linear(x, sd[p + ".Wqkv.weight"], sd[p + ".Wqkv.bias"])
@@ -111,6 +114,9 @@ def cross_block(sd, i, x0, x1, heads):
     sim = torch.einsum("bhid, bhjd -> bhij", qk0, qk1)
     attn01 = F.softmax(sim, dim=-1)
     attn10 = F.softmax(sim.transpose(-2, -1).contiguous(), dim=-1)
+    if PROBE is not None and sim.numel():               # (scripts/flip_soak.py: how peaked the attention of these weights is)
+        PROBE["max_abs_logit"] = max(PROBE.get("max_abs_logit", 0.0), float(sim.abs().max()))
+        PROBE.setdefault("row_max_weight", []).append(float(attn01.max(-1).values.mean()))
     m0 = torch.einsum("bhij, bhjd -> bhid", attn01, v1)
     m1 = torch.einsum("bhji, bhjd -> bhid", attn10.transpose(-2, -1), v0)
     m0, m1 = (t.transpose(1, 2).flatten(start_dim=-2) for t in (m0, m1))

@@ -31,7 +31,7 @@ from split_study import sharpen, fwd64
 
 W = importlib.import_module("opencv-simpleslam_amd.weights")
 LG = importlib.import_module("opencv-simpleslam_amd.lightglue").LightGlueHIP
-MODES = ("f16x3", "f16x3p1")
+MODES = ("f32", "f16x3", "f16x3p1")
 
 
 def main():
@@ -45,8 +45,10 @@ def main():
     tot = {m: dict(flips=0, stop=0, score=0.0, bad_pairs=0) for m in MODES}
     n_matches = n_pairs = 0
     worst = []
-    for gamma, gname in ((None, "diffuse (random-init logits)"), (2.0, "q / k x2 (logits x4)"), (4.0, "q / k x4 (logits x16)")):
+    for gamma, gname in ((None, "diffuse (random-init logits)"), (2.0, "q / k x2 (logits x4)"), (4.0, "q / k x4 (logits x16)"),
+                         (8.0, "q / k x8 (logits x64)")):
         acc = {m: dict(flips=0, stop=0, score=0.0, bad_pairs=0) for m in MODES}
+        probe = {}
         g_matches = g_pairs = 0
         for wseed in (1, 2, 3, 4):
             if only is not None and (float(gamma or 0), wseed) not in only:
@@ -61,7 +63,11 @@ def main():
                 if p == 0:
                     m_ = n_ = 2048                      # the bench size itself in every cell
                 k0, d0, k1, d1 = lg_inputs.make_pair(m_, n_, seed=7000 + 100 * wseed + p + int(10 * (gamma or 0)))
-                ref = R.lightglue_forward(sd, k0, d0, k1, d1)
+                R.PROBE = probe
+                try:
+                    ref = R.lightglue_forward(sd, k0, d0, k1, d1)
+                finally:
+                    R.PROBE = None
                 rij, rsc = ref["matches"].numpy(), ref["scores"].numpy()
                 want = {(int(i), int(j)): float(s) for (i, j), s in zip(rij.tolist(), rsc)}
                 g_matches += len(want); g_pairs += 1
@@ -88,21 +94,25 @@ def main():
                         worst.append((mode, gname, wseed, m_, n_, f, len(want), det))
                 print(f"<!-- {gname} w{wseed} pair {p}: {m_} x {n_}, {len(want)} oracle matches, stop {ref['stop']}, {time.time() - t0:.0f} s -->", flush=True)
             lg.close()
-        rows.append((gname, g_pairs, g_matches, acc))
+        rows.append((gname, g_pairs, g_matches, acc, probe))
         n_matches += g_matches; n_pairs += g_pairs
         for m in MODES:
             for k in ("flips", "stop", "bad_pairs"):
                 tot[m][k] += acc[m][k]
             tot[m]["score"] = max(tot[m]["score"], acc[m]["score"])
-    print("\n# r05 flip soak: the two shipped precisions against the torch-CPU oracle on north_star's bar\n")
+    print("\n# r06 flip soak: exact fp32 and the two split forms against the torch-CPU oracle on north_star's bar\n")
     print(f"`scripts/flip_soak.py {per_cell}` on the GPU box: {n_pairs} pairs of 1024 - 2048 keypoints (ragged; every cell starts with a 2048 x 2048 "
-          f"pair), 4 weight seeds x 3 logit scalings, **{n_matches} oracle matches**, min_conf 0 (every match above LightGlue's 0.1 filter), "
+          f"pair), 4 weight seeds x 4 logit scalings, **{n_matches} oracle matches**, min_conf 0 (every match above LightGlue's 0.1 filter), "
           f"host entry `sslam_lightglue_match_host` (the batched-form kernels at these sizes).  Run time {time.time() - t0:.0f} s.\n")
-    print("| inputs | pairs | oracle matches | f16x3: flips / pairs with a flip / stop-layer mismatches / max score err | f16x3p1: flips / pairs / stop / max score err |")
-    print("|---|---|---|---|---|")
-    for gname, gp, gm, acc in rows + [("**total**", n_pairs, n_matches, tot)]:
+    print("Per cell: flips / pairs with a flip / stop-layer mismatches / max score error.  `max |logit|`: the largest cross-attention logit the "
+          "oracle saw; `row max P`: the mean over rows and layers of the largest softmax weight of a row (1 = one-hot).\n")
+    print("| inputs | pairs | oracle matches | max abs logit | row max P | f32 (mode 0) | f16x3 (mode 1) | f16x3p1 (mode 2, default) |")
+    print("|---|---|---|---|---|---|---|---|")
+    for gname, gp, gm, acc, pr in rows + [("**total**", n_pairs, n_matches, tot, {})]:
         cells = [f"{acc[m]['flips']} / {acc[m]['bad_pairs']} / {acc[m]['stop']} / {acc[m]['score']:.2e}" for m in MODES]
-        print(f"| {gname} | {gp} | {gm} | {cells[0]} | {cells[1]} |")
+        ml = f"{pr['max_abs_logit']:.1f}" if pr else ""
+        rp = f"{np.mean(pr['row_max_weight']):.3f}" if pr else ""
+        print(f"| {gname} | {gp} | {gm} | {ml} | {rp} | {cells[0]} | {cells[1]} | {cells[2]} |")
     print()
     for m in MODES:
         f = tot[m]["flips"]

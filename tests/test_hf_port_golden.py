@@ -68,7 +68,7 @@ def test_oracle_reproduces_every_hf_stage(sd):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+@pytest.mark.parametrize("precision", ["f16x3p1", "f16x3", "f32"])       # (f16x3p1: the shipped default)
 def test_hip_path_reproduces_the_hf_stages(sd, gpu_ctx, precision):
     LG = load_pkg("lightglue").LightGlueHIP
     n = int(G["n"])
@@ -76,6 +76,9 @@ def test_hip_path_reproduces_the_hf_stages(sd, gpu_ctx, precision):
     lg.set_precision(precision)
     Kc = lg.capacity
     args = (G["k0"], G["d0"], G["k1"], G["d1"])
+    # token states: fp32-grade (3e-5) in exact fp32 and in "f16x3"; the shipped default carries P into P.V as ONE fp16 plane and
+    # is 4.6e-5 from the HF port at the last layer (r06, this fixture) - inside north_star's 1e-3 by a factor of 20, held to 1e-4
+    atol = 1e-4 if precision == "f16x3p1" else 3e-5
     for key in sorted(G.files):
         if not (key.startswith("self_") or key.startswith("cross_") or key.startswith("rows_")):
             continue
@@ -85,7 +88,7 @@ def test_hip_path_reproduces_the_hf_stages(sd, gpu_ctx, precision):
         x = lg.debug_read(0, (2, Kc, 256))
         rows = G[key].shape[1]                            # whole images for the stored stages, 16 tokens for every half layer
         for img in (0, 1):
-            np.testing.assert_allclose(x[img, :rows], G[key][img], atol=3e-5, rtol=1e-5, err_msg=f"{key} {precision}")
+            np.testing.assert_allclose(x[img, :rows], G[key][img], atol=atol, rtol=1e-5, err_msg=f"{key} {precision}")
     lg.debug_layers(9, False)
     ij, sc, stop = lg.match(*args, min_conf=0.0)
     m0 = G["matches0"]
