@@ -1070,6 +1070,9 @@ __global__ __launch_bounds__(256) void al_agg_pre_kernel(const float* __restrict
     pre[(size_t)11 * n + i] = d1; pre[(size_t)12 * n + i] = d2;
 }
 
+#if defined(AL_AGG_LOAD_NOP) && AL_AGG_LOAD_NOP == 3
+__device__ unsigned al_dbg_words[64];       // experiment only (sslam_aliked_debug_read(99)): see agg_level
+#endif
 // contribution of one upsampled level at a full-resolution pixel: s[o] += up(proj[o]), n2 += the quadratic form
 __device__ __forceinline__ void agg_level(const float* __restrict__ pre, int n, const UpTap& t, float (&s)[8], float& n2) {
 #pragma unroll
@@ -1077,9 +1080,58 @@ __device__ __forceinline__ void agg_level(const float* __restrict__ pre, int n, 
     const float w00 = t.w10 * t.w00, w01 = t.w10 * t.w01, w10 = t.w11 * t.w00, w11 = t.w11 * t.w01;     // hy hx, hy lx, ly hx, ly lx
     const float* S = pre + (size_t)8 * n; const float* H = pre + (size_t)9 * n; const float* V = pre + (size_t)10 * n;
     const float* D1 = pre + (size_t)11 * n; const float* D2 = pre + (size_t)12 * n;
+#ifdef AL_AGG_LOAD_NOP
+    // experiment (scripts/diag_agg_rnorm.sh, profiles/r06_aggregate_rnorm_diagnosis.md): the ten gathers of the quadratic form
+    // in named registers and an asm statement that reads them all - the compiler's s_waitcnt vmcnt lands in FRONT of it - with
+    // (1) or without (2) idle cycles before the first instruction that consumes a loaded register
+    float s00 = S[t.o00], s01 = S[t.o01], s10 = S[t.o10], s11 = S[t.o11], h00 = H[t.o00], h10 = H[t.o10], v00 = V[t.o00],
+          v01 = V[t.o01], d1 = D1[t.o00], d2 = D2[t.o00];
+#if AL_AGG_LOAD_NOP == 1
+    asm volatile("s_nop 7" : "+v"(s00), "+v"(s01), "+v"(s10), "+v"(s11), "+v"(h00), "+v"(h10), "+v"(v00), "+v"(v01), "+v"(d1), "+v"(d2));
+#else
+    asm volatile("" : "+v"(s00), "+v"(s01), "+v"(s10), "+v"(s11), "+v"(h00), "+v"(h10), "+v"(v00), "+v"(v01), "+v"(d1), "+v"(d2));
+#endif
+    const float sq = (w00 * w00 * s00 + w01 * w01 * s01) + (w10 * w10 * s10 + w11 * w11 * s11);
+#if AL_AGG_LOAD_NOP == 3
+    // (3): is it the LOADED REGISTER that holds a wrong value, or the packed instruction that consumes it?  The six cross products
+    // once as the compiler forms them (SLP-vectorised: v_pk_mul_f32 on register pairs) and once by single-lane-width v_mul_f32 in
+    // inline assembly ON THE SAME REGISTERS (coefficients laundered through an asm so both forms read the same six values);
+    // a lane whose two forms disagree records itself in al_dbg_words
+    float c0 = w00 * w01, c1 = w10 * w11, c2 = w00 * w10, c3 = w01 * w11, c4 = w00 * w11, c5 = w01 * w10;
+    asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5));
+    const float p0 = c0 * h00, p1 = c1 * h10, p2 = c2 * v00, p3 = c3 * v01, p4 = c4 * d1, p5 = c5 * d2;
+    float q0, q1, q2, q3, q4, q5;
+    asm volatile("v_mul_f32 %0, %6, %12\n\tv_mul_f32 %1, %7, %13\n\tv_mul_f32 %2, %8, %14\n\tv_mul_f32 %3, %9, %15\n\t"
+                 "v_mul_f32 %4, %10, %16\n\tv_mul_f32 %5, %11, %17"
+                 : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5)
+                 : "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(c4), "v"(c5), "v"(h00), "v"(h10), "v"(v00), "v"(v01), "v"(d1), "v"(d2));
+    const float cr = ((p0 + p1) + (p2 + p3)) + (p4 + p5);
+    {
+        const int differ = (p0 != q0) | ((p1 != q1) << 1) | ((p2 != q2) << 2) | ((p3 != q3) << 3) | ((p4 != q4) << 4) | ((p5 != q5) << 5);
+        if (differ) {
+            const unsigned k = atomicAdd(&al_dbg_words[0], 1u);
+            atomicOr(&al_dbg_words[1], (unsigned)differ);                         // which of the six products ever differed
+            atomicOr(&al_dbg_words[2], 1u << ((threadIdx.x & 63) >> 4));          // which 16-lane group of the wave
+            if (k < 8) {                                                          // the first few in full: packed, scalar, both operands
+                const float pv[6] = {p0, p1, p2, p3, p4, p5}, qv[6] = {q0, q1, q2, q3, q4, q5}, cv[6] = {c0, c1, c2, c3, c4, c5},
+                            gv[6] = {h00, h10, v00, v01, d1, d2};
+                const int w = __ffs(differ) - 1;
+                unsigned* o = al_dbg_words + 8 + 6 * k;
+                o[0] = (unsigned)differ | ((threadIdx.x & 63) << 8) | ((unsigned)n << 16);
+                o[1] = __float_as_uint(pv[w]); o[2] = __float_as_uint(qv[w]); o[3] = __float_as_uint(cv[w]); o[4] = __float_as_uint(gv[w]);
+                o[5] = blockIdx.x | (blockIdx.y << 8) | (blockIdx.z << 24);
+            }
+        }
+    }
+#else
+    const float cr = ((w00 * w01) * h00 + (w10 * w11) * h10) + ((w00 * w10) * v00 + (w01 * w11) * v01) +
+                     ((w00 * w11) * d1 + (w01 * w10) * d2);
+#endif
+#else
     const float sq = (w00 * w00 * S[t.o00] + w01 * w01 * S[t.o01]) + (w10 * w10 * S[t.o10] + w11 * w11 * S[t.o11]);
     const float cr = ((w00 * w01) * H[t.o00] + (w10 * w11) * H[t.o10]) + ((w00 * w10) * V[t.o00] + (w01 * w11) * V[t.o01]) +
                      ((w00 * w11) * D1[t.o00] + (w01 * w10) * D2[t.o00]);
+#endif
     n2 += fmaf(2.0f, cr, sq);
 }
 
@@ -1088,7 +1140,22 @@ __device__ __forceinline__ void agg_level(const float* __restrict__ pre, int n, 
 #ifndef AL_AGG1_UNROLL
 #define AL_AGG1_UNROLL 2
 #endif
-__global__ __launch_bounds__(256) void al_aggregate_kernel(Pyr P0, const float* __restrict__ ws0 /*[128][8]*/,
+// r06: NO packed-fp32 instructions in this kernel (AL_AGG_PACKED=1 lifts that, for the experiment scripts only).  Its one known
+// fault - 1 / ||F|| wrong by 0.2 - 4 % in lanes 48..63 of a wave, once per few hundred frames and only with other streams'
+// kernels on the GPU - is n2 missing exactly ONE gather's term of agg_level's quadratic form, and it needs the shape in which the
+// SLP vectoriser pairs those products into v_pk_mul_f32 / v_pk_fma_f32 on registers that global loads have just filled (147
+// packed instructions in the failing builds, 9 in the build that never failed, 0 events in 400 stress repeats with packing
+// off against 42 with it on; profiles/r06_aggregate_rnorm_diagnosis.md).  Which shape the compiler picks depended on an
+// unrelated detail (the exponential of the tail); the attribute takes the choice away from it.
+#ifndef AL_AGG_PACKED
+#define AL_AGG_PACKED 0
+#endif
+#if AL_AGG_PACKED
+#define AL_AGG_TARGET
+#else
+#define AL_AGG_TARGET __attribute__((target("no-packed-fp32-ops")))
+#endif
+AL_AGG_TARGET __global__ __launch_bounds__(256) void al_aggregate_kernel(Pyr P0, const float* __restrict__ ws0 /*[128][8]*/,
                                                            float* __restrict__ s8, float* __restrict__ rnorm, size_t fs) {
     const Pyr P = pyr_at(P0, blockIdx.z, fs);
     s8 = fsh(s8, blockIdx.z, fs); rnorm = fsh(rnorm, blockIdx.z, fs);
@@ -1136,13 +1203,18 @@ __global__ __launch_bounds__(256) void al_aggregate_kernel(Pyr P0, const float* 
         rnorm[pix] = 1.0f / fmaxf(sqrtf(n2), 1e-12f);            // F.normalize eps
 #endif
     }
-    __syncthreads();
+    // (the header's inline functions - __syncthreads, make_float4 - are compiled with the file's target features and would stay
+    //  CALLS from a kernel whose features differ: the barrier and the 16-byte store are written with the builtins they wrap)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
     const int npx = min(256, P.Wp - (int)(blockIdx.x * blockDim.x));
     float* dst = P.g1cl + ((size_t)y * P.Wp + blockIdx.x * blockDim.x) * 32;
-    for (int i = threadIdx.x; i < npx * 8; i += 256) {           // float4 pieces, fully coalesced
+    for (int i = threadIdx.x; i < npx * 8; i += 256) {           // 16-byte pieces, fully coalesced
         const int p = i >> 3, c4 = (i & 7) * 4;
-        *reinterpret_cast<float4*>(dst + (size_t)p * 32 + c4) =
-            make_float4(g1s[p * 33 + c4], g1s[p * 33 + c4 + 1], g1s[p * 33 + c4 + 2], g1s[p * 33 + c4 + 3]);
+        const f32x4_t v = {g1s[p * 33 + c4], g1s[p * 33 + c4 + 1], g1s[p * 33 + c4 + 2], g1s[p * 33 + c4 + 3]};
+        *reinterpret_cast<f32x4_t*>(dst + (size_t)p * 32 + c4) = v;
     }
 }
 
@@ -2492,6 +2564,13 @@ int sslam_aliked_debug_read(sslam_aliked* g, int which, void* dst, size_t bytes)
         case 16: src = g->pre3; cap = AGG_PRE * HWp / 64 * 4; break;
         case 17: src = g->pre4; cap = AGG_PRE * HWp / 1024 * 4; break;
         case 18: src = g->s8; cap = 8 * HWp * 4; break;
+#if defined(AL_AGG_LOAD_NOP) && AL_AGG_LOAD_NOP == 3
+        case 99: {                                                      // experiment: the packed-versus-scalar discrepancy record
+            SSLAM_REQUIRE(bytes <= sizeof(unsigned) * 64, "sslam_aliked_debug_read: 256 bytes");
+            SSLAM_HIP_CHECK(hipMemcpyFromSymbol(dst, HIP_SYMBOL(al_dbg_words), bytes));
+            return 0;
+        }
+#endif
         default: SSLAM_REQUIRE(false, "sslam_aliked_debug_read: unknown buffer %d", which);
     }
     SSLAM_REQUIRE(bytes <= cap, "sslam_aliked_debug_read: %zu bytes requested, buffer has %zu", bytes, cap);

@@ -1,0 +1,54 @@
+"""What runs BESIDE the extractor streams in the concurrency experiments (scripts/diag_agg_rnorm.py, scripts/stress_aliked_repeat.py):
+`make_aggressor(spec, nat, W, ROOT)` -> (context, enqueue function).  spec: none | copy | lightglue[:opt,opt] | synthetic:<kind>[:launches:blocks:iters]
+(profiles/r06_aggregate_rnorm_diagnosis.md)."""
+import importlib
+
+
+def make_aggressor(AGGR, nat, W, ROOT):
+    aggr_ctx = nat.Context(0)
+    aggressor = lambda: None
+    if AGGR == "copy":                                             # HBM traffic and nothing else: 256 MB device-to-device copies
+        NB = 256 << 20
+        a_src, a_dst = aggr_ctx.malloc(NB), aggr_ctx.malloc(NB)
+        aggressor = lambda: [aggr_ctx.d2d_async(a_dst, a_src, NB) for _ in range(6)]
+    elif AGGR.startswith("lightglue"):                             # MFMA / transcendental / LDS-DMA kernels of another model
+        import lg_inputs
+        LG = importlib.import_module("opencv-simpleslam_amd.lightglue").LightGlueHIP
+        lg = LG(W.random_lightglue_state_dict(0), max_kpts=1024, ctx=aggr_ctx)
+        # "lightglue:<opt>[,<opt>]": f32 (exact-fp32 kernels: no fp16 planes, no LDS-DMA rings, no assembly attention), ring (the 64-row
+        # ring GEMMs instead of the 128 x 128 projections + fused FFN), noasm (the 4-wave HIP attention kernel), layers<N>
+        for opt in (AGGR.split(":")[1].split(",") if ":" in AGGR else []):
+            if opt == "f32":
+                lg.set_precision("f32")
+            elif opt == "ring":
+                lg.debug_big_gemm(0)
+            elif opt == "big":
+                lg.debug_big_gemm(1)
+            elif opt == "noasm":
+                lg.debug_key_split(-1)
+            elif opt.startswith("layers"):
+                lg.debug_layers(int(opt[6:]))
+        k0, d0, k1, d1 = lg_inputs.make_pair(1024, 1024, seed=1)
+        dev = [aggr_ctx.upload(a) for a in (k0, d0, k1, d1)]
+        o_ij, o_sc, o_info = aggr_ctx.malloc(1024 * 8), aggr_ctx.malloc(1024 * 4), aggr_ctx.malloc(16)
+        aggressor = lambda: [lg.match_dev(dev[0], dev[1], 1024, dev[2], dev[3], 1024, o_ij, o_sc, o_info, min_conf=0.1) for _ in range(3)]
+    elif AGGR.startswith("synthetic:"):                            # scripts/ubench/aggressors.hip: ONE property each
+        import ctypes
+        KIND = {"trans": 1, "mfma": 2, "pk": 3, "valu": 4, "lds": 5, "gather": 6, "store": 7, "scalar": 8, "ldsdma": 9}[AGGR.split(":")[1]]
+        so = ROOT / "scripts" / "ubench" / "libaggr.so"
+        if not so.exists():
+            import subprocess
+            subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-o", str(so),
+                            str(ROOT / "scripts" / "ubench" / "aggressors.hip")], check=True)
+        A = ctypes.CDLL(str(so))
+        A.aggr_launch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        ITERS = {1: 6000, 2: 3000, 3: 12000, 4: 24000, 5: 6000, 6: 3000, 7: 3000, 8: 6000, 9: 3000}[KIND]
+        # "synthetic:<kind>": 3 long launches of 1024 workgroups per two extractor calls; "synthetic:<kind>:<launches>:<blocks>:<iters>":
+        # many short ones (kernel BOUNDARIES of another queue - dispatch-time cache invalidates, wave launches - beside the extractor)
+        spec = AGGR.split(":")
+        LAUNCHES, BLOCKS, ITERS = (int(spec[2]), int(spec[3]), int(spec[4])) if len(spec) == 5 else (3, 1024, ITERS)
+
+        def aggressor():
+            for _ in range(LAUNCHES):
+                assert A.aggr_launch(KIND, ctypes.c_void_p(int(aggr_ctx.stream)), BLOCKS, ITERS) == 0
+    return aggr_ctx, aggressor

@@ -1,15 +1,19 @@
 """Determinism of ALIKED extraction under concurrency: N extractor instances on streams of their own extract the same batches of
 frames over and over without host synchronisation in between; every repeat must reproduce the first one bit for bit.
-usage: stress_aliked_repeat.py [repeats=40] [instances=3] [F=2]"""
+usage: stress_aliked_repeat.py [repeats=40] [instances=3] [F=2] [beside=none]
+`beside`: other work on a stream of its own beside the extractors (scripts/aggressor_util.py), e.g. "lightglue:ring,noasm" - a
+LightGlue matcher on its ring GEMMs and HIP attention kernel, the strongest trigger r06 found for the one fault this guards
+against (profiles/r06_aggregate_rnorm_diagnosis.md)."""
 import importlib, sys, hashlib
 from pathlib import Path
 import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
-sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests")); sys.path.insert(0, str(ROOT / "scripts"))
 import frames
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 NI = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 F = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+BESIDE = sys.argv[4] if len(sys.argv) > 4 else "none"
 pkg = importlib.import_module("opencv-simpleslam_amd")
 W = importlib.import_module("opencv-simpleslam_amd.weights")
 AL = importlib.import_module("opencv-simpleslam_amd.aliked").AlikedHIP
@@ -42,6 +46,8 @@ def stage_hashes(j):                         # frame 0 of instance j: sha1 of th
               15: (13, Hp // 2, Wp // 2), 16: (13, Hp // 8, Wp // 8), 17: (13, Hp // 32, Wp // 32), 18: (8, Hp, Wp)}
     return {k: hashlib.sha1(dets[j].debug_read(k, sh).tobytes()).hexdigest()[:10] for k, sh in shapes.items()}
 NAMES = {0: "score", 3: "x1", 4: "x2", 5: "x3", 6: "x4", 10: "g1cl", 11: "rnorm", 12: "g2", 13: "g3", 14: "g4", 15: "pre2", 16: "pre3", 17: "pre4", 18: "s8"}
+from aggressor_util import make_aggressor
+aggr_ctx, aggressor = make_aggressor(BESIDE, nat, W, ROOT)
 for j in range(NI):
     enqueue(j)
 ref = snapshot()
@@ -53,9 +59,12 @@ for j in range(NI):
 bad = 0
 for r in range(reps):
     for k in range(4):                      # four un-synchronised calls per instance, interleaved across the streams
+        if k % 2 == 0:
+            aggressor()
         for j in range(NI):
             enqueue(j)
     got = snapshot()
+    aggr_ctx.sync()
     for i, (a, b) in enumerate(zip(ref, got)):
         if a[0] != b[0] or not np.array_equal(a[1], b[1]) or not np.array_equal(a[2], b[2]):
             nd = int((a[2] != b[2]).any(axis=1).sum()) if a[0] == b[0] else -1
@@ -71,5 +80,5 @@ for r in range(reps):
                 cur = dets[j].debug_read(11, (Hp, Wp)); ys, xs = np.nonzero(cur != ref_rn[j])
                 print(f"    rnorm: {len(ys)} pixels differ; rows {sorted(set(ys.tolist()))[:8]} cols {xs.min()}..{xs.max()}; "
                       f"ref {ref_rn[j][ys[0], xs[0]]!r} now {cur[ys[0], xs[0]]!r}; max rel {np.abs(cur / ref_rn[j] - 1).max():.3g}", flush=True)
-print(f"{reps} repeats x {NI} instances x {F} frames: {bad} mismatching frame results", flush=True)
+print(f"{reps} repeats x {NI} instances x {F} frames (beside: {BESIDE}): {bad} mismatching frame results", flush=True)
 sys.exit(1 if bad else 0)

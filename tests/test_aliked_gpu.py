@@ -255,3 +255,10 @@ def test_extraction_is_deterministic_under_concurrency():
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "0 mismatching frame results" in out.stdout and "stage buffers differ" not in out.stdout, out.stdout[-2000:]
+    # r06: the strongest trigger found for that fault - one extractor stream beside a LightGlue matcher on its ring GEMMs and HIP
+    # attention kernel (123 events in 400 repeats on the unstable code shape, 0 with packed-fp32 instructions kept out of
+    # al_aggregate_kernel: profiles/r06_aggregate_rnorm_diagnosis.md)
+    out = subprocess.run([sys.executable, str(ROOT / "scripts" / "stress_aliked_repeat.py"), "150", "1", "2", "lightglue:ring,noasm"],
+                         cwd=str(ROOT), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "0 mismatching frame results" in out.stdout and "stage buffers differ" not in out.stdout, out.stdout[-2000:]
