@@ -707,8 +707,9 @@ def main():
         for mat in mats:
             mat.debug_big_gemm(int(os.environ["SSLAM_BIG_GEMM"]))
     plan = fs.ShardPlan(world, rank, FRAMES_PER_RANK)
+    USE_GRAPHS = os.environ.get("SSLAM_BENCH_GRAPHS", "1") != "0"      # A/B hook (scripts/): plain launches instead of cached hipGraphs
     pipe = fs.FrameStreamPipeline(dets, mats, plan, MAX_KPTS, MIN_CONF, batch_pairs=BATCH_PAIRS,
-                                  collate_always=distributed, comm=comm)
+                                  collate_always=distributed, comm=comm, use_graphs=USE_GRAPHS)
     c0 = ctx_e[0]
 
     # synthetic stream, resident in HBM: a pool of rounds that the timed loop cycles through

@@ -119,7 +119,10 @@ def build_native(force: bool = False, verbose: bool = False) -> Path:
         raise RuntimeError(f"SSLAM_EXTRA_HIPCC_FLAGS={' '.join(extra)!r} is set but SSLAM_EXPERIMENT_BUILD is not 1: refusing to build "
                            "the product library with experiment flags (unset the variable, or export SSLAM_EXPERIMENT_BUILD=1 "
                            "for an A/B run under scripts/)")
-    base_key = _digest(hipcc, *HIPCC_FLAGS, "|", *extra, *[h.read_bytes() for h in headers])
+    # (the compiler's own version string is part of every key: another hipcc at the same path rebuilds everything - the code
+    #  shapes the stress tests vouch for are those of the compiler that built the library under test)
+    ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
+    base_key = _digest(hipcc, ver, *HIPCC_FLAGS, "|", *extra, *[h.read_bytes() for h in headers])
 
     def compile_one(src: Path):
         obj = obj_dir / (src.stem + ".o")

@@ -1333,13 +1333,15 @@ __global__ __launch_bounds__(256) void al_score_tail_kernel(const float* __restr
         for (int o = 0; o < 4; ++o) t2[o][ly][lx] = a[o];
     }
     __syncthreads();
-    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    const int yy = y0 + ly, xx = x0 + lx;
-    float a = 0.0f;
-    for (int ci = 0; ci < 4; ++ci)
-        for (int tap = 0; tap < 9; ++tap) a = fmaf(t2[ci][ly + tap / 3][lx + tap % 3], w6[ci * 9 + tap], a);
-    const int uy = yy - pt, ux = xx - pl;
-    if (uy >= 0 && uy < h && ux >= 0 && ux < w) score[(size_t)uy * w + ux] = 1.0f / (1.0f + expf(-a));
+    for (int i = threadIdx.x; i < ST_H * ST_W; i += 256) {        // (ST_H = 8: one pixel per thread)
+        const int lx = i & (ST_W - 1), ly = i / ST_W;
+        const int yy = y0 + ly, xx = x0 + lx;
+        float a = 0.0f;
+        for (int ci = 0; ci < 4; ++ci)
+            for (int tap = 0; tap < 9; ++tap) a = fmaf(t2[ci][ly + tap / 3][lx + tap % 3], w6[ci * 9 + tap], a);
+        const int uy = yy - pt, ux = xx - pl;
+        if (uy >= 0 && uy < h && ux >= 0 && ux < w) score[(size_t)uy * w + ux] = 1.0f / (1.0f + expf(-a));
+    }
 }
 
 // ------------------------------------------------------------------------ //
@@ -2233,6 +2235,7 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
     // block4 at 1/32
     const int H4 = Hp / 32, W4 = Wp / 32, HW4 = H4 * W4;
     const dim3 g4(sslam::cdiv(W4, 32), H4, uF);
+    sslam::graph_cut(s);       // (pieces of 10 - 12 launches: a graph's replay stops for ~25 us after its 15th kernel node, common.hpp)
     hipLaunchKernelGGL(al_avgpool_kernel, dim3(sslam::cdiv(64 * HW4, 256), uF), dim3(256), 0, s, g->x3, g->p4, 64, H3, W3, 4, fs, g->p4cl);
     const float mo4 = (float)(H4 > W4 ? H4 : W4) / 4.0f;
     hipLaunchKernelGGL((al_offset_conv_h_kernel<64>), g4, dim3(256), 0, s, g->p4cl, g->off, H4, W4, g->b4c1of, g->b4c1.ob, mo4, g->ctrl, fs);
@@ -2262,6 +2265,7 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
     const int nbx = sslam::cdiv(d.w, NW_OW), nby = sslam::cdiv(d.h, NW_OH), npx = d.h * d.w;
     hipLaunchKernelGGL(al_nms_wave_kernel, dim3(sslam::cdiv(nbx * nby, 4), uF), dim3(256), 0, s, g->score, d.h, d.w, nbx, nbx * nby,
                        g->nms, g->bsum, 0.2f, g->cand, g->cand_cap, g->ctrl, g->hist, fs);
+    sslam::graph_cut(s);
     hipLaunchKernelGGL(al_collect_kernel, dim3(sslam::cdiv(npx, 256 * COLLECT_PPT), uF), dim3(256), 0, s, g->nms, npx, 0.0f, 1, g->bsum,
                        nbx * nby, g->cand, g->cand_cap, g->ctrl, g->hist, fs);
     hipLaunchKernelGGL(al_select_kernel, dim3(uF), dim3(1024), (SEL_CAP + EDGE_CAP) * 8, s, g->cand, g->cand_cap, n_limit,

@@ -95,7 +95,9 @@ class DeviceFeatureRing:
         self.ransac_thr = None           # threshold of the last filter_matches_ransac call on a resident match (None: not seen)
         self.results = deque(maxlen=self.MEMO)     # match lists handed out: dict(matches, k, ij, a, b, thr, none, mask)
         self.memo = deque(maxlen=self.MEMO)        # dict(a, b, thr, epoch, k, ij, filter_thr, none, mask, asked)
-        detector.use_graphs(True)        # the slots are a fixed set of buffers: the launch sequence replays as a graph
+        import os
+        # the slots are a fixed set of buffers: the launch sequence can replay as a cached hipGraph (SSLAM_RING_GRAPHS: A/B hook)
+        detector.use_graphs(os.environ.get("SSLAM_RING_GRAPHS", "1") != "0")
         self.matcher, self.mctx = None, None
         self.ev_extracted = self.ctx.event()
         self.last = None                 # the most recently extracted frame

@@ -1,18 +1,18 @@
 # The evidence of a round's FINAL build, taken in one gpurun call so that every file names the same sources:
 #   final_evidence.sh TAG GIT_HEAD        (GIT_HEAD: `git rev-parse --short HEAD` of the build container; the box has no .git)
 # Writes gpurun_out/${TAG}_*: the GPU test log, the bench line, rocprofv3 kernel stats of the bench command, of one batched
-# LightGlue forward (8 pairs), of one single-pair forward, of ALIKED at F = 8 and F = 1, the PMC traffic passes, and
+# LightGlue forward (8 pairs), of one single-pair forward, of ALIKED at F = 8 and F = 1, the PMC traffic passes (LightGlue and ALIKED), the inter-kernel gaps of the single-frame ALIKED sequence, and
 # ${TAG}_evidence_meta.json = {csrc_digest, git_head, files}: the digest of csrc/ + the header (build.py --digest) that
 # tests/test_profiles_fresh.py compares with the tree once the files are copied into profiles/.
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-TAG=${1:-r05}; HEAD=${2:-unknown}
+TAG=${1:-r06}; HEAD=${2:-unknown}
 export SSLAM_GIT_HEAD=$HEAD
 mkdir -p gpurun_out
 DIGEST=$(python opencv-simpleslam_amd/build.py --digest)
 echo "== $TAG: csrc digest $DIGEST, head $HEAD"
-timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/${TAG}_gputest.log 2>&1; tail -2 gpurun_out/${TAG}_gputest.log
-timeout -k 10 600 python bench.py > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/${TAG}_bench_n1.err; tail -2 gpurun_out/${TAG}_bench_n1.err
+timeout -k 10 1100 python -m pytest tests -m gpu -q > gpurun_out/${TAG}_gputest.log 2>&1; tail -2 gpurun_out/${TAG}_gputest.log
+timeout -k 10 900 python bench.py > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/${TAG}_bench_n1.err; tail -2 gpurun_out/${TAG}_bench_n1.err
 bash scripts/prof_bench.sh $TAG 40 > gpurun_out/${TAG}_bench_concurrency.txt 2>&1
 bash scripts/prof_lg_batch.sh 8 > gpurun_out/${TAG}_lightglue_batch8_kernels.txt 2>&1; cp gpurun_out/lgb_kernel_stats.csv gpurun_out/${TAG}_lightglue_batch8_kernel_stats.csv
 bash scripts/prof_lg_batch.sh 1 > gpurun_out/${TAG}_lightglue_single_pair_kernels.txt 2>&1
@@ -20,6 +20,9 @@ bash scripts/prof_lg_batch.sh 2 > gpurun_out/${TAG}_lightglue_two_pair_kernels.t
 bash scripts/prof_aliked.sh 8 > gpurun_out/${TAG}_aliked_F8_kernels.txt 2>&1; cp gpurun_out/aliked_kernel_stats_F8.csv gpurun_out/${TAG}_aliked_kernel_stats.csv
 bash scripts/prof_aliked.sh 1 > gpurun_out/${TAG}_aliked_single_frame_kernels.txt 2>&1
 bash scripts/pmc_traffic.sh $TAG 8 > gpurun_out/${TAG}_pmc_traffic.txt 2>&1
+bash scripts/pmc_traffic_aliked.sh $TAG 8 > gpurun_out/${TAG}_pmc_traffic_aliked.txt 2>&1
+bash scripts/gaps_aliked.sh 1 > gpurun_out/${TAG}_aliked_graph_gaps.txt 2>&1
+rm -f gpurun_out/pmc_FETCH_SIZE.* gpurun_out/pmc_WRITE_SIZE.* gpurun_out/prof_gap.log
 python - $TAG $DIGEST $HEAD <<'PY'
 import glob, json, os, sys
 tag, digest, head = sys.argv[1:4]

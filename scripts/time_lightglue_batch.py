@@ -21,6 +21,8 @@ if os.environ.get("SSLAM_BIG_GEMM"):
     lg.debug_big_gemm(int(os.environ["SSLAM_BIG_GEMM"]))
 if os.environ.get("SSLAM_KEY_SPLIT"):          # 1 = the 4-wave attention kernel without key split (A/B against the ping-pong form)
     lg.debug_key_split(int(os.environ["SSLAM_KEY_SPLIT"]))
+if os.environ.get("SSLAM_GRAPHS"):             # replay the launch sequence as a cached hipGraph (what the pipeline and the drop-in path do)
+    lg.use_graphs(bool(int(os.environ["SSLAM_GRAPHS"])))
 pairs = []
 for b in range(B):
     k0, d0, k1, d1 = lg_inputs.make_pair(N, seed=11 + b)
