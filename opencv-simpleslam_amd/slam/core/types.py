@@ -378,13 +378,14 @@ class MatchList(list):
     exactly this order.  A sorted / filtered / copied list is an ordinary or dirty list and is filtered from scratch.  (An
     in-place edit of an ELEMENT - `m.queryIdx = ...` - cannot be seen by the list: the duck type's edit counter is compared,
     see dmatch_edit_epoch; with cv2's class every element's indices are read back and compared.)"""
-    __slots__ = ("_ij", "_dirty", "_epoch")
+    __slots__ = ("_ij", "_dirty", "_epoch", "_qt")
 
     def __init__(self, items=(), ij=None):
         super().__init__(items)
         self._ij = ij
         self._dirty = ij is None
         self._epoch = dmatch_edit_epoch()
+        self._qt = None                 # cv2's class: the two index columns as python lists (made on the first check)
 
     def _touch(self):
         self._dirty = True
@@ -414,7 +415,9 @@ class MatchList(list):
         # cv2's class cannot be watched: read EVERY match's two indices back (two C-level attribute passes)
         if len(self):
             try:
-                same = [list(map(_q_of, self)), list(map(_t_of, self))] == _np.asarray(self._ij).T.tolist()
+                if self._qt is None:
+                    self._qt = _np.asarray(self._ij).T.tolist()
+                same = list(map(_q_of, self)) == self._qt[0] and list(map(_t_of, self)) == self._qt[1]
             except Exception:                              # noqa: BLE001
                 same = False
             if not same:

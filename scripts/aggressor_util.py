@@ -51,4 +51,23 @@ def make_aggressor(AGGR, nat, W, ROOT):
         def aggressor():
             for _ in range(LAUNCHES):
                 assert A.aggr_launch(KIND, ctypes.c_void_p(int(aggr_ctx.stream)), BLOCKS, ITERS) == 0
+    elif AGGR.startswith("aliked"):                                # "aliked[:<instances>]": extractor streams (batched ALIKED calls of two frames)
+        import numpy as np                                             # noqa: F401
+        import frames
+        AL = importlib.import_module("opencv-simpleslam_amd.aliked").AlikedHIP
+        n_inst = int(AGGR.split(":")[1]) if ":" in AGGR else 2
+        K, H, Wd = 384, 376, 1241
+        sd = W.random_aliked_state_dict(0)
+        actx = [aggr_ctx] + [nat.Context(0) for _ in range(n_inst - 1)]
+        dets = [AL(sd, max_num_keypoints=K, max_h=H, max_w=Wd, ctx=c, max_frames=2) for c in actx]
+        imgs = [[c.upload(frames.structured_frame(2 * j + f, h=H, w=Wd)) for f in range(2)] for j, c in enumerate(actx)]
+        outs = [[dict(xy=c.malloc(K * 8), desc=c.malloc(K * 512), sc=c.malloc(K * 4), n=c.malloc(64)) for _ in range(2)] for c in actx]
+
+        def aggressor():
+            for _ in range(2):
+                for j, d in enumerate(dets):
+                    o = outs[j]
+                    d.extract_batch_dev(imgs[j], H, Wd, 3, [x["xy"] for x in o], [x["desc"] for x in o], [x["sc"] for x in o], [x["n"] for x in o])
+        sync_all = lambda: [c.sync() for c in actx]
+        aggr_ctx.sync_all = sync_all
     return aggr_ctx, aggressor
