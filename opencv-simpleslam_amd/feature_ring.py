@@ -93,12 +93,18 @@ class DeviceFeatureRing:
         self.pin_rs_info = self.pin_match[self.o_rsi:self.o_rsm].view(np.int32).reshape(P, 4)
         self.pin_rs_mask = self.pin_match[self.o_rsm:].reshape(P, KM)
         self.ransac_thr = None           # threshold of the last filter_matches_ransac call on a resident match (None: not seen)
-        self.results = deque(maxlen=self.MEMO)     # match lists handed out: dict(matches, k, ij, a, b, thr, none, mask)
+        self.results = deque(maxlen=self.MEMO)     # match lists handed out: dict(matches, k, ij, a, b, thr, entry = the memo entry with none / mask)
         self.memo = deque(maxlen=self.MEMO)        # dict(a, b, thr, epoch, k, ij, filter_thr, none, mask, asked)
         import os
         # the slots are a fixed set of buffers: the launch sequence can replay as a cached hipGraph (SSLAM_RING_GRAPHS: A/B hook)
         detector.use_graphs(os.environ.get("SSLAM_RING_GRAPHS", "1") != "0")
         self.matcher, self.mctx = None, None
+        # the F-matrix filter behind a match runs on a stream of its own (r06): `feature_matcher` returns when {count, pairs}
+        # are back, the filter's ~70 us of small kernels run while the host builds the match list and the caller gets to its
+        # `filter_matches_ransac` call, which then only waits for the mask
+        self.fctx, self.ev_matched = None, None
+        self.filter_inflight = False     # filter launches (and the mask's read-back) are queued on fctx behind ev_matched
+        self.pending_masks = []          # [(memo entry, pair index)]: entries whose mask is still on its way
         self.ev_extracted = self.ctx.event()
         self.last = None                 # the most recently extracted frame
         self.ahead_on = False            # the prev -> cur pattern has been seen
@@ -113,12 +119,17 @@ class DeviceFeatureRing:
         self.stats = dict(resident=0, memo=0, ahead=0, ahead_kf=0, reupload=0, wasted=0)
 
     def attach_matcher(self, matcher):
+        self._resolve_masks()
+        if self.fctx is None or matcher.ctx is not self.mctx:
+            self.fctx = type(matcher.ctx)(matcher.ctx.device)
+            self.ev_matched = matcher.ctx.event()
         self.matcher, self.mctx = matcher, matcher.ctx
 
     def forget_patterns(self):
         """Drop everything learned about the caller (look-ahead, keyframe role, filter threshold, memo); the resident
         frames stay."""
         self._finish_ahead()
+        self._resolve_masks()
         self.memo.clear(); self.results.clear()
         self.ahead_on, self.last_thr, self.ransac_thr = False, None, None
         self.kf = self.kf_next = self.kf_gap = None
@@ -213,6 +224,7 @@ class DeviceFeatureRing:
         if self.ahead is not None:       # the last look-ahead was never collected: the caller is not in the prev -> cur loop
             self._finish_ahead()
             self.ahead_on = False
+        self._resolve_masks()            # (a filter still reading two frames' keypoints: their slots may be recycled below)
         self._retire_unasked()
         sl = self._take_slot()
         self.seq += 1
@@ -294,6 +306,7 @@ class DeviceFeatureRing:
         """pairs: [(slot a, bound a, slot b, bound b)] -> one launch sequence on the matcher's stream, the filter behind every
         pair, one read-back."""
         mt = self.matcher
+        self._resolve_masks()            # the mirror and the device outputs are about to be overwritten
         if len(pairs) == 1:
             sa, na, sb, nb = pairs[0]
             mt.match_dev(sa["xy"], sa["desc"], na, sb["xy"], sb["desc"], nb, self.out_ij, self.out_sc, self.out_info,
@@ -309,14 +322,18 @@ class DeviceFeatureRing:
         own output (sslam_fmat_ransac_dev: no host round trip, no pixel gather on the host) and its mask rides back with
         {count, pairs} in the same copy."""
         K = self.K
+        self.mctx.d2h_async(self.pin_match[:self.o_rsi], self.out_info)           # {count, pairs}: what feature_matcher waits for
         if self.ransac_thr is not None:
+            self.mctx.record(self.ev_matched)
+            self.fctx.wait(self.ev_matched)
             for p, (xy_a, xy_b) in enumerate(xys):
-                epipolar.filter_matches_dev(self.mctx, K, self.out_info + 16 * p, xy_a, xy_b, self.out_ij + 8 * K * p, None,
+                epipolar.filter_matches_dev(self.fctx, K, self.out_info + 16 * p, xy_a, xy_b, self.out_ij + 8 * K * p, None,
                                             self.rs_info + 16 * p, thresh=self.ransac_thr, confidence=0.99,
                                             mask_out_dev=self.rs_mask + self.KM * p)
-            self.mctx.d2h_async(self.pin_match, self.out_info)
-        else:
-            self.mctx.d2h_async(self.pin_match[:self.o_rsi], self.out_info)
+            self.fctx.d2h_async(self.pin_match[self.o_rsi:], self.rs_info)        # {RANSAC verdict, mask}: what filter_matches_ransac waits for
+            # (nothing is queued on the matcher's stream behind the filter - its synchronisation must not wait for it; whoever
+            #  enqueues there next, or recycles a slot, resolves the masks first: _enqueue, extract)
+            self.filter_inflight = True
 
     def _harvest(self, pairs, thr, filter_thr, asked):
         """After the matcher's stream has been synchronised: the results of `pairs` out of the page-locked mirror as memo entries
@@ -329,10 +346,20 @@ class DeviceFeatureRing:
                      none=False, mask=None, asked=asked)
             if filter_thr is not None and k >= 0:
                 e["filter_thr"] = filter_thr
-                e["none"] = int(self.pin_rs_info[p, 3]) == -1      # no model (cv2 returns mask None): nothing is kept
-                e["mask"] = self.pin_rs_mask[p, :k].copy()
+                self.pending_masks.append((e, p))                  # (the filter may still be running: _resolve_masks)
             out.append(e)
         return out
+
+    def _resolve_masks(self):
+        """The filter's verdicts of the last launch out of the page-locked mirror into their memo entries (waits for the filter's
+        stream if they are still on their way)."""
+        if self.filter_inflight:
+            self.fctx.sync()
+            self.filter_inflight = False
+        for e, p in self.pending_masks:
+            e["none"] = int(self.pin_rs_info[p, 3]) == -1          # no model (cv2 returns mask None): nothing is kept
+            e["mask"] = self.pin_rs_mask[p, :e["k"]].copy()
+        self.pending_masks = []
 
     def _finish_ahead(self):
         ahead, self.ahead = self.ahead, None
@@ -416,7 +443,7 @@ class DeviceFeatureRing:
         self.shell_hint = max(256, k + k // 4 + 64)
         if known:
             self._learn(ra, rb, thr, first_ask)
-            self.results.append(dict(matches=out, k=k, ij=ij, a=ra, b=rb, thr=e["filter_thr"], none=e["none"], mask=e["mask"]))
+            self.results.append(dict(matches=out, k=k, ij=ij, a=ra, b=rb, thr=e["filter_thr"], entry=e))
         return out
 
     def _learn(self, ra, rb, thr, first_ask):
@@ -454,8 +481,10 @@ class DeviceFeatureRing:
                 or kp1.pristine_xy() is not r["a"].xy or kp2.pristine_xy() is not r["b"].xy):
             return None
         if r["thr"] is not None and r["thr"] == float(thresh):
-            if r["none"]:                         # no model: cv2 returns mask None, the reference returns []
+            self._resolve_masks()                 # (the filter ran beside the host's work on the match list: its mask is due now)
+            e = r["entry"]
+            if e["none"]:                         # no model: cv2 returns mask None, the reference returns []
                 return []
-            return list(compress(matches, r["mask"].tolist()))
+            return list(compress(matches, e["mask"].tolist()))
         self.ransac_thr = float(thresh)
         return None
