@@ -83,7 +83,7 @@ EARLY_STOP_MATCH_BIAS = float(os.environ.get("SSLAM_BENCH_MATCH_BIAS", -9.0))
 
 def _pmc_traffic():
     """Per-launch HBM-side bytes of the attention kernel at the bench size, from profiles/ (None when absent)."""
-    for name in ("r05_attention_traffic.json", "r04_attention_traffic.json", "r03_attention_traffic.json", "r02final_attention_traffic.json", "r02_attention_traffic.json", "r01_attention_traffic.json"):
+    for name in ("r06_attention_traffic.json", "r05_attention_traffic.json", "r04_attention_traffic.json", "r03_attention_traffic.json", "r02final_attention_traffic.json", "r02_attention_traffic.json", "r01_attention_traffic.json"):
         try:
             d = json.loads((ROOT / "profiles" / name).read_text())
             return int(d["fetch_bytes_per_launch"]) + int(d["write_bytes_per_launch"]), name
@@ -1037,7 +1037,7 @@ def main():
             # and, when the caller passed it along (SSLAM_GIT_HEAD, scripts/final_evidence.sh), the commit
             "build": {"csrc_digest": _source_digest(), "git_head": os.environ.get("SSLAM_GIT_HEAD") or _git_head()},
             "dtype": "f32 (contractions: f16 hi/lo split operands, f32 accumulate; 3 MFMA per product, 2 in attention's P.V = "
-                     "precision 'f16x3p1', the default since r05: profiles/r05_flip_soak.md)",
+                     "precision 'f16x3p1', the default since r05: profiles/r05_flip_soak.md, r06_flip_soak.md)",
             "data": "synthetic",
             "config": {"workload": "C2/C4: synthetic 1241x376x3 uint8 frame stream, ALIKED-n16 extract + "
                                    "LightGlue match (t-1,t), 2048 kpts/frame, min_conf 0.7, random-init weights; "
