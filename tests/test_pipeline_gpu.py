@@ -175,3 +175,41 @@ def test_pipeline_reports_a_split_precision_range_overflow(native):
         for m in mats:
             m.close()
     dets[0].close()
+
+
+def test_pipeline_reports_a_frame_the_extractor_voided(native):
+    """an EXTRACTOR range overflow leaves keypoint count -1 in the frame's record, the matcher reads such a
+    frame as empty, so the pair's `info` shows 0 matches - not -1 - and `results()` / `infos()` used to hand the round on as
+    valid.  They poll every extractor's sticky word now and raise, naming the frames; a sane round on the same pipeline is served
+    normally afterwards."""
+    W = load_pkg("weights"); fs = load_pkg("frame_shard")
+    AL = load_pkg("aliked").AlikedHIP; LG = load_pkg("lightglue").LightGlueHIP
+    K, H, Wd, B, P = 256, 160, 256, 4, 2
+    sd_l = W.random_lightglue_state_dict(1, match_gain=4.0, match_bias=3.0)
+    imgs = np.stack([frames.structured_frame(i, h=H, w=Wd) for i in range(B)])
+    for scale, expect in ((1e5, True), (1.0, False)):
+        sd_a = W.random_aliked_state_dict(0)
+        sd_a["block1.bn1.weight"] = (sd_a["block1.bn1.weight"] * scale).astype(np.float32)      # conv1's activations x scale: 1e5 cannot fit the fp16 planes
+        sd_a["block1.bn1.bias"] = (sd_a["block1.bn1.bias"] * scale).astype(np.float32)
+        dets = [AL(sd_a, max_num_keypoints=K, max_h=H, max_w=Wd, ctx=native.Context(0), max_frames=2)]
+        mats = [LG(sd_l, max_kpts=K, ctx=native.Context(0), max_pairs=P, filter_threshold=0.0)]
+        pipe = fs.FrameStreamPipeline(dets, mats, fs.ShardPlan(1, 0, B), K, 0.0, batch_pairs=P)
+        chunk = pipe.ctx.upload(imgs)
+        pipe.round(chunk, H, Wd, 3)
+        pipe.round(chunk, H, Wd, 3)
+        if expect:
+            with pytest.raises(fs.RangeOverflowError, match=r"ALIKED.*frame\(s\) \[0, 1, 2, 3\]"):
+                pipe.infos()
+            assert pipe.range_overflow() is False                    # the report cleared the sticky words
+            pipe.round(chunk, H, Wd, 3)
+            with pytest.raises(fs.RangeOverflowError, match="ALIKED"):
+                pipe.results()
+            with pytest.raises(fs.RangeOverflowError):               # features(): the record's count says so itself
+                pipe.features()
+        else:
+            info = pipe.infos()
+            assert (info[:, 0] >= 0).all() and len(pipe.results()) == B
+            assert pipe.range_overflow() is False
+        pipe.ctx.free(chunk)
+        for x in dets + mats:
+            x.close()
