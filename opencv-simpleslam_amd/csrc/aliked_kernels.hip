@@ -117,6 +117,36 @@ template <typename T> __device__ __forceinline__ T* fsh(T* p, int f, size_t fs) 
     using B = std::conditional_t<std::is_const_v<T>, const char, char>;
     return reinterpret_cast<T*>(reinterpret_cast<B*>(p) + (size_t)f * fs);
 }
+// XCD-aware placement of image tiles (r06).  Workgroups are dealt to the 8 XCDs round-robin by their linear id and each XCD has
+// an L2 of its own, so with tiles numbered in raster order the eight neighbours of a tile sit behind seven OTHER L2s and every
+// halo line is fetched from HBM once per XCD that touches it (PMC r04 - r06: al_score_tail fetched 30.8 MB for 10.5 MB of s8).
+// xcd_band() renumbers: inside every frame the workgroups that share an XCD (ids congruent mod 8) get a CONTIGUOUS band of tile
+// rows, so a halo is re-read from the L2 that already holds it (30.8 -> 11.9 MB; al_resize_pad 12.4 -> 5.9 MB; kernel times
+// unchanged within 2 %: neither kernel is bound by that traffic - scripts/ab_aliked_band.sh; form 1, whole frames per XCD at
+// F = 8, measured 2 % slower per call).  Placement only: every tile is computed by exactly one workgroup with the same arithmetic.
+// -> (x, y, z) the kernel uses in place of blockIdx.
+#ifndef AL_XCD_BAND
+#define AL_XCD_BAND 2
+#endif
+struct Tile3 { int x, y, z; };
+__device__ __forceinline__ Tile3 xcd_band() {
+#if AL_XCD_BAND == 1
+    const unsigned nx = gridDim.x, ny = gridDim.y, total = nx * ny * gridDim.z;
+    if ((total & 7u) == 0u) {
+        const unsigned L = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+        const unsigned g = (L & 7u) * (total >> 3) + (L >> 3);
+        return Tile3{(int)(g % nx), (int)((g / nx) % ny), (int)(g / (nx * ny))};
+    }
+#elif AL_XCD_BAND == 2          // bands inside every frame (the XCDs work on the same frame at the same time)
+    const unsigned nx = gridDim.x, ny = gridDim.y, per = nx * ny;
+    if ((per & 7u) == 0u) {
+        const unsigned L = blockIdx.x + nx * blockIdx.y;
+        const unsigned g = (L & 7u) * (per >> 3) + (L >> 3);
+        return Tile3{(int)(g % nx), (int)(g / nx), (int)blockIdx.z};
+    }
+#endif
+    return Tile3{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+}
 template <typename T> __device__ __forceinline__ T* fsh0(T* p, int f, size_t fs) {      // null stays null (run-time optional outputs)
     return p ? fsh(p, f, fs) : nullptr;
 }
@@ -162,8 +192,9 @@ __global__ void al_to_float_kernel(FrameIn srcs, float* __restrict__ dst, Dims d
 __global__ void al_resize_pad_kernel(const float* __restrict__ src, float* __restrict__ img, Dims d,
                                      const float* __restrict__ gy, int ky, int blur, size_t fs) {
     // img [3][Hp][Wp]: replicate-padded bilinear (align_corners=False) resize of (vertically blurred) src
-    src = fsh(src, blockIdx.z, fs); img = fsh(img, blockIdx.z, fs);
-    const int xp = blockIdx.x * blockDim.x + threadIdx.x, yp = blockIdx.y;
+    const Tile3 tb = xcd_band();                    // (the vertical taps and the bilinear rows of neighbouring output rows overlap)
+    src = fsh(src, tb.z, fs); img = fsh(img, tb.z, fs);
+    const int xp = tb.x * blockDim.x + threadIdx.x, yp = tb.y;
     if (xp >= d.Wp) return;
     const int y = min(max(yp - d.pt, 0), d.h - 1), x = min(max(xp - d.pl, 0), d.w - 1);
     const float sy_ = (float)d.H / (float)d.h, sx_ = (float)d.W / (float)d.w;
@@ -953,12 +984,20 @@ __global__ __launch_bounds__(256) void al_gate_kernel(const float* __restrict__ 
     }
 }
 
-// small-map variant (1/8, 1/32 resolution): one thread per (co, pixel), more parallelism
-__global__ void al_gate_small_kernel(const float* __restrict__ in, float* __restrict__ out, int CIN, int HW,
-                                     const float* __restrict__ w /*[ci][32]*/, float* __restrict__ out_cl, size_t fs) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// small-map variant (1/8, 1/32 resolution): one thread per (co, pixel), more parallelism.  r06: both small levels in ONE launch
+// (a launch of a few workgroups is ~5 us of a single frame's dependent chain): the first `blocks_a` workgroups gate level a,
+// the rest level b - each thread's arithmetic is what its own launch did.
+struct GateSmall { const float* in; float* out; int CIN; int HW; const float* w; float* out_cl; };
+__global__ void al_gate_small_kernel(GateSmall a, GateSmall b, int blocks_a, size_t fs) {
+    const bool second = (int)blockIdx.x >= blocks_a;
+    const GateSmall& q = second ? b : a;
+    const int i = ((int)blockIdx.x - (second ? blocks_a : 0)) * blockDim.x + threadIdx.x;
+    const int CIN = q.CIN, HW = q.HW;
     if (i >= 32 * HW) return;
-    in = fsh(in, blockIdx.y, fs); out = fsh(out, blockIdx.y, fs); out_cl = fsh0(out_cl, blockIdx.y, fs);
+    const float* __restrict__ in = fsh(q.in, blockIdx.y, fs);
+    float* __restrict__ out = fsh(q.out, blockIdx.y, fs);
+    float* __restrict__ out_cl = fsh0(q.out_cl, blockIdx.y, fs);
+    const float* __restrict__ w = q.w;           /*[ci][32]*/
     const int co = i / HW, p = i % HW;
     float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll 8                 // 16 loads in flight per thread: the loop is pure load latency otherwise
@@ -1038,6 +1077,8 @@ __global__ __launch_bounds__(256) void al_agg_pre_kernel(const float* __restrict
                                                          const float* __restrict__ g4cl, const float* __restrict__ ws0 /*[128][8]*/,
                                                          float* __restrict__ pre2, float* __restrict__ pre3, float* __restrict__ pre4,
                                                          int Hp, int Wp, size_t fs) {
+    // (xcd_band() here halves this kernel's fetch - 23.3 -> 11.2 MB per frame, its threads read their pixel's right and lower
+    //  neighbours - and costs it 20 % of its time, 6.1 -> 7.4 us per frame: eight far-apart streams per plane instead of one; not used)
     const int f = blockIdx.y;
     const int n2 = (Hp / 2) * (Wp / 2), n3 = (Hp / 8) * (Wp / 8), n4 = (Hp / 32) * (Wp / 32);
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1282,11 +1323,12 @@ __global__ __launch_bounds__(256) void al_score_tail_kernel(const float* __restr
                                                             const float* __restrict__ w6 /*[4][9][1]*/,
                                                             float* __restrict__ score, int h, int w, int pl,
                                                             int pt, size_t fs) {
-    s8 = fsh(s8, blockIdx.z, fs); score = fsh(score, blockIdx.z, fs);
+    const Tile3 tb = xcd_band();
+    s8 = fsh(s8, tb.z, fs); score = fsh(score, tb.z, fs);
     __shared__ float t0[8][ST_H + 6][ST_W + 6];
     __shared__ float t1[4][ST_H + 4][ST_W + 4];
     __shared__ float t2[4][ST_H + 2][ST_W + 2];
-    const int x0 = blockIdx.x * ST_W, y0 = blockIdx.y * ST_H;
+    const int x0 = tb.x * ST_W, y0 = tb.y * ST_H;
     const size_t HW = (size_t)Hp * Wp;
     for (int i = threadIdx.x; i < 8 * (ST_H + 6) * (ST_W + 6); i += 256) {
         const int c = i / ((ST_H + 6) * (ST_W + 6)), rem = i % ((ST_H + 6) * (ST_W + 6));
@@ -2245,8 +2287,11 @@ int al_enqueue(sslam_aliked* g, int F, const FrameIn& srcs, int H, int W, int C,
     hipLaunchKernelGGL((al_dcn_h_kernel<128, 128, 64, AL_DCN4_CS>), g4s, dim3(256), 0, s, g->t4cl, g->off, g->p4cl, H4, W4, g->b4c2f, g->b4c2.b, g->b4db, g->x4, nullptr, g->ctrl, fs);
     // gates
     hipLaunchKernelGGL(al_gate_kernel<32>, dim3(sslam::cdiv(H2 * W2, 256), uF), dim3(256), 0, s, g->x2, g->g2, H2 * W2, g->gw2, g->g2cl, fs);
-    hipLaunchKernelGGL(al_gate_small_kernel, dim3(sslam::cdiv(32 * HW3, 256), uF), dim3(256), 0, s, g->x3, g->g3, 64, HW3, g->gw3, g->g3cl, fs);
-    hipLaunchKernelGGL(al_gate_small_kernel, dim3(sslam::cdiv(32 * HW4, 256), uF), dim3(256), 0, s, g->x4, g->g4, 128, HW4, g->gw4, g->g4cl, fs);
+    {
+        const int ba = sslam::cdiv(32 * HW3, 256), bb = sslam::cdiv(32 * HW4, 256);
+        hipLaunchKernelGGL(al_gate_small_kernel, dim3(ba + bb, uF), dim3(256), 0, s, GateSmall{g->x3, g->g3, 64, HW3, g->gw3, g->g3cl},
+                           GateSmall{g->x4, g->g4, 128, HW4, g->gw4, g->g4cl}, ba, fs);
+    }
     // aggregation + score head
     Pyr P{g->x1, g->g2, g->g3, g->g4, g->gw1, Hp, Wp, g->g1cl};
     {
