@@ -272,6 +272,11 @@ def dropin_leg(n_frames=48, only_matched_loops=False):
     planter = lg_inputs.PlantedExtractor(det, chain)
     adaptive = None
     try:
+        if only_matched_loops:
+            # the child process of `dropin.cv2_classes` starts on a GPU that has idled for the seconds its imports and weight
+            # set-up took: a few hundred untimed frames bring the clocks back to where the parent's legs measured
+            for _ in range(4):
+                loop(False); planter.i = 0
         planted = loop(False)
         planter.i = 0
         slam = loop(True)

@@ -97,10 +97,11 @@ class DeviceFeatureRing:
         self.memo = deque(maxlen=self.MEMO)        # dict(a, b, thr, epoch, k, ij, filter_thr, none, mask, asked)
         import os
         # the slots are a fixed set of buffers, so the launch sequence COULD replay as a cached hipGraph (SSLAM_RING_GRAPHS=1) - the
-        # frame loop is a dependent chain on the device, though, and there plain launches measured ahead in every A/B of r06
-        # (`value` 479.7 / 487.0 / 485.9 against 476.0 / 479.2 / 467.5 frames/s on three boxes): a graph's replay stops behind its
-        # 15th node or pays a hand-over per piece (profiles/r06_graph_segments.md), and the host enqueues the 32 launches while
-        # the first ones already run.  The batched pipeline, which has host time to save and long kernels, keeps its graphs.
+        # frame loop is a dependent chain on the device, though, and there a graph's replay stops behind its 15th node or pays a
+        # hand-over per piece (0.405 against 0.381 ms per single-frame call by HIP events, profiles/r06_graph_segments.md) while
+        # the host enqueues the 32 plain launches as the first ones already run.  (At the level of the whole loop the two forms
+        # are inside the run-to-run noise of +-3 %.)  The batched pipeline, which has host time to save and long kernels, keeps
+        # its graphs.
         detector.use_graphs(os.environ.get("SSLAM_RING_GRAPHS", "0") == "1")
         self.matcher, self.mctx = None, None
         # the F-matrix filter behind a match runs on a stream of its own (r06): `feature_matcher` returns when {count, pairs}
