@@ -184,7 +184,7 @@ def _cpu_leg(threads, warmup, timed, budget_s, probe_limit_s=6.0):
             "p90_s": round(float(np.percentile(a, 90)), 4), "frames_per_s": round(1.0 / float(np.median(a)), 4)}
 
 
-def dropin_leg(n_frames=48, only_matched_loops=False):
+def dropin_leg(n_frames=96, only_matched_loops=False):
     """The literal drop-in path: init_feature_pipeline / feature_extractor / feature_matcher / filter_matches_ransac exactly as
     slam/monocular/main_revamped.py calls them - one frame at a time, host arrays and KeyPoint / DMatch objects in and out,
     nothing overlapped by the caller.  Three loops over the same 1241x376 frames:

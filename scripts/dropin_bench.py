@@ -4,4 +4,4 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 import bench
-print(json.dumps(bench.dropin_leg(int(sys.argv[1]) if len(sys.argv) > 1 else 48), indent=1))
+print(json.dumps(bench.dropin_leg(int(sys.argv[1]) if len(sys.argv) > 1 else 96), indent=1))

@@ -13,6 +13,6 @@ cv2 = cv2_stub.install(native_classes=True)        # BEFORE the product binds cv
 import bench                                       # noqa: E402
 T = importlib.import_module("opencv-simpleslam_amd.slam.core.types")
 assert T.HAVE_CV2 and T.KeyPoint is cv2.KeyPoint and T.DMatch is cv2.DMatch
-out = bench.dropin_leg(int(sys.argv[1]) if len(sys.argv) > 1 else 48, only_matched_loops=True)
+out = bench.dropin_leg(int(sys.argv[1]) if len(sys.argv) > 1 else 96, only_matched_loops=True)
 out["classes"] = f"{cv2.KeyPoint.__name__} / {cv2.DMatch.__name__} of tests/cv2like/cv2like.c (cv2 stand-in: the wheel is absent from the image)"
 print(json.dumps(out))

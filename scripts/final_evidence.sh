@@ -25,11 +25,11 @@ bash scripts/gaps_aliked.sh 1 > gpurun_out/${TAG}_aliked_graph_gaps.txt 2>&1
 rm -f gpurun_out/pmc_FETCH_SIZE.* gpurun_out/pmc_WRITE_SIZE.* gpurun_out/prof_gap.log
 # the drop-in loops once more on this box, duck types and cv2's classes back to back (bench.py ran them minutes apart), and the ring's
 # extractor as a cached graph against plain launches
-{ for G in 0 1; do SSLAM_RING_GRAPHS=$G SSLAM_ALLOW_RANDOM_WEIGHTS=1 python scripts/dropin_bench.py 48 2>/dev/null | python -c "
+{ for G in 0 1; do SSLAM_RING_GRAPHS=$G SSLAM_ALLOW_RANDOM_WEIGHTS=1 python scripts/dropin_bench.py 96 2>/dev/null | python -c "
 import json, sys
 d = json.load(sys.stdin)
 print('ring graphs $G, duck types : value', d['value'], 'slam_loop', d['slam_loop']['value'], 'frame_loop', d['frame_loop']['value'], 'extractor / matcher / filter ms', d['feature_extractor_ms'], d['feature_matcher_ms'], d['filter_matches_ransac_ms'])"
-  SSLAM_RING_GRAPHS=$G SSLAM_ALLOW_RANDOM_WEIGHTS=1 python scripts/dropin_bench_cv2.py 48 2>/dev/null | tail -1 | python -c "
+  SSLAM_RING_GRAPHS=$G SSLAM_ALLOW_RANDOM_WEIGHTS=1 python scripts/dropin_bench_cv2.py 96 2>/dev/null | tail -1 | python -c "
 import json, sys
 d = json.load(sys.stdin)
 print('ring graphs $G, cv2 classes: value', d['value'], 'slam_loop', d['slam_loop']['value'], 'extractor / matcher / filter ms', d['feature_extractor_ms'], d['feature_matcher_ms'], d['filter_matches_ransac_ms'])"
