@@ -32,9 +32,10 @@ Rank 0 prints ONE JSON line with the contract fields plus
   dropin       - the six names of slam/core/features_utils.py driven as
                  slam/monocular/main_revamped.py drives them (one frame at a
                  time, host objects in and out): frames/s of that literal path
-                 (+ `dropin.cv2_classes`: the same loops in a child interpreter where `cv2`
+                 (+ `dropin.cv2_classes`: the matched loops in a child interpreter where `cv2`
                  is importable - a stand-in with C value classes - so the lists hold cv2's own
-                 KeyPoint / DMatch objects, as they do wherever the reference runs)
+                 KeyPoint / DMatch objects, as they do wherever the reference runs; and the same
+                 loops in a partner child without cv2: `vs_duck_types_same_conditions`)
   planted_matches - the pipeline of `value` on frames that MATCH (records overwritten
                  behind every batched extraction with a synthetic matched chain, LightGlue
                  weights with a sharp assignment head): hundreds of matches per pair
@@ -273,9 +274,10 @@ def dropin_leg(n_frames=96, only_matched_loops=False):
     adaptive = None
     try:
         if only_matched_loops:
-            # the child process of `dropin.cv2_classes` starts on a GPU that has idled for the seconds its imports and weight
-            # set-up took: a few hundred untimed frames bring the clocks back to where the parent's legs measured
-            for _ in range(4):
+            # a child process of `dropin.cv2_classes` starts on a GPU that has idled for the seconds its imports and weight
+            # set-up took, and this loop is a LIGHT load (short kernels, one stream at a time): ~1 500 untimed frames (3 s)
+            # before the timed ones - without them whichever child ran second measured 2 - 4 % faster
+            for _ in range(16):
                 loop(False); planter.i = 0
         planted = loop(False)
         planter.i = 0
@@ -341,20 +343,31 @@ def dropin_cv2_classes_leg():
     hands out cv2's own KeyPoint / DMatch objects - the only environment slam/monocular/main_revamped.py runs in
     (features_utils.py:2, :61-63, :80-83).  The wheel is absent from the image: `cv2` is tests/cv2_stub.py with the value
     classes of tests/cv2like/cv2like.c (C structs behind python objects, eager construction, a fresh tuple per `pt` read,
-    KeyPoint_convert in one C pass - the cost model of the wheel's classes).  The child is a separate process on the same
-    GPU (scripts/dropin_bench_cv2.py); this process is idle meanwhile."""
-    res = subprocess.run([sys.executable, str(ROOT / "scripts" / "dropin_bench_cv2.py")], capture_output=True, text=True, timeout=900,
-                         env=dict(os.environ, SSLAM_ALLOW_RANDOM_WEIGHTS="1"))
-    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
-    if res.returncode != 0 or not lines:
-        return {"error": (res.stdout[-500:] + res.stderr[-1500:])}
-    r = json.loads(lines[-1])
+    KeyPoint_convert in one C pass - the cost model of the wheel's classes).  Two child processes (scripts/dropin_bench_cv2.py),
+    with the stand-in and - the like-for-like partner - without; main() runs them BEFORE this process creates its own GPU
+    contexts (run behind the other legs, with this process's dozen idle streams mapped on the hardware queues, the child's
+    frame chain measured 3 - 9 % slower than the same child alone: 0.91 - 0.98 of `dropin.value` from call to call)."""
+    def child(*flags):
+        res = subprocess.run([sys.executable, str(ROOT / "scripts" / "dropin_bench_cv2.py"), *flags], capture_output=True, text=True,
+                             timeout=900, env=dict(os.environ, SSLAM_ALLOW_RANDOM_WEIGHTS="1"))
+        lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+        if res.returncode != 0 or not lines:
+            raise RuntimeError(res.stdout[-500:] + res.stderr[-1500:])
+        return json.loads(lines[-1])
+    try:
+        r = child()
+        duck = child("--duck-types")            # the like-for-like partner: same loops, same kind of process, no cv2
+    except Exception as e:
+        return {"error": repr(e)}
     keep = ("value", "unit", "frames_timed", "feature_extractor_ms", "feature_matcher_ms", "filter_matches_ransac_ms", "keypoints",
             "matches_median", "ransac_inliers_median", "answered_from")
     out = {k: r[k] for k in keep if k in r}
     out["slam_loop"] = {k: r["slam_loop"][k] for k in ("value", "unit", "frames_timed", "mean_ms_per_frame", "frame_ms", "keyframe_frames",
                                                        "keyframe_matches_median", "answered_from") if k in r["slam_loop"]}
     out["classes"] = r.get("classes")
+    out["duck_types_same_conditions"] = {"value": duck["value"], "slam_loop": duck["slam_loop"]["value"],
+                                         "feature_matcher_ms": duck["feature_matcher_ms"], "filter_matches_ransac_ms": duck["filter_matches_ransac_ms"]}
+    out["vs_duck_types_same_conditions"] = round(r["value"] / duck["value"], 3)
     out["what"] = ("`dropin.value` / `dropin.slam_loop` in a child interpreter with `cv2` importable (a stand-in whose KeyPoint / DMatch are C "
                    "structs built eagerly, like the wheel's): the lists handed out hold cv2's own classes - cv2.KeyPoint_convert builds a "
                    "frame's keypoints in one C pass, DMatch objects are made behind the running match and their indices stored when it "
@@ -648,6 +661,13 @@ def main():
         _self_launch(args)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    cv2_classes_leg = None
+    if rank == 0 and world == 1 and not args.no_extras and os.environ.get("SSLAM_BENCH_FORCE_DIST") != "1":
+        try:                                     # (child processes: before this one touches the GPU)
+            cv2_classes_leg = dropin_cv2_classes_leg()
+        except Exception as e:                   # never lose the headline line to an auxiliary leg
+            cv2_classes_leg = {"error": repr(e)}
 
     dist = torch = None
     # SSLAM_BENCH_FORCE_DIST=1 (tests): take the N > 1 branches - process group, collective barrier, max-reduce of the
@@ -1125,14 +1145,11 @@ def main():
                 out["dropin"] = dropin_leg()
             except Exception as e:                       # never lose the headline line to an auxiliary leg
                 out["dropin"] = {"error": repr(e)}
-            try:
-                if "error" not in out["dropin"]:
-                    out["dropin"]["cv2_classes"] = dropin_cv2_classes_leg()
-                    v, c = out["dropin"]["value"], out["dropin"]["cv2_classes"].get("value")
-                    if c:
-                        out["dropin"]["cv2_classes"]["vs_duck_types"] = round(c / v, 3)
-            except Exception as e:
-                out["dropin"]["cv2_classes"] = {"error": repr(e)}
+            if "error" not in out["dropin"] and cv2_classes_leg is not None:
+                out["dropin"]["cv2_classes"] = cv2_classes_leg
+                v, c = out["dropin"]["value"], cv2_classes_leg.get("value")
+                if c:
+                    cv2_classes_leg["vs_duck_types"] = round(c / v, 3)      # (against the in-process leg above; `vs_duck_types_same_conditions`: against its partner child)
         if not args.no_cpu_baseline and world == 1:        # the CPU leg is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
