@@ -97,3 +97,35 @@ def test_the_timed_pipeline_configuration_against_the_oracle(native):
     ctx.free(chunk)
     for x in dets + mats:
         x.close()
+
+
+def test_batched_extractor_at_the_c5_size_equals_the_single_frame_entry(native):
+    """BASELINE config C5 (1920 x 1080): the batched extractor entry at that size - what `bench.py`'s `c5` leg times, F = 8 per
+    call - gives the single-frame entry's keypoints, descriptors and scores bit for bit (that entry is held to the oracle at this
+    size by tests/test_aliked_gpu.py::test_c5_size_downscale_with_real_blur)."""
+    W = load_pkg("weights"); AL = load_pkg("aliked").AlikedHIP
+    Hh, Ww, Kk, F = 1080, 1920, 2048, 8
+    sd_a = W.random_aliked_state_dict(3)
+    ctx = native.Context(0)
+    imgs = [frames.structured_frame(i, h=Hh, w=Ww) if i % 2 else frames.noise_frame(i, h=Hh, w=Ww) for i in range(F)]
+    single = AL(sd_a, max_num_keypoints=Kk, max_h=Hh, max_w=Ww, ctx=ctx)
+    want = [single.extract(im, Kk, return_scores=True) for im in imgs[:3] + imgs[-1:]]
+    single.close()
+    al = AL(sd_a, max_num_keypoints=Kk, max_h=Hh, max_w=Ww, ctx=ctx, max_frames=F)
+    al.use_graphs(True)
+    dev = [ctx.upload(im) for im in imgs]
+    xy = [ctx.malloc(Kk * 8) for _ in imgs]; de = [ctx.malloc(Kk * 512) for _ in imgs]
+    sc = [ctx.malloc(Kk * 4) for _ in imgs]; nn = [ctx.malloc(16) for _ in imgs]
+    for _ in range(2):                                   # (the second call replays the cached graph pieces)
+        al.extract_batch_dev(dev, Hh, Ww, 3, xy, de, sc, nn, Kk)
+    ctx.sync()
+    for slot, w in zip((0, 1, 2, F - 1), want):
+        n = np.empty(4, np.int32); ctx.d2h(n, nn[slot])
+        k = int(n[0])
+        assert k == len(w[0]) > 0
+        a = np.empty((Kk, 2), np.float32); d = np.empty((Kk, 128), np.float32); s = np.empty(Kk, np.float32)
+        ctx.d2h(a, xy[slot]); ctx.d2h(d, de[slot]); ctx.d2h(s, sc[slot])
+        np.testing.assert_array_equal(a[:k], w[0]); np.testing.assert_array_equal(d[:k], w[1]); np.testing.assert_array_equal(s[:k], w[2])
+    for p in dev + xy + de + sc + nn:
+        ctx.free(p)
+    al.close()
