@@ -391,3 +391,28 @@ def test_key_range_merge_inside_the_fused_ffn_at_other_capacities(gpu_ctx, cap, 
     assert stop == o_stop and len(ij) > 10
     assert not single.range_overflow()
     single.close()
+
+
+def test_four_pair_batch_at_the_reference_default_of_4000_keypoints_equals_the_oracle(gpu_ctx):
+    """`main_revamped.py:206`: --max_features defaults to 4000, and `bench.py`'s `kpts4000` leg times batches of 4 pairs at that
+    size.  The batched entry at 4000 keypoints (ragged: 4000 x 3700 and 3811 x 4000 in the slots the oracle is run on; the oracle
+    needs ~10 s per pair at this size, so two of the four pairs are held to it and the other two to the single-pair entry):
+    index arrays equal, scores within 1e-4."""
+    W, LG = load_pkg("weights"), load_pkg("lightglue").LightGlueHIP
+    sd = W.random_lightglue_state_dict(1, match_gain=4.0, match_bias=3.0)
+    sizes = [(4000, 3700), (4000, 4000), (2900, 3333), (3811, 4000)]
+    pairs = [lg_inputs.make_pair(m, n, seed=40 + i) for i, (m, n) in enumerate(sizes)]
+    batch = LG(sd, max_kpts=4000, max_pairs=4, ctx=gpu_ctx)
+    dev = DevBatch(gpu_ctx, pairs, 4000)
+    got = dev.run(batch, 0.1)
+    for p in (0, 3):
+        rij, rsc, stop = _oracle(sd, pairs[p], 0.1)
+        np.testing.assert_array_equal(got[p][0].astype(np.int64), rij, err_msg=f"pair {p}")
+        np.testing.assert_allclose(got[p][1], rsc, atol=1e-4)
+        assert got[p][2][1] == stop and len(rij) > 500
+    single = LG(sd, max_kpts=4000, ctx=gpu_ctx)
+    for p in (1, 2):
+        ij, sc, stop = single.match(*pairs[p], min_conf=0.1)
+        np.testing.assert_array_equal(got[p][0], ij, err_msg=f"pair {p}")
+        assert got[p][2][1] == stop and len(ij) > 500
+    dev.free(); batch.close(); single.close()
