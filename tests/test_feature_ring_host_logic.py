@@ -242,3 +242,27 @@ def test_match_objects_prepared_from_the_last_count_are_topped_up_when_more_come
         kp_prev, des_prev = kp, des
     assert ring.stats["ahead"] >= 5                    # (the look-ahead path is the one that prepares shells)
     assert all(h >= 256 for h in seen)                 # the hint follows the results again
+
+
+def test_filter_verdicts_that_are_never_collected_do_not_leak_into_later_pairs(rig):
+    """r06: the filter behind a match runs on a stream of its own and its verdict is fetched when `filter_matches_ransac` asks
+    (or before anything reuses the mirror / the device outputs).  A caller that skips the filter for some frames, filters a
+    LATER pair, or comes back to an earlier result after other matches have run must get each pair's own mask."""
+    fu, det, mat, ring = rig.fu, rig.det, rig.mat, rig.ring
+    thr = 2.5
+    kp, des = [None] * 9, [None] * 9
+    raw = [None] * 9
+    kp[0], des[0] = fu.feature_extractor(ARGS, IMG, det)
+    for f in range(1, 9):
+        kp[f], des[f] = fu.feature_extractor(ARGS, IMG, det)
+        raw[f] = fu.feature_matcher(ARGS, kp[f - 1], kp[f], des[f - 1], des[f], mat)
+        if f in (1, 2, 5, 8):                              # frames 3, 4, 6, 7: the loop does not filter
+            kept = fu.filter_matches_ransac(kp[f - 1], kp[f], raw[f], thr)
+            assert pairs(kept) == host_filter(rig, kp[f - 1], kp[f], raw[f], thr), f
+        assert len(ring.pending_masks) <= ring.PAIRS
+    # an earlier result, asked after later matches overwrote the mirror: its verdict was taken into its entry in time
+    n_host = rig.ep.host_calls
+    for f in (7, 6):
+        kept = fu.filter_matches_ransac(kp[f - 1], kp[f], raw[f], thr)
+        assert pairs(kept) == host_filter(rig, kp[f - 1], kp[f], raw[f], thr), f
+    assert rig.ep.host_calls == n_host + 2                 # (+2: the two host_filter reference calls; the ring answered from its entries)
