@@ -52,6 +52,14 @@ def test_bench_contract_single_rank():
     es = d["early_stop"]
     assert es["value"] > 0 and es["lightglue_layers_histogram"] and set(es["lightglue_layers_histogram"]) != {"9"}, es
     assert es["points_pruned"] and es["kpts_after_pruning_min_max"][0] < 2048, es          # the width control fired under load
+    # r06: the batched pipeline on frames that match (emit / compaction / the per-pair outputs carry hundreds of matches) ...
+    pm = d["planted_matches"]
+    assert pm.get("value", 0) > 0 and pm["matches_per_pair"] > 100 and pm["lightglue_layers_executed"] == 9, pm
+    # ... and the drop-in loops with cv2's own KeyPoint / DMatch classes beside their like-for-like partner (present and sane;
+    # how close the two rates are is bench.py's business, not a test's)
+    cv = d["dropin"]["cv2_classes"]
+    assert cv.get("value", 0) > 0 and cv["matches_median"] > 100 and cv["slam_loop"]["value"] > 0, cv
+    assert cv["duck_types_same_conditions"]["value"] > 0 and cv["answered_from"]["ahead"] > 0, cv
 
 
 def test_bench_self_launches_its_ranks():
