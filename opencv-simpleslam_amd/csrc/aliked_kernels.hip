@@ -48,19 +48,17 @@ __device__ __forceinline__ float selu(float x) {
 #endif
 }
 
-// SELU on ocml's expm1f (a polynomial + v_ldexp: no transcendental instruction): al_aggregate_kernel keeps it.  With the
-// hardware-exponential form IN THAT KERNEL, 1 / ||F|| came out wrong by 0.2 - 3 % on 16 consecutive pixels (one quarter of a
-// wave) about once in 150 frames when several extractor streams share the GPU - g1, s8 and every other kernel's output stayed
-// bit-stable (scripts/stress_aliked_repeat.py, r04: bisected over commits and call sites).  r05 narrowed it
-// (profiles/r05_aggregate_selu_hazard.md, scripts/ab_stress_aliked.sh with -DAL_AGG_FAST_SELU=<bits>): the channel LOOP on
-// v_exp_f32 is stable (0 of 1 440 frames); builds with the eight v_exp_f32 in the TAIL (the s8 outputs) reproduce it (3 - 5
-// events per 1 440 frames) - whatever the form of the norm behind them: moved in front, padded with idle cycles in front of or
-// behind v_sqrt / v_rcp, or made of FMAs only (scripts/ubench/r05_agg_norm_experiments.patch).  n2 does not change across the
-// exponentials and the norm is a consistent function of it: n2 is already slightly wrong when the tail begins.  The cheap
-// tail is a switch, not the place - it gives the compiler another schedule for the whole kernel, and that code shape is
-// sensitive to what else runs on the GPU.  Not explained beyond that: the kernel is not issue-bound (no time difference),
-// so it stays on the polynomial form - the code shape that is bit-stable in every stress run - and the concurrency stress
-// is a GPU test (test_extraction_is_deterministic_under_concurrency).
+// SELU on ocml's expm1f (a polynomial + v_ldexp: no transcendental instruction): al_aggregate_kernel keeps it.  History: with
+// the hardware-exponential form in that kernel's tail, 1 / ||F|| came out wrong by 0.2 - 4 % on 16 consecutive pixels about once
+// in 150 frames when other streams' kernels shared the GPU (r04: bisected over commits; r05: the exponentials are a switch, not
+// the place - profiles/r05_aggregate_selu_hazard.md).  r06 found the place (profiles/r06_aggregate_rnorm_diagnosis.md, section 5):
+// the cheap tail tipped the SLP vectoriser into pairing agg_level's bilinear coefficients as
+//     v_pk_mul_f32 v[32:33], v[14:15], v[12:13] op_sel:[0,1] op_sel_hi:[1,0]        ; (hy * lx, hx * ly)
+// and on gfx950 a packed fp32 instruction with op_sel = [0,1] and two different sources computes its LOW half with src1's high
+// half read as 0.0 in lanes 48..63, about once in 10^4 executions, while a wave of another kernel executes a wide-operand MFMA
+// on the same SIMD (scripts/ubench/pk_probe.hip reproduces it in a 60-line kernel).  The kernel now carries no packed fp32 at all
+// (AL_AGG_TARGET below) and build.py refuses any library that holds the form (isa_guard.py); the polynomial SELU stays because
+// the kernel is latency-bound (no time difference) and its outputs are the ones every golden hash was taken with.
 #ifndef AL_AGG_FAST_SELU
 #define AL_AGG_FAST_SELU 0
 #endif
@@ -1183,11 +1181,10 @@ __device__ __forceinline__ void agg_level(const float* __restrict__ pre, int n, 
 #endif
 // r06: NO packed-fp32 instructions in this kernel (AL_AGG_PACKED=1 lifts that, for the experiment scripts only).  Its one known
 // fault - 1 / ||F|| wrong by 0.2 - 4 % in lanes 48..63 of a wave, once per few hundred frames and only with other streams'
-// kernels on the GPU - is n2 missing exactly ONE gather's term of agg_level's quadratic form, and it needs the shape in which the
-// SLP vectoriser pairs those products into v_pk_mul_f32 / v_pk_fma_f32 on registers that global loads have just filled (147
-// packed instructions in the failing builds, 9 in the build that never failed, 0 events in 400 stress repeats with packing
-// off against 42 with it on; profiles/r06_aggregate_rnorm_diagnosis.md).  Which shape the compiler picks depended on an
-// unrelated detail (the exponential of the tail); the attribute takes the choice away from it.
+// kernels on the GPU - was n2 missing the D2 term of one level's quadratic form because its coefficient hy lx came out 0.0 of
+// `v_pk_mul_f32 ... op_sel:[0,1]` (see selu_precise above; bisected in the compiler's own assembly, one instruction at a time:
+// scripts/agg_isa_patch.py).  Whether the vectoriser forms that instruction depended on an unrelated detail (the exponential of
+// the tail); the attribute takes the choice away from it, and isa_guard.py checks every kernel of every build for the form.
 #ifndef AL_AGG_PACKED
 #define AL_AGG_PACKED 0
 #endif

@@ -34,7 +34,9 @@ def make_aggressor(AGGR, nat, W, ROOT):
         aggressor = lambda: [lg.match_dev(dev[0], dev[1], 1024, dev[2], dev[3], 1024, o_ij, o_sc, o_info, min_conf=0.1) for _ in range(3)]
     elif AGGR.startswith("synthetic:"):                            # scripts/ubench/aggressors.hip: ONE property each
         import ctypes
-        KIND = {"trans": 1, "mfma": 2, "pk": 3, "valu": 4, "lds": 5, "gather": 6, "store": 7, "scalar": 8, "ldsdma": 9}[AGGR.split(":")[1]]
+        KIND = {"trans": 1, "mfma": 2, "pk": 3, "valu": 4, "lds": 5, "gather": 6, "store": 7, "scalar": 8, "ldsdma": 9,
+                "mixlo": 10, "mixhi": 11, "sdwa": 12, "cvtpk": 13, "perm": 14, "permswap": 15, "bitop3": 16, "mov64": 17, "max3": 18, "pkmul_hi10": 19, "pkmul_01": 20, "pkfma_hi101": 21, "mfma16": 22, "cvtf16": 23, "fmamk": 24, "bfi": 25, "cmpabs": 26, "lshladd64": 27, "exp": 28, "pkmul": 30, "cvt_f16": 31, "shl64": 32, "insn_all": 40,
+                "mfma_16x16x32_f16": 50, "mfma_32x32x16_bf16": 51, "mfma_16x16x32_bf16": 52, "mfma_32x32x8_f16": 53, "mfma_16x16x16_f16": 54, "mfma_32x32x64_f8f6f4": 55, "mfma_32x32x2_f32": 56, "mfma_32x32x32_i8": 57, "mfma_32x32x16_fp8": 58, "mfma_16x16x128_f8f6f4": 59}[AGGR.split(":")[1]]
         so = ROOT / "scripts" / "ubench" / "libaggr.so"
         if not so.exists():
             import subprocess
@@ -42,7 +44,8 @@ def make_aggressor(AGGR, nat, W, ROOT):
                             str(ROOT / "scripts" / "ubench" / "aggressors.hip")], check=True)
         A = ctypes.CDLL(str(so))
         A.aggr_launch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
-        ITERS = {1: 6000, 2: 3000, 3: 12000, 4: 24000, 5: 6000, 6: 3000, 7: 3000, 8: 6000, 9: 3000}[KIND]
+        # (kinds >= 10: one instruction each in the form lg_attention_p_kernel uses it, four per loop iteration)
+        ITERS = {1: 6000, 2: 3000, 3: 12000, 4: 24000, 5: 6000, 6: 3000, 7: 3000, 8: 6000, 9: 3000, 22: 2000, 40: 1000}.get(KIND, 2000 if KIND >= 50 else 12000)
         # "synthetic:<kind>": 3 long launches of 1024 workgroups per two extractor calls; "synthetic:<kind>:<launches>:<blocks>:<iters>":
         # many short ones (kernel BOUNDARIES of another queue - dispatch-time cache invalidates, wave launches - beside the extractor)
         spec = AGGR.split(":")

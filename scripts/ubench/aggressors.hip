@@ -74,6 +74,74 @@ __global__ __launch_bounds__(256) void k_ldsdma(const float* __restrict__ tab, f
     if (acc == 123.456f) out[0] = acc;
 }
 
+
+// r06, section 5 of the diagnosis: ONE instruction each, in the very form lg_attention_p_kernel (the strongest trigger) uses it - which
+// instruction of another wave on the same SIMD makes `v_pk_mul_f32 ... op_sel:[0,1]` (scripts/ubench/pk_probe.hip) return 0.0 in
+// its last 16 lanes?  Registers are named outright (nothing is computed: the operands are whatever the registers hold).
+#define INSN_KERNEL(NAME, TEXT)                                                                                            \
+    __global__ __launch_bounds__(256) void NAME(float* out, int iters) {                                                   \
+        for (int i = 0; i < iters; ++i)                                                                                    \
+            asm volatile(TEXT "\n\t" TEXT "\n\t" TEXT "\n\t" TEXT ::: "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "s20", "s21");                                             \
+    }
+INSN_KERNEL(k_i_mixlo, "v_fma_mixlo_f16 v20, v10, -1.0, v11 op_sel_hi:[1,0,0]")
+INSN_KERNEL(k_i_mixhi, "v_fma_mixhi_f16 v20, v10, -1.0, v11 op_sel:[1,0,0] op_sel_hi:[1,0,0]")
+INSN_KERNEL(k_i_sdwa, "v_cvt_f32_f16_sdwa v20, v10 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1")
+INSN_KERNEL(k_i_cvtpk, "v_cvt_pk_f16_f32 v20, v10, v11")
+INSN_KERNEL(k_i_perm, "v_perm_b32 v20, v10, v11, v12")
+INSN_KERNEL(k_i_permswap, "v_permlane32_swap_b32_e32 v20, v21")
+INSN_KERNEL(k_i_bitop3, "v_bitop3_b32 v20, v10, v11, 7 bitop3:0x78")
+INSN_KERNEL(k_i_mov64, "v_mov_b64_e32 v[20:21], v[10:11]")
+INSN_KERNEL(k_i_max3, "v_max3_f32 v20, v10, v11, v12")
+INSN_KERNEL(k_i_pkmul_hi10, "v_pk_mul_f32 v[20:21], v[10:11], v[12:13] op_sel_hi:[1,0]")
+INSN_KERNEL(k_i_pkmul_01, "v_pk_mul_f32 v[20:21], v[10:11], v[12:13] op_sel:[0,1] op_sel_hi:[1,0]")
+INSN_KERNEL(k_i_pkfma_hi101, "v_pk_fma_f32 v[20:21], v[10:11], v[12:13], v[14:15] op_sel_hi:[1,0,1]")
+INSN_KERNEL(k_i_mfma16, "v_mfma_f32_32x32x16_f16 v[32:47], v[10:13], v[14:17], v[32:47]")
+INSN_KERNEL(k_i_cvtf16, "v_cvt_f32_f16_e32 v20, v10")
+INSN_KERNEL(k_i_fmamk, "v_fmamk_f32 v20, v10, 0x3a000000, v11")
+INSN_KERNEL(k_i_bfi, "v_bfi_b32 v20, v10, v11, v12")
+INSN_KERNEL(k_i_cmpabs, "v_cmp_nlg_f32_e64 s[20:21], |v10|, v11")
+INSN_KERNEL(k_i_lshladd64, "v_lshl_add_u64 v[20:21], v[10:11], 2, v[12:13]")
+INSN_KERNEL(k_i_exp, "v_exp_f32_e32 v20, v10")
+INSN_KERNEL(k_i_pkmul, "v_pk_mul_f32 v[20:21], v[10:11], v[12:13]")
+INSN_KERNEL(k_i_cvt_f16, "v_cvt_f16_f32_e32 v20, v10")
+INSN_KERNEL(k_i_shl64, "v_lshlrev_b64 v[20:21], 2, v[10:11]")
+// (which MFMA: the gfx950 double-K forms, the older ones, other types)
+INSN_KERNEL(k_i_mfma_16x16x32_f16, "v_mfma_f32_16x16x32_f16 v[32:35], v[10:13], v[14:17], v[32:35]")
+INSN_KERNEL(k_i_mfma_32x32x16_bf16, "v_mfma_f32_32x32x16_bf16 v[32:47], v[10:13], v[14:17], v[32:47]")
+INSN_KERNEL(k_i_mfma_16x16x32_bf16, "v_mfma_f32_16x16x32_bf16 v[32:35], v[10:13], v[14:17], v[32:35]")
+INSN_KERNEL(k_i_mfma_32x32x8_f16, "v_mfma_f32_32x32x8_f16 v[32:47], v[10:11], v[14:15], v[32:47]")
+INSN_KERNEL(k_i_mfma_16x16x16_f16, "v_mfma_f32_16x16x16_f16 v[32:35], v[10:11], v[14:15], v[32:35]")
+INSN_KERNEL(k_i_mfma_32x32x64_f8f6f4, "v_mfma_f32_32x32x64_f8f6f4 v[32:47], v[10:17], v[18:25], v[32:47]")
+INSN_KERNEL(k_i_mfma_32x32x2_f32, "v_mfma_f32_32x32x2_f32 v[32:47], v10, v11, v[32:47]")
+INSN_KERNEL(k_i_mfma_32x32x32_i8, "v_mfma_i32_32x32x32_i8 v[32:47], v[10:13], v[14:17], v[32:47]")
+INSN_KERNEL(k_i_mfma_32x32x16_fp8, "v_mfma_f32_32x32x16_fp8_fp8 v[32:47], v[10:11], v[14:15], v[32:47]")
+INSN_KERNEL(k_i_mfma_16x16x128_f8f6f4, "v_mfma_f32_16x16x128_f8f6f4 v[32:35], v[10:17], v[18:25], v[32:35]")
+__global__ __launch_bounds__(256) void k_i_all(float* out, int iters) {
+    for (int i = 0; i < iters; ++i)
+        asm volatile("v_fma_mixlo_f16 v20, v10, -1.0, v11 op_sel_hi:[1,0,0]" "\n\t"
+                     "v_fma_mixhi_f16 v20, v10, -1.0, v11 op_sel:[1,0,0] op_sel_hi:[1,0,0]" "\n\t"
+                     "v_cvt_f32_f16_sdwa v20, v10 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" "\n\t"
+                     "v_cvt_pk_f16_f32 v20, v10, v11" "\n\t"
+                     "v_perm_b32 v20, v10, v11, v12" "\n\t"
+                     "v_permlane32_swap_b32_e32 v20, v21" "\n\t"
+                     "v_bitop3_b32 v20, v10, v11, 7 bitop3:0x78" "\n\t"
+                     "v_mov_b64_e32 v[20:21], v[10:11]" "\n\t"
+                     "v_max3_f32 v20, v10, v11, v12" "\n\t"
+                     "v_pk_mul_f32 v[20:21], v[10:11], v[12:13] op_sel_hi:[1,0]" "\n\t"
+                     "v_pk_mul_f32 v[20:21], v[10:11], v[12:13] op_sel:[0,1] op_sel_hi:[1,0]" "\n\t"
+                     "v_pk_fma_f32 v[20:21], v[10:11], v[12:13], v[14:15] op_sel_hi:[1,0,1]" "\n\t"
+                     "v_mfma_f32_32x32x16_f16 v[32:47], v[10:13], v[14:17], v[32:47]" "\n\t"
+                     "v_cvt_f32_f16_e32 v20, v10" "\n\t"
+                     "v_fmamk_f32 v20, v10, 0x3a000000, v11" "\n\t"
+                     "v_bfi_b32 v20, v10, v11, v12" "\n\t"
+                     "v_cmp_nlg_f32_e64 s[20:21], |v10|, v11" "\n\t"
+                     "v_lshl_add_u64 v[20:21], v[10:11], 2, v[12:13]" "\n\t"
+                     "v_exp_f32_e32 v20, v10" "\n\t"
+                     "v_pk_mul_f32 v[20:21], v[10:11], v[12:13]" "\n\t"
+                     "v_cvt_f16_f32_e32 v20, v10" "\n\t"
+                     "v_lshlrev_b64 v[20:21], 2, v[10:11]" ::: "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "s20", "s21");
+}
+
 static float* g_buf = nullptr;
 extern "C" int aggr_launch(int kind, void* stream, int blocks, int iters) {
     hipStream_t s = (hipStream_t)stream;
@@ -89,6 +157,39 @@ extern "C" int aggr_launch(int kind, void* stream, int blocks, int iters) {
         case 7: hipLaunchKernelGGL(k_store, dim3(blocks), dim3(256), 0, s, g_buf, iters, (1u << 20) - 1); break;
         case 8: hipLaunchKernelGGL(k_scalar, dim3(blocks), dim3(256), 0, s, (const int*)g_buf, out, iters); break;
         case 9: hipLaunchKernelGGL(k_ldsdma, dim3(blocks), dim3(256), 32768, s, g_buf, out, iters, (1u << 20) - 1); break;
+        case 10: hipLaunchKernelGGL(k_i_mixlo, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 11: hipLaunchKernelGGL(k_i_mixhi, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 12: hipLaunchKernelGGL(k_i_sdwa, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 13: hipLaunchKernelGGL(k_i_cvtpk, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 14: hipLaunchKernelGGL(k_i_perm, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 15: hipLaunchKernelGGL(k_i_permswap, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 16: hipLaunchKernelGGL(k_i_bitop3, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 17: hipLaunchKernelGGL(k_i_mov64, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 18: hipLaunchKernelGGL(k_i_max3, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 19: hipLaunchKernelGGL(k_i_pkmul_hi10, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 20: hipLaunchKernelGGL(k_i_pkmul_01, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 21: hipLaunchKernelGGL(k_i_pkfma_hi101, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 22: hipLaunchKernelGGL(k_i_mfma16, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 23: hipLaunchKernelGGL(k_i_cvtf16, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 24: hipLaunchKernelGGL(k_i_fmamk, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 25: hipLaunchKernelGGL(k_i_bfi, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 26: hipLaunchKernelGGL(k_i_cmpabs, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 27: hipLaunchKernelGGL(k_i_lshladd64, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 28: hipLaunchKernelGGL(k_i_exp, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 30: hipLaunchKernelGGL(k_i_pkmul, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 31: hipLaunchKernelGGL(k_i_cvt_f16, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 32: hipLaunchKernelGGL(k_i_shl64, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 50: hipLaunchKernelGGL(k_i_mfma_16x16x32_f16, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 51: hipLaunchKernelGGL(k_i_mfma_32x32x16_bf16, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 52: hipLaunchKernelGGL(k_i_mfma_16x16x32_bf16, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 53: hipLaunchKernelGGL(k_i_mfma_32x32x8_f16, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 54: hipLaunchKernelGGL(k_i_mfma_16x16x16_f16, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 55: hipLaunchKernelGGL(k_i_mfma_32x32x64_f8f6f4, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 56: hipLaunchKernelGGL(k_i_mfma_32x32x2_f32, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 57: hipLaunchKernelGGL(k_i_mfma_32x32x32_i8, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 58: hipLaunchKernelGGL(k_i_mfma_32x32x16_fp8, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 59: hipLaunchKernelGGL(k_i_mfma_16x16x128_f8f6f4, dim3(blocks), dim3(256), 0, s, out, iters); break;
+        case 40: hipLaunchKernelGGL(k_i_all, dim3(blocks), dim3(256), 0, s, out, iters); break;
         default: return 2;
     }
     return hipGetLastError() == hipSuccess ? 0 : 3;
