@@ -1,14 +1,18 @@
-// pk_probe.hip - ONE instruction as the victim: v_pk_mul_f32 with op_sel:[0,1] (low result = src0.lo x src1.HI).
+// pk_probe.hip - ONE instruction as the victim: v_pk_{mul,add,fma}_f32 under every op_sel / op_sel_hi.
 //
 // profiles/r06_aggregate_rnorm_diagnosis.md section 5 bisected the one fault of al_aggregate_kernel's packed-fp32 shape, in the
 // compiler's own assembly, to a single instruction - `v_pk_mul_f32 v[32:33], v[14:15], v[12:13] op_sel:[0,1] op_sel_hi:[1,0]` - whose LOW
-// result is exactly 0.0 in lanes 48..63 about once per 10^4 wave executions while lg_attention_p_kernel runs on another queue; of
-// the 16 op_sel / op_sel_hi combinations exactly the four with op_sel = [0,1] fail, always in the low half.  This file takes the
-// instruction out of that kernel: a loop of it in inline assembly on lane-dependent operands, each result checked against
-// single-width multiplies, with the same C entry points as agg_victim.hip so that scripts/agg_victim_run.py drives it beside
-// the same aggressors.  MODE (victim_create's `F` argument): index into a generated table - every op_sel of v_pk_mul_f32, v_pk_add_f32
-// and v_pk_fma_f32, each with op_sel_hi straight and [1,0,..], and the same-source horizontal add (victim_mode_text(m) names it);
-// +256: a global load per iteration in front of the instruction.
+// result is exactly 0.0 in lanes 48..63 about once per 10^4 wave executions while a kernel built on wide-operand MFMAs runs on
+// another queue.  This file takes the instruction out of that kernel: a loop of it in inline assembly on lane-dependent operands
+// in [0.5, 1.5), each half of each result checked against a single-width instruction on the same registers, with the same C
+// entry points as agg_victim.hip so that scripts/agg_victim_run.py drives it beside the same aggressors (scripts/pk_probe_run.sh).
+// MODE (victim_create's `F` argument; victim_mode_text(m) names it):
+//     0 ..  15   v_pk_mul_f32  op_sel:[a,b]   op_sel_hi:[c,d]        m = 8a + 4b + 2c + d
+//    16 ..  31   v_pk_add_f32  the same
+//    32 ..  95   v_pk_fma_f32  op_sel:[a,b,e] op_sel_hi:[c,d,f]      m = 32 + 32a + 16b + 8e + 4c + 2d + f
+//    96          v_pk_add_f32 D, A, A op_sel:[0,1] op_sel_hi:[1,0]   (same-source horizontal add: the one instance in the product)
+//    97          v_pk_mul_f32 D, A, A op_sel:[0,1] op_sel_hi:[1,0]
+//    +256        a global load per iteration in front of the instruction
 //   hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -shared -o scripts/ubench/libpkprobe.so scripts/ubench/pk_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -20,10 +24,51 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct Probe { unsigned* bad; float* tab; int mode; };
 
+#define COMBOS2(X) X(0,0,0,0) X(0,0,0,1) X(0,0,1,0) X(0,0,1,1) X(0,1,0,0) X(0,1,0,1) X(0,1,1,0) X(0,1,1,1) X(1,0,0,0) X(1,0,0,1) X(1,0,1,0) X(1,0,1,1) X(1,1,0,0) X(1,1,0,1) X(1,1,1,0) X(1,1,1,1)
+#define COMBOS3(X) X(0,0,0,0,0,0) X(0,0,0,0,0,1) X(0,0,0,0,1,0) X(0,0,0,0,1,1) X(0,0,0,1,0,0) X(0,0,0,1,0,1) X(0,0,0,1,1,0) X(0,0,0,1,1,1) X(0,0,1,0,0,0) X(0,0,1,0,0,1) X(0,0,1,0,1,0) X(0,0,1,0,1,1) X(0,0,1,1,0,0) X(0,0,1,1,0,1) X(0,0,1,1,1,0) X(0,0,1,1,1,1) X(0,1,0,0,0,0) X(0,1,0,0,0,1) X(0,1,0,0,1,0) X(0,1,0,0,1,1) X(0,1,0,1,0,0) X(0,1,0,1,0,1) X(0,1,0,1,1,0) X(0,1,0,1,1,1) X(0,1,1,0,0,0) X(0,1,1,0,0,1) X(0,1,1,0,1,0) X(0,1,1,0,1,1) X(0,1,1,1,0,0) X(0,1,1,1,0,1) X(0,1,1,1,1,0) X(0,1,1,1,1,1) X(1,0,0,0,0,0) X(1,0,0,0,0,1) X(1,0,0,0,1,0) X(1,0,0,0,1,1) X(1,0,0,1,0,0) X(1,0,0,1,0,1) X(1,0,0,1,1,0) X(1,0,0,1,1,1) X(1,0,1,0,0,0) X(1,0,1,0,0,1) X(1,0,1,0,1,0) X(1,0,1,0,1,1) X(1,0,1,1,0,0) X(1,0,1,1,0,1) X(1,0,1,1,1,0) X(1,0,1,1,1,1) X(1,1,0,0,0,0) X(1,1,0,0,0,1) X(1,1,0,0,1,0) X(1,1,0,0,1,1) X(1,1,0,1,0,0) X(1,1,0,1,0,1) X(1,1,0,1,1,0) X(1,1,0,1,1,1) X(1,1,1,0,0,0) X(1,1,1,0,0,1) X(1,1,1,0,1,0) X(1,1,1,0,1,1) X(1,1,1,1,0,0) X(1,1,1,1,0,1) X(1,1,1,1,1,0) X(1,1,1,1,1,1)
+
+__device__ __forceinline__ float pick(f32x2 v, int hi) { return hi ? v.y : v.x; }
+
+// one packed instruction and the two single-width ones it must agree with; OP: 0 mul, 1 add, 2 fma
+template <int OP, int A, int B, int E, int C, int D, int F>
+__device__ __forceinline__ void pk_and_expected(f32x2 a, f32x2 b, f32x2 c, f32x2& d, float& elo, float& ehi);
+
+#define X(A, B, C, D)                                                                                                         \
+    template <> __device__ __forceinline__ void pk_and_expected<0, A, B, 0, C, D, 1>(f32x2 a, f32x2 b, f32x2, f32x2& d, float& elo, float& ehi) { \
+        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[" #A "," #B "] op_sel_hi:[" #C "," #D "]" : "=v"(d) : "v"(a), "v"(b));     \
+        asm volatile("s_nop 1\n\tv_mul_f32 %0, %1, %2" : "=v"(elo) : "v"(pick(a, A)), "v"(pick(b, B)));                          \
+        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(ehi) : "v"(pick(a, C)), "v"(pick(b, D)));                                     \
+    }                                                                                                                         \
+    template <> __device__ __forceinline__ void pk_and_expected<1, A, B, 0, C, D, 1>(f32x2 a, f32x2 b, f32x2, f32x2& d, float& elo, float& ehi) { \
+        asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[" #A "," #B "] op_sel_hi:[" #C "," #D "]" : "=v"(d) : "v"(a), "v"(b));     \
+        asm volatile("s_nop 1\n\tv_add_f32 %0, %1, %2" : "=v"(elo) : "v"(pick(a, A)), "v"(pick(b, B)));                          \
+        asm volatile("v_add_f32 %0, %1, %2" : "=v"(ehi) : "v"(pick(a, C)), "v"(pick(b, D)));                                     \
+    }
+COMBOS2(X)
+#undef X
+#define X(A, B, E, C, D, F)                                                                                                   \
+    template <> __device__ __forceinline__ void pk_and_expected<2, A, B, E, C, D, F>(f32x2 a, f32x2 b, f32x2 c, f32x2& d, float& elo, float& ehi) { \
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[" #A "," #B "," #E "] op_sel_hi:[" #C "," #D "," #F "]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); \
+        asm volatile("s_nop 1\n\tv_fma_f32 %0, %1, %2, %3" : "=v"(elo) : "v"(pick(a, A)), "v"(pick(b, B)), "v"(pick(c, E)));     \
+        asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(ehi) : "v"(pick(a, C)), "v"(pick(b, D)), "v"(pick(c, F)));                \
+    }
+COMBOS3(X)
+#undef X
+// same-source forms (OP 3: add, 4: mul)
+template <> __device__ __forceinline__ void pk_and_expected<3, 0, 1, 0, 1, 0, 1>(f32x2 a, f32x2, f32x2, f32x2& d, float& elo, float& ehi) {
+    asm volatile("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(a));
+    asm volatile("s_nop 1\n\tv_add_f32 %0, %1, %2" : "=v"(elo) : "v"(a.x), "v"(a.y));
+    asm volatile("v_add_f32 %0, %1, %2" : "=v"(ehi) : "v"(a.y), "v"(a.x));
+}
+template <> __device__ __forceinline__ void pk_and_expected<4, 0, 1, 0, 1, 0, 1>(f32x2 a, f32x2, f32x2, f32x2& d, float& elo, float& ehi) {
+    asm volatile("v_pk_mul_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(a));
+    asm volatile("s_nop 1\n\tv_mul_f32 %0, %1, %2" : "=v"(elo) : "v"(a.x), "v"(a.y));
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(ehi) : "v"(a.y), "v"(a.x));
+}
+
 // bad[0] low-half mismatches, bad[1] high-half mismatches; bad[4 + 4k ...]: first events - (lane | half << 8 | block << 16), got,
-// expected, launch.  MODE: index into the table below (generated: every op_sel of v_pk_mul / add / fma_f32, op_sel_hi straight and
-// [1,0,..]); LOADS: a global load per iteration in front of the instruction.
-template <int MODE, bool LOADS>
+// expected, launch
+template <int OP, int A, int B, int E, int C, int D, int F, bool LOADS>
 __global__ __launch_bounds__(256) void pk_probe_kernel(unsigned* __restrict__ bad, const float* __restrict__ tab, int iters, unsigned launch) {
     const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
     // operands in [0.5, 1.5): every product and sum is a normal, non-zero number
@@ -35,171 +80,7 @@ __global__ __launch_bounds__(256) void pk_probe_kernel(unsigned* __restrict__ ba
         if (LOADS) b.x = 0.5f + tab[(tid * 31u + (unsigned)it * 977u) & 0xfffffu];     // (values in [0, 1))
         f32x2 d;
         float elo, ehi;
-        if (MODE == 0) {
-            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(b));
-            asm volatile("s_nop 1\n\tv_mul_f32 %0, %1, %2" : "=v"(elo) : "v"(a.x), "v"(b.x));
-            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(ehi) : "v"(a.y), "v"(b.y));
-        }
-        if (MODE == 1) {
-            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
-            asm volatile("s_nop 1\n\tv_mul_f32 %0, %1, %2" : "=v"(elo) : "v"(a.x), "v"(b.x));
-            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(ehi) : "v"(a.y), "v"(b.x));
-        }
-        if (MODE == 2) {
-            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(b));
-            asm volatile("s_nop 1\n\tv_mul_f32 %0, %1, %2" : "=v"(elo) : "v"(a.y), "v"(b.x));
-            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(ehi) : "v"(a.y), "v"(b.y));
-        }
-        if (MODE == 3) {
-            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
-            asm volatile("s_nop 1\n\tv_mul_f32 %0, %1, %2" : "=v"(elo) : "v"(a.y), "v"(b.x));
-            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(ehi) : "v"(a.y), "v"(b.x));
-        }
-        if (MODE == 4) {
-            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(b));
-            asm volatile("s_nop 1\n\tv_mul_f32 %0, %1, %2" : "=v"(elo) : "v"(a.x), "v"(b.y));
-            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(ehi) : "v"(a.y), "v"(b.y));
-        }
-        if (MODE == 5) {
-            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
-            asm volatile("s_nop 1\n\tv_mul_f32 %0, %1, %2" : "=v"(elo) : "v"(a.x), "v"(b.y));
-            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(ehi) : "v"(a.y), "v"(b.x));
-        }
-        if (MODE == 6) {
-            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(b));
-            asm volatile("s_nop 1\n\tv_mul_f32 %0, %1, %2" : "=v"(elo) : "v"(a.y), "v"(b.y));
-            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(ehi) : "v"(a.y), "v"(b.y));
-        }
-        if (MODE == 7) {
-            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
-            asm volatile("s_nop 1\n\tv_mul_f32 %0, %1, %2" : "=v"(elo) : "v"(a.y), "v"(b.y));
-            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(ehi) : "v"(a.y), "v"(b.x));
-        }
-        if (MODE == 8) {
-            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(b));
-            asm volatile("s_nop 1\n\tv_add_f32 %0, %1, %2" : "=v"(elo) : "v"(a.x), "v"(b.x));
-            asm volatile("v_add_f32 %0, %1, %2" : "=v"(ehi) : "v"(a.y), "v"(b.y));
-        }
-        if (MODE == 9) {
-            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
-            asm volatile("s_nop 1\n\tv_add_f32 %0, %1, %2" : "=v"(elo) : "v"(a.x), "v"(b.x));
-            asm volatile("v_add_f32 %0, %1, %2" : "=v"(ehi) : "v"(a.y), "v"(b.x));
-        }
-        if (MODE == 10) {
-            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(b));
-            asm volatile("s_nop 1\n\tv_add_f32 %0, %1, %2" : "=v"(elo) : "v"(a.y), "v"(b.x));
-            asm volatile("v_add_f32 %0, %1, %2" : "=v"(ehi) : "v"(a.y), "v"(b.y));
-        }
-        if (MODE == 11) {
-            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
-            asm volatile("s_nop 1\n\tv_add_f32 %0, %1, %2" : "=v"(elo) : "v"(a.y), "v"(b.x));
-            asm volatile("v_add_f32 %0, %1, %2" : "=v"(ehi) : "v"(a.y), "v"(b.x));
-        }
-        if (MODE == 12) {
-            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(b));
-            asm volatile("s_nop 1\n\tv_add_f32 %0, %1, %2" : "=v"(elo) : "v"(a.x), "v"(b.y));
-            asm volatile("v_add_f32 %0, %1, %2" : "=v"(ehi) : "v"(a.y), "v"(b.y));
-        }
-        if (MODE == 13) {
-            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
-            asm volatile("s_nop 1\n\tv_add_f32 %0, %1, %2" : "=v"(elo) : "v"(a.x), "v"(b.y));
-            asm volatile("v_add_f32 %0, %1, %2" : "=v"(ehi) : "v"(a.y), "v"(b.x));
-        }
-        if (MODE == 14) {
-            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(b));
-            asm volatile("s_nop 1\n\tv_add_f32 %0, %1, %2" : "=v"(elo) : "v"(a.y), "v"(b.y));
-            asm volatile("v_add_f32 %0, %1, %2" : "=v"(ehi) : "v"(a.y), "v"(b.y));
-        }
-        if (MODE == 15) {
-            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
-            asm volatile("s_nop 1\n\tv_add_f32 %0, %1, %2" : "=v"(elo) : "v"(a.y), "v"(b.y));
-            asm volatile("v_add_f32 %0, %1, %2" : "=v"(ehi) : "v"(a.y), "v"(b.x));
-        }
-        if (MODE == 16) {
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-            asm volatile("s_nop 1\n\tv_fma_f32 %0, %1, %2, %3" : "=v"(elo) : "v"(a.x), "v"(b.x), "v"(c.x));
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(ehi) : "v"(a.y), "v"(b.y), "v"(c.y));
-        }
-        if (MODE == 17) {
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-            asm volatile("s_nop 1\n\tv_fma_f32 %0, %1, %2, %3" : "=v"(elo) : "v"(a.x), "v"(b.x), "v"(c.x));
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(ehi) : "v"(a.y), "v"(b.x), "v"(c.y));
-        }
-        if (MODE == 18) {
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-            asm volatile("s_nop 1\n\tv_fma_f32 %0, %1, %2, %3" : "=v"(elo) : "v"(a.y), "v"(b.x), "v"(c.x));
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(ehi) : "v"(a.y), "v"(b.y), "v"(c.y));
-        }
-        if (MODE == 19) {
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-            asm volatile("s_nop 1\n\tv_fma_f32 %0, %1, %2, %3" : "=v"(elo) : "v"(a.y), "v"(b.x), "v"(c.x));
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(ehi) : "v"(a.y), "v"(b.x), "v"(c.y));
-        }
-        if (MODE == 20) {
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-            asm volatile("s_nop 1\n\tv_fma_f32 %0, %1, %2, %3" : "=v"(elo) : "v"(a.x), "v"(b.y), "v"(c.x));
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(ehi) : "v"(a.y), "v"(b.y), "v"(c.y));
-        }
-        if (MODE == 21) {
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-            asm volatile("s_nop 1\n\tv_fma_f32 %0, %1, %2, %3" : "=v"(elo) : "v"(a.x), "v"(b.y), "v"(c.x));
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(ehi) : "v"(a.y), "v"(b.x), "v"(c.y));
-        }
-        if (MODE == 22) {
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-            asm volatile("s_nop 1\n\tv_fma_f32 %0, %1, %2, %3" : "=v"(elo) : "v"(a.y), "v"(b.y), "v"(c.x));
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(ehi) : "v"(a.y), "v"(b.y), "v"(c.y));
-        }
-        if (MODE == 23) {
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-            asm volatile("s_nop 1\n\tv_fma_f32 %0, %1, %2, %3" : "=v"(elo) : "v"(a.y), "v"(b.y), "v"(c.x));
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(ehi) : "v"(a.y), "v"(b.x), "v"(c.y));
-        }
-        if (MODE == 24) {
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-            asm volatile("s_nop 1\n\tv_fma_f32 %0, %1, %2, %3" : "=v"(elo) : "v"(a.x), "v"(b.x), "v"(c.y));
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(ehi) : "v"(a.y), "v"(b.y), "v"(c.y));
-        }
-        if (MODE == 25) {
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-            asm volatile("s_nop 1\n\tv_fma_f32 %0, %1, %2, %3" : "=v"(elo) : "v"(a.x), "v"(b.x), "v"(c.y));
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(ehi) : "v"(a.y), "v"(b.x), "v"(c.y));
-        }
-        if (MODE == 26) {
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-            asm volatile("s_nop 1\n\tv_fma_f32 %0, %1, %2, %3" : "=v"(elo) : "v"(a.y), "v"(b.x), "v"(c.y));
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(ehi) : "v"(a.y), "v"(b.y), "v"(c.y));
-        }
-        if (MODE == 27) {
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-            asm volatile("s_nop 1\n\tv_fma_f32 %0, %1, %2, %3" : "=v"(elo) : "v"(a.y), "v"(b.x), "v"(c.y));
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(ehi) : "v"(a.y), "v"(b.x), "v"(c.y));
-        }
-        if (MODE == 28) {
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-            asm volatile("s_nop 1\n\tv_fma_f32 %0, %1, %2, %3" : "=v"(elo) : "v"(a.x), "v"(b.y), "v"(c.y));
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(ehi) : "v"(a.y), "v"(b.y), "v"(c.y));
-        }
-        if (MODE == 29) {
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-            asm volatile("s_nop 1\n\tv_fma_f32 %0, %1, %2, %3" : "=v"(elo) : "v"(a.x), "v"(b.y), "v"(c.y));
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(ehi) : "v"(a.y), "v"(b.x), "v"(c.y));
-        }
-        if (MODE == 30) {
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,1] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-            asm volatile("s_nop 1\n\tv_fma_f32 %0, %1, %2, %3" : "=v"(elo) : "v"(a.y), "v"(b.y), "v"(c.y));
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(ehi) : "v"(a.y), "v"(b.y), "v"(c.y));
-        }
-        if (MODE == 31) {
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-            asm volatile("s_nop 1\n\tv_fma_f32 %0, %1, %2, %3" : "=v"(elo) : "v"(a.y), "v"(b.y), "v"(c.y));
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(ehi) : "v"(a.y), "v"(b.x), "v"(c.y));
-        }
-        if (MODE == 32) {
-            asm volatile("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(a));
-            asm volatile("s_nop 1\n\tv_add_f32 %0, %1, %2" : "=v"(elo) : "v"(a.x), "v"(a.y));
-            asm volatile("v_add_f32 %0, %1, %2" : "=v"(ehi) : "v"(a.y), "v"(a.x));
-        }
+        pk_and_expected<OP, A, B, E, C, D, F>(a, b, c, d, elo, ehi);
         asm volatile("s_nop 1" : "+v"(d));                    // (a result written with op_sel needs a wait state in front of its reader)
         if (d.x != elo || d.y != ehi) {
             const int half = d.x != elo ? 0 : 1;
@@ -217,42 +98,13 @@ __global__ __launch_bounds__(256) void pk_probe_kernel(unsigned* __restrict__ ba
     if (nhi) atomicAdd(&bad[1], nhi);
 }
 
-const char* const MODE_TEXT[] = {
-    "v_pk_mul_f32 A, B op_sel:[0,0] op_sel_hi:[1,1]",
-    "v_pk_mul_f32 A, B op_sel:[0,0] op_sel_hi:[1,0]",
-    "v_pk_mul_f32 A, B op_sel:[1,0] op_sel_hi:[1,1]",
-    "v_pk_mul_f32 A, B op_sel:[1,0] op_sel_hi:[1,0]",
-    "v_pk_mul_f32 A, B op_sel:[0,1] op_sel_hi:[1,1]",
-    "v_pk_mul_f32 A, B op_sel:[0,1] op_sel_hi:[1,0]",
-    "v_pk_mul_f32 A, B op_sel:[1,1] op_sel_hi:[1,1]",
-    "v_pk_mul_f32 A, B op_sel:[1,1] op_sel_hi:[1,0]",
-    "v_pk_add_f32 A, B op_sel:[0,0] op_sel_hi:[1,1]",
-    "v_pk_add_f32 A, B op_sel:[0,0] op_sel_hi:[1,0]",
-    "v_pk_add_f32 A, B op_sel:[1,0] op_sel_hi:[1,1]",
-    "v_pk_add_f32 A, B op_sel:[1,0] op_sel_hi:[1,0]",
-    "v_pk_add_f32 A, B op_sel:[0,1] op_sel_hi:[1,1]",
-    "v_pk_add_f32 A, B op_sel:[0,1] op_sel_hi:[1,0]",
-    "v_pk_add_f32 A, B op_sel:[1,1] op_sel_hi:[1,1]",
-    "v_pk_add_f32 A, B op_sel:[1,1] op_sel_hi:[1,0]",
-    "v_pk_fma_f32 A, B, C op_sel:[0,0,0] op_sel_hi:[1,1,1]",
-    "v_pk_fma_f32 A, B, C op_sel:[0,0,0] op_sel_hi:[1,0,1]",
-    "v_pk_fma_f32 A, B, C op_sel:[1,0,0] op_sel_hi:[1,1,1]",
-    "v_pk_fma_f32 A, B, C op_sel:[1,0,0] op_sel_hi:[1,0,1]",
-    "v_pk_fma_f32 A, B, C op_sel:[0,1,0] op_sel_hi:[1,1,1]",
-    "v_pk_fma_f32 A, B, C op_sel:[0,1,0] op_sel_hi:[1,0,1]",
-    "v_pk_fma_f32 A, B, C op_sel:[1,1,0] op_sel_hi:[1,1,1]",
-    "v_pk_fma_f32 A, B, C op_sel:[1,1,0] op_sel_hi:[1,0,1]",
-    "v_pk_fma_f32 A, B, C op_sel:[0,0,1] op_sel_hi:[1,1,1]",
-    "v_pk_fma_f32 A, B, C op_sel:[0,0,1] op_sel_hi:[1,0,1]",
-    "v_pk_fma_f32 A, B, C op_sel:[1,0,1] op_sel_hi:[1,1,1]",
-    "v_pk_fma_f32 A, B, C op_sel:[1,0,1] op_sel_hi:[1,0,1]",
-    "v_pk_fma_f32 A, B, C op_sel:[0,1,1] op_sel_hi:[1,1,1]",
-    "v_pk_fma_f32 A, B, C op_sel:[0,1,1] op_sel_hi:[1,0,1]",
-    "v_pk_fma_f32 A, B, C op_sel:[1,1,1] op_sel_hi:[1,1,1]",
-    "v_pk_fma_f32 A, B, C op_sel:[1,1,1] op_sel_hi:[1,0,1]",
-    "v_pk_add_f32 A, A op_sel:[0,1] op_sel_hi:[1,0]",
-};
-constexpr int N_MODES = 33;
+template <int OP, int A, int B, int E, int C, int D, int F>
+void launch_one(Probe* p, hipStream_t s, bool loads, unsigned launch) {
+    if (loads) hipLaunchKernelGGL((pk_probe_kernel<OP, A, B, E, C, D, F, true>), dim3(2048), dim3(256), 0, s, p->bad, p->tab, 256, launch);
+    else hipLaunchKernelGGL((pk_probe_kernel<OP, A, B, E, C, D, F, false>), dim3(2048), dim3(256), 0, s, p->bad, p->tab, 256, launch);
+}
+
+constexpr int N_MODES = 98;
 
 }  // namespace
 
@@ -262,12 +114,12 @@ void* victim_create(int, int, int mode, unsigned) {
     Probe* p = new Probe();
     p->mode = mode;
     if (hipMalloc(&p->bad, 64 * sizeof(unsigned)) != hipSuccess) return nullptr;
-    hipMemset(p->bad, 0, 64 * sizeof(unsigned));
+    (void)hipMemset(p->bad, 0, 64 * sizeof(unsigned));
     std::vector<float> h(1u << 20);
     unsigned s = 12345u;
     for (auto& x : h) { s = s * 1664525u + 1013904223u; x = (float)(s >> 8) * (1.0f / 16777216.0f); }
     if (hipMalloc(&p->tab, h.size() * sizeof(float)) != hipSuccess) return nullptr;
-    hipMemcpy(p->tab, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
+    (void)hipMemcpy(p->tab, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
     return p;
 }
 
@@ -276,16 +128,22 @@ int victim_run(void* h, void* stream, int iters, int) {
     Probe* p = (Probe*)h;
     hipStream_t s = (hipStream_t)stream;
     static unsigned launch = 0;
+    const int m = p->mode & 0xff; const bool loads = (p->mode >> 8) & 1;
     for (int i = 0; i < iters; ++i) {
         ++launch;
-        const int m = p->mode & 0xff; const bool loads = (p->mode >> 8) & 1;
-        switch (m) {
-#define L(M) case M: if (loads) hipLaunchKernelGGL((pk_probe_kernel<M, true>), dim3(2048), dim3(256), 0, s, p->bad, p->tab, 256, launch); \
-                     else hipLaunchKernelGGL((pk_probe_kernel<M, false>), dim3(2048), dim3(256), 0, s, p->bad, p->tab, 256, launch); break;
-            L(0) L(1) L(2) L(3) L(4) L(5) L(6) L(7) L(8) L(9) L(10) L(11) L(12) L(13) L(14) L(15) L(16) L(17) L(18) L(19) L(20) L(21) L(22) L(23) L(24) L(25) L(26) L(27) L(28) L(29) L(30) L(31) L(32)
-#undef L
-            default: return -3;
-        }
+        bool done = false;
+#define X(A, B, C, D)                                                                                          \
+        if (m == 8 * A + 4 * B + 2 * C + D) { launch_one<0, A, B, 0, C, D, 1>(p, s, loads, launch); done = true; }       \
+        if (m == 16 + 8 * A + 4 * B + 2 * C + D) { launch_one<1, A, B, 0, C, D, 1>(p, s, loads, launch); done = true; }
+        COMBOS2(X)
+#undef X
+#define X(A, B, E, C, D, F)                                                                                    \
+        if (m == 32 + 32 * A + 16 * B + 8 * E + 4 * C + 2 * D + F) { launch_one<2, A, B, E, C, D, F>(p, s, loads, launch); done = true; }
+        COMBOS3(X)
+#undef X
+        if (m == 96) { launch_one<3, 0, 1, 0, 1, 0, 1>(p, s, loads, launch); done = true; }
+        if (m == 97) { launch_one<4, 0, 1, 0, 1, 0, 1>(p, s, loads, launch); done = true; }
+        if (!done) return -3;
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -297,7 +155,15 @@ int victim_poll(void* h, void* stream, unsigned* out64) {
 }
 
 // the instruction of mode m (A, B, C: the three operand pairs), or nullptr
-const char* victim_mode_text(int m) { return m >= 0 && m < N_MODES ? MODE_TEXT[m] : nullptr; }
+const char* victim_mode_text(int m) {
+    static char buf[128];
+    if (m < 0 || m >= N_MODES) return nullptr;
+    if (m == 96) return "v_pk_add_f32 D, A, A op_sel:[0,1] op_sel_hi:[1,0]";
+    if (m == 97) return "v_pk_mul_f32 D, A, A op_sel:[0,1] op_sel_hi:[1,0]";
+    if (m < 32) snprintf(buf, sizeof buf, "v_pk_%s_f32 D, A, B op_sel:[%d,%d] op_sel_hi:[%d,%d]", m < 16 ? "mul" : "add", (m >> 3) & 1, (m >> 2) & 1, (m >> 1) & 1, m & 1);
+    else { const int k = m - 32; snprintf(buf, sizeof buf, "v_pk_fma_f32 D, A, B, C op_sel:[%d,%d,%d] op_sel_hi:[%d,%d,%d]", (k >> 5) & 1, (k >> 4) & 1, (k >> 3) & 1, (k >> 2) & 1, (k >> 1) & 1, k & 1); }
+    return buf;
+}
 
 void victim_destroy(void* h) {
     Probe* p = (Probe*)h;
