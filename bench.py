@@ -680,6 +680,7 @@ def main():
     # exchanged through the host (frame_shard.GlooRowsComm).
     backend = os.environ.get("SSLAM_DIST_BACKEND", "rccl")
     comm = None
+    rccl_fallback = None
     if distributed:
         if backend not in ("rccl", "gloo"):
             raise SystemExit(f"SSLAM_DIST_BACKEND={backend!r}: 'rccl' (default) or 'gloo' (ranks sharing a GPU, tests)")
@@ -700,8 +701,32 @@ def main():
                 box = [payload]
                 dist.broadcast_object_list(box, src=0)
                 return box[0]
-            comm = rccl.RcclComm.create(rank, world, _exchange)
-        else:
+
+            def _all_agree(err):                 # every rank takes the same branch: one rank's failure is everybody's
+                flags = [None] * world
+                dist.all_gather_object(flags, err)
+                return next((f"rank {r}: {e}" for r, e in enumerate(flags) if e), None)
+            try:
+                rccl.lib()
+                err = None
+            except Exception as e:               # (librccl.so missing / not loadable on this node)
+                err = repr(e)
+            rccl_fallback = _all_agree(err)
+            if rccl_fallback is None:
+                try:
+                    comm = rccl.RcclComm.create(rank, world, _exchange)
+                    err = None
+                except Exception as e:
+                    err = repr(e)
+                rccl_fallback = _all_agree(err)
+            if rccl_fallback is not None:
+                # never lose the scaling line to the collation transport: the exchange is two 100-KB gathers per round, the
+                # frames shard with no data-path collective either way; the JSON line says which transport ran and why
+                if rank == 0:
+                    print(f"[bench] RCCL communicator not available ({rccl_fallback}); collation through the host over gloo", file=sys.stderr, flush=True)
+                backend = "gloo"
+                comm = None
+        if backend == "gloo":
             comm = importlib.import_module("opencv-simpleslam_amd.frame_shard").GlooRowsComm(rank, world)
 
     pkg = importlib.import_module("opencv-simpleslam_amd")
@@ -1081,7 +1106,8 @@ def main():
                                          if distributed else ""),
                        # N > 1: the size of the communicator the collation ran on, as the communicator reports it
                        "rccl_ranks": (comm.count() if distributed and backend == "rccl" else None),
-                       "collation_backend": (("rccl (direct)" if backend == "rccl" else "gloo (host round trip, test mode)") if distributed else None)},
+                       "collation_backend": (("rccl (direct)" if backend == "rccl" else
+                                              "gloo (host round trip" + (f"; RCCL not available: {rccl_fallback})" if rccl_fallback else ", test mode)")) if distributed else None)},
             # achieved = ALGORITHMIC flops (8 n0 n1 256 per pair, x pairs per launch) / HIP-event launch
             # duration on an otherwise idle GPU; the kernel issues 20 v_mfma_f32_32x32x16_f16 per 32-key sub-step for 8
             # algorithmic products' worth (3 per product in K.Q^T, 2 in P.V): executed = 2.5x

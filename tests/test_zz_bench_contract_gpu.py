@@ -93,3 +93,15 @@ def test_bench_direct_rccl_with_one_rank():
                    [sys.executable, "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "4", "--no-cpu-baseline", "--no-extras"])
     assert d["n_gpus"] == 1 and d["value"] > 0
     assert d["config"]["rccl_ranks"] == 1 and d["config"]["collation_backend"] == "rccl (direct)"
+
+
+def test_bench_falls_back_to_the_host_exchange_when_rccl_cannot_be_loaded():
+    """No scaling line lost to the collation transport: with librccl.so not loadable every rank agrees (over the gloo rendezvous)
+    to exchange the rows through the host, and the line says which transport ran and why."""
+    import sys
+    d = _run_bench({"SSLAM_BENCH_FORCE_DIST": "1", "SSLAM_RCCL_LIB": "/nonexistent/librccl.so", "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": "29633"},
+                   [sys.executable, "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "4", "--no-cpu-baseline", "--no-extras"])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert d["config"]["rccl_ranks"] is None
+    assert d["config"]["collation_backend"].startswith("gloo (host round trip; RCCL not available: rank 0:"), d["config"]["collation_backend"]
