@@ -4,6 +4,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp SSLAM_ALLOW_RANDOM_WEIGHTS=1
 R=${1:-300}; shift
 U=scripts/ubench
+[ -f $U/libaggvictim_pk.so ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -shared -DAL_AGG_FAST_SELU=2 -DAL_AGG_PACKED=1 -o $U/libaggvictim_pk.so $U/agg_victim.hip 2>/dev/null
 NAMES="$@"; [ -n "$NAMES" ] || NAMES=$(ls $U/isa/*.co | xargs -n1 basename | sed 's/\.co$//')
 for n in $NAMES; do
   timeout -k 10 200 python scripts/agg_victim_run.py $U/libaggvictim_pk.so:$U/isa/$n.co ${BESIDE:-lightglue:big,noasm} $R 40 1 2 1 2>&1 | grep "rnorm words differing\|Error\|assert\|stream 0" | awk -v show=${SHOW:-0} '/stream 0/{ if (++k <= show) print; next } {k=0; print}' | sed "s/300 rounds x 40 launches x 1 streams x 2 frames = //"

@@ -4,6 +4,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp SSLAM_ALLOW_RANDOM_WEIGHTS=1
 R=${1:-300}
 U=scripts/ubench
+[ -f $U/libaggvictim_pk.so ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -shared -DAL_AGG_FAST_SELU=2 -DAL_AGG_PACKED=1 -o $U/libaggvictim_pk.so $U/agg_victim.hip 2>/dev/null
 for spec in "none 1" "none 2" "copy 1" "lightglue 1" "lightglue:f32 1" "lightglue:layers1 1" "lightglue:ring 1" "lightglue:big 1" "lightglue:noasm 1" "lightglue:big,noasm 1" "lightglue:ring,noasm 1" \
             "lightglue:ring,noasm,layers1 1" "aliked:1 1" "aliked:2 1" \
             "synthetic:trans 1" "synthetic:mfma 1" "synthetic:pk 1" "synthetic:valu 1" "synthetic:lds 1" "synthetic:gather 1" "synthetic:store 1" "synthetic:scalar 1" "synthetic:ldsdma 1" \
