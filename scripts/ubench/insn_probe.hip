@@ -1,11 +1,11 @@
 // insn_probe.hip - any ONE instruction as a victim: is its result the same beside another queue's MFMA kernels as alone?
 //
-// pk_probe.hip checks packed fp32 against expected values; this file asks the same of every OTHER modifier-bearing instruction form
-// the product's ISA contains (mixed-precision FMAs with op_sel, SDWA, DPP, v_pk_mov_b32 ...: `llvm-objdump -d` of the library,
-// profiles/r06_aggregate_rnorm_diagnosis.md section 5) without knowing what each computes: every lane runs the instruction on a
+// pk_probe.hip checks packed fp32 against expected values; this file asks the same of EVERY VALU instruction form the product's ISA
+// contains (467 forms of 59 139 instructions: f64 arithmetic, 64-bit integer, mixed-precision FMAs with op_sel, SDWA, DPP, compares
+// ...: scripts/gen_insn_probe_forms.py, profiles/r06_aggregate_rnorm_diagnosis.md section 5) without knowing what each computes: every lane runs the instruction on a
 // deterministic operand sequence and folds the results into a hash; the hashes of a launch are compared on the device with those
 // of the first launch, taken alone.  Same C entry points as agg_victim.hip (scripts/agg_victim_run.py, scripts/insn_probe_run.sh);
-// MODE = index into FORMS below (victim_mode_text(m)).
+// MODE = index into PRODUCT_FORMS, then EXTRA_FORMS (victim_mode_text(m), victim_modes()).
 //   hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -shared -o scripts/ubench/libinsnprobe.so scripts/ubench/insn_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -13,44 +13,25 @@
 
 namespace {
 
-// operands: v[10:11] = A, v[12:13] = B, v[14:15] = C (every 16-bit half a normal f16 in [0.5, 2), the 32-bit words normal floats);
-// result: v[20:21] (zeroed in front of the instruction)
-#define FORMS(X)                                                                                          \
-    X(0, "v_fma_mixlo_f16 v20, v10, v12, v14 op_sel_hi:[1,0,0]")                                          \
-    X(1, "v_fma_mixhi_f16 v20, v10, v12, v14 op_sel:[1,0,0] op_sel_hi:[1,0,0]")                            \
-    X(2, "v_fma_mix_f32 v20, v10, 1.0, v14 op_sel_hi:[1,0,0]")                                            \
-    X(3, "v_fma_mix_f32 v20, v10, 1.0, v14 op_sel:[1,0,0] op_sel_hi:[1,0,0]")                              \
-    X(4, "v_fma_mix_f32 v20, v10, v12, -v14 op_sel_hi:[0,0,1]")                                           \
-    X(5, "v_cvt_f32_f16_sdwa v20, v10 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1")               \
-    X(6, "v_add_u32_sdwa v20, v10, v12 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0") \
-    X(7, "v_add_u32_sdwa v20, v10, v12 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1") \
-    X(8, "v_mul_u32_u24_sdwa v20, v10, v12 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD") \
-    X(9, "v_mul_u32_u24_sdwa v20, v10, v12 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD") \
-    X(10, "v_lshlrev_b32_sdwa v20, v10, v12 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0") \
-    X(11, "v_or_b32_sdwa v20, v10, v12 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1") \
-    X(12, "v_pk_mov_b32 v[20:21], v[10:11], v[12:13] op_sel:[1,0]")                                        \
-    X(13, "v_mov_b32_dpp v20, v10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")                    \
-    X(14, "v_mov_b32_dpp v20, v10 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")                    \
-    X(15, "v_mov_b32_dpp v20, v10 row_shr:8 row_mask:0xf bank_mask:0xf")                                  \
-    X(16, "v_mov_b32_dpp v20, v10 row_bcast:15 row_mask:0xf bank_mask:0xf")                               \
-    X(17, "v_add_f32_dpp v20, v10, v12 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")                \
-    X(18, "v_cvt_pk_f16_f32 v20, v10, v12")                                                               \
-    X(19, "v_pk_fma_f32 v[20:21], v[10:11], v[12:13], v[14:15] op_sel_hi:[0,1,1]")                         \
-    X(20, "v_pk_mul_f32 v[20:21], v[10:11], v[12:13] op_sel_hi:[0,1]")                                     \
-    X(21, "v_pk_mul_f32 v[20:21], v[10:11], v[12:13] op_sel:[0,1] op_sel_hi:[1,0]")                        \
-    X(22, "v_pk_mul_f16 v20, v10, v12 op_sel:[0,1] op_sel_hi:[1,0]")                                      \
-    X(23, "v_pk_fma_f16 v20, v10, v12, v14 op_sel:[0,1,0] op_sel_hi:[1,0,1]")                              \
-    X(24, "v_pk_add_f16 v20, v10, v12 op_sel:[0,1] op_sel_hi:[1,0]")                                      \
-    X(25, "v_dot2c_f32_f16 v20, v10, v12")                                                                \
-    X(26, "v_pk_mul_lo_u16 v20, v10, v12 op_sel:[0,1] op_sel_hi:[1,0]")                                   \
-    X(27, "v_perm_b32 v20, v10, v12, v14")                                                                \
-    X(28, "v_permlane32_swap_b32_e32 v20, v21")
-constexpr int N_MODES = 29;
+// operands: v[10:13] = A, v[14:17] = B, v[18:21] = C (every 16-bit half a normal f16 in [0.5, 2), the 32-bit words normal floats,
+// the 64-bit pairs normal doubles), vcc = a fixed lane pattern; result: v[30:33] (zeroed in front of the instruction; v30 / v31 are hashed).
+// PRODUCT_FORMS: generated from the built library (scripts/gen_insn_probe_forms.py); EXTRA_FORMS: forms the product does NOT contain -
+// the positive control and the 16-bit packed forms with the swizzle that fails on register pairs.
+#include "insn_probe_forms.inc"
+#define EXTRA_FORMS(X)                                                                                    \
+    X(0, "v_pk_mul_f32 v[30:31], v[10:11], v[14:15] op_sel:[0,1] op_sel_hi:[1,0]")                         \
+    X(1, "v_pk_mul_f16 v30, v10, v14 op_sel:[0,1] op_sel_hi:[1,0]")                                       \
+    X(2, "v_pk_fma_f16 v30, v10, v14, v18 op_sel:[0,1,0] op_sel_hi:[1,0,1]")                               \
+    X(3, "v_pk_add_f16 v30, v10, v14 op_sel:[0,1] op_sel_hi:[1,0]")                                       \
+    X(4, "v_pk_mul_lo_u16 v30, v10, v14 op_sel:[0,1] op_sel_hi:[1,0]")                                    \
+    X(5, "v_dot2c_f32_f16 v30, v10, v14")
+constexpr int N_EXTRA_FORMS = 6;
+constexpr int N_MODES = N_PRODUCT_FORMS + N_EXTRA_FORMS;
 
 struct Probe { unsigned *hash, *ref, *bad; int mode; bool have_ref; };
 constexpr int BLOCKS = 2048, THREADS = 256, N = BLOCKS * THREADS;
 
-template <int MODE>
+template <int MODE, bool EXTRA>
 __global__ __launch_bounds__(256) void insn_probe_kernel(unsigned* __restrict__ out, int iters) {
     const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned r = tid * 2654435761u + 12345u, h = 0;
@@ -62,14 +43,17 @@ __global__ __launch_bounds__(256) void insn_probe_kernel(unsigned* __restrict__ 
             w[k] = 0x38003800u | ((r >> 8) & 0x07ff07ffu);
         }
         unsigned d0, d1;
+#define PROLOGUE "v_mov_b32 v10, %2\n\tv_mov_b32 v11, %3\n\tv_mov_b32 v12, %4\n\tv_mov_b32 v13, %5\n\t"                                  \
+                 "v_mov_b32 v14, %4\n\tv_mov_b32 v15, %5\n\tv_mov_b32 v16, %6\n\tv_mov_b32 v17, %7\n\t"                                  \
+                 "v_mov_b32 v18, %6\n\tv_mov_b32 v19, %7\n\tv_mov_b32 v20, %2\n\tv_mov_b32 v21, %3\n\t"                                  \
+                 "v_mov_b32 v30, 0\n\tv_mov_b32 v31, 0\n\tv_mov_b32 v32, 0\n\tv_mov_b32 v33, 0\n\t"                                      \
+                 "s_mov_b32 vcc_lo, 0x5a5a5a5a\n\ts_mov_b32 vcc_hi, 0xa5a5a5a5\n\ts_nop 4\n\t"
 #define X(M, TEXT)                                                                                                              \
         if (MODE == M)                                                                                                          \
-            asm volatile("v_mov_b32 v10, %2\n\tv_mov_b32 v11, %3\n\tv_mov_b32 v12, %4\n\tv_mov_b32 v13, %5\n\tv_mov_b32 v14, %6\n\t"   \
-                         "v_mov_b32 v15, %7\n\tv_mov_b32 v20, 0\n\tv_mov_b32 v21, 0\n\ts_nop 1\n\t" TEXT "\n\ts_nop 1\n\t"           \
-                         "v_mov_b32 %0, v20\n\tv_mov_b32 %1, v21"                                                                \
+            asm volatile(PROLOGUE TEXT "\n\ts_nop 1\n\tv_mov_b32 %0, v30\n\tv_mov_b32 %1, v31"                                    \
                          : "=v"(d0), "=v"(d1) : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5])                   \
-                         : "v10", "v11", "v12", "v13", "v14", "v15", "v20", "v21");
-        FORMS(X)
+                         : "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v30", "v31", "v32", "v33", "vcc");
+        if (EXTRA) { EXTRA_FORMS(X) } else { PRODUCT_FORMS(X) }
 #undef X
         h = (h * 31u + d0) ^ (d1 * 2246822519u);
     }
@@ -104,9 +88,13 @@ int victim_run(void* h, void* stream, int iters, int) {
     static unsigned launch = 0;
     for (int i = 0; i < iters; ++i) {
         ++launch;
-        switch (p->mode) {
-#define X(M, TEXT) case M: hipLaunchKernelGGL(insn_probe_kernel<M>, dim3(BLOCKS), dim3(THREADS), 0, s, p->hash, 256); break;
-            FORMS(X)
+        if (p->mode < N_PRODUCT_FORMS) switch (p->mode) {
+#define X(M, TEXT) case M: hipLaunchKernelGGL((insn_probe_kernel<M, false>), dim3(BLOCKS), dim3(THREADS), 0, s, p->hash, 256); break;
+            PRODUCT_FORMS(X)
+#undef X
+        } else switch (p->mode - N_PRODUCT_FORMS) {
+#define X(M, TEXT) case M: hipLaunchKernelGGL((insn_probe_kernel<M, true>), dim3(BLOCKS), dim3(THREADS), 0, s, p->hash, 256); break;
+            EXTRA_FORMS(X)
 #undef X
         }
         if (!p->have_ref) { (void)hipMemcpyAsync(p->ref, p->hash, N * 4, hipMemcpyDeviceToDevice, s); p->have_ref = true; }
@@ -122,13 +110,19 @@ int victim_poll(void* h, void* stream, unsigned* out64) {
 }
 
 const char* victim_mode_text(int m) {
-    switch (m) {
+    if (m >= 0 && m < N_PRODUCT_FORMS) switch (m) {
 #define X(M, TEXT) case M: return TEXT;
-        FORMS(X)
+        PRODUCT_FORMS(X)
+#undef X
+    } else switch (m - N_PRODUCT_FORMS) {
+#define X(M, TEXT) case M: return TEXT;
+        EXTRA_FORMS(X)
 #undef X
     }
     return nullptr;
 }
+
+int victim_modes(int* product) { if (product) *product = N_PRODUCT_FORMS; return N_MODES; }
 
 void victim_destroy(void* h) {
     Probe* p = (Probe*)h;
