@@ -170,12 +170,16 @@ def build_native(force: bool = False, verbose: bool = False) -> Path:
         # r06: no product library with a packed-fp32 instruction of the one form that silently computes a wrong value beside
         # another queue's MFMA kernels (isa_guard.py; the compiler forms it whenever its cost model likes).  Experiment builds
         # (the scripts that REPRODUCE the fault) are exempt.
-        if os.environ.get("SSLAM_EXPERIMENT_BUILD") != "1":
+        if os.environ.get("SSLAM_EXPERIMENT_BUILD") != "1" and os.environ.get("SSLAM_SKIP_ISA_GUARD") != "1":
             try:
                 _isa_guard().check([LIB_PATH, *sorted(obj_dir.glob("*.hsaco"))])
             except RuntimeError:
                 LIB_PATH.unlink(missing_ok=True)
                 raise
+            except (OSError, subprocess.CalledProcessError) as e:      # the disassembler itself is missing or failed: fail closed, say how to opt out
+                LIB_PATH.unlink(missing_ok=True)
+                raise RuntimeError(f"isa_guard could not disassemble the library ({e!r}): it needs llvm-objdump of the ROCm install under "
+                                   "/opt/rocm/lib/llvm/bin; SSLAM_SKIP_ISA_GUARD=1 builds without the check (not for a product build)") from e
         lib_keyf.write_text(lib_key + "\n")
     return LIB_PATH
 
